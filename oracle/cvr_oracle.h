@@ -1,0 +1,104 @@
+/* oracle/cvr_oracle.h -- TEST INFRASTRUCTURE.  NOT part of the product.
+ *
+ * Plain-C CPU restatement of the reference's hot path (puckbee/CVR, /root/reference/spmv.cpp):
+ *   orc_read_matrix   <- readMatrix            spmv.cpp:311-535   (Matrix-Market -> padded 1-based CSR)
+ *   orc_csr_spmv      <- the CSR self-check    spmv.cpp:1843-1850 (THE parity oracle)
+ *   orc_cvr8_convert  <- pre_processing        spmv.cpp:565-1014  (CSR -> 8-lane CVR, reference layout)
+ *   orc_cvr8_spmv     <- spmv_compute_kernel   spmv.cpp:1016-1667 (y = A x over the 8-lane layout,
+ *                                                                  bugs K1/K2 of SURVEY App. B fixed)
+ * plus (cvr64_mirror.c) a CPU mirror of THIS repo's 64-lane device format, used only to check the
+ * HIP converter bit-for-bit and to interpret a CVR64 image without a GPU.
+ *
+ * Pinned by tests/golden/NAME.npz, which hold the outputs of the unmodified reference run in the
+ * build container (oracle/gen_fixtures.py).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library.
+ */
+#ifndef CVR_ORACLE_H
+#define CVR_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- reference-compatible CSR (1-based; numRows+2 row pointers; nnz padded to a multiple of 16) ---- */
+typedef struct {
+    int     nItems;     /* padded nnz                      (spmv.cpp:390, 457, 490)            */
+    int     nItemsRaw;  /* entries read incl. mirrors      (spmv.cpp:455)                      */
+    int     numRows;    /* header value                    (spmv.cpp:386)                      */
+    int     numCols;
+    double *val;        /* [nItems]  fp32-rounded          (spmv.cpp:65, 432-433, 512)         */
+    int    *cols;       /* [nItems]  1-based               (spmv.cpp:437-438 commented out)    */
+    int    *rowptr;     /* [numRows+2]; tail = nItems-1    (spmv.cpp:499-526)                  */
+} orc_csr;
+
+int  orc_read_matrix(const char *path, orc_csr *out);  /* 0 ok, <0 error (reference: exit(1)) */
+void orc_free_csr(orc_csr *m);
+
+/* y[i] = sum_j val[j]*x[cols[j]], j ascending, rows 0..numRows-1 (spmv.cpp:1843-1850).
+ * x must hold numCols+1 entries (1-based columns). */
+void orc_csr_spmv(int numRows, const int *rowptr, const int *cols, const double *val,
+                  const double *x, double *y);
+/* same loop over any 0-based CSR with 64-bit row pointers; also returns sum_j |a_ij x_j| per row
+ * (the scale of the stated tolerance) when absy != NULL */
+void orc_csr_spmv64(int64_t nrows, const int64_t *rowptr, const int32_t *cols, const double *val,
+                    const double *x, double *y, double *absy);
+void orc_csr_spmv64_f32(int64_t nrows, const int64_t *rowptr, const int32_t *cols, const float *val,
+                        const float *x, double *y, double *absy);
+
+/* seeded non-constant x: splitmix64(0xC0FFEE, j) -> uniform [-1,1)   */
+double orc_x_rand(uint64_t j);
+
+/* ---- 8-lane CVR in the reference's own layout ---- */
+typedef struct {
+    int     T;          /* chunks = reference threads                                           */
+    int     nItems, numRows;
+    double *vals;       /* [nItems]  step-major [step][lane] per chunk       (A.3)              */
+    int    *cols;       /* [nItems]                                                              */
+    int    *record;     /* [2*(numRows+240+32T)] (pos,wb) pairs              (A.5, A.7, A.8)    */
+    int64_t record_len;
+    int    *split;      /* [2T]  {ncsr_start, ncsr}                          (A.5)              */
+    int    *final2;     /* [16T] tail rows                                   (A.5, A.7)         */
+    int    *nnz_rows;   /* [4T]  {s_t, e_t, first_row, last_row}             (A.2)              */
+} orc_cvr8;
+
+#define ORC_RECORD_SENTINEL (-0x7f7f7f7f)
+int  orc_cvr8_convert(const orc_csr *m, int T, orc_cvr8 *out);   /* <0 if nItems < 16*T */
+void orc_cvr8_free(orc_cvr8 *c);
+/* y (numRows+2 entries, zeroed inside) = A x; nthreads OpenMP threads over the T chunks */
+void orc_cvr8_spmv(const orc_cvr8 *c, const double *x, double *y, int nthreads);
+
+/* ---- CPU mirror of the repo's 64-lane device format (cvr64_mirror.c) ---- */
+typedef struct {
+    int64_t nrows, ncols, nnz;
+    int     S;               /* steps per chunk (multiple of 4)                                  */
+    int     is_f32;
+    int64_t nchunks;
+    int64_t nseg;            /* total dest entries                                               */
+    int64_t nshared;         /* rows split over several chunks                                   */
+    /* plan */
+    int64_t *nz_begin;       /* [nchunks+1]                                                      */
+    int64_t *row_first;      /* [nchunks]                                                        */
+    int64_t *row_last;       /* [nchunks]                                                        */
+    /* image */
+    uint32_t *cols;          /* [nchunks*S*64] as uint4 [chunk][g][lane][4], bit31 = segment end */
+    void     *vals;          /* f64: [chunk][g][2][lane][2]; f32: [chunk][g][lane][4]            */
+    uint32_t *desc;          /* [nchunks][2] = {rbase, n_c}                                      */
+    uint32_t *dest;          /* [nseg] index into y_ext                                          */
+    uint8_t  *target;        /* [nchunks][64]                                                    */
+    /* fix-up list */
+    int64_t *shared_row;     /* [nshared]                                                        */
+    int64_t *shared_c0;      /* [nshared] first chunk                                            */
+    int64_t *shared_c1;      /* [nshared] last chunk                                             */
+} orc_cvr64;
+
+int  orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
+                     const void *vals, int is_f32, int S, int64_t split_threshold, orc_cvr64 *out);
+void orc_cvr64_free(orc_cvr64 *c);
+/* interpret the image exactly as the HIP kernel does (same per-lane order of operations) */
+void orc_cvr64_spmv(const orc_cvr64 *c, const void *x, void *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

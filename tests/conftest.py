@@ -1,0 +1,24 @@
+"""pytest configuration: registers the `gpu` marker and builds the checker library on demand."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    lib = os.path.join(ROOT, "oracle", "liboracle.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("cvr_oracle.c", "cvr64_mirror.c", "cvr_oracle.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], check=True,
+                       stdout=subprocess.DEVNULL)
+    yield

@@ -1,0 +1,204 @@
+"""ctypes view of oracle/liboracle.so -- the CHECKER (test infrastructure, never the product path)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+class OrcCsr(C.Structure):
+    _fields_ = [("nItems", C.c_int), ("nItemsRaw", C.c_int), ("numRows", C.c_int), ("numCols", C.c_int),
+                ("val", C.POINTER(C.c_double)), ("cols", C.POINTER(C.c_int)), ("rowptr", C.POINTER(C.c_int))]
+
+
+class OrcCvr8(C.Structure):
+    _fields_ = [("T", C.c_int), ("nItems", C.c_int), ("numRows", C.c_int),
+                ("vals", C.POINTER(C.c_double)), ("cols", C.POINTER(C.c_int)),
+                ("record", C.POINTER(C.c_int)), ("record_len", C.c_int64),
+                ("split", C.POINTER(C.c_int)), ("final2", C.POINTER(C.c_int)),
+                ("nnz_rows", C.POINTER(C.c_int))]
+
+
+class OrcCvr64(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("S", C.c_int),
+                ("is_f32", C.c_int), ("nchunks", C.c_int64), ("nseg", C.c_int64), ("nshared", C.c_int64),
+                ("nz_begin", C.POINTER(C.c_int64)), ("row_first", C.POINTER(C.c_int64)),
+                ("row_last", C.POINTER(C.c_int64)), ("cols", C.POINTER(C.c_uint32)), ("vals", C.c_void_p),
+                ("desc", C.POINTER(C.c_uint32)), ("dest", C.POINTER(C.c_uint32)),
+                ("target", C.POINTER(C.c_uint8)), ("shared_row", C.POINTER(C.c_int64)),
+                ("shared_c0", C.POINTER(C.c_int64)), ("shared_c1", C.POINTER(C.c_int64))]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        _lib.orc_read_matrix.argtypes = [C.c_char_p, C.POINTER(OrcCsr)]
+        _lib.orc_csr_spmv.argtypes = [C.c_int] + [C.c_void_p] * 5
+        _lib.orc_csr_spmv64.argtypes = [C.c_int64] + [C.c_void_p] * 6
+        _lib.orc_csr_spmv64_f32.argtypes = [C.c_int64] + [C.c_void_p] * 6
+        _lib.orc_x_rand.argtypes = [C.c_uint64]
+        _lib.orc_x_rand.restype = C.c_double
+        _lib.orc_cvr8_convert.argtypes = [C.POINTER(OrcCsr), C.c_int, C.POINTER(OrcCvr8)]
+        _lib.orc_cvr8_spmv.argtypes = [C.POINTER(OrcCvr8), C.c_void_p, C.c_void_p, C.c_int]
+        _lib.orc_cvr64_build.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int64, C.POINTER(OrcCvr64)]
+        _lib.orc_cvr64_spmv.argtypes = [C.POINTER(OrcCvr64), C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def _np(ptr, n, dt):
+    if n == 0:
+        return np.zeros(0, dtype=dt)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt, copy=True)
+
+
+def read_matrix(path):
+    """orc_read_matrix -> dict(nItems, nItemsRaw, numRows, numCols, val, cols, rowptr)"""
+    m = OrcCsr()
+    rc = lib().orc_read_matrix(path.encode(), C.byref(m))
+    if rc:
+        raise RuntimeError(f"orc_read_matrix({path}) = {rc}")
+    out = dict(nItems=m.nItems, nItemsRaw=m.nItemsRaw, numRows=m.numRows, numCols=m.numCols,
+               val=_np(m.val, m.nItems, np.float64), cols=_np(m.cols, m.nItems, np.int32),
+               rowptr=_np(m.rowptr, m.numRows + 2, np.int32))
+    lib().orc_free_csr(C.byref(m))
+    return out
+
+
+def x_vec(n, mode):
+    if mode == "ones":
+        return np.ones(n, dtype=np.float64)
+    return np.array([lib().orc_x_rand(j) for j in range(n)], dtype=np.float64)
+
+
+def x_vec_fast(n, mode="rand"):
+    """vectorised splitmix64 identical to orc_x_rand"""
+    if mode == "ones":
+        return np.ones(n, dtype=np.float64)
+    j = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(0xC0FFEE) + (j + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0) * 2.0 - 1.0
+
+
+def csr_spmv_ref(m, x):
+    """the reference's CSR loop on reference-layout arrays (rows 0..numRows-1)"""
+    y = np.zeros(m["numRows"], dtype=np.float64)
+    rp = np.ascontiguousarray(m["rowptr"], dtype=np.int32)
+    cl = np.ascontiguousarray(m["cols"], dtype=np.int32)
+    vl = np.ascontiguousarray(m["val"], dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    lib().orc_csr_spmv(m["numRows"], rp.ctypes.data, cl.ctypes.data, vl.ctypes.data, x.ctypes.data, y.ctypes.data)
+    return y
+
+
+def csr_spmv64(rowptr, cols, vals, x):
+    """CSR oracle on 0-based int64/int32 arrays; returns (y, sum|a x|) in float64"""
+    n = len(rowptr) - 1
+    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+    cl = np.ascontiguousarray(cols, dtype=np.int32)
+    y = np.zeros(n, dtype=np.float64)
+    a = np.zeros(n, dtype=np.float64)
+    if vals.dtype == np.float32:
+        vl = np.ascontiguousarray(vals)
+        xx = np.ascontiguousarray(x, dtype=np.float32)
+        lib().orc_csr_spmv64_f32(n, rp.ctypes.data, cl.ctypes.data, vl.ctypes.data, xx.ctypes.data, y.ctypes.data, a.ctypes.data)
+    else:
+        vl = np.ascontiguousarray(vals, dtype=np.float64)
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        lib().orc_csr_spmv64(n, rp.ctypes.data, cl.ctypes.data, vl.ctypes.data, xx.ctypes.data, y.ctypes.data, a.ctypes.data)
+    return y, a
+
+
+class Cvr8:
+    def __init__(self, m, T):
+        self._m = OrcCsr()
+        self._keep = [np.ascontiguousarray(m["val"], dtype=np.float64), np.ascontiguousarray(m["cols"], dtype=np.int32),
+                      np.ascontiguousarray(m["rowptr"], dtype=np.int32)]
+        self._m.nItems, self._m.nItemsRaw = m["nItems"], m.get("nItemsRaw", m["nItems"])
+        self._m.numRows, self._m.numCols = m["numRows"], m["numCols"]
+        self._m.val = self._keep[0].ctypes.data_as(C.POINTER(C.c_double))
+        self._m.cols = self._keep[1].ctypes.data_as(C.POINTER(C.c_int))
+        self._m.rowptr = self._keep[2].ctypes.data_as(C.POINTER(C.c_int))
+        self.c = OrcCvr8()
+        self.rc = lib().orc_cvr8_convert(C.byref(self._m), T, C.byref(self.c))
+        self.T = T
+        self.numRows = m["numRows"]
+        if self.rc == 0:
+            c = self.c
+            self.vals = _np(c.vals, c.nItems, np.float64)
+            self.cols = _np(c.cols, c.nItems, np.int32)
+            self.record = _np(c.record, c.record_len, np.int32)
+            self.split = _np(c.split, 2 * T, np.int32)
+            self.final2 = _np(c.final2, 16 * T, np.int32)
+            self.nnz_rows = _np(c.nnz_rows, 4 * T, np.int32)
+
+    def spmv(self, x, nthreads=1):
+        y = np.zeros(self.numRows + 2, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lib().orc_cvr8_spmv(C.byref(self.c), x.ctypes.data, y.ctypes.data, nthreads)
+        return y
+
+    def __del__(self):
+        try:
+            if self.rc == 0:
+                lib().orc_cvr8_free(C.byref(self.c))
+        except Exception:
+            pass
+
+
+class Cvr64:
+    """CPU mirror of the device format (arrays copied to numpy)"""
+
+    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0):
+        self.rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+        self.cl = np.ascontiguousarray(cols, dtype=np.int32)
+        self.f32 = vals.dtype == np.float32
+        self.vl = np.ascontiguousarray(vals, dtype=np.float32 if self.f32 else np.float64)
+        self.c = OrcCvr64()
+        self.rc = lib().orc_cvr64_build(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data,
+                                        int(self.f32), S, thr, C.byref(self.c))
+        if self.rc:
+            raise RuntimeError(f"orc_cvr64_build = {self.rc}")
+        c = self.c
+        self.nrows, self.S, self.nchunks, self.nseg, self.nshared = c.nrows, c.S, c.nchunks, c.nseg, c.nshared
+        n = c.nchunks * 64 * c.S
+        self.nz_begin = _np(c.nz_begin, c.nchunks + 1, np.int64)
+        self.row_first = _np(c.row_first, c.nchunks, np.int64)
+        self.row_last = _np(c.row_last, c.nchunks, np.int64)
+        self.cols = _np(c.cols, n, np.uint32)
+        vp = C.cast(c.vals, C.POINTER(C.c_float if self.f32 else C.c_double))
+        self.vals = _np(vp, n, np.float32 if self.f32 else np.float64)
+        self.desc = _np(c.desc, 2 * c.nchunks, np.uint32)
+        self.dest = _np(c.dest, c.nseg, np.uint32)
+        self.target = _np(c.target, 64 * c.nchunks, np.uint8)
+        self.shared_row = _np(c.shared_row, c.nshared, np.int64)
+        self.shared_c0 = _np(c.shared_c0, c.nshared, np.int64)
+        self.shared_c1 = _np(c.shared_c1, c.nshared, np.int64)
+
+    def spmv(self, x):
+        dt = np.float32 if self.f32 else np.float64
+        x = np.ascontiguousarray(x, dtype=dt)
+        y = np.zeros(self.nrows, dtype=dt)
+        lib().orc_cvr64_spmv(C.byref(self.c), x.ctypes.data, y.ctypes.data)
+        return y
+
+    def __del__(self):
+        try:
+            lib().orc_cvr64_free(C.byref(self.c))
+        except Exception:
+            pass
+
+
+def tol_check(y, yref, absy, tol=1e-12):
+    """|y - y_ref| <= tol * sum_j |a_ij x_j| + tiny, per row"""
+    err = np.abs(np.asarray(y, dtype=np.float64) - yref)
+    bound = tol * absy + 1e-300
+    bad = np.nonzero(err > bound)[0]
+    return bad, (err / np.maximum(absy, 1e-300)).max() if len(err) else 0.0
