@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement: CVR-format SpMV on MI355X (BASELINE.json).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+              --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one y = A x over the web-Google-shaped matrix (916 428 x 916 428, 5 105 039 nnz, fp64; seeded
+synthetic stand-in, or the real web-Google.mtx when CVR_DATA_DIR holds it), matrix image, x and y resident
+in HBM.  N > 1: rows are sharded over the ranks (balanced nnz, cut at row boundaries), x is replicated, every
+step ends with the all-gather of the y slices over RCCL ("strong" scaling: the matrix is fixed).
+Rank 0 prints ONE JSON line.  The roofline object prices the SpMV kernel alone (algorithmic bytes of SURVEY.md
+8(d) / mean kernel time from HIP events on the launch stream); cpu_baseline is the oracle's 8-lane OpenMP
+restatement of the reference's CVR path on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def load_workload():
+    from cvr_amd import capi, synth
+    import cvr_amd
+    f = synth.data_file("web-Google.mtx")
+    if f:
+        m = cvr_amd.load_mm(f, capi.MM_STRICT)
+        vals = (np.arange(m["nnz"], dtype=np.int64) % 13).astype(np.float64)   # pattern file: spmv.cpp:417
+        return m["nrows"], m["ncols"], m["row_ptr"], m["col_idx"], vals, "web-Google.mtx (SNAP)"
+    n, nc, rp, ci, va = synth.web_google_like()
+    return n, nc, rp, ci, va, "synthetic web-Google-shaped, seed 20261002"
+
+
+def cpu_baseline(nrows, ncols, rp, ci, va, budget_s=12.0):
+    """the oracle's restatement of the reference CPU path (8 AVX-512-style lanes, one chunk per OpenMP thread;
+    spmv.cpp:565-1014, 1016-1667) on the reference loader's 1-based arrays; bounded number of iterations"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as O
+    from cvr_amd import synth
+    cores = len(os.sched_getaffinity(0))
+    T = cores
+    m = synth.to_refcompat(nrows, ncols, rp, ci, va)
+    t0 = time.perf_counter()
+    c = O.Cvr8(m, T)
+    if c.rc != 0:
+        return None
+    pre = time.perf_counter() - t0
+    x = np.ones(ncols + 2)
+    c.spmv(x, nthreads=T)
+    iters, t_used = 0, 0.0
+    t_start = time.perf_counter()
+    while iters < 2000 and t_used < budget_s:
+        c.spmv(x, nthreads=T)
+        iters += 1
+        t_used = time.perf_counter() - t_start
+    per = t_used / iters
+    return {"value": 2.0 * len(ci) / per / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} SpMV iterations of the full matrix, {T} OpenMP threads, y zeroing inside the timer",
+            "ms_per_step": per * 1e3, "preprocess_s": pre,
+            "gbs_alg": synth.b_alg(nrows, ncols, len(ci)) / per / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps-per-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import cvr_amd
+    from cvr_amd import shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    nrows, ncols, rp, ci, va, source = load_workload()
+    nnz = len(ci)
+    bounds = shard.row_partition(rp, world)
+    lrows, lrp, lci, lva = shard.local_csr(rp, ci, va, bounds, rank)
+    A = cvr_amd.CvrMatrix(lrows, ncols, lrp, lci, lva, device=local_rank, steps_per_chunk=args.steps_per_chunk)
+    info = A.info
+    max_rows, pick = shard.gather_layout(bounds)
+
+    dev = torch.device("cuda", local_rank)
+    x = torch.zeros(info.x_elems, dtype=torch.float64, device=dev)
+    x[:ncols] = torch.from_numpy(synth.x_rand(ncols)).to(dev)
+    y = torch.zeros(max(info.yext_elems, max_rows), dtype=torch.float64, device=dev)
+    yall = torch.zeros(world * max_rows, dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+
+    def step(n=1):
+        if world == 1:
+            A.spmv_device(x.data_ptr(), y.data_ptr(), sptr, repeat=n)
+        else:
+            for _ in range(n):
+                A.spmv_device(x.data_ptr(), y.data_ptr(), sptr)
+                dist.all_gather_into_tensor(yall, y[:max_rows])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step(args.warmup)
+    sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    step(args.steps)
+    e1.record(stream)
+    sync()
+    wall = time.perf_counter() - t0
+    ev_s = e0.elapsed_time(e1) * 1e-3
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    # the SpMV kernel alone, HIP events on the launch stream (N > 1: this rank's shard, no gather)
+    e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    A.spmv_device(x.data_ptr(), y.data_ptr(), sptr, repeat=args.warmup)
+    e2.record(stream)
+    A.spmv_device(x.data_ptr(), y.data_ptr(), sptr, repeat=args.steps)
+    e3.record(stream)
+    torch.cuda.synchronize()
+    kern_s = e2.elapsed_time(e3) * 1e-3 / args.steps
+    lnnz = int(lrp[-1])
+    balg_local = synth.b_alg(lrows, ncols, lnnz)
+    achieved = balg_local / kern_s / 1e9
+
+    # parity guard on the timed configuration: y of the last step against the host CSR loop of the product
+    # (the reference's own self-check, spmv.cpp:1843-1850, 1916-1938)
+    yh = (yall[torch.from_numpy(pick).to(dev)] if world > 1 else y[:nrows]).cpu().numpy()
+    wrong = -1
+    if rank == 0:
+        yref = cvr_amd.csr_spmv_host(rp, ci, va, x[:ncols].cpu().numpy(), nthreads=len(os.sched_getaffinity(0)))
+        wrong = int(cvr_amd.verdict(yh, yref, nrows))
+
+    if rank == 0:
+        per = wall / args.steps
+        out = {
+            "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64",
+            "value": 2.0 * nnz / per / 1e9,
+            "unit": "GFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": per * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic" if source.startswith("synthetic") else "real",
+            "config": {"workload": f"{source}: {nrows}x{ncols}, nnz {nnz}, fp64, y = A x with A (CVR64 image), x, y resident in HBM",
+                       "rows_per_gpu": [int(v) for v in np.diff(bounds)],
+                       "steps_per_chunk": int(info.steps_per_chunk), "chunks_rank0": int(info.nchunks),
+                       "rows_cut_rank0": int(info.nshared),
+                       "parallelism": "rows sharded, x replicated, y all-gathered (RCCL)" if world > 1 else "1 GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "cvr::spmv_kernel<double>", "kernel_us": kern_s * 1e6,
+                         "algorithmic_bytes_per_launch": int(balg_local)},
+            "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz) / per / 1e9,
+            "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
+            "preprocess": {"plan_s": info.plan_s, "upload_s": info.upload_s, "convert_s": info.convert_s},
+            "verdict_wrong_rows": wrong,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(nrows, ncols, rp, ci, va)
+            except Exception as e:   # the checker is optional on the bench box; the GPU numbers stand without it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    A.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

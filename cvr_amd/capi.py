@@ -1,0 +1,253 @@
+"""ctypes binding of include/cvr_amd.h (libcvr_amd.so).  Mirrors the reference's call sequence
+(main, spmv.cpp:1771-1938): load -> create/preprocess (pre_processing) -> spmv (spmv_compute_kernel) -> verdict."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_NOMEM, ERR_STATE, ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7
+MM_REFCOMPAT, MM_STRICT = 0, 1
+
+
+class CvrError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__(f"{where}: error {code}: {last_error()}")
+
+
+class CsrView(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p),
+                ("vals", C.c_void_p), ("is_f32", C.c_int32)]
+
+
+class Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
+                ("xcd_swizzle", C.c_int32), ("nontemporal", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("mean_s", C.c_double), ("min_s", C.c_double), ("max_s", C.c_double),
+                ("total_s", C.c_double), ("h2d_s", C.c_double), ("d2h_s", C.c_double)]
+
+
+class Info(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("is_f32", C.c_int32),
+                ("steps_per_chunk", C.c_int32), ("nchunks", C.c_int64), ("nslots", C.c_int64), ("nshared", C.c_int64),
+                ("image_bytes", C.c_int64), ("yext_elems", C.c_int64), ("x_elems", C.c_int64),
+                ("plan_s", C.c_double), ("upload_s", C.c_double), ("convert_s", C.c_double)]
+
+
+class MmMatrix(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("ref_numRows", C.c_int64),
+                ("ref_numCols", C.c_int64), ("ref_nItems", C.c_int64), ("ref_nItemsRaw", C.c_int64),
+                ("row_ptr", C.POINTER(C.c_int64)), ("col_idx", C.POINTER(C.c_int32)), ("vals", C.POINTER(C.c_double))]
+
+
+# every symbol include/cvr_amd.h declares (tests check the library exports all of them)
+SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_count", "cvr_create", "cvr_preprocess",
+           "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
+           "cvr_spmv_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free",
+           "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict"]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libcvr_amd.so")
+
+
+def lib():
+    """Loads libcvr_amd.so; raises if it is not built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ImportError(f"{p} is missing: build it with `make -C cvr_amd/csrc` (or __graft_entry__.build())")
+        L = C.CDLL(p)
+        L.cvr_last_error.restype = C.c_char_p
+        L.cvr_version.restype = C.c_char_p
+        L.cvr_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CsrView), C.POINTER(Options)]
+        L.cvr_preprocess.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.cvr_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+        L.cvr_destroy.argtypes = [C.c_void_p]
+        L.cvr_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Timing)]
+        L.cvr_spmv_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvr_spmv_device_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        for f in ("cvr_x_device", "cvr_y_device", "cvr_stream"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_void_p
+        L.cvr_spmv_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.cvr_export_image.argtypes = [C.c_void_p] * 5
+        L.cvr_plan_bound.argtypes = [C.c_int64, C.c_int64, C.c_int32]
+        L.cvr_plan_bound.restype = C.c_int64
+        L.cvr_plan_chunks.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 4
+        L.cvr_plan_chunks.restype = C.c_int64
+        L.cvr_mm_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(MmMatrix)]
+        L.cvr_mm_free.argtypes = [C.POINTER(MmMatrix)]
+        L.cvr_fill_x.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        L.cvr_csr_spmv_host.argtypes = [C.c_int64] + [C.c_void_p] * 5 + [C.c_int]
+        L.cvr_verdict.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.cvr_verdict.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().cvr_last_error().decode()
+
+
+def version():
+    return lib().cvr_version().decode()
+
+
+def device_count():
+    return lib().cvr_device_count()
+
+
+def load_mm(path, mode=MM_REFCOMPAT):
+    """cvr_mm_read -> dict(nrows, ncols, nnz, ref_*, row_ptr int64, col_idx int32, vals float64) (numpy copies)"""
+    m = MmMatrix()
+    rc = lib().cvr_mm_read(os.fsencode(path), mode, C.byref(m))
+    if rc:
+        raise CvrError(rc, f"cvr_mm_read({path})")
+    n = m.ref_nItems if mode == MM_REFCOMPAT else m.nnz
+    out = dict(nrows=m.nrows, ncols=m.ncols, nnz=m.nnz, ref_numRows=m.ref_numRows, ref_numCols=m.ref_numCols,
+               ref_nItems=m.ref_nItems, ref_nItemsRaw=m.ref_nItemsRaw,
+               row_ptr=np.ctypeslib.as_array(m.row_ptr, shape=(m.nrows + 1,)).copy(),
+               col_idx=np.ctypeslib.as_array(m.col_idx, shape=(max(n, 1),))[:n].copy(),
+               vals=np.ctypeslib.as_array(m.vals, shape=(max(n, 1),))[:n].copy())
+    lib().cvr_mm_free(C.byref(m))
+    return out
+
+
+def fill_x(n, mode=0):
+    x = np.empty(n, dtype=np.float64)
+    lib().cvr_fill_x(x.ctypes.data, n, mode)
+    return x
+
+
+def csr_spmv_host(row_ptr, col_idx, vals, x, nthreads=1):
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    ci = np.ascontiguousarray(col_idx, dtype=np.int32)
+    va = np.ascontiguousarray(vals, dtype=np.float64)
+    xx = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(len(rp) - 1, dtype=np.float64)
+    lib().cvr_csr_spmv_host(len(rp) - 1, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, xx.ctypes.data, y.ctypes.data, nthreads)
+    return y
+
+
+def verdict(y, yref, n):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    yref = np.ascontiguousarray(yref, dtype=np.float64)
+    return lib().cvr_verdict(y.ctypes.data, yref.ctypes.data, n)
+
+
+def plan_chunks(row_ptr, S, thr=0):
+    """host planner only (runs without a GPU): dict(nz_begin[n+1], row_first[n], nseg[n], pad_cnt[n])"""
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    nrows = len(rp) - 1
+    bound = lib().cvr_plan_bound(nrows, int(rp[-1] - rp[0]) if nrows else 0, S)
+    nzb = np.zeros(bound + 1, dtype=np.int64)
+    rf, ns, pc = (np.zeros(bound, dtype=np.int64) for _ in range(3))
+    n = lib().cvr_plan_chunks(nrows, rp.ctypes.data, S, thr, nzb.ctypes.data, rf.ctypes.data, ns.ctypes.data, pc.ctypes.data)
+    if n < 0:
+        raise CvrError(n, "cvr_plan_chunks")
+    return dict(nz_begin=nzb[: n + 1].copy(), row_first=rf[:n].copy(), nseg=ns[:n].copy(), pad_cnt=pc[:n].copy())
+
+
+class CvrMatrix:
+    """One matrix (or row shard) resident on one GPU: cvr_create + cvr_preprocess, then spmv()."""
+
+    def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
+                 xcd_swizzle=-1, nontemporal=-1, keep_csr=False):
+        self._h = C.c_void_p()
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        ci = np.ascontiguousarray(col_idx, dtype=np.int32)
+        self.f32 = np.asarray(vals).dtype == np.float32
+        self.dtype = np.float32 if self.f32 else np.float64
+        va = np.ascontiguousarray(vals, dtype=self.dtype)
+        if len(rp) != nrows + 1:
+            raise ValueError("row_ptr must have nrows + 1 entries")
+        view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
+        opt = Options()
+        lib().cvr_default_options(C.byref(opt))
+        opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
+        opt.xcd_swizzle, opt.nontemporal = xcd_swizzle, nontemporal
+        rc = lib().cvr_create(C.byref(self._h), C.byref(view), C.byref(opt))
+        if rc:
+            self._h = C.c_void_p()
+            raise CvrError(rc, "cvr_create")
+        sec = C.c_double()
+        rc = lib().cvr_preprocess(self._h, int(keep_csr), C.byref(sec))
+        if rc:
+            err = CvrError(rc, "cvr_preprocess")
+            self.close()
+            raise err
+        self.preprocess_s = sec.value
+        self.info = Info()
+        lib().cvr_get_info(self._h, C.byref(self.info))
+        self.nrows, self.ncols = nrows, ncols
+
+    def spmv(self, x, iters=1):
+        """y = A x through host buffers; returns (y, Timing)"""
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        if len(x) < self.ncols:
+            raise ValueError("x is shorter than ncols")
+        y = np.zeros(max(self.nrows, 1), dtype=self.dtype)
+        t = Timing()
+        rc = lib().cvr_spmv(self._h, x.ctypes.data, y.ctypes.data, iters, C.byref(t))
+        if rc:
+            raise CvrError(rc, "cvr_spmv")
+        return y[: self.nrows], t
+
+    def spmv_device(self, x_ptr, y_ptr, stream=None, repeat=1):
+        """asynchronous launch(es) on caller-owned device buffers (x_ext: ncols+1 values, last one 0; y_ext)"""
+        if repeat == 1:
+            rc = lib().cvr_spmv_device(self._h, x_ptr, y_ptr, stream)
+        else:
+            rc = lib().cvr_spmv_device_repeat(self._h, x_ptr, y_ptr, stream, repeat)
+        if rc:
+            raise CvrError(rc, "cvr_spmv_device")
+
+    def bench(self, warmup, iters):
+        s = C.c_double()
+        rc = lib().cvr_spmv_bench(self._h, warmup, iters, C.byref(s))
+        if rc:
+            raise CvrError(rc, "cvr_spmv_bench")
+        return s.value
+
+    @property
+    def x_device(self):
+        return lib().cvr_x_device(self._h)
+
+    @property
+    def y_device(self):
+        return lib().cvr_y_device(self._h)
+
+    @property
+    def stream(self):
+        return lib().cvr_stream(self._h)
+
+    def export_image(self):
+        i = self.info
+        gb = 2048 if self.f32 else 3072
+        image = np.zeros(i.nchunks * (i.steps_per_chunk // 4) * gb, dtype=np.uint8)
+        desc = np.zeros((i.nchunks, 4), dtype=np.uint32)
+        target = np.zeros((i.nchunks, 64), dtype=np.uint8)
+        shared = np.zeros((i.nshared, 3), dtype=np.int64)
+        rc = lib().cvr_export_image(self._h, image.ctypes.data, desc.ctypes.data, target.ctypes.data, shared.ctypes.data)
+        if rc:
+            raise CvrError(rc, "cvr_export_image")
+        return dict(image=image, desc=desc, target=target, shared=shared)
+
+    def close(self):
+        if self._h:
+            lib().cvr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,146 @@
+// cvr_convert.hip -- CSR -> CVR64 on the device, one wavefront per chunk (gfx950, wave64).
+//
+// This is the reference's tracker loop (pre_processing, /root/reference/spmv.cpp:711-1000) with the
+// 8 AVX-512 trackers (valID, rowID, count; spmv.cpp:711-759) widened to 64 lanes:
+//   * "is any tracker empty" (_mm512_mask_reduce_min_epi32, spmv.cpp:810) is one __ballot;
+//   * the scalar in-lane-order refill loop (spmv.cpp:814-946) becomes rank-among-empty-lanes
+//     (mbcnt of the ballot): lane with rank r takes segment fed + r -- the identical assignment;
+//   * stealing (spmv.cpp:869-943: ave = remaining steps, victim = FIRST lane with count > ave,
+//     the stealer takes the FIRST ave elements of the victim's remainder) is resolved victim by
+//     victim in a wave-uniform loop: a victim with count c serves ceil(c/ave)-1 consecutive stealers;
+//   * the 8-wide CSR gathers + 64-B stores (spmv.cpp:963-977) are per-lane loads and one 16-B store
+//     per lane per 4 steps, already in the layout the SpMV kernel streams (cvr_format.h).
+// No (pos, wb) records are written (spmv.cpp:832-834, 898-899): the end of a segment is bit 31 of
+// the column word, and the row a lane writes follows from the hand-out order.
+#include "cvr_kernels.h"
+
+namespace cvr {
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef double   f64x2 __attribute__((ext_vector_type(2)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <typename T>
+__global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
+    const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx, const T *__restrict__ vals,
+    const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt, const uint4 *__restrict__ desc,
+    uint8_t *__restrict__ stream, uint8_t *__restrict__ target, uint32_t *__restrict__ err, int G,
+    uint32_t nchunks, uint32_t pad_col)
+{
+    constexpr int GB = sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (k >= nchunks) return;
+    const int64_t  b = nzb[k], e = nzb[k + 1];
+    const uint4    d = desc[k];
+    const uint32_t row_first = d.x, nseg = d.y, pc = pad_cnt[k];
+    const uint32_t nrow_seg = nseg - (pc > 0 ? 1u : 0u);
+    const int      S = G * kGroupSteps;
+
+    int64_t  pos = -1;     // CSR element this lane emits next; -1 = pad slot
+    uint32_t cnt = 0;      // slots left in the lane's current segment
+    uint32_t fed = 0;      // segments handed out so far (wave-uniform)
+    uint32_t tgt = lane;   // lane this one stole from
+    uint32_t bad = 0;
+    uint8_t *out = stream + (size_t)k * G * GB + lane * 16;
+
+    for (int g = 0; g < G; g++) {
+        uint32_t cw[4];
+        T        vv[4];
+#pragma unroll
+        for (int j = 0; j < kGroupSteps; j++) {
+            const uint64_t em = __ballot(cnt == 0);
+            if (em) {
+                const uint32_t rank = lane_rank(em);
+                const uint32_t nempty = (uint32_t)__popcll(em);
+                const uint32_t navail = nseg - fed;
+                bool           want = cnt == 0;
+                if (want && rank < navail) {                 // feeding, spmv.cpp:821-868
+                    const uint32_t q = fed + rank;
+                    if (q < nrow_seg) {
+                        const int64_t r = (int64_t)row_first + q;
+                        int64_t       a = rp[r], z = rp[r + 1];
+                        a = a > b ? a : b;                   // a row begun in an earlier chunk (spmv.cpp:748-756)
+                        z = z < e ? z : e;                   // a row continued in the next one (spmv.cpp:851)
+                        if (z > a) { pos = a; cnt = (uint32_t)(z - a); }
+                        else { pos = -1; cnt = 1; }          // empty row: one pad slot
+                    } else { pos = -1; cnt = pc; }           // the chunk's trailing pad segment
+                    want = false;
+                }
+                fed += nempty < navail ? nempty : navail;
+                if (nempty > navail) {                       // stealing, spmv.cpp:869-943
+                    const uint32_t ave = (uint32_t)(S - (g * kGroupSteps + j));   // == sum(count)/64, App. A.6
+                    const uint32_t nsteal = nempty - navail;
+                    const uint32_t s = rank - navail;        // steal order = lane order (spmv.cpp:814)
+                    uint32_t       base = 0;
+                    while (base < nsteal) {
+                        const uint64_t of = __ballot(cnt > ave);
+                        if (!of) { bad |= 2u; break; }
+                        const int      v = __ffsll((unsigned long long)of) - 1;     // FIRST over-full lane (spmv.cpp:876-879)
+                        const uint32_t cv = __shfl(cnt, v);
+                        const int64_t  pv = __shfl(pos, v);
+                        const uint32_t m = (cv + ave - 1) / ave - 1;  // steals until v is no longer over-full
+                        const uint32_t kk = m < nsteal - base ? m : nsteal - base;
+                        if (want && s >= base && s < base + kk) {     // takes the FIRST ave (spmv.cpp:927-931)
+                            pos = pv < 0 ? -1 : pv + (int64_t)(s - base) * ave;
+                            cnt = ave;
+                            tgt = (uint32_t)v;
+                            want = false;
+                        }
+                        if (lane == (uint32_t)v) {
+                            if (pos >= 0) pos += (int64_t)kk * ave;
+                            cnt -= kk * ave;
+                        }
+                        base += kk;
+                    }
+                }
+            }
+            uint32_t c = pad_col;
+            T        v = 0;
+            if (pos >= 0) { c = (uint32_t)cidx[pos]; v = vals[pos]; pos++; }
+            cw[j] = c | (cnt == 1 ? kEndBit : 0u);
+            vv[j] = v;
+            cnt--;
+        }
+        uint8_t *o = out + (size_t)g * GB;
+        u32x4    cq = {cw[0], cw[1], cw[2], cw[3]};
+        *reinterpret_cast<u32x4 *>(o) = cq;
+        if constexpr (sizeof(T) == 8) {
+            f64x2 lo = {vv[0], vv[1]}, hi = {vv[2], vv[3]};
+            *reinterpret_cast<f64x2 *>(o + kColsBytes) = lo;
+            *reinterpret_cast<f64x2 *>(o + kColsBytes + kLanes * 16) = hi;
+        } else {
+            f32x4 vq = {vv[0], vv[1], vv[2], vv[3]};
+            *reinterpret_cast<f32x4 *>(o + kColsBytes) = vq;
+        }
+    }
+    if (cnt != 0) bad |= 1u;
+    if (bad) atomicOr(err, bad);
+    target[(size_t)k * kLanes + lane] = (uint8_t)tgt;
+}
+
+}  // namespace
+
+hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st)
+{
+    if (img.nchunks == 0) return hipSuccess;
+    const uint32_t blocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3     grid(blocks), block(kLanes * kWavesPerBlock);
+    if (img.f32)
+        hipLaunchKernelGGL(convert_kernel<float>, grid, block, 0, st, csr.row_ptr, csr.col_idx,
+                           static_cast<const float *>(csr.vals), csr.nz_begin, csr.pad_cnt, img.desc, img.stream,
+                           img.target, err_flag, img.G, img.nchunks, img.pad_col);
+    else
+        hipLaunchKernelGGL(convert_kernel<double>, grid, block, 0, st, csr.row_ptr, csr.col_idx,
+                           static_cast<const double *>(csr.vals), csr.nz_begin, csr.pad_cnt, img.desc, img.stream,
+                           img.target, err_flag, img.G, img.nchunks, img.pad_col);
+    return hipGetLastError();
+}
+
+}  // namespace cvr

@@ -1,0 +1,43 @@
+// cvr_format.h -- the CVR64 device format.  Shared by the host planner, the
+// device converter and the SpMV kernel.  Re-derives the reference's CVR layout
+// (pre_processing, /root/reference/spmv.cpp:565-1014) for 64-lane wavefronts.
+//
+//   chunk      = 64 lane streams x S steps, handled by ONE wavefront (the reference: one OpenMP
+//                thread x 8 AVX-512 lanes, spmv.cpp:584-627).  S is a multiple of 4.
+//   slot       = one (column, value) element of a lane stream.  Every matrix row owns
+//                max(1, nnz_row) consecutive slots: an EMPTY row owns one pad slot
+//                (column = ncols -> x_ext[ncols] == 0, value 0), so that the row a lane writes is
+//                implied by the order rows are handed out and no (pos, wb) record list
+//                (spmv.cpp:832-834) is needed.
+//   segment    = the slots of one row inside one chunk (rows are cut only when longer than the
+//                split threshold), plus at most one trailing pad segment that fills the chunk to
+//                exactly 64*S slots (the reference pads nnz to 16 instead, spmv.cpp:474-482).
+//   group      = 4 consecutive steps of all 64 lanes, stored as
+//                  [64 lanes][4 x u32 column words]                  1024 B   (one dwordx4 / lane)
+//                  fp64: [2 halves][64 lanes][2 x f64]               2048 B   (two dwordx4 / lane)
+//                  fp32: [64 lanes][4 x f32]                         1024 B   (one dwordx4 / lane)
+//                bit 31 of a column word = "last slot of this lane's current segment"
+//   desc[k]    = {row_first, nseg, head_dest, last_dest}: segment q of chunk k writes
+//                y_ext[q == 0 ? head_dest : q == nseg-1 ? last_dest : row_first + q]
+//   y_ext      = [ y[0..nrows) | dump | carry_head(0), carry_tail(0), carry_head(1), ... ]
+//   target[k]  = per lane: the lane it stole from (itself if it never stole); spmv.cpp:900, 982-999
+//   shared[]   = rows cut over chunks c0..c1: y[row] = carry_tail(c0) + sum_{c0<c<=c1} carry_head(c)
+#pragma once
+#include <cstdint>
+
+namespace cvr {
+
+constexpr int      kLanes        = 64;
+constexpr uint32_t kEndBit       = 0x80000000u;
+constexpr uint32_t kColMask      = 0x7fffffffu;
+constexpr int      kGroupSteps   = 4;
+constexpr int      kColsBytes    = kLanes * 16;            // 1024
+constexpr int      kGroupBytes64 = kColsBytes + kLanes * 32;  // 3072
+constexpr int      kGroupBytes32 = kColsBytes + kLanes * 16;  // 2048
+constexpr int      kWavesPerBlock = 4;
+
+inline int group_bytes(bool f32) { return f32 ? kGroupBytes32 : kGroupBytes64; }
+
+struct Shared { int64_t row, c0, c1; };
+
+}  // namespace cvr

@@ -1,0 +1,41 @@
+// cvr_kernels.h -- launch wrappers of the gfx950 kernels (cvr_convert.hip, cvr_spmv.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "cvr_format.h"
+
+namespace cvr {
+
+struct DeviceImage {
+    int32_t  S = 0, G = 0;
+    bool     f32 = false;
+    uint32_t nchunks = 0;
+    uint32_t nrows = 0;          // y rows; y_ext[nrows] is the dump slot
+    uint32_t pad_col = 0;        // = ncols: x_ext[pad_col] == 0
+    uint8_t *stream = nullptr;   // nchunks * G * group_bytes
+    uint4   *desc = nullptr;     // [nchunks] {row_first, nseg, head_dest, last_dest}
+    uint8_t *target = nullptr;   // [nchunks][64]
+    int64_t *shared = nullptr;   // [nshared][3] {row, c0, c1}
+    uint32_t nshared = 0;
+    bool     xcd_swizzle = true;
+    bool     nontemporal = true;
+};
+
+struct DeviceCsr {
+    const int64_t  *row_ptr = nullptr;
+    const int32_t  *col_idx = nullptr;
+    const void     *vals = nullptr;
+    const int64_t  *nz_begin = nullptr;   // [nchunks+1]
+    const uint32_t *pad_cnt = nullptr;    // [nchunks]
+};
+
+// CSR -> CVR64 (one wavefront per chunk).  *err_flag (device u32, zeroed by the caller) gets bit 0 if a
+// lane stream did not drain, bit 1 if stealing found no over-full lane.
+hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st);
+
+// y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0)
+hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st);
+
+}  // namespace cvr

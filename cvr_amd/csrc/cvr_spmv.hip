@@ -1,0 +1,237 @@
+// cvr_spmv.hip -- y = A x over the CVR64 image, one wavefront per chunk (gfx950, wave64).  HBM-bound.
+//
+// The reference's spmv_compute_kernel (/root/reference/spmv.cpp:1016-1667) re-derived for 64 lanes:
+//   * one loop instead of the five hand-split phases A-E (spmv.cpp:1167-1629): each step is
+//     acc += val * x[col] (spmv.cpp:1226-1233), the matrix streams arrive as 16-B-per-lane coalesced
+//     loads (1 KiB per wave instruction; the reference: one 64-B load per 8 lanes), the x gather
+//     (_mm512_i32logather_pd, spmv.cpp:1227) is one global_load_dwordx2 per lane, issued one
+//     group (4 steps) ahead of its use in place of the software prefetch of spmv.cpp:1183-1190;
+//   * the scalar record-servicing `while` (spmv.cpp:1197-1224) is replaced by bit 31 of the column
+//     word: the lanes whose segment ends at this step form a __ballot mask; each stores its row sum
+//     (spmv.cpp:1204-1205 get_simd/set_simd_zero) and takes segment fed + rank-in-mask, the same
+//     hand-out order the converter used, so no write-back ids are read from memory;
+//   * the steal part (spmv.cpp:1579-1629) runs the SAME loop; only the write-back differs: a lane whose
+//     own row ends after the last segment was handed out parks the sum in its LDS slot (t_rets,
+//     spmv.cpp:1607-1616), lanes that stole add their partial sums to the victim's slot at the end
+//     (tail records, spmv.cpp:1633-1638: ds_add here), and the owners store the slots;
+//   * no `#pragma omp atomic` on y (spmv.cpp:1280-1282, 1640-1649) and no zeroing of y
+//     (spmv.cpp:1026-1031): chunks end at row boundaries; the few rows cut over chunks go to carry
+//     slots behind y and are summed in chunk order by fixup_kernel (bitwise reproducible).
+#include "cvr_kernels.h"
+
+namespace cvr {
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef double   f64x2 __attribute__((ext_vector_type(2)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <typename V, bool NT>
+__device__ __forceinline__ V ldg(const uint8_t *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+    else return *reinterpret_cast<const V *>(p);
+}
+
+template <typename T> struct Group;
+template <> struct Group<double> { u32x4 c; f64x2 lo, hi; };
+template <> struct Group<float>  { u32x4 c; f32x4 v; };
+
+template <typename T, bool NT>
+__device__ __forceinline__ Group<T> load_group(const uint8_t *p)
+{
+    Group<T> g;
+    g.c = ldg<u32x4, NT>(p);
+    if constexpr (sizeof(T) == 8) {
+        g.lo = ldg<f64x2, NT>(p + kColsBytes);
+        g.hi = ldg<f64x2, NT>(p + kColsBytes + kLanes * 16);
+    } else {
+        g.v = ldg<f32x4, NT>(p + kColsBytes);
+    }
+    return g;
+}
+
+template <typename T> struct X4 { T v[4]; };
+
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float  fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ X4<T> gather(const T *__restrict__ x, const u32x4 c)
+{
+    X4<T> r;
+    r.v[0] = x[c.x & kColMask];
+    r.v[1] = x[c.y & kColMask];
+    r.v[2] = x[c.z & kColMask];
+    r.v[3] = x[c.w & kColMask];
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ T val_of(const Group<T> &g, int j)
+{
+    if constexpr (sizeof(T) == 8) return j == 0 ? g.lo.x : j == 1 ? g.lo.y : j == 2 ? g.hi.x : g.hi.y;
+    else return j == 0 ? g.v.x : j == 1 ? g.v.y : j == 2 ? g.v.z : g.v.w;
+}
+
+__device__ __forceinline__ uint32_t col_of(const u32x4 c, int j) { return j == 0 ? c.x : j == 1 ? c.y : j == 2 ? c.z : c.w; }
+
+__device__ __forceinline__ uint32_t remap_block(uint32_t b, uint32_t nblocks_per_xcd, bool swz)
+{
+    // blocks are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, "Workgroup dispatch"): give each
+    // XCD one contiguous range of chunks so that neighbouring rows' x lines meet in one L2.  Speed only.
+    return swz ? (b & 7u) * nblocks_per_xcd + (b >> 3) : b;
+}
+
+
+// Wave-uniform and per-lane state of one chunk.
+template <typename T> struct ChunkState {
+    T        acc;       // running sum of the lane's current segment
+    uint32_t cur;       // ordinal of that segment in the chunk
+    uint32_t fed;       // segments handed out so far (wave-uniform)
+    uint32_t feeding;   // 0: the lane is (or has become) a stealer
+    uint32_t own;       // the lane parked a row sum in its LDS slot
+    uint32_t tail;      // every segment handed out (wave-uniform): write-backs go through the slots
+};
+
+// four steps of all 64 lanes: FMA, then the write-back of the lanes whose segment ends at the step
+template <typename T>
+__device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T> &Q, const X4<T> &xq, T *__restrict__ yext,
+                                          T *slot_lane, uint32_t row_first, uint32_t nseg, uint32_t head_dest,
+                                          uint32_t last_dest)
+{
+#pragma unroll
+    for (int j = 0; j < kGroupSteps; j++) {
+        const uint32_t cw = col_of(Q.c, j);
+        s.acc = fma_t(val_of<T>(Q, j), xq.v[j], s.acc);
+        const bool     fl = (cw & kEndBit) != 0;
+        const uint64_t m = __ballot(fl);
+        if (m) {
+            if (!s.tail) {
+                if (fl) {
+                    const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
+                    yext[dst] = s.acc;
+                    s.acc = 0;
+                    const uint32_t nx = s.fed + lane_rank(m);
+                    if (nx < nseg) s.cur = nx; else s.feeding = 0;   // rows exhausted: turns stealer
+                }
+                s.fed = __builtin_amdgcn_readfirstlane(s.fed + (uint32_t)__popcll(m));
+                if (s.fed >= nseg) { s.fed = nseg; s.tail = 1; }
+            } else if (fl && s.feeding) {
+                *slot_lane = s.acc;
+                s.acc = 0;
+                s.feeding = 0;
+                s.own = 1;
+            }
+        }
+    }
+}
+
+template <typename T, bool NT>
+__global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
+    const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
+    const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz)
+{
+    constexpr int GB = sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
+    __shared__ T slot[kWavesPerBlock][kLanes];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t k = __builtin_amdgcn_readfirstlane(remap_block(blockIdx.x, nblocks_per_xcd, swz != 0) * kWavesPerBlock + wv);
+    if (k >= nchunks) return;
+
+    const uint8_t *p = stream + (size_t)k * G * GB + lane * 16;
+    Group<T>       A = load_group<T, NT>(p);
+    Group<T>       B = load_group<T, NT>(p + (G > 1 ? GB : 0));
+    const uint4    d = desc[k];
+    const uint32_t tg = target[(size_t)k * kLanes + lane];
+    const uint32_t row_first = d.x, nseg = d.y, head_dest = d.z, last_dest = d.w;
+
+    ChunkState<T> s;
+    s.acc = 0;
+    s.cur = lane;
+    s.fed = nseg < kLanes ? nseg : kLanes;
+    s.feeding = lane < s.fed;
+    s.own = 0;
+    s.tail = s.fed == nseg;
+    T    *slot_lane = &slot[wv][lane];
+    X4<T> xa = gather<T>(x, A.c);
+#define CVR_SUM(Q, XQ) sum_group<T>(s, Q, XQ, yext, slot_lane, row_first, nseg, head_dest, last_dest)
+
+    // steady state: the loads are unconditional so that the counted vmcnt waits keep the next group's
+    // gathers and the group after's stream loads in flight while this group is summed
+    int g = 0;
+    for (; g + 2 < G; g++) {
+        const Group<T> C = load_group<T, NT>(p + (size_t)(g + 2) * GB);
+        const X4<T>    xb = gather<T>(x, B.c);
+        CVR_SUM(A, xa);
+        A = B; xa = xb; B = C;
+    }
+    if (G > 1) {
+        const X4<T> xb = gather<T>(x, B.c);
+        CVR_SUM(A, xa);
+        A = B; xa = xb;
+    }
+    CVR_SUM(A, xa);
+
+    // tail records (spmv.cpp:1633-1638): stolen partial sums go to the victim's slot, owners store
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#undef CVR_SUM
+    if (tg != lane) __hip_atomic_fetch_add(&slot[wv][tg], s.acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (s.own) {
+        const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
+        yext[dst] = *slot_lane;
+    }
+}
+
+// rows cut over chunks c0..c1: y[row] = carry_tail(c0) + sum_{c0 < c <= c1} carry_head(c), one wavefront per
+// row, fixed summation tree (replaces the atomics of spmv.cpp:1280-1282, 1640-1649)
+template <typename T>
+__global__ __launch_bounds__(kLanes * kWavesPerBlock) void fixup_kernel(const int64_t *__restrict__ shared, uint32_t nshared,
+                                                                        T *__restrict__ yext, uint32_t nrows)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t s = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (s >= nshared) return;
+    const int64_t row = shared[3 * (size_t)s], c0 = shared[3 * (size_t)s + 1], c1 = shared[3 * (size_t)s + 2];
+    const T      *carry = yext + nrows + 1;
+    T             v = 0;
+    for (int64_t c = c0 + 1 + lane; c <= c1; c += kLanes) v += carry[2 * c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) yext[row] = carry[2 * c0 + 1] + v;
+}
+
+}  // namespace
+
+hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st)
+{
+    if (img.nchunks == 0) return hipSuccess;
+    const uint32_t nblocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t per_xcd = (nblocks + 7) / 8;
+    const uint32_t grid = img.xcd_swizzle ? per_xcd * 8 : nblocks;
+    const dim3     block(kLanes * kWavesPerBlock);
+#define CVR_LAUNCH(T, NT)                                                                                         \
+    hipLaunchKernelGGL((spmv_kernel<T, NT>), dim3(grid), block, 0, st, img.stream, img.desc, img.target,          \
+                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
+                       img.xcd_swizzle ? 1 : 0)
+    if (img.f32) { if (img.nontemporal) CVR_LAUNCH(float, true); else CVR_LAUNCH(float, false); }
+    else         { if (img.nontemporal) CVR_LAUNCH(double, true); else CVR_LAUNCH(double, false); }
+#undef CVR_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || img.nshared == 0) return e;
+    const uint32_t fb = (img.nshared + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (img.f32)
+        hipLaunchKernelGGL(fixup_kernel<float>, dim3(fb), block, 0, st, img.shared, img.nshared, static_cast<float *>(y_ext), img.nrows);
+    else
+        hipLaunchKernelGGL(fixup_kernel<double>, dim3(fb), block, 0, st, img.shared, img.nshared, static_cast<double *>(y_ext), img.nrows);
+    return hipGetLastError();
+}
+
+}  // namespace cvr

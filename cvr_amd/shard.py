@@ -1,0 +1,34 @@
+"""Row sharding of one SpMV over the GPUs of a node: contiguous row blocks with balanced nnz, cut at row
+boundaries (the reference balances nnz per thread the same way, spmv.cpp:584-667, but cuts inside rows and
+repairs with atomics); x replicated; y slices all-gathered (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+import numpy as np
+
+
+def row_partition(row_ptr, nparts):
+    """bounds[nparts+1]: part p owns rows bounds[p] .. bounds[p+1]-1; nnz per part as equal as row
+    boundaries allow"""
+    rp = np.asarray(row_ptr, dtype=np.int64)
+    nrows = len(rp) - 1
+    nnz = int(rp[-1] - rp[0])
+    targets = rp[0] + (np.arange(1, nparts, dtype=np.int64) * nnz) // nparts
+    cuts = np.searchsorted(rp, targets, side="left")
+    bounds = np.concatenate([[0], np.clip(cuts, 0, nrows), [nrows]]).astype(np.int64)
+    return np.maximum.accumulate(bounds)
+
+
+def local_csr(row_ptr, col_idx, vals, bounds, p):
+    """the rebased CSR arrays of part p (views / small copies)"""
+    rp = np.asarray(row_ptr, dtype=np.int64)
+    b, e = int(bounds[p]), int(bounds[p + 1])
+    lo, hi = int(rp[b]), int(rp[e])
+    return e - b, rp[b:e + 1] - lo, col_idx[lo:hi], vals[lo:hi]
+
+
+def gather_layout(bounds):
+    """equal-count all-gather: every rank contributes max_rows values; returns (max_rows, index array that
+    picks the real rows out of the [nparts * max_rows] gathered buffer)"""
+    sizes = np.diff(bounds)
+    max_rows = int(sizes.max()) if len(sizes) else 0
+    idx = np.concatenate([p * max_rows + np.arange(int(sizes[p]), dtype=np.int64) for p in range(len(sizes))]) \
+        if len(sizes) else np.zeros(0, dtype=np.int64)
+    return max_rows, idx

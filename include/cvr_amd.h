@@ -1,0 +1,159 @@
+/* include/cvr_amd.h -- C ABI of libcvr_amd.so: CVR-format SpMV for MI355X (gfx950), wave64.
+ *
+ * This is the drop-in boundary for the ONE hot path of puckbee/CVR (/root/reference/spmv.cpp):
+ *
+ *   reference interface (C++ linkage, void, caller-owned arrays)        replaced by
+ *   ------------------------------------------------------------------  ---------------------------
+ *   readMatrix(char*, double**, int**, int**, int*, int*, int*)         cvr_mm_read / cvr_mm_free
+ *       spmv.cpp:311-535, call site spmv.cpp:1771
+ *   fill(double*, int)  (x = 1.0)   spmv.cpp:556-563, call :1788        cvr_fill_x
+ *   pre_processing(int Nthrds, ..19 args..)                             cvr_create + cvr_preprocess
+ *       spmv.cpp:565-1014, call site spmv.cpp:1857
+ *   spmv_compute_kernel(..21 args.., double* h_vec, int Ntimes)         cvr_spmv (host x,y, timed) /
+ *       spmv.cpp:1016-1667, call site spmv.cpp:1882                     cvr_spmv_device (async)
+ *   the CSR self-check loop + verdict  spmv.cpp:1843-1850, 1916-1938    cvr_csr_spmv_host, cvr_verdict
+ *   (nothing: frees are commented out, spmv.cpp:1889-1907)              cvr_destroy
+ *
+ * Conventions: plain C, POD structs, opaque handle, every entry point returns an int
+ * status (0 = ok, <0 = error class) and never exits or throws; the message of the last error of the
+ * calling thread is cvr_last_error().  The handle owns all device memory; the caller owns the host
+ * CSR / x / y buffers and may free them as soon as the call that received them returns.
+ * Calls on one handle must be serialised by the caller; different handles are independent.
+ *
+ * There is no CPU fallback behind this ABI: without a HIP device every compute entry point returns
+ * CVR_ERR_NO_DEVICE.
+ */
+#ifndef CVR_AMD_H
+#define CVR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVR_OK              0
+#define CVR_ERR_INVALID    -1   /* bad argument / malformed CSR                       */
+#define CVR_ERR_NO_DEVICE  -2   /* no HIP device, or device index out of range        */
+#define CVR_ERR_HIP        -3   /* a HIP runtime call failed (text in cvr_last_error) */
+#define CVR_ERR_IO         -4   /* loader: cannot open / not a coordinate matrix      */
+#define CVR_ERR_NOMEM      -5
+#define CVR_ERR_STATE      -6   /* call out of order (spmv before preprocess ...)     */
+#define CVR_ERR_INTERNAL   -7   /* device converter self-check failed                 */
+
+typedef struct cvr_handle cvr_handle;
+
+/* Host CSR as the library reads it.  The arrays are taken LITERALLY: row r owns elements
+ * row_ptr[r] .. row_ptr[r+1]-1, and col_idx indexes x directly.  The reference loader's 1-based
+ * arrays (numRows+2 row pointers, columns 1..numCols) are therefore passed as a
+ * matrix of numRows+1 rows and numCols+1 columns, and its "tail = nItems-1" quirk (Q9) excludes the
+ * same last element the reference's CSR loop excludes. */
+typedef struct {
+    int64_t        nrows;
+    int64_t        ncols;     /* x has ncols entries, y has nrows entries                      */
+    const int64_t *row_ptr;   /* [nrows+1], non-decreasing, row_ptr[0] >= 0                    */
+    const int32_t *col_idx;   /* [row_ptr[nrows]], each in [0, ncols)                          */
+    const void    *vals;      /* double[] or float[] by is_f32                                 */
+    int32_t        is_f32;    /* 0: fp64 values, x, y    1: fp32 values, x, y (fp32 accumulate) */
+} cvr_csr_view;
+
+typedef struct {
+    int32_t device;            /* HIP device ordinal                                           */
+    int32_t steps_per_chunk;   /* S: lane-stream length of one chunk, multiple of 4; 0 = auto  */
+    int64_t split_threshold;   /* rows with more remaining nnz than this may be cut at a chunk */
+                               /* boundary; 0 = default (16*S)                                 */
+    int32_t xcd_swizzle;       /* 1 (default when <0): contiguous chunk ranges per XCD         */
+    int32_t nontemporal;       /* 1 (default when <0): stream the matrix image with nt loads   */
+    int32_t reserved[4];
+} cvr_options;
+
+typedef struct {
+    int32_t iters;
+    double  mean_s, min_s, max_s;   /* per-SpMV seconds over `iters` timed launches (HIP events)     */
+    double  total_s;                /* events around the whole back-to-back loop                      */
+    double  h2d_s, d2h_s;           /* host<->device copies of x and y (outside mean_s)               */
+} cvr_timing;
+
+typedef struct {
+    int64_t nrows, ncols, nnz;
+    int32_t is_f32, steps_per_chunk;
+    int64_t nchunks;
+    int64_t nslots;            /* nchunks * 64 * S  (nnz + one pad slot per empty row + chunk tails) */
+    int64_t nshared;           /* rows cut over several chunks (fix-up list length)                   */
+    int64_t image_bytes;       /* device bytes of the CVR image incl. descriptors                     */
+    int64_t yext_elems;        /* y_ext = [y | dump | 2 carry slots per chunk]                        */
+    int64_t x_elems;           /* ncols + 1 : x_ext[ncols] must be 0 (pad slot)                       */
+    double  plan_s, upload_s, convert_s;  /* host planner, H2D of CSR, device conversion kernel      */
+} cvr_info;
+
+void        cvr_default_options(cvr_options *opt);
+const char *cvr_last_error(void);
+const char *cvr_version(void);
+int         cvr_device_count(void);                     /* 0 when there is no usable HIP device */
+
+/* ---- the handle: one matrix (or one row shard of it) on one GPU ------------------------------ */
+/* Validates the CSR, plans the chunks on the host, uploads the CSR.  (pre_processing's setup half:
+ * chunk partition + row search, spmv.cpp:584-694.) */
+int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt);
+/* CSR -> CVR64 on the device (the tracker loop, spmv.cpp:711-1000); `seconds` = what the reference
+ * prints at spmv.cpp:1009.  Frees the device copy of the CSR unless keep_csr != 0. */
+int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds);
+int cvr_get_info(const cvr_handle *h, cvr_info *info);
+int cvr_destroy(cvr_handle *h);
+
+/* y = A x.  x_host: ncols values, y_host: nrows values (type by is_f32).  One untimed warm-up launch,
+ * then `iters` timed launches; y of the last one is copied back.  (spmv.cpp:1016-1667; unlike the
+ * reference, spmv.cpp:1026-1033, nothing the result needs is left outside the timed region.) */
+int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_timing *timing);
+
+/* Asynchronous single SpMV on caller-provided device buffers and stream (hipStream_t passed as
+ * void*, NULL = the handle's own stream).  x_dev must hold info.x_elems values with
+ * x_dev[ncols] == 0; y_dev must hold info.yext_elems values (the first nrows are y).  Rows without
+ * non-zeros are written as 0 on every call; y needs no zeroing. */
+int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream);
+/* the same, `n` launches back to back (the Ntimes loop of spmv.cpp:1024 without a host round trip per launch) */
+int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *stream, int n);
+/* the handle's own device vectors (valid until cvr_destroy) and stream */
+void *cvr_x_device(cvr_handle *h);
+void *cvr_y_device(cvr_handle *h);
+void *cvr_stream(cvr_handle *h);
+/* `iters` back-to-back launches on the handle's stream and buffers between two HIP events;
+ * returns mean seconds per launch.  No host copies.  (bench.py's roofline leg) */
+int cvr_spmv_bench(cvr_handle *h, int warmup, int iters, double *mean_s);
+
+/* Copies the device-resident CVR64 image back for inspection (tests compare it bit for bit with the
+ * CPU mirror).  Any pointer may be NULL.  Sizes: cols_vals = image_bytes of the stream part
+ * (nchunks * S/4 * group_bytes), desc = 4 u32 per chunk, target = 64 u8 per chunk,
+ * shared = 3 i64 per shared row {row, first chunk, last chunk}. */
+int cvr_export_image(cvr_handle *h, void *stream_image, uint32_t *desc, uint8_t *target, int64_t *shared);
+/* host planner only (no device needed): chunk boundaries for a row_ptr; returns nchunks or <0.
+ * out arrays (each may be NULL) need room for cvr_plan_bound(nrows, nnz, S) chunks. */
+int64_t cvr_plan_bound(int64_t nrows, int64_t nnz, int32_t S);
+int64_t cvr_plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_t split_threshold,
+                        int64_t *nz_begin /*[n+1]*/, int64_t *row_first, int64_t *nseg, int64_t *pad_cnt);
+
+/* ---- host side of the reference program ------------------------------------------------------ */
+#define CVR_MM_REFCOMPAT 0   /* the reference loader's arrays bit for bit (quirks Q1-Q9)           */
+#define CVR_MM_STRICT    1   /* Matrix-Market semantics: 0-based, fp64 values, no padding, 64-bit  */
+typedef struct {
+    int64_t  nrows, ncols, nnz;   /* of the arrays below, taken literally (see cvr_csr_view)      */
+    int64_t  ref_numRows, ref_numCols, ref_nItems, ref_nItemsRaw;  /* header rows/cols, padded and */
+                                                                   /* raw entry counts (refcompat) */
+    int64_t *row_ptr;
+    int32_t *col_idx;
+    double  *vals;
+} cvr_mm_matrix;
+int  cvr_mm_read(const char *path, int mode, cvr_mm_matrix *out);   /* readMatrix, spmv.cpp:311-535 */
+void cvr_mm_free(cvr_mm_matrix *m);
+/* x[j] = 1.0 (mode 0; fill, spmv.cpp:556-563) or splitmix64(0xC0FFEE, j) -> [-1,1) (mode 1) */
+void cvr_fill_x(double *x, int64_t n, int mode);
+/* the reference's self-check loop, OpenMP over rows, j ascending (spmv.cpp:1843-1850) */
+void cvr_csr_spmv_host(int64_t nrows, const int64_t *row_ptr, const int32_t *col_idx, const double *vals,
+                       const double *x, double *y, int nthreads);
+/* rows i in [0, nrows_checked) with (y[i]-yref[i])^2 > 1e-6 (spmv.cpp:1916-1929) */
+int64_t cvr_verdict(const double *y, const double *yref, int64_t nrows_checked);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -74,22 +74,15 @@ typedef struct {
     int     S;               /* steps per chunk (multiple of 4)                                  */
     int     is_f32;
     int64_t nchunks;
-    int64_t nseg;            /* total dest entries                                               */
-    int64_t nshared;         /* rows split over several chunks                                   */
-    /* plan */
-    int64_t *nz_begin;       /* [nchunks+1]                                                      */
-    int64_t *row_first;      /* [nchunks]                                                        */
-    int64_t *row_last;       /* [nchunks]                                                        */
-    /* image */
-    uint32_t *cols;          /* [nchunks*S*64] as uint4 [chunk][g][lane][4], bit31 = segment end */
-    void     *vals;          /* f64: [chunk][g][2][lane][2]; f32: [chunk][g][lane][4]            */
-    uint32_t *desc;          /* [nchunks][2] = {rbase, n_c}                                      */
-    uint32_t *dest;          /* [nseg] index into y_ext                                          */
-    uint8_t  *target;        /* [nchunks][64]                                                    */
-    /* fix-up list */
-    int64_t *shared_row;     /* [nshared]                                                        */
-    int64_t *shared_c0;      /* [nshared] first chunk                                            */
-    int64_t *shared_c1;      /* [nshared] last chunk                                             */
+    int64_t nshared;         /* rows cut over several chunks                                     */
+    int64_t image_bytes;     /* nchunks * S/4 * (3072 | 2048)                                    */
+    uint8_t  *image;         /* per group: [64][4] u32 column words (bit 31 = segment end), then */
+                             /* f64: [2][64][2] values; f32: [64][4] values                      */
+    uint32_t *desc;          /* [nchunks][4] = {row_first, nseg, head_dest, last_dest}           */
+    uint8_t  *target;        /* [nchunks][64] lane stolen from (itself if none)                  */
+    int64_t  *shared;        /* [nshared][3] = {row, first chunk, last chunk}                    */
+    int64_t  *nz_begin;      /* [nchunks+1] plan: first CSR element of each chunk                */
+    int64_t  *pad_cnt;       /* [nchunks]   plan: slots of the trailing pad segment              */
 } orc_cvr64;
 
 int  orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,

@@ -23,12 +23,10 @@ class OrcCvr8(C.Structure):
 
 class OrcCvr64(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("S", C.c_int),
-                ("is_f32", C.c_int), ("nchunks", C.c_int64), ("nseg", C.c_int64), ("nshared", C.c_int64),
-                ("nz_begin", C.POINTER(C.c_int64)), ("row_first", C.POINTER(C.c_int64)),
-                ("row_last", C.POINTER(C.c_int64)), ("cols", C.POINTER(C.c_uint32)), ("vals", C.c_void_p),
-                ("desc", C.POINTER(C.c_uint32)), ("dest", C.POINTER(C.c_uint32)),
-                ("target", C.POINTER(C.c_uint8)), ("shared_row", C.POINTER(C.c_int64)),
-                ("shared_c0", C.POINTER(C.c_int64)), ("shared_c1", C.POINTER(C.c_int64))]
+                ("is_f32", C.c_int), ("nchunks", C.c_int64), ("nshared", C.c_int64), ("image_bytes", C.c_int64),
+                ("image", C.POINTER(C.c_uint8)), ("desc", C.POINTER(C.c_uint32)),
+                ("target", C.POINTER(C.c_uint8)), ("shared", C.POINTER(C.c_int64)),
+                ("nz_begin", C.POINTER(C.c_int64)), ("pad_cnt", C.POINTER(C.c_int64))]
 
 
 def lib():
@@ -167,27 +165,22 @@ class Cvr64:
         if self.rc:
             raise RuntimeError(f"orc_cvr64_build = {self.rc}")
         c = self.c
-        self.nrows, self.S, self.nchunks, self.nseg, self.nshared = c.nrows, c.S, c.nchunks, c.nseg, c.nshared
-        n = c.nchunks * 64 * c.S
-        self.nz_begin = _np(c.nz_begin, c.nchunks + 1, np.int64)
-        self.row_first = _np(c.row_first, c.nchunks, np.int64)
-        self.row_last = _np(c.row_last, c.nchunks, np.int64)
-        self.cols = _np(c.cols, n, np.uint32)
-        vp = C.cast(c.vals, C.POINTER(C.c_float if self.f32 else C.c_double))
-        self.vals = _np(vp, n, np.float32 if self.f32 else np.float64)
-        self.desc = _np(c.desc, 2 * c.nchunks, np.uint32)
-        self.dest = _np(c.dest, c.nseg, np.uint32)
-        self.target = _np(c.target, 64 * c.nchunks, np.uint8)
-        self.shared_row = _np(c.shared_row, c.nshared, np.int64)
-        self.shared_c0 = _np(c.shared_c0, c.nshared, np.int64)
-        self.shared_c1 = _np(c.shared_c1, c.nshared, np.int64)
+        self.nrows, self.ncols, self.S, self.nchunks, self.nshared = c.nrows, c.ncols, c.S, c.nchunks, c.nshared
+        self.image = _np(c.image, c.image_bytes, np.uint8)
+        self.desc = _np(c.desc, 4 * c.nchunks, np.uint32).reshape(-1, 4)
+        self.target = _np(c.target, 64 * c.nchunks, np.uint8).reshape(-1, 64)
+        self.shared = _np(c.shared, 3 * c.nshared, np.int64).reshape(-1, 3)
+        self.nz_begin = _np(c.nz_begin, c.nchunks + 1 if c.nchunks else 0, np.int64)
+        self.pad_cnt = _np(c.pad_cnt, c.nchunks, np.int64)
 
     def spmv(self, x):
+        """x: ncols values (the pad slot x_ext[ncols] = 0 is appended here)"""
         dt = np.float32 if self.f32 else np.float64
-        x = np.ascontiguousarray(x, dtype=dt)
-        y = np.zeros(self.nrows, dtype=dt)
-        lib().orc_cvr64_spmv(C.byref(self.c), x.ctypes.data, y.ctypes.data)
-        return y
+        xe = np.zeros(self.ncols + 1, dtype=dt)
+        xe[: self.ncols] = np.asarray(x, dtype=dt)[: self.ncols]
+        y = np.zeros(max(self.nrows, 1), dtype=dt)
+        lib().orc_cvr64_spmv(C.byref(self.c), xe.ctypes.data, y.ctypes.data)
+        return y[: self.nrows]
 
     def __del__(self):
         try:

@@ -1,0 +1,99 @@
+"""CPU: the CVR64 format (oracle/cvr64_mirror.c, written with the reference's sequential refill semantics,
+spmv.cpp:814-946) against the CSR oracle (spmv.cpp:1843-1850), and the product's host planner
+(cvr_amd/csrc/cvr_plan.cpp, through the C ABI) against the mirror's plan.  No GPU."""
+import os
+
+import numpy as np
+import pytest
+
+import cases as K
+import oraclelib as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = K.cases()
+CASES32 = K.cases(np.float32)
+
+
+def _check(nrows, ncols, rp, ci, va, S, thr=0):
+    m = O.Cvr64(nrows, ncols, rp, ci, va, S, thr)
+    f32 = va.dtype == np.float32
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(ncols, mode).astype(va.dtype)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y = m.spmv(x)
+        bad, worst = O.tol_check(y, yref, absy, tol=2e-5 if f32 else 1e-12)
+        if f32:
+            bad = bad[np.abs(np.asarray(y, dtype=np.float64) - yref)[bad] > 1e-6 * np.maximum(1.0, absy[bad])]
+        assert len(bad) == 0, (mode, S, worst, bad[:5])
+    return m
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("S", [4, 8, 32])
+def test_mirror_matches_csr_oracle(name, S):
+    m = _check(*CASES[name], S)
+    nrows = CASES[name][0]
+    # structure: every chunk holds exactly 64*S slots; descriptors stay inside y_ext
+    assert m.image.size == m.nchunks * (S // 4) * 3072
+    assert np.all(m.desc[:, 2] < nrows + 1 + 2 * m.nchunks) and np.all(m.desc[:, 3] < nrows + 1 + 2 * m.nchunks)
+
+
+@pytest.mark.parametrize("name", ["few_rows_lt_lanes", "power_law_3000", "two_giants", "leading_trailing_empty"])
+def test_mirror_fp32(name):
+    _check(*CASES32[name], 8)
+
+
+@pytest.mark.parametrize("thr", [1, 16, 100000])
+def test_mirror_split_threshold(thr):
+    _check(*CASES["power_law_3000"], 8, thr)
+    _check(*CASES["two_giants"], 16, thr)
+
+
+def test_mirror_is_a_permutation_of_csr():
+    """CVR is a permutation of the CSR non-zeros plus explicit pads (property 1)"""
+    nrows, ncols, rp, ci, va = CASES["power_law_3000"]
+    m = O.Cvr64(nrows, ncols, rp, ci, va, 8)
+    img = m.image.reshape(m.nchunks * 2, 3072)
+    cols = img[:, :1024].copy().view(np.uint32).reshape(-1, 64, 4)
+    vals = img[:, 1024:].copy().view(np.float64).reshape(-1, 2, 64, 2)
+    c = (cols & 0x7FFFFFFF).reshape(-1)
+    v = np.stack([vals[:, 0, :, 0], vals[:, 0, :, 1], vals[:, 1, :, 0], vals[:, 1, :, 1]], axis=-1).reshape(-1)
+    real = c != ncols
+    assert real.sum() == len(ci)
+    assert np.array_equal(np.sort(c[real].astype(np.int64) * 4 + 0), np.sort(ci.astype(np.int64) * 4 + 0))
+    assert np.array_equal(np.sort(v[real]), np.sort(va))
+    assert np.all(v[~real] == 0)
+    # one end flag per segment (rows with a segment here + pad segments) and one per stolen piece
+    stolen = (m.target != np.arange(64, dtype=np.uint8)[None, :]).sum()
+    assert (cols >> 31).sum() == m.desc[:, 1].sum() + stolen
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("S", [4, 16])
+def test_product_planner_equals_mirror(name, S):
+    import cvr_amd
+    nrows, ncols, rp, ci, va = CASES[name]
+    m = O.Cvr64(nrows, ncols, rp, ci, va, S)
+    p = cvr_amd.plan_chunks(rp, S)
+    assert len(p["row_first"]) == m.nchunks
+    assert np.array_equal(p["nz_begin"], m.nz_begin)
+    assert np.array_equal(p["row_first"], m.desc[:, 0].astype(np.int64))
+    assert np.array_equal(p["nseg"], m.desc[:, 1].astype(np.int64))
+    assert np.array_equal(p["pad_cnt"], m.pad_cnt)
+
+
+def test_mirror_on_reference_loader_arrays():
+    """the literal 1-based arrays of the reference loader (Q1, Q9) through CVR64 == the reference's CSR y"""
+    for name in ("pl2000_pattern", "skew12", "sym250_real", "rect64x300_int", "onerow"):
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        nItems, numRows, numCols = (int(v) for v in z["dims"])
+        rp = z["csr_rowptr"].astype(np.int64)
+        nrows, ncols = numRows + 1, numCols + 1
+        m = O.Cvr64(nrows, ncols, rp, z["csr_col"], z["csr_val"], 8)
+        for mode in ("ones", "rand"):
+            x = z[f"x_{mode}"][:ncols]
+            y = m.spmv(x)
+            yref = z[f"y_csr_{mode}"]
+            _, absy = O.csr_spmv64(rp, z["csr_col"], z["csr_val"], x)
+            bad, worst = O.tol_check(y[:numRows], yref, absy[:numRows])
+            assert len(bad) == 0, (name, mode, worst)

@@ -1,0 +1,178 @@
+"""GPU (MI355X): the HIP path through the C ABI against the oracle.
+
+  * converter image  == CPU mirror of the format, bit for bit (integer/byte work: desc, target, column words,
+    value bits, fix-up list)
+  * y                within 1e-12 * sum_j |a_ij x_j| of the CSR oracle (spmv.cpp:1843-1850) for fp64, x == 1 and
+                     seeded x; 2e-5 for the fp32 path against the fp64-accumulated CSR oracle
+  * golden fixtures  the reference loader's arrays and the reference's CSR y (unmodified reference, run in the
+                     build container by oracle/gen_fixtures.py)
+  * full size        web-Google-shaped matrix (BASELINE.json configs[1]): oracle comparison + linearity +
+                     run-to-run bit equality
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import cases as K
+import cvr_amd
+from cvr_amd import capi, synth
+import oraclelib as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
+CASES = K.cases()
+CASES32 = K.cases(np.float32)
+TOL64, TOL32 = 1e-12, 2e-5
+
+
+def _assert_close(y, yref, absy, tol, ctx):
+    bad, worst = O.tol_check(y, yref, absy, tol=tol)
+    assert len(bad) == 0, (ctx, "rows", bad[:8], "worst rel", worst)
+
+
+def test_library_is_the_hip_build_and_sees_the_gpu():
+    assert os.path.exists(capi.lib_path())
+    assert cvr_amd.device_count() >= 1
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("S", [4, 8, 32])
+def test_converter_image_bit_exact_and_y_parity(name, S):
+    nrows, ncols, rp, ci, va = CASES[name]
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, S)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S)
+    assert (A.info.nchunks, A.info.nshared) == (mir.nchunks, mir.nshared)
+    img = A.export_image()
+    assert np.array_equal(img["desc"], mir.desc)
+    assert np.array_equal(img["target"], mir.target)
+    assert np.array_equal(img["shared"], mir.shared)
+    assert np.array_equal(img["image"], mir.image)
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(ncols, mode)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL64, (name, S, mode))
+    A.close()
+
+
+@pytest.mark.parametrize("name", sorted(CASES32))
+def test_fp32_path(name):
+    nrows, ncols, rp, ci, va = CASES32[name]
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, 8)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=8)
+    assert np.array_equal(A.export_image()["image"], mir.image)
+    x = O.x_vec_fast(ncols, "rand").astype(np.float32)
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    y, _ = A.spmv(x)
+    _assert_close(y, yref, absy + 1e-30, TOL32, name)
+    A.close()
+
+
+@pytest.mark.parametrize("thr", [1, 16, 100000])
+@pytest.mark.parametrize("swz,nt", [(0, 0), (1, 1)])
+def test_split_threshold_and_launch_options(thr, swz, nt):
+    for name, S in (("power_law_3000", 8), ("two_giants", 16), ("dense_row_plus_singletons", 4)):
+        nrows, ncols, rp, ci, va = CASES[name]
+        mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr)
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, nontemporal=nt)
+        img = A.export_image()
+        assert np.array_equal(img["image"], mir.image) and np.array_equal(img["shared"], mir.shared)
+        x = O.x_vec_fast(ncols, "rand")
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL64, (name, thr))
+        A.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_reference_fixtures(name):
+    """reference loader arrays (taken literally: 1-based, Q1/Q9) -> GPU y == the reference's CSR y"""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    m = cvr_amd.load_mm(os.path.join(GOLD, "mtx", name + ".mtx"), capi.MM_REFCOMPAT)
+    numRows = int(z["dims"][1])
+    for S in (4, 16):
+        A = cvr_amd.CvrMatrix(m["nrows"], m["ncols"], m["row_ptr"], m["col_idx"], m["vals"], steps_per_chunk=S)
+        for mode in ("ones", "rand"):
+            x = np.zeros(m["ncols"])
+            xs = z[f"x_{mode}"]
+            x[: min(len(xs), m["ncols"])] = xs[: m["ncols"]]
+            y, _ = A.spmv(x)
+            _, absy = O.csr_spmv64(m["row_ptr"], m["col_idx"], m["vals"], x)
+            _assert_close(y[:numRows], z[f"y_csr_{mode}"], absy[:numRows], TOL64, (name, S, mode))
+            assert cvr_amd.verdict(y, np.concatenate([z[f"y_csr_{mode}"], y[numRows:]]), numRows) == 0
+        A.close()
+
+
+def test_call_order_errors():
+    nrows, ncols, rp, ci, va = CASES["uniform_2000"]
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    with pytest.raises(ValueError):
+        A.spmv(np.ones(3))
+    y1, t = A.spmv(np.ones(ncols), iters=3)
+    assert t.iters == 3 and t.mean_s > 0 and t.min_s <= t.mean_s <= t.max_s
+    A.close()
+
+
+@pytest.fixture(scope="module")
+def web_google():
+    nrows, ncols, rp, ci, va = synth.web_google_like()
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    yield nrows, ncols, rp, ci, va, A
+    A.close()
+
+
+def test_full_size_web_google_parity(web_google):
+    nrows, ncols, rp, ci, va, A = web_google
+    assert A.info.nshared == 0              # no row of web-Google's shape is cut at the default threshold
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(ncols, mode)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x, iters=2)
+        _assert_close(y, yref, absy, TOL64, mode)
+        assert np.all(y[np.diff(rp) == 0] == 0)         # rows without non-zeros are written as +0
+
+
+def test_full_size_properties(web_google):
+    nrows, ncols, rp, ci, va, A = web_google
+    x1 = O.x_vec_fast(ncols, "rand")
+    x2 = np.cos(np.arange(ncols) * 0.37)
+    y1, _ = A.spmv(x1)
+    y1b, _ = A.spmv(x1)
+    assert np.array_equal(y1.view(np.uint64), y1b.view(np.uint64))     # bitwise reproducible (no atomics on y)
+    y2, _ = A.spmv(x2)
+    y12, _ = A.spmv(2.0 * x1 - 3.0 * x2)
+    _, a1 = O.csr_spmv64(rp, ci, va, np.abs(x1))
+    _, a2 = O.csr_spmv64(rp, ci, va, np.abs(x2))
+    err = np.abs(y12 - (2.0 * y1 - 3.0 * y2))
+    assert np.all(err <= 1e-12 * (2 * a1 + 3 * a2) + 1e-300)          # linearity
+    # checksum of checksums: 1^T (A x) == (A^T 1)^T x
+    colsum = np.bincount(ci, weights=va, minlength=ncols)
+    assert abs(y1.sum() - colsum @ x1) <= 1e-9 * (np.abs(colsum) @ np.abs(x1))
+
+
+def test_full_size_chunk_lengths_agree(web_google):
+    """results are invariant to the chunk length within the tolerance (property 2)"""
+    nrows, ncols, rp, ci, va, A = web_google
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    for S in (8, 64, 256):
+        B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S)
+        y, _ = B.spmv(x)
+        _assert_close(y, yref, absy, TOL64, S)
+        B.close()
+
+
+def test_livejournal_shape_scaled_with_cut_rows():
+    """soc-LiveJournal1's shape at 1/8 scale: rows longer than the split threshold exercise the carry fix-up"""
+    nrows, ncols, rp, ci, va = synth.livejournal_like(scale=0.125)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=16, split_threshold=64)
+    assert A.info.nshared > 0
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    y, _ = A.spmv(x)
+    _assert_close(y, yref, absy, TOL64, "lj")
+    A.close()
