@@ -131,11 +131,11 @@ int64_t cvr_plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_
 
 static int pick_steps(int64_t nslots_est)
 {
-    // enough chunks to put >= ~8 wavefronts on every one of the 256 CUs, long enough lane streams to
-    // amortise the per-chunk prologue: S = 32 for web-Google (2.6 k chunks), larger for bigger matrices
-    const int64_t want_chunks = 256 * 12;
-    int           S = 16;
-    while (S < 128 && nslots_est / (64 * (int64_t)S * 2) >= want_chunks) S *= 2;
+    // the longest lane streams (fewest per-chunk prologues, fewest cut rows) that still leave >= 8 wavefronts
+    // for every one of the 256 CUs: S = 32 for web-Google (2.6 k chunks), 128 for soc-LiveJournal1
+    const int64_t want_chunks = 256 * 8;
+    int           S = 128;
+    while (S > 16 && nslots_est / (64 * (int64_t)S) < want_chunks) S /= 2;
     return S;
 }
 
@@ -201,7 +201,11 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     cvr::DeviceImage &img = h->img;
     img.S = S; img.G = G; img.f32 = csr->is_f32 != 0; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
     img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)plan.shared.size();
-    img.xcd_swizzle = opt.xcd_swizzle != 0; img.nontemporal = opt.nontemporal != 0;
+    img.xcd_swizzle = opt.xcd_swizzle != 0;
+    img.stream_policy = opt.nontemporal > 0 ? opt.nontemporal == 1 ? 2 : opt.nontemporal : 0;   // 1 = nt; other values: raw aux bits
+    if (opt.reserved[1]) img.gather_policy = opt.reserved[1];
+    if (opt.reserved[2]) img.depth = opt.reserved[2];
+    if (opt.reserved[0]) img.col_mask = (uint32_t)opt.reserved[0] & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
 
 #define HIP_TRY_H(expr)                                                                                     \
     do {                                                                                                    \
@@ -313,7 +317,7 @@ int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream)
 {
     if (!h || !x_dev || !y_dev) return fail(CVR_ERR_INVALID, "null argument");
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_spmv before cvr_preprocess");
-    HIP_TRY(cvr::launch_spmv(h->img, x_dev, y_dev, stream ? (hipStream_t)stream : h->stream));
+    HIP_TRY(cvr::launch_spmv(h->img, x_dev, y_dev, (hipStream_t)stream));
     return CVR_OK;
 }
 
@@ -321,7 +325,7 @@ int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *
 {
     if (!h || !x_dev || !y_dev) return fail(CVR_ERR_INVALID, "null argument");
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_spmv before cvr_preprocess");
-    const hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < n; i++) HIP_TRY(cvr::launch_spmv(h->img, x_dev, y_dev, st));
     return CVR_OK;
 }

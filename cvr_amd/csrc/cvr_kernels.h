@@ -20,7 +20,10 @@ struct DeviceImage {
     int64_t *shared = nullptr;   // [nshared][3] {row, c0, c1}
     uint32_t nshared = 0;
     bool     xcd_swizzle = true;
-    bool     nontemporal = true;
+    int      stream_policy = 0;     // buffer-load cache policy of the matrix stream: 0 default, 2 nt, 16 sc1, 18 sc1+nt
+    int      gather_policy = 0;     // ... of the x gather: 0, 2, 16
+    int      depth = 1;             // groups the x gather runs ahead of the FMAs (1 or 2)
+    uint32_t col_mask = kColMask;   // profiling only: a narrower mask folds the x gather onto a small table
 };
 
 struct DeviceCsr {

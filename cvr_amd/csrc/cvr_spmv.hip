@@ -31,27 +31,33 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <typename V, bool NT>
-__device__ __forceinline__ V ldg(const uint8_t *p)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// Cache-policy bits of a gfx950 buffer load (the `aux` immediate): sc0 = 1, nt = 2, sc1 = 16.
+constexpr int kPolDefault = 0, kPolNt = 2, kPolSc1 = 16;
+
+// Both the matrix stream and x are read through buffer descriptors: 32-bit offsets, the cache policy is an
+// immediate, and a load past num_records returns 0 without touching memory -- which lets the software
+// pipeline run its loads unconditionally past the end of a chunk (counted vmcnt waits stay exact).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes)
 {
-    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
-    else return *reinterpret_cast<const V *>(p);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
 
 template <typename T> struct Group;
 template <> struct Group<double> { u32x4 c; f64x2 lo, hi; };
 template <> struct Group<float>  { u32x4 c; f32x4 v; };
 
-template <typename T, bool NT>
-__device__ __forceinline__ Group<T> load_group(const uint8_t *p)
+template <typename T, int POL>
+__device__ __forceinline__ Group<T> load_group(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
     Group<T> g;
-    g.c = ldg<u32x4, NT>(p);
+    g.c = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL));
     if constexpr (sizeof(T) == 8) {
-        g.lo = ldg<f64x2, NT>(p + kColsBytes);
-        g.hi = ldg<f64x2, NT>(p + kColsBytes + kLanes * 16);
+        g.lo = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, voff + kColsBytes, soff, POL));
+        g.hi = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, voff + kColsBytes + kLanes * 16, soff, POL));
     } else {
-        g.v = ldg<f32x4, NT>(p + kColsBytes);
+        g.v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + kColsBytes, soff, POL));
     }
     return g;
 }
@@ -61,14 +67,21 @@ template <typename T> struct X4 { T v[4]; };
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float  fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-template <typename T>
-__device__ __forceinline__ X4<T> gather(const T *__restrict__ x, const u32x4 c)
+template <typename T, int POL>
+__device__ __forceinline__ T load_x(__amdgpu_buffer_rsrc_t rx, uint32_t col)
+{
+    if constexpr (sizeof(T) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rx, col * 8u, 0, POL));
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, col * 4u, 0, POL));
+}
+
+template <typename T, int POL>
+__device__ __forceinline__ X4<T> gather(__amdgpu_buffer_rsrc_t rx, const u32x4 c, const uint32_t mask)
 {
     X4<T> r;
-    r.v[0] = x[c.x & kColMask];
-    r.v[1] = x[c.y & kColMask];
-    r.v[2] = x[c.z & kColMask];
-    r.v[3] = x[c.w & kColMask];
+    r.v[0] = load_x<T, POL>(rx, c.x & mask);
+    r.v[1] = load_x<T, POL>(rx, c.y & mask);
+    r.v[2] = load_x<T, POL>(rx, c.z & mask);
+    r.v[3] = load_x<T, POL>(rx, c.w & mask);
     return r;
 }
 
@@ -132,10 +145,11 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T> &Q, c
     }
 }
 
-template <typename T, bool NT>
+template <typename T, int SPOL, int XPOL, int DEPTH>
 __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
-    const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz)
+    const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
+    uint32_t cmask, uint32_t xbytes)
 {
     constexpr int GB = sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     __shared__ T slot[kWavesPerBlock][kLanes];
@@ -145,9 +159,16 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     const uint32_t k = __builtin_amdgcn_readfirstlane(remap_block(blockIdx.x, nblocks_per_xcd, swz != 0) * kWavesPerBlock + wv);
     if (k >= nchunks) return;
 
-    const uint8_t *p = stream + (size_t)k * G * GB + lane * 16;
-    Group<T>       A = load_group<T, NT>(p);
-    Group<T>       B = load_group<T, NT>(p + (G > 1 ? GB : 0));
+    const uint32_t cbytes = (uint32_t)G * GB;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)k * cbytes, cbytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes);
+    const uint32_t voff = lane * 16;
+
+    // software pipeline: the matrix stream runs DEPTH+1 groups ahead, the x gather DEPTH groups ahead
+    Group<T> Q[DEPTH + 1];
+    X4<T>    xs[DEPTH];
+#pragma unroll
+    for (int i = 0; i <= DEPTH; i++) Q[i] = load_group<T, SPOL>(rs, voff, (uint32_t)i * GB);
     const uint4    d = desc[k];
     const uint32_t tg = target[(size_t)k * kLanes + lane];
     const uint32_t row_first = d.x, nseg = d.y, head_dest = d.z, last_dest = d.w;
@@ -159,29 +180,26 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     s.feeding = lane < s.fed;
     s.own = 0;
     s.tail = s.fed == nseg;
-    T    *slot_lane = &slot[wv][lane];
-    X4<T> xa = gather<T>(x, A.c);
-#define CVR_SUM(Q, XQ) sum_group<T>(s, Q, XQ, yext, slot_lane, row_first, nseg, head_dest, last_dest)
+    T *slot_lane = &slot[wv][lane];
+#pragma unroll
+    for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL>(rx, Q[i].c, cmask);
 
-    // steady state: the loads are unconditional so that the counted vmcnt waits keep the next group's
-    // gathers and the group after's stream loads in flight while this group is summed
-    int g = 0;
-    for (; g + 2 < G; g++) {
-        const Group<T> C = load_group<T, NT>(p + (size_t)(g + 2) * GB);
-        const X4<T>    xb = gather<T>(x, B.c);
-        CVR_SUM(A, xa);
-        A = B; xa = xb; B = C;
+    // every load is unconditional: past the end of the chunk the stream loads are out of range (zeros, no
+    // traffic) and the gathers they feed all read x[0]
+    for (int g = 0; g < G; g++) {
+        const Group<T> Qn = load_group<T, SPOL>(rs, voff, (uint32_t)(g + DEPTH + 1) * GB);
+        const X4<T>    xn = gather<T, XPOL>(rx, Q[DEPTH].c, cmask);
+        sum_group<T>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest);
+#pragma unroll
+        for (int i = 0; i < DEPTH; i++) Q[i] = Q[i + 1];
+        Q[DEPTH] = Qn;
+#pragma unroll
+        for (int i = 0; i + 1 < DEPTH; i++) xs[i] = xs[i + 1];
+        xs[DEPTH - 1] = xn;
     }
-    if (G > 1) {
-        const X4<T> xb = gather<T>(x, B.c);
-        CVR_SUM(A, xa);
-        A = B; xa = xb;
-    }
-    CVR_SUM(A, xa);
 
     // tail records (spmv.cpp:1633-1638): stolen partial sums go to the victim's slot, owners store
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#undef CVR_SUM
     if (tg != lane) __hip_atomic_fetch_add(&slot[wv][tg], s.acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (s.own) {
@@ -217,12 +235,24 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     const uint32_t per_xcd = (nblocks + 7) / 8;
     const uint32_t grid = img.xcd_swizzle ? per_xcd * 8 : nblocks;
     const dim3     block(kLanes * kWavesPerBlock);
-#define CVR_LAUNCH(T, NT)                                                                                         \
-    hipLaunchKernelGGL((spmv_kernel<T, NT>), dim3(grid), block, 0, st, img.stream, img.desc, img.target,          \
+    const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
+    if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
+#define CVR_LAUNCH(T, SP, XP, D)                                                                                  \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, XP, D>), dim3(grid), block, 0, st, img.stream, img.desc, img.target,   \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
-                       img.xcd_swizzle ? 1 : 0)
-    if (img.f32) { if (img.nontemporal) CVR_LAUNCH(float, true); else CVR_LAUNCH(float, false); }
-    else         { if (img.nontemporal) CVR_LAUNCH(double, true); else CVR_LAUNCH(double, false); }
+                       img.xcd_swizzle ? 1 : 0, img.col_mask, (uint32_t)xb)
+#define CVR_PICK_D(T, SP, XP)                                                                                     \
+    do { if (img.depth == 2) CVR_LAUNCH(T, SP, XP, 2); else CVR_LAUNCH(T, SP, XP, 1); } while (0)
+#define CVR_PICK_XP(T, SP)                                                                                        \
+    do { switch (img.gather_policy) { case kPolNt: CVR_PICK_D(T, SP, kPolNt); break; case kPolSc1: CVR_PICK_D(T, SP, kPolSc1); break; \
+         default: CVR_PICK_D(T, SP, kPolDefault); } } while (0)
+#define CVR_PICK_SP(T)                                                                                            \
+    do { switch (img.stream_policy) { case kPolNt: CVR_PICK_XP(T, kPolNt); break; case kPolSc1: CVR_PICK_XP(T, kPolSc1); break; \
+         case kPolSc1 | kPolNt: CVR_PICK_XP(T, kPolSc1 | kPolNt); break; default: CVR_PICK_XP(T, kPolDefault); } } while (0)
+    if (img.f32) CVR_PICK_SP(float); else CVR_PICK_SP(double);
+#undef CVR_PICK_SP
+#undef CVR_PICK_XP
+#undef CVR_PICK_D
 #undef CVR_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || img.nshared == 0) return e;

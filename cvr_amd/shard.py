@@ -32,3 +32,16 @@ def gather_layout(bounds):
     idx = np.concatenate([p * max_rows + np.arange(int(sizes[p]), dtype=np.int64) for p in range(len(sizes))]) \
         if len(sizes) else np.zeros(0, dtype=np.int64)
     return max_rows, idx
+
+
+def all_gather_y(y_local, max_rows, out=None):
+    """the one exchange step of the sharded SpMV: every rank contributes the first max_rows values of its
+    y buffer (its own rows, then don't-care), every rank receives all slices.  torch.distributed: RCCL over
+    xGMI for device tensors ("nccl" backend), gloo for the CPU tests."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    if out is None:
+        out = torch.empty(world * max_rows, dtype=y_local.dtype, device=y_local.device)
+    dist.all_gather_into_tensor(out, y_local[:max_rows])
+    return out

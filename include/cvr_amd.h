@@ -106,8 +106,8 @@ int cvr_destroy(cvr_handle *h);
  * reference, spmv.cpp:1026-1033, nothing the result needs is left outside the timed region.) */
 int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_timing *timing);
 
-/* Asynchronous single SpMV on caller-provided device buffers and stream (hipStream_t passed as
- * void*, NULL = the handle's own stream).  x_dev must hold info.x_elems values with
+/* Asynchronous single SpMV on caller-provided device buffers and stream (a hipStream_t passed as
+ * void*; NULL is HIP's null stream, cvr_stream(h) is the handle's own).  x_dev must hold info.x_elems values with
  * x_dev[ncols] == 0; y_dev must hold info.yext_elems values (the first nrows are y).  Rows without
  * non-zeros are written as 0 on every call; y needs no zeroing. */
 int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream);

@@ -401,3 +401,20 @@ void orc_cvr8_spmv(const orc_cvr8 *c, const double *x, double *y, int nthreads)
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * bench.py helper: write a 0-based CSR pattern as a row-major `pattern general` Matrix-Market file, so
+ * that the unmodified reference binary (oracle/_ref/spmv.cvr.ref) can be timed on the bench matrix.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_write_mtx_pattern(const char *path, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    static char buf[1 << 20];
+    setvbuf(f, buf, _IOFBF, sizeof(buf));
+    fprintf(f, "%%%%MatrixMarket matrix coordinate pattern general\n%lld %lld %lld\n", (long long)nrows,
+            (long long)ncols, (long long)(rp[nrows] - rp[0]));
+    for (int64_t r = 0; r < nrows; r++)
+        for (int64_t j = rp[r]; j < rp[r + 1]; j++) fprintf(f, "%lld %d\n", (long long)(r + 1), ci[j] + 1);
+    return fclose(f) ? -1 : 0;
+}

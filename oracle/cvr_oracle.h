@@ -49,6 +49,9 @@ void orc_csr_spmv64_f32(int64_t nrows, const int64_t *rowptr, const int32_t *col
 /* seeded non-constant x: splitmix64(0xC0FFEE, j) -> uniform [-1,1)   */
 double orc_x_rand(uint64_t j);
 
+/* bench.py helper: row-major `pattern general` .mtx of a 0-based CSR pattern (input for oracle/_ref) */
+int orc_write_mtx_pattern(const char *path, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci);
+
 /* ---- 8-lane CVR in the reference's own layout ---- */
 typedef struct {
     int     T;          /* chunks = reference threads                                           */

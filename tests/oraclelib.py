@@ -44,6 +44,7 @@ def lib():
         _lib.orc_cvr64_build.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int64, C.POINTER(OrcCvr64)]
         _lib.orc_cvr64_spmv.argtypes = [C.POINTER(OrcCvr64), C.c_void_p, C.c_void_p]
+        _lib.orc_write_mtx_pattern.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -64,6 +65,13 @@ def read_matrix(path):
                rowptr=_np(m.rowptr, m.numRows + 2, np.int32))
     lib().orc_free_csr(C.byref(m))
     return out
+
+
+def write_mtx_pattern(path, nrows, ncols, rowptr, cols):
+    rp = np.ascontiguousarray(rowptr, dtype=np.int64)
+    ci = np.ascontiguousarray(cols, dtype=np.int32)
+    if lib().orc_write_mtx_pattern(os.fsencode(path), nrows, ncols, rp.ctypes.data, ci.ctypes.data):
+        raise OSError(f"cannot write {path}")
 
 
 def x_vec(n, mode):

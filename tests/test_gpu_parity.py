@@ -120,14 +120,14 @@ def test_call_order_errors():
 @pytest.fixture(scope="module")
 def web_google():
     nrows, ncols, rp, ci, va = synth.web_google_like()
-    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=32)
     yield nrows, ncols, rp, ci, va, A
     A.close()
 
 
 def test_full_size_web_google_parity(web_google):
     nrows, ncols, rp, ci, va, A = web_google
-    assert A.info.nshared == 0              # no row of web-Google's shape is cut at the default threshold
+    assert A.info.nshared == 0              # S = 32: no row of web-Google's shape (max 456 nnz) exceeds the threshold 512
     for mode in ("ones", "rand"):
         x = O.x_vec_fast(ncols, mode)
         yref, absy = O.csr_spmv64(rp, ci, va, x)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""tools/sweep.py -- time the SpMV kernel over the format / launch knobs on one GPU (HIP events on the handle's
+stream, cvr_spmv_bench).  Usage: python tools/sweep.py [webgoogle|livejournal|rmat22] [--S 8,16,32] ..."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cvr_amd
+from cvr_amd import synth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("matrix", nargs="?", default="webgoogle")
+    ap.add_argument("--S", default="8,16,32,64,128")
+    ap.add_argument("--swz", default="1,0")
+    ap.add_argument("--nt", default="1,0")
+    ap.add_argument("--thr", default="0")
+    ap.add_argument("--xpol", default="0", help="x-gather cache policy bits: 0 default, 2 nt, 16 sc1")
+    ap.add_argument("--depth", default="1")
+    ap.add_argument("--colmask", default="0", help="comma list of hex masks: folds the x gather onto a small table (timing only)")
+    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scale", type=float, default=1.0)
+    a = ap.parse_args()
+    t0 = time.time()
+    if a.matrix == "webgoogle":
+        n, nc, rp, ci, va = synth.web_google_like(scale=a.scale)
+    elif a.matrix == "livejournal":
+        n, nc, rp, ci, va = synth.livejournal_like(scale=a.scale)
+    elif a.matrix.startswith("rmat"):
+        n, nc, rp, ci, va = synth.rmat(int(a.matrix[4:]), dtype=np.float32)
+    elif a.matrix.startswith("band"):
+        n, nc, rp, ci, va = synth.banded_sym(int(float(a.matrix[4:])))
+    else:
+        raise SystemExit("unknown matrix")
+    nnz = len(ci)
+    vb = va.dtype.itemsize
+    balg = synth.b_alg(n, nc, nnz, vb)
+    print(f"# {a.matrix}: {n} x {nc}, nnz {nnz}, B_alg {balg / 1e6:.1f} MB, generated in {time.time() - t0:.1f}s", flush=True)
+    print("#   S  swz nt    thr  chunks   cut  slots/nnz   conv_us    us/spmv   GFLOP/s   GB/s(alg)  %8TB/s")
+    for S in [int(s) for s in a.S.split(",")]:
+        for thr in [int(s) for s in a.thr.split(",")]:
+            for swz in [int(s) for s in a.swz.split(",")]:
+                for nt, cm, xp, dp in [(int(s), int(m, 16), int(xp), int(dp)) for s in a.nt.split(",") for m in a.colmask.split(",")
+                                       for xp in a.xpol.split(",") for dp in a.depth.split(",")]:
+                    A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, nontemporal=nt,
+                                          debug_col_mask=cm, gather_policy=xp, depth=dp)
+                    x = synth.x_rand(nc, va.dtype)
+                    A.spmv(x)
+                    s = A.bench(a.warmup, a.iters)
+                    i = A.info
+                    print(f"  {S:4d}  {swz}  {nt:2d}  {thr:6d}  {i.nchunks:6d} {i.nshared:5d}  {i.nslots / max(nnz, 1):8.4f}  {i.convert_s * 1e6:9.1f}  "
+                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  xpol {xp} depth {dp}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
+                    A.close()
+
+
+if __name__ == "__main__":
+    main()
