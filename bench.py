@@ -8,7 +8,8 @@
 A "step" is one y = A x over the web-Google-shaped matrix (916 428 x 916 428, 5 105 039 nnz, fp64; seeded
 synthetic stand-in, or the real web-Google.mtx when CVR_DATA_DIR holds it), matrix image, x and y resident
 in HBM.  N > 1: rows are sharded over the ranks (balanced nnz, cut at row boundaries), x is replicated, every
-step ends with the all-gather of the y slices over RCCL ("strong" scaling: the matrix is fixed).
+step ends with the all-gather of the y slices over RCCL ("strong" scaling: the matrix is fixed); the steps of this
+fixed-x loop are independent, so the gather of step k is left to overlap the SpMV of step k+1 (double-buffered y).
 Rank 0 prints ONE JSON line.  The roofline object prices the SpMV kernel alone (algorithmic bytes of SURVEY.md
 8(d) / mean kernel time from HIP events on the launch stream); cpu_baseline is the oracle's 8-lane OpenMP
 restatement of the reference's CVR path on the host cores (rank 0, N = 1 only).
@@ -155,11 +156,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU fallback")
+    if os.environ.get("CVR_BENCH_ONE_DEVICE"):      # plumbing check of the N > 1 path on a 1-GPU box (all ranks on cuda:0)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CVR_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     nrows, ncols, rp, ci, va, source = load_workload()
     nnz = len(ci)
@@ -172,19 +179,21 @@ def main():
     dev = torch.device("cuda", local_rank)
     x = torch.zeros(info.x_elems, dtype=torch.float64, device=dev)
     x[:ncols] = torch.from_numpy(synth.x_rand(ncols)).to(dev)
-    y = torch.zeros(max(info.yext_elems, max_rows), dtype=torch.float64, device=dev)
-    yall = torch.zeros(world * max_rows, dtype=torch.float64, device=dev) if world > 1 else None
+    ny = max(info.yext_elems, max_rows)
+    ybufs = [torch.zeros(ny, dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 1)]
+    yalls = [torch.zeros(world * max_rows, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    y = ybufs[0]
     stream = torch.cuda.Stream(device=dev)     # kernels, events and the collective all go on this stream
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
 
+    last = [0]
+
     def step(n=1):
         if world == 1:
             A.spmv_device(x.data_ptr(), y.data_ptr(), sptr, repeat=n)
-        else:
-            for _ in range(n):
-                A.spmv_device(x.data_ptr(), y.data_ptr(), sptr)
-                shard.all_gather_y(y, max_rows, out=yall)
+        else:   # every step = local SpMV + all-gather of the y slices; the gather of step k overlaps the SpMV of k+1
+            last[0] = shard.pipelined_steps(lambda yb: A.spmv_device(x.data_ptr(), yb.data_ptr(), sptr), ybufs, yalls, max_rows, n)
 
     def sync():
         if world > 1:
@@ -220,7 +229,7 @@ def main():
 
     # parity guard on the timed configuration: y of the last step against the host CSR loop of the product
     # (the reference's own self-check, spmv.cpp:1843-1850, 1916-1938)
-    yh = (yall[torch.from_numpy(pick).to(dev)] if world > 1 else y[:nrows]).cpu().numpy()
+    yh = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if world > 1 else y[:nrows]).cpu().numpy()
     wrong = -1
     if rank == 0:
         yref = cvr_amd.csr_spmv_host(rp, ci, va, x[:ncols].cpu().numpy(), nthreads=len(os.sched_getaffinity(0)))
@@ -245,7 +254,7 @@ def main():
                        "rows_cut_rank0": int(info.nshared),
                        "parallelism": "rows sharded, x replicated, y all-gathered (RCCL)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if world == 1 else None,
                          "kernel": "cvr::spmv_kernel<double>", "kernel_us": kern_s * 1e6,
                          "algorithmic_bytes_per_launch": int(balg_local)},
             "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz) / per / 1e9,

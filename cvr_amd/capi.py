@@ -25,7 +25,9 @@ class CsrView(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
-                ("xcd_swizzle", C.c_int32), ("nontemporal", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("stream_policy", C.c_int32),
+                ("gather_policy", C.c_int32), ("gather_depth", C.c_int32), ("debug_col_mask", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class Timing(C.Structure):
@@ -160,7 +162,7 @@ class CvrMatrix:
     """One matrix (or row shard) resident on one GPU: cvr_create + cvr_preprocess, then spmv()."""
 
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
-                 xcd_swizzle=-1, nontemporal=-1, keep_csr=False, debug_col_mask=0, gather_policy=0, depth=0):
+                 xcd_swizzle=-1, x_window=-1, nontemporal=0, keep_csr=False, debug_col_mask=0, gather_policy=0, depth=0):
         self._h = C.c_void_p()
         rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
         ci = np.ascontiguousarray(col_idx, dtype=np.int32)
@@ -173,9 +175,9 @@ class CvrMatrix:
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
-        opt.xcd_swizzle, opt.nontemporal = xcd_swizzle, nontemporal
-        opt.reserved[1], opt.reserved[2] = gather_policy, depth   # tuning knobs: x-gather cache policy bits, gather run-ahead
-        opt.reserved[0] = debug_col_mask        # profiling only: folds the x gather onto a 2^k-entry table (wrong y)
+        opt.xcd_swizzle, opt.x_window = xcd_swizzle, x_window
+        # tuning / profiling knobs (tools/sweep.py)
+        opt.stream_policy, opt.gather_policy, opt.gather_depth, opt.debug_col_mask = nontemporal, gather_policy, depth, debug_col_mask
         rc = lib().cvr_create(C.byref(self._h), C.byref(view), C.byref(opt))
         if rc:
             self._h = C.c_void_p()

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -84,7 +85,7 @@ void cvr_default_options(cvr_options *o)
     o->steps_per_chunk = 0;
     o->split_threshold = 0;
     o->xcd_swizzle = -1;
-    o->nontemporal = -1;
+    o->x_window = -1;
 }
 
 int cvr_device_count(void)
@@ -202,10 +203,17 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     img.S = S; img.G = G; img.f32 = csr->is_f32 != 0; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
     img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)plan.shared.size();
     img.xcd_swizzle = opt.xcd_swizzle != 0;
-    img.stream_policy = opt.nontemporal > 0 ? opt.nontemporal == 1 ? 2 : opt.nontemporal : 0;   // 1 = nt; other values: raw aux bits
-    if (opt.reserved[1]) img.gather_policy = opt.reserved[1];
-    if (opt.reserved[2]) img.depth = opt.reserved[2];
-    if (opt.reserved[0]) img.col_mask = (uint32_t)opt.reserved[0] & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
+    img.stream_policy = opt.stream_policy > 0 ? opt.stream_policy : 0;
+    img.gather_policy = opt.gather_policy > 0 ? opt.gather_policy : 0;
+    img.depth = opt.gather_depth == 2 ? 2 : 1;
+    // LDS window of x per workgroup: off by default.  Measured on MI355X (profiles/r01_lds_window_sweep.log): the
+    // gathers it absorbs are the cheap ones (L1/L2 hits near the diagonal); the kernel's time is set by the L2
+    // misses of the scattered columns, which a contiguous window cannot hold, and the LDS it takes costs occupancy.
+    int64_t win = opt.x_window < 0 ? 0 : opt.x_window;
+    if (win > ncols + 1) win = ncols + 1;
+    if (win > 16384) win = 16384;                     // 128 KiB of fp64 + the steal slots stay under 160 KiB
+    img.win_elems = (uint32_t)win;
+    if (opt.debug_col_mask) img.col_mask = (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
 
 #define HIP_TRY_H(expr)                                                                                     \
     do {                                                                                                    \
@@ -225,10 +233,15 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     HIP_TRY_H(hipMalloc(&h->d_nzb, sizeof(int64_t) * ((size_t)nchunks + 1)));
     HIP_TRY_H(hipMalloc(&h->d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY_H(hipMalloc(&h->d_err, sizeof(uint32_t)));
-    HIP_TRY_H(hipMalloc(&img.stream, std::max<size_t>(h->stream_bytes, 16)));
+    if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
+        HIP_TRY_H(hipExtMallocWithFlags((void **)&img.stream, std::max<size_t>(h->stream_bytes, 16), hipDeviceMallocUncached));
+    else
+        HIP_TRY_H(hipMalloc(&img.stream, std::max<size_t>(h->stream_bytes, 16)));
     HIP_TRY_H(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY_H(hipMalloc(&img.target, 64 * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY_H(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
+    HIP_TRY_H(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)nchunks / cvr::kWavesPerBlock + 1)));
+    HIP_TRY_H(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / cvr::kWavesPerBlock + 1), h->stream));
     HIP_TRY_H(hipMalloc(&h->d_x, h->vsz * (size_t)in.x_elems));
     HIP_TRY_H(hipMalloc(&h->d_y, h->vsz * (size_t)in.yext_elems));
     HIP_TRY_H(hipMemsetAsync(h->d_x, 0, h->vsz * (size_t)in.x_elems, h->stream));
@@ -267,6 +280,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     csr.row_ptr = h->d_rp; csr.col_idx = h->d_ci; csr.vals = h->d_va; csr.nz_begin = h->d_nzb; csr.pad_cnt = h->d_pad;
     HIP_TRY(hipEventRecord(e0, h->stream));
     HIP_TRY(cvr::launch_convert(h->img, csr, h->d_err, h->stream));
+    HIP_TRY(cvr::launch_window(h->img, csr, h->stream));
     HIP_TRY(hipEventRecord(e1, h->stream));
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(&err, h->d_err, sizeof(err), hipMemcpyDeviceToHost, h->stream));
@@ -302,6 +316,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->img.desc) (void)hipFree(h->img.desc);
     if (h->img.target) (void)hipFree(h->img.target);
     if (h->img.shared) (void)hipFree(h->img.shared);
+    if (h->img.win_base) (void)hipFree(h->img.win_base);
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_y) (void)hipFree(h->d_y);
     if (h->stream) (void)hipStreamDestroy(h->stream);

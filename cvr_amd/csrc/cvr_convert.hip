@@ -125,6 +125,41 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     target[(size_t)k * kLanes + lane] = (uint8_t)tgt;
 }
 
+
+// Window choice for the SpMV kernel's LDS staging of x: one workgroup per SpMV workgroup (kWavesPerBlock
+// consecutive chunks = one contiguous CSR range).  Histogram of the range's columns over bins of 2^binshift
+// columns in LDS, then the best run of `nb` consecutive bins; ties go to the lowest column.
+__global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__ cidx, const int64_t *__restrict__ nzb,
+                                                      uint32_t nchunks, uint32_t ncols1, uint32_t wn, uint32_t binshift,
+                                                      uint32_t nbins, uint32_t nb, uint32_t *__restrict__ win_base)
+{
+    extern __shared__ uint32_t hist[];                       // [nbins + nb] then one u64 for the arg-max
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(hist + ((nbins + nb + 1) & ~1u));
+    const uint32_t c0 = blockIdx.x * kWavesPerBlock;
+    const uint32_t c1 = c0 + kWavesPerBlock < nchunks ? c0 + kWavesPerBlock : nchunks;
+    for (uint32_t i = threadIdx.x; i < nbins + nb; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) *best = 0;
+    __syncthreads();
+    const int64_t lo = nzb[c0], hi = nzb[c1];
+    for (int64_t j = lo + threadIdx.x; j < hi; j += blockDim.x) atomicAdd(&hist[(uint32_t)cidx[j] >> binshift], 1u);
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (uint32_t s = threadIdx.x; s < nbins; s += blockDim.x) {
+        uint32_t score = 0;
+        for (uint32_t t = 0; t < nb; t++) score += hist[s + t];
+        const unsigned long long key = ((unsigned long long)score << 32) | (0xffffffffu - s);
+        mine = key > mine ? key : mine;
+    }
+    atomicMax(best, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t s = 0xffffffffu - (uint32_t)(*best & 0xffffffffu);
+        uint32_t       wb = (*best >> 32) ? s << binshift : 0;
+        if (wb + wn > ncols1) wb = ncols1 > wn ? ncols1 - wn : 0;   // keep the window inside x_ext
+        win_base[blockIdx.x] = wb;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st)
@@ -140,6 +175,27 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
         hipLaunchKernelGGL(convert_kernel<double>, grid, block, 0, st, csr.row_ptr, csr.col_idx,
                            static_cast<const double *>(csr.vals), csr.nz_begin, csr.pad_cnt, img.desc, img.stream,
                            img.target, err_flag, img.G, img.nchunks, img.pad_col);
+    return hipGetLastError();
+}
+
+}  // namespace cvr
+
+namespace cvr {
+
+hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st)
+{
+    if (img.nchunks == 0 || img.win_elems == 0) return hipSuccess;
+    const uint32_t blocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t ncols1 = img.pad_col + 1;
+    uint32_t       binshift = 0;
+    while ((1u << binshift) * 4 < img.win_elems) binshift++;              // bins of >= window/4 columns ...
+    while (((uint64_t)ncols1 >> binshift) + 1 > 8192) binshift++;         // ... and at most 8192 of them
+    const uint32_t nbins = (uint32_t)(((uint64_t)ncols1 + (1u << binshift) - 1) >> binshift);
+    uint32_t       nb = img.win_elems >> binshift;
+    if (nb == 0) nb = 1;
+    const size_t lds = sizeof(uint32_t) * ((size_t)((nbins + nb + 1) & ~1u)) + 16;
+    hipLaunchKernelGGL(window_kernel, dim3(blocks), dim3(256), lds, st, csr.col_idx, csr.nz_begin, img.nchunks, ncols1,
+                       img.win_elems, binshift, nbins, nb, img.win_base);
     return hipGetLastError();
 }
 

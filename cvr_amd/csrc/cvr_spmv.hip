@@ -62,7 +62,7 @@ __device__ __forceinline__ Group<T> load_group(__amdgpu_buffer_rsrc_t r, uint32_
     return g;
 }
 
-template <typename T> struct X4 { T v[4]; };
+template <typename T> struct X4 { T v[4]; T w[4]; };   // v: through the buffer descriptor, w: from the LDS window
 
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float  fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -74,15 +74,37 @@ __device__ __forceinline__ T load_x(__amdgpu_buffer_rsrc_t rx, uint32_t col)
     else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, col * 4u, 0, POL));
 }
 
-template <typename T, int POL>
-__device__ __forceinline__ X4<T> gather(__amdgpu_buffer_rsrc_t rx, const u32x4 c, const uint32_t mask)
+// The x values of four steps.  Without a window every lane reads x[col] through the buffer descriptor.  With a
+// window [wbase, wbase + wn) staged in LDS, lanes whose column falls inside read LDS and send the global load out
+// of range (returns 0, no memory traffic); the other lanes read the zero slot win[wn].  The two halves are OR-ed
+// where the value is used (x_of), so that both loads stay in flight until then.
+template <typename T, int POL, bool WIN>
+__device__ __forceinline__ X4<T> gather(__amdgpu_buffer_rsrc_t rx, const T *win, const u32x4 c, const uint32_t mask,
+                                        const uint32_t wbase, const uint32_t wn)
 {
-    X4<T> r;
-    r.v[0] = load_x<T, POL>(rx, c.x & mask);
-    r.v[1] = load_x<T, POL>(rx, c.y & mask);
-    r.v[2] = load_x<T, POL>(rx, c.z & mask);
-    r.v[3] = load_x<T, POL>(rx, c.w & mask);
+    X4<T>          r;
+    const uint32_t col[4] = {c.x & mask, c.y & mask, c.z & mask, c.w & mask};
+    if constexpr (!WIN) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.v[j] = load_x<T, POL>(rx, col[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t rel = col[j] - wbase;
+            const bool     in = rel < wn;
+            r.v[j] = load_x<T, POL>(rx, in ? 0x3fffffffu : col[j]);   // 0x3fffffff * sizeof(T) is past num_records
+            r.w[j] = win[in ? rel : wn];
+        }
+    }
     return r;
+}
+
+template <typename T, bool WIN>
+__device__ __forceinline__ T x_of(const X4<T> &x, int j)
+{
+    if constexpr (!WIN) return x.v[j];
+    else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, x.v[j]) | __builtin_bit_cast(uint64_t, x.w[j]));
+    else return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x.v[j]) | __builtin_bit_cast(uint32_t, x.w[j]));
 }
 
 template <typename T>
@@ -113,7 +135,7 @@ template <typename T> struct ChunkState {
 };
 
 // four steps of all 64 lanes: FMA, then the write-back of the lanes whose segment ends at the step
-template <typename T>
+template <typename T, bool WIN>
 __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T> &Q, const X4<T> &xq, T *__restrict__ yext,
                                           T *slot_lane, uint32_t row_first, uint32_t nseg, uint32_t head_dest,
                                           uint32_t last_dest)
@@ -121,7 +143,7 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T> &Q, c
 #pragma unroll
     for (int j = 0; j < kGroupSteps; j++) {
         const uint32_t cw = col_of(Q.c, j);
-        s.acc = fma_t(val_of<T>(Q, j), xq.v[j], s.acc);
+        s.acc = fma_t(val_of<T>(Q, j), x_of<T, WIN>(xq, j), s.acc);
         const bool     fl = (cw & kEndBit) != 0;
         const uint64_t m = __ballot(fl);
         if (m) {
@@ -145,22 +167,26 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T> &Q, c
     }
 }
 
-template <typename T, int SPOL, int XPOL, int DEPTH>
+template <typename T, int SPOL, int XPOL, int DEPTH, bool WIN>
 __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
     const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
-    uint32_t cmask, uint32_t xbytes)
+    uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn)
 {
     constexpr int GB = sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
-    __shared__ T slot[kWavesPerBlock][kLanes];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [waves][64] steal slots, then the x window (+ zero slot)
+    T *const slots = reinterpret_cast<T *>(smem);
+    T *const win = slots + kWavesPerBlock * kLanes;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t k = __builtin_amdgcn_readfirstlane(remap_block(blockIdx.x, nblocks_per_xcd, swz != 0) * kWavesPerBlock + wv);
-    if (k >= nchunks) return;
+    const uint32_t blk = remap_block(blockIdx.x, nblocks_per_xcd, swz != 0);
+    const uint32_t k = __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + wv);
+    if (!WIN && k >= nchunks) return;
+    const bool live = k < nchunks;
 
-    const uint32_t cbytes = (uint32_t)G * GB;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)k * cbytes, cbytes);
+    const uint32_t cbytes = live ? (uint32_t)G * GB : 0u;             // a wave past the last chunk streams nothing
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G * GB), cbytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes);
     const uint32_t voff = lane * 16;
 
@@ -169,6 +195,16 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     X4<T>    xs[DEPTH];
 #pragma unroll
     for (int i = 0; i <= DEPTH; i++) Q[i] = load_group<T, SPOL>(rs, voff, (uint32_t)i * GB);
+
+    // stage this workgroup's window of x in LDS: coalesced loads, behind the first stream loads
+    uint32_t wbase = 0;
+    if constexpr (WIN) {
+        wbase = blk * kWavesPerBlock < nchunks ? win_base[blk] : 0u;
+        for (uint32_t i = threadIdx.x; i <= wn; i += kLanes * kWavesPerBlock)
+            win[i] = i < wn ? load_x<T, kPolDefault>(rx, wbase + i) : T(0);
+        __syncthreads();
+        if (!live) return;
+    }
     const uint4    d = desc[k];
     const uint32_t tg = target[(size_t)k * kLanes + lane];
     const uint32_t row_first = d.x, nseg = d.y, head_dest = d.z, last_dest = d.w;
@@ -180,16 +216,16 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     s.feeding = lane < s.fed;
     s.own = 0;
     s.tail = s.fed == nseg;
-    T *slot_lane = &slot[wv][lane];
+    T *slot_lane = &slots[wv * kLanes + lane];
 #pragma unroll
-    for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL>(rx, Q[i].c, cmask);
+    for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL, WIN>(rx, win, Q[i].c, cmask, wbase, wn);
 
     // every load is unconditional: past the end of the chunk the stream loads are out of range (zeros, no
     // traffic) and the gathers they feed all read x[0]
     for (int g = 0; g < G; g++) {
         const Group<T> Qn = load_group<T, SPOL>(rs, voff, (uint32_t)(g + DEPTH + 1) * GB);
-        const X4<T>    xn = gather<T, XPOL>(rx, Q[DEPTH].c, cmask);
-        sum_group<T>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest);
+        const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn);
+        sum_group<T, WIN>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest);
 #pragma unroll
         for (int i = 0; i < DEPTH; i++) Q[i] = Q[i + 1];
         Q[DEPTH] = Qn;
@@ -200,7 +236,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
 
     // tail records (spmv.cpp:1633-1638): stolen partial sums go to the victim's slot, owners store
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (tg != lane) __hip_atomic_fetch_add(&slot[wv][tg], s.acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (tg != lane) __hip_atomic_fetch_add(&slots[wv * kLanes + tg], s.acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (s.own) {
         const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
@@ -237,18 +273,21 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     const dim3     block(kLanes * kWavesPerBlock);
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
     if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
-#define CVR_LAUNCH(T, SP, XP, D)                                                                                  \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, XP, D>), dim3(grid), block, 0, st, img.stream, img.desc, img.target,   \
+    const bool   use_win = img.win_elems > 0 && img.win_base != nullptr;
+    const size_t lds = (size_t)(kWavesPerBlock * kLanes + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
+#define CVR_LAUNCH(T, SP, XP, D, W)                                                                               \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, XP, D, W>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
-                       img.xcd_swizzle ? 1 : 0, img.col_mask, (uint32_t)xb)
+                       img.xcd_swizzle ? 1 : 0, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems)
 #define CVR_PICK_D(T, SP, XP)                                                                                     \
-    do { if (img.depth == 2) CVR_LAUNCH(T, SP, XP, 2); else CVR_LAUNCH(T, SP, XP, 1); } while (0)
+    do { if (use_win) { if (img.depth == 2) CVR_LAUNCH(T, SP, XP, 2, true); else CVR_LAUNCH(T, SP, XP, 1, true); } \
+         else { if (img.depth == 2) CVR_LAUNCH(T, SP, XP, 2, false); else CVR_LAUNCH(T, SP, XP, 1, false); } } while (0)
 #define CVR_PICK_XP(T, SP)                                                                                        \
     do { switch (img.gather_policy) { case kPolNt: CVR_PICK_D(T, SP, kPolNt); break; case kPolSc1: CVR_PICK_D(T, SP, kPolSc1); break; \
          default: CVR_PICK_D(T, SP, kPolDefault); } } while (0)
 #define CVR_PICK_SP(T)                                                                                            \
     do { switch (img.stream_policy) { case kPolNt: CVR_PICK_XP(T, kPolNt); break; case kPolSc1: CVR_PICK_XP(T, kPolSc1); break; \
-         case kPolSc1 | kPolNt: CVR_PICK_XP(T, kPolSc1 | kPolNt); break; default: CVR_PICK_XP(T, kPolDefault); } } while (0)
+         case kPolSc1 | kPolNt: CVR_PICK_XP(T, kPolSc1 | kPolNt); break; case 17: CVR_PICK_XP(T, 17); break; case 19: CVR_PICK_XP(T, 19); break; default: CVR_PICK_XP(T, kPolDefault); } } while (0)
     if (img.f32) CVR_PICK_SP(float); else CVR_PICK_SP(double);
 #undef CVR_PICK_SP
 #undef CVR_PICK_XP

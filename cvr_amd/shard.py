@@ -45,3 +45,22 @@ def all_gather_y(y_local, max_rows, out=None):
         out = torch.empty(world * max_rows, dtype=y_local.dtype, device=y_local.device)
     dist.all_gather_into_tensor(out, y_local[:max_rows])
     return out
+
+
+def pipelined_steps(spmv, y_bufs, yall_bufs, max_rows, steps):
+    """`steps` sharded SpMVs of the fixed-x loop (the reference's Ntimes loop, spmv.cpp:1024): step k computes into
+    y_bufs[k % 2] and starts the all-gather of that slice asynchronously; the gather of step k overlaps the compute of
+    step k + 1 and is waited for before its buffers are reused (step k + 2).  Every step's y is fully gathered on
+    every rank when this returns.  spmv(y_buf) must enqueue the local SpMV into y_buf on the current stream."""
+    import torch.distributed as dist
+    pending = [None, None]
+    for k in range(steps):
+        b = k & 1
+        if pending[b] is not None:
+            pending[b].wait()              # the gather that last read y_bufs[b] / wrote yall_bufs[b]
+        spmv(y_bufs[b])
+        pending[b] = dist.all_gather_into_tensor(yall_bufs[b], y_bufs[b][:max_rows], async_op=True)
+    for w in pending:
+        if w is not None:
+            w.wait()
+    return (steps - 1) & 1                 # index of the buffers holding the last step's result

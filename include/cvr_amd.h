@@ -63,8 +63,14 @@ typedef struct {
     int64_t split_threshold;   /* rows with more remaining nnz than this may be cut at a chunk */
                                /* boundary; 0 = default (16*S)                                 */
     int32_t xcd_swizzle;       /* 1 (default when <0): contiguous chunk ranges per XCD         */
-    int32_t nontemporal;       /* 1 (default when <0): stream the matrix image with nt loads   */
-    int32_t reserved[4];
+    int32_t x_window;          /* values of x each workgroup stages in LDS with coalesced loads */
+                               /* and serves its gathers from; 0 = off (<0 = default = off)    */
+    /* tuning / profiling knobs (tools/sweep.py); 0 = default */
+    int32_t stream_policy;     /* buffer-load cache-policy bits of the matrix stream: 2 nt, 16 sc1 */
+    int32_t gather_policy;     /* ... of the x gather                                          */
+    int32_t gather_depth;      /* groups (of 4 steps) the x gather runs ahead of the FMAs: 1 or 2 */
+    int32_t debug_col_mask;    /* profiling only: folds the gather onto a 2^k-entry table (wrong y) */
+    int32_t reserved[2];
 } cvr_options;
 
 typedef struct {

@@ -176,3 +176,69 @@ def test_livejournal_shape_scaled_with_cut_rows():
     y, _ = A.spmv(x)
     _assert_close(y, yref, absy, TOL64, "lj")
     A.close()
+
+
+@pytest.mark.parametrize("win", [0, 64, 1000, 8192, 16384])
+def test_lds_window_is_bitwise_neutral(win):
+    """the LDS window of x only changes where a value is read from: y must be bit-identical to the windowless kernel"""
+    for name, S in (("power_law_3000", 8), ("uniform_2000", 16), ("leading_trailing_empty", 4), ("single_entry", 4)):
+        nrows, ncols, rp, ci, va = CASES[name]
+        x = O.x_vec_fast(ncols, "rand")
+        A0 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, x_window=0)
+        A1 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, x_window=win)
+        y0, _ = A0.spmv(x)
+        y1, _ = A1.spmv(x)
+        assert np.array_equal(y0.view(np.uint64), y1.view(np.uint64)), (name, win)
+        A0.close()
+        A1.close()
+    nrows, ncols, rp, ci, va = CASES32["power_law_3000"]
+    x = O.x_vec_fast(ncols, "rand").astype(np.float32)
+    y0, _ = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=8, x_window=0).spmv(x)
+    y1, _ = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=8, x_window=win).spmv(x)
+    assert np.array_equal(y0.view(np.uint32), y1.view(np.uint32))
+
+
+def test_cli_prints_the_reference_lines():
+    """./spmv.cvr [mtx] [nThreads] [nIters]: argv contract (spmv.cpp:1693, 1703, 1771) and the four greppable lines
+    (spmv.cpp:1009, 1662, 1664, 1932; README.md:47-49) on fixtures the unmodified reference was run on"""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "spmv.cvr")
+    assert os.path.exists(exe), "build the host program: make -C cvr_amd/csrc"
+    for name, xmode in (("pl2000_pattern", "ones"), ("sym250_real", "rand"), ("skew12", "ones")):
+        mtx = os.path.join(GOLD, "mtx", name + ".mtx")
+        r = subprocess.run([exe, mtx, "2", "7"], capture_output=True, text=True, timeout=120, env=dict(os.environ, CVR_X=xmode))
+        assert r.returncode == 0, r.stderr
+        out = r.stdout
+        f = re.escape(mtx)
+        assert re.search(r"^The Pre-processing\(CSR->CVR\)   Time of CVR   is \S+ seconds\.   \[file: " + f + r"\] \[threads: 2\]$", out, re.M)
+        assert re.search(r"^The SpMV Execution Time of CVR    is \S+ seconds\.   \[file: " + f + r"\] \[threads: 2\]$", out, re.M)
+        assert re.search(r"^         The Throughput of CVR    is \S+ GFlops\.    \[file: " + f + r"\] \[threads: 2\]$", out, re.M)
+        assert "     Very Good! Your result is correct  " in out
+        assert '"wrong":0' in out
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
+    r = subprocess.run([exe, "/nonexistent.mtx", "1", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1                                   # loader errors exit 1 as the reference (spmv.cpp:325)
+
+
+def test_banded_and_rmat_shapes():
+    """the other BASELINE.json shapes at reduced size: banded symmetric (nlpkkt240's shape) fp64, R-MAT fp32"""
+    nrows, ncols, rp, ci, va = synth.banded_sym(300_000)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    y, _ = A.spmv(x)
+    _assert_close(y, yref, absy, TOL64, "banded")
+    A.close()
+    nrows, ncols, rp, ci, va = synth.rmat(17, dtype=np.float32)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    assert A.info.nshared > 0 or np.diff(rp).max() <= 16 * A.info.steps_per_chunk
+    x = O.x_vec_fast(ncols, "rand").astype(np.float32)
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    y, _ = A.spmv(x)
+    _assert_close(y, yref, absy + 1e-30, TOL32, "rmat17")
+    y2, _ = A.spmv(x)
+    assert np.array_equal(y.view(np.uint32), y2.view(np.uint32))
+    A.close()

@@ -61,7 +61,21 @@ def _worker(rank, world, port, name, q):
         yall = shard.all_gather_y(buf, max_rows)
         y = yall[torch.from_numpy(pick)].numpy()
         yref, _ = O.csr_spmv64(rp, ci, va, x)
-        q.put((rank, bool(np.array_equal(y, yref))))
+        ok = bool(np.array_equal(y, yref))
+        # the pipelined fixed-x loop of bench.py (double-buffered y, asynchronous gathers)
+        ybufs = [torch.full_like(buf, -1.0) for _ in range(2)]
+        yalls = [torch.zeros(world * max_rows, dtype=torch.float64) for _ in range(2)]
+        calls = []
+
+        def spmv(yb):
+            calls.append(1)
+            yb[:n] = torch.from_numpy(yl) * len(calls)      # step k writes k * y so that stale buffers show
+        for steps in (1, 2, 5):
+            del calls[:]
+            last = shard.pipelined_steps(spmv, ybufs, yalls, max_rows, steps)
+            yk = yalls[last][torch.from_numpy(pick)].numpy()
+            ok = ok and len(calls) == steps and bool(np.array_equal(yk, yref * steps))
+        q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
