@@ -51,7 +51,7 @@ class MmMatrix(C.Structure):
 # every symbol include/cvr_amd.h declares (tests check the library exports all of them)
 SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_count", "cvr_create", "cvr_preprocess",
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
-           "cvr_spmv_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free",
+           "cvr_spmv_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict"]
 
 
@@ -87,6 +87,8 @@ def lib():
         L.cvr_plan_chunks.restype = C.c_int64
         L.cvr_mm_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(MmMatrix)]
         L.cvr_mm_free.argtypes = [C.POINTER(MmMatrix)]
+        L.cvr_mm_write_bin.argtypes = [C.c_char_p, C.POINTER(MmMatrix)]
+        L.cvr_mm_read_bin.argtypes = [C.c_char_p, C.POINTER(MmMatrix)]
         L.cvr_fill_x.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         L.cvr_csr_spmv_host.argtypes = [C.c_int64] + [C.c_void_p] * 5 + [C.c_int]
         L.cvr_verdict.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -107,13 +109,21 @@ def device_count():
     return lib().cvr_device_count()
 
 
-def load_mm(path, mode=MM_REFCOMPAT):
-    """cvr_mm_read -> dict(nrows, ncols, nnz, ref_*, row_ptr int64, col_idx int32, vals float64) (numpy copies)"""
+def load_mm(path, mode=MM_REFCOMPAT, cache=None):
+    """cvr_mm_read -> dict(nrows, ncols, nnz, ref_*, row_ptr int64, col_idx int32, vals float64) (numpy copies).
+    cache: path of a binary image; read when it exists, written after a text parse otherwise."""
     m = MmMatrix()
-    rc = lib().cvr_mm_read(os.fsencode(path), mode, C.byref(m))
-    if rc:
-        raise CvrError(rc, f"cvr_mm_read({path})")
-    n = m.ref_nItems if mode == MM_REFCOMPAT else m.nnz
+    if cache and os.path.exists(cache):
+        rc = lib().cvr_mm_read_bin(os.fsencode(cache), C.byref(m))
+        if rc:
+            raise CvrError(rc, f"cvr_mm_read_bin({cache})")
+    else:
+        rc = lib().cvr_mm_read(os.fsencode(path), mode, C.byref(m))
+        if rc:
+            raise CvrError(rc, f"cvr_mm_read({path})")
+        if cache and lib().cvr_mm_write_bin(os.fsencode(cache), C.byref(m)):
+            raise CvrError(ERR_IO, f"cvr_mm_write_bin({cache})")
+    n = max(m.ref_nItems, m.nnz)
     out = dict(nrows=m.nrows, ncols=m.ncols, nnz=m.nnz, ref_numRows=m.ref_numRows, ref_numCols=m.ref_numCols,
                ref_nItems=m.ref_nItems, ref_nItemsRaw=m.ref_nItemsRaw,
                row_ptr=np.ctypeslib.as_array(m.row_ptr, shape=(m.nrows + 1,)).copy(),

@@ -4,13 +4,21 @@
 //                    (SURVEY.md Appendix B): indices stay 1-based (Q1), values pass through a float
 //                    (Q2), pattern entries get value index%13 (Q3), only `symmetric` is mirrored
 //                    (Q4), a last line without '\n' is dropped (Q5), nnz is padded to a multiple of
-//                    16 with zero copies of the last entry (Q6), libc qsort on (row, col) (Q7), row
+//                    16 with zero copies of the last entry (Q6), sorted by (row, col) (Q7), row
 //                    pointers after the last non-empty row are nnz-1 (Q9).  Unlike the reference it
 //                    uses 64-bit sizes (Q8) and returns errors instead of exit(1) (spmv.cpp:322-356).
 //   CVR_MM_STRICT    is what the format means: 0-based, fp64 values (pattern = 1.0), symmetric /
-//                    skew-symmetric / hermitian expansion, no padding, counting sort into CSR.
+//                    skew-symmetric / hermitian expansion, no padding.
+//
+// The reference parses with getline + sscanf on one thread and sorts 12-byte records with libc qsort
+// (spmv.cpp:411-451, 485): seconds for web-Google, minutes for 10^8..10^9 entries.  Here the text is cut into
+// one segment per OpenMP thread at line boundaries, every segment is parsed independently, and the entries
+// are brought into (row, col) order by a stable counting sort on the row followed by a stable sort of each
+// row -- the order libc's (merge-sort) qsort produces: entries with equal coordinates stay in file order.
+// A binary image of the parsed CSR (cvr_mm_write_bin / cvr_mm_read_bin) skips the text altogether.
+#include <omp.h>
+
 #include <algorithm>
-#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,30 +29,9 @@
 
 namespace {
 
-struct Coord { int x, y; float val; };   // struct Coordinate, spmv.cpp:62-66
+struct Rec { int64_t r; int32_t c; float vf; double vd; };   // vf: refcompat (through a float), vd: strict
 
-int coordcmp(const void *a, const void *b)   // spmv.cpp:131-144
-{
-    const Coord *p = static_cast<const Coord *>(a), *q = static_cast<const Coord *>(b);
-    if (p->x != q->x) return p->x - q->x;
-    return p->y - q->y;
-}
-
-// std::getline(...).eof() as the reference loops on it (spmv.cpp:337, 377, 411): only '\n'-terminated
-// lines count
-struct Lines {
-    const char *buf; size_t len, pos;
-    bool next(std::string &line)
-    {
-        if (pos >= len) return false;
-        const void *nl = memchr(buf + pos, '\n', len - pos);
-        if (!nl) { pos = len; return false; }
-        const size_t n = (size_t)(static_cast<const char *>(nl) - (buf + pos));
-        line.assign(buf + pos, n);
-        pos += n + 1;
-        return true;
-    }
-};
+struct Banner { bool pattern, complex_, symmetric, skew, hermitian; };
 
 bool slurp(const char *path, std::vector<char> &out)
 {
@@ -53,19 +40,29 @@ bool slurp(const char *path, std::vector<char> &out)
     fseek(f, 0, SEEK_END);
     const long n = ftell(f);
     fseek(f, 0, SEEK_SET);
-    out.assign((size_t)(n > 0 ? n : 0) + 1, '\0');   // NUL-terminated for strtoll/strtod
+    out.assign((size_t)(n > 0 ? n : 0) + 1, '\0');   // NUL-terminated
     const bool ok = n <= 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
     fclose(f);
     return ok;
 }
 
-struct Banner { bool pattern, complex_, symmetric, skew, hermitian; };
-
-int parse_banner(Lines &ln, Banner &b, long long &nr, long long &nc, long long &ne)
+// next '\n'-terminated line of [p, end): std::getline(...).eof() as the reference loops on it
+// (spmv.cpp:337, 377, 411) -- an unterminated last line does not count
+bool next_line(const char *&p, const char *end, const char *&b, const char *&e)
 {
-    std::string line;
-    if (!ln.next(line)) return CVR_ERR_IO;
-    char id[128] = "", object[128] = "", format[128] = "", field[128] = "", symmetry[128] = "";
+    if (p >= end) return false;
+    const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+    if (!nl) { p = end; return false; }
+    b = p; e = nl; p = nl + 1;
+    return true;
+}
+
+int parse_banner(const char *&p, const char *end, Banner &b, long long &nr, long long &nc, long long &ne)
+{
+    const char *lb, *le;
+    if (!next_line(p, end, lb, le)) return CVR_ERR_IO;
+    std::string line(lb, le);
+    char        id[128] = "", object[128] = "", format[128] = "", field[128] = "", symmetry[128] = "";
     sscanf(line.c_str(), "%127s %127s %127s %127s %127s", id, object, format, field, symmetry);
     if (strcmp(object, "matrix") != 0 || strcmp(format, "coordinate") != 0) return CVR_ERR_IO;   // spmv.cpp:346-356
     b.pattern = strcmp(field, "pattern") == 0;
@@ -74,65 +71,192 @@ int parse_banner(Lines &ln, Banner &b, long long &nr, long long &nc, long long &
     b.skew = strcmp(symmetry, "skew-symmetric") == 0;
     b.hermitian = strcmp(symmetry, "hermitian") == 0;
     line.clear();
-    while (ln.next(line))                           // spmv.cpp:377-383
+    while (next_line(p, end, lb, le)) {             // spmv.cpp:377-383
+        line.assign(lb, le);
         if (line.empty() || line[0] != '%') break;
+    }
     nr = nc = ne = 0;
     sscanf(line.c_str(), "%lld %lld %lld", &nr, &nc, &ne);   // spmv.cpp:386
     return CVR_OK;
 }
 
-int read_refcompat(Lines &ln, cvr_mm_matrix *out)
+inline bool is_ws(char ch) { return ch == ' ' || ch == '\t' || ch == '\r' || ch == '\v' || ch == '\f' || ch == '\n'; }
+
+// "%d"-like: skips white space, optional sign, digits; false (nothing stored) when no digit follows
+inline bool scan_int(const char *&p, const char *e, long long &v)
+{
+    while (p < e && is_ws(*p)) p++;
+    const char *q = p;
+    bool        neg = false;
+    if (q < e && (*q == '-' || *q == '+')) { neg = *q == '-'; q++; }
+    if (q >= e || *q < '0' || *q > '9') return false;
+    long long a = 0;
+    while (q < e && *q >= '0' && *q <= '9') { a = a * 10 + (*q - '0'); q++; }
+    v = neg ? -a : a;
+    p = q;
+    return true;
+}
+
+// "%f" (through a float, spmv.cpp:432) or a double, on a token bounded by the line
+inline bool scan_real(const char *&p, const char *e, bool as_float, float &vf, double &vd)
+{
+    while (p < e && is_ws(*p)) p++;
+    if (p >= e) return false;
+    char   tok[96];
+    size_t n = 0;
+    while (p + n < e && !is_ws(p[n]) && n < sizeof(tok) - 1) { tok[n] = p[n]; n++; }
+    tok[n] = 0;
+    char *endp = nullptr;
+    if (as_float) { vf = strtof(tok, &endp); vd = vf; } else { vd = strtod(tok, &endp); vf = (float)vd; }
+    if (endp == tok) return false;
+    p += (size_t)(endp - tok);
+    return true;
+}
+
+struct Parsed {
+    std::vector<std::vector<Rec>> part;    // entries of each text segment, file order, mirrors in place
+    std::vector<long long>        offset;  // global index of each segment's first entry
+    long long                     total = 0;
+    int                           bad = 0;
+};
+
+// mode 0: the reference's line semantics (every '\n'-terminated line is an entry, fields that do not parse stay 0);
+// mode 1: strict (blank and % lines skipped, 1-based indices checked and shifted to 0-based)
+void parse_parallel(const char *p0, const char *end, const Banner &b, int mode, long long nRows, long long nCols, Parsed &out)
+{
+    int          T = omp_get_max_threads();
+    const size_t len = (size_t)(end - p0);
+    if (len < (1u << 16)) T = 1;
+    std::vector<const char *> cut((size_t)T + 1);
+    cut[0] = p0;
+    cut[(size_t)T] = end;
+    for (int t = 1; t < T; t++) {
+        const char *q = p0 + len / (size_t)T * (size_t)t;
+        const char *nl = static_cast<const char *>(memchr(q, '\n', (size_t)(end - q)));
+        cut[(size_t)t] = nl ? nl + 1 : end;
+    }
+    for (int t = 1; t <= T; t++) if (cut[(size_t)t] < cut[(size_t)t - 1]) cut[(size_t)t] = cut[(size_t)t - 1];
+    out.part.assign((size_t)T, {});
+    out.offset.assign((size_t)T + 1, 0);
+    const bool mirror = mode == 0 ? b.symmetric : (b.symmetric || b.skew || b.hermitian);
+    int        bad = 0;
+#pragma omp parallel for num_threads(T) schedule(static, 1) reduction(| : bad)
+    for (int t = 0; t < T; t++) {
+        std::vector<Rec> &v = out.part[(size_t)t];
+        v.reserve((size_t)(cut[(size_t)t + 1] - cut[(size_t)t]) / 12 + 16);
+        const char *p = cut[(size_t)t], *e = cut[(size_t)t + 1], *lb = nullptr, *le = nullptr;
+        while (next_line(p, e, lb, le)) {
+            const char *q = lb;
+            if (mode == 1) {
+                while (q < le && is_ws(*q)) q++;
+                if (q == le || *q == '%') continue;
+            }
+            Rec       r{0, 0, 0.f, mode == 1 ? 1.0 : 0.0};
+            long long a = 0, c = 0;
+            bool      ok = scan_int(q, le, a);
+            if (ok) { r.r = a; ok = scan_int(q, le, c); if (ok) r.c = (int32_t)c; }
+            if (ok && !b.pattern) ok = scan_real(q, le, mode == 0, r.vf, r.vd);   // complex: real part only (spmv.cpp:423-428)
+            if (mode == 1) {
+                if (!ok || a < 1 || a > nRows || c < 1 || c > nCols) { bad |= 1; continue; }
+                r.r = a - 1; r.c = (int32_t)(c - 1);
+            }
+            v.push_back(r);
+            if (mirror && a != c) {                  // spmv.cpp:443-449
+                Rec m = r;
+                if (mode == 0) { m.r = c; m.c = (int32_t)a; }
+                else { m.r = c - 1; m.c = (int32_t)(a - 1); if (b.skew) m.vd = -m.vd; }
+                v.push_back(m);
+            }
+        }
+    }
+    for (int t = 0; t < T; t++) out.offset[(size_t)t + 1] = out.offset[(size_t)t] + (long long)out.part[(size_t)t].size();
+    out.total = out.offset[(size_t)T];
+    out.bad = bad;
+}
+
+// stable (row, col) order of recs with rows in [0, nrows): counting sort on the row, then each row by column
+void sort_rows(std::vector<Rec> &recs, long long nrows, std::vector<int64_t> &rowstart)
+{
+    const size_t n = recs.size();
+    rowstart.assign((size_t)nrows + 1, 0);
+    for (size_t i = 0; i < n; i++) rowstart[(size_t)recs[i].r + 1]++;
+    for (long long r = 0; r < nrows; r++) rowstart[(size_t)r + 1] += rowstart[(size_t)r];
+    std::vector<Rec>     tmp(n);
+    std::vector<int64_t> fill(rowstart.begin(), rowstart.end() - 1);
+    for (size_t i = 0; i < n; i++) tmp[(size_t)fill[(size_t)recs[i].r]++] = recs[i];   // file order inside a row
+    recs.swap(tmp);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (long long r = 0; r < nrows; r++) {
+        Rec *a = recs.data() + rowstart[(size_t)r], *z = recs.data() + rowstart[(size_t)r + 1];
+        bool sorted = true;
+        for (Rec *t = a; t + 1 < z; t++) if (t[1].c < t[0].c) { sorted = false; break; }
+        if (!sorted) std::stable_sort(a, z, [](const Rec &p, const Rec &q) { return p.c < q.c; });
+    }
+}
+
+int read_refcompat(const char *p, const char *end, cvr_mm_matrix *out)
 {
     Banner    b;
     long long nRows, nCols, nHdr;
-    int       rc = parse_banner(ln, b, nRows, nCols, nHdr);
+    int       rc = parse_banner(p, end, b, nRows, nCols, nHdr);
     if (rc) return rc;
-    std::vector<Coord> co;
-    co.reserve((size_t)(nHdr > 0 ? nHdr : 16) * (b.symmetric ? 2 : 1) + 32);
-    std::string line;
-    long long   index = 0;
-    while (ln.next(line)) {                         // spmv.cpp:411-451
-        Coord c{0, 0, 0.f};
-        if (b.pattern) {
-            sscanf(line.c_str(), "%d %d", &c.x, &c.y);
-            c.val = (float)(index % 13);            // spmv.cpp:417
-        } else if (b.complex_) {
-            float im;
-            sscanf(line.c_str(), "%d %d %f %f", &c.x, &c.y, &c.val, &im);
-        } else {
-            sscanf(line.c_str(), "%d %d %f", &c.x, &c.y, &c.val);   // spmv.cpp:432 (through a float)
-        }
-        co.push_back(c);
-        index++;
-        if (b.symmetric && c.x != c.y) {            // spmv.cpp:443-449
-            co.push_back(Coord{c.y, c.x, c.val});
-            index++;
-        }
-    }
+    if (nRows < 0 || nCols < 0) return CVR_ERR_INVALID;
+    Parsed ps;
+    parse_parallel(p, end, b, 0, nRows, nCols, ps);
+    const long long index = ps.total;                // spmv.cpp:455
     if (index == 0) return CVR_ERR_IO;
     const long long npad = index % 16 == 0 ? index : (index + 16) / 16 * 16;   // spmv.cpp:457
-    const Coord     last = co.back();
-    for (long long q = index; q < npad; q++) co.push_back(Coord{last.x, last.y, 0.f});   // spmv.cpp:474-482
-    qsort(co.data(), (size_t)npad, sizeof(Coord), coordcmp);                          // spmv.cpp:485
+    std::vector<Rec> recs((size_t)npad);
+    const int        T = (int)ps.part.size();
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < T; t++) {
+        // pattern files: value = running entry index % 13, the index counting mirrored entries too, a mirror
+        // repeating its original's value (spmv.cpp:413-417, 443-449).  Inside a segment a mirror directly follows
+        // its original and a segment starts with an original.
+        long long g = ps.offset[(size_t)t];
+        const std::vector<Rec> &v = ps.part[(size_t)t];
+        for (size_t i = 0; i < v.size(); i++, g++) {
+            Rec q = v[i];
+            if (b.pattern) {
+                q.vf = (float)(g % 13);
+                recs[(size_t)g] = q;
+                if (b.symmetric && q.r != q.c && i + 1 < v.size()) {   // its mirror
+                    Rec m = v[i + 1];
+                    m.vf = q.vf;
+                    recs[(size_t)g + 1] = m;
+                    i++; g++;
+                }
+            } else {
+                recs[(size_t)g] = q;
+            }
+        }
+    }
+    ps.part.clear();
+    const Rec last = recs[(size_t)index - 1];
+    for (long long q = index; q < npad; q++) recs[(size_t)q] = Rec{last.r, last.c, 0.f, 0.0};   // spmv.cpp:474-482
     for (long long i = 0; i < npad; i++)
-        if (co[(size_t)i].x < 0 || co[(size_t)i].x > nRows + 1 || co[(size_t)i].y < 0) return CVR_ERR_INVALID;
+        if (recs[(size_t)i].r < 0 || recs[(size_t)i].r > nRows + 1 || recs[(size_t)i].c < 0) return CVR_ERR_INVALID;
+
+    std::vector<int64_t> rowstart;
+    sort_rows(recs, nRows + 2, rowstart);            // spmv.cpp:485 (rows 0 .. nRows+1 can occur)
 
     out->ref_numRows = nRows; out->ref_numCols = nCols; out->ref_nItems = npad; out->ref_nItemsRaw = index;
     out->row_ptr = static_cast<int64_t *>(malloc(sizeof(int64_t) * (size_t)(nRows + 2)));
     out->col_idx = static_cast<int32_t *>(malloc(sizeof(int32_t) * (size_t)npad));
     out->vals = static_cast<double *>(malloc(sizeof(double) * (size_t)npad));
     if (!out->row_ptr || !out->col_idx || !out->vals) return CVR_ERR_NOMEM;
-    int64_t *rp = out->row_ptr;
-    rp[0] = 0;                                      // spmv.cpp:499
-    long long r = 0, i = 0;
-    int32_t   maxc = 0;
-    for (; i < npad; i++) {                         // spmv.cpp:505-514
-        while (co[(size_t)i].x != r) rp[++r] = i;
-        out->vals[i] = co[(size_t)i].val;
-        out->col_idx[i] = co[(size_t)i].y;
-        if (co[(size_t)i].y > maxc) maxc = co[(size_t)i].y;
+    int32_t maxc = 0;
+#pragma omp parallel for reduction(max : maxc)
+    for (long long i = 0; i < npad; i++) {
+        out->vals[i] = recs[(size_t)i].vf;
+        out->col_idx[i] = recs[(size_t)i].c;
+        if (recs[(size_t)i].c > maxc) maxc = recs[(size_t)i].c;
     }
-    for (long long k = r + 1; k <= nRows + 1; k++) rp[k] = i - 1;   // spmv.cpp:522-526 (Q9)
+    // the reference's row-pointer walk (spmv.cpp:499-526): rp[r] = first element of row r up to the last non-empty
+    // row, nItems-1 afterwards (Q9)
+    int64_t        *rp = out->row_ptr;
+    const long long lastrow = recs[(size_t)npad - 1].r;
+    for (long long r = 0; r <= nRows + 1; r++) rp[r] = r <= lastrow ? rowstart[(size_t)r] : npad - 1;
     // the arrays taken literally: rows 0..numRows (row 0 is always empty), columns 0..numCols
     out->nrows = nRows + 1;
     out->ncols = (nCols > maxc ? nCols : maxc) + 1;
@@ -140,65 +264,48 @@ int read_refcompat(Lines &ln, cvr_mm_matrix *out)
     return CVR_OK;
 }
 
-struct Entry { int64_t r; int32_t c; double v; };
-
-int read_strict(Lines &ln, cvr_mm_matrix *out)
+int read_strict(const char *p, const char *end, cvr_mm_matrix *out)
 {
     Banner    b;
     long long nRows, nCols, nHdr;
-    int       rc = parse_banner(ln, b, nRows, nCols, nHdr);
+    int       rc = parse_banner(p, end, b, nRows, nCols, nHdr);
     if (rc) return rc;
     if (nRows < 0 || nCols < 0 || nCols >= 0x7fffffffLL) return CVR_ERR_INVALID;
-    std::vector<Entry> en;
-    en.reserve((size_t)(nHdr > 0 ? nHdr : 16) * ((b.symmetric || b.skew || b.hermitian) ? 2 : 1));
-    // the rest of the buffer, including a last line without '\n'
-    const char *p = ln.buf + ln.pos, *end = ln.buf + ln.len;
-    while (p < end) {
-        while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) p++;
-        if (p >= end) break;
-        if (*p == '%') { while (p < end && *p != '\n') p++; continue; }
-        char     *q;
-        long long r = strtoll(p, &q, 10);
-        if (q == p) return CVR_ERR_IO;
-        p = q;
-        long long c = strtoll(p, &q, 10);
-        if (q == p) return CVR_ERR_IO;
-        p = q;
-        double v = 1.0;
-        if (!b.pattern) {
-            v = strtod(p, &q);
-            if (q == p) return CVR_ERR_IO;
-            p = q;
-            if (b.complex_) { (void)strtod(p, &q); p = q; }   // real part only, as the reference (spmv.cpp:423-428)
-        }
-        while (p < end && *p != '\n') p++;
-        if (r < 1 || r > nRows || c < 1 || c > nCols) return CVR_ERR_INVALID;
-        en.push_back(Entry{r - 1, (int32_t)(c - 1), v});
-        if ((b.symmetric || b.skew || b.hermitian) && r != c) en.push_back(Entry{c - 1, (int32_t)(r - 1), b.skew ? -v : v});
+    // strict mode also takes a last line without '\n': it is parsed from a copy that ends with one
+    std::vector<char> tail;
+    if (end > p && end[-1] != '\n') {
+        const char *ls = end;
+        while (ls > p && ls[-1] != '\n') ls--;
+        tail.assign(ls, end);
+        tail.push_back('\n');
+        end = ls;
     }
-    const size_t nnz = en.size();
-    out->ref_numRows = nRows; out->ref_numCols = nCols; out->ref_nItems = (int64_t)nnz; out->ref_nItemsRaw = (int64_t)nnz;
-    out->nrows = nRows; out->ncols = nCols; out->nnz = (int64_t)nnz;
-    out->row_ptr = static_cast<int64_t *>(calloc((size_t)nRows + 1, sizeof(int64_t)));
-    out->col_idx = static_cast<int32_t *>(malloc(sizeof(int32_t) * (nnz ? nnz : 1)));
-    out->vals = static_cast<double *>(malloc(sizeof(double) * (nnz ? nnz : 1)));
+    Parsed ps, pt;
+    parse_parallel(p, end, b, 1, nRows, nCols, ps);
+    if (!tail.empty()) parse_parallel(tail.data(), tail.data() + tail.size(), b, 1, nRows, nCols, pt);
+    if (ps.bad || pt.bad) return CVR_ERR_INVALID;
+    const long long  nnz = ps.total + pt.total;
+    std::vector<Rec> recs((size_t)nnz);
+    const int        T = (int)ps.part.size();
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < T; t++) std::copy(ps.part[(size_t)t].begin(), ps.part[(size_t)t].end(), recs.begin() + ps.offset[(size_t)t]);
+    for (size_t t = 0; t < pt.part.size(); t++) std::copy(pt.part[t].begin(), pt.part[t].end(), recs.begin() + ps.total + pt.offset[t]);
+    ps.part.clear();
+    std::vector<int64_t> rowstart;
+    sort_rows(recs, nRows, rowstart);
+    out->ref_numRows = nRows; out->ref_numCols = nCols; out->ref_nItems = nnz; out->ref_nItemsRaw = nnz;
+    out->nrows = nRows; out->ncols = nCols; out->nnz = nnz;
+    out->row_ptr = static_cast<int64_t *>(malloc(sizeof(int64_t) * ((size_t)nRows + 1)));
+    out->col_idx = static_cast<int32_t *>(malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1)));
+    out->vals = static_cast<double *>(malloc(sizeof(double) * (size_t)(nnz ? nnz : 1)));
     if (!out->row_ptr || !out->col_idx || !out->vals) return CVR_ERR_NOMEM;
-    // counting sort by row, then (stable) by column inside each row
-    int64_t *rp = out->row_ptr;
-    for (const Entry &e : en) rp[e.r + 1]++;
-    for (long long r = 0; r < nRows; r++) rp[r + 1] += rp[r];
-    std::vector<int64_t> fill(rp, rp + nRows);
-    std::vector<Entry>   byrow(nnz);
-    for (const Entry &e : en) byrow[(size_t)fill[(size_t)e.r]++] = e;
-    for (long long r = 0; r < nRows; r++) {
-        Entry *a = byrow.data() + rp[r], *z = byrow.data() + rp[r + 1];
-        bool   sorted = true;
-        for (Entry *t = a; t + 1 < z; t++) if (t[1].c < t[0].c) { sorted = false; break; }
-        if (!sorted) std::stable_sort(a, z, [](const Entry &p, const Entry &q) { return p.c < q.c; });   // file order among duplicates
-    }
-    for (size_t i = 0; i < nnz; i++) { out->col_idx[i] = byrow[i].c; out->vals[i] = byrow[i].v; }
+    std::copy(rowstart.begin(), rowstart.end(), out->row_ptr);
+#pragma omp parallel for
+    for (long long i = 0; i < nnz; i++) { out->col_idx[i] = recs[(size_t)i].c; out->vals[i] = recs[(size_t)i].vd; }
     return CVR_OK;
 }
+
+constexpr uint64_t kBinMagic = 0x3152534352564331ull;   // "1CVRCSR1"
 
 }  // namespace
 
@@ -208,8 +315,8 @@ extern "C" int cvr_mm_read(const char *path, int mode, cvr_mm_matrix *out)
     memset(out, 0, sizeof(*out));
     std::vector<char> buf;
     if (!slurp(path, buf)) return CVR_ERR_IO;       // spmv.cpp:322-326
-    Lines ln{buf.data(), buf.size() - 1, 0};
-    int   rc = mode == CVR_MM_REFCOMPAT ? read_refcompat(ln, out) : read_strict(ln, out);
+    const char *p = buf.data(), *end = buf.data() + buf.size() - 1;
+    int         rc = mode == CVR_MM_REFCOMPAT ? read_refcompat(p, end, out) : read_strict(p, end, out);
     if (rc) cvr_mm_free(out);
     return rc;
 }
@@ -219,4 +326,42 @@ extern "C" void cvr_mm_free(cvr_mm_matrix *m)
     if (!m) return;
     free(m->row_ptr); free(m->col_idx); free(m->vals);
     memset(m, 0, sizeof(*m));
+}
+
+// Binary image of a parsed matrix: header {magic, 7 x int64}, then row_ptr, col_idx, vals.
+extern "C" int cvr_mm_write_bin(const char *path, const cvr_mm_matrix *m)
+{
+    if (!path || !m || !m->row_ptr) return CVR_ERR_INVALID;
+    FILE *f = fopen(path, "wb");
+    if (!f) return CVR_ERR_IO;
+    const int64_t n = m->ref_nItems > m->nnz ? m->ref_nItems : m->nnz;   // refcompat keeps the excluded last element (Q9)
+    const int64_t hdr[8] = {(int64_t)kBinMagic, m->nrows, m->ncols, m->nnz, m->ref_numRows, m->ref_numCols, m->ref_nItems, m->ref_nItemsRaw};
+    bool ok = fwrite(hdr, sizeof(hdr), 1, f) == 1;
+    ok = ok && fwrite(m->row_ptr, sizeof(int64_t), (size_t)m->nrows + 1, f) == (size_t)m->nrows + 1;
+    ok = ok && (n == 0 || fwrite(m->col_idx, sizeof(int32_t), (size_t)n, f) == (size_t)n);
+    ok = ok && (n == 0 || fwrite(m->vals, sizeof(double), (size_t)n, f) == (size_t)n);
+    return (fclose(f) == 0 && ok) ? CVR_OK : CVR_ERR_IO;
+}
+
+extern "C" int cvr_mm_read_bin(const char *path, cvr_mm_matrix *out)
+{
+    if (!path || !out) return CVR_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    FILE *f = fopen(path, "rb");
+    if (!f) return CVR_ERR_IO;
+    int64_t hdr[8];
+    if (fread(hdr, sizeof(hdr), 1, f) != 1 || (uint64_t)hdr[0] != kBinMagic || hdr[1] < 0 || hdr[3] < 0 || hdr[6] < 0) { fclose(f); return CVR_ERR_IO; }
+    out->nrows = hdr[1]; out->ncols = hdr[2]; out->nnz = hdr[3];
+    out->ref_numRows = hdr[4]; out->ref_numCols = hdr[5]; out->ref_nItems = hdr[6]; out->ref_nItemsRaw = hdr[7];
+    const int64_t n = out->ref_nItems > out->nnz ? out->ref_nItems : out->nnz;
+    out->row_ptr = static_cast<int64_t *>(malloc(sizeof(int64_t) * ((size_t)out->nrows + 1)));
+    out->col_idx = static_cast<int32_t *>(malloc(sizeof(int32_t) * (size_t)(n ? n : 1)));
+    out->vals = static_cast<double *>(malloc(sizeof(double) * (size_t)(n ? n : 1)));
+    bool ok = out->row_ptr && out->col_idx && out->vals;
+    ok = ok && fread(out->row_ptr, sizeof(int64_t), (size_t)out->nrows + 1, f) == (size_t)out->nrows + 1;
+    ok = ok && (n == 0 || fread(out->col_idx, sizeof(int32_t), (size_t)n, f) == (size_t)n);
+    ok = ok && (n == 0 || fread(out->vals, sizeof(double), (size_t)n, f) == (size_t)n);
+    fclose(f);
+    if (!ok) { cvr_mm_free(out); return CVR_ERR_IO; }
+    return CVR_OK;
 }

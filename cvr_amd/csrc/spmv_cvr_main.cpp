@@ -10,6 +10,7 @@
 //     CVR_X=ones|rand     x = 1.0 as the reference (spmv.cpp:556-563) or the seeded non-constant x
 //     CVR_MM=refcompat|strict   loader mode (default refcompat = the reference loader's arrays)
 //     CVR_S=<steps>       lane-stream length per chunk (default: chosen from the matrix size)
+//     CVR_CACHE=1         keep / reuse a binary image of the parsed matrix (<mtx>.ref.cvrbin / .strict.cvrbin)
 // Exit code 0 as the reference (spmv.cpp:1947), 1 on loader errors (spmv.cpp:325-355), 2 on usage / device errors.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -59,8 +60,16 @@ int main(int argc, char **argv)
     std::vector<int>  devs = parse_devices(getenv("CVR_DEVICES"));
     const int         G = (int)devs.size();
 
-    cvr_mm_matrix m;
-    int           rc = cvr_mm_read(fn, mmmode, &m);   // spmv.cpp:1771
+    // CVR_CACHE=1: keep / reuse a binary image of the parsed matrix next to the .mtx file
+    cvr_mm_matrix     m;
+    const std::string bin = std::string(fn) + (mmmode == CVR_MM_STRICT ? ".strict.cvrbin" : ".ref.cvrbin");
+    int               rc = CVR_ERR_IO;
+    const bool        use_cache = getenv("CVR_CACHE") && atoi(getenv("CVR_CACHE"));
+    if (use_cache) rc = cvr_mm_read_bin(bin.c_str(), &m);
+    if (rc) {
+        rc = cvr_mm_read(fn, mmmode, &m);   // spmv.cpp:1771
+        if (!rc && use_cache) (void)cvr_mm_write_bin(bin.c_str(), &m);
+    }
     if (rc) { fprintf(stderr, "Error: unable to read matrix file %s (%d)\n", fn, rc); return 1; }
     printf("Matrix %s: %lld rows, %lld columns, %lld stored entries (%s loader)\n", fn, (long long)m.ref_numRows,
            (long long)m.ref_numCols, (long long)m.ref_nItems, mmmode == CVR_MM_STRICT ? "strict" : "reference-compatible");

@@ -151,6 +151,9 @@ typedef struct {
 } cvr_mm_matrix;
 int  cvr_mm_read(const char *path, int mode, cvr_mm_matrix *out);   /* readMatrix, spmv.cpp:311-535 */
 void cvr_mm_free(cvr_mm_matrix *m);
+/* binary image of a parsed matrix (all fields of cvr_mm_matrix): skips the text parse on the next run */
+int  cvr_mm_write_bin(const char *path, const cvr_mm_matrix *m);
+int  cvr_mm_read_bin(const char *path, cvr_mm_matrix *out);
 /* x[j] = 1.0 (mode 0; fill, spmv.cpp:556-563) or splitmix64(0xC0FFEE, j) -> [-1,1) (mode 1) */
 void cvr_fill_x(double *x, int64_t n, int mode);
 /* the reference's self-check loop, OpenMP over rows, j ascending (spmv.cpp:1843-1850) */

@@ -121,3 +121,48 @@ def test_synthetic_refcompat_view_matches_loader_convention(tmp_path):
     assert np.array_equal(rc["rowptr"].astype(np.int64), m["row_ptr"])
     assert np.array_equal(rc["cols"], m["col_idx"])
     assert np.array_equal(rc["val"], m["vals"])
+
+
+@pytest.mark.parametrize("mode", [capi.MM_REFCOMPAT, capi.MM_STRICT])
+def test_binary_cache_roundtrip(tmp_path, mode):
+    src = os.path.join(GOLD, "mtx", "sym250_real.mtx")
+    cache = str(tmp_path / "m.cvrbin")
+    a = cvr_amd.load_mm(src, mode, cache=cache)           # parses the text, writes the image
+    assert os.path.exists(cache)
+    b = cvr_amd.load_mm("/nonexistent/ignored.mtx", mode, cache=cache)   # served from the image alone
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    with open(cache, "r+b") as f:                          # a damaged image is an error code, not a crash
+        f.write(b"garbage!")
+    with pytest.raises(cvr_amd.CvrError):
+        cvr_amd.load_mm(src, mode, cache=cache)
+
+
+def test_parallel_parse_matches_on_a_large_file(tmp_path):
+    """a file large enough to be cut into one text segment per thread: both loader modes against numpy"""
+    from cvr_amd import synth
+    n, nc, rp, ci, va = synth.web_google_like(scale=0.02)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    perm = np.random.default_rng(5).permutation(len(ci))  # file order shuffled: the loader has to sort
+    p = tmp_path / "big.mtx"
+    with open(p, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% comment\n")
+        f.write(f"{n} {nc} {len(ci)}\n")
+        f.write("".join(f"{rows[k] + 1} {ci[k] + 1} {va[k] + 0.25:.17g}\n" for k in perm))
+    assert os.path.getsize(p) > (1 << 16)
+    s = cvr_amd.load_mm(str(p), capi.MM_STRICT)
+    assert np.array_equal(s["row_ptr"], rp) and np.array_equal(s["col_idx"], ci) and np.array_equal(s["vals"], va + 0.25)
+    r = cvr_amd.load_mm(str(p), capi.MM_REFCOMPAT)
+    raw = len(ci)
+    assert r["ref_nItemsRaw"] == raw and r["ref_nItems"] % 16 == 0
+    # same entries 1-based, values through a float, plus zero-valued pad copies of the file's last entry (Q6)
+    npad, lc = r["ref_nItems"], int(ci[perm[-1]]) + 1
+    assert len(r["col_idx"]) == npad and r["row_ptr"][-1] == npad - 1      # Q9: tail row pointers = nItems - 1
+    exp_c = np.sort(np.concatenate([ci + 1, np.full(npad - raw, lc, dtype=np.int32)]))
+    exp_v = np.sort(np.concatenate([(va + 0.25).astype(np.float32).astype(np.float64), np.zeros(npad - raw)]))
+    assert np.array_equal(np.sort(r["col_idx"]), exp_c) and np.array_equal(np.sort(r["vals"]), exp_v)
+    # rows: the row pointers up to the last non-empty row reproduce the 1-based row counts
+    cnt = np.bincount(rows + 1, minlength=n + 2).astype(np.int64)
+    cnt[int(rows[perm[-1]]) + 1] += npad - raw
+    lastrow = int(np.nonzero(cnt)[0].max())
+    assert np.array_equal(r["row_ptr"][: lastrow + 1], np.concatenate([[0], np.cumsum(cnt)])[: lastrow + 1])

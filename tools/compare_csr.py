@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""tools/compare_csr.py [matrix] -- preprocessing-amortisation report (paper Eq. 1; Tables 1 and 4):
+    I_pre = T_pre(CVR) / (T_spmv(baseline) - T_spmv(CVR))
+with GPU-resident CSR baselines on the same device: a plain CSR-vector kernel and rocSPARSE (adaptive, rowsplit,
+LRB).  The paper's baseline is MKL's CSR on KNL (I_pre = 8.4 iterations on web-Google, Table 4).
+Comparators live in cvr_amd/libcvr_cmp.so; they are sanity comparators, not oracles."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cvr_amd
+import oraclelib as O
+from cvr_amd import synth
+
+L = C.CDLL(os.path.join(ROOT, "cvr_amd", "libcvr_cmp.so"))
+L.cmp_last_error.restype = C.c_char_p
+L.cmp_csr_create.argtypes = [C.POINTER(C.c_void_p), C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+L.cmp_csr_set_x.argtypes = [C.c_void_p, C.c_void_p]
+L.cmp_csr_get_y.argtypes = [C.c_void_p, C.c_void_p]
+L.cmp_csr_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+L.cmp_csr_destroy.argtypes = [C.c_void_p]
+KINDS = {0: "csr_vector (own)", 1: "rocsparse adaptive", 2: "rocsparse rowsplit"}
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "webgoogle"
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    if name == "webgoogle":
+        n, nc, rp, ci, va = synth.web_google_like()
+    elif name == "livejournal":
+        n, nc, rp, ci, va = synth.livejournal_like()
+    elif name.startswith("band"):
+        n, nc, rp, ci, va = synth.banded_sym(int(float(name[4:])))
+    elif name.startswith("rmat"):
+        n, nc, rp, ci, va = synth.rmat(int(name[4:]), dtype=np.float64)
+    else:
+        raise SystemExit("unknown matrix")
+    nnz = len(ci)
+    x = synth.x_rand(nc)
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    A = cvr_amd.CvrMatrix(n, nc, rp, ci, va)
+    y, _ = A.spmv(x)
+    assert len(O.tol_check(y, yref, absy)[0]) == 0
+    t_cvr = A.bench(20, iters)
+    t_pre = A.info.plan_s + A.info.convert_s
+    out = {"matrix": name, "rows": n, "nnz": nnz, "cvr": {"spmv_us": t_cvr * 1e6, "gflops": 2 * nnz / t_cvr / 1e9,
+           "preprocess_us": {"plan_host": A.info.plan_s * 1e6, "convert_device": A.info.convert_s * 1e6}}, "baselines": {}}
+    h = C.c_void_p()
+    rc = L.cmp_csr_create(C.byref(h), n, nc, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, 0, 0)
+    assert rc == 0, L.cmp_last_error()
+    L.cmp_csr_set_x(h, x.ctypes.data)
+    for kind, label in KINDS.items():
+        s, p = C.c_double(), C.c_double()
+        rc = L.cmp_csr_bench(h, kind, 20, iters, C.byref(s), C.byref(p))
+        if rc:
+            out["baselines"][label] = {"error": L.cmp_last_error().decode()}
+            continue
+        yb = np.zeros(n)
+        L.cmp_csr_get_y(h, yb.ctypes.data)
+        ok = len(O.tol_check(yb, yref, absy, tol=1e-11)[0]) == 0
+        gain = s.value - t_cvr
+        out["baselines"][label] = {"spmv_us": s.value * 1e6, "gflops": 2 * nnz / s.value / 1e9, "own_preprocess_us": p.value * 1e6,
+                                   "result_ok": ok, "cvr_speedup": s.value / t_cvr,
+                                   "I_pre_iterations": (t_pre / gain) if gain > 0 else None}
+    L.cmp_csr_destroy(h)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
