@@ -242,3 +242,31 @@ def test_banded_and_rmat_shapes():
     y2, _ = A.spmv(x)
     assert np.array_equal(y.view(np.uint32), y2.view(np.uint32))
     A.close()
+
+
+def test_degenerate_shapes():
+    """no rows, no columns, no non-zeros: handled by the boundary without touching the kernels' limits"""
+    A = cvr_amd.CvrMatrix(0, 5, np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0))
+    y, _ = A.spmv(np.ones(5))
+    assert len(y) == 0 and A.info.nchunks == 0
+    A.close()
+    A = cvr_amd.CvrMatrix(3, 0, np.zeros(4, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0))
+    y, _ = A.spmv(np.zeros(0))
+    assert np.array_equal(y, np.zeros(3))
+    A.close()
+
+
+def test_power_iteration_device_resident():
+    """the iterative caller (cvr_amd/power.py): y feeds x on the device; against the same loop in numpy"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    from cvr_amd import power
+    nrows, ncols, rp, ci, va = synth.web_google_like(scale=0.02)
+    va = np.abs(va) + 0.5                      # positive matrix: the dominant eigenpair is real and simple
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    lam, x, _ = power.power_iteration(A, nrows, iters=30)
+    lam_ref, x_ref = power.power_iteration_numpy(rp, ci, va, iters=30)
+    assert abs(lam - lam_ref) <= 1e-9 * abs(lam_ref)
+    assert np.allclose(x.cpu().numpy(), x_ref, rtol=0, atol=1e-9)
+    A.close()
