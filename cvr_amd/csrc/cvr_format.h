@@ -34,7 +34,7 @@ constexpr int      kGroupSteps   = 4;
 constexpr int      kColsBytes    = kLanes * 16;            // 1024
 constexpr int      kGroupBytes64 = kColsBytes + kLanes * 32;  // 3072
 constexpr int      kGroupBytes32 = kColsBytes + kLanes * 16;  // 2048
-constexpr int      kWavesPerBlock = 4;
+constexpr int      kWavesPerBlock = 1;   // measured: 1 wave per workgroup spreads the chunks most evenly over the CUs (profiles/r01_waves_per_block.log)
 
 inline int group_bytes(bool f32) { return f32 ? kGroupBytes32 : kGroupBytes64; }
 

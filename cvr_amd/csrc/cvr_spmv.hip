@@ -124,6 +124,10 @@ __device__ __forceinline__ uint32_t remap_block(uint32_t b, uint32_t nblocks_per
 }
 
 
+// y stores stay plain: nontemporal stores of these scattered 8-byte values doubled the kernel time
+// (profiles/r01_waves_per_block.log)
+template <typename T> __device__ __forceinline__ void store_y(T *p, T v) { *p = v; }
+
 // Wave-uniform and per-lane state of one chunk.
 template <typename T> struct ChunkState {
     T        acc;       // running sum of the lane's current segment
@@ -150,7 +154,7 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T> &Q, c
             if (!s.tail) {
                 if (fl) {
                     const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
-                    yext[dst] = s.acc;
+                    store_y(yext + dst, s.acc);
                     s.acc = 0;
                     const uint32_t nx = s.fed + lane_rank(m);
                     if (nx < nseg) s.cur = nx; else s.feeding = 0;   // rows exhausted: turns stealer
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (s.own) {
         const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
-        yext[dst] = *slot_lane;
+        store_y(yext + dst, *slot_lane);
     }
 }
 
