@@ -80,7 +80,7 @@ def _cpu_reference(nrows, ncols, rp, ci, cores):
     per = float(m.group(1))
     from cvr_amd import synth
     return {"value": 2.0 * len(ci) / per / 1e9, "unit": "GFLOP/s", "cores": T, "kind": "reference",
-            "sample": f"unmodified reference binary (g++ -O3 -mavx512f -fopenmp), {iters} timed SpMV iterations of the full matrix, "
+            "sample": f"unmodified reference source built by oracle/Makefile (g++ -O3 -mavx512f -fopenmp, 4 intrinsic-spelling aliases in oracle/ref_shim.h), {iters} timed SpMV iterations of the full matrix, "
                       f"{T} OpenMP threads, y zeroing outside the timer as the reference does (spmv.cpp:1026-1033)",
             "ms_per_step": per * 1e3, "preprocess_s": float(p.group(1)) if p else None,
             "gbs_alg": synth.b_alg(nrows, ncols, len(ci)) / per / 1e9}
