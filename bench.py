@@ -39,9 +39,15 @@ def pmc_traffic():
         return None
 
 
-def load_workload():
+def load_workload(kind="webgoogle"):
     from cvr_amd import capi, synth
     import cvr_amd
+    if kind == "livejournal":      # BASELINE.json configs[2]
+        n, nc, rp, ci, va = synth.livejournal_like()
+        return n, nc, rp, ci, va, "synthetic soc-LiveJournal1-shaped, seed 20261003"
+    if kind.startswith("banded"):  # configs[3]: nlpkkt240's shape; banded<rows>, default 28e6 rows / 8
+        n, nc, rp, ci, va = synth.banded_sym(int(float(kind[6:] or 3.5e6)))
+        return n, nc, rp, ci, va, "synthetic banded symmetric (27 nnz/row, nlpkkt240's shape)"
     f = synth.data_file("web-Google.mtx")
     if f:
         m = cvr_amd.load_mm(f, capi.MM_STRICT)
@@ -141,6 +147,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--steps-per-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="webgoogle", help="webgoogle (the headline, default) | livejournal | banded[<rows>]")
     args = ap.parse_args()
 
     import torch
@@ -168,7 +175,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    nrows, ncols, rp, ci, va, source = load_workload()
+    nrows, ncols, rp, ci, va, source = load_workload(args.workload)
     nnz = len(ci)
     bounds = shard.row_partition(rp, world)
     lrows, lrp, lci, lva = shard.local_csr(rp, ci, va, bounds, rank)
@@ -238,7 +245,7 @@ def main():
     if rank == 0:
         per = wall / args.steps
         out = {
-            "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64",
+            "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64" if args.workload == "webgoogle" else f"SpMV GFLOP/s (2*nnz/t), {args.workload} fp64",
             "value": 2.0 * nnz / per / 1e9,
             "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,7 +261,7 @@ def main():
                        "rows_cut_rank0": int(info.nshared),
                        "parallelism": "rows sharded, x replicated, y all-gathered (RCCL)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if world == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if world == 1 and args.workload == "webgoogle" else None,
                          "kernel": "cvr::spmv_kernel<double>", "kernel_us": kern_s * 1e6,
                          "algorithmic_bytes_per_launch": int(balg_local)},
             "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz) / per / 1e9,
