@@ -2,6 +2,7 @@
 // Host orchestration that the reference keeps in main() (allocation block spmv.cpp:1777-1829, calls at
 // spmv.cpp:1857 and 1882) lives behind the handle here; the caller keeps only CSR, x and y.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -34,6 +35,38 @@ int fail(int code, const char *fmt, ...)
         hipError_t e_ = (expr);                                                                             \
         if (e_ != hipSuccess) return fail(CVR_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+// roctx ranges around the phases of the path (the reference times them with microtime(), spmv.cpp:575/1009,
+// 1033/1656), visible with `rocprofv3 --marker-trace`.  The roctx library is only loaded when CVR_ROCTX=1:
+// linking it unconditionally costs every process seconds of profiler start-up.
+struct Range {
+    typedef int (*push_t)(const char *);
+    typedef int (*pop_t)(void);
+    static void resolve(push_t &push, pop_t &pop)
+    {
+        static push_t p = nullptr;
+        static pop_t  q = nullptr;
+        static bool   tried = false;
+        if (!tried) {
+            tried = true;
+            const char *e = getenv("CVR_ROCTX");
+            if (e && atoi(e)) {
+                void *lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+                if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+                if (lib) { p = (push_t)dlsym(lib, "roctxRangePushA"); q = (pop_t)dlsym(lib, "roctxRangePop"); }
+            }
+        }
+        push = p; pop = q;
+    }
+    pop_t pop_ = nullptr;
+    explicit Range(const char *name)
+    {
+        push_t push;
+        resolve(push, pop_);
+        if (push && pop_) push(name); else pop_ = nullptr;
+    }
+    ~Range() { if (pop_) pop_(); }
+};
 
 double now_s()
 {
@@ -144,6 +177,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
 {
     if (!out) return fail(CVR_ERR_INVALID, "out is null");
     *out = nullptr;
+    Range range("cvr_create (validate, plan, upload)");
     int rc = check_csr(csr);
     if (rc) return rc;
     cvr_options opt;
@@ -271,6 +305,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
 {
     if (!h) return fail(CVR_ERR_INVALID, "handle is null");
     if (!h->d_rp) return fail(CVR_ERR_STATE, "the device CSR was already released: cvr_preprocess runs once unless keep_csr was set");
+    Range range("cvr_preprocess (CSR -> CVR64)");
     HIP_TRY(hipSetDevice(h->device));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -371,6 +406,7 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
     if (!h || !x_host || !y_host) return fail(CVR_ERR_INVALID, "null argument");
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_spmv before cvr_preprocess");
     if (iters < 1) iters = 1;
+    Range range("cvr_spmv (h2d x, timed launches, d2h y)");
     HIP_TRY(hipSetDevice(h->device));
     const size_t need = (size_t)iters + 1;
     while (h->events.size() < need) {

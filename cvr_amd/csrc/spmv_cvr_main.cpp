@@ -115,7 +115,7 @@ int main(int argc, char **argv)
     // device vectors: x replicated; per GPU its y_ext; with G > 1 a gathered y of G * max_rows
     std::vector<double *>    dx((size_t)G), dy((size_t)G), dall((size_t)G, nullptr);
     std::vector<hipStream_t> st((size_t)G);
-    std::vector<hipEvent_t>  e0((size_t)G), e1((size_t)G), e2((size_t)G);
+    std::vector<hipEvent_t>  e0((size_t)G), e1((size_t)G);
     std::vector<ncclComm_t>  comm((size_t)G);
     for (int g = 0; g < G; g++) {
         HIP_OK(hipSetDevice(devs[(size_t)g]));
@@ -129,7 +129,6 @@ int main(int argc, char **argv)
         HIP_OK(hipStreamCreateWithFlags(&st[(size_t)g], hipStreamNonBlocking));
         HIP_OK(hipEventCreate(&e0[(size_t)g]));
         HIP_OK(hipEventCreate(&e1[(size_t)g]));
-        HIP_OK(hipEventCreate(&e2[(size_t)g]));
     }
     if (G > 1) NCCL_OK(ncclCommInitAll(comm.data(), G, devs.data()));
 

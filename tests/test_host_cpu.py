@@ -166,3 +166,15 @@ def test_parallel_parse_matches_on_a_large_file(tmp_path):
     cnt[int(rows[perm[-1]]) + 1] += npad - raw
     lastrow = int(np.nonzero(cnt)[0].max())
     assert np.array_equal(r["row_ptr"][: lastrow + 1], np.concatenate([[0], np.cumsum(cnt)])[: lastrow + 1])
+
+
+def test_host_sources_under_sanitizers():
+    """loader, planner and CSR loop under AddressSanitizer + UBSan over the golden files (make asan-check);
+    sanitizers run on the CPU build only -- the GPU pool offers none"""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "cvr_amd", "csrc"), "asan-check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 failure(s)" in r.stdout
