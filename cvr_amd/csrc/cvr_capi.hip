@@ -135,6 +135,8 @@ static int check_csr(const cvr_csr_view *c)
     if (!c || c->nrows < 0 || c->ncols < 0) return fail(CVR_ERR_INVALID, "null or negative-size CSR view");
     if (c->nrows > 0 && !c->row_ptr) return fail(CVR_ERR_INVALID, "row_ptr is null");
     if (c->ncols >= (int64_t)0x7fffffff) return fail(CVR_ERR_INVALID, "ncols must be < 2^31 - 1 (bit 31 of a column word is the segment-end flag)");
+    if ((uint64_t)(c->ncols + 1) * (c->is_f32 ? 4u : 8u) > 0xffffffffull)
+        return fail(CVR_ERR_INVALID, "x (%lld values) exceeds the 4 GiB a buffer descriptor addresses; shard the columns", (long long)c->ncols);
     if (c->nrows == 0) return CVR_OK;
     if (c->row_ptr[0] < 0) return fail(CVR_ERR_INVALID, "row_ptr[0] < 0");
     for (int64_t r = 0; r < c->nrows; r++)
