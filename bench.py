@@ -230,6 +230,17 @@ def main():
     e3.record(stream)
     torch.cuda.synchronize()
     kern_s = e2.elapsed_time(e3) * 1e-3 / args.steps
+    gather_s = None
+    if world > 1:                       # the exchange step alone, same message, same stream (reported beside the total)
+        e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            shard.all_gather_y(ybufs[0], max_rows, out=yalls[0])
+        e4.record(stream)
+        for _ in range(args.steps):
+            shard.all_gather_y(ybufs[0], max_rows, out=yalls[0])
+        e5.record(stream)
+        torch.cuda.synchronize()
+        gather_s = e4.elapsed_time(e5) * 1e-3 / args.steps
     lnnz = int(lrp[-1])
     balg_local = synth.b_alg(lrows, ncols, lnnz)
     achieved = balg_local / kern_s / 1e9
@@ -266,6 +277,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(balg_local)},
             "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz) / per / 1e9,
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
+            "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
             "preprocess": {"plan_s": info.plan_s, "upload_s": info.upload_s, "convert_s": info.convert_s},
             "verdict_wrong_rows": wrong,
         }

@@ -178,3 +178,33 @@ def test_host_sources_under_sanitizers():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "cvr_amd", "csrc"), "asan-check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 failure(s)" in r.stdout
+
+
+@pytest.mark.parametrize("kind", ["pattern symmetric", "real general", "real symmetric", "integer general"])
+def test_parallel_loader_equals_pinned_oracle_loader_on_large_files(tmp_path, kind):
+    """files large enough to be parsed in several text segments: the product loader (REFCOMPAT) against the oracle's
+    sequential restatement of readMatrix, which the golden fixtures pin to the unmodified reference"""
+    rng = np.random.default_rng(99)
+    field, sym = kind.split()
+    n, m = 3000, 40000
+    r = rng.integers(1, n + 1, size=m)
+    c = rng.integers(1, n + 1, size=m)
+    if sym == "symmetric":
+        r, c = np.maximum(r, c), np.minimum(r, c)      # lower triangle, with diagonal entries and duplicates
+    p = tmp_path / "big.mtx"
+    with open(p, "w") as f:
+        f.write(f"%%MatrixMarket matrix coordinate {field} {sym}\n% a comment line\n{n} {n} {m}\n")
+        for k in range(m):
+            if field == "pattern":
+                f.write(f"{r[k]} {c[k]}\n")
+            elif field == "integer":
+                f.write(f"{r[k]} {c[k]} {int(rng.integers(-50, 50))}\n")
+            else:
+                f.write(f"{r[k]} {c[k]} {rng.normal():.9g}\n")
+    assert os.path.getsize(p) > (1 << 16)
+    a = cvr_amd.load_mm(str(p), capi.MM_REFCOMPAT)
+    b = O.read_matrix(str(p))
+    assert (a["ref_nItems"], a["ref_nItemsRaw"], a["ref_numRows"]) == (b["nItems"], b["nItemsRaw"], b["numRows"])
+    assert np.array_equal(a["row_ptr"], b["rowptr"].astype(np.int64))
+    assert np.array_equal(a["col_idx"], b["cols"])
+    assert np.array_equal(a["vals"].view(np.uint64), b["val"].view(np.uint64))
