@@ -253,6 +253,13 @@ def main():
         yref = cvr_amd.csr_spmv_host(rp, ci, va, x[:ncols].cpu().numpy(), nthreads=len(os.sched_getaffinity(0)))
         wrong = int(cvr_amd.verdict(yh, yref, nrows))
 
+    copy_gbs = None
+    if rank == 0:
+        try:                      # achievable-HBM yardstick measured live: 1 GiB streaming copy, read + write
+            from cvr_amd import capi
+            copy_gbs = capi.device_copy_gbs(local_rank, 1 << 30, 20)
+        except Exception:
+            copy_gbs = None
     if rank == 0:
         per = wall / args.steps
         out = {
@@ -274,6 +281,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if world == 1 and args.workload == "webgoogle" else None,
                          "kernel": "cvr::spmv_kernel<double>", "kernel_us": kern_s * 1e6,
+                         "copy_kernel_gbs": copy_gbs, "frac_of_copy_kernel": achieved / copy_gbs if copy_gbs else None,
                          "algorithmic_bytes_per_launch": int(balg_local)},
             "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz) / per / 1e9,
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,

@@ -51,7 +51,7 @@ class MmMatrix(C.Structure):
 # every symbol include/cvr_amd.h declares (tests check the library exports all of them)
 SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_count", "cvr_create", "cvr_preprocess",
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
-           "cvr_spmv_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
+           "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict"]
 
 
@@ -81,6 +81,7 @@ def lib():
             getattr(L, f).restype = C.c_void_p
         L.cvr_spmv_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.cvr_export_image.argtypes = [C.c_void_p] * 5
+        L.cvr_device_copy_bench.argtypes = [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)]
         L.cvr_plan_bound.argtypes = [C.c_int64, C.c_int64, C.c_int32]
         L.cvr_plan_bound.restype = C.c_int64
         L.cvr_plan_chunks.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 4
@@ -107,6 +108,15 @@ def version():
 
 def device_count():
     return lib().cvr_device_count()
+
+
+def device_copy_gbs(device=0, nbytes=1 << 30, iters=20):
+    """measured read+write rate of a streaming copy kernel (GB/s): the achievable-HBM yardstick"""
+    g = C.c_double()
+    rc = lib().cvr_device_copy_bench(device, nbytes, iters, C.byref(g))
+    if rc:
+        raise CvrError(rc, "cvr_device_copy_bench")
+    return g.value
 
 
 def load_mm(path, mode=MM_REFCOMPAT, cache=None):

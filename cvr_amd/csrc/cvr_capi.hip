@@ -448,6 +448,32 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
     return CVR_OK;
 }
 
+int cvr_device_copy_bench(int device, int64_t bytes, int iters, double *gbs)
+{
+    if (bytes < 16 || iters < 1) return fail(CVR_ERR_INVALID, "bad argument");
+    if (device < 0 || device >= cvr_device_count()) return fail(CVR_ERR_NO_DEVICE, "device %d not available", device);
+    HIP_TRY(hipSetDevice(device));
+    void       *a = nullptr, *b = nullptr;
+    hipStream_t st;
+    hipEvent_t  e0, e1;
+    HIP_TRY(hipMalloc(&a, (size_t)bytes));
+    HIP_TRY(hipMalloc(&b, (size_t)bytes));
+    HIP_TRY(hipStreamCreate(&st));
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipMemsetAsync(a, 1, (size_t)bytes, st));
+    for (int i = 0; i < 3; i++) HIP_TRY(cvr::launch_copy(a, b, (size_t)bytes, st));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; i++) HIP_TRY(cvr::launch_copy(a, b, (size_t)bytes, st));
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (gbs) *gbs = 2.0 * (double)(bytes / 16 * 16) * iters / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); (void)hipFree(a); (void)hipFree(b);
+    return CVR_OK;
+}
+
 int cvr_export_image(cvr_handle *h, void *stream_image, uint32_t *desc, uint8_t *target, int64_t *shared)
 {
     if (!h) return fail(CVR_ERR_INVALID, "handle is null");

@@ -47,4 +47,7 @@ hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream
 // y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0)
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st);
 
+// 16-B-per-lane streaming copy (roofline calibration)
+hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st);
+
 }  // namespace cvr

@@ -7,6 +7,7 @@
 // through the C ABI of include/cvr_amd.h.  nThreads keeps its meaning for the host side (the CSR self-check
 // loop).  Everything else is selected by environment variables so that the CLI stays drop-in:
 //     CVR_DEVICES=0,1,..  GPUs to shard the rows over (default 0); x replicated, y all-gathered by RCCL
+//                         (the same GPU listed several times: same sharding, slices moved by D2D copies)
 //     CVR_X=ones|rand     x = 1.0 as the reference (spmv.cpp:556-563) or the seeded non-constant x
 //     CVR_MM=refcompat|strict   loader mode (default refcompat = the reference loader's arrays)
 //     CVR_S=<steps>       lane-stream length per chunk (default: chosen from the matrix size)
@@ -130,14 +131,28 @@ int main(int argc, char **argv)
         HIP_OK(hipEventCreate(&e0[(size_t)g]));
         HIP_OK(hipEventCreate(&e1[(size_t)g]));
     }
-    if (G > 1) NCCL_OK(ncclCommInitAll(comm.data(), G, devs.data()));
+    // RCCL needs distinct devices.  CVR_DEVICES=0,0,.. (the same GPU listed several times) keeps the sharding, the
+    // per-shard handles and the gather layout but moves the slices with device-to-device copies: a plumbing check
+    // of the multi-GPU path on a 1-GPU box.
+    bool distinct = true;
+    for (int a = 0; a < G; a++) for (int b2 = a + 1; b2 < G; b2++) if (devs[(size_t)a] == devs[(size_t)b2]) distinct = false;
+    const bool use_rccl = G > 1 && distinct;
+    if (use_rccl) NCCL_OK(ncclCommInitAll(comm.data(), G, devs.data()));
 
     auto spmv_all = [&](bool gather) -> int {
         for (int g = 0; g < G; g++) {
             HIP_OK(hipSetDevice(devs[(size_t)g]));
             CVR_OKAY(cvr_spmv_device(H[(size_t)g], dx[(size_t)g], dy[(size_t)g], st[(size_t)g]));   // spmv.cpp:1882
         }
-        if (gather && G > 1) {
+        if (gather && G > 1 && !use_rccl) {
+            for (int g = 0; g < G; g++) {          // every "rank" receives every slice, as the all-gather would deliver
+                HIP_OK(hipSetDevice(devs[(size_t)g]));
+                for (int src = 0; src < G; src++)
+                    HIP_OK(hipMemcpyAsync(dall[(size_t)g] + (size_t)src * (size_t)max_rows, dy[(size_t)src], sizeof(double) * (size_t)max_rows,
+                                          hipMemcpyDeviceToDevice, st[(size_t)src]));
+            }
+        }
+        if (gather && use_rccl) {
             NCCL_OK(ncclGroupStart());
             for (int g = 0; g < G; g++)
                 NCCL_OK(ncclAllGather(dy[(size_t)g], dall[(size_t)g], (size_t)max_rows, ncclDouble, comm[(size_t)g], st[(size_t)g]));
@@ -195,7 +210,7 @@ int main(int argc, char **argv)
 
     for (int g = 0; g < G; g++) {
         (void)hipSetDevice(devs[(size_t)g]);
-        if (G > 1) ncclCommDestroy(comm[(size_t)g]);
+        if (use_rccl) ncclCommDestroy(comm[(size_t)g]);
         (void)hipFree(dx[(size_t)g]); (void)hipFree(dy[(size_t)g]);
         if (dall[(size_t)g]) (void)hipFree(dall[(size_t)g]);
         cvr_destroy(H[(size_t)g]);

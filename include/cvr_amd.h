@@ -127,6 +127,10 @@ void *cvr_stream(cvr_handle *h);
  * returns mean seconds per launch.  No host copies.  (bench.py's roofline leg) */
 int cvr_spmv_bench(cvr_handle *h, int warmup, int iters, double *mean_s);
 
+/* Calibration for the roofline: a 16-byte-per-lane copy kernel over `bytes` of device memory (read
+ * `bytes`, write `bytes`); returns the mean read+write rate in GB/s over `iters` launches on `device`. */
+int cvr_device_copy_bench(int device, int64_t bytes, int iters, double *gbs);
+
 /* Copies the device-resident CVR64 image back for inspection (tests compare it bit for bit with the
  * CPU mirror).  Any pointer may be NULL.  Sizes: cols_vals = image_bytes of the stream part
  * (nchunks * S/4 * group_bytes), desc = 4 u32 per chunk, target = 64 u8 per chunk,

@@ -217,6 +217,11 @@ def test_cli_prints_the_reference_lines():
         assert re.search(r"^         The Throughput of CVR    is \S+ GFlops\.    \[file: " + f + r"\] \[threads: 2\]$", out, re.M)
         assert "     Very Good! Your result is correct  " in out
         assert '"wrong":0' in out
+    # the sharded path on one GPU: three row shards, x replicated, slices gathered (D2D copies stand in for RCCL)
+    mtx = os.path.join(GOLD, "mtx", "pl2000_pattern.mtx")
+    r = subprocess.run([exe, mtx, "2", "5"], capture_output=True, text=True, timeout=120, env=dict(os.environ, CVR_DEVICES="0,0,0", CVR_X="rand"))
+    assert r.returncode == 0, r.stderr
+    assert "Very Good! Your result is correct" in r.stdout and '"gpus":3' in r.stdout and '"wrong":0' in r.stdout
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "usage" in r.stderr
     r = subprocess.run([exe, "/nonexistent.mtx", "1", "1"], capture_output=True, text=True, timeout=60)

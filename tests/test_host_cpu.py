@@ -208,3 +208,18 @@ def test_parallel_loader_equals_pinned_oracle_loader_on_large_files(tmp_path, ki
     assert np.array_equal(a["row_ptr"], b["rowptr"].astype(np.int64))
     assert np.array_equal(a["col_idx"], b["cols"])
     assert np.array_equal(a["vals"].view(np.uint64), b["val"].view(np.uint64))
+
+
+def test_size_limits_are_rejected_with_a_message():
+    """the format's limits (bit 31 of a column word is the segment-end flag; x is addressed through a 32-bit buffer
+    descriptor) are error codes at cvr_create, before any device work"""
+    rp = np.array([0, 1], dtype=np.int64)
+    with pytest.raises(cvr_amd.CvrError) as e:
+        cvr_amd.CvrMatrix(1, 2**31 - 1, rp, np.zeros(1, dtype=np.int32), np.ones(1))
+    assert e.value.code == capi.ERR_INVALID and "2^31" in str(e.value)
+    with pytest.raises(cvr_amd.CvrError) as e:
+        cvr_amd.CvrMatrix(1, 600_000_000, rp, np.zeros(1, dtype=np.int32), np.ones(1))      # 4.8 GB of fp64 x
+    assert e.value.code == capi.ERR_INVALID and "4 GiB" in str(e.value)
+    with pytest.raises(cvr_amd.CvrError) as e:
+        cvr_amd.CvrMatrix(1, 8, rp, np.zeros(1, dtype=np.int32), np.ones(1), steps_per_chunk=6)
+    assert e.value.code in (capi.ERR_INVALID, capi.ERR_NO_DEVICE)
