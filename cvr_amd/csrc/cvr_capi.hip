@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/cvr_amd.h"
@@ -75,11 +77,9 @@ double now_s()
 
 }  // namespace
 
-struct cvr_handle {
-    int              device = 0;
-    hipStream_t      stream = nullptr;
-    bool             converted = false;
-    cvr_info         info{};
+// One CVR64 image on the device: the whole matrix, or one column panel of it (rows compacted to those that
+// have a non-zero in the panel).
+struct Part {
     cvr::DeviceImage img{};
     // device CSR + plan (dropped after conversion unless keep_csr)
     int64_t  *d_rp = nullptr;
@@ -87,12 +87,9 @@ struct cvr_handle {
     void     *d_va = nullptr;
     int64_t  *d_nzb = nullptr;
     uint32_t *d_pad = nullptr;
-    uint32_t *d_err = nullptr;
-    void     *d_x = nullptr;   // x_ext: ncols + 1
-    void     *d_y = nullptr;   // y_ext
-    size_t    vsz = 8;
     size_t    stream_bytes = 0;
-    std::vector<hipEvent_t> events;
+    int64_t   nrows = 0, nnz = 0, nchunks = 0, nshared = 0, yext = 0;
+    int64_t   zoff = 0;        // panels: where this part's y_ext starts in the partial-sum buffer z
 
     void release_csr()
     {
@@ -103,7 +100,50 @@ struct cvr_handle {
         if (d_pad) (void)hipFree(d_pad);
         d_rp = nullptr; d_ci = nullptr; d_va = nullptr; d_nzb = nullptr; d_pad = nullptr;
     }
+    void release_all()
+    {
+        release_csr();
+        if (img.stream) (void)hipFree(img.stream);
+        if (img.desc) (void)hipFree(img.desc);
+        if (img.target) (void)hipFree(img.target);
+        if (img.shared) (void)hipFree(img.shared);
+        if (img.win_base) (void)hipFree(img.win_base);
+        img = cvr::DeviceImage{};
+    }
 };
+
+struct cvr_handle {
+    int               device = 0;
+    hipStream_t       stream = nullptr;
+    bool              converted = false;
+    cvr_info          info{};
+    std::vector<Part> parts;            // 1 part, or one per column panel
+    // column panels: y[r] = sum over the panels that hold row r of z[cmb_idx[k]], k in cmb_ptr[r] .. cmb_ptr[r+1]
+    void     *d_z = nullptr;
+    uint32_t *d_cmb_ptr = nullptr, *d_cmb_idx = nullptr;
+    uint32_t *d_err = nullptr;
+    void     *d_x = nullptr;            // x_ext: ncols + 1
+    void     *d_y = nullptr;            // y_ext (1 part) or y (panels)
+    size_t    vsz = 8;
+    std::vector<hipEvent_t> events;
+
+    bool paneled() const { return parts.size() > 1; }
+};
+
+namespace {
+
+// y_ext = A x for the whole handle on `st`: one SpMV launch, or one per column panel followed by the combine
+hipError_t run_spmv(const cvr_handle *h, const void *x, void *y, hipStream_t st)
+{
+    if (!h->paneled()) return h->parts.empty() ? hipSuccess : cvr::launch_spmv(h->parts[0].img, x, y, st);
+    for (const Part &p : h->parts) {
+        hipError_t e = cvr::launch_spmv(p.img, x, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * h->vsz, st);
+        if (e != hipSuccess) return e;
+    }
+    return cvr::launch_combine(h->d_cmb_ptr, h->d_cmb_idx, h->d_z, y, (uint32_t)h->info.nrows, h->vsz == 4, st);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -119,6 +159,7 @@ void cvr_default_options(cvr_options *o)
     o->split_threshold = 0;
     o->xcd_swizzle = -1;
     o->x_window = -1;
+    o->col_panels = -1;
 }
 
 int cvr_device_count(void)
@@ -167,50 +208,30 @@ int64_t cvr_plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_
 
 static int pick_steps(int64_t nslots_est)
 {
-    // the longest lane streams (fewest per-chunk prologues, fewest cut rows) that still leave >= 8 wavefronts
-    // for every one of the 256 CUs: S = 32 for web-Google (2.6 k chunks), 128 for soc-LiveJournal1
-    const int64_t want_chunks = 256 * 8;
-    int           S = 128;
-    while (S > 16 && nslots_est / (64 * (int64_t)S) < want_chunks) S /= 2;
-    return S;
+    // S = 32 (2 048-slot chunks, 24.6-KB stream per wavefront) unless that leaves fewer than 8 wavefronts per CU.
+    // Measured: web-Google S = 8..48 within 2 % (profiles/r01_steps_threshold_depth_sweep.log); LiveJournal shape
+    // S = 16/32 800 us vs S = 128 856 us; banded S = 32..128 within noise (profiles/r01_steps_large_matrices.log).
+    return nslots_est / (64 * 32) >= 256 * 8 ? 32 : 16;
 }
 
-int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt_in)
+// plans one part on the host, allocates its device image and uploads its CSR (asynchronously on h->stream)
+static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
+                      bool f32, const cvr_options &opt, double *plan_s)
 {
-    if (!out) return fail(CVR_ERR_INVALID, "out is null");
-    *out = nullptr;
-    Range range("cvr_create (validate, plan, upload)");
-    int rc = check_csr(csr);
-    if (rc) return rc;
-    cvr_options opt;
-    if (opt_in) opt = *opt_in; else cvr_default_options(&opt);
-    const int ndev = cvr_device_count();
-    if (ndev <= 0) return fail(CVR_ERR_NO_DEVICE, "no HIP device visible: libcvr_amd has no CPU fallback");
-    if (opt.device < 0 || opt.device >= ndev) return fail(CVR_ERR_NO_DEVICE, "device %d out of range [0, %d)", opt.device, ndev);
-
-    const int64_t nrows = csr->nrows, ncols = csr->ncols;
-    const int64_t nz0 = nrows ? csr->row_ptr[0] : 0, nz1 = nrows ? csr->row_ptr[nrows] : 0;
-    int S = opt.steps_per_chunk;
+    const int64_t nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
+    int           S = opt.steps_per_chunk;
     if (S == 0) S = pick_steps(nz1 - nz0 + nrows / 4);
-    if (S < 4 || S % 4 || S > 4096) return fail(CVR_ERR_INVALID, "steps_per_chunk must be a multiple of 4 in [4, 4096]");
-
-    cvr_handle *h = new (std::nothrow) cvr_handle;
-    if (!h) return fail(CVR_ERR_NOMEM, "out of host memory");
-    h->device = opt.device;
-    h->vsz = csr->is_f32 ? 4 : 8;
-
     const double    t0 = now_s();
-    const cvr::Plan plan = cvr::plan_chunks(nrows, csr->row_ptr, S, opt.split_threshold);
+    const cvr::Plan plan = cvr::plan_chunks(nrows, rp, S, opt.split_threshold);
     const int64_t   nchunks = (int64_t)plan.chunks.size();
     const int64_t   yext = nrows + 1 + 2 * nchunks;
-    if (yext >= (int64_t)0xffffffffu || nchunks >= (int64_t)0x7fffffff) { delete h; return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU"); }
+    if (yext >= (int64_t)0xffffffffu || nchunks >= (int64_t)0x7fffffff) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
     std::vector<uint32_t> desc((size_t)nchunks * 4), pad((size_t)nchunks);
     std::vector<int64_t>  nzb((size_t)nchunks + 1);
     for (int64_t k = 0; k < nchunks; k++) {
         const cvr::Chunk &c = plan.chunks[(size_t)k];
-        const uint32_t    rf = (uint32_t)c.row_first, ns = (uint32_t)c.nseg;
-        desc[4 * k + 0] = rf;
-        desc[4 * k + 1] = ns;
+        desc[4 * k + 0] = (uint32_t)c.row_first;
+        desc[4 * k + 1] = (uint32_t)c.nseg;
         // where segment q writes: a row begun earlier -> carry_head(k); a row continued later -> carry_tail(k);
         // the pad segment -> dump; else its row.  head_dest / last_dest are that rule at q = 0 and q = nseg-1.
         auto dest = [&](int64_t q) -> uint32_t {
@@ -225,18 +246,13 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
         nzb[(size_t)k] = c.nz_begin;
     }
     nzb[(size_t)nchunks] = plan.nz_end;
-    const double t1 = now_s();
+    if (plan_s) *plan_s += now_s() - t0;
 
-    cvr_info &in = h->info;
-    in.nrows = nrows; in.ncols = ncols; in.nnz = nz1 - nz0; in.is_f32 = csr->is_f32 ? 1 : 0; in.steps_per_chunk = S;
-    in.nchunks = nchunks; in.nslots = nchunks * 64 * S; in.nshared = (int64_t)plan.shared.size();
-    in.yext_elems = yext; in.x_elems = ncols + 1; in.plan_s = t1 - t0;
+    part.nrows = nrows; part.nnz = nz1 - nz0; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
     const int G = S / 4;
-    h->stream_bytes = (size_t)nchunks * G * cvr::group_bytes(csr->is_f32 != 0);
-    in.image_bytes = (int64_t)(h->stream_bytes + (size_t)nchunks * (16 + 64) + plan.shared.size() * 24);
-
-    cvr::DeviceImage &img = h->img;
-    img.S = S; img.G = G; img.f32 = csr->is_f32 != 0; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
+    part.stream_bytes = (size_t)nchunks * G * cvr::group_bytes(f32);
+    cvr::DeviceImage &img = part.img;
+    img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
     img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)plan.shared.size();
     img.xcd_swizzle = opt.xcd_swizzle != 0;
     img.stream_policy = opt.stream_policy > 0 ? opt.stream_policy : 0;
@@ -251,7 +267,175 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     img.win_elems = (uint32_t)win;
     if (opt.debug_col_mask) img.col_mask = (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
 
-#define HIP_TRY_H(expr)                                                                                     \
+    const size_t vsz = f32 ? 4 : 8, nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
+    HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
+    HIP_TRY(hipMalloc(&part.d_ci, sizeof(int32_t) * std::max<size_t>(nnz_span, 1)));
+    HIP_TRY(hipMalloc(&part.d_va, vsz * std::max<size_t>(nnz_span, 1)));
+    HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nchunks + 1)));
+    HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nchunks, 1)));
+    if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
+        HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, std::max<size_t>(part.stream_bytes, 16), hipDeviceMallocUncached));
+    else
+        HIP_TRY(hipMalloc(&img.stream, std::max<size_t>(part.stream_bytes, 16)));
+    HIP_TRY(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
+    HIP_TRY(hipMalloc(&img.target, 64 * std::max<size_t>((size_t)nchunks, 1)));
+    HIP_TRY(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
+    HIP_TRY(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)nchunks / cvr::kWavesPerBlock + 1)));
+    HIP_TRY(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / cvr::kWavesPerBlock + 1), h->stream));
+    if (nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
+    if (nnz_span) {
+        HIP_TRY(hipMemcpyAsync(part.d_ci, ci, sizeof(int32_t) * nnz_span, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(part.d_va, va, vsz * nnz_span, hipMemcpyHostToDevice, h->stream));
+    }
+    if (nchunks) {
+        HIP_TRY(hipMemcpyAsync(part.d_nzb, nzb.data(), sizeof(int64_t) * nzb.size(), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(part.d_pad, pad.data(), sizeof(uint32_t) * pad.size(), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(img.desc, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, h->stream));
+    }
+    if (!plan.shared.empty())
+        HIP_TRY(hipMemcpyAsync(img.shared, plan.shared.data(), sizeof(cvr::Shared) * plan.shared.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the host staging vectors go out of scope; the caller may free its CSR
+    return CVR_OK;
+}
+
+// Column panels (the remedy when x outgrows the L2s).  The columns are cut into P ranges of
+// equal width; panel p keeps, for every row that has a non-zero in its range, that row's entries of the
+// range (rows compacted, order inside a row kept).  cmb_ptr / cmb_idx list, for every row, where its partial sums
+// will stand in the concatenated y_ext buffers of the panels.
+}  // extern "C"
+
+// host arrays without value-initialisation (hundreds of MB: a zero-fill pass per array is measurable)
+template <typename T> struct Raw {
+    std::unique_ptr<T[]> p;
+    size_t               n = 0;
+    void     alloc(size_t m) { p.reset(new T[m ? m : 1]); n = m; }
+    T       *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+    size_t   size() const { return n; }
+    T       &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
+struct PanelSplit {
+    std::vector<Raw<int64_t>>  rp;
+    std::vector<Raw<int32_t>>  ci;
+    std::vector<Raw<uint64_t>> va;     // values as raw 8-byte words (fp32: two per word)
+    std::vector<Raw<uint32_t>> rows;   // compact sub-row -> row
+};
+
+// A parallel counting sort of the non-zeros by panel: row blocks are counted, then filled, by T host threads.
+template <typename V>
+static void split_panels_t(const cvr_csr_view &v, int P, PanelSplit &out)
+{
+    const int64_t nrows = v.nrows, ncols = v.ncols, nz0 = nrows ? v.row_ptr[0] : 0, nz1 = nrows ? v.row_ptr[nrows] : 0;
+    const V      *vals = static_cast<const V *>(v.vals);
+    // panels are column ranges of equal width: what has to fit the L2 is the panel's slice of x, and the panels run
+    // one after the other on the whole GPU, so their non-zero counts need not balance
+    const int64_t width = (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1;
+    auto          panel_of_col = [width](int32_t c) { return (int)(c / width); };
+    int T = (int)std::thread::hardware_concurrency();
+    if (T > 32) T = 32;
+    if (T < 1 || nz1 - nz0 < (1 << 20)) T = 1;
+    std::vector<int64_t> lo((size_t)T + 1);
+    for (int t = 0; t <= T; t++) lo[(size_t)t] = nrows * t / T;
+    // counts per (thread, panel): non-zeros and sub-rows
+    std::vector<int64_t> cn((size_t)T * P, 0), cr((size_t)T * P, 0);
+    auto count = [&](int t) {
+        std::vector<int64_t> last((size_t)P, -1);
+        for (int64_t r = lo[(size_t)t]; r < lo[(size_t)t + 1]; r++)
+            for (int64_t j = v.row_ptr[r]; j < v.row_ptr[r + 1]; j++) {
+                const int p = panel_of_col(v.col_idx[j]);
+                cn[(size_t)t * P + p]++;
+                if (last[(size_t)p] != r) { last[(size_t)p] = r; cr[(size_t)t * P + p]++; }
+            }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(count, t);
+        count(0);
+        for (auto &x : th) x.join();
+    }
+    out.rp.resize((size_t)P); out.ci.resize((size_t)P); out.va.resize((size_t)P); out.rows.resize((size_t)P);
+    std::vector<int64_t> on((size_t)T * P), orow((size_t)T * P);
+    for (int p = 0; p < P; p++) {
+        int64_t an = 0, ar = 0;
+        for (int t = 0; t < T; t++) { on[(size_t)t * P + p] = an; orow[(size_t)t * P + p] = ar; an += cn[(size_t)t * P + p]; ar += cr[(size_t)t * P + p]; }
+        out.ci[(size_t)p].alloc((size_t)an);
+        out.va[(size_t)p].alloc((size_t)((an * (int64_t)sizeof(V) + 7) / 8));
+        out.rows[(size_t)p].alloc((size_t)ar);
+        out.rp[(size_t)p].alloc((size_t)ar + 1);
+        out.rp[(size_t)p][(size_t)ar] = an;
+    }
+    auto fill = [&](int t) {
+        std::vector<int64_t> last((size_t)P, -1), pn((size_t)P), pr((size_t)P);
+        for (int p = 0; p < P; p++) { pn[(size_t)p] = on[(size_t)t * P + p]; pr[(size_t)p] = orow[(size_t)t * P + p]; }
+        for (int64_t r = lo[(size_t)t]; r < lo[(size_t)t + 1]; r++)
+            for (int64_t j = v.row_ptr[r]; j < v.row_ptr[r + 1]; j++) {
+                const int p = panel_of_col(v.col_idx[j]);
+                if (last[(size_t)p] != r) {
+                    last[(size_t)p] = r;
+                    out.rows[(size_t)p][(size_t)pr[(size_t)p]] = (uint32_t)r;
+                    out.rp[(size_t)p][(size_t)pr[(size_t)p]] = pn[(size_t)p];
+                    pr[(size_t)p]++;
+                }
+                out.ci[(size_t)p][(size_t)pn[(size_t)p]] = v.col_idx[j];
+                reinterpret_cast<V *>(out.va[(size_t)p].data())[pn[(size_t)p]] = vals[j];
+                pn[(size_t)p]++;
+            }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(fill, t);
+        fill(0);
+        for (auto &x : th) x.join();
+    }
+}
+
+static void split_panels(const cvr_csr_view &v, int P, PanelSplit &out)
+{
+    if (v.is_f32) split_panels_t<float>(v, P, out); else split_panels_t<double>(v, P, out);
+}
+
+extern "C" {
+
+int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt_in)
+{
+    if (!out) return fail(CVR_ERR_INVALID, "out is null");
+    *out = nullptr;
+    Range range("cvr_create (validate, plan, upload)");
+    int rc = check_csr(csr);
+    if (rc) return rc;
+    cvr_options opt;
+    if (opt_in) opt = *opt_in; else cvr_default_options(&opt);
+    const int ndev = cvr_device_count();
+    if (ndev <= 0) return fail(CVR_ERR_NO_DEVICE, "no HIP device visible: libcvr_amd has no CPU fallback");
+    if (opt.device < 0 || opt.device >= ndev) return fail(CVR_ERR_NO_DEVICE, "device %d out of range [0, %d)", opt.device, ndev);
+    if (opt.steps_per_chunk != 0 && (opt.steps_per_chunk < 4 || opt.steps_per_chunk % 4 || opt.steps_per_chunk > 4096))
+        return fail(CVR_ERR_INVALID, "steps_per_chunk must be a multiple of 4 in [4, 4096]");
+
+    const int64_t nrows = csr->nrows, ncols = csr->ncols;
+    const bool    f32 = csr->is_f32 != 0;
+    const size_t  vsz = f32 ? 4 : 8;
+    // column panels: asked for, or (col_panels < 0: auto) when x is several times the 4-MiB L2 of an XCD, one panel per
+    // ~4.5 MB of x (profiles/r01_column_panel_probe_livejournal.log); never for matrices whose x nearly fits
+    // (web-Google: profiles/r01_column_panel_probe.log)
+    int P = opt.col_panels;
+    if (P < 0) {
+        const double xb = (double)ncols * (double)vsz;
+        P = xb >= 24e6 ? (int)(xb / 4.5e6 + 0.5) : 1;
+    }
+    if (P < 1) P = 1;
+    if (P > 64) P = 64;
+    if (nrows >= (int64_t)0xfffffff0u) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
+
+    cvr_handle *h = new (std::nothrow) cvr_handle;
+    if (!h) return fail(CVR_ERR_NOMEM, "out of host memory");
+    h->device = opt.device;
+    h->vsz = vsz;
+    cvr_info &in = h->info;
+    in.nrows = nrows; in.ncols = ncols; in.nnz = nrows ? csr->row_ptr[nrows] - csr->row_ptr[0] : 0; in.is_f32 = f32 ? 1 : 0;
+    in.x_elems = ncols + 1; in.col_panels = P;
+#define CREATE_TRY(expr)                                                                                    \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
         if (e_ != hipSuccess) {                                                                             \
@@ -260,45 +444,64 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
             return CVR_ERR_HIP;                                                                             \
         }                                                                                                   \
     } while (0)
-    HIP_TRY_H(hipSetDevice(h->device));
-    HIP_TRY_H(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    const size_t nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
-    HIP_TRY_H(hipMalloc(&h->d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
-    HIP_TRY_H(hipMalloc(&h->d_ci, sizeof(int32_t) * std::max<size_t>(nnz_span, 1)));
-    HIP_TRY_H(hipMalloc(&h->d_va, h->vsz * std::max<size_t>(nnz_span, 1)));
-    HIP_TRY_H(hipMalloc(&h->d_nzb, sizeof(int64_t) * ((size_t)nchunks + 1)));
-    HIP_TRY_H(hipMalloc(&h->d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nchunks, 1)));
-    HIP_TRY_H(hipMalloc(&h->d_err, sizeof(uint32_t)));
-    if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
-        HIP_TRY_H(hipExtMallocWithFlags((void **)&img.stream, std::max<size_t>(h->stream_bytes, 16), hipDeviceMallocUncached));
-    else
-        HIP_TRY_H(hipMalloc(&img.stream, std::max<size_t>(h->stream_bytes, 16)));
-    HIP_TRY_H(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
-    HIP_TRY_H(hipMalloc(&img.target, 64 * std::max<size_t>((size_t)nchunks, 1)));
-    HIP_TRY_H(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
-    HIP_TRY_H(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)nchunks / cvr::kWavesPerBlock + 1)));
-    HIP_TRY_H(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / cvr::kWavesPerBlock + 1), h->stream));
-    HIP_TRY_H(hipMalloc(&h->d_x, h->vsz * (size_t)in.x_elems));
-    HIP_TRY_H(hipMalloc(&h->d_y, h->vsz * (size_t)in.yext_elems));
-    HIP_TRY_H(hipMemsetAsync(h->d_x, 0, h->vsz * (size_t)in.x_elems, h->stream));
-    HIP_TRY_H(hipMemsetAsync(h->d_y, 0, h->vsz * (size_t)in.yext_elems, h->stream));
-    HIP_TRY_H(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
-    const double t2 = now_s();
-    if (nrows > 0) HIP_TRY_H(hipMemcpyAsync(h->d_rp, csr->row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
-    if (nnz_span) {
-        HIP_TRY_H(hipMemcpyAsync(h->d_ci, csr->col_idx, sizeof(int32_t) * nnz_span, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY_H(hipMemcpyAsync(h->d_va, csr->vals, h->vsz * nnz_span, hipMemcpyHostToDevice, h->stream));
+    CREATE_TRY(hipSetDevice(h->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const double t_up0 = now_s();
+    h->parts.resize((size_t)P);
+    if (P == 1) {
+        rc = build_part(h, h->parts[0], nrows, ncols, csr->row_ptr, csr->col_idx, csr->vals, f32, opt, &in.plan_s);
+        if (rc) { cvr_destroy(h); return rc; }
+        in.yext_elems = h->parts[0].yext;
+    } else {
+        const double t0 = now_s();
+        PanelSplit   sp;
+        split_panels(*csr, P, sp);
+        // where row r's partial sums stand: part p's y_ext starts at zoff[p]; compact sub-row u of part p is row rows[p][u]
+        std::vector<uint32_t> cmb_ptr((size_t)nrows + 1, 0);
+        for (int p = 0; p < P; p++) for (size_t u = 0; u < sp.rows[(size_t)p].size(); u++) cmb_ptr[(size_t)sp.rows[(size_t)p][u] + 1]++;
+        for (int64_t r = 0; r < nrows; r++) cmb_ptr[(size_t)r + 1] += cmb_ptr[(size_t)r];
+        in.plan_s += now_s() - t0;
+        int64_t zoff = 0;
+        for (int p = 0; p < P; p++) {
+            Part &part = h->parts[(size_t)p];
+            rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
+                            sp.va[(size_t)p].data(), f32, opt, &in.plan_s);
+            if (rc) { cvr_destroy(h); return rc; }
+            part.zoff = zoff;
+            zoff += part.yext;
+        }
+        if (zoff >= (int64_t)0xffffffffu) { cvr_destroy(h); return fail(CVR_ERR_INVALID, "partial-sum buffer too large for 32-bit indices"); }
+        const double t1 = now_s();
+        std::vector<uint32_t> cmb_idx((size_t)cmb_ptr[(size_t)nrows]), fill(cmb_ptr.begin(), cmb_ptr.end() - 1);
+        for (int p = 0; p < P; p++) {                 // panel order inside a row: the combine adds in panel order
+            const Raw<uint32_t> &rows = sp.rows[(size_t)p];
+            for (size_t u = 0; u < rows.size(); u++) cmb_idx[(size_t)fill[rows[u]]++] = (uint32_t)(h->parts[(size_t)p].zoff + (int64_t)u);
+        }
+        in.plan_s += now_s() - t1;
+        CREATE_TRY(hipMalloc(&h->d_z, vsz * (size_t)std::max<int64_t>(zoff, 1)));
+        CREATE_TRY(hipMalloc(&h->d_cmb_ptr, sizeof(uint32_t) * ((size_t)nrows + 1)));
+        CREATE_TRY(hipMalloc(&h->d_cmb_idx, sizeof(uint32_t) * std::max<size_t>(cmb_idx.size(), 1)));
+        CREATE_TRY(hipMemsetAsync(h->d_z, 0, vsz * (size_t)std::max<int64_t>(zoff, 1), h->stream));
+        CREATE_TRY(hipMemcpyAsync(h->d_cmb_ptr, cmb_ptr.data(), sizeof(uint32_t) * cmb_ptr.size(), hipMemcpyHostToDevice, h->stream));
+        if (!cmb_idx.empty()) CREATE_TRY(hipMemcpyAsync(h->d_cmb_idx, cmb_idx.data(), sizeof(uint32_t) * cmb_idx.size(), hipMemcpyHostToDevice, h->stream));
+        CREATE_TRY(hipStreamSynchronize(h->stream));
+        in.yext_elems = nrows + 1;
+        in.image_bytes += (int64_t)(sizeof(uint32_t) * (cmb_ptr.size() + cmb_idx.size()));
     }
-    if (nchunks) {
-        HIP_TRY_H(hipMemcpyAsync(h->d_nzb, nzb.data(), sizeof(int64_t) * nzb.size(), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY_H(hipMemcpyAsync(h->d_pad, pad.data(), sizeof(uint32_t) * pad.size(), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY_H(hipMemcpyAsync(img.desc, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, h->stream));
+    in.steps_per_chunk = h->parts[0].img.S;
+    for (const Part &p : h->parts) {
+        in.nchunks += p.nchunks; in.nshared += p.nshared; in.nslots += p.nchunks * 64 * p.img.S;
+        in.image_bytes += (int64_t)(p.stream_bytes + (size_t)p.nchunks * (16 + 64) + (size_t)p.nshared * 24);
     }
-    if (!plan.shared.empty())
-        HIP_TRY_H(hipMemcpyAsync(img.shared, plan.shared.data(), sizeof(cvr::Shared) * plan.shared.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY_H(hipStreamSynchronize(h->stream));   // the caller may free its CSR when this returns
-    in.upload_s = now_s() - t2;
-#undef HIP_TRY_H
+    CREATE_TRY(hipMalloc(&h->d_err, sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&h->d_x, vsz * (size_t)in.x_elems));
+    CREATE_TRY(hipMalloc(&h->d_y, vsz * (size_t)in.yext_elems));
+    CREATE_TRY(hipMemsetAsync(h->d_x, 0, vsz * (size_t)in.x_elems, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_y, 0, vsz * (size_t)in.yext_elems, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
+    CREATE_TRY(hipStreamSynchronize(h->stream));   // the caller may free its CSR when this returns
+    in.upload_s = now_s() - t_up0 - in.plan_s;
+#undef CREATE_TRY
     *out = h;
     return CVR_OK;
 }
@@ -306,18 +509,20 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
 int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
 {
     if (!h) return fail(CVR_ERR_INVALID, "handle is null");
-    if (!h->d_rp) return fail(CVR_ERR_STATE, "the device CSR was already released: cvr_preprocess runs once unless keep_csr was set");
+    if (h->parts.empty() || !h->parts[0].d_rp) return fail(CVR_ERR_STATE, "the device CSR was already released: cvr_preprocess runs once unless keep_csr was set");
     Range range("cvr_preprocess (CSR -> CVR64)");
     HIP_TRY(hipSetDevice(h->device));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
-    cvr::DeviceCsr csr;
-    csr.row_ptr = h->d_rp; csr.col_idx = h->d_ci; csr.vals = h->d_va; csr.nz_begin = h->d_nzb; csr.pad_cnt = h->d_pad;
     HIP_TRY(hipEventRecord(e0, h->stream));
-    HIP_TRY(cvr::launch_convert(h->img, csr, h->d_err, h->stream));
-    HIP_TRY(cvr::launch_window(h->img, csr, h->stream));
+    for (Part &p : h->parts) {
+        cvr::DeviceCsr csr;
+        csr.row_ptr = p.d_rp; csr.col_idx = p.d_ci; csr.vals = p.d_va; csr.nz_begin = p.d_nzb; csr.pad_cnt = p.d_pad;
+        HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream));
+        HIP_TRY(cvr::launch_window(p.img, csr, h->stream));
+    }
     HIP_TRY(hipEventRecord(e1, h->stream));
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(&err, h->d_err, sizeof(err), hipMemcpyDeviceToHost, h->stream));
@@ -330,7 +535,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     if (seconds) *seconds = ms * 1e-3;
     if (err) return fail(CVR_ERR_INTERNAL, "device converter self-check failed (flags 0x%x)", err);
     h->converted = true;
-    if (!keep_csr) h->release_csr();
+    if (!keep_csr) for (Part &p : h->parts) p.release_csr();
     return CVR_OK;
 }
 
@@ -346,16 +551,9 @@ int cvr_destroy(cvr_handle *h)
     if (!h) return CVR_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->release_csr();
+    for (Part &p : h->parts) p.release_all();
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    if (h->d_err) (void)hipFree(h->d_err);
-    if (h->img.stream) (void)hipFree(h->img.stream);
-    if (h->img.desc) (void)hipFree(h->img.desc);
-    if (h->img.target) (void)hipFree(h->img.target);
-    if (h->img.shared) (void)hipFree(h->img.shared);
-    if (h->img.win_base) (void)hipFree(h->img.win_base);
-    if (h->d_x) (void)hipFree(h->d_x);
-    if (h->d_y) (void)hipFree(h->d_y);
+    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_cmb_ptr, (void *)h->d_cmb_idx, h->d_x, h->d_y}) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return CVR_OK;
@@ -369,7 +567,7 @@ int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream)
 {
     if (!h || !x_dev || !y_dev) return fail(CVR_ERR_INVALID, "null argument");
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_spmv before cvr_preprocess");
-    HIP_TRY(cvr::launch_spmv(h->img, x_dev, y_dev, (hipStream_t)stream));
+    HIP_TRY(run_spmv(h, x_dev, y_dev, (hipStream_t)stream));
     return CVR_OK;
 }
 
@@ -378,7 +576,7 @@ int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *
     if (!h || !x_dev || !y_dev) return fail(CVR_ERR_INVALID, "null argument");
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_spmv before cvr_preprocess");
     const hipStream_t st = (hipStream_t)stream;
-    for (int i = 0; i < n; i++) HIP_TRY(cvr::launch_spmv(h->img, x_dev, y_dev, st));
+    for (int i = 0; i < n; i++) HIP_TRY(run_spmv(h, x_dev, y_dev, st));
     return CVR_OK;
 }
 
@@ -392,9 +590,9 @@ int cvr_spmv_bench(cvr_handle *h, int warmup, int iters, double *mean_s)
         HIP_TRY(hipEventCreate(&h->events[0]));
         HIP_TRY(hipEventCreate(&h->events[1]));
     }
-    for (int i = 0; i < warmup; i++) HIP_TRY(cvr::launch_spmv(h->img, h->d_x, h->d_y, h->stream));
+    for (int i = 0; i < warmup; i++) HIP_TRY(run_spmv(h, h->d_x, h->d_y, h->stream));
     HIP_TRY(hipEventRecord(h->events[0], h->stream));
-    for (int i = 0; i < iters; i++) HIP_TRY(cvr::launch_spmv(h->img, h->d_x, h->d_y, h->stream));
+    for (int i = 0; i < iters; i++) HIP_TRY(run_spmv(h, h->d_x, h->d_y, h->stream));
     HIP_TRY(hipEventRecord(h->events[1], h->stream));
     HIP_TRY(hipEventSynchronize(h->events[1]));
     float ms = 0;
@@ -420,10 +618,10 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
     if (h->info.ncols) HIP_TRY(hipMemcpyAsync(h->d_x, x_host, h->vsz * (size_t)h->info.ncols, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const double h2d = now_s() - t0;
-    HIP_TRY(cvr::launch_spmv(h->img, h->d_x, h->d_y, h->stream));   // warm-up, untimed
+    HIP_TRY(run_spmv(h, h->d_x, h->d_y, h->stream));   // warm-up, untimed
     HIP_TRY(hipEventRecord(h->events[0], h->stream));
     for (int i = 0; i < iters; i++) {
-        HIP_TRY(cvr::launch_spmv(h->img, h->d_x, h->d_y, h->stream));
+        HIP_TRY(run_spmv(h, h->d_x, h->d_y, h->stream));
         HIP_TRY(hipEventRecord(h->events[(size_t)i + 1], h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -478,13 +676,15 @@ int cvr_export_image(cvr_handle *h, void *stream_image, uint32_t *desc, uint8_t 
 {
     if (!h) return fail(CVR_ERR_INVALID, "handle is null");
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_export_image before cvr_preprocess");
+    if (h->paneled()) return fail(CVR_ERR_STATE, "cvr_export_image exports one image: create the handle with col_panels = 1");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    const size_t nc = (size_t)h->info.nchunks;
-    if (stream_image && h->stream_bytes) HIP_TRY(hipMemcpy(stream_image, h->img.stream, h->stream_bytes, hipMemcpyDeviceToHost));
-    if (desc && nc) HIP_TRY(hipMemcpy(desc, h->img.desc, 16 * nc, hipMemcpyDeviceToHost));
-    if (target && nc) HIP_TRY(hipMemcpy(target, h->img.target, 64 * nc, hipMemcpyDeviceToHost));
-    if (shared && h->info.nshared) HIP_TRY(hipMemcpy(shared, h->img.shared, 24 * (size_t)h->info.nshared, hipMemcpyDeviceToHost));
+    const Part  &p = h->parts[0];
+    const size_t nc = (size_t)p.nchunks;
+    if (stream_image && p.stream_bytes) HIP_TRY(hipMemcpy(stream_image, p.img.stream, p.stream_bytes, hipMemcpyDeviceToHost));
+    if (desc && nc) HIP_TRY(hipMemcpy(desc, p.img.desc, 16 * nc, hipMemcpyDeviceToHost));
+    if (target && nc) HIP_TRY(hipMemcpy(target, p.img.target, 64 * nc, hipMemcpyDeviceToHost));
+    if (shared && p.nshared) HIP_TRY(hipMemcpy(shared, p.img.shared, 24 * (size_t)p.nshared, hipMemcpyDeviceToHost));
     return CVR_OK;
 }
 

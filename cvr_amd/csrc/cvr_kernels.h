@@ -47,6 +47,9 @@ hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream
 // y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0)
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st);
 
+// column panels: y[r] = sum_{k in cmb_ptr[r] .. cmb_ptr[r+1]} z[cmb_idx[k]], in that order (bitwise reproducible)
+hipError_t launch_combine(const uint32_t *cmb_ptr, const uint32_t *cmb_idx, const void *z, void *y, uint32_t nrows, bool f32, hipStream_t st);
+
 // 16-B-per-lane streaming copy (roofline calibration)
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st);
 

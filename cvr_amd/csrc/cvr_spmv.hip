@@ -266,6 +266,18 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void fixup_kernel(const in
     if (lane == 0) yext[row] = carry[2 * c0 + 1] + v;
 }
 
+// column panels: one lane per row adds the row's partial sums in panel order
+template <typename T>
+__global__ __launch_bounds__(256) void combine_kernel(const uint32_t *__restrict__ cmb_ptr, const uint32_t *__restrict__ cmb_idx,
+                                                      const T *__restrict__ z, T *__restrict__ y, uint32_t nrows)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    T sum = 0;
+    for (uint32_t k = cmb_ptr[r], e = cmb_ptr[r + 1]; k < e; k++) sum += z[cmb_idx[k]];
+    y[r] = sum;
+}
+
 // plain streaming copy: the achievable-HBM-rate yardstick beside the 8 TB/s nominal peak.  Four independent
 // 16-byte loads per lane in flight, block-contiguous tiles.
 __global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n)
@@ -282,6 +294,15 @@ __global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ src
 }
 
 }  // namespace
+
+hipError_t launch_combine(const uint32_t *cmb_ptr, const uint32_t *cmb_idx, const void *z, void *y, uint32_t nrows, bool f32, hipStream_t st)
+{
+    if (nrows == 0) return hipSuccess;
+    const dim3 grid((nrows + 255) / 256), block(256);
+    if (f32) hipLaunchKernelGGL(combine_kernel<float>, grid, block, 0, st, cmb_ptr, cmb_idx, static_cast<const float *>(z), static_cast<float *>(y), nrows);
+    else hipLaunchKernelGGL(combine_kernel<double>, grid, block, 0, st, cmb_ptr, cmb_idx, static_cast<const double *>(z), static_cast<double *>(y), nrows);
+    return hipGetLastError();
+}
 
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st)
 {

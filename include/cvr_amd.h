@@ -70,7 +70,9 @@ typedef struct {
     int32_t gather_policy;     /* ... of the x gather                                          */
     int32_t gather_depth;      /* groups (of 4 steps) the x gather runs ahead of the FMAs: 1 or 2 */
     int32_t debug_col_mask;    /* profiling only: folds the gather onto a 2^k-entry table (wrong y) */
-    int32_t reserved[2];
+    int32_t col_panels;        /* column panels (each with its slice of x L2-resident, partial sums combined by a second
+                                  kernel): 1 = off, <0 = auto (only when x is several times the L2), else the count   */
+    int32_t reserved[1];
 } cvr_options;
 
 typedef struct {
@@ -90,6 +92,8 @@ typedef struct {
     int64_t yext_elems;        /* y_ext = [y | dump | 2 carry slots per chunk]                        */
     int64_t x_elems;           /* ncols + 1 : x_ext[ncols] must be 0 (pad slot)                       */
     double  plan_s, upload_s, convert_s;  /* host planner, H2D of CSR, device conversion kernel      */
+    int32_t col_panels;        /* 1, or the number of column panels the matrix was cut into                          */
+    int32_t reserved_;
 } cvr_info;
 
 void        cvr_default_options(cvr_options *opt);
@@ -114,7 +118,8 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
 
 /* Asynchronous single SpMV on caller-provided device buffers and stream (a hipStream_t passed as
  * void*; NULL is HIP's null stream, cvr_stream(h) is the handle's own).  x_dev must hold info.x_elems values with
- * x_dev[ncols] == 0; y_dev must hold info.yext_elems values (the first nrows are y).  Rows without
+ * x_dev[ncols] == 0; y_dev must hold info.yext_elems values (the first nrows are y; the rest is
+ * scratch: carry slots of rows cut over chunks).  Rows without
  * non-zeros are written as 0 on every call; y needs no zeroing. */
 int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream);
 /* the same, `n` launches back to back (the Ntimes loop of spmv.cpp:1024 without a host round trip per launch) */

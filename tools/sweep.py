@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--xpol", default="0", help="x-gather cache policy bits: 0 default, 2 nt, 16 sc1")
     ap.add_argument("--depth", default="1")
     ap.add_argument("--win", default="-1", help="x window values staged in LDS per workgroup (-1 auto, 0 off)")
+    ap.add_argument("--panels", default="-1", help="column panels (-1 auto, 1 off)")
     ap.add_argument("--colmask", default="0", help="comma list of hex masks: folds the x gather onto a small table (timing only)")
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
@@ -47,17 +48,17 @@ def main():
     for S in [int(s) for s in a.S.split(",")]:
         for thr in [int(s) for s in a.thr.split(",")]:
             for swz in [int(s) for s in a.swz.split(",")]:
-                for (nt, cm, xp, dp, win) in [(int(s), int(m, 16), int(xp), int(dp), int(w)) for s in a.nt.split(",")
-                                              for m in a.colmask.split(",") for xp in a.xpol.split(",")
-                                              for dp in a.depth.split(",") for w in a.win.split(",")]:
+                for (nt, cm, xp, dp, win, pan) in [(int(s), int(m, 16), int(xp), int(dp), int(w), int(pn)) for s in a.nt.split(",")
+                                                   for m in a.colmask.split(",") for xp in a.xpol.split(",")
+                                                   for dp in a.depth.split(",") for w in a.win.split(",") for pn in a.panels.split(",")]:
                     A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, nontemporal=nt,
-                                          debug_col_mask=cm, gather_policy=xp, depth=dp, x_window=win)
+                                          debug_col_mask=cm, gather_policy=xp, depth=dp, x_window=win, col_panels=pan)
                     x = synth.x_rand(nc, va.dtype)
                     A.spmv(x)
                     s = A.bench(a.warmup, a.iters)
                     i = A.info
                     print(f"  {S:4d}  {swz}  {nt:2d}  {thr:6d}  {i.nchunks:6d} {i.nshared:5d}  {i.nslots / max(nnz, 1):8.4f}  {i.convert_s * 1e6:9.1f}  "
-                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  xpol {xp} depth {dp} win {win}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
+                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  xpol {xp} depth {dp} win {win} panels {i.col_panels}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
                     A.close()
 
 
