@@ -121,6 +121,8 @@ struct cvr_handle {
     // column panels: y[r] = sum over the panels that hold row r of z[cmb_idx[k]], k in cmb_ptr[r] .. cmb_ptr[r+1]
     void     *d_z = nullptr;
     uint32_t *d_cmb_ptr = nullptr, *d_cmb_idx = nullptr;
+    cvr::FixPart *d_fixparts = nullptr;   // panels: the fix-up of every panel in one launch
+    uint32_t  max_nshared = 0;
     uint32_t *d_err = nullptr;
     void     *d_x = nullptr;            // x_ext: ncols + 1
     void     *d_y = nullptr;            // y_ext (1 part) or y (panels)
@@ -137,9 +139,11 @@ hipError_t run_spmv(const cvr_handle *h, const void *x, void *y, hipStream_t st)
 {
     if (!h->paneled()) return h->parts.empty() ? hipSuccess : cvr::launch_spmv(h->parts[0].img, x, y, st);
     for (const Part &p : h->parts) {
-        hipError_t e = cvr::launch_spmv(p.img, x, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * h->vsz, st);
+        hipError_t e = cvr::launch_spmv(p.img, x, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * h->vsz, st, false);
         if (e != hipSuccess) return e;
     }
+    hipError_t e = cvr::launch_fixup_multi(h->d_fixparts, (uint32_t)h->parts.size(), h->max_nshared, h->vsz == 4, st);
+    if (e != hipSuccess) return e;
     return cvr::launch_combine(h->d_cmb_ptr, h->d_cmb_idx, h->d_z, y, (uint32_t)h->info.nrows, h->vsz == 4, st);
 }
 
@@ -391,6 +395,31 @@ static void split_panels_t(const cvr_csr_view &v, int P, PanelSplit &out)
     }
 }
 
+// How many bytes of x does a block of consecutive rows touch?  (What one XCD works on at a time is of that order.)
+// Counted in 128-byte lines over up to four evenly spaced windows of 65 536 rows; the largest is returned.  A banded
+// matrix touches little more than the window itself, a scattered one most of x.
+static double window_footprint_bytes(const cvr_csr_view &v)
+{
+    const int64_t nrows = v.nrows, W = std::min<int64_t>(65536, nrows);
+    if (W <= 0) return 0;
+    const int64_t per_line = v.is_f32 ? 32 : 16, nlines = v.ncols / per_line + 1;
+    std::vector<uint64_t> bits((size_t)(nlines / 64 + 1));
+    double worst = 0;
+    for (int w = 0; w < 4; w++) {
+        const int64_t r0 = (nrows - W) * w / 3;
+        std::fill(bits.begin(), bits.end(), 0);
+        int64_t lines = 0;
+        for (int64_t j = v.row_ptr[r0]; j < v.row_ptr[r0 + W]; j++) {
+            const int64_t  l = v.col_idx[j] / per_line;
+            const uint64_t m = 1ull << (l & 63);
+            if (!(bits[(size_t)(l >> 6)] & m)) { bits[(size_t)(l >> 6)] |= m; lines++; }
+        }
+        worst = std::max(worst, (double)lines * 128.0);
+        if (nrows == W) break;
+    }
+    return worst;
+}
+
 static void split_panels(const cvr_csr_view &v, int P, PanelSplit &out)
 {
     if (v.is_f32) split_panels_t<float>(v, P, out); else split_panels_t<double>(v, P, out);
@@ -416,13 +445,15 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     const int64_t nrows = csr->nrows, ncols = csr->ncols;
     const bool    f32 = csr->is_f32 != 0;
     const size_t  vsz = f32 ? 4 : 8;
-    // column panels: asked for, or (col_panels < 0: auto) when x is several times the 4-MiB L2 of an XCD, one panel per
-    // ~4.5 MB of x (profiles/r01_column_panel_probe_livejournal.log); never for matrices whose x nearly fits
-    // (web-Google: profiles/r01_column_panel_probe.log)
+    // column panels: asked for, or (col_panels < 0: auto) when x is several times the 4-MiB L2 of an XCD AND a block of
+    // consecutive rows really touches that much of it (a banded matrix does not): one panel per ~4.5 MB of x
+    // (profiles/r01_column_panels_livejournal_sweep.log); never for matrices whose x nearly fits (web-Google:
+    // profiles/r01_column_panel_probe.log)
     int P = opt.col_panels;
     if (P < 0) {
         const double xb = (double)ncols * (double)vsz;
-        P = xb >= 24e6 ? (int)(xb / 4.5e6 + 0.5) : 1;
+        P = 1;
+        if (xb >= 24e6 && window_footprint_bytes(*csr) > 8e6) P = (int)(xb / 4.5e6 + 0.5);   // scattered columns, x >> L2
     }
     if (P < 1) P = 1;
     if (P > 64) P = 64;
@@ -484,6 +515,14 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
         CREATE_TRY(hipMemsetAsync(h->d_z, 0, vsz * (size_t)std::max<int64_t>(zoff, 1), h->stream));
         CREATE_TRY(hipMemcpyAsync(h->d_cmb_ptr, cmb_ptr.data(), sizeof(uint32_t) * cmb_ptr.size(), hipMemcpyHostToDevice, h->stream));
         if (!cmb_idx.empty()) CREATE_TRY(hipMemcpyAsync(h->d_cmb_idx, cmb_idx.data(), sizeof(uint32_t) * cmb_idx.size(), hipMemcpyHostToDevice, h->stream));
+        std::vector<cvr::FixPart> fp((size_t)P);
+        for (int p = 0; p < P; p++) {
+            const Part &part = h->parts[(size_t)p];
+            fp[(size_t)p] = cvr::FixPart{part.img.shared, static_cast<uint8_t *>(h->d_z) + (size_t)part.zoff * vsz, (uint32_t)part.nshared, (uint32_t)part.nrows};
+            h->max_nshared = std::max(h->max_nshared, (uint32_t)part.nshared);
+        }
+        CREATE_TRY(hipMalloc(&h->d_fixparts, sizeof(cvr::FixPart) * (size_t)P));
+        CREATE_TRY(hipMemcpyAsync(h->d_fixparts, fp.data(), sizeof(cvr::FixPart) * (size_t)P, hipMemcpyHostToDevice, h->stream));
         CREATE_TRY(hipStreamSynchronize(h->stream));
         in.yext_elems = nrows + 1;
         in.image_bytes += (int64_t)(sizeof(uint32_t) * (cmb_ptr.size() + cmb_idx.size()));
@@ -553,7 +592,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Part &p : h->parts) p.release_all();
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_cmb_ptr, (void *)h->d_cmb_idx, h->d_x, h->d_y}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_cmb_ptr, (void *)h->d_cmb_idx, (void *)h->d_fixparts, h->d_x, h->d_y}) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return CVR_OK;

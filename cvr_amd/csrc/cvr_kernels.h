@@ -44,8 +44,12 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 // of its non-zeros (LDS histogram over coarse column bins); writes img.win_base
 hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st);
 
-// y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0)
-hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st);
+// y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0 and with_fixup)
+hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup = true);
+
+// column panels: one fix-up launch for all panels (each with its own y_ext inside the partial-sum buffer)
+struct FixPart { const int64_t *shared; void *yext; uint32_t nshared, nrows; };
+hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t max_nshared, bool f32, hipStream_t st);
 
 // column panels: y[r] = sum_{k in cmb_ptr[r] .. cmb_ptr[r+1]} z[cmb_idx[k]], in that order (bitwise reproducible)
 hipError_t launch_combine(const uint32_t *cmb_ptr, const uint32_t *cmb_idx, const void *z, void *y, uint32_t nrows, bool f32, hipStream_t st);

@@ -293,7 +293,34 @@ __global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ src
     }
 }
 
+// column panels: the fix-ups of all panels in one launch (blockIdx.y = panel)
+template <typename T>
+__global__ __launch_bounds__(kLanes * 4) void fixup_multi_kernel(const FixPart *__restrict__ parts)
+{
+    const FixPart  p = parts[blockIdx.y];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= p.nshared) return;
+    const int64_t row = p.shared[3 * (size_t)s], c0 = p.shared[3 * (size_t)s + 1], c1 = p.shared[3 * (size_t)s + 2];
+    T            *yext = static_cast<T *>(p.yext);
+    const T      *carry = yext + p.nrows + 1;
+    T             v = 0;
+    for (int64_t c = c0 + 1 + lane; c <= c1; c += kLanes) v += carry[2 * c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) yext[row] = carry[2 * c0 + 1] + v;
+}
+
 }  // namespace
+
+hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t max_nshared, bool f32, hipStream_t st)
+{
+    if (nparts == 0 || max_nshared == 0) return hipSuccess;
+    const dim3 grid((max_nshared + 3) / 4, nparts), block(kLanes * 4);
+    if (f32) hipLaunchKernelGGL(fixup_multi_kernel<float>, grid, block, 0, st, parts);
+    else hipLaunchKernelGGL(fixup_multi_kernel<double>, grid, block, 0, st, parts);
+    return hipGetLastError();
+}
 
 hipError_t launch_combine(const uint32_t *cmb_ptr, const uint32_t *cmb_idx, const void *z, void *y, uint32_t nrows, bool f32, hipStream_t st)
 {
@@ -311,7 +338,7 @@ hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st)
+hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup)
 {
     if (img.nchunks == 0) return hipSuccess;
     const uint32_t nblocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -341,7 +368,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #undef CVR_PICK_D
 #undef CVR_LAUNCH
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || img.nshared == 0) return e;
+    if (e != hipSuccess || img.nshared == 0 || !with_fixup) return e;
     const uint32_t fb = (img.nshared + kWavesPerBlock - 1) / kWavesPerBlock;
     if (img.f32)
         hipLaunchKernelGGL(fixup_kernel<float>, dim3(fb), block, 0, st, img.shared, img.nshared, static_cast<float *>(y_ext), img.nrows);
