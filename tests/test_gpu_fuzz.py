@@ -1,0 +1,63 @@
+"""GPU: randomised parity -- random row-length distributions (empty rows, giants, uniform, power law), random chunk
+length, split threshold, column panels and LDS window; converter image against the CPU mirror (bit for bit, when one
+image) and y against the CSR oracle.  CVR_FUZZ_CASES raises the number of cases (default 48)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases as K
+import cvr_amd
+import oraclelib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(rng):
+    kind = rng.integers(0, 5)
+    nrows = int(rng.integers(1, 4000))
+    ncols = int(rng.integers(1, 6000))
+    if kind == 0:
+        lens = rng.integers(0, 12, size=nrows)
+    elif kind == 1:
+        lens = np.minimum((rng.pareto(1.1, size=nrows) + 0.5).astype(np.int64), 3000)
+    elif kind == 2:
+        lens = np.zeros(nrows, dtype=np.int64)
+        lens[rng.integers(0, nrows, size=max(1, nrows // 50))] = rng.integers(1, 5000, size=max(1, nrows // 50))
+    elif kind == 3:
+        lens = np.full(nrows, int(rng.integers(1, 70)))
+    else:
+        lens = rng.integers(0, 3, size=nrows) * rng.integers(0, 40, size=nrows)
+    lens = np.asarray(lens, dtype=np.int64)
+    if lens.sum() > 400_000:
+        lens = lens // (lens.sum() // 400_000 + 1)
+    return K.csr_from_lengths(lens, ncols, rng, sort=bool(rng.integers(0, 2)))
+
+
+def test_fuzz_parity():
+    ncases = int(os.environ.get("CVR_FUZZ_CASES", "48"))
+    rng = np.random.default_rng(int(os.environ.get("CVR_FUZZ_SEED", "20261002")))
+    for case in range(ncases):
+        nrows, ncols, rp, ci, va = _random_case(rng)
+        f32 = bool(rng.integers(0, 4) == 0)
+        if f32:
+            va = va.astype(np.float32)
+        S = int(rng.choice([4, 8, 12, 16, 32, 64]))
+        thr = int(rng.choice([0, 1, 7, 64, 10**6]))
+        P = int(rng.choice([1, 1, 2, 3]))
+        win = int(rng.choice([0, 0, 64, 1000]))
+        ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32)
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, col_panels=P, x_window=win)
+        if P == 1:
+            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr)
+            img = A.export_image()
+            assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc), ctx
+            assert np.array_equal(img["target"], mir.target) and np.array_equal(img["shared"], mir.shared), ctx
+        x = O.x_vec_fast(ncols, "rand").astype(va.dtype)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        bad, worst = O.tol_check(y, yref, absy + 1e-30, tol=2e-5 if f32 else 1e-12)
+        assert len(bad) == 0, (ctx, bad[:5], worst)
+        y2, _ = A.spmv(x)
+        assert np.array_equal(y.view(np.uint8), y2.view(np.uint8)), ctx
+        A.close()
