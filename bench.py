@@ -297,6 +297,7 @@ def main():
         print(json.dumps(out))
     A.close()
     if world > 1:
+        dist.barrier()                      # rank 0 is still verifying / printing: leave together
         dist.destroy_process_group()
 
 
