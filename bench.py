@@ -276,7 +276,8 @@ def main():
             "config": {"workload": f"{source}: {nrows}x{ncols}, nnz {nnz}, fp64, y = A x with A (CVR64 image), x, y resident in HBM",
                        "rows_per_gpu": [int(v) for v in np.diff(bounds)],
                        "steps_per_chunk": int(info.steps_per_chunk), "chunks_rank0": int(info.nchunks),
-                       "rows_cut_rank0": int(info.nshared),
+                       "rows_cut_rank0": int(info.nshared), "col_panels": int(info.col_panels),
+                       "value_dictionary_entries": int(info.value_dict),
                        "parallelism": "rows sharded, x replicated, y all-gathered (RCCL)" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if world == 1 and args.workload == "webgoogle" else None,

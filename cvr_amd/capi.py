@@ -27,7 +27,7 @@ class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
                 ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("stream_policy", C.c_int32),
                 ("gather_policy", C.c_int32), ("gather_depth", C.c_int32), ("debug_col_mask", C.c_int32),
-                ("col_panels", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("col_panels", C.c_int32), ("value_dict", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -40,7 +40,7 @@ class Info(C.Structure):
                 ("steps_per_chunk", C.c_int32), ("nchunks", C.c_int64), ("nslots", C.c_int64), ("nshared", C.c_int64),
                 ("image_bytes", C.c_int64), ("yext_elems", C.c_int64), ("x_elems", C.c_int64),
                 ("plan_s", C.c_double), ("upload_s", C.c_double), ("convert_s", C.c_double),
-                ("col_panels", C.c_int32), ("reserved_", C.c_int32)]
+                ("col_panels", C.c_int32), ("value_dict", C.c_int32)]
 
 
 class MmMatrix(C.Structure):
@@ -184,7 +184,7 @@ class CvrMatrix:
 
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
                  xcd_swizzle=-1, x_window=-1, nontemporal=0, keep_csr=False, debug_col_mask=0, gather_policy=0, depth=0,
-                 col_panels=-1):
+                 col_panels=-1, value_dict=-1):
         self._h = C.c_void_p()
         rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
         ci = np.ascontiguousarray(col_idx, dtype=np.int32)
@@ -197,7 +197,7 @@ class CvrMatrix:
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
-        opt.xcd_swizzle, opt.x_window, opt.col_panels = xcd_swizzle, x_window, col_panels
+        opt.xcd_swizzle, opt.x_window, opt.col_panels, opt.value_dict = xcd_swizzle, x_window, col_panels, value_dict
         # tuning / profiling knobs (tools/sweep.py)
         opt.stream_policy, opt.gather_policy, opt.gather_depth, opt.debug_col_mask = nontemporal, gather_policy, depth, debug_col_mask
         rc = lib().cvr_create(C.byref(self._h), C.byref(view), C.byref(opt))
@@ -257,7 +257,7 @@ class CvrMatrix:
 
     def export_image(self):
         i = self.info
-        gb = 2048 if self.f32 else 3072
+        gb = 1280 if i.value_dict else 2048 if self.f32 else 3072
         image = np.zeros(i.nchunks * (i.steps_per_chunk // 4) * gb, dtype=np.uint8)
         desc = np.zeros((i.nchunks, 4), dtype=np.uint32)
         target = np.zeros((i.nchunks, 64), dtype=np.uint8)

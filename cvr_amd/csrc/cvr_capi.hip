@@ -121,6 +121,8 @@ struct cvr_handle {
     // column panels: y[r] = sum over the panels that hold row r of z[cmb_idx[k]], k in cmb_ptr[r] .. cmb_ptr[r+1]
     void     *d_z = nullptr;
     uint32_t *d_cmb_ptr = nullptr, *d_cmb_idx = nullptr;
+    void     *d_dict = nullptr;           // value dictionary (sorted by bit pattern) shared by all parts, or null
+    uint32_t  ndict = 0;
     cvr::FixPart *d_fixparts = nullptr;   // panels: the fix-up of every panel in one launch
     uint32_t  max_nshared = 0;
     uint32_t *d_err = nullptr;
@@ -149,6 +151,48 @@ hipError_t run_spmv(const cvr_handle *h, const void *x, void *y, hipStream_t st)
 
 }  // namespace
 
+// Value dictionary: the distinct bit patterns of the matrix values plus +0.0 (pad slots), sorted, when there are at
+// most kDictMax of them (pattern matrices: the reference gives them index % 13, spmv.cpp:417; Matrix Market says 1).
+// A general real matrix leaves after a few hundred values.  Row blocks are scanned by host threads.
+template <typename B>
+static bool find_dictionary(const B *vals, int64_t n0, int64_t n1, std::vector<B> &dict)
+{
+    int T = (int)std::thread::hardware_concurrency();
+    if (T > 32) T = 32;
+    if (T < 1 || n1 - n0 < (1 << 20)) T = 1;
+    std::vector<std::vector<B>> found((size_t)T);
+    std::vector<char>           over((size_t)T, 0);
+    auto scan = [&](int t) {
+        // open addressing over 1024 slots; the all-ones pattern marks an empty slot (and is handled separately)
+        std::vector<B> tab(1024, (B)~(B)0);
+        bool           has_ones = false;
+        size_t         cnt = 0;
+        const int64_t  lo = n0 + (n1 - n0) * t / T, hi = n0 + (n1 - n0) * (t + 1) / T;
+        for (int64_t j = lo; j < hi; j++) {
+            const B b = vals[j];
+            if (b == (B)~(B)0) { has_ones = true; continue; }
+            size_t hsh = (size_t)((uint64_t)b * 0x9E3779B97F4A7C15ull >> 54) & 1023;
+            while (tab[hsh] != (B)~(B)0 && tab[hsh] != b) hsh = (hsh + 1) & 1023;
+            if (tab[hsh] != b) { tab[hsh] = b; if (++cnt > (size_t)cvr::kDictMax) { over[(size_t)t] = 1; return; } }
+        }
+        for (B b : tab) if (b != (B)~(B)0) found[(size_t)t].push_back(b);
+        if (has_ones) found[(size_t)t].push_back((B)~(B)0);
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(scan, t);
+    scan(0);
+    for (auto &x : th) x.join();
+    dict.clear();
+    dict.push_back(0);                                   // +0.0: the value of every pad slot
+    for (int t = 0; t < T; t++) {
+        if (over[(size_t)t]) return false;
+        dict.insert(dict.end(), found[(size_t)t].begin(), found[(size_t)t].end());
+    }
+    std::sort(dict.begin(), dict.end());
+    dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
+    return dict.size() <= (size_t)cvr::kDictMax;
+}
+
 extern "C" {
 
 const char *cvr_last_error(void) { return g_err; }
@@ -164,6 +208,7 @@ void cvr_default_options(cvr_options *o)
     o->xcd_swizzle = -1;
     o->x_window = -1;
     o->col_panels = -1;
+    o->value_dict = -1;
 }
 
 int cvr_device_count(void)
@@ -254,10 +299,11 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
 
     part.nrows = nrows; part.nnz = nz1 - nz0; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
     const int G = S / 4;
-    part.stream_bytes = (size_t)nchunks * G * cvr::group_bytes(f32);
+    part.stream_bytes = (size_t)nchunks * G * cvr::group_bytes(f32, h->d_dict != nullptr);
     cvr::DeviceImage &img = part.img;
     img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
     img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)plan.shared.size();
+    img.dict = h->d_dict; img.ndict = h->ndict;
     img.xcd_swizzle = opt.xcd_swizzle != 0;
     img.stream_policy = opt.stream_policy > 0 ? opt.stream_policy : 0;
     img.gather_policy = opt.gather_policy > 0 ? opt.gather_policy : 0;
@@ -478,6 +524,25 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     CREATE_TRY(hipSetDevice(h->device));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const double t_up0 = now_s();
+    // value dictionary (value_dict: <0 auto, 0 off): one byte per slot instead of the value when the matrix has at most
+    // 256 distinct values -- 12 -> 5 bytes per slot for fp64 (profiles/r01_value_dictionary.log)
+    if (opt.value_dict != 0 && nrows > 0) {
+        const double  t0 = now_s();
+        const int64_t n0 = csr->row_ptr[0], n1 = csr->row_ptr[nrows];
+        std::vector<uint64_t> d64;
+        std::vector<uint32_t> d32;
+        const bool ok = f32 ? find_dictionary<uint32_t>(static_cast<const uint32_t *>(csr->vals), n0, n1, d32)
+                            : find_dictionary<uint64_t>(static_cast<const uint64_t *>(csr->vals), n0, n1, d64);
+        in.plan_s += now_s() - t0;
+        if (ok) {
+            h->ndict = (uint32_t)(f32 ? d32.size() : d64.size());
+            CREATE_TRY(hipMalloc(&h->d_dict, vsz * (size_t)cvr::kDictMax));
+            CREATE_TRY(hipMemsetAsync(h->d_dict, 0, vsz * (size_t)cvr::kDictMax, h->stream));
+            CREATE_TRY(hipMemcpyAsync(h->d_dict, f32 ? (const void *)d32.data() : (const void *)d64.data(), vsz * h->ndict, hipMemcpyHostToDevice, h->stream));
+            CREATE_TRY(hipStreamSynchronize(h->stream));
+        }
+    }
+    in.value_dict = (int32_t)h->ndict;
     h->parts.resize((size_t)P);
     if (P == 1) {
         rc = build_part(h, h->parts[0], nrows, ncols, csr->row_ptr, csr->col_idx, csr->vals, f32, opt, &in.plan_s);
@@ -592,7 +657,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Part &p : h->parts) p.release_all();
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_cmb_ptr, (void *)h->d_cmb_idx, (void *)h->d_fixparts, h->d_x, h->d_y}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_cmb_ptr, (void *)h->d_cmb_idx, (void *)h->d_fixparts, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return CVR_OK;

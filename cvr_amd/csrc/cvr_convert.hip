@@ -26,14 +26,34 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+template <typename T> struct Bits;
+template <> struct Bits<double> { typedef uint64_t type; };
+template <> struct Bits<float>  { typedef uint32_t type; };
+
+// code of value v in the dictionary (LDS, sorted by bit pattern; the host put every value of the matrix and +0.0 in)
 template <typename T>
+__device__ __forceinline__ uint32_t dict_code(const typename Bits<T>::type *dict, uint32_t ndict, T v)
+{
+    const typename Bits<T>::type b = __builtin_bit_cast(typename Bits<T>::type, v);
+    uint32_t lo = 0, hi = ndict;            // first entry >= b
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (dict[mid] < b) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+template <typename T, bool DICT>
 __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx, const T *__restrict__ vals,
     const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt, const uint4 *__restrict__ desc,
     uint8_t *__restrict__ stream, uint8_t *__restrict__ target, uint32_t *__restrict__ err, int G,
-    uint32_t nchunks, uint32_t pad_col)
+    uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict)
 {
-    constexpr int GB = sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
+    constexpr int GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
+    typedef typename Bits<T>::type bits_t;
+    __shared__ bits_t dict[DICT ? kDictMax : 1];
+    if constexpr (DICT) {
+        for (uint32_t i = threadIdx.x; i < ndict; i += blockDim.x) dict[i] = __builtin_bit_cast(bits_t, dict_g[i]);
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (k >= nchunks) return;
@@ -111,7 +131,16 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
         uint8_t *o = out + (size_t)g * GB;
         u32x4    cq = {cw[0], cw[1], cw[2], cw[3]};
         *reinterpret_cast<u32x4 *>(o) = cq;
-        if constexpr (sizeof(T) == 8) {
+        if constexpr (DICT) {
+            uint32_t codes = 0;
+#pragma unroll
+            for (int j = 0; j < kGroupSteps; j++) {
+                const uint32_t cd = dict_code<T>(dict, ndict, vv[j]);
+                if (cd >= ndict || dict[cd] != __builtin_bit_cast(bits_t, vv[j])) bad |= 4u;   // value missing from the dictionary
+                codes |= (cd & 0xffu) << (8 * j);
+            }
+            *reinterpret_cast<uint32_t *>(stream + (size_t)k * G * GB + (size_t)g * GB + kColsBytes + lane * 4) = codes;
+        } else if constexpr (sizeof(T) == 8) {
             f64x2 lo = {vv[0], vv[1]}, hi = {vv[2], vv[3]};
             *reinterpret_cast<f64x2 *>(o + kColsBytes) = lo;
             *reinterpret_cast<f64x2 *>(o + kColsBytes + kLanes * 16) = hi;
@@ -167,14 +196,13 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     if (img.nchunks == 0) return hipSuccess;
     const uint32_t blocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3     grid(blocks), block(kLanes * kWavesPerBlock);
-    if (img.f32)
-        hipLaunchKernelGGL(convert_kernel<float>, grid, block, 0, st, csr.row_ptr, csr.col_idx,
-                           static_cast<const float *>(csr.vals), csr.nz_begin, csr.pad_cnt, img.desc, img.stream,
-                           img.target, err_flag, img.G, img.nchunks, img.pad_col);
-    else
-        hipLaunchKernelGGL(convert_kernel<double>, grid, block, 0, st, csr.row_ptr, csr.col_idx,
-                           static_cast<const double *>(csr.vals), csr.nz_begin, csr.pad_cnt, img.desc, img.stream,
-                           img.target, err_flag, img.G, img.nchunks, img.pad_col);
+#define CVR_CONVERT(T, DI)                                                                                         \
+    hipLaunchKernelGGL((convert_kernel<T, DI>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
+                       csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
+                       static_cast<const T *>(img.dict), img.ndict)
+    if (img.f32) { if (img.dict) CVR_CONVERT(float, true); else CVR_CONVERT(float, false); }
+    else         { if (img.dict) CVR_CONVERT(double, true); else CVR_CONVERT(double, false); }
+#undef CVR_CONVERT
     return hipGetLastError();
 }
 

@@ -16,6 +16,9 @@
 //                  [64 lanes][4 x u32 column words]                  1024 B   (one dwordx4 / lane)
 //                  fp64: [2 halves][64 lanes][2 x f64]               2048 B   (two dwordx4 / lane)
 //                  fp32: [64 lanes][4 x f32]                         1024 B   (one dwordx4 / lane)
+//                value dictionary (matrices with <= 256 distinct values, e.g. pattern matrices):
+//                  [64 lanes][4 x u8 code]  256 B after the column words instead of the values; the
+//                  dictionary (sorted by bit pattern, contains +0.0 for the pad slots) sits in LDS
 //                bit 31 of a column word = "last slot of this lane's current segment"
 //   desc[k]    = {row_first, nseg, head_dest, last_dest}: segment q of chunk k writes
 //                y_ext[q == 0 ? head_dest : q == nseg-1 ? last_dest : row_first + q]
@@ -34,9 +37,11 @@ constexpr int      kGroupSteps   = 4;
 constexpr int      kColsBytes    = kLanes * 16;            // 1024
 constexpr int      kGroupBytes64 = kColsBytes + kLanes * 32;  // 3072
 constexpr int      kGroupBytes32 = kColsBytes + kLanes * 16;  // 2048
+constexpr int      kGroupBytesDict = kColsBytes + kLanes * 4;  // 1280: column words + one code byte per slot
+constexpr int      kDictMax = 256;
 constexpr int      kWavesPerBlock = 1;   // measured: 1 wave per workgroup spreads the chunks most evenly over the CUs (profiles/r01_waves_per_block.log)
 
-inline int group_bytes(bool f32) { return f32 ? kGroupBytes32 : kGroupBytes64; }
+inline int group_bytes(bool f32, bool dict = false) { return dict ? kGroupBytesDict : f32 ? kGroupBytes32 : kGroupBytes64; }
 
 struct Shared { int64_t row, c0, c1; };
 

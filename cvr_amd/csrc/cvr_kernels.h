@@ -23,6 +23,8 @@ struct DeviceImage {
     int      stream_policy = 0;     // buffer-load cache policy of the matrix stream: 0 default, 2 nt, 16 sc1, 18 sc1+nt
     int      gather_policy = 0;     // ... of the x gather: 0, 2, 16
     int      depth = 1;             // groups the x gather runs ahead of the FMAs (1 or 2)
+    const void *dict = nullptr;     // value dictionary: ndict values of T sorted by bit pattern (device), or null
+    uint32_t  ndict = 0;
     uint32_t *win_base = nullptr;   // [ceil(nchunks / kWavesPerBlock)] first column of each workgroup's LDS window of x
     uint32_t win_elems = 0;         // window length in values (0 = no window)
     uint32_t col_mask = kColMask;   // profiling only: a narrower mask folds the x gather onto a small table
@@ -37,7 +39,7 @@ struct DeviceCsr {
 };
 
 // CSR -> CVR64 (one wavefront per chunk).  *err_flag (device u32, zeroed by the caller) gets bit 0 if a
-// lane stream did not drain, bit 1 if stealing found no over-full lane.
+// lane stream did not drain, bit 1 if stealing found no over-full lane, bit 2 if a value is missing from the dictionary.
 hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st);
 
 // picks, per workgroup of kWavesPerBlock chunks, the window of img.win_elems consecutive columns that holds most

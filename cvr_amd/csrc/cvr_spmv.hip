@@ -44,16 +44,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint3
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
 
-template <typename T> struct Group;
-template <> struct Group<double> { u32x4 c; f64x2 lo, hi; };
-template <> struct Group<float>  { u32x4 c; f32x4 v; };
+template <typename T, bool DICT> struct Group;
+template <> struct Group<double, false> { u32x4 c; f64x2 lo, hi; };
+template <> struct Group<float, false>  { u32x4 c; f32x4 v; };
+template <typename T> struct Group<T, true> { u32x4 c; uint32_t codes; };   // four dictionary codes, one byte per step
 
-template <typename T, int POL>
-__device__ __forceinline__ Group<T> load_group(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+template <typename T, int POL, bool DICT>
+__device__ __forceinline__ Group<T, DICT> load_group(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
-    Group<T> g;
+    Group<T, DICT> g;
     g.c = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL));
-    if constexpr (sizeof(T) == 8) {
+    if constexpr (DICT) {
+        g.codes = __builtin_amdgcn_raw_buffer_load_b32(r, (voff >> 2) + kColsBytes, soff, POL);
+    } else if constexpr (sizeof(T) == 8) {
         g.lo = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, voff + kColsBytes, soff, POL));
         g.hi = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, voff + kColsBytes + kLanes * 16, soff, POL));
     } else {
@@ -107,10 +110,11 @@ __device__ __forceinline__ T x_of(const X4<T> &x, int j)
     else return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x.v[j]) | __builtin_bit_cast(uint32_t, x.w[j]));
 }
 
-template <typename T>
-__device__ __forceinline__ T val_of(const Group<T> &g, int j)
+template <typename T, bool DICT>
+__device__ __forceinline__ T val_of(const Group<T, DICT> &g, int j, const T *dict)
 {
-    if constexpr (sizeof(T) == 8) return j == 0 ? g.lo.x : j == 1 ? g.lo.y : j == 2 ? g.hi.x : g.hi.y;
+    if constexpr (DICT) return dict[(g.codes >> (8 * j)) & 0xffu];            // LDS lookup
+    else if constexpr (sizeof(T) == 8) return j == 0 ? g.lo.x : j == 1 ? g.lo.y : j == 2 ? g.hi.x : g.hi.y;
     else return j == 0 ? g.v.x : j == 1 ? g.v.y : j == 2 ? g.v.z : g.v.w;
 }
 
@@ -139,15 +143,15 @@ template <typename T> struct ChunkState {
 };
 
 // four steps of all 64 lanes: FMA, then the write-back of the lanes whose segment ends at the step
-template <typename T, bool WIN>
-__device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T> &Q, const X4<T> &xq, T *__restrict__ yext,
+template <typename T, bool WIN, bool DICT>
+__device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT> &Q, const X4<T> &xq, T *__restrict__ yext,
                                           T *slot_lane, uint32_t row_first, uint32_t nseg, uint32_t head_dest,
-                                          uint32_t last_dest)
+                                          uint32_t last_dest, const T *dict)
 {
 #pragma unroll
     for (int j = 0; j < kGroupSteps; j++) {
         const uint32_t cw = col_of(Q.c, j);
-        s.acc = fma_t(val_of<T>(Q, j), x_of<T, WIN>(xq, j), s.acc);
+        s.acc = fma_t(val_of<T, DICT>(Q, j, dict), x_of<T, WIN>(xq, j), s.acc);
         const bool     fl = (cw & kEndBit) != 0;
         const uint64_t m = __ballot(fl);
         if (m) {
@@ -171,22 +175,25 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T> &Q, c
     }
 }
 
-template <typename T, int SPOL, int XPOL, int DEPTH, bool WIN>
+template <typename T, int SPOL, int XPOL, int DEPTH, bool WIN, bool DICT>
 __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
     const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
-    uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn)
+    uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict)
 {
-    constexpr int GB = sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [waves][64] steal slots, then the x window (+ zero slot)
+    constexpr int  GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
+    constexpr bool kSync = WIN || (DICT && kWavesPerBlock > 1);      // LDS filled by other waves of the workgroup
+    // LDS: [waves][64] steal slots, the value dictionary (DICT), then the x window and its zero slot (WIN)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     T *const slots = reinterpret_cast<T *>(smem);
-    T *const win = slots + kWavesPerBlock * kLanes;
+    T *const dict = slots + kWavesPerBlock * kLanes;
+    T *const win = dict + (DICT ? kDictMax : 0);
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
     const uint32_t blk = remap_block(blockIdx.x, nblocks_per_xcd, swz != 0);
     const uint32_t k = __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + wv);
-    if (!WIN && k >= nchunks) return;
+    if (!kSync && k >= nchunks) return;
     const bool live = k < nchunks;
 
     const uint32_t cbytes = live ? (uint32_t)G * GB : 0u;             // a wave past the last chunk streams nothing
@@ -195,19 +202,25 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     const uint32_t voff = lane * 16;
 
     // software pipeline: the matrix stream runs DEPTH+1 groups ahead, the x gather DEPTH groups ahead
-    Group<T> Q[DEPTH + 1];
+    Group<T, DICT> Q[DEPTH + 1];
     X4<T>    xs[DEPTH];
 #pragma unroll
-    for (int i = 0; i <= DEPTH; i++) Q[i] = load_group<T, SPOL>(rs, voff, (uint32_t)i * GB);
+    for (int i = 0; i <= DEPTH; i++) Q[i] = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)i * GB);
 
     // stage this workgroup's window of x in LDS: coalesced loads, behind the first stream loads
     uint32_t wbase = 0;
+    if constexpr (DICT)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += kLanes * kWavesPerBlock) dict[i] = i < ndict ? dict_g[i] : T(0);
     if constexpr (WIN) {
         wbase = blk * kWavesPerBlock < nchunks ? win_base[blk] : 0u;
         for (uint32_t i = threadIdx.x; i <= wn; i += kLanes * kWavesPerBlock)
             win[i] = i < wn ? load_x<T, kPolDefault>(rx, wbase + i) : T(0);
+    }
+    if constexpr (kSync) {
         __syncthreads();
         if (!live) return;
+    } else if constexpr (DICT) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // one wavefront per workgroup: its own LDS writes, in order
     }
     const uint4    d = desc[k];
     const uint32_t tg = target[(size_t)k * kLanes + lane];
@@ -227,9 +240,9 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     // every load is unconditional: past the end of the chunk the stream loads are out of range (zeros, no
     // traffic) and the gathers they feed all read x[0]
     for (int g = 0; g < G; g++) {
-        const Group<T> Qn = load_group<T, SPOL>(rs, voff, (uint32_t)(g + DEPTH + 1) * GB);
+        const Group<T, DICT> Qn = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)(g + DEPTH + 1) * GB);
         const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn);
-        sum_group<T, WIN>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest);
+        sum_group<T, WIN, DICT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict);
 #pragma unroll
         for (int i = 0; i < DEPTH; i++) Q[i] = Q[i + 1];
         Q[DEPTH] = Qn;
@@ -348,24 +361,23 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
     if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
     const bool   use_win = img.win_elems > 0 && img.win_base != nullptr;
-    const size_t lds = (size_t)(kWavesPerBlock * kLanes + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
-#define CVR_LAUNCH(T, SP, XP, D, W)                                                                               \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, XP, D, W>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
+    const bool   use_dict = img.dict != nullptr;
+    const size_t lds = (size_t)(kWavesPerBlock * kLanes + (use_dict ? kDictMax : 0) + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
+    // template parameters: <value type, stream cache policy, gather cache policy, gather run-ahead, LDS window, dictionary>
+#define CVR_LAUNCH(T, SP, D, W, DI)                                                                               \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
-                       img.xcd_swizzle ? 1 : 0, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems)
-#define CVR_PICK_D(T, SP, XP)                                                                                     \
-    do { if (use_win) { if (img.depth == 2) CVR_LAUNCH(T, SP, XP, 2, true); else CVR_LAUNCH(T, SP, XP, 1, true); } \
-         else { if (img.depth == 2) CVR_LAUNCH(T, SP, XP, 2, false); else CVR_LAUNCH(T, SP, XP, 1, false); } } while (0)
-#define CVR_PICK_XP(T, SP)                                                                                        \
-    do { switch (img.gather_policy) { case kPolNt: CVR_PICK_D(T, SP, kPolNt); break; case kPolSc1: CVR_PICK_D(T, SP, kPolSc1); break; \
-         default: CVR_PICK_D(T, SP, kPolDefault); } } while (0)
-#define CVR_PICK_SP(T)                                                                                            \
-    do { switch (img.stream_policy) { case kPolNt: CVR_PICK_XP(T, kPolNt); break; case kPolSc1: CVR_PICK_XP(T, kPolSc1); break; \
-         case kPolSc1 | kPolNt: CVR_PICK_XP(T, kPolSc1 | kPolNt); break; case 17: CVR_PICK_XP(T, 17); break; case 19: CVR_PICK_XP(T, 19); break; default: CVR_PICK_XP(T, kPolDefault); } } while (0)
+                       img.xcd_swizzle ? 1 : 0, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
+                       static_cast<const T *>(img.dict), img.ndict)
+#define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_LAUNCH(T, SP, D, W, true); else CVR_LAUNCH(T, SP, D, W, false); } while (0)
+#define CVR_PICK_W(T, SP, D)     do { if (use_win) CVR_PICK_DI(T, SP, D, true); else CVR_PICK_DI(T, SP, D, false); } while (0)
+#define CVR_PICK_D(T, SP)        do { if (img.depth == 2) CVR_PICK_W(T, SP, 2); else CVR_PICK_W(T, SP, 1); } while (0)
+#define CVR_PICK_SP(T)           do { if (img.stream_policy == kPolNt) CVR_PICK_D(T, kPolNt); else CVR_PICK_D(T, kPolDefault); } while (0)
     if (img.f32) CVR_PICK_SP(float); else CVR_PICK_SP(double);
 #undef CVR_PICK_SP
-#undef CVR_PICK_XP
 #undef CVR_PICK_D
+#undef CVR_PICK_W
+#undef CVR_PICK_DI
 #undef CVR_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || img.nshared == 0 || !with_fixup) return e;

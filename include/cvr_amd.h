@@ -72,7 +72,8 @@ typedef struct {
     int32_t debug_col_mask;    /* profiling only: folds the gather onto a 2^k-entry table (wrong y) */
     int32_t col_panels;        /* column panels (each with its slice of x L2-resident, partial sums combined by a second
                                   kernel): 1 = off, <0 = auto (only when x is several times the L2), else the count   */
-    int32_t reserved[1];
+    int32_t value_dict;        /* value dictionary: one byte per slot instead of the value when the matrix has at most
+                                  256 distinct values (pattern matrices); <0 = auto (default), 0 = off                */
 } cvr_options;
 
 typedef struct {
@@ -93,7 +94,7 @@ typedef struct {
     int64_t x_elems;           /* ncols + 1 : x_ext[ncols] must be 0 (pad slot)                       */
     double  plan_s, upload_s, convert_s;  /* host planner, H2D of CSR, device conversion kernel      */
     int32_t col_panels;        /* 1, or the number of column panels the matrix was cut into                          */
-    int32_t reserved_;
+    int32_t value_dict;        /* 0, or the number of dictionary entries (distinct values + the pad slots' 0)         */
 } cvr_info;
 
 void        cvr_default_options(cvr_options *opt);

@@ -68,8 +68,35 @@ static int64_t plan(int64_t nrows, const int64_t *rp, int64_t cap, int64_t thr, 
     return n;
 }
 
+static int cmp_u64(const void *a, const void *b)
+{
+    const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* value dictionary: the distinct bit patterns of the values plus +0.0 (pad slots), sorted; -1 if more than 256 */
+static int build_dict(const void *vals, int is_f32, int64_t n0, int64_t n1, uint64_t *dict)
+{
+    int n = 0;
+    dict[n++] = 0;
+    for (int64_t j = n0; j < n1; j++) {
+        const uint64_t b = is_f32 ? (uint64_t)((const uint32_t *)vals)[j] : ((const uint64_t *)vals)[j];
+        int k = 0;
+        while (k < n && dict[k] != b) k++;
+        if (k == n) { if (n == 256) return -1; dict[n++] = b; }
+    }
+    qsort(dict, (size_t)n, sizeof(uint64_t), cmp_u64);
+    return n;
+}
+
 int orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols,
                     const void *vals, int is_f32, int S, int64_t thr, orc_cvr64 *c)
+{
+    return orc_cvr64_build_dict(nrows, ncols, rp, cols, vals, is_f32, S, thr, 0, c);
+}
+
+int orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols,
+                         const void *vals, int is_f32, int S, int64_t thr, int use_dict, orc_cvr64 *c)
 {
     memset(c, 0, sizeof(*c));
     if (S < 4 || S % 4) return -1;
@@ -81,7 +108,11 @@ int orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rp, const int32
     c->nchunks = plan(nrows, rp, cap, thr, &ch, &c->shared, &c->nshared);
     const int64_t NC = c->nchunks;
     const int G = S / 4;
-    const size_t gb = is_f32 ? 2048 : 3072;
+    if (use_dict) {
+        c->ndict = build_dict(vals, is_f32, nrows ? rp[0] : 0, nrows ? rp[nrows] : 0, c->dict);
+        if (c->ndict < 0) { free(ch); return -5; }
+    }
+    const size_t gb = c->ndict ? 1280 : is_f32 ? 2048 : 3072;
     c->image_bytes = (int64_t)((size_t)NC * G * gb);
     c->image = (uint8_t *)calloc((size_t)c->image_bytes + 16, 1);
     c->desc = (uint32_t *)calloc((size_t)NC * 4 + 4, sizeof(uint32_t));
@@ -148,7 +179,14 @@ int orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rp, const int32
                 }
                 if (cnt[l] == 1) col |= 0x80000000u;
                 ((uint32_t *)grp)[l * 4 + j] = col;
-                if (is_f32) ((float *)(grp + 1024))[l * 4 + j] = (float)v;
+                if (c->ndict) {                               /* one code byte per slot: position in the sorted dictionary */
+                    uint64_t b;
+                    if (is_f32) { float f = (float)v; uint32_t u; memcpy(&u, &f, 4); b = u; } else memcpy(&b, &v, 8);
+                    int code = 0;
+                    while (code < c->ndict && c->dict[code] != b) code++;
+                    (grp + 1024)[l * 4 + j] = (uint8_t)code;
+                }
+                else if (is_f32) ((float *)(grp + 1024))[l * 4 + j] = (float)v;
                 else ((double *)(grp + 1024 + (j / 2) * 1024))[l * 2 + j % 2] = v;
                 cnt[l]--;
             }
@@ -177,7 +215,7 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
 {
     const int S = c->S, G = S / 4;
     const int64_t NC = c->nchunks, nrows = c->nrows;
-    const size_t gb = c->is_f32 ? 2048 : 3072;
+    const size_t gb = c->ndict ? 1280 : c->is_f32 ? 2048 : 3072;
     const size_t next = (size_t)(nrows + 1 + 2 * NC);
     double *yext = (double *)calloc(next + 1, sizeof(double));
     for (int64_t k = 0; k < NC; k++) {
@@ -198,10 +236,14 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
                 const uint32_t col = cw & 0x7fffffffu;
                 flagged[l] = cw >> 31;
                 if (c->is_f32) {
-                    const float v = ((const float *)(grp + 1024))[l * 4 + j];
+                    float v;
+                    if (c->ndict) { const uint32_t u = (uint32_t)c->dict[(grp + 1024)[l * 4 + j]]; memcpy(&v, &u, 4); }
+                    else v = ((const float *)(grp + 1024))[l * 4 + j];
                     acc[l] = (double)fmaf(v, ((const float *)xv)[col], (float)acc[l]);
                 } else {
-                    const double v = ((const double *)(grp + 1024 + (j / 2) * 1024))[l * 2 + j % 2];
+                    double v;
+                    if (c->ndict) memcpy(&v, &c->dict[(grp + 1024)[l * 4 + j]], 8);
+                    else v = ((const double *)(grp + 1024 + (j / 2) * 1024))[l * 2 + j % 2];
                     acc[l] = fma(v, ((const double *)xv)[col], acc[l]);
                 }
             }

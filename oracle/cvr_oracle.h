@@ -86,10 +86,16 @@ typedef struct {
     int64_t  *shared;        /* [nshared][3] = {row, first chunk, last chunk}                    */
     int64_t  *nz_begin;      /* [nchunks+1] plan: first CSR element of each chunk                */
     int64_t  *pad_cnt;       /* [nchunks]   plan: slots of the trailing pad segment              */
+    int       ndict;         /* 0, or entries of the value dictionary: the group then holds       */
+                             /* [64][4] u8 codes (256 B) after the column words instead of values */
+    uint64_t  dict[256];     /* distinct value bit patterns + 0, sorted                           */
 } orc_cvr64;
 
 int  orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
                      const void *vals, int is_f32, int S, int64_t split_threshold, orc_cvr64 *out);
+/* the same with a value dictionary (use_dict != 0): -5 when the matrix has more than 256 distinct values */
+int  orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
+                          const void *vals, int is_f32, int S, int64_t split_threshold, int use_dict, orc_cvr64 *out);
 void orc_cvr64_free(orc_cvr64 *c);
 /* interpret the image exactly as the HIP kernel does (same per-lane order of operations) */
 void orc_cvr64_spmv(const orc_cvr64 *c, const void *x, void *y);

@@ -26,7 +26,8 @@ class OrcCvr64(C.Structure):
                 ("is_f32", C.c_int), ("nchunks", C.c_int64), ("nshared", C.c_int64), ("image_bytes", C.c_int64),
                 ("image", C.POINTER(C.c_uint8)), ("desc", C.POINTER(C.c_uint32)),
                 ("target", C.POINTER(C.c_uint8)), ("shared", C.POINTER(C.c_int64)),
-                ("nz_begin", C.POINTER(C.c_int64)), ("pad_cnt", C.POINTER(C.c_int64))]
+                ("nz_begin", C.POINTER(C.c_int64)), ("pad_cnt", C.POINTER(C.c_int64)),
+                ("ndict", C.c_int), ("dict", C.c_uint64 * 256)]
 
 
 def lib():
@@ -44,6 +45,8 @@ def lib():
         _lib.orc_cvr64_build.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_int64, C.POINTER(OrcCvr64)]
         _lib.orc_cvr64_spmv.argtypes = [C.POINTER(OrcCvr64), C.c_void_p, C.c_void_p]
+        _lib.orc_cvr64_build_dict.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(OrcCvr64)]
         _lib.orc_write_mtx_pattern.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     return _lib
 
@@ -162,14 +165,14 @@ class Cvr8:
 class Cvr64:
     """CPU mirror of the device format (arrays copied to numpy)"""
 
-    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0):
+    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0, use_dict=False):
         self.rp = np.ascontiguousarray(rowptr, dtype=np.int64)
         self.cl = np.ascontiguousarray(cols, dtype=np.int32)
         self.f32 = vals.dtype == np.float32
         self.vl = np.ascontiguousarray(vals, dtype=np.float32 if self.f32 else np.float64)
         self.c = OrcCvr64()
-        self.rc = lib().orc_cvr64_build(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data,
-                                        int(self.f32), S, thr, C.byref(self.c))
+        self.rc = lib().orc_cvr64_build_dict(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data,
+                                             int(self.f32), S, thr, int(use_dict), C.byref(self.c))
         if self.rc:
             raise RuntimeError(f"orc_cvr64_build = {self.rc}")
         c = self.c
@@ -180,6 +183,7 @@ class Cvr64:
         self.shared = _np(c.shared, 3 * c.nshared, np.int64).reshape(-1, 3)
         self.nz_begin = _np(c.nz_begin, c.nchunks + 1 if c.nchunks else 0, np.int64)
         self.pad_cnt = _np(c.pad_cnt, c.nchunks, np.int64)
+        self.ndict = c.ndict
 
     def spmv(self, x):
         """x: ncols values (the pad slot x_ext[ncols] = 0 is appended here)"""

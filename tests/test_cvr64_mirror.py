@@ -97,3 +97,20 @@ def test_mirror_on_reference_loader_arrays():
             _, absy = O.csr_spmv64(rp, z["csr_col"], z["csr_val"], x)
             bad, worst = O.tol_check(y[:numRows], yref, absy[:numRows])
             assert len(bad) == 0, (name, mode, worst)
+
+
+@pytest.mark.parametrize("name", ["power_law_3000", "two_giants", "leading_trailing_empty", "single_entry"])
+def test_mirror_value_dictionary(name):
+    """the dictionary layout (one code byte per slot) of the mirror against the CSR oracle; > 256 values are refused"""
+    nrows, ncols, rp, ci, va = CASES[name]
+    vq = ((np.arange(len(va)) % 13) - 3).astype(np.float64)
+    for S in (4, 16):
+        m = O.Cvr64(nrows, ncols, rp, ci, vq, S, use_dict=True)
+        assert m.image.size == m.nchunks * (S // 4) * 1280 and 1 <= m.ndict <= 14
+        x = O.x_vec_fast(ncols, "rand")
+        yref, absy = O.csr_spmv64(rp, ci, vq, x)
+        bad, worst = O.tol_check(m.spmv(x), yref, absy)
+        assert len(bad) == 0, (name, S, worst)
+    if len(np.unique(va)) > 256:
+        with pytest.raises(RuntimeError):
+            O.Cvr64(nrows, ncols, rp, ci, va, 8, use_dict=True)

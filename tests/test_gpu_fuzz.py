@@ -40,6 +40,8 @@ def test_fuzz_parity():
     for case in range(ncases):
         nrows, ncols, rp, ci, va = _random_case(rng)
         f32 = bool(rng.integers(0, 4) == 0)
+        if rng.integers(0, 3) == 0:                      # few distinct values: the value dictionary kicks in
+            va = rng.choice(np.array([0.0, 1.0, -1.0, 0.5, 3.0, 1e-3, -7.25]), size=len(va))
         if f32:
             va = va.astype(np.float32)
         S = int(rng.choice([4, 8, 12, 16, 32, 64]))
@@ -49,7 +51,7 @@ def test_fuzz_parity():
         ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32)
         A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, col_panels=P, x_window=win)
         if P == 1:
-            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr)
+            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0)
             img = A.export_image()
             assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc), ctx
             assert np.array_equal(img["target"], mir.target) and np.array_equal(img["shared"], mir.shared), ctx

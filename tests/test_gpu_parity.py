@@ -43,9 +43,9 @@ def test_library_is_the_hip_build_and_sees_the_gpu():
 @pytest.mark.parametrize("S", [4, 8, 32])
 def test_converter_image_bit_exact_and_y_parity(name, S):
     nrows, ncols, rp, ci, va = CASES[name]
-    mir = O.Cvr64(nrows, ncols, rp, ci, va, S)
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S)
-    assert (A.info.nchunks, A.info.nshared) == (mir.nchunks, mir.nshared)
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=A.info.value_dict > 0)
+    assert (A.info.nchunks, A.info.nshared, A.info.value_dict) == (mir.nchunks, mir.nshared, mir.ndict)
     img = A.export_image()
     assert np.array_equal(img["desc"], mir.desc)
     assert np.array_equal(img["target"], mir.target)
@@ -62,8 +62,8 @@ def test_converter_image_bit_exact_and_y_parity(name, S):
 @pytest.mark.parametrize("name", sorted(CASES32))
 def test_fp32_path(name):
     nrows, ncols, rp, ci, va = CASES32[name]
-    mir = O.Cvr64(nrows, ncols, rp, ci, va, 8)
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=8)
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, 8, use_dict=A.info.value_dict > 0)
     assert np.array_equal(A.export_image()["image"], mir.image)
     x = O.x_vec_fast(ncols, "rand").astype(np.float32)
     yref, absy = O.csr_spmv64(rp, ci, va, x)
@@ -77,8 +77,8 @@ def test_fp32_path(name):
 def test_split_threshold_and_launch_options(thr, swz, nt):
     for name, S in (("power_law_3000", 8), ("two_giants", 16), ("dense_row_plus_singletons", 4)):
         nrows, ncols, rp, ci, va = CASES[name]
-        mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr)
         A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, nontemporal=nt)
+        mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0)
         img = A.export_image()
         assert np.array_equal(img["image"], mir.image) and np.array_equal(img["shared"], mir.shared)
         x = O.x_vec_fast(ncols, "rand")
@@ -313,4 +313,44 @@ def test_column_panels_livejournal_shape():
     yref, absy = O.csr_spmv64(rp, ci, va, x)
     y, _ = A.spmv(x)
     _assert_close(y, yref, absy, TOL64, "lj panels")
+    A.close()
+
+
+def test_value_dictionary():
+    """matrices with at most 256 distinct values (pattern matrices: the reference assigns index % 13, spmv.cpp:417)
+    store one code byte per slot: image == mirror bit for bit, y bitwise identical to the plain layout (same values,
+    same order of operations), general real matrices fall back to the plain layout"""
+    nrows, ncols, rp, ci, va = synth.web_google_like(scale=0.05)
+    assert len(np.unique(va)) == 13
+    for dt in (np.float64, np.float32):
+        v = va.astype(dt)
+        x = O.x_vec_fast(ncols, "rand").astype(dt)
+        A0 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, v, steps_per_chunk=16, value_dict=0)
+        A1 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, v, steps_per_chunk=16)           # auto
+        assert A0.info.value_dict == 0 and A1.info.value_dict == 13                   # 0 is among the 13 values
+        assert A1.info.image_bytes < (0.45 if dt == np.float64 else 0.7) * A0.info.image_bytes    # 12 -> 5 and 8 -> 5 bytes per slot
+        mir = O.Cvr64(nrows, ncols, rp, ci, v, 16, use_dict=True)
+        img = A1.export_image()
+        assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc)
+        y0, _ = A0.spmv(x)
+        y1, _ = A1.spmv(x)
+        assert np.array_equal(y0.view(np.uint8), y1.view(np.uint8))
+        yref, absy = O.csr_spmv64(rp, ci, v, x)
+        _assert_close(y1, yref, absy + 1e-30, TOL32 if dt == np.float32 else TOL64, ("dict", dt))
+        A0.close()
+        A1.close()
+    # special bit patterns are values like any other: -0.0, inf, nan payloads, the all-ones pattern
+    nrows, ncols, rp, ci, va = CASES["uniform_2000"]
+    special = np.array([0.0, -0.0, 1.5, -2.25, np.inf], dtype=np.float64)
+    v = special[np.arange(len(ci)) % len(special)].copy()
+    v[::97] = np.frombuffer(np.uint64(0xFFFFFFFFFFFFFFFF).tobytes(), dtype=np.float64)[0]      # a NaN: all ones
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, v, steps_per_chunk=8)
+    assert A.info.value_dict == 6
+    mir = O.Cvr64(nrows, ncols, rp, ci, v, 8, use_dict=True)
+    assert np.array_equal(A.export_image()["image"], mir.image)
+    A.close()
+    # 300 distinct values: no dictionary
+    nrows, ncols, rp, ci, va = CASES["power_law_3000"]
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, (np.arange(len(ci)) % 300).astype(np.float64), steps_per_chunk=8)
+    assert A.info.value_dict == 0
     A.close()
