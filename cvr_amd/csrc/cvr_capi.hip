@@ -88,7 +88,7 @@ struct Part {
     int64_t  *d_nzb = nullptr;
     uint32_t *d_pad = nullptr;
     size_t    stream_bytes = 0;
-    int64_t   nrows = 0, nnz = 0, nchunks = 0, nshared = 0, yext = 0;
+    int64_t   nrows = 0, nnz = 0, nnz_span = 0, nchunks = 0, nshared = 0, yext = 0;
     int64_t   zoff = 0;        // panels: where this part's y_ext starts in the partial-sum buffer z
 
     void release_csr()
@@ -150,48 +150,6 @@ hipError_t run_spmv(const cvr_handle *h, const void *x, void *y, hipStream_t st)
 }
 
 }  // namespace
-
-// Value dictionary: the distinct bit patterns of the matrix values plus +0.0 (pad slots), sorted, when there are at
-// most kDictMax of them (pattern matrices: the reference gives them index % 13, spmv.cpp:417; Matrix Market says 1).
-// A general real matrix leaves after a few hundred values.  Row blocks are scanned by host threads.
-template <typename B>
-static bool find_dictionary(const B *vals, int64_t n0, int64_t n1, std::vector<B> &dict)
-{
-    int T = (int)std::thread::hardware_concurrency();
-    if (T > 32) T = 32;
-    if (T < 1 || n1 - n0 < (1 << 20)) T = 1;
-    std::vector<std::vector<B>> found((size_t)T);
-    std::vector<char>           over((size_t)T, 0);
-    auto scan = [&](int t) {
-        // open addressing over 1024 slots; the all-ones pattern marks an empty slot (and is handled separately)
-        std::vector<B> tab(1024, (B)~(B)0);
-        bool           has_ones = false;
-        size_t         cnt = 0;
-        const int64_t  lo = n0 + (n1 - n0) * t / T, hi = n0 + (n1 - n0) * (t + 1) / T;
-        for (int64_t j = lo; j < hi; j++) {
-            const B b = vals[j];
-            if (b == (B)~(B)0) { has_ones = true; continue; }
-            size_t hsh = (size_t)((uint64_t)b * 0x9E3779B97F4A7C15ull >> 54) & 1023;
-            while (tab[hsh] != (B)~(B)0 && tab[hsh] != b) hsh = (hsh + 1) & 1023;
-            if (tab[hsh] != b) { tab[hsh] = b; if (++cnt > (size_t)cvr::kDictMax) { over[(size_t)t] = 1; return; } }
-        }
-        for (B b : tab) if (b != (B)~(B)0) found[(size_t)t].push_back(b);
-        if (has_ones) found[(size_t)t].push_back((B)~(B)0);
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back(scan, t);
-    scan(0);
-    for (auto &x : th) x.join();
-    dict.clear();
-    dict.push_back(0);                                   // +0.0: the value of every pad slot
-    for (int t = 0; t < T; t++) {
-        if (over[(size_t)t]) return false;
-        dict.insert(dict.end(), found[(size_t)t].begin(), found[(size_t)t].end());
-    }
-    std::sort(dict.begin(), dict.end());
-    dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
-    return dict.size() <= (size_t)cvr::kDictMax;
-}
 
 extern "C" {
 
@@ -297,14 +255,12 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     nzb[(size_t)nchunks] = plan.nz_end;
     if (plan_s) *plan_s += now_s() - t0;
 
-    part.nrows = nrows; part.nnz = nz1 - nz0; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
+    part.nrows = nrows; part.nnz = nz1 - nz0; part.nnz_span = nz1; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
     const int G = S / 4;
-    part.stream_bytes = (size_t)nchunks * G * cvr::group_bytes(f32, h->d_dict != nullptr);
     cvr::DeviceImage &img = part.img;
     img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
     img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)plan.shared.size();
-    img.dict = h->d_dict; img.ndict = h->ndict;
-    img.xcd_swizzle = opt.xcd_swizzle != 0;
+    img.xcd_swizzle = opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
     img.stream_policy = opt.stream_policy > 0 ? opt.stream_policy : 0;
     img.gather_policy = opt.gather_policy > 0 ? opt.gather_policy : 0;
     img.depth = opt.gather_depth == 2 ? 2 : 1;
@@ -323,10 +279,6 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     HIP_TRY(hipMalloc(&part.d_va, vsz * std::max<size_t>(nnz_span, 1)));
     HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nchunks + 1)));
     HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nchunks, 1)));
-    if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
-        HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, std::max<size_t>(part.stream_bytes, 16), hipDeviceMallocUncached));
-    else
-        HIP_TRY(hipMalloc(&img.stream, std::max<size_t>(part.stream_bytes, 16)));
     HIP_TRY(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY(hipMalloc(&img.target, 64 * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
@@ -345,6 +297,19 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     if (!plan.shared.empty())
         HIP_TRY(hipMemcpyAsync(img.shared, plan.shared.data(), sizeof(cvr::Shared) * plan.shared.size(), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));   // the host staging vectors go out of scope; the caller may free its CSR
+    return CVR_OK;
+}
+
+// second half of build_part, once it is known whether the values go through a dictionary: the stream image
+static int finish_part(cvr_handle *h, Part &part)
+{
+    cvr::DeviceImage &img = part.img;
+    img.dict = h->d_dict; img.ndict = h->ndict;
+    part.stream_bytes = (size_t)part.nchunks * img.G * cvr::group_bytes(img.f32, h->d_dict != nullptr);
+    if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
+        HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, std::max<size_t>(part.stream_bytes, 16), hipDeviceMallocUncached));
+    else
+        HIP_TRY(hipMalloc(&img.stream, std::max<size_t>(part.stream_bytes, 16)));
     return CVR_OK;
 }
 
@@ -524,25 +489,6 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     CREATE_TRY(hipSetDevice(h->device));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const double t_up0 = now_s();
-    // value dictionary (value_dict: <0 auto, 0 off): one byte per slot instead of the value when the matrix has at most
-    // 256 distinct values -- 12 -> 5 bytes per slot for fp64 (profiles/r01_value_dictionary.log)
-    if (opt.value_dict != 0 && nrows > 0) {
-        const double  t0 = now_s();
-        const int64_t n0 = csr->row_ptr[0], n1 = csr->row_ptr[nrows];
-        std::vector<uint64_t> d64;
-        std::vector<uint32_t> d32;
-        const bool ok = f32 ? find_dictionary<uint32_t>(static_cast<const uint32_t *>(csr->vals), n0, n1, d32)
-                            : find_dictionary<uint64_t>(static_cast<const uint64_t *>(csr->vals), n0, n1, d64);
-        in.plan_s += now_s() - t0;
-        if (ok) {
-            h->ndict = (uint32_t)(f32 ? d32.size() : d64.size());
-            CREATE_TRY(hipMalloc(&h->d_dict, vsz * (size_t)cvr::kDictMax));
-            CREATE_TRY(hipMemsetAsync(h->d_dict, 0, vsz * (size_t)cvr::kDictMax, h->stream));
-            CREATE_TRY(hipMemcpyAsync(h->d_dict, f32 ? (const void *)d32.data() : (const void *)d64.data(), vsz * h->ndict, hipMemcpyHostToDevice, h->stream));
-            CREATE_TRY(hipStreamSynchronize(h->stream));
-        }
-    }
-    in.value_dict = (int32_t)h->ndict;
     h->parts.resize((size_t)P);
     if (P == 1) {
         rc = build_part(h, h->parts[0], nrows, ncols, csr->row_ptr, csr->col_idx, csr->vals, f32, opt, &in.plan_s);
@@ -592,6 +538,44 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
         in.yext_elems = nrows + 1;
         in.image_bytes += (int64_t)(sizeof(uint32_t) * (cmb_ptr.size() + cmb_idx.size()));
     }
+    // value dictionary (value_dict: <0 auto, 0 off): one code byte per slot instead of the value when the matrix has at
+    // most 256 distinct values -- 12 -> 5 bytes per slot for fp64 (profiles/r01_value_dictionary.log).  The distinct
+    // values are collected on the device from the uploaded CSR (a 40-MB scan takes microseconds there, milliseconds
+    // on the host).
+    if (opt.value_dict != 0 && in.nnz > 0) {
+        unsigned long long *d_tab = nullptr;
+        uint32_t           *d_flags = nullptr;
+        CREATE_TRY(hipMalloc(&d_tab, sizeof(unsigned long long) * 1024));
+        CREATE_TRY(hipMalloc(&d_flags, sizeof(uint32_t) * 2));
+        CREATE_TRY(hipMemsetAsync(d_tab, 0xff, sizeof(unsigned long long) * 1024, h->stream));
+        CREATE_TRY(hipMemsetAsync(d_flags, 0, sizeof(uint32_t) * 2, h->stream));
+        for (const Part &p : h->parts) CREATE_TRY(cvr::launch_dict_scan(p.d_va, p.nnz_span - p.nnz, p.nnz_span, f32, d_tab, d_flags, h->stream));
+        std::vector<unsigned long long> tab(1024);
+        uint32_t                        flags[2] = {0, 0};
+        CREATE_TRY(hipMemcpyAsync(tab.data(), d_tab, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost, h->stream));
+        CREATE_TRY(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
+        CREATE_TRY(hipStreamSynchronize(h->stream));
+        (void)hipFree(d_tab);
+        (void)hipFree(d_flags);
+        if (!(flags[0] & 1u)) {
+            std::vector<unsigned long long> d;
+            d.push_back(0);                                                  // +0.0: the value of every pad slot
+            for (unsigned long long b : tab) if (b != ~0ull) d.push_back(b);
+            if (flags[0] & 2u) d.push_back(f32 ? 0xffffffffull : ~0ull);     // the all-ones pattern occurs as a value
+            std::sort(d.begin(), d.end());
+            d.erase(std::unique(d.begin(), d.end()), d.end());
+            if (d.size() <= (size_t)cvr::kDictMax) {
+                h->ndict = (uint32_t)d.size();
+                std::vector<uint32_t> d32(d.begin(), d.end());
+                CREATE_TRY(hipMalloc(&h->d_dict, vsz * (size_t)cvr::kDictMax));
+                CREATE_TRY(hipMemsetAsync(h->d_dict, 0, vsz * (size_t)cvr::kDictMax, h->stream));
+                CREATE_TRY(hipMemcpyAsync(h->d_dict, f32 ? (const void *)d32.data() : (const void *)d.data(), vsz * h->ndict, hipMemcpyHostToDevice, h->stream));
+                CREATE_TRY(hipStreamSynchronize(h->stream));
+            }
+        }
+    }
+    in.value_dict = (int32_t)h->ndict;
+    for (Part &p : h->parts) { rc = finish_part(h, p); if (rc) { cvr_destroy(h); return rc; } }
     in.steps_per_chunk = h->parts[0].img.S;
     for (const Part &p : h->parts) {
         in.nchunks += p.nchunks; in.nshared += p.nshared; in.nslots += p.nchunks * 64 * p.img.S;

@@ -14,6 +14,8 @@
 // the column word, and the row a lane writes follows from the hand-out order.
 #include "cvr_kernels.h"
 
+#include <algorithm>
+
 namespace cvr {
 namespace {
 
@@ -189,7 +191,63 @@ __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__
     }
 }
 
+// Value-dictionary detection: every workgroup collects the distinct bit patterns of its slice of the values in an LDS
+// hash table and merges them into a global one (1024 slots, all-ones = empty; the all-ones pattern itself is reported
+// through flags bit 1).  More than kDictMax distinct patterns anywhere -> flags bit 0 (no dictionary).
+template <typename B>
+__global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ vals, long long n0, long long n1,
+                                                        unsigned long long *__restrict__ table, uint32_t *__restrict__ flags)
+{
+    constexpr unsigned long long kEmpty = ~0ull;
+    __shared__ unsigned long long tab[512];
+    __shared__ uint32_t           cnt, over;
+    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) tab[i] = kEmpty;
+    if (threadIdx.x == 0) { cnt = 0; over = 0; }
+    __syncthreads();
+    unsigned long long last = kEmpty;
+    for (long long j = n0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n1; j += (long long)gridDim.x * blockDim.x) {
+        if (__hip_atomic_load(&over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || (flags[0] & 1u)) break;
+        const B                  raw = vals[j];
+        const unsigned long long b = sizeof(B) == 4 && raw == (B)~(B)0 ? kEmpty : (unsigned long long)raw;
+        if (b == last) continue;
+        last = b;
+        if (b == kEmpty) { atomicOr(&flags[0], 2u); continue; }
+        uint32_t hsh = (uint32_t)((b * 0x9E3779B97F4A7C15ull) >> 55);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&tab[hsh], kEmpty, b);
+            if (old == b) break;
+            if (old == kEmpty) { if (atomicAdd(&cnt, 1u) + 1 > (uint32_t)kDictMax) over = 1; break; }
+            hsh = (hsh + 1) & 511u;
+            if (over) break;
+        }
+    }
+    __syncthreads();
+    if (over) { if (threadIdx.x == 0) atomicOr(&flags[0], 1u); return; }
+    for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) {
+        const unsigned long long b = tab[i];
+        if (b == kEmpty) continue;
+        uint32_t hsh = (uint32_t)((b * 0x9E3779B97F4A7C15ull) >> 54);
+        for (uint32_t probes = 0; probes < 1024; probes++) {
+            const unsigned long long old = atomicCAS(&table[hsh], kEmpty, b);
+            if (old == b) break;
+            if (old == kEmpty) { if (atomicAdd(&flags[1], 1u) + 1 > (uint32_t)kDictMax) atomicOr(&flags[0], 1u); break; }
+            hsh = (hsh + 1) & 1023u;
+            if (flags[0] & 1u) break;
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, unsigned long long *table, uint32_t *flags, hipStream_t st)
+{
+    if (n1 <= n0) return hipSuccess;
+    const int64_t n = n1 - n0;
+    const uint32_t blocks = (uint32_t)std::min<int64_t>(2048, (n + 256 * 16 - 1) / (256 * 16));
+    if (f32) hipLaunchKernelGGL(dict_scan_kernel<uint32_t>, dim3(blocks), dim3(256), 0, st, static_cast<const uint32_t *>(vals), (long long)n0, (long long)n1, table, flags);
+    else hipLaunchKernelGGL(dict_scan_kernel<uint64_t>, dim3(blocks), dim3(256), 0, st, static_cast<const uint64_t *>(vals), (long long)n0, (long long)n1, table, flags);
+    return hipGetLastError();
+}
 
 hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st)
 {

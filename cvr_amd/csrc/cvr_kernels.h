@@ -19,7 +19,7 @@ struct DeviceImage {
     uint8_t *target = nullptr;   // [nchunks][64]
     int64_t *shared = nullptr;   // [nshared][3] {row, c0, c1}
     uint32_t nshared = 0;
-    bool     xcd_swizzle = true;
+    int      xcd_swizzle = 1;       // 0 off, 1 contiguous chunk range per XCD, 2 additionally consecutive chunks per CU (experiment)
     int      stream_policy = 0;     // buffer-load cache policy of the matrix stream: 0 default, 2 nt, 16 sc1, 18 sc1+nt
     int      gather_policy = 0;     // ... of the x gather: 0, 2, 16
     int      depth = 1;             // groups the x gather runs ahead of the FMAs (1 or 2)
@@ -41,6 +41,10 @@ struct DeviceCsr {
 // CSR -> CVR64 (one wavefront per chunk).  *err_flag (device u32, zeroed by the caller) gets bit 0 if a
 // lane stream did not drain, bit 1 if stealing found no over-full lane, bit 2 if a value is missing from the dictionary.
 hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st);
+
+// value-dictionary detection over vals[n0, n1) on the device: `table` = 1024 u64 slots preset to all ones, flags[0] bit 0 =
+// more than kDictMax distinct values, bit 1 = the all-ones pattern occurs, flags[1] = entries in the table
+hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, unsigned long long *table, uint32_t *flags, hipStream_t st);
 
 // picks, per workgroup of kWavesPerBlock chunks, the window of img.win_elems consecutive columns that holds most
 // of its non-zeros (LDS histogram over coarse column bins); writes img.win_base

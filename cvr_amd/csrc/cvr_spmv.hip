@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // Cache-policy bits of a gfx950 buffer load (the `aux` immediate): sc0 = 1, nt = 2, sc1 = 16.
-constexpr int kPolDefault = 0, kPolNt = 2, kPolSc1 = 16;
+constexpr int kPolDefault = 0, kPolNt = 2;
 
 // Both the matrix stream and x are read through buffer descriptors: 32-bit offsets, the cache policy is an
 // immediate, and a load past num_records returns 0 without touching memory -- which lets the software
@@ -120,11 +120,18 @@ __device__ __forceinline__ T val_of(const Group<T, DICT> &g, int j, const T *dic
 
 __device__ __forceinline__ uint32_t col_of(const u32x4 c, int j) { return j == 0 ? c.x : j == 1 ? c.y : j == 2 ? c.z : c.w; }
 
-__device__ __forceinline__ uint32_t remap_block(uint32_t b, uint32_t nblocks_per_xcd, bool swz)
+__device__ __forceinline__ uint32_t remap_block(uint32_t b, uint32_t nblocks_per_xcd, int swz)
 {
     // blocks are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, "Workgroup dispatch"): give each
     // XCD one contiguous range of chunks so that neighbouring rows' x lines meet in one L2.  Speed only.
-    return swz ? (b & 7u) * nblocks_per_xcd + (b >> 3) : b;
+    if (swz == 0) return b;
+    const uint32_t xcd = b & 7u, j = b >> 3;
+    if (swz == 1) return xcd * nblocks_per_xcd + j;
+    // swz = 2 (experiment): within the XCD, blocks j, j+32, j+64, .. (one CU under round-robin placement) take
+    // consecutive chunks, so that the waves resident on a CU work on neighbouring rows and share x lines in its L1
+    const uint32_t per_cu = (nblocks_per_xcd + 31) / 32;
+    const uint32_t t = (j & 31u) * per_cu + (j >> 5);
+    return t < nblocks_per_xcd ? xcd * nblocks_per_xcd + t : 0xffffffffu / kWavesPerBlock;
 }
 
 
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t blk = remap_block(blockIdx.x, nblocks_per_xcd, swz != 0);
+    const uint32_t blk = remap_block(blockIdx.x, nblocks_per_xcd, swz);
     const uint32_t k = __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + wv);
     if (!kSync && k >= nchunks) return;
     const bool live = k < nchunks;
@@ -356,7 +363,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     if (img.nchunks == 0) return hipSuccess;
     const uint32_t nblocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const uint32_t per_xcd = (nblocks + 7) / 8;
-    const uint32_t grid = img.xcd_swizzle ? per_xcd * 8 : nblocks;
+    const uint32_t grid = img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;
     const dim3     block(kLanes * kWavesPerBlock);
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
     if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
@@ -367,7 +374,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_LAUNCH(T, SP, D, W, DI)                                                                               \
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
-                       img.xcd_swizzle ? 1 : 0, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
+                       img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
                        static_cast<const T *>(img.dict), img.ndict)
 #define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_LAUNCH(T, SP, D, W, true); else CVR_LAUNCH(T, SP, D, W, false); } while (0)
 #define CVR_PICK_W(T, SP, D)     do { if (use_win) CVR_PICK_DI(T, SP, D, true); else CVR_PICK_DI(T, SP, D, false); } while (0)

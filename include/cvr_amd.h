@@ -62,7 +62,8 @@ typedef struct {
     int32_t steps_per_chunk;   /* S: lane-stream length of one chunk, multiple of 4; 0 = auto  */
     int64_t split_threshold;   /* rows with more remaining nnz than this may be cut at a chunk */
                                /* boundary; 0 = default (16*S)                                 */
-    int32_t xcd_swizzle;       /* 1 (default when <0): contiguous chunk ranges per XCD         */
+    int32_t xcd_swizzle;       /* 1 (default when <0): contiguous chunk ranges per XCD; 0 off; */
+                               /* 2: also consecutive chunks per CU (measured within +-2 %)    */
     int32_t x_window;          /* values of x each workgroup stages in LDS with coalesced loads */
                                /* and serves its gathers from; 0 = off (<0 = default = off)    */
     /* tuning / profiling knobs (tools/sweep.py); 0 = default */
