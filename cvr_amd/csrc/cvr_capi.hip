@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -215,10 +216,22 @@ int64_t cvr_plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_
 
 static int pick_steps(int64_t nslots_est)
 {
-    // S = 32 (2 048-slot chunks, 24.6-KB stream per wavefront) unless that leaves fewer than 8 wavefronts per CU.
-    // Measured: web-Google S = 8..48 within 2 % (profiles/r01_steps_threshold_depth_sweep.log); LiveJournal shape
-    // S = 16/32 800 us vs S = 128 856 us; banded S = 32..128 within noise (profiles/r01_steps_large_matrices.log).
-    return nslots_est / (64 * 32) >= 256 * 8 ? 32 : 16;
+    // One wavefront per chunk, all of them resident at once when there are few: the kernel then lasts as long as the CU
+    // with the most chunks, so S is chosen to make chunks / 256 CUs land just below an integer (web-Google: S = 48 ->
+    // 1 751 chunks = 6.84 per CU, 32.4 us; S = 64 -> 5.1 per CU, 35.7 us; profiles/r01_y_staging.log).  Large matrices
+    // run many rounds and take S = 32 (profiles/r01_steps_large_matrices.log).
+    const double kCus = 256.0;
+    if ((double)nslots_est / (64.0 * 32.0) > kCus * 24.0) return 32;
+    int    best = 16;
+    double best_score = -1;
+    for (int S = 64; S >= 16; S -= 4) {
+        const double per_cu = ((double)nslots_est * 1.004 / (64.0 * S) + 1.0) / kCus;
+        if (per_cu < 4.0 && S > 16) continue;                      // too few wavefronts per CU to cover the gather latency
+        const double fill = per_cu / std::ceil(per_cu + 0.04);     // + 0.04: margin for the planner's pad segments
+        const double score = fill - (S < 32 ? 0.02 : 0.0);         // slightly prefer fewer, longer chunks
+        if (score > best_score) { best_score = score; best = S; }
+    }
+    return best;
 }
 
 // plans one part on the host, allocates its device image and uploads its CSR (asynchronously on h->stream)
@@ -269,7 +282,7 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     // misses of the scattered columns, which a contiguous window cannot hold, and the LDS it takes costs occupancy.
     int64_t win = opt.x_window < 0 ? 0 : opt.x_window;
     if (win > ncols + 1) win = ncols + 1;
-    if (win > 16384) win = 16384;                     // 128 KiB of fp64 + the steal slots stay under 160 KiB
+    if (win > 16384) win = 16384;                     // 128 KiB of fp64 + steal slots, staged row sums and dictionary stay under 160 KiB
     img.win_elems = (uint32_t)win;
     if (opt.debug_col_mask) img.col_mask = (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
 

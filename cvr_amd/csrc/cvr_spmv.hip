@@ -153,7 +153,7 @@ template <typename T> struct ChunkState {
 template <typename T, bool WIN, bool DICT>
 __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT> &Q, const X4<T> &xq, T *__restrict__ yext,
                                           T *slot_lane, uint32_t row_first, uint32_t nseg, uint32_t head_dest,
-                                          uint32_t last_dest, const T *dict)
+                                          uint32_t last_dest, const T *dict, T *ystage, bool staged)
 {
 #pragma unroll
     for (int j = 0; j < kGroupSteps; j++) {
@@ -164,8 +164,12 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
         if (m) {
             if (!s.tail) {
                 if (fl) {
-                    const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
-                    store_y(yext + dst, s.acc);
+                    if (staged) {
+                        ystage[s.cur] = s.acc;           // written out coalesced at the end of the chunk
+                    } else {
+                        const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
+                        store_y(yext + dst, s.acc);
+                    }
                     s.acc = 0;
                     const uint32_t nx = s.fed + lane_rank(m);
                     if (nx < nseg) s.cur = nx; else s.feeding = 0;   // rows exhausted: turns stealer
@@ -190,10 +194,12 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
 {
     constexpr int  GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     constexpr bool kSync = WIN || (DICT && kWavesPerBlock > 1);      // LDS filled by other waves of the workgroup
-    // LDS: [waves][64] steal slots, the value dictionary (DICT), then the x window and its zero slot (WIN)
+    // LDS: [waves][64] steal slots, [waves][kYStage] staged row sums, the value dictionary (DICT), then the x window and
+    // its zero slot (WIN)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     T *const slots = reinterpret_cast<T *>(smem);
-    T *const dict = slots + kWavesPerBlock * kLanes;
+    T *const ystage_all = slots + kWavesPerBlock * kLanes;
+    T *const dict = ystage_all + kWavesPerBlock * kYStage;
     T *const win = dict + (DICT ? kDictMax : 0);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -241,6 +247,11 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     s.own = 0;
     s.tail = s.fed == nseg;
     T *slot_lane = &slots[wv * kLanes + lane];
+    // Row sums go to LDS and leave as coalesced stores at the end of the chunk (its rows are consecutive): the scattered
+    // 8-byte stores they replace cost 12 % of the kernel (profiles/r01_y_staging.log).  A chunk of more than kYStage
+    // segments (very short rows) stores directly.
+    T *const   ystage = ystage_all + wv * kYStage;
+    const bool staged = nseg <= (uint32_t)kYStage;
 #pragma unroll
     for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL, WIN>(rx, win, Q[i].c, cmask, wbase, wn);
 
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     for (int g = 0; g < G; g++) {
         const Group<T, DICT> Qn = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)(g + DEPTH + 1) * GB);
         const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn);
-        sum_group<T, WIN, DICT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict);
+        sum_group<T, WIN, DICT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged);
 #pragma unroll
         for (int i = 0; i < DEPTH; i++) Q[i] = Q[i + 1];
         Q[DEPTH] = Qn;
@@ -263,8 +274,19 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     if (tg != lane) __hip_atomic_fetch_add(&slots[wv * kLanes + tg], s.acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (s.own) {
-        const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
-        store_y(yext + dst, *slot_lane);
+        if (staged) {
+            ystage[s.cur] = *slot_lane;
+        } else {
+            const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
+            store_y(yext + dst, *slot_lane);
+        }
+    }
+    if (staged) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (uint32_t i = lane; i < nseg; i += kLanes) {
+            const uint32_t dst = i == 0 ? head_dest : i == nseg - 1 ? last_dest : row_first + i;
+            store_y(yext + dst, ystage[i]);
+        }
     }
 }
 
@@ -369,7 +391,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
     const bool   use_win = img.win_elems > 0 && img.win_base != nullptr;
     const bool   use_dict = img.dict != nullptr;
-    const size_t lds = (size_t)(kWavesPerBlock * kLanes + (use_dict ? kDictMax : 0) + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
+    const size_t lds = (size_t)(kWavesPerBlock * (kLanes + kYStage) + (use_dict ? kDictMax : 0) + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
     // template parameters: <value type, stream cache policy, gather cache policy, gather run-ahead, LDS window, dictionary>
 #define CVR_LAUNCH(T, SP, D, W, DI)                                                                               \
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
