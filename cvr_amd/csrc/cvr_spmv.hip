@@ -2,21 +2,22 @@
 //
 // The reference's spmv_compute_kernel (/root/reference/spmv.cpp:1016-1667) re-derived for 64 lanes:
 //   * one loop instead of the five hand-split phases A-E (spmv.cpp:1167-1629): each step is
-//     acc += val * x[col] (spmv.cpp:1226-1233), the matrix streams arrive as 16-B-per-lane coalesced
-//     loads (1 KiB per wave instruction; the reference: one 64-B load per 8 lanes), the x gather
-//     (_mm512_i32logather_pd, spmv.cpp:1227) is one global_load_dwordx2 per lane, issued one
-//     group (4 steps) ahead of its use in place of the software prefetch of spmv.cpp:1183-1190;
-//   * the scalar record-servicing `while` (spmv.cpp:1197-1224) is replaced by bit 31 of the column
-//     word: the lanes whose segment ends at this step form a __ballot mask; each stores its row sum
-//     (spmv.cpp:1204-1205 get_simd/set_simd_zero) and takes segment fed + rank-in-mask, the same
-//     hand-out order the converter used, so no write-back ids are read from memory;
-//   * the steal part (spmv.cpp:1579-1629) runs the SAME loop; only the write-back differs: a lane whose
-//     own row ends after the last segment was handed out parks the sum in its LDS slot (t_rets,
-//     spmv.cpp:1607-1616), lanes that stole add their partial sums to the victim's slot at the end
-//     (tail records, spmv.cpp:1633-1638: ds_add here), and the owners store the slots;
-//   * no `#pragma omp atomic` on y (spmv.cpp:1280-1282, 1640-1649) and no zeroing of y
-//     (spmv.cpp:1026-1031): chunks end at row boundaries; the few rows cut over chunks go to carry
-//     slots behind y and are summed in chunk order by fixup_kernel (bitwise reproducible).
+//     acc += val * x[col] (spmv.cpp:1226-1233).  The matrix stream arrives as 16-B-per-lane coalesced buffer loads
+//     (1 KiB per wave instruction; the reference: one 64-B load per 8 lanes) two groups of 4 steps ahead; the x gather
+//     (_mm512_i32logather_pd, spmv.cpp:1227) is one buffer_load_dwordx2 per lane, issued one group ahead of its use in
+//     place of the software prefetch of spmv.cpp:1183-1190; matrices with <= 256 distinct values stream one code byte
+//     per slot and look the value up in LDS;
+//   * the scalar record-servicing `while` (spmv.cpp:1197-1224) is replaced by bit 31 of the column word: the lanes
+//     whose segment ends at this step form a __ballot mask; each hands over its row sum (spmv.cpp:1204-1205
+//     get_simd/set_simd_zero) and takes segment fed + rank-in-mask, the same hand-out order the converter used, so no
+//     write-back ids are read from memory.  The row sums are staged in LDS by segment ordinal and leave as coalesced
+//     stores at the end of the chunk (its rows are consecutive);
+//   * the steal part (spmv.cpp:1579-1629) runs the SAME loop; only the write-back differs: a lane whose own row ends
+//     after the last segment was handed out parks the sum in its LDS slot (t_rets, spmv.cpp:1607-1616), lanes that
+//     stole add their partial sums to the victim's slot at the end (tail records, spmv.cpp:1633-1638: ds_add here);
+//   * no `#pragma omp atomic` on y (spmv.cpp:1280-1282, 1640-1649) and no zeroing of y (spmv.cpp:1026-1031): chunks
+//     end at row boundaries; the few rows cut over chunks go to carry slots behind y and are summed in chunk order by
+//     fixup_kernel (bitwise reproducible); column panels add their partial sums in panel order (combine_kernel).
 #include "cvr_kernels.h"
 
 namespace cvr {
@@ -30,8 +31,6 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // Cache-policy bits of a gfx950 buffer load (the `aux` immediate): sc0 = 1, nt = 2, sc1 = 16.
 constexpr int kPolDefault = 0, kPolNt = 2;
