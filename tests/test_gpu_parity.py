@@ -349,6 +349,13 @@ def test_value_dictionary():
     mir = O.Cvr64(nrows, ncols, rp, ci, v, 8, use_dict=True)
     assert np.array_equal(A.export_image()["image"], mir.image)
     A.close()
+    v32 = special[np.arange(len(ci)) % len(special)].astype(np.float32)
+    v32[::89] = np.frombuffer(np.uint32(0xFFFFFFFF).tobytes(), dtype=np.float32)[0]
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, v32, steps_per_chunk=8)
+    assert A.info.value_dict == 6
+    mir = O.Cvr64(nrows, ncols, rp, ci, v32, 8, use_dict=True)
+    assert np.array_equal(A.export_image()["image"], mir.image)
+    A.close()
     # 300 distinct values: no dictionary
     nrows, ncols, rp, ci, va = CASES["power_law_3000"]
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, (np.arange(len(ci)) % 300).astype(np.float64), steps_per_chunk=8)
