@@ -119,9 +119,11 @@ struct cvr_handle {
     bool              converted = false;
     cvr_info          info{};
     std::vector<Part> parts;            // 1 part, or one per column panel
-    // column panels: y[r] = sum over the panels that hold row r of z[cmb_idx[k]], k in cmb_ptr[r] .. cmb_ptr[r+1]
+    // column panels: partial sums z (the panels' y_ext buffers, concatenated), per panel the rows of its sub-rows, and
+    // where each block of kCombineRows rows starts in every panel (combine_kernel)
     void     *d_z = nullptr;
-    uint32_t *d_cmb_ptr = nullptr, *d_cmb_idx = nullptr;
+    uint32_t *d_rows = nullptr, *d_block_off = nullptr;
+    cvr::CombinePanel *d_cpanels = nullptr;
     void     *d_dict = nullptr;           // value dictionary (sorted by bit pattern) shared by all parts, or null
     uint32_t  ndict = 0;
     cvr::FixPart *d_fixparts = nullptr;   // panels: the fix-up of every panel in one launch
@@ -147,7 +149,7 @@ hipError_t run_spmv(const cvr_handle *h, const void *x, void *y, hipStream_t st)
     }
     hipError_t e = cvr::launch_fixup_multi(h->d_fixparts, (uint32_t)h->parts.size(), h->max_nshared, h->vsz == 4, st);
     if (e != hipSuccess) return e;
-    return cvr::launch_combine(h->d_cmb_ptr, h->d_cmb_idx, h->d_z, y, (uint32_t)h->info.nrows, h->vsz == 4, st);
+    return cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st);
 }
 
 }  // namespace
@@ -511,12 +513,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
         const double t0 = now_s();
         PanelSplit   sp;
         split_panels(*csr, P, sp);
-        // where row r's partial sums stand: part p's y_ext starts at zoff[p]; compact sub-row u of part p is row rows[p][u]
-        std::vector<uint32_t> cmb_ptr((size_t)nrows + 1, 0);
-        for (int p = 0; p < P; p++) for (size_t u = 0; u < sp.rows[(size_t)p].size(); u++) cmb_ptr[(size_t)sp.rows[(size_t)p][u] + 1]++;
-        for (int64_t r = 0; r < nrows; r++) cmb_ptr[(size_t)r + 1] += cmb_ptr[(size_t)r];
         in.plan_s += now_s() - t0;
-        int64_t zoff = 0;
+        int64_t zoff = 0, nsub = 0;
         for (int p = 0; p < P; p++) {
             Part &part = h->parts[(size_t)p];
             rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
@@ -524,21 +522,40 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
             if (rc) { cvr_destroy(h); return rc; }
             part.zoff = zoff;
             zoff += part.yext;
+            nsub += part.nrows;
         }
         if (zoff >= (int64_t)0xffffffffu) { cvr_destroy(h); return fail(CVR_ERR_INVALID, "partial-sum buffer too large for 32-bit indices"); }
-        const double t1 = now_s();
-        std::vector<uint32_t> cmb_idx((size_t)cmb_ptr[(size_t)nrows]), fill(cmb_ptr.begin(), cmb_ptr.end() - 1);
-        for (int p = 0; p < P; p++) {                 // panel order inside a row: the combine adds in panel order
+        // combine tables: the rows of every panel's sub-rows (concatenated) and, per panel, where each block of
+        // kCombineRows rows starts among them
+        const double   t1 = now_s();
+        const uint32_t nblocks = (uint32_t)((nrows + cvr::kCombineRows - 1) / cvr::kCombineRows);
+        std::vector<uint32_t> block_off((size_t)P * (nblocks + 1));
+        for (int p = 0; p < P; p++) {
             const Raw<uint32_t> &rows = sp.rows[(size_t)p];
-            for (size_t u = 0; u < rows.size(); u++) cmb_idx[(size_t)fill[rows[u]]++] = (uint32_t)(h->parts[(size_t)p].zoff + (int64_t)u);
+            uint32_t            *bo = block_off.data() + (size_t)p * (nblocks + 1);
+            size_t               u = 0;
+            for (uint32_t b2 = 0; b2 <= nblocks; b2++) {
+                const uint64_t lim = (uint64_t)b2 * cvr::kCombineRows;
+                while (u < rows.size() && rows[u] < lim) u++;
+                bo[b2] = (uint32_t)u;
+            }
         }
         in.plan_s += now_s() - t1;
         CREATE_TRY(hipMalloc(&h->d_z, vsz * (size_t)std::max<int64_t>(zoff, 1)));
-        CREATE_TRY(hipMalloc(&h->d_cmb_ptr, sizeof(uint32_t) * ((size_t)nrows + 1)));
-        CREATE_TRY(hipMalloc(&h->d_cmb_idx, sizeof(uint32_t) * std::max<size_t>(cmb_idx.size(), 1)));
+        CREATE_TRY(hipMalloc(&h->d_rows, sizeof(uint32_t) * (size_t)std::max<int64_t>(nsub, 1)));
+        CREATE_TRY(hipMalloc(&h->d_block_off, sizeof(uint32_t) * block_off.size()));
+        CREATE_TRY(hipMalloc(&h->d_cpanels, sizeof(cvr::CombinePanel) * (size_t)P));
         CREATE_TRY(hipMemsetAsync(h->d_z, 0, vsz * (size_t)std::max<int64_t>(zoff, 1), h->stream));
-        CREATE_TRY(hipMemcpyAsync(h->d_cmb_ptr, cmb_ptr.data(), sizeof(uint32_t) * cmb_ptr.size(), hipMemcpyHostToDevice, h->stream));
-        if (!cmb_idx.empty()) CREATE_TRY(hipMemcpyAsync(h->d_cmb_idx, cmb_idx.data(), sizeof(uint32_t) * cmb_idx.size(), hipMemcpyHostToDevice, h->stream));
+        std::vector<cvr::CombinePanel> cps((size_t)P);
+        int64_t roff = 0;
+        for (int p = 0; p < P; p++) {
+            const Raw<uint32_t> &rows = sp.rows[(size_t)p];
+            if (rows.size()) CREATE_TRY(hipMemcpyAsync(h->d_rows + roff, rows.data(), sizeof(uint32_t) * rows.size(), hipMemcpyHostToDevice, h->stream));
+            cps[(size_t)p] = cvr::CombinePanel{static_cast<uint8_t *>(h->d_z) + (size_t)h->parts[(size_t)p].zoff * vsz, h->d_rows + roff};
+            roff += (int64_t)rows.size();
+        }
+        CREATE_TRY(hipMemcpyAsync(h->d_block_off, block_off.data(), sizeof(uint32_t) * block_off.size(), hipMemcpyHostToDevice, h->stream));
+        CREATE_TRY(hipMemcpyAsync(h->d_cpanels, cps.data(), sizeof(cvr::CombinePanel) * (size_t)P, hipMemcpyHostToDevice, h->stream));
         std::vector<cvr::FixPart> fp((size_t)P);
         for (int p = 0; p < P; p++) {
             const Part &part = h->parts[(size_t)p];
@@ -549,7 +566,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
         CREATE_TRY(hipMemcpyAsync(h->d_fixparts, fp.data(), sizeof(cvr::FixPart) * (size_t)P, hipMemcpyHostToDevice, h->stream));
         CREATE_TRY(hipStreamSynchronize(h->stream));
         in.yext_elems = nrows + 1;
-        in.image_bytes += (int64_t)(sizeof(uint32_t) * (cmb_ptr.size() + cmb_idx.size()));
+        in.image_bytes += (int64_t)(sizeof(uint32_t) * ((size_t)nsub + block_off.size()));
     }
     // value dictionary (value_dict: <0 auto, 0 off): one code byte per slot instead of the value when the matrix has at
     // most 256 distinct values -- 12 -> 5 bytes per slot for fp64 (profiles/r01_value_dictionary.log).  The distinct
@@ -654,7 +671,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Part &p : h->parts) p.release_all();
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
-    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_cmb_ptr, (void *)h->d_cmb_idx, (void *)h->d_fixparts, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return CVR_OK;

@@ -57,8 +57,11 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 struct FixPart { const int64_t *shared; void *yext; uint32_t nshared, nrows; };
 hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t max_nshared, bool f32, hipStream_t st);
 
-// column panels: y[r] = sum_{k in cmb_ptr[r] .. cmb_ptr[r+1]} z[cmb_idx[k]], in that order (bitwise reproducible)
-hipError_t launch_combine(const uint32_t *cmb_ptr, const uint32_t *cmb_idx, const void *z, void *y, uint32_t nrows, bool f32, hipStream_t st);
+// column panels: y = sum over the panels, in panel order, of their partial sums.  Panel p's partial sum u stands at z[u]
+// and belongs to row rows[u] (ascending); block_off[p * (nblocks + 1) + b] = first u of panel p with rows[u] >= b * kCombineRows.
+constexpr int kCombineRows = 1024;
+struct CombinePanel { const void *z; const uint32_t *rows; };
+hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st);
 
 // 16-B-per-lane streaming copy (roofline calibration)
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st);

@@ -307,16 +307,26 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void fixup_kernel(const in
     if (lane == 0) yext[row] = carry[2 * c0 + 1] + v;
 }
 
-// column panels: one lane per row adds the row's partial sums in panel order
+// column panels: a workgroup owns kCombineRows consecutive rows.  For every panel in turn it streams the panel's
+// partial sums of those rows (a contiguous range of the panel's y_ext: the panel's rows are sorted) together with their
+// row numbers and adds them into LDS accumulators; a row occurs at most once per panel, and a barrier separates the
+// panels, so the additions happen in panel order (bitwise reproducible).  All global accesses are coalesced streams.
 template <typename T>
-__global__ __launch_bounds__(256) void combine_kernel(const uint32_t *__restrict__ cmb_ptr, const uint32_t *__restrict__ cmb_idx,
-                                                      const T *__restrict__ z, T *__restrict__ y, uint32_t nrows)
+__global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off,
+                                                      uint32_t nblocks, T *__restrict__ y, uint32_t nrows)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
-    T sum = 0;
-    for (uint32_t k = cmb_ptr[r], e = cmb_ptr[r + 1]; k < e; k++) sum += z[cmb_idx[k]];
-    y[r] = sum;
+    __shared__ T acc[kCombineRows];
+    const uint32_t b = blockIdx.x, r0 = b * kCombineRows;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kCombineRows; i += blockDim.x) acc[i] = 0;
+    __syncthreads();
+    for (uint32_t p = 0; p < npanels; p++) {
+        const CombinePanel cp = panels[p];
+        const uint32_t     lo = block_off[(size_t)p * (nblocks + 1) + b], hi = block_off[(size_t)p * (nblocks + 1) + b + 1];
+        const T           *z = static_cast<const T *>(cp.z);
+        for (uint32_t u = lo + threadIdx.x; u < hi; u += blockDim.x) acc[cp.rows[u] - r0] += z[u];
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kCombineRows && r0 + i < nrows; i += blockDim.x) y[r0 + i] = acc[i];
 }
 
 // plain streaming copy: the achievable-HBM-rate yardstick beside the 8 TB/s nominal peak.  Four independent
@@ -363,12 +373,12 @@ hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t ma
     return hipGetLastError();
 }
 
-hipError_t launch_combine(const uint32_t *cmb_ptr, const uint32_t *cmb_idx, const void *z, void *y, uint32_t nrows, bool f32, hipStream_t st)
+hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st)
 {
     if (nrows == 0) return hipSuccess;
-    const dim3 grid((nrows + 255) / 256), block(256);
-    if (f32) hipLaunchKernelGGL(combine_kernel<float>, grid, block, 0, st, cmb_ptr, cmb_idx, static_cast<const float *>(z), static_cast<float *>(y), nrows);
-    else hipLaunchKernelGGL(combine_kernel<double>, grid, block, 0, st, cmb_ptr, cmb_idx, static_cast<const double *>(z), static_cast<double *>(y), nrows);
+    const uint32_t nblocks = (nrows + kCombineRows - 1) / kCombineRows;
+    if (f32) hipLaunchKernelGGL(combine_kernel<float>, dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<float *>(y), nrows);
+    else hipLaunchKernelGGL(combine_kernel<double>, dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<double *>(y), nrows);
     return hipGetLastError();
 }
 
