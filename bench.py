@@ -275,6 +275,8 @@ def main():
             "data": "synthetic" if source.startswith("synthetic") else "real",
             "config": {"workload": f"{source}: {nrows}x{ncols}, nnz {nnz}, fp64, y = A x with A (CVR64 image), x, y resident in HBM",
                        "rows_per_gpu": [int(v) for v in np.diff(bounds)],
+                       "nnz_per_gpu": [int(rp[bounds[p + 1]] - rp[bounds[p]]) for p in range(world)],
+                       "nnz_imbalance_max_over_mean": float(max(int(rp[bounds[p + 1]] - rp[bounds[p]]) for p in range(world)) * world / max(nnz, 1)),
                        "steps_per_chunk": int(info.steps_per_chunk), "chunks_rank0": int(info.nchunks),
                        "rows_cut_rank0": int(info.nshared), "col_panels": int(info.col_panels),
                        "value_dictionary_entries": int(info.value_dict),
