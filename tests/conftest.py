@@ -21,4 +21,9 @@ def _build_oracle():
     if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], check=True,
                        stdout=subprocess.DEVNULL)
+    # the product library (hipcc cross-compiles gfx950 without a GPU); normally built by __graft_entry__.build()
+    prod = os.path.join(ROOT, "cvr_amd", "libcvr_amd.so")
+    if not os.path.exists(prod) or not os.path.exists(os.path.join(ROOT, "spmv.cvr")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "cvr_amd", "csrc"), "all"], check=True,
+                       stdout=subprocess.DEVNULL)
     yield
