@@ -421,29 +421,36 @@ static void split_panels_t(const cvr_csr_view &v, int P, PanelSplit &out)
     }
 }
 
-// How many bytes of x does a block of consecutive rows touch?  (What one XCD works on at a time is of that order.)
-// Counted in 128-byte lines over up to four evenly spaced windows of 65 536 rows; the largest is returned.  A banded
-// matrix touches little more than the window itself, a scattered one most of x.
-static double window_footprint_bytes(const cvr_csr_view &v)
+// How does a block of consecutive rows use x?  (What one XCD works on at a time is of that order.)  Up to four evenly
+// spaced windows of 65 536 rows are looked at; for the one with the most non-zeros: the bytes of x it touches, counted
+// in 128-byte lines, and how many of its gathers fall on a line for the first time.  A banded matrix touches little
+// more than the window itself; hub-dominated rows (R-MAT) touch much but re-use every line dozens of times, so the L2s
+// already serve them; scattered columns with little re-use are what column panels help.
+static void window_footprint(const cvr_csr_view &v, double *bytes, double *first_touch_ratio)
 {
+    *bytes = 0; *first_touch_ratio = 0;
     const int64_t nrows = v.nrows, W = std::min<int64_t>(65536, nrows);
-    if (W <= 0) return 0;
+    if (W <= 0) return;
     const int64_t per_line = v.is_f32 ? 32 : 16, nlines = v.ncols / per_line + 1;
     std::vector<uint64_t> bits((size_t)(nlines / 64 + 1));
-    double worst = 0;
+    int64_t best_refs = -1;
     for (int w = 0; w < 4; w++) {
         const int64_t r0 = (nrows - W) * w / 3;
-        std::fill(bits.begin(), bits.end(), 0);
-        int64_t lines = 0;
-        for (int64_t j = v.row_ptr[r0]; j < v.row_ptr[r0 + W]; j++) {
-            const int64_t  l = v.col_idx[j] / per_line;
-            const uint64_t m = 1ull << (l & 63);
-            if (!(bits[(size_t)(l >> 6)] & m)) { bits[(size_t)(l >> 6)] |= m; lines++; }
+        const int64_t refs = v.row_ptr[r0 + W] - v.row_ptr[r0];
+        if (refs > best_refs) {
+            best_refs = refs;
+            std::fill(bits.begin(), bits.end(), 0);
+            int64_t lines = 0;
+            for (int64_t j = v.row_ptr[r0]; j < v.row_ptr[r0 + W]; j++) {
+                const int64_t  l = v.col_idx[j] / per_line;
+                const uint64_t m = 1ull << (l & 63);
+                if (!(bits[(size_t)(l >> 6)] & m)) { bits[(size_t)(l >> 6)] |= m; lines++; }
+            }
+            *bytes = (double)lines * 128.0;
+            *first_touch_ratio = refs > 0 ? (double)lines / (double)refs : 0.0;
         }
-        worst = std::max(worst, (double)lines * 128.0);
         if (nrows == W) break;
     }
-    return worst;
 }
 
 static void split_panels(const cvr_csr_view &v, int P, PanelSplit &out)
@@ -472,14 +479,19 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     const bool    f32 = csr->is_f32 != 0;
     const size_t  vsz = f32 ? 4 : 8;
     // column panels: asked for, or (col_panels < 0: auto) when x is several times the 4-MiB L2 of an XCD AND a block of
-    // consecutive rows really touches that much of it (a banded matrix does not): one panel per ~4.5 MB of x
+    // consecutive rows really touches that much of it without re-using the lines (a banded matrix touches little, R-MAT's
+    // hub rows re-use every line dozens of times: profiles/r01_panel_rule_windows.log): one panel per ~4.5 MB of x
     // (profiles/r01_column_panels_livejournal_sweep.log); never for matrices whose x nearly fits (web-Google:
     // profiles/r01_column_panel_probe.log)
     int P = opt.col_panels;
     if (P < 0) {
         const double xb = (double)ncols * (double)vsz;
         P = 1;
-        if (xb >= 24e6 && window_footprint_bytes(*csr) > 8e6) P = (int)(xb / 4.5e6 + 0.5);   // scattered columns, x >> L2
+        if (xb >= 24e6) {
+            double fp = 0, ratio = 0;
+            window_footprint(*csr, &fp, &ratio);
+            if (fp > 8e6 && ratio > 0.10) P = (int)(xb / 4.5e6 + 0.5);   // x >> L2, scattered columns, little re-use of a line
+        }
     }
     if (P < 1) P = 1;
     if (P > 64) P = 64;
