@@ -26,7 +26,7 @@ class CsrView(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
                 ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("stream_policy", C.c_int32),
-                ("gather_policy", C.c_int32), ("gather_depth", C.c_int32), ("debug_col_mask", C.c_int32),
+                ("reserved0", C.c_int32), ("gather_depth", C.c_int32), ("debug_col_mask", C.c_int32),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32)]
 
 
@@ -183,7 +183,7 @@ class CvrMatrix:
     """One matrix (or row shard) resident on one GPU: cvr_create + cvr_preprocess, then spmv()."""
 
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
-                 xcd_swizzle=-1, x_window=-1, nontemporal=0, keep_csr=False, debug_col_mask=0, gather_policy=0, depth=0,
+                 xcd_swizzle=-1, x_window=-1, nontemporal=0, keep_csr=False, debug_col_mask=0, depth=0,
                  col_panels=-1, value_dict=-1):
         self._h = C.c_void_p()
         rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
@@ -199,7 +199,7 @@ class CvrMatrix:
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
         opt.xcd_swizzle, opt.x_window, opt.col_panels, opt.value_dict = xcd_swizzle, x_window, col_panels, value_dict
         # tuning / profiling knobs (tools/sweep.py)
-        opt.stream_policy, opt.gather_policy, opt.gather_depth, opt.debug_col_mask = nontemporal, gather_policy, depth, debug_col_mask
+        opt.stream_policy, opt.gather_depth, opt.debug_col_mask = nontemporal, depth, debug_col_mask
         rc = lib().cvr_create(C.byref(self._h), C.byref(view), C.byref(opt))
         if rc:
             self._h = C.c_void_p()

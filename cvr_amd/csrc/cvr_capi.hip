@@ -277,7 +277,6 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)plan.shared.size();
     img.xcd_swizzle = opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
     img.stream_policy = opt.stream_policy > 0 ? opt.stream_policy : 0;
-    img.gather_policy = opt.gather_policy > 0 ? opt.gather_policy : 0;
     img.depth = opt.gather_depth == 2 ? 2 : 1;
     // LDS window of x per workgroup: off by default.  Measured on MI355X (profiles/r01_lds_window_sweep.log): the
     // gathers it absorbs are the cheap ones (L1/L2 hits near the diagonal); the kernel's time is set by the L2

@@ -20,8 +20,7 @@ struct DeviceImage {
     int64_t *shared = nullptr;   // [nshared][3] {row, c0, c1}
     uint32_t nshared = 0;
     int      xcd_swizzle = 1;       // 0 off, 1 contiguous chunk range per XCD, 2 additionally consecutive chunks per CU (experiment)
-    int      stream_policy = 0;     // buffer-load cache policy of the matrix stream: 0 default, 2 nt, 16 sc1, 18 sc1+nt
-    int      gather_policy = 0;     // ... of the x gather: 0, 2, 16
+    int      stream_policy = 0;     // buffer-load cache policy of the matrix stream: 0 default, 2 nt
     int      depth = 1;             // groups the x gather runs ahead of the FMAs (1 or 2)
     const void *dict = nullptr;     // value dictionary: ndict values of T sorted by bit pattern (device), or null
     uint32_t  ndict = 0;

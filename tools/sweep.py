@@ -20,7 +20,6 @@ def main():
     ap.add_argument("--swz", default="1,0")
     ap.add_argument("--nt", default="1,0")
     ap.add_argument("--thr", default="0")
-    ap.add_argument("--xpol", default="0", help="x-gather cache policy bits: 0 default, 2 nt, 16 sc1")
     ap.add_argument("--depth", default="1")
     ap.add_argument("--win", default="-1", help="x window values staged in LDS per workgroup (-1 auto, 0 off)")
     ap.add_argument("--panels", default="-1", help="column panels (-1 auto, 1 off)")
@@ -49,16 +48,16 @@ def main():
         for thr in [int(s) for s in a.thr.split(",")]:
             for swz in [int(s) for s in a.swz.split(",")]:
                 for (nt, cm, xp, dp, win, pan) in [(int(s), int(m, 16), int(xp), int(dp), int(w), int(pn)) for s in a.nt.split(",")
-                                                   for m in a.colmask.split(",") for xp in a.xpol.split(",")
+                                                   for m in a.colmask.split(",") for xp in ("0",)
                                                    for dp in a.depth.split(",") for w in a.win.split(",") for pn in a.panels.split(",")]:
                     A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, nontemporal=nt,
-                                          debug_col_mask=cm, gather_policy=xp, depth=dp, x_window=win, col_panels=pan)
+                                          debug_col_mask=cm, depth=dp, x_window=win, col_panels=pan)
                     x = synth.x_rand(nc, va.dtype)
                     A.spmv(x)
                     s = A.bench(a.warmup, a.iters)
                     i = A.info
                     print(f"  {S:4d}  {swz}  {nt:2d}  {thr:6d}  {i.nchunks:6d} {i.nshared:5d}  {i.nslots / max(nnz, 1):8.4f}  {i.convert_s * 1e6:9.1f}  "
-                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  xpol {xp} depth {dp} win {win} panels {i.col_panels}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
+                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  depth {dp} win {win} panels {i.col_panels} dict {i.value_dict}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
                     A.close()
 
 
