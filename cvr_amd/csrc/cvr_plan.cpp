@@ -37,6 +37,23 @@ Plan plan_chunks(int64_t nrows, const int64_t *rp, int32_t S, int64_t thr)
         c.head_shared = off > 0;
         int64_t used = 0;
         while (r < nrows) {
+            // fast path: eight whole rows at a time while they fit (the slot counts are summed as a tree, so the loop
+            // carries one addition per eight rows instead of one add, compare and branch per row); same result as
+            // taking them one by one: no prefix of the eight can fill the chunk exactly unless all eight do
+            if (off == 0) {
+                bool full = false;
+                while (r + 8 <= nrows) {
+                    const int64_t *q = rp + r;
+                    const int64_t  d0 = q[1] - q[0], d1 = q[2] - q[1], d2 = q[3] - q[2], d3 = q[4] - q[3];
+                    const int64_t  d4 = q[5] - q[4], d5 = q[6] - q[5], d6 = q[7] - q[6], d7 = q[8] - q[7];
+                    const int64_t  s8 = ((d0 > 0 ? d0 : 1) + (d1 > 0 ? d1 : 1)) + ((d2 > 0 ? d2 : 1) + (d3 > 0 ? d3 : 1)) +
+                                       (((d4 > 0 ? d4 : 1) + (d5 > 0 ? d5 : 1)) + ((d6 > 0 ? d6 : 1) + (d7 > 0 ? d7 : 1)));
+                    if (used + s8 > cap) break;
+                    used += s8; r += 8;
+                    if (used == cap) { full = true; break; }
+                }
+                if (full || r >= nrows) break;
+            }
             const int64_t len = rp[r + 1] - rp[r] - off;   // what is left of row r (off > 0 implies len > 0)
             const int64_t slots = len > 0 ? len : 1;        // an empty row owns one pad slot
             if (used + slots <= cap) {
