@@ -3,9 +3,6 @@ device-resident.  The realistic consumer of a web-graph SpMV, and the one settin
 the critical path: with the rows sharded over the ranks, every iteration ends with the all-gather of the y slices,
 from which each rank rebuilds its replicated x.  PyTorch provides the vectors, the norm and torch.distributed;
 the SpMV itself is cvr_spmv_device (HIP kernels behind the C ABI).  Square matrices only."""
-import numpy as np
-
-
 def power_iteration(A, nrows_total, bounds=None, rank=0, iters=20, x0=None):
     """A: CvrMatrix of this rank's row block (all rows when bounds is None).  Returns (eigenvalue estimate,
     x as a torch tensor of nrows_total values, seconds per iteration)."""
@@ -39,16 +36,3 @@ def power_iteration(A, nrows_total, bounds=None, rank=0, iters=20, x0=None):
     dt_s = (time.perf_counter() - t0) / max(iters, 1)
     lam = float(lam_t.item()) if iters else 0.0
     return lam, x[:nrows_total], dt_s
-
-
-def power_iteration_numpy(rp, ci, va, iters=20):
-    """the same loop in numpy (tests): CSR matvec by np.add.reduceat-free bincount"""
-    n = len(rp) - 1
-    rows = np.repeat(np.arange(n), np.diff(rp))
-    x = np.ones(n) / np.sqrt(n)
-    lam = 0.0
-    for _ in range(iters):
-        y = np.bincount(rows, weights=va * x[ci], minlength=n)
-        lam = float(x @ y)
-        x = y / np.linalg.norm(y)
-    return lam, x
