@@ -374,3 +374,30 @@ def test_value_dictionary():
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, (np.arange(len(ci)) % 300).astype(np.float64), steps_per_chunk=8)
     assert A.info.value_dict == 0
     A.close()
+
+
+def test_abi_call_order_and_null_handling():
+    """the C ABI returns codes instead of crashing: null handles, preprocess twice, keep_csr, destroy(NULL)"""
+    import ctypes as C
+    L = capi.lib()
+    assert L.cvr_destroy(None) == 0
+    assert L.cvr_spmv(None, None, None, 1, None) == capi.ERR_INVALID
+    assert L.cvr_preprocess(None, 0, None) == capi.ERR_INVALID
+    assert L.cvr_get_info(None, None) == capi.ERR_INVALID
+    nrows, ncols, rp, ci, va = CASES["uniform_2000"]
+    view = capi.CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, 0)
+    for keep in (0, 1):
+        h = C.c_void_p()
+        assert L.cvr_create(C.byref(h), C.byref(view), None) == 0, cvr_amd.last_error()
+        x = np.ones(ncols)
+        y = np.zeros(nrows)
+        assert L.cvr_spmv(h, x.ctypes.data, y.ctypes.data, 1, None) == capi.ERR_STATE      # before cvr_preprocess
+        sec = C.c_double()
+        assert L.cvr_preprocess(h, keep, C.byref(sec)) == 0 and sec.value > 0
+        rc2 = L.cvr_preprocess(h, keep, C.byref(sec))
+        assert rc2 == (0 if keep else capi.ERR_STATE)                                       # the CSR is gone unless kept
+        assert L.cvr_spmv(h, x.ctypes.data, y.ctypes.data, 2, None) == 0
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        _assert_close(y, yref, absy, TOL64, ("abi", keep))
+        assert L.cvr_spmv_device(h, None, None, None) == capi.ERR_INVALID
+        assert L.cvr_destroy(h) == 0
