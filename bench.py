@@ -167,7 +167,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or bool(os.environ.get("CVR_BENCH_FORCE_SHARDED"))   # the latter: the N > 1 code path with one rank (RCCL plumbing check)
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         backend = os.environ.get("CVR_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -187,8 +192,8 @@ def main():
     x = torch.zeros(info.x_elems, dtype=torch.float64, device=dev)
     x[:ncols] = torch.from_numpy(synth.x_rand(ncols)).to(dev)
     ny = max(info.yext_elems, max_rows)
-    ybufs = [torch.zeros(ny, dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 1)]
-    yalls = [torch.zeros(world * max_rows, dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    ybufs = [torch.zeros(ny, dtype=torch.float64, device=dev) for _ in range(2 if sharded else 1)]
+    yalls = [torch.zeros(world * max_rows, dtype=torch.float64, device=dev) for _ in range(2)] if sharded else None
     y = ybufs[0]
     stream = torch.cuda.Stream(device=dev)     # kernels, events and the collective all go on this stream
     torch.cuda.set_stream(stream)
@@ -196,16 +201,68 @@ def main():
 
     last = [0]
 
+    # The exchange step.  "native" (default): the pipelined loop of cvr_spmv_gather_repeat, RCCL called from the library
+    # with no Python between the steps; "torch": the same loop in Python over torch.distributed (shard.pipelined_steps).
+    # Native is used only if every rank could build its communicator and its first gather equals torch.distributed's.
+    comm = None
+    gather_impl = "none"
+    if sharded:
+        gather_impl = "torch"
+        if os.environ.get("CVR_BENCH_GATHER", "native") == "native" and os.environ.get("CVR_BENCH_BACKEND", "nccl") == "nccl":
+            ok = 1
+            try:
+                box = [cvr_amd.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = cvr_amd.Comm(box[0], world, rank, local_rank)
+                A.spmv_device(x.data_ptr(), ybufs[0].data_ptr(), sptr)
+                stream.synchronize()
+                comm.all_gather(ybufs[0].data_ptr(), yalls[0].data_ptr(), max_rows, False, sptr)
+                stream.synchronize()
+                want = shard.all_gather_y(ybufs[0], max_rows)
+                torch.cuda.synchronize()
+                ok = int(torch.equal(want.view(torch.int64), yalls[0].view(torch.int64)))
+            except Exception as e:      # stay on the torch.distributed path
+                print(f"[bench rank {rank}] native gather unavailable: {e!r}", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                gather_impl = "native"
+            elif comm is not None:
+                comm.close()
+                comm = None
+
+    overlap = [False]
+
     def step(n=1):
-        if world == 1:
+        if not sharded:
             A.spmv_device(x.data_ptr(), y.data_ptr(), sptr, repeat=n)
-        else:   # every step = local SpMV + all-gather of the y slices; the gather of step k overlaps the SpMV of k+1
+        elif comm is not None:   # every step = local SpMV + all-gather of the y slices
+            last[0] = A.spmv_gather(comm, x.data_ptr(), [b.data_ptr() for b in ybufs], [b.data_ptr() for b in yalls], max_rows, n, sptr,
+                                    overlap=overlap[0])
+        else:                    # the gather of step k overlaps the SpMV of k+1
             last[0] = shard.pipelined_steps(lambda yb: A.spmv_device(x.data_ptr(), yb.data_ptr(), sptr), ybufs, yalls, max_rows, n)
 
     def sync():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
+
+    calib = None
+    if comm is not None:         # in-order or overlapped gather: whichever this node runs faster (untimed, every rank agrees)
+        calib = {}
+        for mode in (False, True):
+            overlap[0] = mode
+            step(20)
+            sync()
+            t0 = time.perf_counter()
+            step(200)
+            sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            calib["overlap" if mode else "in_order"] = float(t.item()) / 200 * 1e3
+        overlap[0] = calib["overlap"] < calib["in_order"]
+        gather_impl = "native, " + ("overlapped" if overlap[0] else "in order")
 
     step(args.warmup)
     sync()
@@ -217,7 +274,7 @@ def main():
     sync()
     wall = time.perf_counter() - t0
     ev_s = e0.elapsed_time(e1) * 1e-3
-    if world > 1:
+    if sharded:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -231,13 +288,18 @@ def main():
     torch.cuda.synchronize()
     kern_s = e2.elapsed_time(e3) * 1e-3 / args.steps
     gather_s = None
-    if world > 1:                       # the exchange step alone, same message, same stream (reported beside the total)
+    if sharded:                         # the exchange step alone, same message, same stream (reported beside the total)
         e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        def gather_once():
+            if comm is not None:
+                comm.all_gather(ybufs[0].data_ptr(), yalls[0].data_ptr(), max_rows, False, sptr)
+            else:
+                shard.all_gather_y(ybufs[0], max_rows, out=yalls[0])
         for _ in range(5):
-            shard.all_gather_y(ybufs[0], max_rows, out=yalls[0])
+            gather_once()
         e4.record(stream)
         for _ in range(args.steps):
-            shard.all_gather_y(ybufs[0], max_rows, out=yalls[0])
+            gather_once()
         e5.record(stream)
         torch.cuda.synchronize()
         gather_s = e4.elapsed_time(e5) * 1e-3 / args.steps
@@ -247,7 +309,7 @@ def main():
 
     # parity guard on the timed configuration: y of the last step against the host CSR loop of the product
     # (the reference's own self-check, spmv.cpp:1843-1850, 1916-1938)
-    yh = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if world > 1 else y[:nrows]).cpu().numpy()
+    yh = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()
     wrong = -1
     if rank == 0:
         yref = cvr_amd.csr_spmv_host(rp, ci, va, x[:ncols].cpu().numpy(), nthreads=len(os.sched_getaffinity(0)))
@@ -280,7 +342,7 @@ def main():
                        "steps_per_chunk": int(info.steps_per_chunk), "chunks_rank0": int(info.nchunks),
                        "rows_cut_rank0": int(info.nshared), "col_panels": int(info.col_panels),
                        "value_dictionary_entries": int(info.value_dict),
-                       "parallelism": "rows sharded, x replicated, y all-gathered (RCCL)" if world > 1 else "1 GPU"},
+                       "parallelism": "rows sharded, x replicated, y all-gathered (RCCL)" if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if world == 1 and args.workload == "webgoogle" else None,
                          "kernel": "cvr::spmv_kernel<double>", "kernel_us": kern_s * 1e6,
@@ -290,7 +352,7 @@ def main():
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
             "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
             "preprocess": {"plan_s": info.plan_s, "upload_s": info.upload_s, "convert_s": info.convert_s},
-            "verdict_wrong_rows": wrong,
+            "verdict_wrong_rows": wrong, "gather_impl": gather_impl, "gather_calibration_ms_per_step": calib,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -298,8 +360,10 @@ def main():
             except Exception as e:   # the checker is optional on the bench box; the GPU numbers stand without it
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     A.close()
-    if world > 1:
+    if sharded:
         dist.barrier()                      # rank 0 is still verifying / printing: leave together
         dist.destroy_process_group()
 

@@ -53,7 +53,8 @@ class MmMatrix(C.Structure):
 SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_count", "cvr_create", "cvr_preprocess",
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
            "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
-           "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict"]
+           "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
+           "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
 
 
 def lib_path():
@@ -95,6 +96,12 @@ def lib():
         L.cvr_csr_spmv_host.argtypes = [C.c_int64] + [C.c_void_p] * 5 + [C.c_int]
         L.cvr_verdict.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.cvr_verdict.restype = C.c_int64
+        L.cvr_comm_unique_id.argtypes = [C.c_void_p]
+        L.cvr_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.cvr_comm_destroy.argtypes = [C.c_void_p]
+        L.cvr_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.cvr_spmv_gather_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                             C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -179,6 +186,47 @@ def plan_chunks(row_ptr, S, thr=0):
     return dict(nz_begin=nzb[: n + 1].copy(), row_first=rf[:n].copy(), nseg=ns[:n].copy(), pad_cnt=pc[:n].copy())
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 bytes from rank 0 that every rank passes to Comm() (hand them over with torch.distributed, a file, ...)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().cvr_comm_unique_id(buf)
+    if rc:
+        raise CvrError(rc, "cvr_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the row-sharded SpMV, one rank per process and GPU (cvr_comm_create; collective)"""
+
+    def __init__(self, unique_id, nranks, rank, device):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        self._c = C.c_void_p()
+        self.nranks, self.rank, self.device = nranks, rank, device
+        rc = lib().cvr_comm_create(C.byref(self._c), unique_id, nranks, rank, device)
+        if rc:
+            raise CvrError(rc, "cvr_comm_create")
+
+    def all_gather(self, send_ptr, recv_ptr, count, is_f32=False, stream=None):
+        rc = lib().cvr_comm_all_gather(self._c, send_ptr, recv_ptr, count, int(is_f32), stream)
+        if rc:
+            raise CvrError(rc, "cvr_comm_all_gather")
+
+    def close(self):
+        if self._c:
+            lib().cvr_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CvrMatrix:
     """One matrix (or row shard) resident on one GPU: cvr_create + cvr_preprocess, then spmv()."""
 
@@ -235,6 +283,18 @@ class CvrMatrix:
             rc = lib().cvr_spmv_device_repeat(self._h, x_ptr, y_ptr, stream, repeat)
         if rc:
             raise CvrError(rc, "cvr_spmv_device")
+
+    def spmv_gather(self, comm, x_ptr, y_ptrs, yall_ptrs, max_rows, steps, stream=None, overlap=False):
+        """`steps` sharded SpMVs, each followed by the all-gather of this rank's y slice over RCCL, looped inside the
+        library (cvr_spmv_gather_repeat; overlap: gather of step k under the SpMV of step k+1); returns the index of
+        the buffers holding the last step"""
+        ys = (C.c_void_p * 2)(*y_ptrs)
+        yalls = (C.c_void_p * 2)(*yall_ptrs)
+        last = C.c_int()
+        rc = lib().cvr_spmv_gather_repeat(self._h, comm._c, x_ptr, ys, yalls, max_rows, steps, int(overlap), stream, C.byref(last))
+        if rc:
+            raise CvrError(rc, "cvr_spmv_gather_repeat")
+        return last.value
 
     def bench(self, warmup, iters):
         s = C.c_double()

@@ -2,6 +2,7 @@
 // Host orchestration that the reference keeps in main() (allocation block spmv.cpp:1777-1829, calls at
 // spmv.cpp:1857 and 1882) lives behind the handle here; the caller keeps only CSR, x and y.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library itself is loaded on first use (rccl_api)
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -706,6 +707,163 @@ int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_spmv before cvr_preprocess");
     const hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < n; i++) HIP_TRY(run_spmv(h, x_dev, y_dev, st));
+    return CVR_OK;
+}
+
+// ---- the exchange step of the row-sharded SpMV: RCCL, one process per GPU -----------------------------------
+
+}  // extern "C"
+
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId)    get_unique_id = nullptr;
+    decltype(&ncclCommInitRank)   comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy)    comm_destroy = nullptr;
+    decltype(&ncclAllGather)      all_gather = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+// RCCL is half a gigabyte of code objects: load it only when a communicator is asked for, and prefer the
+// instance the process already holds (PyTorch ships its own librccl.so) so that one runtime serves both.
+const RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static bool    tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {getenv("CVR_RCCL_LIB"), "librccl.so", "librccl.so.1"};
+        for (int pass = 0; pass < 2 && !api.lib; pass++)
+            for (const char *n : names) {
+                if (!n || !*n) continue;
+                api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (api.lib) break;
+            }
+        if (api.lib) {
+            api.get_unique_id = (decltype(api.get_unique_id))dlsym(api.lib, "ncclGetUniqueId");
+            api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(api.lib, "ncclCommInitRank");
+            api.comm_destroy = (decltype(api.comm_destroy))dlsym(api.lib, "ncclCommDestroy");
+            api.all_gather = (decltype(api.all_gather))dlsym(api.lib, "ncclAllGather");
+            api.error_string = (decltype(api.error_string))dlsym(api.lib, "ncclGetErrorString");
+            if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_gather || !api.error_string) api.lib = nullptr;
+        }
+    }
+    return api.lib ? &api : nullptr;
+}
+
+#define RCCL_TRY(api, expr)                                                                                       \
+    do {                                                                                                          \
+        ncclResult_t r_ = (expr);                                                                                 \
+        if (r_ != ncclSuccess) return fail(CVR_ERR_HIP, "%s: %s (%s:%d)", #expr, (api)->error_string(r_), __FILE__, __LINE__); \
+    } while (0)
+
+}  // namespace
+
+struct cvr_comm {
+    ncclComm_t  comm = nullptr;
+    int         nranks = 0, rank = 0, device = 0;
+    hipStream_t stream = nullptr;                 // the collectives of cvr_spmv_gather_repeat run here
+    hipEvent_t  ready[2] = {nullptr, nullptr};    // y_dev[b] computed
+    hipEvent_t  done[2] = {nullptr, nullptr};     // gather of y_dev[b] into yall_dev[b] finished
+    bool        pending[2] = {false, false};
+};
+
+extern "C" {
+
+int cvr_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(CVR_ERR_INVALID, "null argument");
+    const RcclApi *api = rccl_api();
+    if (!api) return fail(CVR_ERR_NO_DEVICE, "RCCL not found (librccl.so; set CVR_RCCL_LIB): %s", dlerror());
+    static_assert(sizeof(ncclUniqueId) == CVR_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    RCCL_TRY(api, api->get_unique_id(&id));
+    memcpy(id128, &id, sizeof(id));
+    return CVR_OK;
+}
+
+int cvr_comm_create(cvr_comm **out, const void *id128, int nranks, int rank, int device)
+{
+    if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(CVR_ERR_INVALID, "bad communicator arguments");
+    *out = nullptr;
+    const RcclApi *api = rccl_api();
+    if (!api) return fail(CVR_ERR_NO_DEVICE, "RCCL not found (librccl.so; set CVR_RCCL_LIB): %s", dlerror());
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<cvr_comm> c(new (std::nothrow) cvr_comm);
+    if (!c) return fail(CVR_ERR_NOMEM, "out of host memory");
+    c->nranks = nranks; c->rank = rank; c->device = device;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    RCCL_TRY(api, api->comm_init_rank(&c->comm, nranks, id, rank));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipEventCreateWithFlags(&c->ready[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->done[b], hipEventDisableTiming));
+    }
+    *out = c.release();
+    return CVR_OK;
+}
+
+int cvr_comm_destroy(cvr_comm *c)
+{
+    if (!c) return CVR_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    const RcclApi *api = rccl_api();
+    if (api && c->comm) (void)api->comm_destroy(c->comm);
+    for (int b = 0; b < 2; b++) {
+        if (c->ready[b]) (void)hipEventDestroy(c->ready[b]);
+        if (c->done[b]) (void)hipEventDestroy(c->done[b]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return CVR_OK;
+}
+
+int cvr_comm_all_gather(cvr_comm *c, const void *send_dev, void *recv_dev, int64_t count, int is_f32, void *stream)
+{
+    if (!c || !send_dev || !recv_dev || count < 0) return fail(CVR_ERR_INVALID, "bad all-gather arguments");
+    const RcclApi *api = rccl_api();
+    if (!api) return fail(CVR_ERR_NO_DEVICE, "RCCL not loaded");
+    RCCL_TRY(api, api->all_gather(send_dev, recv_dev, (size_t)count, is_f32 ? ncclFloat : ncclDouble, c->comm, (hipStream_t)stream));
+    return CVR_OK;
+}
+
+int cvr_spmv_gather_repeat(cvr_handle *h, cvr_comm *c, const void *x_dev, void *const y_dev[2], void *const yall_dev[2],
+                           int64_t max_rows, int n, int overlap, void *stream, int *last_buf)
+{
+    if (!h || !c || !x_dev || !y_dev || !yall_dev || !y_dev[0] || !y_dev[1] || !yall_dev[0] || !yall_dev[1])
+        return fail(CVR_ERR_INVALID, "null argument");
+    if (!h->converted) return fail(CVR_ERR_STATE, "cvr_spmv before cvr_preprocess");
+    if (max_rows < h->info.nrows) return fail(CVR_ERR_INVALID, "max_rows %lld < the %lld rows of this shard", (long long)max_rows, (long long)h->info.nrows);
+    if (c->device != h->device) return fail(CVR_ERR_INVALID, "communicator on device %d, matrix on device %d", c->device, h->device);
+    const RcclApi *api = rccl_api();
+    if (!api) return fail(CVR_ERR_NO_DEVICE, "RCCL not loaded");
+    const hipStream_t    st = (hipStream_t)stream;
+    const ncclDataType_t dt = h->vsz == 4 ? ncclFloat : ncclDouble;
+    for (int b = 0; b < 2; b++)     // gathers an earlier overlapped call left on the communicator's stream
+        if (c->pending[b]) { HIP_TRY(hipStreamWaitEvent(st, c->done[b], 0)); c->pending[b] = false; }
+    if (!overlap) {                 // everything in order on the caller's stream: two enqueues per step, no events
+        for (int k = 0; k < n; k++) {
+            HIP_TRY(run_spmv(h, x_dev, y_dev[k & 1], st));
+            RCCL_TRY(api, api->all_gather(y_dev[k & 1], yall_dev[k & 1], (size_t)max_rows, dt, c->comm, st));
+        }
+    } else {                        // the gather of step k (communicator's stream) overlaps the SpMV of step k + 1
+        for (int k = 0; k < n; k++) {
+            const int b = k & 1;
+            if (c->pending[b]) HIP_TRY(hipStreamWaitEvent(st, c->done[b], 0));    // the gather that last read y_dev[b] / wrote yall_dev[b]
+            HIP_TRY(run_spmv(h, x_dev, y_dev[b], st));
+            HIP_TRY(hipEventRecord(c->ready[b], st));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ready[b], 0));
+            RCCL_TRY(api, api->all_gather(y_dev[b], yall_dev[b], (size_t)max_rows, dt, c->comm, c->stream));
+            HIP_TRY(hipEventRecord(c->done[b], c->stream));
+            c->pending[b] = true;
+        }
+        for (int b = 0; b < 2; b++)
+            if (c->pending[b]) { HIP_TRY(hipStreamWaitEvent(st, c->done[b], 0)); c->pending[b] = false; }
+    }
+    if (last_buf) *last_buf = n > 0 ? (n - 1) & 1 : 0;
     return CVR_OK;
 }
 

@@ -126,6 +126,32 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
 int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream);
 /* the same, `n` launches back to back (the Ntimes loop of spmv.cpp:1024 without a host round trip per launch) */
 int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *stream, int n);
+/* ---- rows sharded over GPUs, one process per GPU: the exchange step ------------------------------------
+ * The reference's threads share one y in host memory (spmv.cpp:1280-1282, 1640-1649); with one row shard per GPU
+ * (contiguous rows, cut at row boundaries, x replicated) the shards' y slices are all-gathered over RCCL / xGMI.
+ * RCCL is loaded on first use (dlopen; the instance already in the process, e.g. PyTorch's, is preferred), so
+ * single-GPU users never pay for it. */
+typedef struct cvr_comm cvr_comm;
+#define CVR_COMM_ID_BYTES 128
+/* rank 0 calls this and hands the 128 bytes to every rank by its own means (file, socket, torch.distributed) */
+int cvr_comm_unique_id(void *id128);
+/* collective over all ranks; `device` is this rank's GPU */
+int cvr_comm_create(cvr_comm **comm, const void *id128, int nranks, int rank, int device);
+int cvr_comm_destroy(cvr_comm *comm);
+/* one all-gather of `count` values per rank (type by is_f32) on `stream`: recv_dev holds nranks * count values */
+int cvr_comm_all_gather(cvr_comm *comm, const void *send_dev, void *recv_dev, int64_t count, int is_f32, void *stream);
+/* `n` sharded SpMVs of the fixed-x loop (spmv.cpp:1024), each followed by the all-gather of this rank's y slice
+ * (the first max_rows values of y; every rank passes the same max_rows >= its row count).  Step k computes into
+ * y_dev[k & 1] and gathers into yall_dev[k & 1] (nranks * max_rows values).  overlap = 0: SpMV and gather follow
+ * each other on `stream` (two enqueues per step; the cheapest for the host).  overlap = 1: the gather runs on the
+ * communicator's own stream, so the gather of step k overlaps the SpMV of step k + 1, and buffers are reused only
+ * after the gather that used them has finished (two events per step: worth it when the gather outlasts the
+ * SpMV by more than their cost).  Every rank must pass the same n and overlap.  On return `stream` is ordered after
+ * every gather; *last_buf = index of the buffers holding the last step.  y_dev[i] must hold
+ * max(info.yext_elems, max_rows) values.  No host synchronisation. */
+int cvr_spmv_gather_repeat(cvr_handle *h, cvr_comm *comm, const void *x_dev, void *const y_dev[2], void *const yall_dev[2],
+                           int64_t max_rows, int n, int overlap, void *stream, int *last_buf);
+
 /* the handle's own device vectors (valid until cvr_destroy) and stream */
 void *cvr_x_device(cvr_handle *h);
 void *cvr_y_device(cvr_handle *h);

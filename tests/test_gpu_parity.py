@@ -401,3 +401,35 @@ def test_abi_call_order_and_null_handling():
         _assert_close(y, yref, absy, TOL64, ("abi", keep))
         assert L.cvr_spmv_device(h, None, None, None) == capi.ERR_INVALID
         assert L.cvr_destroy(h) == 0
+
+
+def test_native_gather_loop_single_rank_rccl():
+    """cvr_spmv_gather_repeat with a 1-rank RCCL communicator: the library's own pipelined SpMV + all-gather loop
+    (the N > 1 path of bench.py; more ranks need more GPUs than this box has)"""
+    import torch
+    nrows, ncols, rp, ci, va = CASES["power_law_3000"]
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    comm = cvr_amd.Comm(cvr_amd.comm_unique_id(), 1, 0, 0)
+    dev = torch.device("cuda", 0)
+    xh = O.x_vec_fast(ncols)
+    x = torch.zeros(A.info.x_elems, dtype=torch.float64, device=dev)
+    x[:ncols] = torch.from_numpy(xh).to(dev)
+    max_rows = nrows + 5                                   # padded slices, as with uneven shards
+    ny = max(A.info.yext_elems, max_rows)
+    ys = [torch.full((ny,), float("nan"), dtype=torch.float64, device=dev) for _ in range(2)]
+    yalls = [torch.full((max_rows,), float("nan"), dtype=torch.float64, device=dev) for _ in range(2)]
+    st = torch.cuda.Stream(device=dev)
+    yref, absy = O.csr_spmv64(rp, ci, va, xh)
+    for n, ov in ((1, False), (2, True), (7, False), (7, True), (4, False)):
+        for t in ys + yalls:
+            t.fill_(float("nan"))
+        torch.cuda.synchronize()
+        last = A.spmv_gather(comm, x.data_ptr(), [t.data_ptr() for t in ys], [t.data_ptr() for t in yalls], max_rows, n, st.cuda_stream, overlap=ov)
+        st.synchronize()
+        assert last == (n - 1) & 1
+        _assert_close(yalls[last][:nrows].cpu().numpy(), yref, absy, TOL64, ("native gather", n))
+        assert torch.equal(yalls[last][:nrows].view(torch.int64), ys[last][:nrows].view(torch.int64))
+    with pytest.raises(cvr_amd.CvrError):                  # a slice shorter than the shard
+        A.spmv_gather(comm, x.data_ptr(), [t.data_ptr() for t in ys], [t.data_ptr() for t in yalls], nrows - 1, 1, st.cuda_stream)
+    comm.close()
+    A.close()
