@@ -209,26 +209,39 @@ def main():
     if sharded:
         gather_impl = "torch"
         if os.environ.get("CVR_BENCH_GATHER", "native") == "native" and os.environ.get("CVR_BENCH_BACKEND", "nccl") == "nccl":
-            ok = 1
-            try:
-                box = [cvr_amd.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = cvr_amd.comm_unique_id()
+                except Exception as e:
+                    print(f"[bench rank 0] no RCCL id: {e!r}", file=sys.stderr)
+            dist.broadcast_object_list(box, src=0)       # always reached by every rank, id or not
+            def agree(ok):          # every rank must have succeeded
+                flag = torch.tensor([int(ok)], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return int(flag.item()) == 1
+
+            try:                    # phase 1: the communicators
+                if box[0] is None:
+                    raise RuntimeError("rank 0 could not make an RCCL id")
                 comm = cvr_amd.Comm(box[0], world, rank, local_rank)
-                A.spmv_device(x.data_ptr(), ybufs[0].data_ptr(), sptr)
-                stream.synchronize()
-                comm.all_gather(ybufs[0].data_ptr(), yalls[0].data_ptr(), max_rows, False, sptr)
-                stream.synchronize()
-                want = shard.all_gather_y(ybufs[0], max_rows)
-                torch.cuda.synchronize()
-                ok = int(torch.equal(want.view(torch.int64), yalls[0].view(torch.int64)))
-            except Exception as e:      # stay on the torch.distributed path
+            except Exception as e:
                 print(f"[bench rank {rank}] native gather unavailable: {e!r}", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                gather_impl = "native"
-            elif comm is not None:
+            if agree(comm is not None):
+                ok = False
+                try:                # phase 2: its first gather against torch.distributed's, bit for bit
+                    A.spmv_device(x.data_ptr(), ybufs[0].data_ptr(), sptr)
+                    stream.synchronize()
+                    comm.all_gather(ybufs[0].data_ptr(), yalls[0].data_ptr(), max_rows, False, sptr)
+                    stream.synchronize()
+                    want = shard.all_gather_y(ybufs[0], max_rows)
+                    torch.cuda.synchronize()
+                    ok = torch.equal(want.view(torch.int64), yalls[0].view(torch.int64))
+                except Exception as e:
+                    print(f"[bench rank {rank}] native gather failed its check: {e!r}", file=sys.stderr)
+                if agree(ok):
+                    gather_impl = "native"
+            if gather_impl != "native" and comm is not None:     # stay on the torch.distributed path
                 comm.close()
                 comm = None
 
