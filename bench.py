@@ -184,7 +184,9 @@ def main():
     nnz = len(ci)
     bounds = shard.row_partition(rp, world)
     lrows, lrp, lci, lva = shard.local_csr(rp, ci, va, bounds, rank)
-    A = cvr_amd.CvrMatrix(lrows, ncols, lrp, lci, lva, device=local_rank, steps_per_chunk=args.steps_per_chunk)
+    # a shard of this matrix on one of N GPUs is small enough for the chunk count to matter: measure S (cvr_tune_steps)
+    tune = world > 1 and args.steps_per_chunk == 0 and not os.environ.get("CVR_BENCH_NO_TUNE")
+    A = cvr_amd.CvrMatrix(lrows, ncols, lrp, lci, lva, device=local_rank, steps_per_chunk=args.steps_per_chunk, tune_steps=tune)
     info = A.info
     max_rows, pick = shard.gather_layout(bounds)
 
@@ -364,7 +366,7 @@ def main():
             "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz) / per / 1e9,
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
             "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
-            "preprocess": {"plan_s": info.plan_s, "upload_s": info.upload_s, "convert_s": info.convert_s},
+            "preprocess": {"plan_s": info.plan_s, "upload_s": info.upload_s, "convert_s": info.convert_s, "tune_steps_s": A.tuning_s},
             "verdict_wrong_rows": wrong, "gather_impl": gather_impl, "gather_calibration_ms_per_step": calib,
         }
         if world == 1 and not args.no_cpu_baseline:

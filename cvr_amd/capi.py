@@ -54,7 +54,7 @@ SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_c
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
            "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
-           "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
+           "cvr_tune_steps", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
 
 
 def lib_path():
@@ -96,6 +96,7 @@ def lib():
         L.cvr_csr_spmv_host.argtypes = [C.c_int64] + [C.c_void_p] * 5 + [C.c_int]
         L.cvr_verdict.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.cvr_verdict.restype = C.c_int64
+        L.cvr_tune_steps.argtypes = [C.POINTER(CsrView), C.POINTER(Options), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.cvr_comm_unique_id.argtypes = [C.c_void_p]
         L.cvr_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cvr_comm_destroy.argtypes = [C.c_void_p]
@@ -232,8 +233,10 @@ class CvrMatrix:
 
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
                  xcd_swizzle=-1, x_window=-1, nontemporal=0, keep_csr=False, debug_col_mask=0, depth=0,
-                 col_panels=-1, value_dict=-1):
+                 col_panels=-1, value_dict=-1, tune_steps=False):
+        """tune_steps: choose steps_per_chunk by measurement first (cvr_tune_steps; its cost is self.tuning_s)"""
         self._h = C.c_void_p()
+        self.tuning_s = 0.0
         rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
         ci = np.ascontiguousarray(col_idx, dtype=np.int32)
         self.f32 = np.asarray(vals).dtype == np.float32
@@ -248,6 +251,12 @@ class CvrMatrix:
         opt.xcd_swizzle, opt.x_window, opt.col_panels, opt.value_dict = xcd_swizzle, x_window, col_panels, value_dict
         # tuning / profiling knobs (tools/sweep.py)
         opt.stream_policy, opt.gather_depth, opt.debug_col_mask = nontemporal, depth, debug_col_mask
+        if tune_steps and steps_per_chunk == 0:
+            best, best_t, tun = C.c_int32(), C.c_double(), C.c_double()
+            rc = lib().cvr_tune_steps(C.byref(view), C.byref(opt), C.byref(best), C.byref(best_t), C.byref(tun))
+            if rc:
+                raise CvrError(rc, "cvr_tune_steps")
+            opt.steps_per_chunk, self.tuning_s = best.value, tun.value
         rc = lib().cvr_create(C.byref(self._h), C.byref(view), C.byref(opt))
         if rc:
             self._h = C.c_void_p()

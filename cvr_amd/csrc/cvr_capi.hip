@@ -219,20 +219,21 @@ int64_t cvr_plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_
 
 static int pick_steps(int64_t nslots_est)
 {
-    // One wavefront per chunk, all of them resident at once when there are few: the kernel then lasts as long as the CU
-    // with the most chunks, so S is chosen to make chunks / 256 CUs land just below an integer (web-Google: S = 48 ->
-    // 1 751 chunks = 6.84 per CU, 32.4 us; S = 64 -> 5.1 per CU, 35.7 us; profiles/r01_y_staging.log).  Large matrices
-    // run many rounds and take S = 32 (profiles/r01_steps_large_matrices.log).
+    // One wavefront per chunk, all of them resident at once when there are few.  A CU's chunks share its L1 miss path,
+    // so the kernel lasts about as long as the CU with the most chunks: overhead + S * max(t_wave, t_cu * k) with
+    // k = ceil(chunks / 256 CUs), plus a little per resident chunk.  Fitted on S = 8..80 over row shards of web-Google
+    // for 1..16 GPUs (profiles/r01_steps_rule_fit.log: within 1 % of the best S for 1, 2, 3, 4, 6 shards; cvr_tune_steps
+    // measures instead).  The 0.98 keeps the chunk count a little under k * 256: the dispatcher does not place the
+    // workgroups perfectly evenly.  Large matrices run many rounds and take S = 32 (profiles/r01_steps_large_matrices.log).
     const double kCus = 256.0;
     if ((double)nslots_est / (64.0 * 32.0) > kCus * 24.0) return 32;
-    int    best = 16;
-    double best_score = -1;
-    for (int S = 64; S >= 16; S -= 4) {
-        const double per_cu = ((double)nslots_est * 1.004 / (64.0 * S) + 1.0) / kCus;
-        if (per_cu < 4.0 && S > 16) continue;                      // too few wavefronts per CU to cover the gather latency
-        const double fill = per_cu / std::ceil(per_cu + 0.04);     // + 0.04: margin for the planner's pad segments
-        const double score = fill - (S < 32 ? 0.02 : 0.0);         // slightly prefer fewer, longer chunks
-        if (score > best_score) { best_score = score; best = S; }
+    int    best = 32;
+    double best_t = 1e300;
+    for (int S = 64; S >= 8; S -= 4) {
+        const double chunks = (double)nslots_est * 1.004 / (64.0 * S) + 1.0;      // 1.004: the planner's pad segments
+        const double k = std::ceil(chunks / (kCus * 0.98));
+        const double t = 3.9 + S * std::max(0.10, 0.075 * k) + 0.3 * k;           // microseconds
+        if (t < best_t) { best_t = t; best = S; }
     }
     return best;
 }
@@ -251,8 +252,10 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     if (yext >= (int64_t)0xffffffffu || nchunks >= (int64_t)0x7fffffff) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
     std::vector<uint32_t> desc((size_t)nchunks * 4), pad((size_t)nchunks);
     std::vector<int64_t>  nzb((size_t)nchunks + 1);
+    int64_t               max_nseg = 0;
     for (int64_t k = 0; k < nchunks; k++) {
         const cvr::Chunk &c = plan.chunks[(size_t)k];
+        max_nseg = std::max(max_nseg, c.nseg);
         desc[4 * k + 0] = (uint32_t)c.row_first;
         desc[4 * k + 1] = (uint32_t)c.nseg;
         // where segment q writes: a row begun earlier -> carry_head(k); a row continued later -> carry_tail(k);
@@ -272,6 +275,9 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     if (plan_s) *plan_s += now_s() - t0;
 
     part.nrows = nrows; part.nnz = nz1 - nz0; part.nnz_span = nz1; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
+    // LDS row-sum stage of the SpMV kernel: sized for the chunk with the most segments, so every chunk writes its y
+    // coalesced; capped (chunks of very short rows beyond the cap store directly)
+    part.img.ystage = (uint32_t)std::min<int64_t>(std::max<int64_t>((max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
     const int G = S / 4;
     cvr::DeviceImage &img = part.img;
     img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
@@ -930,6 +936,32 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
         HIP_TRY(hipEventElapsedTime(&tot, h->events[0], h->events[(size_t)iters]));
         tm->mean_s = sum / iters; tm->min_s = mn; tm->max_s = mx; tm->total_s = tot * 1e-3;
     }
+    return CVR_OK;
+}
+
+int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt_in, int32_t *best_steps, double *best_spmv_s, double *tuning_s)
+{
+    if (!csr || !best_steps) return fail(CVR_ERR_INVALID, "null argument");
+    cvr_options opt;
+    if (opt_in) opt = *opt_in; else cvr_default_options(&opt);
+    const double t0 = now_s();
+    int32_t      best = 0;
+    double       best_t = 0;
+    for (int32_t S = 8; S <= 64; S += 4) {     // every candidate is the real thing: plan, upload, convert, timed launches
+        opt.steps_per_chunk = S;
+        cvr_handle *h = nullptr;
+        int         rc = cvr_create(&h, csr, &opt);
+        double      t = 0;
+        if (rc == CVR_OK) rc = cvr_preprocess(h, 0, nullptr);
+        if (rc == CVR_OK) rc = cvr_spmv_bench(h, 5, 10, &t);                                   // settle clocks and caches
+        if (rc == CVR_OK) rc = cvr_spmv_bench(h, 0, t > 0 ? std::max(20, std::min(200, (int)(1.5e-3 / t))) : 20, &t);
+        cvr_destroy(h);
+        if (rc != CVR_OK) return rc;
+        if (best == 0 || t < best_t) { best = S; best_t = t; }
+    }
+    *best_steps = best;
+    if (best_spmv_s) *best_spmv_s = best_t;
+    if (tuning_s) *tuning_s = now_s() - t0;
     return CVR_OK;
 }
 

@@ -39,7 +39,7 @@ constexpr int      kGroupBytes64 = kColsBytes + kLanes * 32;  // 3072
 constexpr int      kGroupBytes32 = kColsBytes + kLanes * 16;  // 2048
 constexpr int      kGroupBytesDict = kColsBytes + kLanes * 4;  // 1280: column words + one code byte per slot
 constexpr int      kDictMax = 256;
-constexpr int      kYStage = 1024;   // row sums a wavefront stages in LDS and writes out coalesced at the end of its chunk
+constexpr int      kYStageMax = 4096;   // most row sums a wavefront stages in LDS and writes out coalesced at the end of its chunk (32 KB of fp64)
 constexpr int      kWavesPerBlock = 1;   // measured: 1 wave per workgroup spreads the chunks most evenly over the CUs (profiles/r01_waves_per_block.log)
 
 inline int group_bytes(bool f32, bool dict = false) { return dict ? kGroupBytesDict : f32 ? kGroupBytes32 : kGroupBytes64; }

@@ -21,6 +21,7 @@ struct DeviceImage {
     uint32_t nshared = 0;
     int      xcd_swizzle = 1;       // 0 off, 1 contiguous chunk range per XCD, 2 additionally consecutive chunks per CU (experiment)
     int      stream_policy = 0;     // buffer-load cache policy of the matrix stream: 0 default, 2 nt
+    uint32_t ystage = 1024;         // row sums a wavefront stages in LDS (multiple of 64, <= kYStageMax)
     int      depth = 1;             // groups the x gather runs ahead of the FMAs (1 or 2)
     const void *dict = nullptr;     // value dictionary: ndict values of T sorted by bit pattern (device), or null
     uint32_t  ndict = 0;

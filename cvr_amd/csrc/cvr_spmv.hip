@@ -189,16 +189,17 @@ template <typename T, int SPOL, int XPOL, int DEPTH, bool WIN, bool DICT>
 __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
     const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
-    uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict)
+    uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict,
+    uint32_t ystage_n)
 {
     constexpr int  GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     constexpr bool kSync = WIN || (DICT && kWavesPerBlock > 1);      // LDS filled by other waves of the workgroup
-    // LDS: [waves][64] steal slots, [waves][kYStage] staged row sums, the value dictionary (DICT), then the x window and
+    // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums, the value dictionary (DICT), then the x window and
     // its zero slot (WIN)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     T *const slots = reinterpret_cast<T *>(smem);
     T *const ystage_all = slots + kWavesPerBlock * kLanes;
-    T *const dict = ystage_all + kWavesPerBlock * kYStage;
+    T *const dict = ystage_all + kWavesPerBlock * ystage_n;
     T *const win = dict + (DICT ? kDictMax : 0);
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -247,10 +248,10 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
     s.tail = s.fed == nseg;
     T *slot_lane = &slots[wv * kLanes + lane];
     // Row sums go to LDS and leave as coalesced stores at the end of the chunk (its rows are consecutive): the scattered
-    // 8-byte stores they replace cost 12 % of the kernel (profiles/r01_y_staging.log).  A chunk of more than kYStage
+    // 8-byte stores they replace cost 12 % of the kernel (profiles/r01_y_staging.log).  A chunk of more than ystage_n
     // segments (very short rows) stores directly.
-    T *const   ystage = ystage_all + wv * kYStage;
-    const bool staged = nseg <= (uint32_t)kYStage;
+    T *const   ystage = ystage_all + wv * ystage_n;
+    const bool staged = nseg <= ystage_n;
 #pragma unroll
     for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL, WIN>(rx, win, Q[i].c, cmask, wbase, wn);
 
@@ -400,13 +401,13 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
     const bool   use_win = img.win_elems > 0 && img.win_base != nullptr;
     const bool   use_dict = img.dict != nullptr;
-    const size_t lds = (size_t)(kWavesPerBlock * (kLanes + kYStage) + (use_dict ? kDictMax : 0) + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
+    const size_t lds = (size_t)(kWavesPerBlock * (kLanes + img.ystage) + (use_dict ? kDictMax : 0) + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
     // template parameters: <value type, stream cache policy, gather cache policy, gather run-ahead, LDS window, dictionary>
 #define CVR_LAUNCH(T, SP, D, W, DI)                                                                               \
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
-                       static_cast<const T *>(img.dict), img.ndict)
+                       static_cast<const T *>(img.dict), img.ndict, img.ystage)
 #define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_LAUNCH(T, SP, D, W, true); else CVR_LAUNCH(T, SP, D, W, false); } while (0)
 #define CVR_PICK_W(T, SP, D)     do { if (use_win) CVR_PICK_DI(T, SP, D, true); else CVR_PICK_DI(T, SP, D, false); } while (0)
 #define CVR_PICK_D(T, SP)        do { if (img.depth == 2) CVR_PICK_W(T, SP, 2); else CVR_PICK_W(T, SP, 1); } while (0)

@@ -126,6 +126,14 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
 int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream);
 /* the same, `n` launches back to back (the Ntimes loop of spmv.cpp:1024 without a host round trip per launch) */
 int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *stream, int n);
+/* Optional tuning of steps_per_chunk by measurement: builds the matrix with S = 8, 12, ... 64 on the device, times the
+ * SpMV of each (about 1.5 ms of launches per candidate) and returns the fastest; the caller then passes it as
+ * cvr_options.steps_per_chunk to cvr_create.  The default rule (steps_per_chunk = 0) needs no tuning on matrices
+ * that fill the GPU many times over; on small ones (a row shard of web-Google on one of 8 GPUs) which chunk counts run
+ * fastest depends on how the workgroups fall onto the CUs, and measuring beats the rule by 10-20 %.
+ * Costs one upload of the CSR arrays per candidate (*tuning_s); counts as preprocessing time. */
+int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt, int32_t *best_steps, double *best_spmv_s, double *tuning_s);
+
 /* ---- rows sharded over GPUs, one process per GPU: the exchange step ------------------------------------
  * The reference's threads share one y in host memory (spmv.cpp:1280-1282, 1640-1649); with one row shard per GPU
  * (contiguous rows, cut at row boundaries, x replicated) the shards' y slices are all-gathered over RCCL / xGMI.

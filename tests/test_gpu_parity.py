@@ -433,3 +433,35 @@ def test_native_gather_loop_single_rank_rccl():
         A.spmv_gather(comm, x.data_ptr(), [t.data_ptr() for t in ys], [t.data_ptr() for t in yalls], nrows - 1, 1, st.cuda_stream)
     comm.close()
     A.close()
+
+
+def test_lds_row_stage_sizes_and_direct_store_fallback():
+    """the LDS stage of row sums is sized for the chunk with the most rows; beyond kYStageMax (4096) a chunk stores directly:
+    rows of one non-zero (64*S rows per chunk) with S = 16 (1024 rows), 64 (4096: the cap), 128 (8192: fallback), mixed with long rows"""
+    rng = np.random.default_rng(7)
+    nrows = ncols = 30000
+    lens = np.ones(nrows, dtype=np.int64)
+    lens[rng.integers(0, nrows, 40)] = rng.integers(100, 3000, 40)
+    lens[rng.integers(0, nrows, 500)] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ci = rng.integers(0, ncols, int(rp[-1])).astype(np.int32)
+    va = rng.standard_normal(int(rp[-1]))
+    x = O.x_vec_fast(ncols)
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    for S in (16, 64, 128):
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S)
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL64, ("ystage", S))
+        A.close()
+
+
+def test_tune_steps_returns_a_measured_choice():
+    """cvr_tune_steps: S from measurement; the tuned matrix computes the same y"""
+    nrows, ncols, rp, ci, va = CASES["power_law_3000"]
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, tune_steps=True)
+    assert A.info.steps_per_chunk in range(8, 68, 4) and A.tuning_s > 0
+    x = O.x_vec_fast(ncols)
+    y, _ = A.spmv(x)
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    _assert_close(y, yref, absy, TOL64, "tuned")
+    A.close()
