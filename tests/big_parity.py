@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/big_parity.py [band<n>|livejournal|rmat<scale>] -- full-size parity + timing of one large matrix on one GPU:
+"""tests/big_parity.py [band<n>|livejournal|rmat<scale>] -- full-size parity + timing of one large matrix on one GPU:
 y against the CSR oracle (all rows), run-to-run bit equality, preprocessing breakdown."""
 import os
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/compare_csr.py [matrix] -- preprocessing-amortisation report (paper Eq. 1; Tables 1 and 4):
+"""tests/compare_csr.py [matrix] -- preprocessing-amortisation report (paper Eq. 1; Tables 1 and 4):
     I_pre = T_pre(CVR) / (T_spmv(baseline) - T_spmv(CVR))
 with GPU-resident CSR baselines on the same device: a plain CSR-vector kernel and rocSPARSE (adaptive, rowsplit,
 LRB).  The paper's baseline is MKL's CSR on KNL (I_pre = 8.4 iterations on web-Google, Table 4).

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/make_mtx.py OUT.mtx [webgoogle|livejournal] [scale] -- write a seeded synthetic matrix as a row-major
+"""tests/make_mtx.py OUT.mtx [webgoogle|livejournal] [scale] -- write a seeded synthetic matrix as a row-major
 `pattern general` Matrix-Market file (input for ./spmv.cvr and for the reference binary).  Uses the oracle
 library's writer (test/bench infrastructure)."""
 import os

@@ -6,7 +6,7 @@ MAT=${1:-webgoogle}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/locality_$MAT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 for grp in "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   g=$(echo $grp | cut -c1-7)
-  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/$g -- python3 $R/tools/compare_csr.py $MAT 3 > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/$g -- python3 $R/tests/compare_csr.py $MAT 3 > /dev/null 2>&1
 done
 python3 - <<PY
 import csv, glob, collections
