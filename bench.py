@@ -357,7 +357,7 @@ def main():
                        "steps_per_chunk": int(info.steps_per_chunk), "chunks_rank0": int(info.nchunks),
                        "rows_cut_rank0": int(info.nshared), "col_panels": int(info.col_panels),
                        "value_dictionary_entries": int(info.value_dict),
-                       "parallelism": "rows sharded, x replicated, y all-gathered (RCCL)" if sharded else "1 GPU"},
+                       "parallelism": ("rows sharded, x replicated, y all-gathered (%s)" % ("RCCL" if os.environ.get("CVR_BENCH_BACKEND", "nccl") == "nccl" else os.environ["CVR_BENCH_BACKEND"])) if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if world == 1 and args.workload == "webgoogle" else None,
                          "kernel": "cvr::spmv_kernel<double>", "kernel_us": kern_s * 1e6,
