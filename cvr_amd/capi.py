@@ -54,7 +54,7 @@ SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_c
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
            "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
-           "cvr_tune_steps", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
+           "cvr_tune_steps", "cvr_auto_panels", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
 
 
 def lib_path():
@@ -97,6 +97,7 @@ def lib():
         L.cvr_verdict.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.cvr_verdict.restype = C.c_int64
         L.cvr_tune_steps.argtypes = [C.POINTER(CsrView), C.POINTER(Options), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.cvr_auto_panels.argtypes = [C.POINTER(CsrView), C.POINTER(C.c_double)]
         L.cvr_comm_unique_id.argtypes = [C.c_void_p]
         L.cvr_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cvr_comm_destroy.argtypes = [C.c_void_p]
@@ -185,6 +186,18 @@ def plan_chunks(row_ptr, S, thr=0):
     if n < 0:
         raise CvrError(n, "cvr_plan_chunks")
     return dict(nz_begin=nzb[: n + 1].copy(), row_first=rf[:n].copy(), nseg=ns[:n].copy(), pad_cnt=pc[:n].copy())
+
+
+def auto_panels(nrows, ncols, row_ptr, col_idx, is_f32=False):
+    """(column panels cvr_create would choose, estimated L2 miss share of the x gathers); host only"""
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    ci = np.ascontiguousarray(col_idx, dtype=np.int32)
+    view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, None, int(is_f32))
+    miss = C.c_double()
+    P = lib().cvr_auto_panels(C.byref(view), C.byref(miss))
+    if P < 0:
+        raise CvrError(P, "cvr_auto_panels")
+    return P, miss.value
 
 
 COMM_ID_BYTES = 128

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <new>
 #include <thread>
@@ -427,36 +428,54 @@ static void split_panels_t(const cvr_csr_view &v, int P, PanelSplit &out)
     }
 }
 
-// How does a block of consecutive rows use x?  (What one XCD works on at a time is of that order.)  Up to four evenly
-// spaced windows of 65 536 rows are looked at; for the one with the most non-zeros: the bytes of x it touches, counted
-// in 128-byte lines, and how many of its gathers fall on a line for the first time.  A banded matrix touches little
-// more than the window itself; hub-dominated rows (R-MAT) touch much but re-use every line dozens of times, so the L2s
-// already serve them; scattered columns with little re-use are what column panels help.
-static void window_footprint(const cvr_csr_view &v, double *bytes, double *first_touch_ratio)
+// Which share of the x gathers would miss a 4-MiB L2?  Eight evenly spaced windows of 65 536 consecutive rows (what one
+// XCD works on at a time is of that order): in each, the gathers are counted per 128-byte line of x; the 32 768 most
+// used lines (4 MiB) are taken as resident, every other gather and every first touch of a line as a miss.  The windows
+// are weighted by their non-zeros.  Banded matrices: ~0; R-MAT's hub columns keep it low (scale 22, fp64: 0.13) until the
+// tail outgrows the cache (scale 24, fp32: 0.22); scattered columns with little re-use: 0.44 (LiveJournal shape).
+// profiles/r01_panel_rule_l2_estimate.log
+static double l2_miss_estimate(const cvr_csr_view &v)
 {
-    *bytes = 0; *first_touch_ratio = 0;
     const int64_t nrows = v.nrows, W = std::min<int64_t>(65536, nrows);
-    if (W <= 0) return;
+    if (W <= 0) return 0.0;
     const int64_t per_line = v.is_f32 ? 32 : 16, nlines = v.ncols / per_line + 1;
-    std::vector<uint64_t> bits((size_t)(nlines / 64 + 1));
-    int64_t best_refs = -1;
-    for (int w = 0; w < 4; w++) {
-        const int64_t r0 = (nrows - W) * w / 3;
-        const int64_t refs = v.row_ptr[r0 + W] - v.row_ptr[r0];
-        if (refs > best_refs) {
-            best_refs = refs;
-            std::fill(bits.begin(), bits.end(), 0);
-            int64_t lines = 0;
-            for (int64_t j = v.row_ptr[r0]; j < v.row_ptr[r0 + W]; j++) {
-                const int64_t  l = v.col_idx[j] / per_line;
-                const uint64_t m = 1ull << (l & 63);
-                if (!(bits[(size_t)(l >> 6)] & m)) { bits[(size_t)(l >> 6)] |= m; lines++; }
-            }
-            *bytes = (double)lines * 128.0;
-            *first_touch_ratio = refs > 0 ? (double)lines / (double)refs : 0.0;
+    const size_t  resident = (size_t)(4u << 20) / 128;
+    std::vector<uint32_t> cnt((size_t)nlines, 0u), touched, top;
+    double  refs_all = 0, miss_all = 0;
+    const int nwin = nrows == W ? 1 : 8;
+    for (int w = 0; w < nwin; w++) {
+        const int64_t r0 = nwin == 1 ? 0 : (nrows - W) * w / (nwin - 1);
+        const int64_t j0 = v.row_ptr[r0], j1 = v.row_ptr[r0 + W];
+        if (j1 <= j0) continue;
+        touched.clear();
+        for (int64_t j = j0; j < j1; j++) {
+            const size_t l = (size_t)(v.col_idx[j] / per_line);
+            if (cnt[l]++ == 0) touched.push_back((uint32_t)l);
         }
-        if (nrows == W) break;
+        top.resize(touched.size());
+        for (size_t i = 0; i < touched.size(); i++) { top[i] = cnt[touched[i]]; cnt[touched[i]] = 0; }
+        const size_t k = std::min(resident, top.size());
+        if (k < top.size()) std::nth_element(top.begin(), top.begin() + (ptrdiff_t)k, top.end(), std::greater<uint32_t>());
+        double hits = 0;
+        for (size_t i = 0; i < k; i++) hits += (double)top[i] - 1.0;        // all but the first touch of a resident line
+        const double refs = (double)(j1 - j0);
+        refs_all += refs;
+        miss_all += refs - hits;
     }
+    return refs_all > 0 ? miss_all / refs_all : 0.0;
+}
+
+static int auto_panels(const cvr_csr_view &v, double *miss_out)
+{
+    const double xb = (double)v.ncols * (v.is_f32 ? 4.0 : 8.0);
+    int          P = 1;
+    double       miss = 0;
+    if (xb >= 24e6) {
+        miss = l2_miss_estimate(v);
+        if (miss > 0.17) P = std::min(64, std::max(2, (int)(xb * miss / 1.8e6 + 0.5)));
+    }
+    if (miss_out) *miss_out = miss;
+    return P;
 }
 
 static void split_panels(const cvr_csr_view &v, int P, PanelSplit &out)
@@ -484,21 +503,14 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     const int64_t nrows = csr->nrows, ncols = csr->ncols;
     const bool    f32 = csr->is_f32 != 0;
     const size_t  vsz = f32 ? 4 : 8;
-    // column panels: asked for, or (col_panels < 0: auto) when x is several times the 4-MiB L2 of an XCD AND a block of
-    // consecutive rows really touches that much of it without re-using the lines (a banded matrix touches little, R-MAT's
-    // hub rows re-use every line dozens of times: profiles/r01_panel_rule_windows.log): one panel per ~4.5 MB of x
-    // (profiles/r01_column_panels_livejournal_sweep.log); never for matrices whose x nearly fits (web-Google:
-    // profiles/r01_column_panel_probe.log)
+    // column panels: asked for, or (col_panels < 0: auto) when x is several times the 4-MiB L2 of an XCD AND a sizeable
+    // share of the gathers would miss such an L2 (l2_miss_estimate: a banded matrix re-uses its few lines, R-MAT's hub
+    // columns stay resident).  One panel per 1.8 MB of *missing* x: LiveJournal shape (38.8 MB, 0.44) -> 9, the best of
+    // 4..32 (profiles/r01_column_panels_livejournal_sweep2.log); R-MAT-24 fp32 (67 MB, 0.22) -> 8, 1 660 against
+    // 2 300 us as one image (profiles/r01_column_panels_rmat24_fp32.log); R-MAT-22 fp64 (33.5 MB, 0.13) and matrices
+    // whose x nearly fits (web-Google: profiles/r01_column_panel_probe.log) stay whole.
     int P = opt.col_panels;
-    if (P < 0) {
-        const double xb = (double)ncols * (double)vsz;
-        P = 1;
-        if (xb >= 24e6) {
-            double fp = 0, ratio = 0;
-            window_footprint(*csr, &fp, &ratio);
-            if (fp > 8e6 && ratio > 0.10) P = (int)(xb / 4.5e6 + 0.5);   // x >> L2, scattered columns, little re-use of a line
-        }
-    }
+    if (P < 0) P = auto_panels(*csr, nullptr);
     if (P < 1) P = 1;
     if (P > 64) P = 64;
     if (nrows >= (int64_t)0xfffffff0u) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
@@ -937,6 +949,12 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
         tm->mean_s = sum / iters; tm->min_s = mn; tm->max_s = mx; tm->total_s = tot * 1e-3;
     }
     return CVR_OK;
+}
+
+int cvr_auto_panels(const cvr_csr_view *csr, double *l2_miss_estimate_out)
+{
+    if (!csr || (csr->nrows > 0 && (!csr->row_ptr || (csr->row_ptr[csr->nrows] > 0 && !csr->col_idx)))) return fail(CVR_ERR_INVALID, "null argument");
+    return auto_panels(*csr, l2_miss_estimate_out);
 }
 
 int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt_in, int32_t *best_steps, double *best_spmv_s, double *tuning_s)

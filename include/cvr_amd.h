@@ -126,6 +126,11 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
 int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream);
 /* the same, `n` launches back to back (the Ntimes loop of spmv.cpp:1024 without a host round trip per launch) */
 int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *stream, int n);
+/* The column-panel count cvr_create chooses for col_panels = -1 (host only, no device needed): 1 unless x is >= 24 MB
+ * and the estimated share of x gathers missing a 4-MiB L2 (*l2_miss_estimate, sampled over eight windows of 65 536
+ * rows) exceeds 0.17; then one panel per 1.8 MB of missing x.  Returns the count (>= 1) or a negative error. */
+int cvr_auto_panels(const cvr_csr_view *csr, double *l2_miss_estimate);
+
 /* Optional tuning of steps_per_chunk by measurement: builds the matrix with S = 8, 12, ... 64 on the device, times the
  * SpMV of each (about 1.5 ms of launches per candidate) and returns the fastest; the caller then passes it as
  * cvr_options.steps_per_chunk to cvr_create.  The default rule (steps_per_chunk = 0) needs no tuning on matrices

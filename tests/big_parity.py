@@ -26,7 +26,7 @@ print(f"{name}: {n} x {nc}, nnz {len(ci)}, generated in {time.time() - t0:.1f}s"
 t0 = time.time()
 A = cvr_amd.CvrMatrix(n, nc, rp, ci, va)
 i = A.info
-print(f"create+preprocess {time.time() - t0:.2f}s: S {i.steps_per_chunk}, chunks {i.nchunks}, rows cut {i.nshared}, image {i.image_bytes / 1e9:.2f} GB, "
+print(f"create+preprocess {time.time() - t0:.2f}s: S {i.steps_per_chunk}, chunks {i.nchunks}, rows cut {i.nshared}, column panels {i.col_panels}, dictionary {i.value_dict}, image {i.image_bytes / 1e9:.2f} GB, "
       f"plan {i.plan_s * 1e3:.1f} ms, upload {i.upload_s * 1e3:.1f} ms, convert {i.convert_s * 1e3:.2f} ms", flush=True)
 x = synth.x_rand(nc, va.dtype)
 y, _ = A.spmv(x)

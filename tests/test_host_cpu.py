@@ -223,3 +223,21 @@ def test_size_limits_are_rejected_with_a_message():
     with pytest.raises(cvr_amd.CvrError) as e:
         cvr_amd.CvrMatrix(1, 8, rp, np.zeros(1, dtype=np.int32), np.ones(1), steps_per_chunk=6)
     assert e.value.code in (capi.ERR_INVALID, capi.ERR_NO_DEVICE)
+
+
+def test_auto_panel_rule_on_the_host():
+    """cvr_auto_panels: x small -> 1; x large and banded (lines re-used) -> 1; x large and scattered -> one panel per
+    1.8 MB of missing x; comm / tuning entry points fail with codes (no device here)"""
+    rng = np.random.default_rng(5)
+    n = 4_000_000                                                          # x = 32 MB of fp64
+    rp = np.arange(n + 1, dtype=np.int64) * 2
+    scattered = rng.integers(0, n, 2 * n).astype(np.int32)
+    P, miss = capi.auto_panels(n, n, rp, scattered)
+    assert miss > 0.6 and P == int(n * 8 * miss / 1.8e6 + 0.5)
+    band = (np.repeat(np.arange(n, dtype=np.int64), 2) + np.tile([0, 3], n)).clip(0, n - 1).astype(np.int32)
+    P, miss = capi.auto_panels(n, n, rp, band)
+    assert P == 1 and miss < 0.2                                           # first touches only: 2 of 32 gathers per line
+    m = 1_000_000                                                          # x = 8 MB: never panelled
+    P, miss = capi.auto_panels(m, m, rp[:m + 1], scattered[:2 * m] % m)
+    assert P == 1 and miss == 0.0
+    assert capi.lib().cvr_auto_panels(None, None) == capi.ERR_INVALID
