@@ -225,9 +225,9 @@ static int pick_steps(int64_t nslots_est)
     // k = ceil(chunks / 256 CUs), plus a little per resident chunk.  Fitted on S = 8..80 over row shards of web-Google
     // for 1..16 GPUs (profiles/r01_steps_rule_fit.log: within 1 % of the best S for 1, 2, 3, 4, 6 shards; cvr_tune_steps
     // measures instead).  The 0.98 keeps the chunk count a little under k * 256: the dispatcher does not place the
-    // workgroups perfectly evenly.  Large matrices run many rounds and take S = 32 (profiles/r01_steps_large_matrices.log).
+    // workgroups perfectly evenly.  Matrices of more than 12 chunks per CU at S = 32 run in rounds and take S = 32.
     const double kCus = 256.0;
-    if ((double)nslots_est / (64.0 * 32.0) > kCus * 24.0) return 32;
+    if ((double)nslots_est / (64.0 * 32.0) > kCus * 12.0) return 32;     // LiveJournal panels (15 per CU): S = 32 beats 24, 48, 64 (r01_steps_large_matrices.log)
     int    best = 32;
     double best_t = 1e300;
     for (int S = 64; S >= 8; S -= 4) {
