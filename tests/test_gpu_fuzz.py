@@ -44,7 +44,7 @@ def test_fuzz_parity():
             va = rng.choice(np.array([0.0, 1.0, -1.0, 0.5, 3.0, 1e-3, -7.25]), size=len(va))
         if f32:
             va = va.astype(np.float32)
-        S = int(rng.choice([4, 8, 12, 16, 32, 64]))
+        S = int(rng.choice([4, 8, 12, 16, 32, 64, 96, 128]))
         thr = int(rng.choice([0, 1, 7, 64, 10**6]))
         P = int(rng.choice([1, 1, 2, 3]))
         win = int(rng.choice([0, 0, 64, 1000]))
