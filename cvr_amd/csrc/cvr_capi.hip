@@ -440,28 +440,32 @@ static double l2_miss_estimate(const cvr_csr_view &v)
     if (W <= 0) return 0.0;
     const int64_t per_line = v.is_f32 ? 32 : 16, nlines = v.ncols / per_line + 1;
     const size_t  resident = (size_t)(4u << 20) / 128;
-    std::vector<uint32_t> cnt((size_t)nlines, 0u), touched, top;
-    double  refs_all = 0, miss_all = 0;
-    const int nwin = nrows == W ? 1 : 8;
-    for (int w = 0; w < nwin; w++) {
+    const int     nwin = nrows == W ? 1 : 8;
+    std::vector<double> refs_w((size_t)nwin, 0.0), miss_w((size_t)nwin, 0.0);
+    auto window = [&](int w) {          // one thread per window, each with its own counters
         const int64_t r0 = nwin == 1 ? 0 : (nrows - W) * w / (nwin - 1);
         const int64_t j0 = v.row_ptr[r0], j1 = v.row_ptr[r0 + W];
-        if (j1 <= j0) continue;
-        touched.clear();
+        if (j1 <= j0) return;
+        std::vector<uint32_t> cnt((size_t)nlines, 0u), touched;
         for (int64_t j = j0; j < j1; j++) {
             const size_t l = (size_t)(v.col_idx[j] / per_line);
             if (cnt[l]++ == 0) touched.push_back((uint32_t)l);
         }
-        top.resize(touched.size());
-        for (size_t i = 0; i < touched.size(); i++) { top[i] = cnt[touched[i]]; cnt[touched[i]] = 0; }
+        std::vector<uint32_t> top(touched.size());
+        for (size_t i = 0; i < touched.size(); i++) top[i] = cnt[touched[i]];
         const size_t k = std::min(resident, top.size());
         if (k < top.size()) std::nth_element(top.begin(), top.begin() + (ptrdiff_t)k, top.end(), std::greater<uint32_t>());
         double hits = 0;
         for (size_t i = 0; i < k; i++) hits += (double)top[i] - 1.0;        // all but the first touch of a resident line
-        const double refs = (double)(j1 - j0);
-        refs_all += refs;
-        miss_all += refs - hits;
-    }
+        refs_w[(size_t)w] = (double)(j1 - j0);
+        miss_w[(size_t)w] = (double)(j1 - j0) - hits;
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < nwin; w++) th.emplace_back(window, w);
+    window(0);
+    for (auto &t : th) t.join();
+    double refs_all = 0, miss_all = 0;
+    for (int w = 0; w < nwin; w++) { refs_all += refs_w[(size_t)w]; miss_all += miss_w[(size_t)w]; }
     return refs_all > 0 ? miss_all / refs_all : 0.0;
 }
 
