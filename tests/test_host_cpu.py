@@ -241,3 +241,27 @@ def test_auto_panel_rule_on_the_host():
     P, miss = capi.auto_panels(m, m, rp[:m + 1], scattered[:2 * m] % m)
     assert P == 1 and miss == 0.0
     assert capi.lib().cvr_auto_panels(None, None) == capi.ERR_INVALID
+
+
+def test_exchange_and_tuning_entry_points_fail_with_codes_without_a_device():
+    """cvr_comm_* / cvr_spmv_gather_repeat / cvr_tune_steps: argument checks and the no-device case return codes"""
+    L = capi.lib()
+    assert L.cvr_comm_unique_id(None) == capi.ERR_INVALID
+    h = C.c_void_p()
+    ident = C.create_string_buffer(capi.COMM_ID_BYTES)
+    assert L.cvr_comm_create(C.byref(h), ident, 0, 0, 0) == capi.ERR_INVALID          # nranks < 1
+    assert L.cvr_comm_create(C.byref(h), ident, 2, 2, 0) == capi.ERR_INVALID          # rank out of range
+    assert L.cvr_comm_create(None, ident, 1, 0, 0) == capi.ERR_INVALID
+    assert L.cvr_comm_destroy(None) == 0
+    assert L.cvr_comm_all_gather(None, None, None, 0, 0, None) == capi.ERR_INVALID
+    assert L.cvr_spmv_gather_repeat(None, None, None, None, None, 0, 1, 0, None, None) == capi.ERR_INVALID
+    assert L.cvr_tune_steps(None, None, None, None, None) == capi.ERR_INVALID
+    if cvr_amd.device_count() == 0:
+        rp = np.array([0, 1], dtype=np.int64)
+        ci = np.zeros(1, dtype=np.int32)
+        va = np.ones(1)
+        view = capi.CsrView(1, 1, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, 0)
+        best = C.c_int32()
+        assert L.cvr_tune_steps(C.byref(view), None, C.byref(best), None, None) == capi.ERR_NO_DEVICE
+        rc = L.cvr_comm_create(C.byref(h), ident, 1, 0, 0)                             # RCCL may load, but there is no GPU
+        assert rc < 0 and cvr_amd.last_error()
