@@ -20,7 +20,7 @@ class CvrError(RuntimeError):
 
 class CsrView(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p),
-                ("vals", C.c_void_p), ("is_f32", C.c_int32)]
+                ("vals", C.c_void_p), ("is_f32", C.c_int32), ("arrays_on_device", C.c_int32)]
 
 
 class Options(C.Structure):
@@ -258,6 +258,25 @@ class CvrMatrix:
         if len(rp) != nrows + 1:
             raise ValueError("row_ptr must have nrows + 1 entries")
         view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
+        self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, nontemporal, keep_csr,
+                    debug_col_mask, depth, col_panels, value_dict, tune_steps)
+
+    @classmethod
+    def from_device(cls, nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, is_f32=False, device=0, steps_per_chunk=0,
+                    split_threshold=0, keep_csr=False, col_panels=-1, value_dict=-1, tune_steps=False):
+        """CSR arrays already in the memory of `device` (raw pointers: int64 row_ptr[nrows+1], int32 col_idx, fp64/fp32 vals),
+        e.g. the .data_ptr() of torch tensors: cvr_csr_view.arrays_on_device = 1"""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.tuning_s = 0.0
+        self.f32 = bool(is_f32)
+        self.dtype = np.float32 if self.f32 else np.float64
+        view = CsrView(nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, int(self.f32), 1)
+        self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, -1, -1, 0, keep_csr, 0, 0, col_panels, value_dict, tune_steps)
+        return self
+
+    def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, nontemporal, keep_csr,
+               debug_col_mask, depth, col_panels, value_dict, tune_steps):
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold

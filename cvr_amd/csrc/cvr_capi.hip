@@ -183,7 +183,7 @@ int cvr_device_count(void)
 
 int64_t cvr_plan_bound(int64_t nrows, int64_t nnz, int32_t S) { return cvr::plan_bound(nrows, nnz, S); }
 
-static int check_csr(const cvr_csr_view *c)
+static int check_csr(const cvr_csr_view *c, bool columns_on_host = true)
 {
     if (!c || c->nrows < 0 || c->ncols < 0) return fail(CVR_ERR_INVALID, "null or negative-size CSR view");
     if (c->nrows > 0 && !c->row_ptr) return fail(CVR_ERR_INVALID, "row_ptr is null");
@@ -196,9 +196,26 @@ static int check_csr(const cvr_csr_view *c)
         if (c->row_ptr[r + 1] < c->row_ptr[r]) return fail(CVR_ERR_INVALID, "row_ptr decreases at row %lld", (long long)r);
     const int64_t nnz = c->row_ptr[c->nrows];
     if (nnz > 0 && (!c->col_idx || !c->vals)) return fail(CVR_ERR_INVALID, "col_idx / vals is null");
+    if (!columns_on_host) return CVR_OK;       // device arrays: the range check is a kernel (check_columns_device)
     for (int64_t j = c->row_ptr[0]; j < nnz; j++)
         if (c->col_idx[j] < 0 || c->col_idx[j] >= c->ncols)
             return fail(CVR_ERR_INVALID, "col_idx[%lld] = %d outside [0, %lld)", (long long)j, c->col_idx[j], (long long)c->ncols);
+    return CVR_OK;
+}
+
+// the column range check for col_idx in device memory
+static int check_columns_device(const int32_t *ci_dev, int64_t j0, int64_t j1, int64_t ncols)
+{
+    if (j1 <= j0) return CVR_OK;
+    int32_t *mm = nullptr;
+    int32_t  host[2] = {0x7fffffff, (int32_t)0x80000000};
+    HIP_TRY(hipMalloc(&mm, sizeof(host)));
+    hipError_t e = hipMemcpy(mm, host, sizeof(host), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = cvr::launch_col_range(ci_dev, j0, j1, mm, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(host, mm, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipFree(mm);
+    if (e != hipSuccess) return fail(CVR_ERR_HIP, "column range check: %s", hipGetErrorString(e));
+    if (host[0] < 0 || host[1] >= ncols) return fail(CVR_ERR_INVALID, "col_idx holds %d .. %d, outside [0, %lld)", host[0], host[1], (long long)ncols);
     return CVR_OK;
 }
 
@@ -241,6 +258,7 @@ static int pick_steps(int64_t nslots_est)
 
 // plans one part on the host, allocates its device image and uploads its CSR (asynchronously on h->stream)
 static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
+                      hipMemcpyKind civa_kind,
                       bool f32, const cvr_options &opt, double *plan_s)
 {
     const int64_t nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
@@ -308,8 +326,8 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     HIP_TRY(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / cvr::kWavesPerBlock + 1), h->stream));
     if (nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
     if (nnz_span) {
-        HIP_TRY(hipMemcpyAsync(part.d_ci, ci, sizeof(int32_t) * nnz_span, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(part.d_va, va, vsz * nnz_span, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(part.d_ci, ci, sizeof(int32_t) * nnz_span, civa_kind, h->stream));     // row_ptr is always a host array here
+        HIP_TRY(hipMemcpyAsync(part.d_va, va, vsz * nnz_span, civa_kind, h->stream));
     }
     if (nchunks) {
         HIP_TRY(hipMemcpyAsync(part.d_nzb, nzb.data(), sizeof(int64_t) * nzb.size(), hipMemcpyHostToDevice, h->stream));
@@ -489,20 +507,59 @@ static void split_panels(const cvr_csr_view &v, int P, PanelSplit &out)
 
 extern "C" {
 
-int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt_in)
+int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *opt_in)
 {
     if (!out) return fail(CVR_ERR_INVALID, "out is null");
     *out = nullptr;
     Range range("cvr_create (validate, plan, upload)");
-    int rc = check_csr(csr);
-    if (rc) return rc;
+    if (!csr_in) return fail(CVR_ERR_INVALID, "null or negative-size CSR view");
     cvr_options opt;
     if (opt_in) opt = *opt_in; else cvr_default_options(&opt);
     const int ndev = cvr_device_count();
+    const bool on_device = csr_in->arrays_on_device != 0;
+    int rc = on_device ? CVR_OK : check_csr(csr_in);          // host arrays: rejected before any device work
+    if (rc) return rc;
     if (ndev <= 0) return fail(CVR_ERR_NO_DEVICE, "no HIP device visible: libcvr_amd has no CPU fallback");
     if (opt.device < 0 || opt.device >= ndev) return fail(CVR_ERR_NO_DEVICE, "device %d out of range [0, %d)", opt.device, ndev);
     if (opt.steps_per_chunk != 0 && (opt.steps_per_chunk < 4 || opt.steps_per_chunk % 4 || opt.steps_per_chunk > 4096))
         return fail(CVR_ERR_INVALID, "steps_per_chunk must be a multiple of 4 in [4, 4096]");
+
+    // CSR arrays already in device memory (of opt.device): the planner walks row_ptr on the host, so that array comes
+    // back (8 B per row); col_idx and vals stay where they are and are copied device to device.  Only when column
+    // panels are possible (x >= 24 MB, or asked for) do they take the detour through the host, where the split runs.
+    cvr_csr_view          hostv = *csr_in;
+    const cvr_csr_view   *csr = &hostv;
+    std::vector<int64_t>  rp_host;
+    std::vector<int32_t>  ci_host;
+    std::vector<uint8_t>  va_host;
+    hipMemcpyKind         civa_kind = hipMemcpyHostToDevice;
+    if (on_device) {
+        if (hostv.nrows < 0 || hostv.ncols < 0 || (hostv.nrows > 0 && !hostv.row_ptr)) return fail(CVR_ERR_INVALID, "null or negative-size CSR view");
+        HIP_TRY(hipSetDevice(opt.device));
+        rp_host.resize((size_t)hostv.nrows + 1, 0);
+        if (hostv.nrows > 0) HIP_TRY(hipMemcpy(rp_host.data(), hostv.row_ptr, sizeof(int64_t) * rp_host.size(), hipMemcpyDeviceToHost));
+        hostv.row_ptr = rp_host.data();
+        rc = check_csr(&hostv, false);
+        if (rc) return rc;
+        const int64_t j0 = rp_host.front(), j1 = rp_host.back();
+        rc = check_columns_device(hostv.col_idx, j0, j1, hostv.ncols);
+        if (rc) return rc;
+        const double xb = (double)hostv.ncols * (hostv.is_f32 ? 4.0 : 8.0);
+        if (opt.col_panels > 1 || (opt.col_panels < 0 && xb >= 24e6)) {
+            const size_t vs = hostv.is_f32 ? 4 : 8;
+            ci_host.resize((size_t)std::max<int64_t>(j1, 1));
+            va_host.resize((size_t)std::max<int64_t>(j1, 1) * vs);
+            if (j1 > 0) {
+                HIP_TRY(hipMemcpy(ci_host.data(), hostv.col_idx, sizeof(int32_t) * (size_t)j1, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(va_host.data(), hostv.vals, vs * (size_t)j1, hipMemcpyDeviceToHost));
+            }
+            hostv.col_idx = ci_host.data();
+            hostv.vals = va_host.data();
+        } else {
+            civa_kind = hipMemcpyDeviceToDevice;
+            if (opt.col_panels < 0) opt.col_panels = 1;
+        }
+    }
 
     const int64_t nrows = csr->nrows, ncols = csr->ncols;
     const bool    f32 = csr->is_f32 != 0;
@@ -540,7 +597,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
     const double t_up0 = now_s();
     h->parts.resize((size_t)P);
     if (P == 1) {
-        rc = build_part(h, h->parts[0], nrows, ncols, csr->row_ptr, csr->col_idx, csr->vals, f32, opt, &in.plan_s);
+        rc = build_part(h, h->parts[0], nrows, ncols, csr->row_ptr, csr->col_idx, csr->vals, civa_kind, f32, opt, &in.plan_s);
         if (rc) { cvr_destroy(h); return rc; }
         in.yext_elems = h->parts[0].yext;
     } else {
@@ -552,7 +609,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt
         for (int p = 0; p < P; p++) {
             Part &part = h->parts[(size_t)p];
             rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
-                            sp.va[(size_t)p].data(), f32, opt, &in.plan_s);
+                            sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, opt, &in.plan_s);
             if (rc) { cvr_destroy(h); return rc; }
             part.zoff = zoff;
             zoff += part.yext;
@@ -957,7 +1014,9 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
 
 int cvr_auto_panels(const cvr_csr_view *csr, double *l2_miss_estimate_out)
 {
-    if (!csr || (csr->nrows > 0 && (!csr->row_ptr || (csr->row_ptr[csr->nrows] > 0 && !csr->col_idx)))) return fail(CVR_ERR_INVALID, "null argument");
+    if (!csr) return fail(CVR_ERR_INVALID, "null argument");
+    if (csr->arrays_on_device) return fail(CVR_ERR_INVALID, "cvr_auto_panels reads host arrays");
+    if (csr->nrows > 0 && (!csr->row_ptr || (csr->row_ptr[csr->nrows] > 0 && !csr->col_idx))) return fail(CVR_ERR_INVALID, "null argument");
     return auto_panels(*csr, l2_miss_estimate_out);
 }
 

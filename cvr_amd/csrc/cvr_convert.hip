@@ -191,6 +191,25 @@ __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__
     }
 }
 
+// smallest and largest column index of col_idx[n0 .. n1): the range check of cvr_create for CSR arrays that are already
+// on the device (the host loop of check_csr otherwise).  minmax[0] = min, minmax[1] = max; the caller initialises both.
+__global__ __launch_bounds__(256) void col_range_kernel(const int32_t *__restrict__ ci, long long n0, long long n1, int32_t *minmax)
+{
+    int32_t lo = 0x7fffffff, hi = (int32_t)0x80000000;
+    for (long long j = n0 + (long long)blockIdx.x * 256 + threadIdx.x; j < n1; j += (long long)gridDim.x * 256) {
+        const int32_t c = ci[j];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63u) == 0) { atomicMin(&minmax[0], lo); atomicMax(&minmax[1], hi); }
+}
+
 // Value-dictionary detection: every workgroup collects the distinct bit patterns of its slice of the values in an LDS
 // hash table and merges them into a global one (1024 slots, all-ones = empty; the all-ones pattern itself is reported
 // through flags bit 1).  More than kDictMax distinct patterns anywhere -> flags bit 0 (no dictionary).
@@ -238,6 +257,14 @@ __global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ va
 }
 
 }  // namespace
+
+hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st)
+{
+    if (n1 <= n0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<int64_t>(2048, (n1 - n0 + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(col_range_kernel, dim3(blocks), dim3(256), 0, st, ci, (long long)n0, (long long)n1, minmax);
+    return hipGetLastError();
+}
 
 hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, unsigned long long *table, uint32_t *flags, hipStream_t st)
 {

@@ -44,6 +44,8 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 
 // value-dictionary detection over vals[n0, n1) on the device: `table` = 1024 u64 slots preset to all ones, flags[0] bit 0 =
 // more than kDictMax distinct values, bit 1 = the all-ones pattern occurs, flags[1] = entries in the table
+// min / max of col_idx[n0 .. n1) into minmax[0..1] (device; initialised by the caller to INT_MAX / INT_MIN)
+hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st);
 hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, unsigned long long *table, uint32_t *flags, hipStream_t st);
 
 // picks, per workgroup of kWavesPerBlock chunks, the window of img.win_elems consecutive columns that holds most

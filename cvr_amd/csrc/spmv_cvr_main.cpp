@@ -99,7 +99,7 @@ int main(int argc, char **argv)
         const int64_t b = bounds[(size_t)g], e = bounds[(size_t)g + 1], lo = m.row_ptr[b];
         lrp[(size_t)g].resize((size_t)(e - b) + 1);
         for (int64_t r = b; r <= e; r++) lrp[(size_t)g][(size_t)(r - b)] = m.row_ptr[r] - lo;
-        cvr_csr_view v;
+        cvr_csr_view v = {};
         v.nrows = e - b; v.ncols = m.ncols; v.row_ptr = lrp[(size_t)g].data(); v.col_idx = m.col_idx + lo; v.vals = m.vals + lo; v.is_f32 = 0;
         cvr_options o;
         cvr_default_options(&o);

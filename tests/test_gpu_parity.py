@@ -465,3 +465,50 @@ def test_tune_steps_returns_a_measured_choice():
     yref, absy = O.csr_spmv64(rp, ci, va, x)
     _assert_close(y, yref, absy, TOL64, "tuned")
     A.close()
+
+
+@pytest.mark.parametrize("name", ["power_law_3000", "two_giants", "leading_trailing_empty", "empty_matrix_rows_only"])
+def test_csr_arrays_already_on_the_device(name):
+    """cvr_csr_view.arrays_on_device = 1 (a GPU-resident caller, here torch tensors): same image, bit for bit, and same y as
+    with host arrays; a column out of range is still rejected (device-side range check)"""
+    import torch
+    nrows, ncols, rp, ci, va = CASES[name]
+    dev = torch.device("cuda", 0)
+    trp = torch.from_numpy(np.ascontiguousarray(rp, dtype=np.int64)).to(dev)
+    tci = torch.from_numpy(np.ascontiguousarray(ci, dtype=np.int32)).to(dev) if len(ci) else torch.zeros(1, dtype=torch.int32, device=dev)
+    tva = torch.from_numpy(np.ascontiguousarray(va, dtype=np.float64)).to(dev) if len(va) else torch.zeros(1, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=16)
+    B = cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), tci.data_ptr(), tva.data_ptr(), steps_per_chunk=16)
+    ia, ib = A.export_image(), B.export_image()
+    for k in ("image", "desc", "target", "shared"):
+        assert np.array_equal(ia[k], ib[k]), (name, k)
+    x = O.x_vec_fast(ncols)
+    ya, _ = A.spmv(x)
+    yb, _ = B.spmv(x)
+    assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8))
+    A.close()
+    B.close()
+    if len(ci):
+        bad = tci.clone()
+        bad[len(ci) // 2] = ncols                                  # one past the last column
+        torch.cuda.synchronize()
+        with pytest.raises(cvr_amd.CvrError) as e:
+            cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), bad.data_ptr(), tva.data_ptr())
+        assert e.value.code == capi.ERR_INVALID
+
+
+def test_device_arrays_with_column_panels_take_the_host_detour():
+    """column panels asked for with device-resident arrays: staged through the host split, same y as the host-array path"""
+    import torch
+    nrows, ncols, rp, ci, va = CASES["power_law_3000"]
+    dev = torch.device("cuda", 0)
+    trp, tci, tva = (torch.from_numpy(a).to(dev) for a in (np.ascontiguousarray(rp, dtype=np.int64), np.ascontiguousarray(ci, dtype=np.int32), np.ascontiguousarray(va, dtype=np.float64)))
+    torch.cuda.synchronize()
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=3)
+    B = cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), tci.data_ptr(), tva.data_ptr(), col_panels=3)
+    assert A.info.col_panels == 3 and B.info.col_panels == 3
+    x = O.x_vec_fast(ncols)
+    assert np.array_equal(A.spmv(x)[0].view(np.uint8), B.spmv(x)[0].view(np.uint8))
+    A.close()
+    B.close()
