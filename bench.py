@@ -318,6 +318,11 @@ def main():
         e5.record(stream)
         torch.cuda.synchronize()
         gather_s = e4.elapsed_time(e5) * 1e-3 / args.steps
+    kern_max_s = kern_s
+    if sharded:                         # the slowest rank's SpMV alone: what the job would run at without the exchange step
+        t = torch.tensor([kern_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kern_max_s = float(t.item())
     lnnz = int(lrp[-1])
     balg_local = synth.b_alg(lrows, ncols, lnnz)
     achieved = balg_local / kern_s / 1e9
@@ -365,6 +370,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(balg_local)},
             "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz) / per / 1e9,
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
+            "spmv_only_ms_max_over_ranks": kern_max_s * 1e3, "gflops_spmv_only_no_exchange": 2.0 * nnz / kern_max_s / 1e9,
             "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
             "preprocess": {"plan_s": info.plan_s, "upload_s": info.upload_s, "convert_s": info.convert_s, "tune_steps_s": A.tuning_s},
             "verdict_wrong_rows": wrong, "gather_impl": gather_impl, "gather_calibration_ms_per_step": calib,
