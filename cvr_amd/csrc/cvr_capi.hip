@@ -862,6 +862,8 @@ int cvr_comm_unique_id(void *id128)
     return CVR_OK;
 }
 
+int cvr_comm_destroy(cvr_comm *c);
+
 int cvr_comm_create(cvr_comm **out, const void *id128, int nranks, int rank, int device)
 {
     if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(CVR_ERR_INVALID, "bad communicator arguments");
@@ -869,18 +871,27 @@ int cvr_comm_create(cvr_comm **out, const void *id128, int nranks, int rank, int
     const RcclApi *api = rccl_api();
     if (!api) return fail(CVR_ERR_NO_DEVICE, "RCCL not found (librccl.so; set CVR_RCCL_LIB): %s", dlerror());
     HIP_TRY(hipSetDevice(device));
-    std::unique_ptr<cvr_comm> c(new (std::nothrow) cvr_comm);
+    cvr_comm *c = new (std::nothrow) cvr_comm;
     if (!c) return fail(CVR_ERR_NOMEM, "out of host memory");
     c->nranks = nranks; c->rank = rank; c->device = device;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    RCCL_TRY(api, api->comm_init_rank(&c->comm, nranks, id, rank));
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; b++) {
-        HIP_TRY(hipEventCreateWithFlags(&c->ready[b], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->done[b], hipEventDisableTiming));
+    const ncclResult_t r = api->comm_init_rank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        cvr_comm_destroy(c);
+        return fail(CVR_ERR_HIP, "ncclCommInitRank: %s", api->error_string(r));
     }
-    *out = c.release();
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipEventCreateWithFlags(&c->ready[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[b], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        cvr_comm_destroy(c);           // whatever was created so far
+        return fail(CVR_ERR_HIP, "communicator stream / events: %s", hipGetErrorString(e));
+    }
+    *out = c;
     return CVR_OK;
 }
 
