@@ -512,3 +512,31 @@ def test_device_arrays_with_column_panels_take_the_host_detour():
     assert np.array_equal(A.spmv(x)[0].view(np.uint8), B.spmv(x)[0].view(np.uint8))
     A.close()
     B.close()
+
+
+def test_spmv_launches_can_be_captured_in_a_hip_graph():
+    """cvr_spmv_device makes no synchronising call: a caller can capture it (here with torch.cuda.graph) and replay"""
+    import torch
+    nrows, ncols, rp, ci, va = CASES["power_law_3000"]
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    dev = torch.device("cuda", 0)
+    xh = O.x_vec_fast(ncols)
+    x = torch.zeros(A.info.x_elems, dtype=torch.float64, device=dev)
+    x[:ncols] = torch.from_numpy(xh).to(dev)
+    y = torch.full((A.info.yext_elems,), float("nan"), dtype=torch.float64, device=dev)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(3):
+            A.spmv_device(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    y.fill_(float("nan"))
+    g.replay()
+    torch.cuda.synchronize()
+    yref, absy = O.csr_spmv64(rp, ci, va, xh)
+    _assert_close(y[:nrows].cpu().numpy(), yref, absy, TOL64, "graph replay")
+    x[:ncols] *= 2.0                                    # the graph reads x at replay time
+    g.replay()
+    torch.cuda.synchronize()
+    _assert_close(y[:nrows].cpu().numpy(), 2.0 * yref, 2.0 * absy, TOL64, "graph replay, new x")
+    A.close()
