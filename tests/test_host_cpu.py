@@ -265,3 +265,41 @@ def test_exchange_and_tuning_entry_points_fail_with_codes_without_a_device():
         assert L.cvr_tune_steps(C.byref(view), None, C.byref(best), None, None) == capi.ERR_NO_DEVICE
         rc = L.cvr_comm_create(C.byref(h), ident, 1, 0, 0)                             # RCCL may load, but there is no GPU
         assert rc < 0 and cvr_amd.last_error()
+
+
+def test_header_is_plain_c99_and_links_against_the_library(tmp_path):
+    """include/cvr_amd.h is the boundary a C (cgo / JNI / ctypes) binding compiles against: strict C99, and a C program
+    linked with libcvr_amd.so runs the host-only entry points"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "cvr_amd.h"
+int main(void)
+{
+    cvr_options o;
+    cvr_default_options(&o);
+    cvr_csr_view v = {0};
+    long long rp[3] = {0, 1, 2};
+    int ci[2] = {0, 1};
+    double va[2] = {1.0, 2.0};
+    v.nrows = 2; v.ncols = 2; v.row_ptr = (const int64_t *)rp; v.col_idx = ci; v.vals = va;
+    double miss = -1;
+    int P = cvr_auto_panels(&v, &miss);
+    cvr_handle *h = 0;
+    int rc = cvr_device_count() > 0 ? 0 : cvr_create(&h, &v, &o);
+    printf("%s|%d|%d|%d|%d\n", cvr_version(), P, rc, (int)sizeof(cvr_csr_view), (int)sizeof(cvr_options));
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{root}/include", str(src), "-o", str(exe),
+                    f"-L{root}/cvr_amd", "-lcvr_amd", f"-Wl,-rpath,{root}/cvr_amd", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().split("|")
+    assert out[0].startswith("cvr_amd") and out[1] == "1"
+    assert int(out[2]) in (0, capi.ERR_NO_DEVICE)
+    assert int(out[3]) == C.sizeof(capi.CsrView) and int(out[4]) == C.sizeof(capi.Options)
