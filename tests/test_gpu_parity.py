@@ -540,3 +540,35 @@ def test_spmv_launches_can_be_captured_in_a_hip_graph():
     torch.cuda.synchronize()
     _assert_close(y[:nrows].cpu().numpy(), 2.0 * yref, 2.0 * absy, TOL64, "graph replay, new x")
     A.close()
+
+
+def test_handles_release_their_device_memory():
+    """create / preprocess / spmv / destroy in a loop (one image, column panels, tuning, device-resident input, a communicator):
+    the free device memory comes back to where it was"""
+    import torch
+    nrows, ncols, rp, ci, va = CASES["power_law_3000"]
+    dev = torch.device("cuda", 0)
+    trp, tci, tva = (torch.from_numpy(a).to(dev) for a in (np.ascontiguousarray(rp, dtype=np.int64), np.ascontiguousarray(ci, dtype=np.int32), np.ascontiguousarray(va, dtype=np.float64)))
+    x = O.x_vec_fast(ncols)
+
+    def cycle():
+        for kw in (dict(), dict(col_panels=3), dict(tune_steps=True), dict(value_dict=0, keep_csr=True)):
+            A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, **kw)
+            A.spmv(x)
+            A.close()
+        B = cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), tci.data_ptr(), tva.data_ptr())
+        B.spmv(x)
+        B.close()
+
+    cycle()                                         # first use: code objects, RCCL, allocator pools
+    comm = cvr_amd.Comm(cvr_amd.comm_unique_id(), 1, 0, 0)
+    comm.close()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    for _ in range(5):
+        cycle()
+    comm = cvr_amd.Comm(cvr_amd.comm_unique_id(), 1, 0, 0)
+    comm.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free1 < (8 << 20), (free0, free1)          # 8 MiB of slack for driver-side pools
