@@ -572,3 +572,30 @@ def test_handles_release_their_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(dev)
     assert free0 - free1 < (8 << 20), (free0, free1)          # 8 MiB of slack for driver-side pools
+
+
+def test_independent_handles_on_concurrent_host_threads():
+    """different handles may be used from different host threads at the same time (the error text is thread-local, every
+    handle has its own stream and buffers); one handle is for one thread at a time, as documented in the header"""
+    import threading
+    names = ["power_law_3000", "uniform_2000", "two_giants", "dense_row_plus_singletons"]
+    out, errs = {}, []
+
+    def work(name):
+        try:
+            nrows, ncols, rp, ci, va = CASES[name]
+            x = O.x_vec_fast(ncols)
+            yref, absy = O.csr_spmv64(rp, ci, va, x)
+            for _ in range(5):
+                A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+                y, _ = A.spmv(x, iters=20)
+                A.close()
+                _assert_close(y, yref, absy, TOL64, ("threads", name))
+            out[name] = True
+        except Exception as e:          # noqa: BLE001 -- reported below with the case name
+            errs.append((name, repr(e)))
+
+    th = [threading.Thread(target=work, args=(n,)) for n in names]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs and len(out) == len(names), errs
