@@ -54,7 +54,7 @@ SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_c
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
            "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
-           "cvr_tune_steps", "cvr_auto_panels", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
+           "cvr_tune_steps", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
 
 
 def lib_path():
@@ -98,6 +98,7 @@ def lib():
         L.cvr_verdict.restype = C.c_int64
         L.cvr_tune_steps.argtypes = [C.POINTER(CsrView), C.POINTER(Options), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.cvr_auto_panels.argtypes = [C.POINTER(CsrView), C.POINTER(C.c_double)]
+        L.cvr_power_iteration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
         L.cvr_comm_unique_id.argtypes = [C.c_void_p]
         L.cvr_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cvr_comm_destroy.argtypes = [C.c_void_p]
@@ -336,6 +337,16 @@ class CvrMatrix:
         if rc:
             raise CvrError(rc, "cvr_spmv_gather_repeat")
         return last.value
+
+    def power_iteration(self, x_ptr, iters, comm=None, bounds=None, stream=None):
+        """x <- A x / ||A x||, `iters` times on the device (cvr_power_iteration); returns (Rayleigh quotient, seconds per iteration)"""
+        lam, sec = C.c_double(), C.c_double()
+        b = None if bounds is None else np.ascontiguousarray(bounds, dtype=np.int64)
+        rc = lib().cvr_power_iteration(self._h, None if comm is None else comm._c, None if b is None else b.ctypes.data, iters, x_ptr,
+                                       C.byref(lam), C.byref(sec), stream)
+        if rc:
+            raise CvrError(rc, "cvr_power_iteration")
+        return lam.value, sec.value
 
     def bench(self, warmup, iters):
         s = C.c_double()

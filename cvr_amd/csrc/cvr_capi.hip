@@ -957,6 +957,82 @@ int cvr_spmv_gather_repeat(cvr_handle *h, cvr_comm *c, const void *x_dev, void *
     return CVR_OK;
 }
 
+// ---- the iterative caller: power iteration x <- A x / ||A x||, everything on the device ------------------------------
+int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int iters, void *x_dev, double *lambda,
+                        double *seconds_per_iter, void *stream)
+{
+    if (!h || !x_dev || iters < 0) return fail(CVR_ERR_INVALID, "null argument");
+    if (!h->converted) return fail(CVR_ERR_STATE, "cvr_power_iteration before cvr_preprocess");
+    const int     nparts = c ? c->nranks : 1;
+    const int64_t n = h->info.ncols;                    // the whole (square) matrix has n rows and n columns
+    if (c && !bounds) return fail(CVR_ERR_INVALID, "a communicator needs the row bounds of the shards");
+    if (nparts > cvr::kIterMaxParts) return fail(CVR_ERR_INVALID, "more than %d shards", cvr::kIterMaxParts);
+    cvr::IterBounds bd;
+    int64_t         max_rows = 0;
+    if (c) {
+        if (c->device != h->device) return fail(CVR_ERR_INVALID, "communicator on device %d, matrix on device %d", c->device, h->device);
+        if (bounds[0] != 0 || bounds[nparts] != n) return fail(CVR_ERR_INVALID, "bounds must run from 0 to ncols = %lld (square matrix)", (long long)n);
+        for (int p = 0; p < nparts; p++) {
+            if (bounds[p + 1] < bounds[p]) return fail(CVR_ERR_INVALID, "bounds decrease");
+            max_rows = std::max(max_rows, bounds[p + 1] - bounds[p]);
+        }
+        for (int p = 0; p <= nparts; p++) bd.b[p] = bounds[p];
+        if (bounds[c->rank + 1] - bounds[c->rank] != h->info.nrows) return fail(CVR_ERR_INVALID, "this rank's bounds do not match its %lld rows", (long long)h->info.nrows);
+    } else if (h->info.nrows != n) {
+        return fail(CVR_ERR_INVALID, "power iteration needs a square matrix (%lld x %lld)", (long long)h->info.nrows, (long long)n);
+    }
+    const RcclApi *api = c ? rccl_api() : nullptr;
+    if (c && !api) return fail(CVR_ERR_NO_DEVICE, "RCCL not loaded");
+    const hipStream_t st = (hipStream_t)stream;
+    const bool        f32 = h->vsz == 4;
+    HIP_TRY(hipSetDevice(h->device));
+
+    // scratch: y_ext of this rank (room for the padded slice), the gathered padded y, the dense y, reduction cells
+    struct Scratch {
+        void *y = nullptr, *yall = nullptr, *dense = nullptr; double *partial = nullptr, *cells = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Scratch() { (void)hipFree(y); (void)hipFree(yall); (void)hipFree(dense); (void)hipFree(partial); (void)hipFree(cells);
+                     if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } s;
+    const size_t ny = (size_t)std::max<int64_t>(h->info.yext_elems, max_rows);
+    HIP_TRY(hipMalloc(&s.y, h->vsz * std::max<size_t>(ny, 1)));
+    HIP_TRY(hipMemsetAsync(s.y, 0, h->vsz * std::max<size_t>(ny, 1), st));
+    if (c) {
+        HIP_TRY(hipMalloc(&s.yall, h->vsz * std::max<size_t>((size_t)nparts * (size_t)max_rows, 1)));
+        HIP_TRY(hipMalloc(&s.dense, h->vsz * std::max<size_t>((size_t)n, 1)));
+    }
+    HIP_TRY(hipMalloc(&s.partial, sizeof(double) * (size_t)cvr::dot_partials()));
+    HIP_TRY(hipMalloc(&s.cells, sizeof(double) * 2));            // [0] = x . y (Rayleigh quotient), [1] = y . y
+    HIP_TRY(hipMemsetAsync(s.cells, 0, sizeof(double) * 2, st));
+    HIP_TRY(hipEventCreate(&s.e0));
+    HIP_TRY(hipEventCreate(&s.e1));
+
+    // x <- x / ||x||
+    HIP_TRY(cvr::launch_dot(x_dev, x_dev, n, f32, s.partial, s.cells + 1, st));
+    HIP_TRY(cvr::launch_scale(x_dev, x_dev, s.cells + 1, n, f32, st));
+    HIP_TRY(hipEventRecord(s.e0, st));
+    for (int it = 0; it < iters; it++) {
+        HIP_TRY(run_spmv(h, x_dev, s.y, st));
+        const void *yfull = s.y;
+        if (c) {            // the exchange step is on the critical path here: x of the next iteration is the gathered y
+            RCCL_TRY(api, api->all_gather(s.y, s.yall, (size_t)max_rows, f32 ? ncclFloat : ncclDouble, c->comm, st));
+            HIP_TRY(cvr::launch_unpad(s.dense, s.yall, bd, nparts, max_rows, f32, st));
+            yfull = s.dense;
+        }
+        HIP_TRY(cvr::launch_dot2(x_dev, yfull, n, f32, s.partial, s.cells, st));      // [0] = x . y, [1] = y . y, one pass
+        HIP_TRY(cvr::launch_scale(x_dev, yfull, s.cells + 1, n, f32, st));
+    }
+    HIP_TRY(hipEventRecord(s.e1, st));
+    double cells[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(cells, s.cells, sizeof(cells), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s.e0, s.e1));
+    if (lambda) *lambda = iters > 0 ? cells[0] : 0.0;
+    if (seconds_per_iter) *seconds_per_iter = iters > 0 ? (double)ms * 1e-3 / iters : 0.0;
+    return CVR_OK;
+}
+
 int cvr_spmv_bench(cvr_handle *h, int warmup, int iters, double *mean_s)
 {
     if (!h || iters < 1) return fail(CVR_ERR_INVALID, "bad argument");

@@ -44,6 +44,19 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 
 // value-dictionary detection over vals[n0, n1) on the device: `table` = 1024 u64 slots preset to all ones, flags[0] bit 0 =
 // more than kDictMax distinct values, bit 1 = the all-ones pattern occurs, flags[1] = entries in the table
+// ---- vector kernels of the iterative caller (cvr_iter.hip) ----
+constexpr int kIterMaxParts = 64;
+struct IterBounds { long long b[kIterMaxParts + 1]; };   // row offsets of the shards (by value into the kernel)
+int        dot_partials();                                // doubles of scratch launch_dot needs
+// out[0] = sum a[i] * b[i] (fp64 accumulation, fixed tree: bitwise reproducible); asynchronous
+hipError_t launch_dot(const void *a, const void *b, int64_t n, bool f32, double *partial, double *out, hipStream_t st);
+// out2[0] = x . y, out2[1] = y . y in one pass (the two reductions of a power-iteration step)
+hipError_t launch_dot2(const void *x, const void *y, int64_t n, bool f32, double *partial, double *out2, hipStream_t st);
+// x[i] = y[i] / sqrt(norm2[0])
+hipError_t launch_scale(void *x, const void *y, const double *norm2, int64_t n, bool f32, hipStream_t st);
+// dense[bd.b[p] + i] = padded[p * max_rows + i], i < bd.b[p+1] - bd.b[p]
+hipError_t launch_unpad(void *dense, const void *padded, const IterBounds &bd, int nparts, int64_t max_rows, bool f32, hipStream_t st);
+
 // min / max of col_idx[n0 .. n1) into minmax[0..1] (device; initialised by the caller to INT_MAX / INT_MIN)
 hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st);
 hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, unsigned long long *table, uint32_t *flags, hipStream_t st);

@@ -168,6 +168,17 @@ int cvr_comm_all_gather(cvr_comm *comm, const void *send_dev, void *recv_dev, in
 int cvr_spmv_gather_repeat(cvr_handle *h, cvr_comm *comm, const void *x_dev, void *const y_dev[2], void *const yall_dev[2],
                            int64_t max_rows, int n, int overlap, void *stream, int *last_buf);
 
+/* The iterative caller (power iteration): x <- A x / ||A x||, `iters` times, everything on the device and on `stream`
+ * with no host round trip inside the loop; dot products use a fixed reduction tree, so results are bitwise reproducible.
+ * x_dev: info.x_elems values, in: the start vector (any non-zero), out: the normalised iterate; x_dev[ncols] stays 0.
+ * *lambda = x_k . (A x_k) of the last iteration (Rayleigh quotient).  comm = NULL: one GPU, the handle holds the whole
+ * square matrix.  comm != NULL: the handle holds this rank's row block of a square matrix of ncols rows, bounds[nranks+1]
+ * are the row offsets of all blocks, and every iteration all-gathers y over RCCL and rebuilds the replicated x from
+ * it -- the one setting where the exchange step is on the critical path.  Synchronises `stream` before returning.
+ * (The reference has no such loop: its Ntimes loop, spmv.cpp:1024, recomputes one y.) */
+int cvr_power_iteration(cvr_handle *h, cvr_comm *comm, const int64_t *bounds, int iters, void *x_dev, double *lambda,
+                        double *seconds_per_iter, void *stream);
+
 /* the handle's own device vectors (valid until cvr_destroy) and stream */
 void *cvr_x_device(cvr_handle *h);
 void *cvr_y_device(cvr_handle *h);

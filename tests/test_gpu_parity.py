@@ -283,11 +283,27 @@ def test_power_iteration_device_resident():
     nrows, ncols, rp, ci, va = synth.web_google_like(scale=0.02)
     va = np.abs(va) + 0.5                      # positive matrix: the dominant eigenpair is real and simple
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
-    lam, x, _ = power.power_iteration(A, nrows, iters=30)
+    lam, x, sec = power.power_iteration(A, nrows, iters=30)
     lam_ref, x_ref = _power_iteration_numpy(rp, ci, va, iters=30)
-    assert abs(lam - lam_ref) <= 1e-9 * abs(lam_ref)
+    assert abs(lam - lam_ref) <= 1e-9 * abs(lam_ref) and sec > 0
     assert np.allclose(x.cpu().numpy(), x_ref, rtol=0, atol=1e-9)
+    lam2, x2, _ = power.power_iteration(A, nrows, iters=30)              # fixed reduction trees: bit for bit again
+    assert lam2 == lam and torch.equal(x2.view(torch.int64), x.view(torch.int64))
+    # the sharded form of the loop with a 1-rank RCCL communicator (all-gather, un-padding, rebuilt x)
+    comm = cvr_amd.Comm(cvr_amd.comm_unique_id(), 1, 0, 0)
+    lam3, x3, _ = power.power_iteration(A, nrows, bounds=[0, nrows], comm=comm, iters=30)
+    assert lam3 == lam and torch.equal(x3.view(torch.int64), x.view(torch.int64))
+    with pytest.raises(cvr_amd.CvrError):
+        power.power_iteration(A, nrows, bounds=[0, nrows - 1], comm=comm, iters=1)
+    comm.close()
     A.close()
+    nr, nc, rp2, ci2, va2 = CASES["few_rows_lt_lanes"]
+    if nr != nc:                                                         # not square: refused with a code
+        B = cvr_amd.CvrMatrix(nr, nc, rp2, ci2, va2)
+        xx = torch.ones(B.info.x_elems, dtype=torch.float64, device="cuda")
+        with pytest.raises(cvr_amd.CvrError):
+            B.power_iteration(xx.data_ptr(), 1)
+        B.close()
 
 
 @pytest.mark.parametrize("P", [2, 3, 7])
