@@ -208,6 +208,16 @@ int main(int argc, char **argv)
            G, niters, nnz_true, (long long)m.ref_numRows, info[0].steps_per_chunk, (long long)chunks, (long long)cut, pre_s, t_compute, t_total,
            2.0 * nnz_true / t_total / 1e9, balg / t_total / 1e9, balg / t_compute / (8e12 * G), (long long)wrong);
 
+    // CVR_POWER=<iterations>: the iterative caller on the same handle (one GPU, square matrix): x <- A x / ||A x||
+    const char *penv = getenv("CVR_POWER");
+    if (penv && atoi(penv) > 0 && G == 1 && m.nrows == m.ncols) {
+        std::vector<double> ones((size_t)m.ncols, 1.0);
+        HIP_OK(hipMemcpy(dx[0], ones.data(), sizeof(double) * (size_t)m.ncols, hipMemcpyHostToDevice));
+        double lambda = 0, sec = 0;
+        CVR_OKAY(cvr_power_iteration(H[0], nullptr, nullptr, atoi(penv), dx[0], &lambda, &sec, st[0]));
+        printf("{\"power_iterations\":%d,\"rayleigh_quotient\":%.15g,\"seconds_per_iteration\":%.6g}\n", atoi(penv), lambda, sec);
+    }
+
     for (int g = 0; g < G; g++) {
         (void)hipSetDevice(devs[(size_t)g]);
         if (use_rccl) ncclCommDestroy(comm[(size_t)g]);

@@ -222,6 +222,14 @@ def test_cli_prints_the_reference_lines():
     r = subprocess.run([exe, mtx, "2", "5"], capture_output=True, text=True, timeout=120, env=dict(os.environ, CVR_DEVICES="0,0,0", CVR_X="rand"))
     assert r.returncode == 0, r.stderr
     assert "Very Good! Your result is correct" in r.stdout and '"gpus":3' in r.stdout and '"wrong":0' in r.stdout
+    # CVR_POWER: the native iterative caller from the host program (square matrix, one GPU)
+    import json
+    r = subprocess.run([exe, mtx, "2", "3"], capture_output=True, text=True, timeout=120, env=dict(os.environ, CVR_POWER="25", CVR_MM="strict"))
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"power_iterations"')]
+    assert len(line) == 1
+    pw = json.loads(line[0])
+    assert pw["power_iterations"] == 25 and pw["rayleigh_quotient"] > 0 and pw["seconds_per_iteration"] > 0
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "usage" in r.stderr
     r = subprocess.run([exe, "/nonexistent.mtx", "1", "1"], capture_output=True, text=True, timeout=60)
