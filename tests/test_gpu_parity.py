@@ -305,6 +305,12 @@ def test_power_iteration_device_resident():
         power.power_iteration(A, nrows, bounds=[0, nrows - 1], comm=comm, iters=1)
     comm.close()
     A.close()
+    # fp32 matrix and column panels: the same loop, fp32 tolerance
+    A32 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va.astype(np.float32), col_panels=2)
+    lam32, x32, _ = power.power_iteration(A32, nrows, iters=30)
+    assert abs(lam32 - lam_ref) <= 1e-4 * abs(lam_ref)
+    assert np.allclose(x32.cpu().numpy().astype(np.float64), x_ref, rtol=0, atol=1e-5)
+    A32.close()
     nr, nc, rp2, ci2, va2 = CASES["few_rows_lt_lanes"]
     if nr != nc:                                                         # not square: refused with a code
         B = cvr_amd.CvrMatrix(nr, nc, rp2, ci2, va2)
