@@ -7,12 +7,16 @@
 
 A "step" is one y = A x over the web-Google-shaped matrix (916 428 x 916 428, 5 105 039 nnz, fp64; seeded
 synthetic stand-in, or the real web-Google.mtx when CVR_DATA_DIR holds it), matrix image, x and y resident
-in HBM.  N > 1: rows are sharded over the ranks (balanced nnz, cut at row boundaries), x is replicated, every
-step ends with the all-gather of the y slices over RCCL ("strong" scaling: the matrix is fixed); the steps of this
-fixed-x loop are independent, so the gather of step k is left to overlap the SpMV of step k+1 (double-buffered y).
+in HBM.  N > 1: rows are sharded over the ranks (balanced nnz, cut at row boundaries; S of a shard chosen by measurement,
+cvr_tune_steps), x is replicated, every step ends with the all-gather of the y slices over RCCL ("strong" scaling: the
+matrix is fixed).  The loop of steps runs inside the library (cvr_spmv_gather_repeat: SpMV and ncclAllGather enqueued
+back to back, no Python between steps) once every rank has built its communicator and its first gather has been checked
+bit for bit against torch.distributed's; in order or overlapped (gather of step k under the SpMV of step k+1), whichever
+200 untimed steps show to be faster on this node.  Otherwise the same loop runs over torch.distributed.
 Rank 0 prints ONE JSON line.  The roofline object prices the SpMV kernel alone (algorithmic bytes of SURVEY.md
-8(d) / mean kernel time from HIP events on the launch stream); cpu_baseline is the oracle's 8-lane OpenMP
-restatement of the reference's CVR path on the host cores (rank 0, N = 1 only).
+8(d) / mean kernel time from HIP events on the launch stream); cpu_baseline is the unmodified reference built by
+oracle/Makefile into oracle/_ref/ (kind "reference"; the oracle's 8-lane OpenMP restatement, kind "port", when that
+binary is absent) on the host cores (rank 0, N = 1 only).
 """
 import argparse
 import json
