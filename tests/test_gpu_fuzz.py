@@ -12,6 +12,11 @@ import oraclelib as O
 
 pytestmark = pytest.mark.gpu
 
+try:
+    import torch
+except Exception:      # noqa: BLE001 -- the device-array cases are skipped without torch
+    torch = None
+
 
 def _random_case(rng):
     kind = rng.integers(0, 5)
@@ -49,7 +54,16 @@ def test_fuzz_parity():
         P = int(rng.choice([1, 1, 2, 3]))
         win = int(rng.choice([0, 0, 64, 1000]))
         ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32)
-        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, col_panels=P, x_window=win)
+        from_dev = torch is not None and len(ci) > 0 and rng.integers(0, 4) == 0     # CSR arrays already on the device
+        if from_dev:
+            keep = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp.astype(np.int64), ci.astype(np.int32), va)]
+            torch.cuda.synchronize()
+            A = cvr_amd.CvrMatrix.from_device(nrows, ncols, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), is_f32=f32,
+                                              steps_per_chunk=S, split_threshold=thr, col_panels=P)
+            win = 0
+        else:
+            A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, col_panels=P, x_window=win)
+        ctx["from_dev"] = bool(from_dev)
         if P == 1:
             mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0)
             img = A.export_image()
