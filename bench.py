@@ -263,6 +263,9 @@ def main():
             last[0] = shard.pipelined_steps(lambda yb: A.spmv_device(x.data_ptr(), yb.data_ptr(), sptr), ybufs, yalls, max_rows, n)
 
     def sync():
+        # drain this rank's queue first: the library's communicator and torch.distributed's are different RCCL
+        # communicators, and their collectives should never be in flight at the same time
+        torch.cuda.synchronize()
         if sharded:
             dist.barrier()
         torch.cuda.synchronize()
