@@ -333,6 +333,21 @@ def main():
         b.record(stream)
     torch.cuda.synchronize()
     singles = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    # throughput of independent SpMVs alternating on two streams with their own y (the per-launch floor of one overlaps the body
+    # of the other); reported for information, never the value: the steps of the metric run one after the other
+    two = None
+    if not sharded:
+        st2 = torch.cuda.Stream(device=dev)
+        y2 = torch.zeros_like(y)
+        pair = ((sptr, y), (st2.cuda_stream, y2))
+        for i in range(2 * args.warmup):
+            A.spmv_device(x.data_ptr(), pair[i & 1][1].data_ptr(), pair[i & 1][0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            A.spmv_device(x.data_ptr(), pair[i & 1][1].data_ptr(), pair[i & 1][0])
+        torch.cuda.synchronize()
+        two = (time.perf_counter() - t0) / args.steps
     kern_max_s = kern_s
     if sharded:                         # the slowest rank's SpMV alone: what the job would run at without the exchange step
         t = torch.tensor([kern_s], dtype=torch.float64, device=dev)
@@ -389,6 +404,7 @@ def main():
             "spmv_only_ms_max_over_ranks": kern_max_s * 1e3, "gflops_spmv_only_no_exchange": 2.0 * nnz / kern_max_s / 1e9,
             "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
             "preprocess": {"plan_s": info.plan_s, "upload_s": info.upload_s, "convert_s": info.convert_s, "tune_steps_s": A.tuning_s},
+            "independent_spmvs_on_two_streams": None if two is None else {"ms_per_spmv": two * 1e3, "gflops": 2.0 * nnz / two / 1e9},
             "verdict_wrong_rows": wrong, "gather_impl": gather_impl, "gather_calibration_ms_per_step": calib,
         }
         if world == 1 and not args.no_cpu_baseline:
