@@ -49,19 +49,18 @@ struct Range {
     typedef int (*pop_t)(void);
     static void resolve(push_t &push, pop_t &pop)
     {
-        static push_t p = nullptr;
-        static pop_t  q = nullptr;
-        static bool   tried = false;
-        if (!tried) {
-            tried = true;
+        struct Fns { push_t p = nullptr; pop_t q = nullptr; };
+        static const Fns f = [] {              // once, thread-safe
+            Fns r;
             const char *e = getenv("CVR_ROCTX");
             if (e && atoi(e)) {
                 void *lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
                 if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
-                if (lib) { p = (push_t)dlsym(lib, "roctxRangePushA"); q = (pop_t)dlsym(lib, "roctxRangePop"); }
+                if (lib) { r.p = (push_t)dlsym(lib, "roctxRangePushA"); r.q = (pop_t)dlsym(lib, "roctxRangePop"); }
             }
-        }
-        push = p; pop = q;
+            return r;
+        }();
+        push = f.p; pop = f.q;
     }
     pop_t pop_ = nullptr;
     explicit Range(const char *name)
@@ -808,26 +807,25 @@ struct RcclApi {
 // instance the process already holds (PyTorch ships its own librccl.so) so that one runtime serves both.
 const RcclApi *rccl_api()
 {
-    static RcclApi api;
-    static bool    tried = false;
-    if (!tried) {
-        tried = true;
+    static const RcclApi api = [] {            // initialised once, thread-safe (C++11 function-local static)
+        RcclApi a;
         const char *names[] = {getenv("CVR_RCCL_LIB"), "librccl.so", "librccl.so.1"};
-        for (int pass = 0; pass < 2 && !api.lib; pass++)
+        for (int pass = 0; pass < 2 && !a.lib; pass++)
             for (const char *n : names) {
                 if (!n || !*n) continue;
-                api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
-                if (api.lib) break;
+                a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (a.lib) break;
             }
-        if (api.lib) {
-            api.get_unique_id = (decltype(api.get_unique_id))dlsym(api.lib, "ncclGetUniqueId");
-            api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(api.lib, "ncclCommInitRank");
-            api.comm_destroy = (decltype(api.comm_destroy))dlsym(api.lib, "ncclCommDestroy");
-            api.all_gather = (decltype(api.all_gather))dlsym(api.lib, "ncclAllGather");
-            api.error_string = (decltype(api.error_string))dlsym(api.lib, "ncclGetErrorString");
-            if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_gather || !api.error_string) api.lib = nullptr;
+        if (a.lib) {
+            a.get_unique_id = (decltype(a.get_unique_id))dlsym(a.lib, "ncclGetUniqueId");
+            a.comm_init_rank = (decltype(a.comm_init_rank))dlsym(a.lib, "ncclCommInitRank");
+            a.comm_destroy = (decltype(a.comm_destroy))dlsym(a.lib, "ncclCommDestroy");
+            a.all_gather = (decltype(a.all_gather))dlsym(a.lib, "ncclAllGather");
+            a.error_string = (decltype(a.error_string))dlsym(a.lib, "ncclGetErrorString");
+            if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather || !a.error_string) a.lib = nullptr;
         }
-    }
+        return a;
+    }();
     return api.lib ? &api : nullptr;
 }
 
