@@ -1,4 +1,5 @@
-// cvr_spmv.hip -- y = A x over the CVR64 image, one wavefront per chunk (gfx950, wave64).  HBM-bound.
+// cvr_spmv.hip -- y = A x over the CVR64 image, one wavefront per chunk (gfx950, wave64).  Memory-bound: by HBM on
+// matrices whose columns share lines (banded), by the CU's L1 miss path (128-byte fills) on scattered columns.
 //
 // The reference's spmv_compute_kernel (/root/reference/spmv.cpp:1016-1667) re-derived for 64 lanes:
 //   * one loop instead of the five hand-split phases A-E (spmv.cpp:1167-1629): each step is
