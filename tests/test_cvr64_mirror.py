@@ -114,3 +114,43 @@ def test_mirror_value_dictionary(name):
     if len(np.unique(va)) > 256:
         with pytest.raises(RuntimeError):
             O.Cvr64(nrows, ncols, rp, ci, va, 8, use_dict=True)
+
+
+def test_product_planner_equals_mirror_on_random_row_lengths():
+    """the product's host planner (eight-rows-at-a-time fast path, split threshold, pad segments) against the mirror's
+    one-row-at-a-time planner on random row-length distributions: same chunk starts, first rows, segment and pad counts;
+    and the mirror built on that plan still reproduces the CSR y"""
+    import cvr_amd
+    rng = np.random.default_rng(424242)
+    for case in range(120):
+        kind = case % 6
+        nrows = int(rng.integers(1, 2500))
+        if kind == 0:
+            lens = rng.integers(0, 3, nrows)
+        elif kind == 1:
+            lens = np.minimum((rng.pareto(1.0, nrows) + 0.5).astype(np.int64), 4000)
+        elif kind == 2:
+            lens = np.full(nrows, int(rng.integers(1, 9)))                     # exact fills of 8-row blocks
+        elif kind == 3:
+            lens = np.where(rng.random(nrows) < 0.02, rng.integers(500, 9000, nrows), rng.integers(0, 4, nrows))
+        elif kind == 4:
+            lens = np.zeros(nrows, dtype=np.int64)                             # only empty rows (pad slots)
+        else:
+            lens = rng.integers(0, 40, nrows) * (rng.random(nrows) < 0.5)
+        lens = np.asarray(lens, dtype=np.int64)
+        ncols = int(rng.integers(1, 3000))
+        nrows, ncols, rp, ci, va = K.csr_from_lengths(lens, ncols, rng)
+        S = int(rng.choice([4, 8, 12, 16, 28, 32, 56, 64, 128]))
+        thr = int(rng.choice([0, 1, 5, 64, 10**7]))
+        m = O.Cvr64(nrows, ncols, rp, ci, va, S, thr)
+        p = cvr_amd.plan_chunks(rp, S, thr)
+        ctx = dict(case=case, kind=kind, nrows=nrows, S=S, thr=thr)
+        assert len(p["row_first"]) == m.nchunks, ctx
+        assert np.array_equal(p["nz_begin"], m.nz_begin), ctx
+        assert np.array_equal(p["row_first"], m.desc[:, 0].astype(np.int64)), ctx
+        assert np.array_equal(p["nseg"], m.desc[:, 1].astype(np.int64)), ctx
+        assert np.array_equal(p["pad_cnt"], m.pad_cnt), ctx
+        x = O.x_vec_fast(ncols, "rand")
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        bad, worst = O.tol_check(m.spmv(x), yref, absy + 1e-30)
+        assert len(bad) == 0, (ctx, worst)
