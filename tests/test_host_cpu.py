@@ -303,3 +303,39 @@ int main(void)
     assert out[0].startswith("cvr_amd") and out[1] == "1"
     assert int(out[2]) in (0, capi.ERR_NO_DEVICE)
     assert int(out[3]) == C.sizeof(capi.CsrView) and int(out[4]) == C.sizeof(capi.Options)
+
+
+def test_loader_fuzz_against_the_pinned_oracle_loader(tmp_path):
+    """random small Matrix-Market files (rectangular, duplicates, comments, every field / symmetry the reference accepts):
+    cvr_mm_read(REFCOMPAT) == the oracle's restatement of readMatrix, array for array"""
+    rng = np.random.default_rng(20261003)
+    for case in range(80):
+        field = ["pattern", "real", "integer"][case % 3]
+        sym = ["general", "symmetric"][(case // 3) % 2]
+        nr = int(rng.integers(1, 60))
+        nc = nr if sym == "symmetric" else int(rng.integers(1, 60))
+        m = int(rng.integers(1, 400))
+        r = rng.integers(1, nr + 1, size=m)
+        c = rng.integers(1, nc + 1, size=m)
+        if sym == "symmetric":
+            r, c = np.maximum(r, c), np.minimum(r, c)
+        p = tmp_path / f"f{case}.mtx"
+        with open(p, "w") as f:
+            f.write(f"%%MatrixMarket matrix coordinate {field} {sym}\n")
+            for _ in range(int(rng.integers(0, 3))):
+                f.write("% comment\n")
+            f.write(f"{nr} {nc} {m}\n")
+            for k in range(m):
+                if field == "pattern":
+                    f.write(f"{r[k]} {c[k]}\n")
+                elif field == "integer":
+                    f.write(f"{r[k]} {c[k]} {int(rng.integers(-9, 10))}\n")
+                else:
+                    f.write(f"{r[k]}  {c[k]}\t{rng.normal():.7g}\n")
+        a = cvr_amd.load_mm(str(p), capi.MM_REFCOMPAT)
+        b = O.read_matrix(str(p))
+        ctx = dict(case=case, field=field, sym=sym, nr=nr, nc=nc, m=m)
+        assert (a["ref_nItems"], a["ref_nItemsRaw"], a["ref_numRows"], a["ref_numCols"]) == (b["nItems"], b["nItemsRaw"], b["numRows"], b["numCols"]), ctx
+        assert np.array_equal(a["row_ptr"], b["rowptr"].astype(np.int64)), ctx
+        assert np.array_equal(a["col_idx"], b["cols"]), ctx
+        assert np.array_equal(a["vals"].view(np.uint64), b["val"].view(np.uint64)), ctx
