@@ -659,3 +659,20 @@ def test_bench_line_keeps_the_driver_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, (k, cb)
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1
+
+
+def test_minimal_c_example_builds_and_runs():
+    """examples/minimal.c: a C99 program over the boundary, compiled with gcc on the GPU box, computes the 4 x 4 product"""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "minimal")
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", f"-I{root}/include", os.path.join(root, "examples", "minimal.c"),
+                        f"-L{root}/cvr_amd", "-lcvr_amd", f"-Wl,-rpath,{root}/cvr_amd", "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.startswith("y = 201 0 5043 600"), r.stdout
