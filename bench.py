@@ -49,6 +49,9 @@ def load_workload(kind="webgoogle"):
     if kind == "livejournal":      # BASELINE.json configs[2]
         n, nc, rp, ci, va = synth.livejournal_like()
         return n, nc, rp, ci, va, "synthetic soc-LiveJournal1-shaped, seed 20261003"
+    if kind.startswith("rmat"):    # configs[4]: R-MAT (Graph500 parameters), fp32, rmat<scale> (default 22)
+        n, nc, rp, ci, va = synth.rmat(int(kind[4:] or 22), dtype=np.float32)
+        return n, nc, rp, ci, va, f"synthetic R-MAT scale {int(kind[4:] or 22)}, edge factor 16, fp32"
     if kind.startswith("banded"):  # configs[3]: nlpkkt240's shape; banded<rows>, default 28e6 rows / 8
         n, nc, rp, ci, va = synth.banded_sym(int(float(kind[6:] or 3.5e6)))
         return n, nc, rp, ci, va, "synthetic banded symmetric (27 nnz/row, nlpkkt240's shape)"
@@ -151,7 +154,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--steps-per-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="webgoogle", help="webgoogle (the headline, default) | livejournal | banded[<rows>]")
+    ap.add_argument("--workload", default="webgoogle", help="webgoogle (the headline, default) | livejournal | banded[<rows>] | rmat[<scale>] (fp32)")
     args = ap.parse_args()
 
     import torch
@@ -195,11 +198,14 @@ def main():
     max_rows, pick = shard.gather_layout(bounds)
 
     dev = torch.device("cuda", local_rank)
-    x = torch.zeros(info.x_elems, dtype=torch.float64, device=dev)
-    x[:ncols] = torch.from_numpy(synth.x_rand(ncols)).to(dev)
+    f32 = va.dtype == np.float32
+    tdt, vbytes = (torch.float32, 4) if f32 else (torch.float64, 8)
+    bits = torch.int32 if f32 else torch.int64
+    x = torch.zeros(info.x_elems, dtype=tdt, device=dev)
+    x[:ncols] = torch.from_numpy(synth.x_rand(ncols, va.dtype)).to(dev)
     ny = max(info.yext_elems, max_rows)
-    ybufs = [torch.zeros(ny, dtype=torch.float64, device=dev) for _ in range(2 if sharded else 1)]
-    yalls = [torch.zeros(world * max_rows, dtype=torch.float64, device=dev) for _ in range(2)] if sharded else None
+    ybufs = [torch.zeros(ny, dtype=tdt, device=dev) for _ in range(2 if sharded else 1)]
+    yalls = [torch.zeros(world * max_rows, dtype=tdt, device=dev) for _ in range(2)] if sharded else None
     y = ybufs[0]
     stream = torch.cuda.Stream(device=dev)     # kernels, events and the collective all go on this stream
     torch.cuda.set_stream(stream)
@@ -238,11 +244,11 @@ def main():
                 try:                # phase 2: its first gather against torch.distributed's, bit for bit
                     A.spmv_device(x.data_ptr(), ybufs[0].data_ptr(), sptr)
                     stream.synchronize()
-                    comm.all_gather(ybufs[0].data_ptr(), yalls[0].data_ptr(), max_rows, False, sptr)
+                    comm.all_gather(ybufs[0].data_ptr(), yalls[0].data_ptr(), max_rows, f32, sptr)
                     stream.synchronize()
                     want = shard.all_gather_y(ybufs[0], max_rows)
                     torch.cuda.synchronize()
-                    ok = torch.equal(want.view(torch.int64), yalls[0].view(torch.int64))
+                    ok = torch.equal(want.view(bits), yalls[0].view(bits))
                 except Exception as e:
                     print(f"[bench rank {rank}] native gather failed its check: {e!r}", file=sys.stderr)
                 if agree(ok):
@@ -314,7 +320,7 @@ def main():
         e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         def gather_once():
             if comm is not None:
-                comm.all_gather(ybufs[0].data_ptr(), yalls[0].data_ptr(), max_rows, False, sptr)
+                comm.all_gather(ybufs[0].data_ptr(), yalls[0].data_ptr(), max_rows, f32, sptr)
             else:
                 shard.all_gather_y(ybufs[0], max_rows, out=yalls[0])
         for _ in range(5):
@@ -354,7 +360,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kern_max_s = float(t.item())
     lnnz = int(lrp[-1])
-    balg_local = synth.b_alg(lrows, ncols, lnnz)
+    balg_local = synth.b_alg(lrows, ncols, lnnz, vbytes)
     achieved = balg_local / kern_s / 1e9
 
     # parity guard on the timed configuration: y of the last step against the host CSR loop of the product
@@ -362,8 +368,13 @@ def main():
     yh = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()
     wrong = -1
     if rank == 0:
-        yref = cvr_amd.csr_spmv_host(rp, ci, va, x[:ncols].cpu().numpy(), nthreads=len(os.sched_getaffinity(0)))
-        wrong = int(cvr_amd.verdict(yh, yref, nrows))
+        xh = x[:ncols].cpu().numpy().astype(np.float64)
+        yref = cvr_amd.csr_spmv_host(rp, ci, va.astype(np.float64), xh, nthreads=len(os.sched_getaffinity(0)))
+        if f32:     # no reference counterpart: rows off by more than 2e-5 of sum |a x| against the fp64 loop
+            absy = cvr_amd.csr_spmv_host(rp, ci, np.abs(va).astype(np.float64), np.abs(xh), nthreads=len(os.sched_getaffinity(0)))
+            wrong = int(np.count_nonzero(np.abs(yh.astype(np.float64) - yref) > 2e-5 * absy + 1e-30))
+        else:
+            wrong = int(cvr_amd.verdict(yh, yref, nrows))
 
     copy_gbs = None
     if rank == 0:
@@ -375,7 +386,7 @@ def main():
     if rank == 0:
         per = wall / args.steps
         out = {
-            "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64" if args.workload == "webgoogle" else f"SpMV GFLOP/s (2*nnz/t), {args.workload} fp64",
+            "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64" if args.workload == "webgoogle" else f"SpMV GFLOP/s (2*nnz/t), {args.workload} {'fp32' if f32 else 'fp64'}",
             "value": 2.0 * nnz / per / 1e9,
             "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -383,9 +394,9 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if f32 else "f64",
             "data": "synthetic" if source.startswith("synthetic") else "real",
-            "config": {"workload": f"{source}: {nrows}x{ncols}, nnz {nnz}, fp64, y = A x with A (CVR64 image), x, y resident in HBM",
+            "config": {"workload": f"{source}: {nrows}x{ncols}, nnz {nnz}, {'fp32' if f32 else 'fp64'}, y = A x with A (CVR64 image), x, y resident in HBM",
                        "rows_per_gpu": [int(v) for v in np.diff(bounds)],
                        "nnz_per_gpu": [int(rp[bounds[p + 1]] - rp[bounds[p]]) for p in range(world)],
                        "nnz_imbalance_max_over_mean": float(max(int(rp[bounds[p + 1]] - rp[bounds[p]]) for p in range(world)) * world / max(nnz, 1)),
@@ -395,11 +406,11 @@ def main():
                        "parallelism": ("rows sharded, x replicated, y all-gathered (%s)" % ("RCCL" if os.environ.get("CVR_BENCH_BACKEND", "nccl") == "nccl" else os.environ["CVR_BENCH_BACKEND"])) if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if world == 1 and args.workload == "webgoogle" else None,
-                         "kernel": "cvr::spmv_kernel<double>", "kernel_us": kern_s * 1e6,
+                         "kernel": "cvr::spmv_kernel<float>" if f32 else "cvr::spmv_kernel<double>", "kernel_us": kern_s * 1e6,
                          "kernel_us_median_single_launches": singles[len(singles) // 2] if singles else None, "kernel_us_min_single_launches": singles[0] if singles else None,
                          "copy_kernel_gbs": copy_gbs, "frac_of_copy_kernel": achieved / copy_gbs if copy_gbs else None,
                          "algorithmic_bytes_per_launch": int(balg_local)},
-            "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz) / per / 1e9,
+            "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz, vbytes) / per / 1e9,
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
             "spmv_only_ms_max_over_ranks": kern_max_s * 1e3, "gflops_spmv_only_no_exchange": 2.0 * nnz / kern_max_s / 1e9,
             "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
