@@ -292,7 +292,7 @@ int main(void)
     int P = cvr_auto_panels(&v, &miss);
     cvr_handle *h = 0;
     int rc = cvr_device_count() > 0 ? 0 : cvr_create(&h, &v, &o);
-    printf("%s|%d|%d|%d|%d\n", cvr_version(), P, rc, (int)sizeof(cvr_csr_view), (int)sizeof(cvr_options));
+    printf("%s|%d|%d|%d|%d|%d|%d\n", cvr_version(), P, rc, (int)sizeof(cvr_csr_view), (int)sizeof(cvr_options), (int)sizeof(cvr_info), (int)sizeof(cvr_timing));
     return 0;
 }
 ''')
@@ -303,6 +303,7 @@ int main(void)
     assert out[0].startswith("cvr_amd") and out[1] == "1"
     assert int(out[2]) in (0, capi.ERR_NO_DEVICE)
     assert int(out[3]) == C.sizeof(capi.CsrView) and int(out[4]) == C.sizeof(capi.Options)
+    assert int(out[5]) == C.sizeof(capi.Info) and int(out[6]) == C.sizeof(capi.Timing)
 
 
 def test_loader_fuzz_against_the_pinned_oracle_loader(tmp_path):
