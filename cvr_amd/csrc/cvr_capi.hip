@@ -459,13 +459,31 @@ static double l2_miss_estimate(const cvr_csr_view &v)
     const size_t  resident = (size_t)(4u << 20) / 128;
     const int     nwin = nrows == W ? 1 : 8;
     std::vector<double> refs_w((size_t)nwin, 0.0), miss_w((size_t)nwin, 0.0);
+    // with the arrays on the device only the windows' slices of col_idx are fetched (row_ptr is a host copy by now)
+    std::vector<std::vector<int32_t>> fetched((size_t)nwin);
+    std::vector<const int32_t *>      base((size_t)nwin, nullptr);
+    std::vector<int64_t>              shift((size_t)nwin, 0);
+    for (int w = 0; w < nwin; w++) {
+        const int64_t r0 = nwin == 1 ? 0 : (nrows - W) * w / (nwin - 1);
+        const int64_t j0 = v.row_ptr[r0], j1 = v.row_ptr[r0 + W];
+        if (v.arrays_on_device) {
+            fetched[(size_t)w].resize((size_t)std::max<int64_t>(j1 - j0, 1));
+            if (j1 > j0 && hipMemcpy(fetched[(size_t)w].data(), v.col_idx + j0, sizeof(int32_t) * (size_t)(j1 - j0), hipMemcpyDeviceToHost) != hipSuccess) return 0.0;
+            base[(size_t)w] = fetched[(size_t)w].data();
+            shift[(size_t)w] = j0;
+        } else {
+            base[(size_t)w] = v.col_idx;
+        }
+    }
     auto window = [&](int w) {          // one thread per window, each with its own counters
         const int64_t r0 = nwin == 1 ? 0 : (nrows - W) * w / (nwin - 1);
         const int64_t j0 = v.row_ptr[r0], j1 = v.row_ptr[r0 + W];
         if (j1 <= j0) return;
+        const int32_t *col = base[(size_t)w];
+        const int64_t  sh = shift[(size_t)w];
         std::vector<uint32_t> cnt((size_t)nlines, 0u), touched;
         for (int64_t j = j0; j < j1; j++) {
-            const size_t l = (size_t)(v.col_idx[j] / per_line);
+            const size_t l = (size_t)(col[j - sh] / per_line);
             if (cnt[l]++ == 0) touched.push_back((uint32_t)l);
         }
         std::vector<uint32_t> top(touched.size());
@@ -524,13 +542,11 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         return fail(CVR_ERR_INVALID, "steps_per_chunk must be a multiple of 4 in [4, 4096]");
 
     // CSR arrays already in device memory (of opt.device): the planner walks row_ptr on the host, so that array comes
-    // back (8 B per row); col_idx and vals stay where they are and are copied device to device.  Only when column
-    // panels are possible (x >= 24 MB, or asked for) do they take the detour through the host, where the split runs.
+    // back (8 B per row); col_idx and vals stay where they are and are copied device to device; column panels are
+    // split on the device too (cvr_split.hip); the automatic panel rule fetches the eight sample windows of col_idx it looks at.
     cvr_csr_view          hostv = *csr_in;
     const cvr_csr_view   *csr = &hostv;
     std::vector<int64_t>  rp_host;
-    std::vector<int32_t>  ci_host;
-    std::vector<uint8_t>  va_host;
     hipMemcpyKind         civa_kind = hipMemcpyHostToDevice;
     if (on_device) {
         if (hostv.nrows < 0 || hostv.ncols < 0 || (hostv.nrows > 0 && !hostv.row_ptr)) return fail(CVR_ERR_INVALID, "null or negative-size CSR view");
@@ -544,20 +560,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         rc = check_columns_device(hostv.col_idx, j0, j1, hostv.ncols);
         if (rc) return rc;
         const double xb = (double)hostv.ncols * (hostv.is_f32 ? 4.0 : 8.0);
-        if (opt.col_panels > 1 || (opt.col_panels < 0 && xb >= 24e6)) {
-            const size_t vs = hostv.is_f32 ? 4 : 8;
-            ci_host.resize((size_t)std::max<int64_t>(j1, 1));
-            va_host.resize((size_t)std::max<int64_t>(j1, 1) * vs);
-            if (j1 > 0) {
-                HIP_TRY(hipMemcpy(ci_host.data(), hostv.col_idx, sizeof(int32_t) * (size_t)j1, hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(va_host.data(), hostv.vals, vs * (size_t)j1, hipMemcpyDeviceToHost));
-            }
-            hostv.col_idx = ci_host.data();
-            hostv.vals = va_host.data();
-        } else {
-            civa_kind = hipMemcpyDeviceToDevice;
-            if (opt.col_panels < 0) opt.col_panels = 1;
-        }
+        civa_kind = hipMemcpyDeviceToDevice;
+        if (opt.col_panels < 0) opt.col_panels = (xb >= 24e6 && j1 > 0) ? auto_panels(hostv, nullptr) : 1;   // fetches only its sample windows of col_idx
+        // (column panels of device arrays are split on the device: cvr_split.hip)
     }
 
     const int64_t nrows = csr->nrows, ncols = csr->ncols;
@@ -602,13 +607,37 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     } else {
         const double t0 = now_s();
         PanelSplit   sp;
-        split_panels(*csr, P, sp);
+        struct SplitGuard { cvr::DeviceSplit d; ~SplitGuard() { cvr::free_device_split(d); } } dsg;
+        if (on_device) {        // split on the device; only row pointers and row numbers of the sub-rows come to the host
+            const int64_t  width = (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1;
+            const int64_t  j0 = nrows ? csr->row_ptr[0] : 0, j1 = nrows ? csr->row_ptr[nrows] : 0;
+            const hipError_t e = cvr::split_panels_device(csr_in->row_ptr, csr_in->col_idx, csr_in->vals, f32, nrows, j0, j1, width, P, &dsg.d, h->stream);
+            if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "column-panel split on the device: %s", hipGetErrorString(e)); }
+            sp.rp.resize((size_t)P); sp.rows.resize((size_t)P);
+            for (int p = 0; p < P; p++) {
+                const int64_t k0 = dsg.d.sub0[p], k1 = dsg.d.sub0[p + 1], ns = k1 - k0;
+                sp.rows[(size_t)p].alloc((size_t)ns);
+                sp.rp[(size_t)p].alloc((size_t)ns + 1);
+                if (ns > 0) {
+                    CREATE_TRY(hipMemcpy(sp.rows[(size_t)p].data(), dsg.d.rows + k0, sizeof(uint32_t) * (size_t)ns, hipMemcpyDeviceToHost));
+                    CREATE_TRY(hipMemcpy(sp.rp[(size_t)p].data(), dsg.d.rp + k0, sizeof(int64_t) * (size_t)ns, hipMemcpyDeviceToHost));
+                }
+                for (int64_t i = 0; i < ns; i++) sp.rp[(size_t)p][(size_t)i] -= dsg.d.off[p];      // panel-local positions
+                sp.rp[(size_t)p][(size_t)ns] = dsg.d.off[p + 1] - dsg.d.off[p];
+            }
+        } else {
+            split_panels(*csr, P, sp);
+        }
         in.plan_s += now_s() - t0;
         int64_t zoff = 0, nsub = 0;
         for (int p = 0; p < P; p++) {
             Part &part = h->parts[(size_t)p];
-            rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
-                            sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, opt, &in.plan_s);
+            if (on_device)
+                rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), dsg.d.ci + dsg.d.off[p],
+                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, opt, &in.plan_s);
+            else
+                rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
+                                sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, opt, &in.plan_s);
             if (rc) { cvr_destroy(h); return rc; }
             part.zoff = zoff;
             zoff += part.yext;

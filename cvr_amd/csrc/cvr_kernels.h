@@ -44,6 +44,22 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 
 // value-dictionary detection over vals[n0, n1) on the device: `table` = 1024 u64 slots preset to all ones, flags[0] bit 0 =
 // more than kDictMax distinct values, bit 1 = the all-ones pattern occurs, flags[1] = entries in the table
+// ---- column-panel split on the device (cvr_split.hip), for CSR arrays that are already there ----
+constexpr int kMaxSplitPanels = 64;
+struct DeviceSplit {
+    int32_t  *ci = nullptr;      // [nnz] column indices, panel after panel, original order inside a panel
+    void     *va = nullptr;      // [nnz] values, same order
+    uint32_t *rows = nullptr;    // [nsub] the row of every sub-row, panel after panel (ascending inside a panel)
+    int64_t  *rp = nullptr;      // [nsub + 1] where every sub-row starts in ci / va (positions over all panels); rp[nsub] = nnz
+    int64_t   nnz = 0, nsub = 0;
+    int64_t   off[kMaxSplitPanels + 1];    // host: first non-zero of every panel, off[P] = nnz
+    int64_t   sub0[kMaxSplitPanels + 1];   // host: first sub-row of every panel, sub0[P] = nsub
+};
+// panels = columns [p * width, (p + 1) * width); needs nnz, nrows < 2^32; synchronises `st`
+hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, const void *va_dev, bool f32, int64_t nrows, int64_t nz0,
+                               int64_t nz1, int64_t width, int P, DeviceSplit *out, hipStream_t st);
+void       free_device_split(DeviceSplit &s);
+
 // ---- vector kernels of the iterative caller (cvr_iter.hip) ----
 constexpr int kIterMaxParts = 64;
 struct IterBounds { long long b[kIterMaxParts + 1]; };   // row offsets of the shards (by value into the kernel)

@@ -1,0 +1,153 @@
+// cvr_split.hip -- column-panel split of a CSR matrix that is already in device memory (cvr_csr_view.arrays_on_device):
+// the device counterpart of split_panels_t in cvr_capi.hip.  Every non-zero gets its panel as a key; one stable radix
+// sort pass (hipCUB) groups the non-zeros by panel and keeps their original order inside a panel, i.e. row after row,
+// each row's entries as they were -- exactly what the host split produces by walking the rows.  Sub-row boundaries
+// (a new row, or a new panel) are flagged and numbered with a prefix sum.  Nothing but the per-panel row pointers and
+// row numbers (12 B per sub-row) has to travel to the host, where the planner needs them.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "cvr_kernels.h"
+
+namespace cvr {
+namespace {
+
+__global__ __launch_bounds__(256) void split_key_kernel(const int32_t *__restrict__ ci, long long nz0, long long n, long long width,
+                                                        uint8_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+        key[t] = (uint8_t)(ci[nz0 + t] / width);
+        idx[t] = (uint32_t)t;
+    }
+}
+
+// off[p] = first position of the sorted keys with key >= p (p = 0 .. P)
+__global__ void split_bounds_kernel(const uint8_t *__restrict__ key, long long n, int P, long long *__restrict__ off)
+{
+    const int p = threadIdx.x;
+    if (p > P) return;
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if ((int)key[mid] < p) lo = mid + 1; else hi = mid;
+    }
+    off[p] = lo;
+}
+
+// the sorted non-zeros: column, value, row (binary search in row_ptr), and the flag "first entry of a sub-row"
+template <typename T>
+__global__ __launch_bounds__(256) void split_gather_kernel(const long long *__restrict__ rp, long long nrows, const int32_t *__restrict__ ci,
+                                                           const T *__restrict__ va, long long nz0, long long n,
+                                                           const uint32_t *__restrict__ idx, int32_t *__restrict__ ci_s, T *__restrict__ va_s,
+                                                           uint32_t *__restrict__ row_s)
+{
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+        const long long j = nz0 + (long long)idx[t];
+        long long lo = 0, hi = nrows;                       // last r with rp[r] <= j (then rp[r+1] > j)
+        while (lo < hi) {
+            const long long mid = (lo + hi + 1) >> 1;
+            if (rp[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        ci_s[t] = ci[j];
+        va_s[t] = va[j];
+        row_s[t] = (uint32_t)lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void split_head_kernel(const uint8_t *__restrict__ key, const uint32_t *__restrict__ row_s, long long n,
+                                                         uint32_t *__restrict__ head)
+{
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256)
+        head[t] = (t == 0 || key[t] != key[t - 1] || row_s[t] != row_s[t - 1]) ? 1u : 0u;
+}
+
+// sub-row k starts at sorted position t: rows[k] = its row, rp[k] = t; rp[nsub] = n
+__global__ __launch_bounds__(256) void split_emit_kernel(const uint32_t *__restrict__ head, const uint32_t *__restrict__ sidx,
+                                                         const uint32_t *__restrict__ row_s, long long n, uint32_t *__restrict__ rows,
+                                                         long long *__restrict__ rp_s, long long nsub)
+{
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256)
+        if (head[t]) { rows[sidx[t]] = row_s[t]; rp_s[sidx[t]] = t; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) rp_s[nsub] = n;
+}
+
+uint32_t grid_for(long long n) { return (uint32_t)std::min<long long>(4096, std::max<long long>(1, (n + 255) / 256)); }
+
+struct Tmp {            // frees whatever was allocated, on every path
+    std::vector<void *> p;
+    template <typename U> hipError_t alloc(U **q, size_t bytes) { hipError_t e = hipMalloc(q, std::max<size_t>(bytes, 16)); if (e == hipSuccess) p.push_back(*q); return e; }
+    ~Tmp() { for (void *q : p) (void)hipFree(q); }
+};
+
+}  // namespace
+
+void free_device_split(DeviceSplit &s)
+{
+    (void)hipFree(s.ci); (void)hipFree(s.va); (void)hipFree(s.rows); (void)hipFree(s.rp);
+    s.ci = nullptr; s.va = nullptr; s.rows = nullptr; s.rp = nullptr;
+}
+
+#define SPLIT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { free_device_split(*out); return e_; } } while (0)
+
+hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, const void *va_dev, bool f32, int64_t nrows, int64_t nz0,
+                               int64_t nz1, int64_t width, int P, DeviceSplit *out, hipStream_t st)
+{
+    *out = DeviceSplit();
+    const long long n = nz1 - nz0;
+    if (P < 1 || P > kMaxSplitPanels || width < 1 || n >= (1ll << 32) || nrows >= (1ll << 32)) return hipErrorInvalidValue;
+    out->nnz = n;
+    const size_t vsz = f32 ? 4 : 8;
+    Tmp tmp;
+    uint8_t  *key_in = nullptr, *key = nullptr;
+    uint32_t *idx_in = nullptr, *idx = nullptr, *row_s = nullptr, *head = nullptr, *sidx = nullptr;
+    long long *off_dev = nullptr;
+    SPLIT_TRY(tmp.alloc(&key_in, (size_t)n)); SPLIT_TRY(tmp.alloc(&key, (size_t)n));
+    SPLIT_TRY(tmp.alloc(&idx_in, 4 * (size_t)n)); SPLIT_TRY(tmp.alloc(&idx, 4 * (size_t)n));
+    SPLIT_TRY(tmp.alloc(&row_s, 4 * (size_t)n)); SPLIT_TRY(tmp.alloc(&head, 4 * (size_t)n)); SPLIT_TRY(tmp.alloc(&sidx, 4 * (size_t)n));
+    SPLIT_TRY(tmp.alloc(&off_dev, sizeof(long long) * (kMaxSplitPanels + 2)));
+    SPLIT_TRY(hipMalloc(&out->ci, std::max<size_t>(4 * (size_t)n, 16)));
+    SPLIT_TRY(hipMalloc(&out->va, std::max<size_t>(vsz * (size_t)n, 16)));
+    for (int p = 0; p <= P; p++) { out->off[p] = 0; out->sub0[p] = 0; }
+    if (n == 0) {
+        SPLIT_TRY(hipMalloc(&out->rows, 16)); SPLIT_TRY(hipMalloc(&out->rp, 16));
+        SPLIT_TRY(hipMemsetAsync(out->rp, 0, 16, st));
+        return hipStreamSynchronize(st);
+    }
+    hipLaunchKernelGGL(split_key_kernel, dim3(grid_for(n)), dim3(256), 0, st, ci_dev, (long long)nz0, n, (long long)width, key_in, idx_in);
+    int bits = 1;
+    while ((1 << bits) < P) bits++;
+    size_t sort_bytes = 0, scan_bytes = 0;
+    SPLIT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, key_in, key, idx_in, idx, (unsigned int)n, 0, bits, st));
+    SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, head, sidx, (unsigned int)n, st));
+    void *work = nullptr;
+    SPLIT_TRY(tmp.alloc(&work, std::max(sort_bytes, scan_bytes)));
+    SPLIT_TRY(hipcub::DeviceRadixSort::SortPairs(work, sort_bytes, key_in, key, idx_in, idx, (unsigned int)n, 0, bits, st));   // stable
+    hipLaunchKernelGGL(split_bounds_kernel, dim3(1), dim3(kMaxSplitPanels + 1), 0, st, key, n, P, off_dev);
+    if (f32) hipLaunchKernelGGL(split_gather_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const float *>(va_dev), (long long)nz0, n, idx, out->ci, static_cast<float *>(out->va), row_s);
+    else hipLaunchKernelGGL(split_gather_kernel<double>, dim3(grid_for(n)), dim3(256), 0, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const double *>(va_dev), (long long)nz0, n, idx, out->ci, static_cast<double *>(out->va), row_s);
+    hipLaunchKernelGGL(split_head_kernel, dim3(grid_for(n)), dim3(256), 0, st, key, row_s, n, head);
+    SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(work, scan_bytes, head, sidx, (unsigned int)n, st));
+    uint32_t  last[2] = {0, 0};
+    long long off_host[kMaxSplitPanels + 2];
+    SPLIT_TRY(hipMemcpyAsync(&last[0], sidx + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SPLIT_TRY(hipMemcpyAsync(&last[1], head + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SPLIT_TRY(hipMemcpyAsync(off_host, off_dev, sizeof(long long) * (size_t)(P + 1), hipMemcpyDeviceToHost, st));
+    SPLIT_TRY(hipStreamSynchronize(st));
+    const long long nsub = (long long)last[0] + last[1];
+    out->nsub = nsub;
+    SPLIT_TRY(hipMalloc(&out->rows, std::max<size_t>(4 * (size_t)nsub, 16)));
+    SPLIT_TRY(hipMalloc(&out->rp, sizeof(long long) * ((size_t)nsub + 1)));
+    hipLaunchKernelGGL(split_emit_kernel, dim3(grid_for(n)), dim3(256), 0, st, head, sidx, row_s, n, out->rows, (long long *)out->rp, nsub);
+    // first sub-row of every panel = the number of sub-row heads before its first element
+    for (int p = 0; p <= P; p++) out->off[p] = off_host[p];
+    std::vector<uint32_t> s0((size_t)P + 1, 0);
+    for (int p = 0; p < P; p++)
+        if (out->off[p] < n) SPLIT_TRY(hipMemcpyAsync(&s0[(size_t)p], sidx + out->off[p], 4, hipMemcpyDeviceToHost, st));
+    SPLIT_TRY(hipStreamSynchronize(st));
+    for (int p = 0; p < P; p++) out->sub0[p] = out->off[p] < n ? (int64_t)s0[(size_t)p] : nsub;
+    out->sub0[P] = nsub;
+    SPLIT_TRY(hipGetLastError());
+    return hipSuccess;
+}
+
+}  // namespace cvr

@@ -528,20 +528,37 @@ def test_csr_arrays_already_on_the_device(name):
         assert e.value.code == capi.ERR_INVALID
 
 
-def test_device_arrays_with_column_panels_take_the_host_detour():
-    """column panels asked for with device-resident arrays: staged through the host split, same y as the host-array path"""
+def test_device_arrays_with_column_panels_are_split_on_the_device():
+    """column panels with device-resident arrays: the split runs on the device (cvr_split.hip: one stable radix-sort pass by
+    panel); bit for bit the same y as the host split of the same matrix -- sorted and unsorted rows, empty rows, fp32, 2..64 panels"""
     import torch
-    nrows, ncols, rp, ci, va = CASES["power_law_3000"]
     dev = torch.device("cuda", 0)
-    trp, tci, tva = (torch.from_numpy(a).to(dev) for a in (np.ascontiguousarray(rp, dtype=np.int64), np.ascontiguousarray(ci, dtype=np.int32), np.ascontiguousarray(va, dtype=np.float64)))
-    torch.cuda.synchronize()
-    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=3)
-    B = cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), tci.data_ptr(), tva.data_ptr(), col_panels=3)
-    assert A.info.col_panels == 3 and B.info.col_panels == 3
-    x = O.x_vec_fast(ncols)
-    assert np.array_equal(A.spmv(x)[0].view(np.uint8), B.spmv(x)[0].view(np.uint8))
-    A.close()
-    B.close()
+    rng = np.random.default_rng(31)
+    todo = [(name, CASES[name], P) for name, P in (("power_law_3000", 3), ("two_giants", 2), ("leading_trailing_empty", 7), ("dense_row_plus_singletons", 64))]
+    nrows, ncols, rp, ci, va = CASES["power_law_3000"]
+    ci_shuffled = ci.copy()
+    for r in range(nrows):                                     # rows whose columns are not sorted
+        seg = ci_shuffled[rp[r]:rp[r + 1]]
+        rng.shuffle(seg)
+    todo.append(("unsorted rows", (nrows, ncols, rp, ci_shuffled, va), 5))
+    todo.append(("fp32", CASES32["power_law_3000"], 4))
+    for name, (nrows, ncols, rp, ci, va), P in todo:
+        trp = torch.from_numpy(np.ascontiguousarray(rp, dtype=np.int64)).to(dev)
+        tci = torch.from_numpy(np.ascontiguousarray(ci, dtype=np.int32)).to(dev)
+        tva = torch.from_numpy(np.ascontiguousarray(va)).to(dev)
+        torch.cuda.synchronize()
+        f32 = va.dtype == np.float32
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=P)
+        B = cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), tci.data_ptr(), tva.data_ptr(), is_f32=f32, col_panels=P)
+        assert A.info.col_panels == P and B.info.col_panels == P
+        assert (A.info.nchunks, A.info.nslots, A.info.nshared) == (B.info.nchunks, B.info.nslots, B.info.nshared), name
+        x = O.x_vec_fast(ncols, "rand").astype(va.dtype)
+        ya, yb = A.spmv(x)[0], B.spmv(x)[0]
+        assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8)), name
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        _assert_close(yb, yref, absy + 1e-30, TOL32 if f32 else TOL64, ("device split", name))
+        A.close()
+        B.close()
 
 
 def test_spmv_launches_can_be_captured_in_a_hip_graph():
