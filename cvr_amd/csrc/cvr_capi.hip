@@ -1140,12 +1140,32 @@ int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt_in, int32_t *
     cvr_options opt;
     if (opt_in) opt = *opt_in; else cvr_default_options(&opt);
     const double t0 = now_s();
-    int32_t      best = 0;
-    double       best_t = 0;
-    for (int32_t S = 8; S <= 64; S += 4) {     // every candidate is the real thing: plan, upload, convert, timed launches
+    // host arrays go to the device once; every candidate is then built from the device copy (device-to-device, no PCIe)
+    cvr_csr_view view = *csr;
+    struct Staged { void *rp = nullptr, *ci = nullptr, *va = nullptr; ~Staged() { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); } } staged;
+    if (!csr->arrays_on_device && cvr_device_count() > 0 && csr->nrows > 0 && csr->row_ptr && csr->row_ptr[csr->nrows] > 0 && csr->col_idx && csr->vals) {
+        int rc = check_csr(csr);
+        if (rc) return rc;
+        const size_t nz = (size_t)csr->row_ptr[csr->nrows], vs = csr->is_f32 ? 4 : 8;
+        HIP_TRY(hipSetDevice(opt.device));
+        HIP_TRY(hipMalloc(&staged.rp, sizeof(int64_t) * ((size_t)csr->nrows + 1)));
+        HIP_TRY(hipMalloc(&staged.ci, sizeof(int32_t) * nz));
+        HIP_TRY(hipMalloc(&staged.va, vs * nz));
+        HIP_TRY(hipMemcpy(staged.rp, csr->row_ptr, sizeof(int64_t) * ((size_t)csr->nrows + 1), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(staged.ci, csr->col_idx, sizeof(int32_t) * nz, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(staged.va, csr->vals, vs * nz, hipMemcpyHostToDevice));
+        view.row_ptr = static_cast<const int64_t *>(staged.rp);
+        view.col_idx = static_cast<const int32_t *>(staged.ci);
+        view.vals = staged.va;
+        view.arrays_on_device = 1;
+        if (opt.col_panels < 0) opt.col_panels = auto_panels(*csr, nullptr);      // decided once, on the host arrays
+    }
+    int32_t best = 0;
+    double  best_t = 0;
+    for (int32_t S = 8; S <= 64; S += 4) {     // every candidate is the real thing: plan, convert, timed launches
         opt.steps_per_chunk = S;
         cvr_handle *h = nullptr;
-        int         rc = cvr_create(&h, csr, &opt);
+        int         rc = cvr_create(&h, &view, &opt);
         double      t = 0;
         if (rc == CVR_OK) rc = cvr_preprocess(h, 0, nullptr);
         if (rc == CVR_OK) rc = cvr_spmv_bench(h, 5, 10, &t);                                   // settle clocks and caches

@@ -139,7 +139,7 @@ int cvr_auto_panels(const cvr_csr_view *csr, double *l2_miss_estimate);
  * cvr_options.steps_per_chunk to cvr_create.  The default rule (steps_per_chunk = 0) needs no tuning on matrices
  * that fill the GPU many times over; on small ones (a row shard of web-Google on one of 8 GPUs) which chunk counts run
  * fastest depends on how the workgroups fall onto the CUs, and measuring beats the rule by 10-20 %.
- * Costs one upload of the CSR arrays per candidate (*tuning_s); counts as preprocessing time. */
+ * Host arrays are uploaded once and every candidate is built from the device copy; *tuning_s counts as preprocessing time. */
 int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt, int32_t *best_steps, double *best_spmv_s, double *tuning_s);
 
 /* ---- rows sharded over GPUs, one process per GPU: the exchange step ------------------------------------
