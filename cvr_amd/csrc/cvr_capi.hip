@@ -524,8 +524,18 @@ static void split_panels(const cvr_csr_view &v, int P, PanelSplit &out)
 
 extern "C" {
 
+namespace {
+// CVR_CREATE_TIMING=1: wall time of the phases of cvr_create on stderr (diagnostics only)
+struct PhaseClock {
+    bool   on = getenv("CVR_CREATE_TIMING") && atoi(getenv("CVR_CREATE_TIMING"));
+    double t = now_s();
+    void   lap(const char *what) { if (on) { const double n = now_s(); fprintf(stderr, "[cvr_create] %-28s %8.2f ms\n", what, (n - t) * 1e3); t = n; } }
+};
+}  // namespace
+
 int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *opt_in)
 {
+    PhaseClock clk;
     if (!out) return fail(CVR_ERR_INVALID, "out is null");
     *out = nullptr;
     Range range("cvr_create (validate, plan, upload)");
@@ -536,6 +546,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     const bool on_device = csr_in->arrays_on_device != 0;
     int rc = on_device ? CVR_OK : check_csr(csr_in);          // host arrays: rejected before any device work
     if (rc) return rc;
+    clk.lap("options, check_csr (host)");
     if (ndev <= 0) return fail(CVR_ERR_NO_DEVICE, "no HIP device visible: libcvr_amd has no CPU fallback");
     if (opt.device < 0 || opt.device >= ndev) return fail(CVR_ERR_NO_DEVICE, "device %d out of range [0, %d)", opt.device, ndev);
     if (opt.steps_per_chunk != 0 && (opt.steps_per_chunk < 4 || opt.steps_per_chunk % 4 || opt.steps_per_chunk > 4096))
@@ -575,7 +586,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // 2 300 us as one image (profiles/r01_column_panels_rmat24_fp32.log); R-MAT-22 fp64 (33.5 MB, 0.13) and matrices
     // whose x nearly fits (web-Google: profiles/r01_column_panel_probe.log) stay whole.
     int P = opt.col_panels;
+    clk.lap("device arrays: row_ptr, checks");
     if (P < 0) P = auto_panels(*csr, nullptr);
+    clk.lap("panel rule");
     if (P < 1) P = 1;
     if (P > 64) P = 64;
     if (nrows >= (int64_t)0xfffffff0u) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
@@ -598,6 +611,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    clk.lap("handle, stream");
     const double t_up0 = now_s();
     h->parts.resize((size_t)P);
     if (P == 1) {
@@ -608,11 +622,38 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         const double t0 = now_s();
         PanelSplit   sp;
         struct SplitGuard { cvr::DeviceSplit d; ~SplitGuard() { cvr::free_device_split(d); } } dsg;
-        if (on_device) {        // split on the device; only row pointers and row numbers of the sub-rows come to the host
+        // The split runs on the device (cvr_split.hip).  Host arrays are uploaded once for it: building the split arrays
+        // on the host means allocating, touching and freeing another copy of the matrix there, which costs more than the
+        // PCIe transfer (LiveJournal shape: 60 ms to split + 130 ms to free against 20 ms to upload).  The host split stays
+        // as the fallback for matrices beyond the device split's 32-bit positions or when the staging copy does not fit.
+        struct Staged {
+            void *rp = nullptr, *ci = nullptr, *va = nullptr;
+            void  release() { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); rp = ci = va = nullptr; }
+            ~Staged() { release(); }
+        } staged;
+        const int64_t  sj0 = nrows ? csr->row_ptr[0] : 0, sj1 = nrows ? csr->row_ptr[nrows] : 0;
+        const int64_t *rp_d = csr_in->row_ptr;
+        const int32_t *ci_d = csr_in->col_idx;
+        const void    *va_d = csr_in->vals;
+        bool           dev_split = on_device;
+        if (!on_device && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !getenv("CVR_HOST_SPLIT")) {
+            if (hipMalloc(&staged.rp, sizeof(int64_t) * ((size_t)nrows + 1)) == hipSuccess && hipMalloc(&staged.ci, sizeof(int32_t) * (size_t)sj1) == hipSuccess &&
+                hipMalloc(&staged.va, vsz * (size_t)sj1) == hipSuccess &&
+                hipMemcpy(staged.rp, csr->row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice) == hipSuccess &&
+                hipMemcpy(staged.ci, csr->col_idx, sizeof(int32_t) * (size_t)sj1, hipMemcpyHostToDevice) == hipSuccess &&
+                hipMemcpy(staged.va, csr->vals, vsz * (size_t)sj1, hipMemcpyHostToDevice) == hipSuccess) {
+                rp_d = static_cast<const int64_t *>(staged.rp); ci_d = static_cast<const int32_t *>(staged.ci); va_d = staged.va;
+                dev_split = true;
+            } else {
+                (void)hipGetLastError();      // not enough device memory for the staging copy: split on the host
+            }
+        }
+        clk.lap("  staging upload");
+        if (dev_split) {        // only row pointers and row numbers of the sub-rows come to the host
             const int64_t  width = (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1;
-            const int64_t  j0 = nrows ? csr->row_ptr[0] : 0, j1 = nrows ? csr->row_ptr[nrows] : 0;
-            const hipError_t e = cvr::split_panels_device(csr_in->row_ptr, csr_in->col_idx, csr_in->vals, f32, nrows, j0, j1, width, P, &dsg.d, h->stream);
+            const hipError_t e = cvr::split_panels_device(rp_d, ci_d, va_d, f32, nrows, sj0, sj1, width, P, &dsg.d, h->stream);
             if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "column-panel split on the device: %s", hipGetErrorString(e)); }
+            staged.release();       // the split arrays replace the staging copy
             sp.rp.resize((size_t)P); sp.rows.resize((size_t)P);
             for (int p = 0; p < P; p++) {
                 const int64_t k0 = dsg.d.sub0[p], k1 = dsg.d.sub0[p + 1], ns = k1 - k0;
@@ -629,10 +670,11 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             split_panels(*csr, P, sp);
         }
         in.plan_s += now_s() - t0;
+        clk.lap("panel split");
         int64_t zoff = 0, nsub = 0;
         for (int p = 0; p < P; p++) {
             Part &part = h->parts[(size_t)p];
-            if (on_device)
+            if (dev_split)
                 rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), dsg.d.ci + dsg.d.off[p],
                                 static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, opt, &in.plan_s);
             else
@@ -644,6 +686,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             nsub += part.nrows;
         }
         if (zoff >= (int64_t)0xffffffffu) { cvr_destroy(h); return fail(CVR_ERR_INVALID, "partial-sum buffer too large for 32-bit indices"); }
+        clk.lap("parts: plan, alloc, copies");
         // combine tables: the rows of every panel's sub-rows (concatenated) and, per panel, where each block of
         // kCombineRows rows starts among them
         const double   t1 = now_s();
@@ -660,11 +703,13 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             }
         }
         in.plan_s += now_s() - t1;
+        clk.lap("  block offsets (host)");
         CREATE_TRY(hipMalloc(&h->d_z, vsz * (size_t)std::max<int64_t>(zoff, 1)));
         CREATE_TRY(hipMalloc(&h->d_rows, sizeof(uint32_t) * (size_t)std::max<int64_t>(nsub, 1)));
         CREATE_TRY(hipMalloc(&h->d_block_off, sizeof(uint32_t) * block_off.size()));
         CREATE_TRY(hipMalloc(&h->d_cpanels, sizeof(cvr::CombinePanel) * (size_t)P));
         CREATE_TRY(hipMemsetAsync(h->d_z, 0, vsz * (size_t)std::max<int64_t>(zoff, 1), h->stream));
+        clk.lap("  z, rows: alloc, memset");
         std::vector<cvr::CombinePanel> cps((size_t)P);
         int64_t roff = 0;
         for (int p = 0; p < P; p++) {
@@ -675,6 +720,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }
         CREATE_TRY(hipMemcpyAsync(h->d_block_off, block_off.data(), sizeof(uint32_t) * block_off.size(), hipMemcpyHostToDevice, h->stream));
         CREATE_TRY(hipMemcpyAsync(h->d_cpanels, cps.data(), sizeof(cvr::CombinePanel) * (size_t)P, hipMemcpyHostToDevice, h->stream));
+        clk.lap("  rows upload enqueued");
         std::vector<cvr::FixPart> fp((size_t)P);
         for (int p = 0; p < P; p++) {
             const Part &part = h->parts[(size_t)p];
@@ -684,9 +730,11 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         CREATE_TRY(hipMalloc(&h->d_fixparts, sizeof(cvr::FixPart) * (size_t)P));
         CREATE_TRY(hipMemcpyAsync(h->d_fixparts, fp.data(), sizeof(cvr::FixPart) * (size_t)P, hipMemcpyHostToDevice, h->stream));
         CREATE_TRY(hipStreamSynchronize(h->stream));
+        clk.lap("  tables synchronised");
         in.yext_elems = nrows + 1;
         in.image_bytes += (int64_t)(sizeof(uint32_t) * ((size_t)nsub + block_off.size()));
     }
+    clk.lap("combine tables / single part");
     // value dictionary (value_dict: <0 auto, 0 off): one code byte per slot instead of the value when the matrix has at
     // most 256 distinct values -- 12 -> 5 bytes per slot for fp64 (profiles/r01_value_dictionary.log).  The distinct
     // values are collected on the device from the uploaded CSR (a 40-MB scan takes microseconds there, milliseconds
@@ -724,6 +772,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }
     }
     in.value_dict = (int32_t)h->ndict;
+    clk.lap("value dictionary scan");
     for (Part &p : h->parts) { rc = finish_part(h, p); if (rc) { cvr_destroy(h); return rc; } }
     in.steps_per_chunk = h->parts[0].img.S;
     for (const Part &p : h->parts) {
@@ -738,6 +787,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
     CREATE_TRY(hipStreamSynchronize(h->stream));   // the caller may free its CSR when this returns
     in.upload_s = now_s() - t_up0 - in.plan_s;
+    clk.lap("images, x, y");
 #undef CREATE_TRY
     *out = h;
     return CVR_OK;

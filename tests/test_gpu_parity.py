@@ -529,8 +529,9 @@ def test_csr_arrays_already_on_the_device(name):
 
 
 def test_device_arrays_with_column_panels_are_split_on_the_device():
-    """column panels with device-resident arrays: the split runs on the device (cvr_split.hip: one stable radix-sort pass by
-    panel); bit for bit the same y as the host split of the same matrix -- sorted and unsorted rows, empty rows, fp32, 2..64 panels"""
+    """the column-panel split runs on the device (cvr_split.hip: one stable radix-sort pass by panel), for device-resident
+    arrays and for host arrays (staged once); bit for bit the same y as the host split (CVR_HOST_SPLIT=1, the fallback) of
+    the same matrix -- sorted and unsorted rows, empty rows, fp32, 2..64 panels"""
     import torch
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(31)
@@ -548,13 +549,19 @@ def test_device_arrays_with_column_panels_are_split_on_the_device():
         tva = torch.from_numpy(np.ascontiguousarray(va)).to(dev)
         torch.cuda.synchronize()
         f32 = va.dtype == np.float32
-        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=P)
+        os.environ["CVR_HOST_SPLIT"] = "1"                       # the threaded counting sort on the host (the fallback path)
+        try:
+            A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=P)
+        finally:
+            del os.environ["CVR_HOST_SPLIT"]
         B = cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), tci.data_ptr(), tva.data_ptr(), is_f32=f32, col_panels=P)
-        assert A.info.col_panels == P and B.info.col_panels == P
-        assert (A.info.nchunks, A.info.nslots, A.info.nshared) == (B.info.nchunks, B.info.nslots, B.info.nshared), name
+        C2 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=P)      # host arrays, staged to the device and split there
+        assert A.info.col_panels == P and B.info.col_panels == P and C2.info.col_panels == P
+        assert (A.info.nchunks, A.info.nslots, A.info.nshared) == (B.info.nchunks, B.info.nslots, B.info.nshared) == (C2.info.nchunks, C2.info.nslots, C2.info.nshared), name
         x = O.x_vec_fast(ncols, "rand").astype(va.dtype)
-        ya, yb = A.spmv(x)[0], B.spmv(x)[0]
-        assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8)), name
+        ya, yb, yc = A.spmv(x)[0], B.spmv(x)[0], C2.spmv(x)[0]
+        C2.close()
+        assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8)) and np.array_equal(ya.view(np.uint8), yc.view(np.uint8)), name
         yref, absy = O.csr_spmv64(rp, ci, va, x)
         _assert_close(yb, yref, absy + 1e-30, TOL32 if f32 else TOL64, ("device split", name))
         A.close()
