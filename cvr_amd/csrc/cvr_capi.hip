@@ -196,9 +196,27 @@ static int check_csr(const cvr_csr_view *c, bool columns_on_host = true)
     const int64_t nnz = c->row_ptr[c->nrows];
     if (nnz > 0 && (!c->col_idx || !c->vals)) return fail(CVR_ERR_INVALID, "col_idx / vals is null");
     if (!columns_on_host) return CVR_OK;       // device arrays: the range check is a kernel (check_columns_device)
-    for (int64_t j = c->row_ptr[0]; j < nnz; j++)
-        if (c->col_idx[j] < 0 || c->col_idx[j] >= c->ncols)
-            return fail(CVR_ERR_INVALID, "col_idx[%lld] = %d outside [0, %lld)", (long long)j, c->col_idx[j], (long long)c->ncols);
+    // the first offending position, searched by a few threads on large matrices (69 M columns: 17 ms on one core)
+    const int64_t j0 = c->row_ptr[0];
+    int           T = (int)std::thread::hardware_concurrency();
+    if (T > 16) T = 16;
+    if (T < 1 || nnz - j0 < (1 << 22)) T = 1;
+    std::vector<int64_t> bad((size_t)T, -1);
+    auto scan = [&](int t) {
+        const int64_t a = j0 + (nnz - j0) * t / T, b = j0 + (nnz - j0) * (t + 1) / T;
+        const int32_t nc = (int32_t)c->ncols;
+        for (int64_t j = a; j < b; j++)
+            if ((uint32_t)c->col_idx[j] >= (uint32_t)nc) { bad[(size_t)t] = j; return; }     // negative or >= ncols
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(scan, t);
+        scan(0);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < T; t++)
+        if (bad[(size_t)t] >= 0)
+            return fail(CVR_ERR_INVALID, "col_idx[%lld] = %d outside [0, %lld)", (long long)bad[(size_t)t], c->col_idx[bad[(size_t)t]], (long long)c->ncols);
     return CVR_OK;
 }
 
