@@ -274,26 +274,35 @@ static int pick_steps(int64_t nslots_est)
 }
 
 // plans one part on the host, allocates its device image and uploads its CSR (asynchronously on h->stream)
-static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
-                      hipMemcpyKind civa_kind,
-                      bool f32, const cvr_options &opt, double *plan_s)
+// the host side of one image: chunk plan and the per-chunk tables derived from it.  No device call, no error text:
+// column panels plan their images on parallel threads.
+struct PartPlan {
+    int                   S = 0;
+    cvr::Plan             plan;
+    std::vector<uint32_t> desc, pad;
+    std::vector<int64_t>  nzb;
+    int64_t               max_nseg = 0, yext = 0;
+    bool                  too_large = false;
+};
+
+static void plan_part(PartPlan &pp, int64_t nrows, const int64_t *rp, const cvr_options &opt)
 {
     const int64_t nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
-    int           S = opt.steps_per_chunk;
-    if (S == 0) S = pick_steps(nz1 - nz0 + nrows / 4);
-    const double    t0 = now_s();
-    const cvr::Plan plan = cvr::plan_chunks(nrows, rp, S, opt.split_threshold);
-    const int64_t   nchunks = (int64_t)plan.chunks.size();
-    const int64_t   yext = nrows + 1 + 2 * nchunks;
-    if (yext >= (int64_t)0xffffffffu || nchunks >= (int64_t)0x7fffffff) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
-    std::vector<uint32_t> desc((size_t)nchunks * 4), pad((size_t)nchunks);
-    std::vector<int64_t>  nzb((size_t)nchunks + 1);
-    int64_t               max_nseg = 0;
+    pp.S = opt.steps_per_chunk;
+    if (pp.S == 0) pp.S = pick_steps(nz1 - nz0 + nrows / 4);
+    pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold);
+    const cvr::Plan &plan = pp.plan;
+    const int64_t    nchunks = (int64_t)plan.chunks.size();
+    pp.yext = nrows + 1 + 2 * nchunks;
+    if (pp.yext >= (int64_t)0xffffffffu || nchunks >= (int64_t)0x7fffffff) { pp.too_large = true; return; }
+    pp.desc.resize((size_t)nchunks * 4);
+    pp.pad.resize((size_t)nchunks);
+    pp.nzb.resize((size_t)nchunks + 1);
     for (int64_t k = 0; k < nchunks; k++) {
         const cvr::Chunk &c = plan.chunks[(size_t)k];
-        max_nseg = std::max(max_nseg, c.nseg);
-        desc[4 * k + 0] = (uint32_t)c.row_first;
-        desc[4 * k + 1] = (uint32_t)c.nseg;
+        pp.max_nseg = std::max(pp.max_nseg, c.nseg);
+        pp.desc[4 * k + 0] = (uint32_t)c.row_first;
+        pp.desc[4 * k + 1] = (uint32_t)c.nseg;
         // where segment q writes: a row begun earlier -> carry_head(k); a row continued later -> carry_tail(k);
         // the pad segment -> dump; else its row.  head_dest / last_dest are that rule at q = 0 and q = nseg-1.
         auto dest = [&](int64_t q) -> uint32_t {
@@ -302,13 +311,33 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
             if (q == c.nrows_in - 1 && c.tail_shared) return (uint32_t)(nrows + 1 + 2 * k + 1);
             return (uint32_t)(c.row_first + q);
         };
-        desc[4 * k + 2] = dest(0);
-        desc[4 * k + 3] = dest(c.nseg - 1);
-        pad[(size_t)k] = (uint32_t)c.pad_cnt;
-        nzb[(size_t)k] = c.nz_begin;
+        pp.desc[4 * k + 2] = dest(0);
+        pp.desc[4 * k + 3] = dest(c.nseg - 1);
+        pp.pad[(size_t)k] = (uint32_t)c.pad_cnt;
+        pp.nzb[(size_t)k] = c.nz_begin;
     }
-    nzb[(size_t)nchunks] = plan.nz_end;
-    if (plan_s) *plan_s += now_s() - t0;
+    pp.nzb[(size_t)nchunks] = plan.nz_end;
+}
+
+// device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
+static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
+                      hipMemcpyKind civa_kind, bool f32, const cvr_options &opt, double *plan_s, PartPlan *planned = nullptr)
+{
+    PartPlan local;
+    if (!planned) {
+        const double t0 = now_s();
+        plan_part(local, nrows, rp, opt);
+        if (plan_s) *plan_s += now_s() - t0;
+        planned = &local;
+    }
+    PartPlan &pp = *planned;
+    if (pp.too_large) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
+    const int64_t    nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
+    const int        S = pp.S;
+    const cvr::Plan &plan = pp.plan;
+    const int64_t    nchunks = (int64_t)plan.chunks.size(), yext = pp.yext, max_nseg = pp.max_nseg;
+    const std::vector<uint32_t> &desc = pp.desc, &pad = pp.pad;
+    const std::vector<int64_t>  &nzb = pp.nzb;
 
     part.nrows = nrows; part.nnz = nz1 - nz0; part.nnz_span = nz1; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
     // LDS row-sum stage of the SpMV kernel: sized for the chunk with the most segments, so every chunk writes its y
@@ -689,15 +718,29 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }
         in.plan_s += now_s() - t0;
         clk.lap("panel split");
+        // the panels' images are planned side by side (the planner is a sequential walk per image), then built one by one
+        std::vector<PartPlan> pps((size_t)P);
+        {
+            const double tp = now_s();
+            int T = (int)std::thread::hardware_concurrency();
+            T = std::max(1, std::min(T, P));
+            auto work = [&](int t) { for (int p = t; p < P; p += T) plan_part(pps[(size_t)p], (int64_t)sp.rows[(size_t)p].size(), sp.rp[(size_t)p].data(), opt); };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+            in.plan_s += now_s() - tp;
+        }
+        clk.lap("  panels planned (parallel)");
         int64_t zoff = 0, nsub = 0;
         for (int p = 0; p < P; p++) {
             Part &part = h->parts[(size_t)p];
             if (dev_split)
                 rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), dsg.d.ci + dsg.d.off[p],
-                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, opt, &in.plan_s);
+                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, opt, &in.plan_s, &pps[(size_t)p]);
             else
                 rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
-                                sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, opt, &in.plan_s);
+                                sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, opt, &in.plan_s, &pps[(size_t)p]);
             if (rc) { cvr_destroy(h); return rc; }
             part.zoff = zoff;
             zoff += part.yext;
