@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--steps-per-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-streams", action="store_true", help="also report the throughput of independent SpMVs alternating on two streams "
+                    "(off by default: concurrent kernels would distort a rocprofv3 kernel-time summary of this command)")
     ap.add_argument("--workload", default="webgoogle", help="webgoogle (the headline, default) | livejournal | banded[<rows>] | rmat[<scale>] (fp32)")
     args = ap.parse_args()
 
@@ -342,7 +344,7 @@ def main():
     # throughput of independent SpMVs alternating on two streams with their own y (the per-launch floor of one overlaps the body
     # of the other); reported for information, never the value: the steps of the metric run one after the other
     two = None
-    if not sharded:
+    if not sharded and args.two_streams:
         st2 = torch.cuda.Stream(device=dev)
         y2 = torch.zeros_like(y)
         pair = ((sptr, y), (st2.cuda_stream, y2))
