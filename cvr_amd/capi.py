@@ -26,7 +26,7 @@ class CsrView(C.Structure):
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
                 ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("stream_policy", C.c_int32),
-                ("reserved0", C.c_int32), ("gather_depth", C.c_int32), ("debug_col_mask", C.c_int32),
+                ("waves_per_block", C.c_int32), ("gather_depth", C.c_int32), ("debug_col_mask", C.c_int32),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32)]
 
 
@@ -247,7 +247,7 @@ class CvrMatrix:
 
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
                  xcd_swizzle=-1, x_window=-1, nontemporal=0, keep_csr=False, debug_col_mask=0, depth=0,
-                 col_panels=-1, value_dict=-1, tune_steps=False):
+                 col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0):
         """tune_steps: choose steps_per_chunk by measurement first (cvr_tune_steps; its cost is self.tuning_s)"""
         self._h = C.c_void_p()
         self.tuning_s = 0.0
@@ -258,9 +258,13 @@ class CvrMatrix:
         va = np.ascontiguousarray(vals, dtype=self.dtype)
         if len(rp) != nrows + 1:
             raise ValueError("row_ptr must have nrows + 1 entries")
+        if nrows > 0 and rp[0] < 0:
+            raise ValueError("row_ptr[0] < 0")
+        if nrows > 0 and (len(ci) < rp[-1] or len(va) < rp[-1]):      # the library reads row_ptr[nrows] entries of both
+            raise ValueError(f"col_idx / vals hold {len(ci)} / {len(va)} entries, row_ptr[nrows] = {int(rp[-1])}")
         view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, nontemporal, keep_csr,
-                    debug_col_mask, depth, col_panels, value_dict, tune_steps)
+                    debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block)
 
     @classmethod
     def from_device(cls, nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, is_f32=False, device=0, steps_per_chunk=0,
@@ -277,13 +281,14 @@ class CvrMatrix:
         return self
 
     def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, nontemporal, keep_csr,
-               debug_col_mask, depth, col_panels, value_dict, tune_steps):
+               debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block=0):
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
         opt.xcd_swizzle, opt.x_window, opt.col_panels, opt.value_dict = xcd_swizzle, x_window, col_panels, value_dict
         # tuning / profiling knobs (tools/sweep.py)
         opt.stream_policy, opt.gather_depth, opt.debug_col_mask = nontemporal, depth, debug_col_mask
+        opt.waves_per_block = waves_per_block
         if tune_steps and steps_per_chunk == 0:
             best, best_t, tun = C.c_int32(), C.c_double(), C.c_double()
             rc = lib().cvr_tune_steps(C.byref(view), C.byref(opt), C.byref(best), C.byref(best_t), C.byref(tun))

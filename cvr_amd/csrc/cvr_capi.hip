@@ -340,9 +340,6 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     const std::vector<int64_t>  &nzb = pp.nzb;
 
     part.nrows = nrows; part.nnz = nz1 - nz0; part.nnz_span = nz1; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
-    // LDS row-sum stage of the SpMV kernel: sized for the chunk with the most segments, so every chunk writes its y
-    // coalesced; capped (chunks of very short rows beyond the cap store directly)
-    part.img.ystage = (uint32_t)std::min<int64_t>(std::max<int64_t>((max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
     const int G = S / 4;
     cvr::DeviceImage &img = part.img;
     img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
@@ -350,12 +347,26 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     img.xcd_swizzle = opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
     img.stream_policy = opt.stream_policy > 0 ? opt.stream_policy : 0;
     img.depth = opt.gather_depth == 2 ? 2 : 1;
-    // LDS window of x per workgroup: off by default.  Measured on MI355X (profiles/r01_lds_window_sweep.log): the
-    // gathers it absorbs are the cheap ones (L1/L2 hits near the diagonal); the kernel's time is set by the L2
-    // misses of the scattered columns, which a contiguous window cannot hold, and the LDS it takes costs occupancy.
+    // Wavefronts (consecutive chunks) per SpMV workgroup: 1 by default; more only pay together with an LDS window of x,
+    // which the workgroup's chunks then share (profiles/r02_wg_window_sweep.log).
+    img.wpb = (uint32_t)std::min(std::max(opt.waves_per_block, 1), cvr::kMaxWavesPerBlock);
+    // LDS window of x per workgroup (off by default): `win` consecutive values of x staged with coalesced loads; gathers
+    // inside it are served by ds_read instead of a 128-byte L1 fill each.
     int64_t win = opt.x_window < 0 ? 0 : opt.x_window;
-    if (win > ncols + 1) win = ncols + 1;
-    if (win > 16384) win = 16384;                     // 128 KiB of fp64 + steal slots, staged row sums and dictionary stay under 160 KiB
+    win = std::min<int64_t>(win, ncols + 1) & ~(int64_t)3;           // whole 16-byte loads, inside x_ext
+    // LDS budget (160 KiB per CU): steal slots and dictionary are fixed; the row-sum stage is sized for the chunk with the
+    // most segments, so every chunk writes its y coalesced (chunks of very short rows beyond the stage store directly);
+    // the window takes what it asked for, the stage at least 64 rows per wavefront, and whatever does not fit is cut:
+    // first the stage down to 512 rows per wavefront, then the window.
+    {
+        const int64_t vs = f32 ? 4 : 8, total = (int64_t)cvr::kLdsBytes / vs;
+        const int64_t fixed = (int64_t)img.wpb * cvr::kLanes + cvr::kDictMax + 4;     // dictionary room is reserved before it is known
+        int64_t stage = std::min<int64_t>(std::max<int64_t>((max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
+        if (fixed + img.wpb * stage + win > total) stage = std::max<int64_t>(std::min<int64_t>(stage, 512), ((total - fixed - win) / img.wpb) & ~(int64_t)63);
+        if (stage < 64) stage = 64;
+        if (fixed + img.wpb * stage + win > total) win = std::max<int64_t>(0, total - fixed - img.wpb * stage) & ~(int64_t)3;
+        part.img.ystage = (uint32_t)stage;
+    }
     img.win_elems = (uint32_t)win;
     if (opt.debug_col_mask) img.col_mask = (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
 
@@ -368,8 +379,8 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     HIP_TRY(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY(hipMalloc(&img.target, 64 * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
-    HIP_TRY(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)nchunks / cvr::kWavesPerBlock + 1)));
-    HIP_TRY(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / cvr::kWavesPerBlock + 1), h->stream));
+    HIP_TRY(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1)));
+    HIP_TRY(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1), h->stream));
     if (nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
     if (nnz_span) {
         HIP_TRY(hipMemcpyAsync(part.d_ci, ci, sizeof(int32_t) * nnz_span, civa_kind, h->stream));     // row_ptr is always a host array here

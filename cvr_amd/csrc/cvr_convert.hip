@@ -157,17 +157,17 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
 }
 
 
-// Window choice for the SpMV kernel's LDS staging of x: one workgroup per SpMV workgroup (kWavesPerBlock
+// Window choice for the SpMV kernel's LDS staging of x: one workgroup per SpMV workgroup (wpb
 // consecutive chunks = one contiguous CSR range).  Histogram of the range's columns over bins of 2^binshift
 // columns in LDS, then the best run of `nb` consecutive bins; ties go to the lowest column.
 __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__ cidx, const int64_t *__restrict__ nzb,
                                                       uint32_t nchunks, uint32_t ncols1, uint32_t wn, uint32_t binshift,
-                                                      uint32_t nbins, uint32_t nb, uint32_t *__restrict__ win_base)
+                                                      uint32_t nbins, uint32_t nb, uint32_t *__restrict__ win_base, uint32_t wpb)
 {
     extern __shared__ uint32_t hist[];                       // [nbins + nb] then one u64 for the arg-max
     unsigned long long *best = reinterpret_cast<unsigned long long *>(hist + ((nbins + nb + 1) & ~1u));
-    const uint32_t c0 = blockIdx.x * kWavesPerBlock;
-    const uint32_t c1 = c0 + kWavesPerBlock < nchunks ? c0 + kWavesPerBlock : nchunks;
+    const uint32_t c0 = blockIdx.x * wpb;
+    const uint32_t c1 = c0 + wpb < nchunks ? c0 + wpb : nchunks;
     for (uint32_t i = threadIdx.x; i < nbins + nb; i += blockDim.x) hist[i] = 0;
     if (threadIdx.x == 0) *best = 0;
     __syncthreads();
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t s = 0xffffffffu - (uint32_t)(*best & 0xffffffffu);
-        uint32_t       wb = (*best >> 32) ? s << binshift : 0;
-        if (wb + wn > ncols1) wb = ncols1 > wn ? ncols1 - wn : 0;   // keep the window inside x_ext
+        uint32_t       wb = ((*best >> 32) ? s << binshift : 0) & ~3u;       // 16-byte aligned for the staging loads
+        if (wb + wn > ncols1) wb = ncols1 > wn ? (ncols1 - wn) & ~3u : 0;   // keep the window inside x_ext, 16-byte aligned
         win_base[blockIdx.x] = wb;
     }
 }
@@ -298,17 +298,18 @@ namespace cvr {
 hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st)
 {
     if (img.nchunks == 0 || img.win_elems == 0) return hipSuccess;
-    const uint32_t blocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;
+    const uint32_t blocks = (img.nchunks + wpb - 1) / wpb;
     const uint32_t ncols1 = img.pad_col + 1;
     uint32_t       binshift = 0;
-    while ((1u << binshift) * 4 < img.win_elems) binshift++;              // bins of >= window/4 columns ...
+    while ((1u << binshift) * 16 < img.win_elems) binshift++;             // bins of >= window/16 columns ...
     while (((uint64_t)ncols1 >> binshift) + 1 > 8192) binshift++;         // ... and at most 8192 of them
     const uint32_t nbins = (uint32_t)(((uint64_t)ncols1 + (1u << binshift) - 1) >> binshift);
     uint32_t       nb = img.win_elems >> binshift;
     if (nb == 0) nb = 1;
     const size_t lds = sizeof(uint32_t) * ((size_t)((nbins + nb + 1) & ~1u)) + 16;
     hipLaunchKernelGGL(window_kernel, dim3(blocks), dim3(256), lds, st, csr.col_idx, csr.nz_begin, img.nchunks, ncols1,
-                       img.win_elems, binshift, nbins, nb, img.win_base);
+                       img.win_elems, binshift, nbins, nb, img.win_base, wpb);
     return hipGetLastError();
 }
 

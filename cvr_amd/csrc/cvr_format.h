@@ -26,6 +26,7 @@
 //   target[k]  = per lane: the lane it stole from (itself if it never stole); spmv.cpp:900, 982-999
 //   shared[]   = rows cut over chunks c0..c1: y[row] = carry_tail(c0) + sum_{c0<c<=c1} carry_head(c)
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 namespace cvr {
@@ -40,7 +41,9 @@ constexpr int      kGroupBytes32 = kColsBytes + kLanes * 16;  // 2048
 constexpr int      kGroupBytesDict = kColsBytes + kLanes * 4;  // 1280: column words + one code byte per slot
 constexpr int      kDictMax = 256;
 constexpr int      kYStageMax = 4096;   // most row sums a wavefront stages in LDS and writes out coalesced at the end of its chunk (32 KB of fp64)
-constexpr int      kWavesPerBlock = 1;   // measured: 1 wave per workgroup spreads the chunks most evenly over the CUs (profiles/r01_waves_per_block.log)
+constexpr int      kWavesPerBlock = 1;   // converter / fix-up launches; the SpMV default: 1 wave per workgroup spreads the chunks most evenly over the CUs (profiles/r01_waves_per_block.log)
+constexpr int      kMaxWavesPerBlock = 16;   // SpMV workgroups of several consecutive chunks share an LDS window of x (cvr_options.waves_per_block)
+constexpr size_t   kLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 
 inline int group_bytes(bool f32, bool dict = false) { return dict ? kGroupBytesDict : f32 ? kGroupBytes32 : kGroupBytes64; }
 

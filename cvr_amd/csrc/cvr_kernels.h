@@ -25,7 +25,8 @@ struct DeviceImage {
     int      depth = 1;             // groups the x gather runs ahead of the FMAs (1 or 2)
     const void *dict = nullptr;     // value dictionary: ndict values of T sorted by bit pattern (device), or null
     uint32_t  ndict = 0;
-    uint32_t *win_base = nullptr;   // [ceil(nchunks / kWavesPerBlock)] first column of each workgroup's LDS window of x
+    uint32_t wpb = 1;               // wavefronts (= consecutive chunks) per SpMV workgroup, 1..kMaxWavesPerBlock
+    uint32_t *win_base = nullptr;   // [ceil(nchunks / wpb)] first column of each workgroup's LDS window of x
     uint32_t win_elems = 0;         // window length in values (0 = no window)
     uint32_t col_mask = kColMask;   // profiling only: a narrower mask folds the x gather onto a small table
 };
@@ -77,12 +78,13 @@ hipError_t launch_unpad(void *dense, const void *padded, const IterBounds &bd, i
 hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st);
 hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, unsigned long long *table, uint32_t *flags, hipStream_t st);
 
-// picks, per workgroup of kWavesPerBlock chunks, the window of img.win_elems consecutive columns that holds most
+// picks, per workgroup of img.wpb chunks, the window of img.win_elems consecutive columns that holds most
 // of its non-zeros (LDS histogram over coarse column bins); writes img.win_base
 hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st);
 
 // y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0 and with_fixup)
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup = true);
+size_t     spmv_lds_bytes(const DeviceImage &img);      // dynamic LDS of that launch
 
 // column panels: one fix-up launch for all panels (each with its own y_ext inside the partial-sum buffer)
 struct FixPart { const int64_t *shared; void *yext; uint32_t nshared, nrows; };

@@ -131,7 +131,7 @@ __device__ __forceinline__ uint32_t remap_block(uint32_t b, uint32_t nblocks_per
     // consecutive chunks, so that the waves resident on a CU work on neighbouring rows and share x lines in its L1
     const uint32_t per_cu = (nblocks_per_xcd + 31) / 32;
     const uint32_t t = (j & 31u) * per_cu + (j >> 5);
-    return t < nblocks_per_xcd ? xcd * nblocks_per_xcd + t : 0xffffffffu / kWavesPerBlock;
+    return t < nblocks_per_xcd ? xcd * nblocks_per_xcd + t : 0x00ffffffu;
 }
 
 
@@ -186,27 +186,30 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
     }
 }
 
-template <typename T, int SPOL, int XPOL, int DEPTH, bool WIN, bool DICT>
-__global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
+// MW: more than one wavefront per workgroup (blockDim.x / 64 consecutive chunks share the workgroup's LDS window of x and its
+// dictionary copy); the single-wavefront form needs no barrier.
+template <typename T, int SPOL, int XPOL, int DEPTH, bool WIN, bool DICT, bool MW>
+__global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv_kernel(
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
     const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
     uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict,
     uint32_t ystage_n)
 {
     constexpr int  GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
-    constexpr bool kSync = WIN || (DICT && kWavesPerBlock > 1);      // LDS filled by other waves of the workgroup
+    constexpr bool kSync = WIN || (DICT && MW);      // LDS filled by other waves of the workgroup
     // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums, the value dictionary (DICT), then the x window and
     // its zero slot (WIN)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t nw = MW ? blockDim.x >> 6 : 1u;
     T *const slots = reinterpret_cast<T *>(smem);
-    T *const ystage_all = slots + kWavesPerBlock * kLanes;
-    T *const dict = ystage_all + kWavesPerBlock * ystage_n;
+    T *const ystage_all = slots + nw * kLanes;
+    T *const dict = ystage_all + nw * ystage_n;
     T *const win = dict + (DICT ? kDictMax : 0);
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wv = MW ? threadIdx.x >> 6 : 0u;
     const uint32_t blk = remap_block(blockIdx.x, nblocks_per_xcd, swz);
-    const uint32_t k = __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + wv);
+    const uint32_t k = __builtin_amdgcn_readfirstlane(blk * nw + wv);
     if (!kSync && k >= nchunks) return;
     const bool live = k < nchunks;
 
@@ -221,14 +224,18 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void spmv_kernel(
 #pragma unroll
     for (int i = 0; i <= DEPTH; i++) Q[i] = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)i * GB);
 
-    // stage this workgroup's window of x in LDS: coalesced loads, behind the first stream loads
+    // stage this workgroup's window of x in LDS: coalesced 16-byte loads, behind the first stream loads
     uint32_t wbase = 0;
     if constexpr (DICT)
-        for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += kLanes * kWavesPerBlock) dict[i] = i < ndict ? dict_g[i] : T(0);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += blockDim.x) dict[i] = i < ndict ? dict_g[i] : T(0);
     if constexpr (WIN) {
-        wbase = blk * kWavesPerBlock < nchunks ? win_base[blk] : 0u;
-        for (uint32_t i = threadIdx.x; i <= wn; i += kLanes * kWavesPerBlock)
-            win[i] = i < wn ? load_x<T, kPolDefault>(rx, wbase + i) : T(0);
+        constexpr uint32_t kPer = 16 / sizeof(T);                      // values per 16-byte load; wbase and wn are multiples of it
+        wbase = blk * nw < nchunks ? win_base[blk] : 0u;
+        for (uint32_t i = threadIdx.x * kPer; i < wn; i += blockDim.x * kPer) {
+            const u32x4 q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (wbase + i) * (uint32_t)sizeof(T), 0, kPolDefault));
+            *reinterpret_cast<u32x4 *>(win + i) = q;
+        }
+        if (threadIdx.x == 0) win[wn] = T(0);
     }
     if constexpr (kSync) {
         __syncthreads();
@@ -391,25 +398,35 @@ hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st)
     return hipGetLastError();
 }
 
+size_t spmv_lds_bytes(const DeviceImage &img)
+{
+    const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;
+    const bool     use_win = img.win_elems > 0 && img.win_base != nullptr;
+    return (size_t)(wpb * (kLanes + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
+}
+
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup)
 {
     if (img.nchunks == 0) return hipSuccess;
-    const uint32_t nblocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;                     // consecutive chunks (wavefronts) per workgroup
+    const uint32_t nblocks = (img.nchunks + wpb - 1) / wpb;
     const uint32_t per_xcd = (nblocks + 7) / 8;
     const uint32_t grid = img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;
-    const dim3     block(kLanes * kWavesPerBlock);
+    const dim3     block(kLanes * wpb);
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
     if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
     const bool   use_win = img.win_elems > 0 && img.win_base != nullptr;
     const bool   use_dict = img.dict != nullptr;
-    const size_t lds = (size_t)(kWavesPerBlock * (kLanes + img.ystage) + (use_dict ? kDictMax : 0) + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
-    // template parameters: <value type, stream cache policy, gather cache policy, gather run-ahead, LDS window, dictionary>
-#define CVR_LAUNCH(T, SP, D, W, DI)                                                                               \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
+    const size_t lds = spmv_lds_bytes(img);
+    if (lds > kLdsBytes) return hipErrorInvalidValue;      // build_part sizes the stage and the window to fit; never reached
+    // template parameters: <value type, stream cache policy, gather cache policy, gather run-ahead, LDS window, dictionary, multi-wave>
+#define CVR_LAUNCH(T, SP, D, W, DI, MW)                                                                           \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
                        static_cast<const T *>(img.dict), img.ndict, img.ystage)
-#define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_LAUNCH(T, SP, D, W, true); else CVR_LAUNCH(T, SP, D, W, false); } while (0)
+#define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_LAUNCH(T, SP, D, W, DI, true); else CVR_LAUNCH(T, SP, D, W, DI, false); } while (0)
+#define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_PICK_MW(T, SP, D, W, true); else CVR_PICK_MW(T, SP, D, W, false); } while (0)
 #define CVR_PICK_W(T, SP, D)     do { if (use_win) CVR_PICK_DI(T, SP, D, true); else CVR_PICK_DI(T, SP, D, false); } while (0)
 #define CVR_PICK_D(T, SP)        do { if (img.depth == 2) CVR_PICK_W(T, SP, 2); else CVR_PICK_W(T, SP, 1); } while (0)
 #define CVR_PICK_SP(T)           do { if (img.stream_policy == kPolNt) CVR_PICK_D(T, kPolNt); else CVR_PICK_D(T, kPolDefault); } while (0)
@@ -418,14 +435,16 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #undef CVR_PICK_D
 #undef CVR_PICK_W
 #undef CVR_PICK_DI
+#undef CVR_PICK_MW
 #undef CVR_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || img.nshared == 0 || !with_fixup) return e;
     const uint32_t fb = (img.nshared + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3     fblock(kLanes * kWavesPerBlock);
     if (img.f32)
-        hipLaunchKernelGGL(fixup_kernel<float>, dim3(fb), block, 0, st, img.shared, img.nshared, static_cast<float *>(y_ext), img.nrows);
+        hipLaunchKernelGGL(fixup_kernel<float>, dim3(fb), fblock, 0, st, img.shared, img.nshared, static_cast<float *>(y_ext), img.nrows);
     else
-        hipLaunchKernelGGL(fixup_kernel<double>, dim3(fb), block, 0, st, img.shared, img.nshared, static_cast<double *>(y_ext), img.nrows);
+        hipLaunchKernelGGL(fixup_kernel<double>, dim3(fb), fblock, 0, st, img.shared, img.nshared, static_cast<double *>(y_ext), img.nrows);
     return hipGetLastError();
 }
 

@@ -68,10 +68,12 @@ typedef struct {
     int32_t xcd_swizzle;       /* 1 (default when <0): contiguous chunk ranges per XCD; 0 off; */
                                /* 2: also consecutive chunks per CU (measured within +-2 %)    */
     int32_t x_window;          /* values of x each workgroup stages in LDS with coalesced loads */
-                               /* and serves its gathers from; 0 = off (<0 = default = off)    */
+                               /* and serves its gathers from (cut to what fits the 160 KiB of */
+                               /* LDS beside the row-sum stage); 0 = off (<0 = default = off)  */
     /* tuning / profiling knobs (tools/sweep.py); 0 = default */
     int32_t stream_policy;     /* 2: nontemporal loads of the matrix stream (measured slower)  */
-    int32_t reserved0;         /* was: cache policy of the x gather -- nt / sc1 measured useless or harmful, removed */
+    int32_t waves_per_block;   /* wavefronts (= consecutive chunks) per SpMV workgroup, 1..16; 0 = default (1).  More than */
+                               /* one pays only with x_window: the chunks of a workgroup share the staged window          */
     int32_t gather_depth;      /* groups (of 4 steps) the x gather runs ahead of the FMAs: 1 or 2 */
     int32_t debug_col_mask;    /* profiling only: folds the gather onto a 2^k-entry table (wrong y) */
     int32_t col_panels;        /* column panels (each with its slice of x L2-resident, partial sums combined by a second
