@@ -110,6 +110,7 @@ struct Part {
         if (img.target) (void)hipFree(img.target);
         if (img.shared) (void)hipFree(img.shared);
         if (img.win_base) (void)hipFree(img.win_base);
+        if (img.desc2) (void)hipFree(img.desc2);
         img = cvr::DeviceImage{};
     }
 };
@@ -171,6 +172,7 @@ void cvr_default_options(cvr_options *o)
     o->x_window = -1;
     o->col_panels = -1;
     o->value_dict = -1;
+    o->col_phases = 0;
 }
 
 int cvr_device_count(void)
@@ -279,23 +281,58 @@ static int pick_steps(int64_t nslots_est)
 struct PartPlan {
     int                   S = 0;
     cvr::Plan             plan;
-    std::vector<uint32_t> desc, pad;
+    std::vector<uint32_t> desc, pad, desc2;
     std::vector<int64_t>  nzb;
     int64_t               max_nseg = 0, yext = 0;
     bool                  too_large = false;
+    // LDS of the SpMV workgroup (160 KiB per CU)
+    int      wpb = 1, phases = 1;
+    int64_t  win = 0;              // x window, values
+    int64_t  stage = 64;           // row sums (column phases: row accumulators) per wavefront
+    int      col_bits = 31;        // column phases: bits of a column index (the row field of a segment's last column word starts there)
+    bool     lds_short = false;    // column phases do not fit beside the window
 };
 
-static void plan_part(PartPlan &pp, int64_t nrows, const int64_t *rp, const cvr_options &opt)
+static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const cvr_options &opt)
 {
     const int64_t nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
     pp.S = opt.steps_per_chunk;
     if (pp.S == 0) pp.S = pick_steps(nz1 - nz0 + nrows / 4);
-    pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold);
+    // Wavefronts (consecutive chunks) per SpMV workgroup: 1 by default; more only pay together with an LDS window of x,
+    // which the workgroup's chunks then share (profiles/r02_wg_window_sweep.log).
+    pp.wpb = std::min(std::max(opt.waves_per_block, 1), cvr::kMaxWavesPerBlock);
+    pp.phases = std::min(std::max(opt.col_phases, 1), 64);
+    if (ncols < 64 * pp.phases) pp.phases = 1;
+    // LDS window of x per workgroup (off by default): `win` consecutive values of x staged with coalesced loads; gathers
+    // inside it are served by ds_read instead of a 128-byte L1 fill each.
+    pp.win = std::min<int64_t>(opt.x_window < 0 ? 0 : opt.x_window, ncols + 1) & ~(int64_t)3;      // whole 16-byte loads, inside x_ext
+    const int64_t vs = f32 ? 4 : 8;
+    int64_t       max_rows = 0;
+    if (pp.phases > 1) {
+        // column phases: every chunk accumulates its rows in LDS, so the planner caps the rows of a chunk at what is left of
+        // the 160 KiB beside steal slots, dictionary and window -- and at what the row field of a segment's last column
+        // word can hold (the bits between the column index and the end flag)
+        pp.col_bits = 1;
+        while (((int64_t)1 << pp.col_bits) <= ncols) pp.col_bits++;
+        const int64_t row_field = pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
+        auto rows_for = [&](int64_t win) {
+            const int64_t left = (int64_t)cvr::kLdsBytes - ((int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + win + 4) * vs;
+            return std::min<int64_t>((left / pp.wpb / vs) & ~(int64_t)3, cvr::kYStageMax);
+        };
+        while (pp.win > 0 && rows_for(pp.win) < 512) pp.win = (pp.win - 1024 > 0 ? pp.win - 1024 : 0) & ~(int64_t)3;      // the window gives way
+        pp.stage = std::min<int64_t>(rows_for(pp.win), (row_field + 1) & ~(int64_t)3);
+        // a chunk of S steps holds at most 64 S rows: no need for more accumulators than that (keeps the LDS small)
+        pp.stage = std::min<int64_t>(pp.stage, ((int64_t)cvr::kLanes * pp.S + 1 + 3) & ~(int64_t)3);
+        if (pp.stage < 64) { pp.lds_short = true; pp.phases = 1; pp.stage = 64; }
+        else max_rows = pp.stage - 1;                 // + the dump entry of the pad segment
+    }
+    pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold, max_rows);
     const cvr::Plan &plan = pp.plan;
     const int64_t    nchunks = (int64_t)plan.chunks.size();
     pp.yext = nrows + 1 + 2 * nchunks;
     if (pp.yext >= (int64_t)0xffffffffu || nchunks >= (int64_t)0x7fffffff) { pp.too_large = true; return; }
     pp.desc.resize((size_t)nchunks * 4);
+    if (pp.phases > 1) pp.desc2.resize((size_t)nchunks * 2, 0u);
     pp.pad.resize((size_t)nchunks);
     pp.nzb.resize((size_t)nchunks + 1);
     for (int64_t k = 0; k < nchunks; k++) {
@@ -313,10 +350,27 @@ static void plan_part(PartPlan &pp, int64_t nrows, const int64_t *rp, const cvr_
         };
         pp.desc[4 * k + 2] = dest(0);
         pp.desc[4 * k + 3] = dest(c.nseg - 1);
+        if (pp.phases > 1) {            // column phases: head / last_dest belong to the first / last ROW; desc.y and desc2.x come from the device
+            pp.desc[4 * k + 3] = dest(c.nrows_in - 1);
+            pp.desc2[2 * k + 1] = (uint32_t)c.nrows_in;
+        }
         pp.pad[(size_t)k] = (uint32_t)c.pad_cnt;
         pp.nzb[(size_t)k] = c.nz_begin;
     }
     pp.nzb[(size_t)nchunks] = plan.nz_end;
+    if (pp.phases == 1) {
+        // LDS budget without phases: steal slots and dictionary are fixed; the row-sum stage is sized for the chunk with the
+        // most segments, so every chunk writes its y coalesced (chunks of very short rows beyond the stage store directly);
+        // the window takes what it asked for, the stage at least 64 rows per wavefront, and whatever does not fit is cut:
+        // first the stage down to 512 rows per wavefront, then the window.
+        const int64_t total = (int64_t)cvr::kLdsBytes / vs;
+        const int64_t fixed = (int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + 4;     // dictionary room is reserved before it is known
+        int64_t stage = std::min<int64_t>(std::max<int64_t>((pp.max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
+        if (fixed + pp.wpb * stage + pp.win > total) stage = std::max<int64_t>(std::min<int64_t>(stage, 512), ((total - fixed - pp.win) / pp.wpb) & ~(int64_t)63);
+        if (stage < 64) stage = 64;
+        if (fixed + pp.wpb * stage + pp.win > total) pp.win = std::max<int64_t>(0, total - fixed - pp.wpb * stage) & ~(int64_t)3;
+        pp.stage = stage;
+    }
 }
 
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
@@ -326,7 +380,7 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     PartPlan local;
     if (!planned) {
         const double t0 = now_s();
-        plan_part(local, nrows, rp, opt);
+        plan_part(local, nrows, ncols, f32, rp, opt);
         if (plan_s) *plan_s += now_s() - t0;
         planned = &local;
     }
@@ -335,7 +389,7 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     const int64_t    nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
     const int        S = pp.S;
     const cvr::Plan &plan = pp.plan;
-    const int64_t    nchunks = (int64_t)plan.chunks.size(), yext = pp.yext, max_nseg = pp.max_nseg;
+    const int64_t    nchunks = (int64_t)plan.chunks.size(), yext = pp.yext;
     const std::vector<uint32_t> &desc = pp.desc, &pad = pp.pad;
     const std::vector<int64_t>  &nzb = pp.nzb;
 
@@ -347,28 +401,19 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     img.xcd_swizzle = opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
     img.stream_policy = opt.stream_policy > 0 ? opt.stream_policy : 0;
     img.depth = opt.gather_depth == 2 ? 2 : 1;
-    // Wavefronts (consecutive chunks) per SpMV workgroup: 1 by default; more only pay together with an LDS window of x,
-    // which the workgroup's chunks then share (profiles/r02_wg_window_sweep.log).
-    img.wpb = (uint32_t)std::min(std::max(opt.waves_per_block, 1), cvr::kMaxWavesPerBlock);
-    // LDS window of x per workgroup (off by default): `win` consecutive values of x staged with coalesced loads; gathers
-    // inside it are served by ds_read instead of a 128-byte L1 fill each.
-    int64_t win = opt.x_window < 0 ? 0 : opt.x_window;
-    win = std::min<int64_t>(win, ncols + 1) & ~(int64_t)3;           // whole 16-byte loads, inside x_ext
-    // LDS budget (160 KiB per CU): steal slots and dictionary are fixed; the row-sum stage is sized for the chunk with the
-    // most segments, so every chunk writes its y coalesced (chunks of very short rows beyond the stage store directly);
-    // the window takes what it asked for, the stage at least 64 rows per wavefront, and whatever does not fit is cut:
-    // first the stage down to 512 rows per wavefront, then the window.
-    {
-        const int64_t vs = f32 ? 4 : 8, total = (int64_t)cvr::kLdsBytes / vs;
-        const int64_t fixed = (int64_t)img.wpb * cvr::kLanes + cvr::kDictMax + 4;     // dictionary room is reserved before it is known
-        int64_t stage = std::min<int64_t>(std::max<int64_t>((max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
-        if (fixed + img.wpb * stage + win > total) stage = std::max<int64_t>(std::min<int64_t>(stage, 512), ((total - fixed - win) / img.wpb) & ~(int64_t)63);
-        if (stage < 64) stage = 64;
-        if (fixed + img.wpb * stage + win > total) win = std::max<int64_t>(0, total - fixed - img.wpb * stage) & ~(int64_t)3;
-        part.img.ystage = (uint32_t)stage;
+    img.wpb = (uint32_t)pp.wpb;
+    img.ystage = (uint32_t)pp.stage;
+    img.phases = (uint32_t)pp.phases;
+    if (pp.phases > 1) {
+        const int64_t pw = ((ncols + pp.phases - 1) / pp.phases + 15) / 16 * 16;
+        img.phase_width = (uint32_t)std::max<int64_t>(pw, 16);
+        img.col_bits = (uint32_t)pp.col_bits;
+        img.col_mask = (1u << pp.col_bits) - 1u;
     }
+    if (opt.col_phases > 1 && pp.lds_short) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
+    const int64_t win = pp.win;
     img.win_elems = (uint32_t)win;
-    if (opt.debug_col_mask) img.col_mask = (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
+    if (opt.debug_col_mask) img.col_mask &= (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
 
     const size_t vsz = f32 ? 4 : 8, nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
     HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
@@ -379,6 +424,10 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     HIP_TRY(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY(hipMalloc(&img.target, 64 * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
+    if (pp.phases > 1) {
+        HIP_TRY(hipMalloc(&img.desc2, 8 * std::max<size_t>((size_t)nchunks, 1)));
+        if (nchunks) HIP_TRY(hipMemcpyAsync(img.desc2, pp.desc2.data(), sizeof(uint32_t) * pp.desc2.size(), hipMemcpyHostToDevice, h->stream));
+    }
     HIP_TRY(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1)));
     HIP_TRY(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1), h->stream));
     if (nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
@@ -731,11 +780,13 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         clk.lap("panel split");
         // the panels' images are planned side by side (the planner is a sequential walk per image), then built one by one
         std::vector<PartPlan> pps((size_t)P);
+        cvr_options           panel_opt = opt;
+        panel_opt.col_phases = 1;          // column phases are for the single image whose chunks are all resident at once
         {
             const double tp = now_s();
             int T = (int)std::thread::hardware_concurrency();
             T = std::max(1, std::min(T, P));
-            auto work = [&](int t) { for (int p = t; p < P; p += T) plan_part(pps[(size_t)p], (int64_t)sp.rows[(size_t)p].size(), sp.rp[(size_t)p].data(), opt); };
+            auto work = [&](int t) { for (int p = t; p < P; p += T) plan_part(pps[(size_t)p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), panel_opt); };
             std::vector<std::thread> th;
             for (int t = 1; t < T; t++) th.emplace_back(work, t);
             work(0);
@@ -748,10 +799,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             Part &part = h->parts[(size_t)p];
             if (dev_split)
                 rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), dsg.d.ci + dsg.d.off[p],
-                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, opt, &in.plan_s, &pps[(size_t)p]);
+                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, panel_opt, &in.plan_s, &pps[(size_t)p]);
             else
                 rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
-                                sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, opt, &in.plan_s, &pps[(size_t)p]);
+                                sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, panel_opt, &in.plan_s, &pps[(size_t)p]);
             if (rc) { cvr_destroy(h); return rc; }
             part.zoff = zoff;
             zoff += part.yext;
@@ -847,6 +898,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     clk.lap("value dictionary scan");
     for (Part &p : h->parts) { rc = finish_part(h, p); if (rc) { cvr_destroy(h); return rc; } }
     in.steps_per_chunk = h->parts[0].img.S;
+    in.col_phases = (int32_t)h->parts[0].img.phases; in.waves_per_block = (int32_t)h->parts[0].img.wpb; in.x_window = (int32_t)h->parts[0].img.win_elems;
+    in.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);
+    in.chunk_row_cap = h->parts[0].img.phases > 1 ? (int64_t)h->parts[0].img.ystage - 1 : 0;
     for (const Part &p : h->parts) {
         in.nchunks += p.nchunks; in.nshared += p.nshared; in.nslots += p.nchunks * 64 * p.img.S;
         in.image_bytes += (int64_t)(p.stream_bytes + (size_t)p.nchunks * (16 + 64) + (size_t)p.nshared * 24);
@@ -876,10 +930,34 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
     HIP_TRY(hipEventRecord(e0, h->stream));
+    struct SegGuard { cvr::SegTable t; ~SegGuard() { (void)hipFree(t.cnt); (void)hipFree(t.begin); (void)hipFree(t.len); (void)hipFree(t.row); (void)hipFree(t.flags); } } sg;
     for (Part &p : h->parts) {
         cvr::DeviceCsr csr;
         csr.row_ptr = p.d_rp; csr.col_idx = p.d_ci; csr.vals = p.d_va; csr.nz_begin = p.d_nzb; csr.pad_cnt = p.d_pad;
-        HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream));
+        if (p.img.phases > 1 && p.nchunks > 0) {
+            // column phases: count the (row, phase) segments of every chunk, scan, fill the table (device); the host only
+            // learns the total (to size the table, which lives until the conversion is done) and whether the rows are sorted
+            cvr::SegTable &t = sg.t;
+            HIP_TRY(hipMalloc(&t.cnt, sizeof(uint32_t) * ((size_t)p.nchunks + 1)));
+            HIP_TRY(hipMalloc(&t.flags, sizeof(uint32_t) * 2));
+            HIP_TRY(hipMemsetAsync(t.flags, 0, sizeof(uint32_t) * 2, h->stream));
+            HIP_TRY(cvr::launch_seg_count(p.img, csr, t, h->stream));
+            HIP_TRY(cvr::launch_seg_scan(p.img, t, h->stream));
+            uint32_t flags[2] = {0, 0}, total = 0;
+            HIP_TRY(hipMemcpyAsync(flags, t.flags, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(&total, t.cnt + p.nchunks, sizeof(total), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (flags[0] & 1u) return fail(CVR_ERR_INVALID, "col_phases needs the column indices of every row in ascending order");
+            t.total = total;
+            HIP_TRY(hipMalloc(&t.begin, sizeof(int64_t) * std::max<size_t>(total, 1)));
+            HIP_TRY(hipMalloc(&t.len, sizeof(uint32_t) * std::max<size_t>(total, 1)));
+            HIP_TRY(hipMalloc(&t.row, sizeof(uint16_t) * std::max<size_t>(total, 1)));
+            h->info.nsegments = total;
+            HIP_TRY(cvr::launch_seg_fill(p.img, csr, t, h->stream));
+            HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream, &t));
+        } else {
+            HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream));
+        }
         HIP_TRY(cvr::launch_window(p.img, csr, h->stream));
     }
     HIP_TRY(hipEventRecord(e1, h->stream));
@@ -891,6 +969,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     h->info.convert_s = ms * 1e-3;
+    h->info.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);      // column phases: the segment-row copy is sized by now
     if (seconds) *seconds = ms * 1e-3;
     if (err) return fail(CVR_ERR_INTERNAL, "device converter self-check failed (flags 0x%x)", err);
     h->converted = true;

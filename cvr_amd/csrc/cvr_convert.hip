@@ -42,12 +42,16 @@ __device__ __forceinline__ uint32_t dict_code(const typename Bits<T>::type *dict
     return lo;
 }
 
-template <typename T, bool DICT>
+// SEGT: the chunk's segments come from a table (column phases: one segment per (row, phase) pair, launch_seg_fill) instead
+// of being the chunk's rows in order.
+template <typename T, bool DICT, bool SEGT>
 __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx, const T *__restrict__ vals,
     const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt, const uint4 *__restrict__ desc,
     uint8_t *__restrict__ stream, uint8_t *__restrict__ target, uint32_t *__restrict__ err, int G,
-    uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict)
+    uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
+    const uint2 *__restrict__ desc2, const int64_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
+    const uint16_t *__restrict__ seg_row, uint32_t col_bits)
 {
     constexpr int GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     typedef typename Bits<T>::type bits_t;
@@ -64,11 +68,14 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     const uint32_t row_first = d.x, nseg = d.y, pc = pad_cnt[k];
     const uint32_t nrow_seg = nseg - (pc > 0 ? 1u : 0u);
     const int      S = G * kGroupSteps;
+    uint32_t       sbase = 0;
+    if constexpr (SEGT) sbase = desc2[k].x;
 
     int64_t  pos = -1;     // CSR element this lane emits next; -1 = pad slot
     uint32_t cnt = 0;      // slots left in the lane's current segment
     uint32_t fed = 0;      // segments handed out so far (wave-uniform)
     uint32_t tgt = lane;   // lane this one stole from
+    uint32_t rowtag = 0;   // SEGT: the chunk's row of the lane's segment, shifted above the column index (goes into its last column word)
     uint32_t bad = 0;
     uint8_t *out = stream + (size_t)k * G * GB + lane * 16;
 
@@ -85,7 +92,11 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
                 bool           want = cnt == 0;
                 if (want && rank < navail) {                 // feeding, spmv.cpp:821-868
                     const uint32_t q = fed + rank;
-                    if (q < nrow_seg) {
+                    if constexpr (SEGT) {
+                        pos = seg_begin[sbase + q];
+                        cnt = seg_len[sbase + q];
+                        rowtag = (uint32_t)seg_row[sbase + q] << col_bits;
+                    } else if (q < nrow_seg) {
                         const int64_t r = (int64_t)row_first + q;
                         int64_t       a = rp[r], z = rp[r + 1];
                         a = a > b ? a : b;                   // a row begun in an earlier chunk (spmv.cpp:748-756)
@@ -112,6 +123,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
                         if (want && s >= base && s < base + kk) {     // takes the FIRST ave (spmv.cpp:927-931)
                             pos = pv < 0 ? -1 : pv + (int64_t)(s - base) * ave;
                             cnt = ave;
+                            rowtag = 0;
                             tgt = (uint32_t)v;
                             want = false;
                         }
@@ -126,7 +138,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
             uint32_t c = pad_col;
             T        v = 0;
             if (pos >= 0) { c = (uint32_t)cidx[pos]; v = vals[pos]; pos++; }
-            cw[j] = c | (cnt == 1 ? kEndBit : 0u);
+            cw[j] = c | (cnt == 1 ? kEndBit | rowtag : 0u);
             vv[j] = v;
             cnt--;
         }
@@ -156,6 +168,127 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     target[(size_t)k * kLanes + lane] = (uint8_t)tgt;
 }
 
+
+// ---- column phases: the segment table -------------------------------------------------------------------------------
+// A chunk with column phases feeds, phase by phase (column range by column range), the pieces of its rows that fall into
+// the phase: one segment per (row, phase) pair with a non-zero, in (phase, row) order; an empty row keeps its pad slot
+// (phase 0); the chunk's trailing pad segment comes last.  Rows must have ascending columns (flags[0] bit 0 otherwise).
+
+// the piece of row i of chunk k inside the chunk's CSR range [b, e)
+__device__ __forceinline__ void row_piece(const int64_t *rp, uint32_t row, int64_t b, int64_t e, int64_t &a, int64_t &z)
+{
+    a = rp[row]; z = rp[row + 1];
+    a = a > b ? a : b;
+    z = z < e ? z : e;
+}
+
+__global__ __launch_bounds__(kLanes) void seg_count_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
+                                                           const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
+                                                           uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, uint32_t nchunks,
+                                                           uint32_t pw, uint32_t *__restrict__ cnt, uint32_t *__restrict__ flags)
+{
+    const uint32_t k = blockIdx.x, lane = threadIdx.x;
+    if (k >= nchunks) return;
+    const int64_t  b = nzb[k], e = nzb[k + 1];
+    const uint32_t row_first = desc[k].x, nri = desc2[k].y;
+    uint32_t       total = 0, bad = 0;
+    for (uint32_t i = lane; i < nri; i += kLanes) {
+        int64_t a, z;
+        row_piece(rp, row_first + i, b, e, a, z);
+        uint32_t c = 1;                                  // an empty row owns one pad slot
+        if (z > a) {
+            int32_t  prev_col = cidx[a];
+            uint32_t prev = (uint32_t)prev_col / pw;
+            for (int64_t j = a + 1; j < z; j++) {
+                const int32_t  col = cidx[j];
+                const uint32_t ph = (uint32_t)col / pw;
+                if (col < prev_col) bad = 1;
+                if (ph != prev) c++;
+                prev = ph; prev_col = col;
+            }
+        }
+        total += c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { total += __shfl_xor(total, o); bad |= __shfl_xor(bad, o); }
+    if (lane == 0) {
+        total += pad_cnt[k] > 0 ? 1u : 0u;
+        cnt[k] = total;
+        desc[k].y = total;
+        atomicMax(&flags[1], total);
+        if (bad) atomicOr(&flags[0], 1u);
+    }
+}
+
+// first position in cidx[a, z) whose column is >= bound (columns ascending)
+__device__ __forceinline__ int64_t lower_col(const int32_t *cidx, int64_t a, int64_t z, uint64_t bound)
+{
+    while (a < z) {
+        const int64_t mid = (a + z) >> 1;
+        if ((uint64_t)(uint32_t)cidx[mid] < bound) a = mid + 1; else z = mid;
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(kLanes) void seg_fill_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
+                                                          const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
+                                                          const uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, uint32_t nchunks,
+                                                          uint32_t pw, uint32_t phases, int64_t *__restrict__ seg_begin,
+                                                          uint32_t *__restrict__ seg_len, uint16_t *__restrict__ seg_row)
+{
+    const uint32_t k = blockIdx.x, lane = threadIdx.x;
+    if (k >= nchunks) return;
+    const int64_t  b = nzb[k], e = nzb[k + 1];
+    const uint32_t row_first = desc[k].x, nri = desc2[k].y;
+    uint32_t       q = desc2[k].x;
+    for (uint32_t p = 0; p < phases; p++) {
+        const uint64_t c0 = (uint64_t)p * pw, c1 = c0 + pw;
+        for (uint32_t r0 = 0; r0 < nri; r0 += kLanes) {
+            const uint32_t i = r0 + lane;
+            bool           has = false;
+            int64_t        beg = -1;
+            uint32_t       len = 1;
+            if (i < nri) {
+                int64_t a, z;
+                row_piece(rp, row_first + i, b, e, a, z);
+                if (z <= a) has = p == 0;
+                else {
+                    const int64_t lo = lower_col(cidx, a, z, c0), hi = lower_col(cidx, lo, z, c1);
+                    if (hi > lo) { has = true; beg = lo; len = (uint32_t)(hi - lo); }
+                }
+            }
+            const uint64_t m = __ballot(has);
+            if (has) {
+                const uint32_t idx = q + lane_rank(m);
+                seg_begin[idx] = beg; seg_len[idx] = len; seg_row[idx] = (uint16_t)i;
+            }
+            q += (uint32_t)__popcll(m);
+        }
+    }
+    const uint32_t pc = pad_cnt[k];
+    if (pc > 0 && lane == 0) { seg_begin[q] = -1; seg_len[q] = pc; seg_row[q] = (uint16_t)nri; }
+}
+
+// exclusive scan of the per-chunk segment counts, one workgroup (a few thousand to a few hundred thousand chunks)
+__global__ __launch_bounds__(1024) void seg_scan_kernel(uint32_t *__restrict__ cnt, uint2 *__restrict__ desc2, uint32_t nchunks)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, per = (nchunks + 1023) / 1024;
+    const uint32_t lo = t * per < nchunks ? t * per : nchunks, hi = lo + per < nchunks ? lo + per : nchunks;
+    uint32_t       s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {            // inclusive scan of the partial sums
+        const uint32_t v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0;
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t c = cnt[i]; cnt[i] = run; desc2[i].x = run; run += c; }
+    if (t == 1023) cnt[nchunks] = part[1023];
+}
 
 // Window choice for the SpMV kernel's LDS staging of x: one workgroup per SpMV workgroup (wpb
 // consecutive chunks = one contiguous CSR range).  Histogram of the range's columns over bins of 2^binshift
@@ -276,17 +409,43 @@ hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, 
     return hipGetLastError();
 }
 
-hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st)
+hipError_t launch_seg_count(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s)
+{
+    if (img.nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(seg_count_kernel, dim3(img.nchunks), dim3(kLanes), 0, s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
+                       img.desc2, img.nchunks, img.phase_width, st.cnt, st.flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_scan(const DeviceImage &img, SegTable &st, hipStream_t s)
+{
+    if (img.nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.desc2, img.nchunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_fill(const DeviceImage &img, const DeviceCsr &csr, const SegTable &st, hipStream_t s)
+{
+    if (img.nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(seg_fill_kernel, dim3(img.nchunks), dim3(kLanes), 0, s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
+                       img.desc2, img.nchunks, img.phase_width, img.phases, st.begin, st.len, st.row);
+    return hipGetLastError();
+}
+
+hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg)
 {
     if (img.nchunks == 0) return hipSuccess;
     const uint32_t blocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3     grid(blocks), block(kLanes * kWavesPerBlock);
-#define CVR_CONVERT(T, DI)                                                                                         \
-    hipLaunchKernelGGL((convert_kernel<T, DI>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
+#define CVR_CONVERT(T, DI, SG)                                                                                     \
+    hipLaunchKernelGGL((convert_kernel<T, DI, SG>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
                        csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
-                       static_cast<const T *>(img.dict), img.ndict)
-    if (img.f32) { if (img.dict) CVR_CONVERT(float, true); else CVR_CONVERT(float, false); }
-    else         { if (img.dict) CVR_CONVERT(double, true); else CVR_CONVERT(double, false); }
+                       static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, \
+                       seg ? seg->row : nullptr, img.col_bits)
+#define CVR_CONVERT_SG(T, DI) do { if (seg) CVR_CONVERT(T, DI, true); else CVR_CONVERT(T, DI, false); } while (0)
+    if (img.f32) { if (img.dict) CVR_CONVERT_SG(float, true); else CVR_CONVERT_SG(float, false); }
+    else         { if (img.dict) CVR_CONVERT_SG(double, true); else CVR_CONVERT_SG(double, false); }
+#undef CVR_CONVERT_SG
 #undef CVR_CONVERT
     return hipGetLastError();
 }

@@ -29,6 +29,14 @@ struct DeviceImage {
     uint32_t *win_base = nullptr;   // [ceil(nchunks / wpb)] first column of each workgroup's LDS window of x
     uint32_t win_elems = 0;         // window length in values (0 = no window)
     uint32_t col_mask = kColMask;   // profiling only: a narrower mask folds the x gather onto a small table
+    // column phases (cvr_options.col_phases > 1): a chunk feeds its rows' pieces phase by phase (column range by column
+    // range), every (row, phase) pair with a non-zero is one segment; the segments' sums are added into per-row
+    // accumulators in LDS and every row is written once at the end of the chunk
+    uint32_t  phases = 1;
+    uint32_t  phase_width = 0;      // columns per phase (multiple of 16)
+    uint2    *desc2 = nullptr;      // [nchunks] {first entry of the chunk in the conversion-time segment table, rows with a segment in the chunk}
+    uint32_t  col_bits = 31;        // column phases: the LAST column word of a segment carries the chunk's row of the segment
+                                    // above the column index: bits [col_bits, 31); bit 31 stays the end flag
 };
 
 struct DeviceCsr {
@@ -39,9 +47,23 @@ struct DeviceCsr {
     const uint32_t *pad_cnt = nullptr;    // [nchunks]
 };
 
+// column phases: the segment table of every chunk, built on the device from the CSR and the plan
+struct SegTable {
+    uint32_t *cnt = nullptr;        // [nchunks + 1] segments per chunk, then (exclusive scan) their offsets
+    int64_t  *begin = nullptr;      // [nseg_total] first CSR element of the segment, -1 = pad slots
+    uint32_t *len = nullptr;        // [nseg_total] slots of the segment
+    uint16_t *row = nullptr;        // [nseg_total] the chunk's row of the segment (rows-in-chunk = the pad segment's dump entry)
+    uint32_t *flags = nullptr;      // [2]: [0] bit 0 = a row's columns are not ascending; [1] = max segments of a chunk
+    uint32_t  total = 0;
+};
+// pass 1: counts (writes desc[k].y = segments of chunk k, st.cnt, st.flags); pass 2 after the scan: fills begin / len / row
+hipError_t launch_seg_count(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t st_);
+hipError_t launch_seg_scan(const DeviceImage &img, SegTable &st, hipStream_t st_);      // cnt -> offsets (in place), desc2[k].x
+hipError_t launch_seg_fill(const DeviceImage &img, const DeviceCsr &csr, const SegTable &st, hipStream_t st_);
+
 // CSR -> CVR64 (one wavefront per chunk).  *err_flag (device u32, zeroed by the caller) gets bit 0 if a
 // lane stream did not drain, bit 1 if stealing found no over-full lane, bit 2 if a value is missing from the dictionary.
-hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st);
+hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg = nullptr);
 
 // value-dictionary detection over vals[n0, n1) on the device: `table` = 1024 u64 slots preset to all ones, flags[0] bit 0 =
 // more than kDictMax distinct values, bit 1 = the all-ones pattern occurs, flags[1] = entries in the table

@@ -9,6 +9,7 @@
 #include "cvr_plan.h"
 
 #include <algorithm>
+#include <cstdint>
 
 namespace cvr {
 
@@ -21,7 +22,7 @@ int64_t plan_bound(int64_t nrows, int64_t nnz, int32_t S)
     return 2 * (slots / cap + 1) + 2;
 }
 
-Plan plan_chunks(int64_t nrows, const int64_t *rp, int32_t S, int64_t thr)
+Plan plan_chunks(int64_t nrows, const int64_t *rp, int32_t S, int64_t thr, int64_t max_rows)
 {
     Plan p;
     p.S = S;
@@ -29,6 +30,8 @@ Plan plan_chunks(int64_t nrows, const int64_t *rp, int32_t S, int64_t thr)
     if (thr <= 0) thr = cap / 4;
     if (thr > cap / 2) thr = cap / 2;      // keeps every chunk at least half full (plan_bound relies on it)
     p.thr = thr;
+    if (max_rows <= 0) max_rows = INT64_MAX;      // column phases: a chunk's rows are accumulated in LDS, so their number is capped
+    p.max_rows = max_rows == INT64_MAX ? 0 : max_rows;
     int64_t r = 0, off = 0;
     while (r < nrows) {
         Chunk c;
@@ -42,7 +45,7 @@ Plan plan_chunks(int64_t nrows, const int64_t *rp, int32_t S, int64_t thr)
             // taking them one by one: no prefix of the eight can fill the chunk exactly unless all eight do
             if (off == 0) {
                 bool full = false;
-                while (r + 8 <= nrows) {
+                while (r + 8 <= nrows && r + 8 - c.row_first <= max_rows) {
                     const int64_t *q = rp + r;
                     const int64_t  d0 = q[1] - q[0], d1 = q[2] - q[1], d2 = q[3] - q[2], d3 = q[4] - q[3];
                     const int64_t  d4 = q[5] - q[4], d5 = q[6] - q[5], d6 = q[7] - q[6], d7 = q[8] - q[7];
@@ -54,6 +57,7 @@ Plan plan_chunks(int64_t nrows, const int64_t *rp, int32_t S, int64_t thr)
                 }
                 if (full || r >= nrows) break;
             }
+            if (r - c.row_first >= max_rows) break;        // row cap reached: the rest of the chunk is padding
             const int64_t len = rp[r + 1] - rp[r] - off;   // what is left of row r (off > 0 implies len > 0)
             const int64_t slots = len > 0 ? len : 1;        // an empty row owns one pad slot
             if (used + slots <= cap) {

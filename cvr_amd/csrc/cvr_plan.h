@@ -20,12 +20,13 @@ struct Chunk {
 struct Plan {
     int32_t S = 0;
     int64_t thr = 0;
+    int64_t max_rows = 0;   // 0 = no cap
     int64_t nz_end = 0;
     std::vector<Chunk>  chunks;
     std::vector<Shared> shared;
 };
 
 int64_t plan_bound(int64_t nrows, int64_t nnz, int32_t S);
-Plan    plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_t split_threshold);
+Plan    plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_t split_threshold, int64_t max_rows = 0);
 
 }  // namespace cvr

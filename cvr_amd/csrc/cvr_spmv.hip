@@ -143,17 +143,25 @@ template <typename T> __device__ __forceinline__ void store_y(T *p, T v) { *p = 
 template <typename T> struct ChunkState {
     T        acc;       // running sum of the lane's current segment
     uint32_t cur;       // ordinal of that segment in the chunk
+    uint32_t currow;    // column phases: the chunk's row the segment belongs to
     uint32_t fed;       // segments handed out so far (wave-uniform)
     uint32_t feeding;   // 0: the lane is (or has become) a stealer
     uint32_t own;       // the lane parked a row sum in its LDS slot
     uint32_t tail;      // every segment handed out (wave-uniform): write-backs go through the slots
 };
 
-// four steps of all 64 lanes: FMA, then the write-back of the lanes whose segment ends at the step
-template <typename T, bool WIN, bool DICT>
+template <typename T> __device__ __forceinline__ void lds_add(T *p, T v)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);      // ds_add_f64 / ds_add_f32
+}
+
+// four steps of all 64 lanes: FMA, then the write-back of the lanes whose segment ends at the step.  SEGT (column phases):
+// the segment's sum is added to its row's accumulator in LDS (ystage[row of the chunk]); the rows of the segments come
+// in the segment's last column word, above the column index (bits [col_bits, 31)).
+template <typename T, bool WIN, bool DICT, bool SEGT>
 __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT> &Q, const X4<T> &xq, T *__restrict__ yext,
                                           T *slot_lane, uint32_t row_first, uint32_t nseg, uint32_t head_dest,
-                                          uint32_t last_dest, const T *dict, T *ystage, bool staged)
+                                          uint32_t last_dest, const T *dict, T *ystage, bool staged, uint32_t col_bits)
 {
 #pragma unroll
     for (int j = 0; j < kGroupSteps; j++) {
@@ -164,7 +172,9 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
         if (m) {
             if (!s.tail) {
                 if (fl) {
-                    if (staged) {
+                    if constexpr (SEGT) {
+                        lds_add(ystage + ((cw & kColMask) >> col_bits), s.acc);
+                    } else if (staged) {
                         ystage[s.cur] = s.acc;           // written out coalesced at the end of the chunk
                     } else {
                         const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
@@ -177,6 +187,7 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
                 s.fed = __builtin_amdgcn_readfirstlane(s.fed + (uint32_t)__popcll(m));
                 if (s.fed >= nseg) { s.fed = nseg; s.tail = 1; }
             } else if (fl && s.feeding) {
+                if constexpr (SEGT) s.currow = (cw & kColMask) >> col_bits;
                 *slot_lane = s.acc;
                 s.acc = 0;
                 s.feeding = 0;
@@ -188,17 +199,17 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
 
 // MW: more than one wavefront per workgroup (blockDim.x / 64 consecutive chunks share the workgroup's LDS window of x and its
 // dictionary copy); the single-wavefront form needs no barrier.
-template <typename T, int SPOL, int XPOL, int DEPTH, bool WIN, bool DICT, bool MW>
+template <typename T, int SPOL, int XPOL, int DEPTH, bool WIN, bool DICT, bool MW, bool SEGT>
 __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv_kernel(
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
     const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
     uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict,
-    uint32_t ystage_n)
+    uint32_t ystage_n, const uint2 *__restrict__ desc2, uint32_t col_bits)
 {
     constexpr int  GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     constexpr bool kSync = WIN || (DICT && MW);      // LDS filled by other waves of the workgroup
-    // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums, the value dictionary (DICT), then the x window and
-    // its zero slot (WIN)
+    // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums (SEGT: row accumulators), the value dictionary (DICT),
+    // the x window and its zero slot (WIN; wn + 4 values)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t nw = MW ? blockDim.x >> 6 : 1u;
     T *const slots = reinterpret_cast<T *>(smem);
@@ -235,21 +246,30 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
             const u32x4 q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (wbase + i) * (uint32_t)sizeof(T), 0, kPolDefault));
             *reinterpret_cast<u32x4 *>(win + i) = q;
         }
-        if (threadIdx.x == 0) win[wn] = T(0);
+        if (threadIdx.x < 4) win[wn + threadIdx.x] = T(0);
+    }
+    const uint4 d = live ? desc[k] : uint4{0, 0, 0, 0};
+    const uint32_t row_first = d.x, nseg = d.y, head_dest = d.z, last_dest = d.w;
+    T *const        ystage = ystage_all + wv * ystage_n;
+    uint32_t        nri = 0;                           // SEGT: rows with a segment in this chunk
+    if constexpr (SEGT) {
+        if (live) {
+            nri = desc2[k].y;
+            for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);                     // the row accumulators (+ the dump entry)
+        }
     }
     if constexpr (kSync) {
         __syncthreads();
         if (!live) return;
-    } else if constexpr (DICT) {
+    } else if constexpr (DICT || SEGT) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // one wavefront per workgroup: its own LDS writes, in order
     }
-    const uint4    d = desc[k];
     const uint32_t tg = target[(size_t)k * kLanes + lane];
-    const uint32_t row_first = d.x, nseg = d.y, head_dest = d.z, last_dest = d.w;
 
     ChunkState<T> s;
     s.acc = 0;
     s.cur = lane;
+    s.currow = 0;
     s.fed = nseg < kLanes ? nseg : kLanes;
     s.feeding = lane < s.fed;
     s.own = 0;
@@ -258,8 +278,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     // Row sums go to LDS and leave as coalesced stores at the end of the chunk (its rows are consecutive): the scattered
     // 8-byte stores they replace cost 12 % of the kernel (profiles/r01_y_staging.log).  A chunk of more than ystage_n
     // segments (very short rows) stores directly.
-    T *const   ystage = ystage_all + wv * ystage_n;
-    const bool staged = nseg <= ystage_n;
+    const bool staged = SEGT || nseg <= ystage_n;
 #pragma unroll
     for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL, WIN>(rx, win, Q[i].c, cmask, wbase, wn);
 
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     for (int g = 0; g < G; g++) {
         const Group<T, DICT> Qn = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)(g + DEPTH + 1) * GB);
         const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn);
-        sum_group<T, WIN, DICT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged);
+        sum_group<T, WIN, DICT, SEGT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged, col_bits);
 #pragma unroll
         for (int i = 0; i < DEPTH; i++) Q[i] = Q[i + 1];
         Q[DEPTH] = Qn;
@@ -282,7 +301,9 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     if (tg != lane) __hip_atomic_fetch_add(&slots[wv * kLanes + tg], s.acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (s.own) {
-        if (staged) {
+        if constexpr (SEGT) {
+            lds_add(ystage + s.currow, *slot_lane);
+        } else if (staged) {
             ystage[s.cur] = *slot_lane;
         } else {
             const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
@@ -291,8 +312,9 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     }
     if (staged) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        for (uint32_t i = lane; i < nseg; i += kLanes) {
-            const uint32_t dst = i == 0 ? head_dest : i == nseg - 1 ? last_dest : row_first + i;
+        const uint32_t nout = SEGT ? nri : nseg;      // SEGT: one entry per row of the chunk; else one per segment
+        for (uint32_t i = lane; i < nout; i += kLanes) {
+            const uint32_t dst = i == 0 ? head_dest : i == nout - 1 ? last_dest : row_first + i;
             store_y(yext + dst, ystage[i]);
         }
     }
@@ -402,7 +424,8 @@ size_t spmv_lds_bytes(const DeviceImage &img)
 {
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;
     const bool     use_win = img.win_elems > 0 && img.win_base != nullptr;
-    return (size_t)(wpb * (kLanes + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? img.win_elems + 1 : 0)) * (img.f32 ? 4 : 8);
+    return (size_t)(wpb * (kLanes + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8) +
+           0;
 }
 
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup)
@@ -420,12 +443,13 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     const size_t lds = spmv_lds_bytes(img);
     if (lds > kLdsBytes) return hipErrorInvalidValue;      // build_part sizes the stage and the window to fit; never reached
     // template parameters: <value type, stream cache policy, gather cache policy, gather run-ahead, LDS window, dictionary, multi-wave>
-#define CVR_LAUNCH(T, SP, D, W, DI, MW)                                                                           \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
+#define CVR_LAUNCH(T, SP, D, W, DI, MW, SG)                                                                       \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, SG>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
-                       static_cast<const T *>(img.dict), img.ndict, img.ystage)
-#define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_LAUNCH(T, SP, D, W, DI, true); else CVR_LAUNCH(T, SP, D, W, DI, false); } while (0)
+                       static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits)
+#define CVR_PICK_SG(T, SP, D, W, DI, MW) do { if (img.phases > 1) CVR_LAUNCH(T, SP, D, W, DI, MW, true); else CVR_LAUNCH(T, SP, D, W, DI, MW, false); } while (0)
+#define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_PICK_SG(T, SP, D, W, DI, true); else CVR_PICK_SG(T, SP, D, W, DI, false); } while (0)
 #define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_PICK_MW(T, SP, D, W, true); else CVR_PICK_MW(T, SP, D, W, false); } while (0)
 #define CVR_PICK_W(T, SP, D)     do { if (use_win) CVR_PICK_DI(T, SP, D, true); else CVR_PICK_DI(T, SP, D, false); } while (0)
 #define CVR_PICK_D(T, SP)        do { if (img.depth == 2) CVR_PICK_W(T, SP, 2); else CVR_PICK_W(T, SP, 1); } while (0)
@@ -436,6 +460,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #undef CVR_PICK_W
 #undef CVR_PICK_DI
 #undef CVR_PICK_MW
+#undef CVR_PICK_SG
 #undef CVR_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || img.nshared == 0 || !with_fixup) return e;

@@ -80,6 +80,12 @@ typedef struct {
                                   kernel): 1 = off, <0 = auto (only when x is several times the L2), else the count   */
     int32_t value_dict;        /* value dictionary: one byte per slot instead of the value when the matrix has at most
                                   256 distinct values (pattern matrices); <0 = auto (default), 0 = off                */
+    int32_t col_phases;        /* column phases: every chunk feeds its rows' non-zeros column range by column range (P equal
+                                  ranges), so that chunks running at the same time gather from the same slice of x and that
+                                  slice stays in the L2s; the sums of a row's pieces are added up in LDS, every row is still
+                                  written once.  For matrices whose chunks are all resident at once and whose x is larger
+                                  than an L2 (web-Google: 7.3 MB); needs ascending columns inside every row.  0 / 1 = off  */
+    int32_t reserved1;
 } cvr_options;
 
 typedef struct {
@@ -101,6 +107,12 @@ typedef struct {
     double  plan_s, upload_s, convert_s;  /* host planner, H2D of CSR, device conversion kernel      */
     int32_t col_panels;        /* 1, or the number of column panels the matrix was cut into                          */
     int32_t value_dict;        /* 0, or the number of dictionary entries (distinct values + the pad slots' 0)         */
+    int32_t col_phases;        /* 1, or the number of column phases                                                    */
+    int32_t waves_per_block;   /* wavefronts (chunks) per SpMV workgroup                                                */
+    int32_t x_window;          /* values of x every workgroup stages in LDS (0 = none)                                  */
+    int32_t lds_bytes;         /* dynamic LDS of one SpMV workgroup                                                     */
+    int64_t nsegments;         /* column phases: (row, phase) segments over all chunks (0 otherwise)                    */
+    int64_t chunk_row_cap;     /* column phases: most rows the planner gives a chunk (their sums live in LDS); 0 = none */
 } cvr_info;
 
 void        cvr_default_options(cvr_options *opt);
@@ -196,7 +208,8 @@ int cvr_device_copy_bench(int device, int64_t bytes, int iters, double *gbs);
 /* Copies the device-resident CVR64 image back for inspection (tests compare it bit for bit with the
  * CPU mirror).  Any pointer may be NULL.  Sizes: cols_vals = image_bytes of the stream part
  * (nchunks * S/4 * group_bytes), desc = 4 u32 per chunk, target = 64 u8 per chunk,
- * shared = 3 i64 per shared row {row, first chunk, last chunk}. */
+ * shared = 3 i64 per shared row {row, first chunk, last chunk}.  With column phases desc[k][1] counts the (row, phase)
+ * segments of the chunk and the last column word of a segment carries the chunk's row of the segment above the column index. */
 int cvr_export_image(cvr_handle *h, void *stream_image, uint32_t *desc, uint8_t *target, int64_t *shared);
 /* host planner only (no device needed): chunk boundaries for a row_ptr; returns nchunks or <0.
  * out arrays (each may be NULL) need room for cvr_plan_bound(nrows, nnz, S) chunks. */

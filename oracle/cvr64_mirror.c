@@ -33,9 +33,10 @@
 typedef struct { int64_t nzb, row_first, nrows_in, nseg, pad; int head, tail; } chunk_t;
 
 /* planner: a sequential walk over the rows (the product's is cvr_amd/csrc/cvr_plan.cpp) */
-static int64_t plan(int64_t nrows, const int64_t *rp, int64_t cap, int64_t thr, chunk_t **out,
+static int64_t plan(int64_t nrows, const int64_t *rp, int64_t cap, int64_t thr, int64_t max_rows, chunk_t **out,
                     int64_t **sh_out, int64_t *nsh_out)
 {
+    if (max_rows <= 0) max_rows = INT64_MAX;
     int64_t capn = 16, n = 0, shcap = 16, nsh = 0;
     chunk_t *ch = (chunk_t *)malloc(sizeof(chunk_t) * (size_t)capn);
     int64_t *sh = (int64_t *)malloc(sizeof(int64_t) * 3 * (size_t)shcap);
@@ -46,6 +47,7 @@ static int64_t plan(int64_t nrows, const int64_t *rp, int64_t cap, int64_t thr, 
         c.row_first = r; c.nzb = rp[r] + off; c.head = off > 0;
         int64_t used = 0;
         while (r < nrows) {
+            if (r - c.row_first >= max_rows) break;        /* row cap (column phases): the rest is padding */
             const int64_t len = rp[r + 1] - rp[r] - off;
             const int64_t slots = len > 0 ? len : 1;
             if (used + slots <= cap) { used += slots; r++; off = 0; if (used == cap) break; continue; }
@@ -98,14 +100,33 @@ int orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rp, const int32
 int orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols,
                          const void *vals, int is_f32, int S, int64_t thr, int use_dict, orc_cvr64 *c)
 {
+    return orc_cvr64_build_ex(nrows, ncols, rp, cols, vals, is_f32, S, thr, use_dict, 1, 0, c);
+}
+
+/* phases > 1: "column phases".  The columns are cut into `phases` ranges of equal width (a multiple of 16); a chunk feeds
+ * its rows' pieces phase by phase -- every (row, phase) pair with a non-zero is one segment, in (phase, row) order -- and
+ * seg_row tells which of the chunk's rows a segment belongs to.  Needs the columns of every row in ascending order.
+ * max_rows caps the rows of a chunk (their sums are accumulated in LDS on the device). */
+int orc_cvr64_build_ex(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
+                       int S, int64_t thr, int use_dict, int phases, int64_t max_rows, orc_cvr64 *c)
+{
     memset(c, 0, sizeof(*c));
+    if (phases < 1) phases = 1;
+    c->phases = phases;
+    int64_t pw = (ncols + phases - 1) / phases;
+    pw = (pw + 15) / 16 * 16;
+    if (pw < 16) pw = 16;
+    int col_bits = 1;                      /* phases: the last column word of a segment carries the chunk's row above the column index */
+    while (((int64_t)1 << col_bits) <= ncols) col_bits++;
+    c->col_bits = phases > 1 ? col_bits : 31;
+    if (phases > 1 && (col_bits >= 31 || max_rows > (((int64_t)1 << (31 - col_bits)) - 1) || max_rows <= 0)) return -7;
     if (S < 4 || S % 4) return -1;
     const int64_t cap = (int64_t)W * S;
     if (thr <= 0) thr = cap / 4;
     if (thr > cap / 2) thr = cap / 2;
     c->nrows = nrows; c->ncols = ncols; c->nnz = nrows ? rp[nrows] - rp[0] : 0; c->S = S; c->is_f32 = is_f32;
     chunk_t *ch;
-    c->nchunks = plan(nrows, rp, cap, thr, &ch, &c->shared, &c->nshared);
+    c->nchunks = plan(nrows, rp, cap, thr, phases > 1 ? max_rows : 0, &ch, &c->shared, &c->nshared);
     const int64_t NC = c->nchunks;
     const int G = S / 4;
     if (use_dict) {
@@ -119,7 +140,12 @@ int orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rp, const 
     c->target = (uint8_t *)calloc((size_t)NC * W + 1, 1);
     c->nz_begin = (int64_t *)calloc((size_t)NC + 1, sizeof(int64_t));
     c->pad_cnt = (int64_t *)calloc((size_t)NC + 1, sizeof(int64_t));
-    int64_t *seg_pos = NULL, *seg_cnt = NULL, segcap = 0;
+    int64_t *seg_pos = NULL, *seg_cnt = NULL, *seg_r = NULL, segcap = 0;
+    int64_t nsegtot = 0, srcap = 0;
+    if (phases > 1) {
+        c->seg_off = (uint32_t *)calloc((size_t)NC + 1, sizeof(uint32_t));
+        c->nrows_in = (uint32_t *)calloc((size_t)NC + 1, sizeof(uint32_t));
+    }
     int rc = 0;
     for (int64_t k = 0; k < NC && !rc; k++) {
         const chunk_t *q = &ch[k];
@@ -127,8 +153,8 @@ int orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rp, const 
         c->nz_begin[k] = b; c->pad_cnt[k] = q->pad;
         c->desc[4 * k + 0] = (uint32_t)q->row_first;
         c->desc[4 * k + 1] = (uint32_t)q->nseg;
-        for (int w = 0; w < 2; w++) {      /* destination of the first and of the last segment */
-            const int64_t s = w ? q->nseg - 1 : 0;
+        for (int w = 0; w < 2; w++) {      /* destination of the first and of the last segment (phases: of the first and last ROW) */
+            const int64_t s = w ? (phases > 1 ? q->nrows_in : q->nseg) - 1 : 0;
             uint32_t d;
             if (s >= q->nrows_in) d = (uint32_t)nrows;                                        /* pad -> dump  */
             else if (s == 0 && q->head) d = (uint32_t)(nrows + 1 + 2 * k);                    /* carry_head   */
@@ -136,33 +162,61 @@ int orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rp, const 
             else d = (uint32_t)(q->row_first + s);
             c->desc[4 * k + 2 + w] = d;
         }
-        if (q->nseg > segcap) {
-            segcap = q->nseg * 2;
+        const int64_t need = phases > 1 ? cap + 1 : q->nseg;       /* a segment holds at least one slot */
+        if (need > segcap) {
+            segcap = need * 2;
             seg_pos = (int64_t *)realloc(seg_pos, sizeof(int64_t) * (size_t)segcap);
             seg_cnt = (int64_t *)realloc(seg_cnt, sizeof(int64_t) * (size_t)segcap);
+            seg_r = (int64_t *)realloc(seg_r, sizeof(int64_t) * (size_t)segcap);
         }
-        /* the chunk's segment list: (first CSR element or -1 for pad slots, slot count) */
+        /* the chunk's segment list: (first CSR element or -1 for pad slots, slot count[, row of the chunk]) */
         int64_t n = 0, tot = 0;
-        for (int64_t r = q->row_first; r < q->row_first + q->nrows_in; r++) {
-            int64_t a = rp[r] > b ? rp[r] : b, z = rp[r + 1] < e ? rp[r + 1] : e;
-            if (z > a) { seg_pos[n] = a; seg_cnt[n] = z - a; } else { seg_pos[n] = -1; seg_cnt[n] = 1; }
-            tot += seg_cnt[n]; n++;
+        if (phases == 1) {
+            for (int64_t r = q->row_first; r < q->row_first + q->nrows_in; r++) {
+                int64_t a = rp[r] > b ? rp[r] : b, z = rp[r + 1] < e ? rp[r + 1] : e;
+                if (z > a) { seg_pos[n] = a; seg_cnt[n] = z - a; } else { seg_pos[n] = -1; seg_cnt[n] = 1; }
+                tot += seg_cnt[n]; n++;
+            }
+        } else {
+            for (int p = 0; p < phases; p++)
+                for (int64_t r = q->row_first; r < q->row_first + q->nrows_in; r++) {
+                    int64_t a = rp[r] > b ? rp[r] : b, z = rp[r + 1] < e ? rp[r + 1] : e;
+                    if (z <= a) {                      /* empty row: its pad slot goes with phase 0 */
+                        if (p == 0) { seg_pos[n] = -1; seg_cnt[n] = 1; seg_r[n] = r - q->row_first; tot++; n++; }
+                        continue;
+                    }
+                    int64_t lo = a, hi;
+                    while (lo < z && cols[lo] < (int64_t)p * pw) lo++;
+                    hi = lo;
+                    while (hi < z && cols[hi] < (int64_t)(p + 1) * pw) hi++;
+                    for (int64_t j = a + 1; j < z; j++) if (cols[j] < cols[j - 1]) rc = -6;      /* unsorted row */
+                    if (hi > lo) { seg_pos[n] = lo; seg_cnt[n] = hi - lo; seg_r[n] = r - q->row_first; tot += hi - lo; n++; }
+                }
         }
-        if (q->pad > 0) { seg_pos[n] = -1; seg_cnt[n] = q->pad; tot += q->pad; n++; }
-        if (n != q->nseg || tot != cap) { fprintf(stderr, "cvr64 mirror: chunk %lld holds %lld slots\n", (long long)k, (long long)tot); rc = -2; break; }
+        if (q->pad > 0) { seg_pos[n] = -1; seg_cnt[n] = q->pad; seg_r[n] = q->nrows_in; tot += q->pad; n++; }
+        if ((phases == 1 && n != q->nseg) || tot != cap) { fprintf(stderr, "cvr64 mirror: chunk %lld holds %lld slots\n", (long long)k, (long long)tot); rc = -2; break; }
+        if (phases > 1) {
+            c->desc[4 * k + 1] = (uint32_t)n;
+            c->seg_off[k] = (uint32_t)nsegtot; c->seg_off[k + 1] = (uint32_t)(nsegtot + n);
+            c->nrows_in[k] = (uint32_t)q->nrows_in;
+            if (nsegtot + n > srcap) { srcap = (nsegtot + n) * 2; c->seg_row = (uint16_t *)realloc(c->seg_row, sizeof(uint16_t) * (size_t)srcap); }
+            for (int64_t i = 0; i < n; i++) c->seg_row[nsegtot + i] = (uint16_t)seg_r[i];
+            nsegtot += n;
+        }
 
         int64_t pos[W], cnt[W], fed = 0;
-        for (int l = 0; l < W; l++) { pos[l] = -1; cnt[l] = 0; c->target[k * W + l] = (uint8_t)l; }
+        uint32_t tag[W];
+        for (int l = 0; l < W; l++) { pos[l] = -1; cnt[l] = 0; tag[l] = 0; c->target[k * W + l] = (uint8_t)l; }
         for (int i = 0; i < S && !rc; i++) {
             const int64_t ave = S - i;      /* == sum(cnt)/64 */
             for (int l = 0; l < W; l++) {   /* empty lanes in lane order (spmv.cpp:814-816) */
                 if (cnt[l] != 0) continue;
-                if (fed < n) { pos[l] = seg_pos[fed]; cnt[l] = seg_cnt[fed]; fed++; }     /* spmv.cpp:821-868 */
+                if (fed < n) { pos[l] = seg_pos[fed]; cnt[l] = seg_cnt[fed]; tag[l] = phases > 1 ? (uint32_t)seg_r[fed] << col_bits : 0; fed++; }     /* spmv.cpp:821-868 */
                 else {
                     int v = 0;
                     while (v < W && cnt[v] <= ave) v++;      /* first over-full lane (spmv.cpp:876-879) */
                     if (v == W) { fprintf(stderr, "cvr64 mirror: no victim\n"); rc = -3; break; }
-                    pos[l] = pos[v]; cnt[l] = ave;           /* the stealer takes the FIRST ave (spmv.cpp:927-931) */
+                    pos[l] = pos[v]; cnt[l] = ave; tag[l] = 0;   /* the stealer takes the FIRST ave (spmv.cpp:927-931) */
                     if (pos[v] >= 0) pos[v] += ave;
                     cnt[v] -= ave;
                     c->target[k * W + l] = (uint8_t)v;
@@ -177,7 +231,7 @@ int orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rp, const 
                     v = is_f32 ? (double)((const float *)vals)[pos[l]] : ((const double *)vals)[pos[l]];
                     pos[l]++;
                 }
-                if (cnt[l] == 1) col |= 0x80000000u;
+                if (cnt[l] == 1) col |= 0x80000000u | tag[l];
                 ((uint32_t *)grp)[l * 4 + j] = col;
                 if (c->ndict) {                               /* one code byte per slot: position in the sorted dictionary */
                     uint64_t b;
@@ -195,13 +249,14 @@ int orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rp, const 
             if (cnt[l] != 0) { fprintf(stderr, "cvr64 mirror: lane not drained\n"); rc = -4; }
     }
     if (NC) c->nz_begin[NC] = nrows ? rp[nrows] : 0;
-    free(seg_pos); free(seg_cnt); free(ch);
+    free(seg_pos); free(seg_cnt); free(seg_r); free(ch);
     return rc;
 }
 
 void orc_cvr64_free(orc_cvr64 *c)
 {
     free(c->image); free(c->desc); free(c->target); free(c->shared); free(c->nz_begin); free(c->pad_cnt);
+    free(c->seg_off); free(c->seg_row); free(c->nrows_in);
     memset(c, 0, sizeof(*c));
 }
 
@@ -217,15 +272,22 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
     const int64_t NC = c->nchunks, nrows = c->nrows;
     const size_t gb = c->ndict ? 1280 : c->is_f32 ? 2048 : 3072;
     const size_t next = (size_t)(nrows + 1 + 2 * NC);
+    const int ph = c->phases > 1;          /* column phases: a segment's sum is ADDED to its row's accumulator (LDS on the device) */
     double *yext = (double *)calloc(next + 1, sizeof(double));
+    double *yloc = (double *)calloc((size_t)W * S + 2, sizeof(double));
     for (int64_t k = 0; k < NC; k++) {
         const uint32_t row_first = c->desc[4 * k], n = c->desc[4 * k + 1], hd = c->desc[4 * k + 2], ld = c->desc[4 * k + 3];
-#define DEST(q) ((q) == 0 ? hd : (q) == n - 1 ? ld : row_first + (q))
+        const uint32_t nri = ph ? c->nrows_in[k] : 0;
+        const uint32_t cmask = ph ? (1u << c->col_bits) - 1u : 0x7fffffffu;
+        const uint32_t nd = ph ? nri : n;      /* DEST is indexed by the segment (implicit rows) or by the chunk's row (phases) */
+#define DEST(q) ((q) == 0 ? hd : (q) == nd - 1 ? ld : row_first + (q))
+#define ADDTO(dst, v) do { if (c->is_f32) (dst) = (double)((float)(dst) + (float)(v)); else (dst) += (v); } while (0)
         double acc[W], slot[W];
-        uint32_t cur[W];
+        uint32_t cur[W], rowtag[W], ownrow[W];
         int feeding[W], own[W];
         uint32_t fed = n < W ? n : W;
         for (int l = 0; l < W; l++) { acc[l] = 0; slot[l] = 0; feeding[l] = (uint32_t)l < fed; own[l] = 0; cur[l] = (uint32_t)l; }
+        if (ph) for (uint32_t i = 0; i <= nri; i++) yloc[i] = 0;
         int tail = fed == n;
         for (int i = 0; i < S; i++) {
             const uint8_t *grp = c->image + ((size_t)k * G + i / 4) * gb;
@@ -233,8 +295,9 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
             int flagged[W];
             for (int l = 0; l < W; l++) {
                 const uint32_t cw = ((const uint32_t *)grp)[l * 4 + j];
-                const uint32_t col = cw & 0x7fffffffu;
+                const uint32_t col = cw & cmask;
                 flagged[l] = cw >> 31;
+                rowtag[l] = ph ? (cw & 0x7fffffffu) >> c->col_bits : 0;
                 if (c->is_f32) {
                     float v;
                     if (c->ndict) { const uint32_t u = (uint32_t)c->dict[(grp + 1024)[l * 4 + j]]; memcpy(&v, &u, 4); }
@@ -251,7 +314,8 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
                 uint32_t rank = 0;
                 for (int l = 0; l < W; l++) {
                     if (!flagged[l]) continue;
-                    yext[DEST(cur[l])] = acc[l]; acc[l] = 0;
+                    if (ph) ADDTO(yloc[rowtag[l]], acc[l]); else yext[DEST(cur[l])] = acc[l];
+                    acc[l] = 0;
                     if (fed + rank < n) cur[l] = fed + rank; else feeding[l] = 0;
                     rank++;
                 }
@@ -259,17 +323,21 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
                 if (fed >= n) { fed = n; tail = 1; }
             } else {
                 for (int l = 0; l < W; l++)
-                    if (flagged[l] && feeding[l]) { slot[l] = acc[l]; acc[l] = 0; feeding[l] = 0; own[l] = 1; }
+                    if (flagged[l] && feeding[l]) { slot[l] = acc[l]; acc[l] = 0; feeding[l] = 0; own[l] = 1; ownrow[l] = rowtag[l]; }
             }
         }
         for (int l = 0; l < W; l++) {
             const int t = c->target[k * W + l];
             if (t == l) continue;
-            if (c->is_f32) slot[t] = (double)((float)slot[t] + (float)acc[l]); else slot[t] += acc[l];
+            ADDTO(slot[t], acc[l]);
         }
-        for (int l = 0; l < W; l++) if (own[l]) yext[DEST(cur[l])] = slot[l];
+        for (int l = 0; l < W; l++)
+            if (own[l]) { if (ph) ADDTO(yloc[ownrow[l]], slot[l]); else yext[DEST(cur[l])] = slot[l]; }
+        if (ph) for (uint32_t i = 0; i < nri; i++) yext[DEST(i)] = yloc[i];
 #undef DEST
+#undef ADDTO
     }
+    free(yloc);
     for (int64_t s = 0; s < c->nshared; s++) {
         const int64_t row = c->shared[3 * s], c0 = c->shared[3 * s + 1], c1 = c->shared[3 * s + 2];
         double v = 0;

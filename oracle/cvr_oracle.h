@@ -89,6 +89,12 @@ typedef struct {
     int       ndict;         /* 0, or entries of the value dictionary: the group then holds       */
                              /* [64][4] u8 codes (256 B) after the column words instead of values */
     uint64_t  dict[256];     /* distinct value bit patterns + 0, sorted                           */
+    int       phases;        /* 1, or the number of column phases (orc_cvr64_build_ex): desc[k].nseg then counts the   */
+                             /* (row, phase) segments + the pad segment, head/last_dest belong to the first / last ROW */
+    uint32_t *seg_off;       /* phases > 1: [nchunks+1] first entry of chunk k in seg_row                               */
+    uint16_t *seg_row;       /* phases > 1: the chunk's row (0 .. nrows_in-1; nrows_in = dump) of every segment        */
+    uint32_t *nrows_in;      /* phases > 1: [nchunks] rows with a segment in the chunk                                  */
+    int       col_bits;      /* phases > 1: the last column word of a segment holds its seg_row in bits [col_bits, 31)   */
 } orc_cvr64;
 
 int  orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
@@ -96,6 +102,9 @@ int  orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rowptr, const 
 /* the same with a value dictionary (use_dict != 0): -5 when the matrix has more than 256 distinct values */
 int  orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
                           const void *vals, int is_f32, int S, int64_t split_threshold, int use_dict, orc_cvr64 *out);
+/* the same with column phases (phases > 1; rows must have ascending columns: -6 otherwise) and a cap on the rows of a chunk */
+int  orc_cvr64_build_ex(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
+                        int S, int64_t split_threshold, int use_dict, int phases, int64_t max_rows, orc_cvr64 *out);
 void orc_cvr64_free(orc_cvr64 *c);
 /* interpret the image exactly as the HIP kernel does (same per-lane order of operations) */
 void orc_cvr64_spmv(const orc_cvr64 *c, const void *x, void *y);

@@ -21,7 +21,7 @@ def _check(nrows, ncols, rp, ci, va, S, thr=0):
         x = O.x_vec_fast(ncols, mode).astype(va.dtype)
         yref, absy = O.csr_spmv64(rp, ci, va, x)
         y = m.spmv(x)
-        bad, worst = O.tol_check(y, yref, absy, tol=2e-5 if f32 else 1e-12)
+        bad, worst = O.tol_check(y, yref, absy, tol=1e-5 if f32 else 1e-12)
         if f32:
             bad = bad[np.abs(np.asarray(y, dtype=np.float64) - yref)[bad] > 1e-6 * np.maximum(1.0, absy[bad])]
         assert len(bad) == 0, (mode, S, worst, bad[:5])

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--panels", default="-1", help="column panels (-1 auto, 1 off)")
     ap.add_argument("--wpb", default="0", help="wavefronts (consecutive chunks) per SpMV workgroup (0 = default 1)")
     ap.add_argument("--dict", default="-1", help="value dictionary (-1 auto, 0 off)")
+    ap.add_argument("--phases", default="0", help="column phases (0 / 1 off)")
     ap.add_argument("--check", action="store_true", help="compare y of every configuration with the host CSR loop")
     ap.add_argument("--colmask", default="0", help="comma list of hex masks: folds the x gather onto a small table (timing only)")
     ap.add_argument("--iters", type=int, default=300)
@@ -45,6 +46,9 @@ def main():
         raise SystemExit("unknown matrix")
     if a.fold:
         ci = (ci & ((1 << a.fold) - 1)).astype(np.int32)
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        o = np.lexsort((ci, rows))                     # keep the columns of every row ascending (column phases need it)
+        ci, va = ci[o], va[o]
     nnz = len(ci)
     vb = va.dtype.itemsize
     balg = synth.b_alg(n, nc, nnz, vb)
@@ -54,13 +58,13 @@ def main():
     for S in [int(s) for s in a.S.split(",")]:
         for thr in [int(s) for s in a.thr.split(",")]:
             for swz in [int(s) for s in a.swz.split(",")]:
-                for (nt, cm, wpb, dp, win, pan, vd) in [(int(s), int(m, 16), int(wp), int(dp), int(w), int(pn), int(vd)) for s in a.nt.split(",")
+                for (nt, cm, wpb, dp, win, pan, vd, php) in [(int(s), int(m, 16), int(wp), int(dp), int(w), int(pn), int(vd), int(php)) for s in a.nt.split(",")
                                                    for m in a.colmask.split(",") for wp in a.wpb.split(",")
                                                    for dp in a.depth.split(",") for w in a.win.split(",") for pn in a.panels.split(",")
-                                                   for vd in a.dict.split(",")]:
+                                                   for vd in a.dict.split(",") for php in a.phases.split(",")]:
                     try:
                         A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, nontemporal=nt,
-                                              debug_col_mask=cm, depth=dp, x_window=win, col_panels=pan, waves_per_block=wpb, value_dict=vd)
+                                              debug_col_mask=cm, depth=dp, x_window=win, col_panels=pan, waves_per_block=wpb, value_dict=vd, col_phases=php)
                     except Exception as e:
                         print(f"  {S:4d} wpb {wpb} win {win}: {e}", flush=True)
                         continue
@@ -77,7 +81,7 @@ def main():
                     s = A.bench(a.warmup, a.iters)
                     i = A.info
                     print(f"  {S:4d}  {swz}  {nt:2d}  {thr:6d}  {i.nchunks:6d} {i.nshared:5d}  {i.nslots / max(nnz, 1):8.4f}  {i.convert_s * 1e6:9.1f}  "
-                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  depth {dp} wpb {wpb} win {win} panels {i.col_panels} dict {i.value_dict}{wrong}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
+                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  depth {dp} wpb {wpb} win {i.x_window} panels {i.col_panels} dict {i.value_dict} phases {i.col_phases} lds {i.lds_bytes}{wrong}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
                     A.close()
 
 
