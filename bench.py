@@ -1,26 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- the headline measurement: CVR-format SpMV on MI355X (BASELINE.json).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-              --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload webgoogle|livejournal|banded<rows>|rmat<scale>]
 
-A "step" is one y = A x over the web-Google-shaped matrix (916 428 x 916 428, 5 105 039 nnz, fp64; seeded
-synthetic stand-in, or the real web-Google.mtx when CVR_DATA_DIR holds it), matrix image, x and y resident
-in HBM.  N > 1: rows are sharded over the ranks (balanced nnz, cut at row boundaries; S of a shard chosen by measurement,
-cvr_tune_steps), x is replicated, every step ends with the all-gather of the y slices over RCCL ("strong" scaling: the
-matrix is fixed).  The loop of steps runs inside the library (cvr_spmv_gather_repeat: SpMV and ncclAllGather enqueued
-back to back, no Python between steps) once every rank has built its communicator and its first gather has been checked
-bit for bit against torch.distributed's; in order or overlapped (gather of step k under the SpMV of step k+1), whichever
-200 untimed steps show to be faster on this node.  Otherwise the same loop runs over torch.distributed.
-Rank 0 prints ONE JSON line.  The roofline object prices the SpMV kernel alone (algorithmic bytes of SURVEY.md
-8(d) / mean kernel time from HIP events on the launch stream); cpu_baseline is the unmodified reference built by
-oracle/Makefile into oracle/_ref/ (kind "reference"; the oracle's 8-lane OpenMP restatement, kind "port", when that
-binary is absent) on the host cores (rank 0, N = 1 only).
+With N > 1 and no torch.distributed environment the command starts itself once per GPU (python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ..., before anything touches the GPU) and relays rank 0's line; under
+torch.distributed.run it is one rank.
+
+A "step" is one y = A x over the web-Google-shaped matrix (916 428 x 916 428, 5 105 039 nnz, fp64; seeded synthetic stand-in,
+or the real web-Google.mtx when CVR_DATA_DIR holds it), matrix image, x and y resident in HBM.  N > 1: rows are sharded over
+the ranks (balanced nnz, cut at row boundaries; the layout of a shard chosen by measurement, cvr_tune), x is replicated, every
+step ends with the all-gather of the y slices over RCCL ("strong" scaling: the matrix is fixed).  The loop of steps runs inside
+the library (cvr_spmv_gather_repeat: SpMV and ncclAllGather enqueued back to back, no Python between steps) once every rank has
+built its communicator and its first gather has been checked bit for bit against torch.distributed's; in order or overlapped
+(gather of step k under the SpMV of step k+1), whichever 200 untimed steps show to be faster on this node.  Otherwise the same
+loop runs over torch.distributed.  The large workloads (banded<rows>, rmat<scale>: BASELINE.json configs[3], [4]) are built
+shard by shard on the GPU (cvr_amd/synth_dev.py) and handed to the library as device-resident CSR.
+Rank 0 prints ONE JSON line.  The roofline object prices the SpMV kernel alone (algorithmic bytes of SURVEY.md 8(d) / mean
+kernel time from HIP events on the launch stream); cpu_baseline is the unmodified reference built by oracle/Makefile into
+oracle/_ref/ (kind "reference"; the oracle's 8-lane OpenMP restatement, kind "port", when that binary is absent) on the host
+cores (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,29 +37,51 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def pmc_traffic():
-    """HBM bytes per SpMV launch from the rocprofv3 PMC passes of this same command (tools/profile_bench.sh:
-    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950); bench.py cannot run the profiler on itself, so it reports the committed summary, or null."""
+def pmc_traffic(info, kernel):
+    """HBM bytes per SpMV launch from the rocprofv3 PMC passes of this same command (tools/profile_bench.sh: FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the
+    profiler on itself, so it reports the committed summary -- but only if that summary was taken on the very configuration
+    timed here (kernel, chunk length, chunk count, image bytes, workgroup layout); otherwise null."""
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
-        return float(json.load(open(p))["hbm_bytes_per_launch_corrected"])
+        d = json.load(open(p))
+        c = d["config"]
+        same = (c["kernel"] == kernel and c["steps_per_chunk"] == info.steps_per_chunk and c["nchunks"] == info.nchunks and
+                c["image_bytes"] == info.image_bytes and c["waves_per_block"] == info.waves_per_block and
+                c["col_phases"] == info.col_phases and c["x_window"] == info.x_window)
+        return float(d["hbm_bytes_per_launch_corrected"]) if same else None
     except Exception:
         return None
 
 
-def load_workload(kind="webgoogle"):
+def host_cpu():
+    """(model string, logical cores usable by this process, physical cores)"""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except Exception:
+        pass
+    logical = len(os.sched_getaffinity(0))
+    return model, logical, (min(len(phys), logical) if phys else logical)
+
+
+def load_host_workload(kind):
     from cvr_amd import capi, synth
     import cvr_amd
     if kind == "livejournal":      # BASELINE.json configs[2]
         n, nc, rp, ci, va = synth.livejournal_like()
         return n, nc, rp, ci, va, "synthetic soc-LiveJournal1-shaped, seed 20261003"
-    if kind.startswith("rmat"):    # configs[4]: R-MAT (Graph500 parameters), fp32, rmat<scale> (default 22)
-        n, nc, rp, ci, va = synth.rmat(int(kind[4:] or 22), dtype=np.float32)
-        return n, nc, rp, ci, va, f"synthetic R-MAT scale {int(kind[4:] or 22)}, edge factor 16, fp32"
-    if kind.startswith("banded"):  # configs[3]: nlpkkt240's shape; banded<rows>, default 28e6 rows / 8
-        n, nc, rp, ci, va = synth.banded_sym(int(float(kind[6:] or 3.5e6)))
-        return n, nc, rp, ci, va, "synthetic banded symmetric (27 nnz/row, nlpkkt240's shape)"
     f = synth.data_file("web-Google.mtx")
     if f:
         m = cvr_amd.load_mm(f, capi.MM_STRICT)
@@ -64,51 +91,64 @@ def load_workload(kind="webgoogle"):
     return n, nc, rp, ci, va, "synthetic web-Google-shaped, seed 20261002"
 
 
-def _cpu_reference(nrows, ncols, rp, ci, cores):
-    """the UNMODIFIED reference (spmv.cpp compiled by oracle/Makefile into oracle/_ref/, prebuilt in the build
-    container) on a Matrix-Market file of the bench matrix: kind = "reference".  None if it cannot run here."""
+def _run_reference(exe, path, T, iters, nnz, nrows, ncols):
     import re
-    import subprocess
-    import tempfile
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oraclelib as O
-    exe = os.path.join(ROOT, "oracle", "_ref", "spmv.cvr.ref")
-    if not os.path.exists(exe):
+    from cvr_amd import synth
+    env = dict(os.environ, OMP_NUM_THREADS=str(T), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    try:
+        r = subprocess.run([exe, path, str(T), str(iters)], capture_output=True, text=True, timeout=240, env=env)
+    except Exception:
         return None
-    T = min(cores, 68)                      # run_sample.sh:10 runs web-Google with 68 threads
-    iters = 300
-    with tempfile.TemporaryDirectory(dir="/tmp") as d:
-        path = os.path.join(d, "bench.mtx")
-        O.write_mtx_pattern(path, nrows, ncols, rp, ci)
-        env = dict(os.environ, OMP_NUM_THREADS=str(T), OMP_PROC_BIND="close", OMP_PLACES="cores")
-        try:
-            r = subprocess.run([exe, path, str(T), str(iters)], capture_output=True, text=True, timeout=240, env=env)
-        except Exception:
-            return None
     out = r.stdout
     m = re.search(r"SpMV Execution Time of CVR\s+is ([0-9.eE+-]+) seconds", out)
     p = re.search(r"Pre-processing\(CSR->CVR\)\s+Time of CVR\s+is ([0-9.eE+-]+) seconds", out)
     if r.returncode != 0 or not m or "Very Good" not in out:
         return None
     per = float(m.group(1))
-    from cvr_amd import synth
-    return {"value": 2.0 * len(ci) / per / 1e9, "unit": "GFLOP/s", "cores": T, "kind": "reference",
-            "sample": f"unmodified reference source built by oracle/Makefile (g++ -O3 -mavx512f -fopenmp, 4 intrinsic-spelling aliases in oracle/ref_shim.h), {iters} timed SpMV iterations of the full matrix, "
-                      f"{T} OpenMP threads, y zeroing outside the timer as the reference does (spmv.cpp:1026-1033)",
-            "ms_per_step": per * 1e3, "preprocess_s": float(p.group(1)) if p else None,
-            "gbs_alg": synth.b_alg(nrows, ncols, len(ci)) / per / 1e9}
+    return {"threads": T, "ms_per_step": per * 1e3, "gflops": 2.0 * nnz / per / 1e9, "reference_convention_gflops": nnz / per / 1e9,
+            "gbs_alg": synth.b_alg(nrows, ncols, nnz) / per / 1e9, "preprocess_s": float(p.group(1)) if p else None}
 
 
-def _cpu_port(nrows, ncols, rp, ci, va, cores, budget_s=10.0):
-    """the oracle's scalar-C restatement of the reference CPU path (8 lanes, one chunk per OpenMP thread;
-    spmv.cpp:565-1014, 1016-1667) on the reference loader's 1-based arrays: kind = "port" """
+def _cpu_reference(nrows, ncols, rp, ci, logical, physical):
+    """the UNMODIFIED reference (spmv.cpp compiled by oracle/Makefile into oracle/_ref/, prebuilt in the build container) on a
+    Matrix-Market file of the bench matrix: kind = "reference".  None if it cannot run here.  Timed with 68 threads
+    (run_sample.sh:10) or all logical cores if fewer, and with one thread per physical core."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib as O
+    exe = os.path.join(ROOT, "oracle", "_ref", "spmv.cvr.ref")
+    if not os.path.exists(exe):
+        return None
+    iters = 300
+    runs = []
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        path = os.path.join(d, "bench.mtx")
+        O.write_mtx_pattern(path, nrows, ncols, rp, ci)
+        for T in sorted({min(logical, 68), physical}, reverse=True):
+            r = _run_reference(exe, path, T, iters, len(ci), nrows, ncols)
+            if r:
+                runs.append(r)
+    if not runs:
+        return None
+    best = max(runs, key=lambda r: r["gflops"])
+    return {"value": best["gflops"], "unit": "GFLOP/s", "cores": best["threads"], "kind": "reference",
+            "sample": f"unmodified reference source built by oracle/Makefile (g++ -O3 -mavx512f -fopenmp, 4 intrinsic-spelling aliases in oracle/ref_shim.h), "
+                      f"{iters} timed SpMV iterations of the full matrix per run, y zeroing outside the timer as the reference does (spmv.cpp:1026-1033); "
+                      "runs: 68 threads (run_sample.sh:10; all logical cores if fewer) and one thread per physical core, the faster one is `value`",
+            "ms_per_step": best["ms_per_step"], "preprocess_s": best["preprocess_s"], "gbs_alg": best["gbs_alg"],
+            "reference_convention_gflops": best["reference_convention_gflops"], "runs": runs}
+
+
+def _cpu_port(nrows, ncols, rp, ci, va, cores, budget_s=8.0, probe=(8, 16, 32, 64, 128)):
+    """the oracle's scalar-C restatement of the reference CPU path (8 lanes, one chunk per OpenMP thread; spmv.cpp:565-1014,
+    1016-1667) on the reference loader's 1-based arrays, y zeroing INSIDE the timer: kind = "port" """
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib as O
     from cvr_amd import synth
     m = synth.to_refcompat(nrows, ncols, rp, ci, va)
     x = np.ones(ncols + 2)
     best = None
-    for T in sorted({min(cores, t) for t in (8, 16, 32, 64, 128)}):     # thread count: quick probe, keep the best
+    for T in sorted({max(1, min(cores, t)) for t in probe}):     # thread count: quick probe, keep the best
         c = O.Cvr8(m, T)
         if c.rc != 0:
             continue
@@ -140,11 +180,51 @@ def _cpu_port(nrows, ncols, rp, ci, va, cores, budget_s=10.0):
 
 
 def cpu_baseline(nrows, ncols, rp, ci, va):
-    cores = len(os.sched_getaffinity(0))
+    """SURVEY 8(d) "CPU baseline beside it": the reference on the host cores (zeroing outside its timer, as it does), and a
+    second figure with the zeroing inside the timer (the oracle's port of the same path: the unmodified reference cannot move it)"""
+    model, logical, physical = host_cpu()
     r = None
     if os.environ.get("CVR_CPU_BASELINE", "reference") == "reference":
-        r = _cpu_reference(nrows, ncols, rp, ci, cores)
-    return r or _cpu_port(nrows, ncols, rp, ci, va, cores)
+        r = _cpu_reference(nrows, ncols, rp, ci, logical, physical)
+    if r is None:
+        r = _cpu_port(nrows, ncols, rp, ci, va, logical)
+    elif not os.environ.get("CVR_BENCH_NO_SECOND_CPU_FIGURE"):
+        try:
+            second = _cpu_port(nrows, ncols, rp, ci, va, logical, budget_s=4.0, probe=(min(logical, 68), physical))
+            if second:
+                r["zeroing_inside_timer"] = {k: second[k] for k in ("value", "unit", "cores", "kind", "ms_per_step", "sample")}
+        except Exception as e:
+            r["zeroing_inside_timer"] = {"error": repr(e)}
+    if r:
+        r["host"] = {"cpu_model": model, "logical_cores": logical, "physical_cores": physical}
+    return r
+
+
+def self_launch(args):
+    """N > 1 without a torch.distributed environment: one child per GPU via torch.distributed.run, started before this
+    process has touched the GPU (the box refuses an exec / fork from a process that has); rank 0's JSON line is relayed."""
+    import torch
+    have = torch.cuda.device_count()          # does not initialise the GPU on this image
+    if have < args.gpus and not os.environ.get("CVR_BENCH_ONE_DEVICE"):
+        sys.exit(f"bench.py --gpus {args.gpus}: {have} GPU(s) visible (CVR_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 as a plumbing check)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // args.gpus)))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line:
+        print(line)
+    sys.exit(r.returncode if r.returncode else (0 if line else 1))
 
 
 def main():
@@ -159,6 +239,9 @@ def main():
     ap.add_argument("--workload", default="webgoogle", help="webgoogle (the headline, default) | livejournal | banded[<rows>] | rmat[<scale>] (fp32)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+
     import torch
     import cvr_amd
     from cvr_amd import shard, synth
@@ -166,15 +249,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    # "nccl" is RCCL on ROCm; RCCL refuses two ranks on one GPU, so the one-device plumbing check runs over gloo
+    backend = os.environ.get("CVR_BENCH_BACKEND", "gloo" if os.environ.get("CVR_BENCH_ONE_DEVICE") else "nccl")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU fallback")
     if os.environ.get("CVR_BENCH_ONE_DEVICE"):      # plumbing check of the N > 1 path on a 1-GPU box (all ranks on cuda:0)
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
     sharded = world > 1 or bool(os.environ.get("CVR_BENCH_FORCE_SHARDED"))   # the latter: the N > 1 code path with one rank (RCCL plumbing check)
     if sharded:
@@ -183,28 +266,65 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
-        backend = os.environ.get("CVR_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
-    nrows, ncols, rp, ci, va, source = load_workload(args.workload)
-    nnz = len(ci)
-    bounds = shard.row_partition(rp, world)
-    lrows, lrp, lci, lva = shard.local_csr(rp, ci, va, bounds, rank)
-    # a shard of this matrix on one of N GPUs is small enough for the chunk count to matter: measure S (cvr_tune_steps)
+    # ---- the workload: host arrays (web-Google, LiveJournal shapes) or shard-local device arrays (banded, R-MAT) ----
+    t_build0 = time.perf_counter()
+    device_built = args.workload.startswith("rmat") or args.workload.startswith("banded")
     tune = world > 1 and args.steps_per_chunk == 0 and not os.environ.get("CVR_BENCH_NO_TUNE")
-    A = cvr_amd.CvrMatrix(lrows, ncols, lrp, lci, lva, device=local_rank, steps_per_chunk=args.steps_per_chunk, tune_steps=tune)
+    rp = ci = va = None
+    if device_built:
+        from cvr_amd import synth_dev as D
+        if args.workload.startswith("rmat"):
+            scale = int(args.workload[4:] or 22)
+            nrows = ncols = 1 << scale
+            deg = D.rmat_row_degrees(scale, device=dev)
+            bounds, grp = D.partition_from_degrees(deg, world)
+            nnz = int(grp[-1])
+            nnz_per = [int(grp[bounds[p + 1]] - grp[bounds[p]]) for p in range(world)]
+            del deg, grp
+            lrp_t, lci_t, lva_t = D.rmat_rows(scale, int(bounds[rank]), int(bounds[rank + 1]), device=dev)
+            source = f"synthetic R-MAT scale {scale}, edge factor 16, fp32, built shard by shard on the GPU (torch generator streams: cvr_amd/synth_dev.py)"
+            f32 = True
+        else:
+            nrows = ncols = int(float(args.workload[6:] or 3.5e6))
+            bounds, nnz = D.banded_partition(nrows, 13, world)
+            lrp_t, lci_t, lva_t = D.banded_rows(nrows, int(bounds[rank]), int(bounds[rank + 1]), device=dev)
+            r = np.arange(nrows, dtype=np.int64)
+            pre = np.concatenate([[0], np.cumsum(np.minimum(r, 13) + 1 + np.minimum(nrows - 1 - r, 13))])
+            nnz_per = [int(pre[bounds[p + 1]] - pre[bounds[p]]) for p in range(world)]
+            del r, pre
+            source = "synthetic banded symmetric (27 nnz/row, nlpkkt240's shape), built shard by shard on the GPU (cvr_amd/synth_dev.py)"
+            f32 = False
+        torch.cuda.synchronize()
+        lrows, lnnz = int(bounds[rank + 1] - bounds[rank]), int(lrp_t[-1])
+        build_s = time.perf_counter() - t_build0
+        A = cvr_amd.CvrMatrix.from_device(lrows, ncols, lrp_t.data_ptr(), lci_t.data_ptr(), lva_t.data_ptr(), is_f32=f32, device=local_rank,
+                                          steps_per_chunk=args.steps_per_chunk, tune_steps=tune)
+        np_dtype = np.float32 if f32 else np.float64
+    else:
+        nrows, ncols, rp, ci, va, source = load_host_workload(args.workload)
+        nnz = len(ci)
+        bounds = shard.row_partition(rp, world)
+        nnz_per = [int(rp[bounds[p + 1]] - rp[bounds[p]]) for p in range(world)]
+        lrows, lrp, lci, lva = shard.local_csr(rp, ci, va, bounds, rank)
+        lnnz = int(lrp[-1])
+        build_s = time.perf_counter() - t_build0
+        # a shard of this matrix on one of N GPUs is small enough for the layout to matter: measure it (cvr_tune)
+        A = cvr_amd.CvrMatrix(lrows, ncols, lrp, lci, lva, device=local_rank, steps_per_chunk=args.steps_per_chunk, tune_steps=tune)
+        f32 = va.dtype == np.float32
+        np_dtype = va.dtype
+    create_s = time.perf_counter() - t_build0 - build_s
     info = A.info
     max_rows, pick = shard.gather_layout(bounds)
 
-    dev = torch.device("cuda", local_rank)
-    f32 = va.dtype == np.float32
     tdt, vbytes = (torch.float32, 4) if f32 else (torch.float64, 8)
     bits = torch.int32 if f32 else torch.int64
     x = torch.zeros(info.x_elems, dtype=tdt, device=dev)
-    x[:ncols] = torch.from_numpy(synth.x_rand(ncols, va.dtype)).to(dev)
+    x[:ncols] = torch.from_numpy(synth.x_rand(ncols, np_dtype)).to(dev)
     ny = max(info.yext_elems, max_rows)
     ybufs = [torch.zeros(ny, dtype=tdt, device=dev) for _ in range(2 if sharded else 1)]
     yalls = [torch.zeros(world * max_rows, dtype=tdt, device=dev) for _ in range(2)] if sharded else None
@@ -222,7 +342,7 @@ def main():
     gather_impl = "none"
     if sharded:
         gather_impl = "torch"
-        if os.environ.get("CVR_BENCH_GATHER", "native") == "native" and os.environ.get("CVR_BENCH_BACKEND", "nccl") == "nccl":
+        if os.environ.get("CVR_BENCH_GATHER", "native") == "native" and backend == "nccl":
             box = [None]
             if rank == 0:
                 try:
@@ -310,13 +430,15 @@ def main():
         wall = float(t.item())
 
     # the SpMV kernel alone, HIP events on the launch stream (N > 1: this rank's shard, no gather)
-    e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    A.spmv_device(x.data_ptr(), y.data_ptr(), sptr, repeat=args.warmup)
-    e2.record(stream)
-    A.spmv_device(x.data_ptr(), y.data_ptr(), sptr, repeat=args.steps)
-    e3.record(stream)
-    torch.cuda.synchronize()
-    kern_s = e2.elapsed_time(e3) * 1e-3 / args.steps
+    def kernel_time(M, ybuf):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        M.spmv_device(x.data_ptr(), ybuf.data_ptr(), sptr, repeat=args.warmup)
+        a.record(stream)
+        M.spmv_device(x.data_ptr(), ybuf.data_ptr(), sptr, repeat=args.steps)
+        b.record(stream)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / args.steps
+    kern_s = kernel_time(A, y)
     gather_s = None
     if sharded:                         # the exchange step alone, same message, same stream (reported beside the total)
         e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -342,9 +464,10 @@ def main():
     torch.cuda.synchronize()
     singles = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
     # throughput of independent SpMVs alternating on two streams with their own y (the per-launch floor of one overlaps the body
-    # of the other); reported for information, never the value: the steps of the metric run one after the other
+    # of the other); reported for information, never the value: the steps of the metric run one after the other.  A handle with
+    # column panels keeps its partial sums in one buffer: one SpMV in flight at a time (include/cvr_amd.h), so no such figure.
     two = None
-    if not sharded and args.two_streams:
+    if not sharded and args.two_streams and info.col_panels == 1:
         st2 = torch.cuda.Stream(device=dev)
         y2 = torch.zeros_like(y)
         pair = ((sptr, y), (st2.cuda_stream, y2))
@@ -361,22 +484,44 @@ def main():
         t = torch.tensor([kern_s], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kern_max_s = float(t.item())
-    lnnz = int(lrp[-1])
     balg_local = synth.b_alg(lrows, ncols, lnnz, vbytes)
     achieved = balg_local / kern_s / 1e9
+    streamed_local = int(info.image_bytes) + (ncols + lrows) * vbytes      # what this layout moves: image + x + y
 
-    # parity guard on the timed configuration: y of the last step against the host CSR loop of the product
-    # (the reference's own self-check, spmv.cpp:1843-1850, 1916-1938)
-    yh = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()
+    # the same matrix with full values in the stream (value_dict = 0): separates the format from the compression of the 13
+    # distinct values the reference's loader gives a pattern file (spmv.cpp:417)
+    kern_nodict_s = None
+    if not sharded and not device_built and info.value_dict > 0 and not os.environ.get("CVR_BENCH_NO_DICT_OFF_RUN"):
+        try:
+            B = cvr_amd.CvrMatrix(lrows, ncols, lrp, lci, lva, device=local_rank, steps_per_chunk=args.steps_per_chunk, value_dict=0)
+            kern_nodict_s = kernel_time(B, torch.zeros(max(B.info.yext_elems, 1), dtype=tdt, device=dev))
+            B.close()
+        except Exception as e:
+            print(f"[bench] value_dict = 0 run failed: {e!r}", file=sys.stderr)
+
+    # parity guard on the timed configuration: y of the last step against the CSR loop (the reference's own self-check,
+    # spmv.cpp:1843-1850, 1916-1938): the product's host loop for host-built workloads, a torch fp64 loop on the rank's own
+    # shard for device-built ones
     wrong = -1
-    if rank == 0:
-        xh = x[:ncols].cpu().numpy().astype(np.float64)
-        yref = cvr_amd.csr_spmv_host(rp, ci, va.astype(np.float64), xh, nthreads=len(os.sched_getaffinity(0)))
-        if f32:     # no reference counterpart: rows off by more than 1e-5 of sum |a x| against the fp64 loop
-            absy = cvr_amd.csr_spmv_host(rp, ci, np.abs(va).astype(np.float64), np.abs(xh), nthreads=len(os.sched_getaffinity(0)))
-            wrong = int(np.count_nonzero(np.abs(yh.astype(np.float64) - yref) > 1e-5 * absy + 1e-30))
-        else:
-            wrong = int(cvr_amd.verdict(yh, yref, nrows))
+    if device_built:
+        from cvr_amd import synth_dev as D
+        yl = (yalls[last[0]][rank * max_rows: rank * max_rows + lrows] if sharded else y[:lrows]).to(torch.float64)
+        yref_t, absy_t = D.csr_spmv_reference(lrp_t, lci_t, lva_t, x[:ncols])
+        bad = torch.count_nonzero((yl - yref_t).abs() > (1e-5 if f32 else 1e-12) * absy_t + 1e-300).to(torch.int64).reshape(1)
+        if sharded:
+            dist.all_reduce(bad)
+        wrong = int(bad.item())
+    else:
+        yh = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()
+        if rank == 0:
+            xh = x[:ncols].cpu().numpy().astype(np.float64)
+            nt = len(os.sched_getaffinity(0))
+            yref = cvr_amd.csr_spmv_host(rp, ci, va.astype(np.float64), xh, nthreads=nt)
+            if f32:     # no reference counterpart: rows off by more than 1e-5 of sum |a x| against the fp64 loop
+                absy = cvr_amd.csr_spmv_host(rp, ci, np.abs(va).astype(np.float64), np.abs(xh), nthreads=nt)
+                wrong = int(np.count_nonzero(np.abs(yh.astype(np.float64) - yref) > 1e-5 * absy + 1e-30))
+            else:
+                wrong = int(cvr_amd.verdict(yh, yref, nrows))
 
     copy_gbs = None
     if rank == 0:
@@ -387,6 +532,7 @@ def main():
             copy_gbs = None
     if rank == 0:
         per = wall / args.steps
+        kname = "cvr::spmv_kernel<float>" if f32 else "cvr::spmv_kernel<double>"
         out = {
             "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64" if args.workload == "webgoogle" else f"SpMV GFLOP/s (2*nnz/t), {args.workload} {'fp32' if f32 else 'fp64'}",
             "value": 2.0 * nnz / per / 1e9,
@@ -400,27 +546,35 @@ def main():
             "data": "synthetic" if source.startswith("synthetic") else "real",
             "config": {"workload": f"{source}: {nrows}x{ncols}, nnz {nnz}, {'fp32' if f32 else 'fp64'}, y = A x with A (CVR64 image), x, y resident in HBM",
                        "rows_per_gpu": [int(v) for v in np.diff(bounds)],
-                       "nnz_per_gpu": [int(rp[bounds[p + 1]] - rp[bounds[p]]) for p in range(world)],
-                       "nnz_imbalance_max_over_mean": float(max(int(rp[bounds[p + 1]] - rp[bounds[p]]) for p in range(world)) * world / max(nnz, 1)),
+                       "nnz_per_gpu": nnz_per,
+                       "nnz_imbalance_max_over_mean": float(max(nnz_per) * world / max(nnz, 1)),
                        "steps_per_chunk": int(info.steps_per_chunk), "chunks_rank0": int(info.nchunks),
                        "rows_cut_rank0": int(info.nshared), "col_panels": int(info.col_panels),
+                       "waves_per_workgroup": int(info.waves_per_block), "x_window_values": int(info.x_window), "col_phases": int(info.col_phases),
+                       "lds_bytes_per_workgroup": int(info.lds_bytes), "near_diagonal_share": float(info.near_diagonal_share),
                        "value_dictionary_entries": int(info.value_dict),
-                       "parallelism": ("rows sharded, x replicated, y all-gathered (%s)" % ("RCCL" if os.environ.get("CVR_BENCH_BACKEND", "nccl") == "nccl" else os.environ["CVR_BENCH_BACKEND"])) if sharded else "1 GPU"},
+                       "parallelism": ("rows sharded, x replicated, y all-gathered (%s)" % ("RCCL" if backend == "nccl" else backend)) if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if world == 1 and args.workload == "webgoogle" else None,
-                         "kernel": "cvr::spmv_kernel<float>" if f32 else "cvr::spmv_kernel<double>", "kernel_us": kern_s * 1e6,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(info, kname) if world == 1 else None,
+                         "achieved_is": "algorithmic bytes of SURVEY 8(d) (12 B per non-zero for fp64, whatever the image stores) / kernel time",
+                         "kernel": kname, "kernel_us": kern_s * 1e6,
                          "kernel_us_median_single_launches": singles[len(singles) // 2] if singles else None, "kernel_us_min_single_launches": singles[0] if singles else None,
                          "copy_kernel_gbs": copy_gbs, "frac_of_copy_kernel": achieved / copy_gbs if copy_gbs else None,
-                         "algorithmic_bytes_per_launch": int(balg_local)},
+                         "algorithmic_bytes_per_launch": int(balg_local),
+                         "streamed_bytes_per_launch": streamed_local, "streamed_gbs": streamed_local / kern_s / 1e9,
+                         "kernel_us_value_dict_off": None if kern_nodict_s is None else kern_nodict_s * 1e6,
+                         "frac_value_dict_off": None if kern_nodict_s is None else balg_local / kern_nodict_s / 1e9 / HBM_PEAK_GBS},
             "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz, vbytes) / per / 1e9,
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
             "spmv_only_ms_max_over_ranks": kern_max_s * 1e3, "gflops_spmv_only_no_exchange": 2.0 * nnz / kern_max_s / 1e9,
             "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
-            "preprocess": {"plan_s": info.plan_s, "upload_s": info.upload_s, "convert_s": info.convert_s, "tune_steps_s": A.tuning_s},
+            "preprocess": {"plan_s": info.plan_s, "probe_s": info.probe_s, "upload_s": info.upload_s, "convert_s": info.convert_s,
+                           "preprocess_wall_s": info.preprocess_wall_s, "tune_s": A.tuning_s,
+                           "workload_build_s": build_s, "create_and_preprocess_wall_s": create_s},
             "independent_spmvs_on_two_streams": None if two is None else {"ms_per_spmv": two * 1e3, "gflops": 2.0 * nnz / two / 1e9},
             "verdict_wrong_rows": wrong, "gather_impl": gather_impl, "gather_calibration_ms_per_step": calib,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not device_built:
             try:
                 out["cpu_baseline"] = cpu_baseline(nrows, ncols, rp, ci, va)
             except Exception as e:   # the checker is optional on the bench box; the GPU numbers stand without it

@@ -25,9 +25,9 @@ class CsrView(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
-                ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("stream_policy", C.c_int32),
+                ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("stream_ahead", C.c_int32),
                 ("waves_per_block", C.c_int32), ("gather_depth", C.c_int32), ("debug_col_mask", C.c_int32),
-                ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("reserved1", C.c_int32)]
+                ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("layout_auto_resident", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -41,7 +41,7 @@ class Info(C.Structure):
                 ("image_bytes", C.c_int64), ("yext_elems", C.c_int64), ("x_elems", C.c_int64),
                 ("plan_s", C.c_double), ("upload_s", C.c_double), ("convert_s", C.c_double),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("waves_per_block", C.c_int32),
-                ("x_window", C.c_int32), ("lds_bytes", C.c_int32), ("nsegments", C.c_int64), ("chunk_row_cap", C.c_int64)]
+                ("x_window", C.c_int32), ("lds_bytes", C.c_int32), ("nsegments", C.c_int64), ("chunk_row_cap", C.c_int64), ("near_diagonal_share", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double)]
 
 
 class MmMatrix(C.Structure):
@@ -55,7 +55,7 @@ SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_c
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
            "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
-           "cvr_tune_steps", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
+           "cvr_tune_steps", "cvr_tune", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
 
 
 def lib_path():
@@ -98,6 +98,7 @@ def lib():
         L.cvr_verdict.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.cvr_verdict.restype = C.c_int64
         L.cvr_tune_steps.argtypes = [C.POINTER(CsrView), C.POINTER(Options), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.cvr_tune.argtypes = [C.POINTER(CsrView), C.POINTER(Options), C.POINTER(Options), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.cvr_auto_panels.argtypes = [C.POINTER(CsrView), C.POINTER(C.c_double)]
         L.cvr_power_iteration.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
         L.cvr_comm_unique_id.argtypes = [C.c_void_p]
@@ -247,8 +248,8 @@ class CvrMatrix:
     """One matrix (or row shard) resident on one GPU: cvr_create + cvr_preprocess, then spmv()."""
 
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
-                 xcd_swizzle=-1, x_window=-1, nontemporal=0, keep_csr=False, debug_col_mask=0, depth=0,
-                 col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0, col_phases=0):
+                 xcd_swizzle=-1, x_window=-1, stream_ahead=0, keep_csr=False, debug_col_mask=0, depth=0,
+                 col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0, col_phases=-1):
         """tune_steps: choose steps_per_chunk by measurement first (cvr_tune_steps; its cost is self.tuning_s)"""
         self._h = C.c_void_p()
         self.tuning_s = 0.0
@@ -264,7 +265,7 @@ class CvrMatrix:
         if nrows > 0 and (len(ci) < rp[-1] or len(va) < rp[-1]):      # the library reads row_ptr[nrows] entries of both
             raise ValueError(f"col_idx / vals hold {len(ci)} / {len(va)} entries, row_ptr[nrows] = {int(rp[-1])}")
         view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
-        self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, nontemporal, keep_csr,
+        self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
                     debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block, col_phases)
 
     @classmethod
@@ -281,21 +282,21 @@ class CvrMatrix:
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, -1, -1, 0, keep_csr, 0, 0, col_panels, value_dict, tune_steps)
         return self
 
-    def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, nontemporal, keep_csr,
-               debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=0):
+    def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
+               debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=-1):
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
         opt.xcd_swizzle, opt.x_window, opt.col_panels, opt.value_dict = xcd_swizzle, x_window, col_panels, value_dict
         # tuning / profiling knobs (tools/sweep.py)
-        opt.stream_policy, opt.gather_depth, opt.debug_col_mask = nontemporal, depth, debug_col_mask
+        opt.stream_ahead, opt.gather_depth, opt.debug_col_mask = stream_ahead, depth, debug_col_mask
         opt.waves_per_block, opt.col_phases = waves_per_block, col_phases
-        if tune_steps and steps_per_chunk == 0:
-            best, best_t, tun = C.c_int32(), C.c_double(), C.c_double()
-            rc = lib().cvr_tune_steps(C.byref(view), C.byref(opt), C.byref(best), C.byref(best_t), C.byref(tun))
+        if tune_steps and steps_per_chunk == 0:          # the layout by measurement (cvr_tune): S, chunks per workgroup, x window, column phases
+            best, best_t, tun = Options(), C.c_double(), C.c_double()
+            rc = lib().cvr_tune(C.byref(view), C.byref(opt), C.byref(best), C.byref(best_t), C.byref(tun))
             if rc:
-                raise CvrError(rc, "cvr_tune_steps")
-            opt.steps_per_chunk, self.tuning_s = best.value, tun.value
+                raise CvrError(rc, "cvr_tune")
+            opt, self.tuning_s = best, tun.value
         rc = lib().cvr_create(C.byref(self._h), C.byref(view), C.byref(opt))
         if rc:
             self._h = C.c_void_p()

@@ -172,7 +172,7 @@ void cvr_default_options(cvr_options *o)
     o->x_window = -1;
     o->col_panels = -1;
     o->value_dict = -1;
-    o->col_phases = 0;
+    o->col_phases = -1;
 }
 
 int cvr_device_count(void)
@@ -373,20 +373,94 @@ static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, cons
     }
 }
 
+// The automatic layout (every layout option left at its default; one image, no column panels).  Matrices small enough
+// for all their chunks to be resident at once -- 6 to 8 chunks per workgroup, one workgroup per CU -- run in the "resident"
+// layout when it pays: the workgroup's chunks share an LDS window of x if a sizeable share of the non-zeros lies near the
+// diagonal, and feed their rows column phase by column phase when x is larger than what an L2 keeps beside the matrix
+// stream (profiles/r02_wg_window_sweep.log, r02_column_phases_sweep.log: 32.5 -> 23.4 us on the web-Google shape).
+// Decided from a device-side pass over the uploaded CSR (sortedness of the rows, near-diagonal share).
+static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, cvr_options &opt)
+{
+    opt.layout_auto_resident = 0;
+    if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT")) {
+        if (opt.col_phases < 0) opt.col_phases = 0;
+        return CVR_OK;
+    }
+    opt.col_phases = 0;
+    if (nrows < 4096 || ncols < 4096) return CVR_OK;
+    const int64_t vs = f32 ? 4 : 8;
+    const double  slots = ((double)(rp[nrows] - rp[0]) + (double)nrows / 4) * 1.006;      // pad slots of empty rows, chunk tails
+    // candidates: 8, 7 or 6 chunks per workgroup with the smallest S that keeps the workgroups at or under 252; the one
+    // that fills the 256 CUs best wins (ties: more waves)
+    int best_w = 0, best_S = 0;
+    double best_fill = 0;
+    for (int w = 8; w >= 6; w--) {
+        int S = (int)std::ceil(slots / (64.0 * w * 252.0) / 4.0) * 4;
+        if (S < 24 || S > 128) continue;                       // tiny shards and matrices beyond one resident pass keep the plain layout
+        const double wgs = std::ceil(slots / (64.0 * w * S));
+        if (wgs > best_fill) { best_fill = wgs; best_w = w; best_S = S; }
+    }
+    if (!best_w) return CVR_OK;
+    const int64_t win = (64 * 1024) / vs;                       // 64 KiB of x per workgroup
+    unsigned long long *d_out = nullptr, out[2] = {0, 0};
+    HIP_TRY(hipMalloc(&d_out, sizeof(out)));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the upload
+    const double tp0 = now_s();
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(out), h->stream);
+    if (e == hipSuccess) e = cvr::launch_probe(part.d_rp, part.d_ci, nrows, ncols, (uint32_t)(win / 4), d_out, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    h->info.probe_s = now_s() - tp0;
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(CVR_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
+    const bool   sorted = out[0] == 0;
+    const double near = (double)out[1] / std::max<double>((double)(rp[nrows] - rp[0]), 1.0);
+    const double xbytes = (double)ncols * vs;
+    // (a matrix with nearly everything near the diagonal is a band: consecutive rows share their lines of x in L1 already)
+    const bool   want_win = near >= 0.15 && near < 0.9, want_phases = sorted && xbytes > 2.5e6 && near < 0.9;
+    h->info.near_diagonal_share = near;
+    if (!want_win && !want_phases) return CVR_OK;
+    opt.layout_auto_resident = 1;
+    opt.waves_per_block = best_w;
+    opt.steps_per_chunk = best_S;
+    opt.x_window = want_win ? (int32_t)win : 0;
+    opt.col_phases = want_phases ? (int32_t)std::min(32.0, std::max(2.0, std::floor(xbytes / 600e3 + 0.5))) : 1;
+    return CVR_OK;
+}
+
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
 static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
                       hipMemcpyKind civa_kind, bool f32, const cvr_options &opt, double *plan_s, PartPlan *planned = nullptr)
 {
-    PartPlan local;
+    const int64_t nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
+    const size_t  vsz = f32 ? 4 : 8, nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
+    // the CSR goes to the device first (asynchronously): the automatic layout choice below looks at it there
+    HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
+    HIP_TRY(hipMalloc(&part.d_ci, sizeof(int32_t) * std::max<size_t>(nnz_span, 1)));
+    HIP_TRY(hipMalloc(&part.d_va, vsz * std::max<size_t>(nnz_span, 1)));
+    if (nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));     // row_ptr is always a host array here
+    if (nnz_span) {
+        HIP_TRY(hipMemcpyAsync(part.d_ci, ci, sizeof(int32_t) * nnz_span, civa_kind, h->stream));
+        HIP_TRY(hipMemcpyAsync(part.d_va, va, vsz * nnz_span, civa_kind, h->stream));
+    }
+    PartPlan    local;
+    cvr_options popt = opt;
     if (!planned) {
+        int rc = auto_layout(h, part, nrows, ncols, f32, rp, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
+        if (rc) return rc;
         const double t0 = now_s();
-        plan_part(local, nrows, ncols, f32, rp, opt);
+        plan_part(local, nrows, ncols, f32, rp, popt);
+        // the resident layout wants every workgroup on a CU of its own at once: one more step per chunk until they fit
+        while (popt.layout_auto_resident && !local.too_large && (int64_t)local.plan.chunks.size() > (int64_t)local.wpb * 256 && popt.steps_per_chunk < 4096) {
+            popt.steps_per_chunk += 4;
+            local = PartPlan();
+            plan_part(local, nrows, ncols, f32, rp, popt);
+        }
         if (plan_s) *plan_s += now_s() - t0;
         planned = &local;
     }
     PartPlan &pp = *planned;
     if (pp.too_large) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
-    const int64_t    nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
     const int        S = pp.S;
     const cvr::Plan &plan = pp.plan;
     const int64_t    nchunks = (int64_t)plan.chunks.size(), yext = pp.yext;
@@ -399,7 +473,7 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
     img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)plan.shared.size();
     img.xcd_swizzle = opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
-    img.stream_policy = opt.stream_policy > 0 ? opt.stream_policy : 0;
+    img.stream_ahead = opt.stream_ahead >= 2 ? 3 : 1;
     img.depth = opt.gather_depth == 2 ? 2 : 1;
     img.wpb = (uint32_t)pp.wpb;
     img.ystage = (uint32_t)pp.stage;
@@ -410,15 +484,11 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
         img.col_bits = (uint32_t)pp.col_bits;
         img.col_mask = (1u << pp.col_bits) - 1u;
     }
-    if (opt.col_phases > 1 && pp.lds_short) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
+    if (popt.col_phases > 1 && pp.lds_short && !popt.layout_auto_resident) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
     const int64_t win = pp.win;
     img.win_elems = (uint32_t)win;
     if (opt.debug_col_mask) img.col_mask &= (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
 
-    const size_t vsz = f32 ? 4 : 8, nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
-    HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
-    HIP_TRY(hipMalloc(&part.d_ci, sizeof(int32_t) * std::max<size_t>(nnz_span, 1)));
-    HIP_TRY(hipMalloc(&part.d_va, vsz * std::max<size_t>(nnz_span, 1)));
     HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nchunks + 1)));
     HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
@@ -430,11 +500,6 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     }
     HIP_TRY(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1)));
     HIP_TRY(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1), h->stream));
-    if (nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
-    if (nnz_span) {
-        HIP_TRY(hipMemcpyAsync(part.d_ci, ci, sizeof(int32_t) * nnz_span, civa_kind, h->stream));     // row_ptr is always a host array here
-        HIP_TRY(hipMemcpyAsync(part.d_va, va, vsz * nnz_span, civa_kind, h->stream));
-    }
     if (nchunks) {
         HIP_TRY(hipMemcpyAsync(part.d_nzb, nzb.data(), sizeof(int64_t) * nzb.size(), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(part.d_pad, pad.data(), sizeof(uint32_t) * pad.size(), hipMemcpyHostToDevice, h->stream));
@@ -452,10 +517,14 @@ static int finish_part(cvr_handle *h, Part &part)
     cvr::DeviceImage &img = part.img;
     img.dict = h->d_dict; img.ndict = h->ndict;
     part.stream_bytes = (size_t)part.nchunks * img.G * cvr::group_bytes(img.f32, h->d_dict != nullptr);
+    // the SpMV kernel's software pipeline issues its stream loads up to 5 groups past the end of a chunk (the buffer
+    // descriptor's range check returns zeros for them); the allocation is padded by that much so that the last chunk's
+    // run-ahead stays inside it whatever the hardware does with an offset beyond num_records
+    const size_t slack = 8 * (size_t)cvr::group_bytes(img.f32, h->d_dict != nullptr);
     if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
-        HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, std::max<size_t>(part.stream_bytes, 16), hipDeviceMallocUncached));
+        HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, part.stream_bytes + slack, hipDeviceMallocUncached));
     else
-        HIP_TRY(hipMalloc(&img.stream, std::max<size_t>(part.stream_bytes, 16)));
+        HIP_TRY(hipMalloc(&img.stream, part.stream_bytes + slack));
     return CVR_OK;
 }
 
@@ -862,6 +931,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // most 256 distinct values -- 12 -> 5 bytes per slot for fp64 (profiles/r01_value_dictionary.log).  The distinct
     // values are collected on the device from the uploaded CSR (a 40-MB scan takes microseconds there, milliseconds
     // on the host).
+    const double t_dict0 = now_s();
     if (opt.value_dict != 0 && in.nnz > 0) {
         unsigned long long *d_tab = nullptr;
         uint32_t           *d_flags = nullptr;
@@ -895,6 +965,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }
     }
     in.value_dict = (int32_t)h->ndict;
+    in.dict_s = now_s() - t_dict0;
     clk.lap("value dictionary scan");
     for (Part &p : h->parts) { rc = finish_part(h, p); if (rc) { cvr_destroy(h); return rc; } }
     in.steps_per_chunk = h->parts[0].img.S;
@@ -912,7 +983,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipMemsetAsync(h->d_y, 0, vsz * (size_t)in.yext_elems, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
     CREATE_TRY(hipStreamSynchronize(h->stream));   // the caller may free its CSR when this returns
-    in.upload_s = now_s() - t_up0 - in.plan_s;
+    in.upload_s = now_s() - t_up0 - in.plan_s - in.probe_s;
     clk.lap("images, x, y");
 #undef CREATE_TRY
     *out = h;
@@ -924,37 +995,42 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     if (!h) return fail(CVR_ERR_INVALID, "handle is null");
     if (h->parts.empty() || !h->parts[0].d_rp) return fail(CVR_ERR_STATE, "the device CSR was already released: cvr_preprocess runs once unless keep_csr was set");
     Range range("cvr_preprocess (CSR -> CVR64)");
+    const double t_wall0 = now_s();
     HIP_TRY(hipSetDevice(h->device));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
+    struct SegGuard { cvr::SegTable t; ~SegGuard() { (void)hipFree(t.cnt); (void)hipFree(t.pcnt); (void)hipFree(t.begin); (void)hipFree(t.len); (void)hipFree(t.row); (void)hipFree(t.flags); } } sg;
+    Part &p0 = h->parts[0];
+    const bool phased = !h->paneled() && p0.img.phases > 1 && p0.nchunks > 0;
+    if (phased) {
+        // column phases: the segment table (conversion-time only) is allocated for the most segments there can be -- one per
+        // slot, or one per (row, phase) pair plus the pad segments -- so that counting, scanning, filling and converting run
+        // back to back on the device without the host in between
+        cvr::SegTable &t = sg.t;
+        const size_t ub = (size_t)std::min<int64_t>(p0.nchunks * 64 * (int64_t)p0.img.S, (p0.nrows + 2 * p0.nchunks) * (int64_t)p0.img.phases + p0.nchunks);
+        HIP_TRY(hipMalloc(&t.cnt, sizeof(uint32_t) * ((size_t)p0.nchunks + 1)));
+        HIP_TRY(hipMalloc(&t.flags, sizeof(uint32_t) * 2));
+        HIP_TRY(hipMalloc(&t.pcnt, sizeof(uint32_t) * (size_t)p0.nchunks * p0.img.phases));
+        HIP_TRY(hipMalloc(&t.begin, sizeof(int64_t) * std::max<size_t>(ub, 1)));
+        HIP_TRY(hipMalloc(&t.len, sizeof(uint32_t) * std::max<size_t>(ub, 1)));
+        HIP_TRY(hipMalloc(&t.row, sizeof(uint16_t) * std::max<size_t>(ub, 1)));
+        HIP_TRY(hipMemsetAsync(t.flags, 0, sizeof(uint32_t) * 2, h->stream));
+    }
     HIP_TRY(hipEventRecord(e0, h->stream));
-    struct SegGuard { cvr::SegTable t; ~SegGuard() { (void)hipFree(t.cnt); (void)hipFree(t.begin); (void)hipFree(t.len); (void)hipFree(t.row); (void)hipFree(t.flags); } } sg;
+    uint32_t seg_flags[2] = {0, 0}, seg_total = 0;
     for (Part &p : h->parts) {
         cvr::DeviceCsr csr;
         csr.row_ptr = p.d_rp; csr.col_idx = p.d_ci; csr.vals = p.d_va; csr.nz_begin = p.d_nzb; csr.pad_cnt = p.d_pad;
-        if (p.img.phases > 1 && p.nchunks > 0) {
-            // column phases: count the (row, phase) segments of every chunk, scan, fill the table (device); the host only
-            // learns the total (to size the table, which lives until the conversion is done) and whether the rows are sorted
+        if (phased) {
             cvr::SegTable &t = sg.t;
-            HIP_TRY(hipMalloc(&t.cnt, sizeof(uint32_t) * ((size_t)p.nchunks + 1)));
-            HIP_TRY(hipMalloc(&t.flags, sizeof(uint32_t) * 2));
-            HIP_TRY(hipMemsetAsync(t.flags, 0, sizeof(uint32_t) * 2, h->stream));
             HIP_TRY(cvr::launch_seg_count(p.img, csr, t, h->stream));
             HIP_TRY(cvr::launch_seg_scan(p.img, t, h->stream));
-            uint32_t flags[2] = {0, 0}, total = 0;
-            HIP_TRY(hipMemcpyAsync(flags, t.flags, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipMemcpyAsync(&total, t.cnt + p.nchunks, sizeof(total), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            if (flags[0] & 1u) return fail(CVR_ERR_INVALID, "col_phases needs the column indices of every row in ascending order");
-            t.total = total;
-            HIP_TRY(hipMalloc(&t.begin, sizeof(int64_t) * std::max<size_t>(total, 1)));
-            HIP_TRY(hipMalloc(&t.len, sizeof(uint32_t) * std::max<size_t>(total, 1)));
-            HIP_TRY(hipMalloc(&t.row, sizeof(uint16_t) * std::max<size_t>(total, 1)));
-            h->info.nsegments = total;
             HIP_TRY(cvr::launch_seg_fill(p.img, csr, t, h->stream));
             HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream, &t));
+            HIP_TRY(hipMemcpyAsync(seg_flags, t.flags, sizeof(seg_flags), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(&seg_total, t.cnt + p.nchunks, sizeof(seg_total), hipMemcpyDeviceToHost, h->stream));
         } else {
             HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream));
         }
@@ -971,7 +1047,10 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     h->info.convert_s = ms * 1e-3;
     h->info.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);      // column phases: the segment-row copy is sized by now
     if (seconds) *seconds = ms * 1e-3;
+    if (seg_flags[0] & 1u) return fail(CVR_ERR_INVALID, "col_phases needs the column indices of every row in ascending order");
     if (err) return fail(CVR_ERR_INTERNAL, "device converter self-check failed (flags 0x%x)", err);
+    h->info.nsegments = seg_total;
+    h->info.preprocess_wall_s = now_s() - t_wall0;
     h->converted = true;
     if (!keep_csr) for (Part &p : h->parts) p.release_csr();
     return CVR_OK;
@@ -1335,9 +1414,8 @@ int cvr_auto_panels(const cvr_csr_view *csr, double *l2_miss_estimate_out)
     return auto_panels(*csr, l2_miss_estimate_out);
 }
 
-int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt_in, int32_t *best_steps, double *best_spmv_s, double *tuning_s)
+static int tune_impl(const cvr_csr_view *csr, const cvr_options *opt_in, bool full_layout, cvr_options *best_out, double *best_spmv_s, double *tuning_s)
 {
-    if (!csr || !best_steps) return fail(CVR_ERR_INVALID, "null argument");
     cvr_options opt;
     if (opt_in) opt = *opt_in; else cvr_default_options(&opt);
     const double t0 = now_s();
@@ -1361,24 +1439,73 @@ int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt_in, int32_t *
         view.arrays_on_device = 1;
         if (opt.col_panels < 0) opt.col_panels = auto_panels(*csr, nullptr);      // decided once, on the host arrays
     }
-    int32_t best = 0;
-    double  best_t = 0;
-    for (int32_t S = 8; S <= 64; S += 4) {     // every candidate is the real thing: plan, convert, timed launches
-        opt.steps_per_chunk = S;
+    // every candidate is the real thing: plan, convert, timed launches
+    auto measure = [&](const cvr_options &o, double *t_out) -> int {
         cvr_handle *h = nullptr;
-        int         rc = cvr_create(&h, &view, &opt);
+        int         rc = cvr_create(&h, &view, &o);
         double      t = 0;
         if (rc == CVR_OK) rc = cvr_preprocess(h, 0, nullptr);
         if (rc == CVR_OK) rc = cvr_spmv_bench(h, 5, 10, &t);                                   // settle clocks and caches
         if (rc == CVR_OK) rc = cvr_spmv_bench(h, 0, t > 0 ? std::max(20, std::min(200, (int)(1.5e-3 / t))) : 20, &t);
         cvr_destroy(h);
+        *t_out = t;
+        return rc;
+    };
+    cvr_options best = opt;
+    double      best_t = 0;
+    bool        have = false;
+    // (1) one chunk per workgroup, S = 8 .. 64
+    opt.waves_per_block = 1; opt.x_window = 0; opt.col_phases = 1;
+    for (int32_t S = 8; S <= 64; S += 4) {
+        opt.steps_per_chunk = S;
+        double t = 0;
+        const int rc = measure(opt, &t);
         if (rc != CVR_OK) return rc;
-        if (best == 0 || t < best_t) { best = S; best_t = t; }
+        if (!have || t < best_t) { have = true; best = opt; best_t = t; }
     }
-    *best_steps = best;
+    // (2) the resident layout (several chunks per workgroup, one workgroup per CU, all at once) where the matrix is small
+    // enough: 64-KiB window of x or none, column phases or none; skipped with column panels and without row pointers here
+    if (full_layout && opt.col_panels <= 1 && csr->nrows > 0 && !csr->arrays_on_device) {
+        const int64_t vs = csr->is_f32 ? 4 : 8;
+        const double  slots = ((double)(csr->row_ptr[csr->nrows] - csr->row_ptr[0]) + (double)csr->nrows / 4) * 1.006;
+        const double  xbytes = (double)csr->ncols * vs;
+        const int     P = (int)std::min(32.0, std::max(2.0, std::floor(xbytes / 600e3 + 0.5)));
+        for (int w : {8, 4}) {
+            int S = (int)std::ceil(slots / (64.0 * w * 252.0) / 4.0) * 4;
+            if (S < 8) S = 8;
+            if (S > 128) continue;
+            for (int win : {(int)(65536 / vs), 0})
+                for (int ph : {P, 1}) {
+                    if (xbytes <= 2.5e6 && ph > 1) continue;
+                    cvr_options o = opt;
+                    o.waves_per_block = w; o.steps_per_chunk = S; o.x_window = win; o.col_phases = ph;
+                    double t = 0;
+                    const int rc = measure(o, &t);
+                    if (rc == CVR_ERR_INVALID) { (void)hipGetLastError(); continue; }     // e.g. unsorted rows with phases: not a candidate
+                    if (rc != CVR_OK) return rc;
+                    if (t < best_t) { best = o; best_t = t; }
+                }
+        }
+    }
+    *best_out = best;
     if (best_spmv_s) *best_spmv_s = best_t;
     if (tuning_s) *tuning_s = now_s() - t0;
     return CVR_OK;
+}
+
+int cvr_tune(const cvr_csr_view *csr, const cvr_options *opt_in, cvr_options *best, double *best_spmv_s, double *tuning_s)
+{
+    if (!csr || !best) return fail(CVR_ERR_INVALID, "null argument");
+    return tune_impl(csr, opt_in, true, best, best_spmv_s, tuning_s);
+}
+
+int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt_in, int32_t *best_steps, double *best_spmv_s, double *tuning_s)
+{
+    if (!csr || !best_steps) return fail(CVR_ERR_INVALID, "null argument");
+    cvr_options best;
+    const int   rc = tune_impl(csr, opt_in, false, &best, best_spmv_s, tuning_s);
+    if (rc == CVR_OK) *best_steps = best.steps_per_chunk;
+    return rc;
 }
 
 int cvr_device_copy_bench(int device, int64_t bytes, int iters, double *gbs)

@@ -51,8 +51,9 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     uint8_t *__restrict__ stream, uint8_t *__restrict__ target, uint32_t *__restrict__ err, int G,
     uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
     const uint2 *__restrict__ desc2, const int64_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
-    const uint16_t *__restrict__ seg_row, uint32_t col_bits)
+    const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags)
 {
+    if constexpr (SEGT) { if (seg_flags[0] & 1u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
     constexpr int GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     typedef typename Bits<T>::type bits_t;
     __shared__ bits_t dict[DICT ? kDictMax : 1];
@@ -182,79 +183,122 @@ __device__ __forceinline__ void row_piece(const int64_t *rp, uint32_t row, int64
     z = z < e ? z : e;
 }
 
-__global__ __launch_bounds__(kLanes) void seg_count_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
-                                                           const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
-                                                           uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, uint32_t nchunks,
-                                                           uint32_t pw, uint32_t *__restrict__ cnt, uint32_t *__restrict__ flags)
+// Both passes stage the chunk's column indices (when the chunk has at most kSegLdsCols slots) and its row pieces in LDS:
+// the per-row scans and binary searches then run at LDS latency instead of as chains of dependent global loads.
+constexpr uint32_t kSegLdsCols = 16384;     // 64 KiB of column indices
+constexpr uint32_t kSegWaves = 8;           // wavefronts per chunk in the fill pass (each takes every 8th phase)
+
+struct SegStage {
+    const int32_t *cols;     // the chunk's column indices, indexed from the chunk's first CSR element
+    uint32_t      *pa, *pz;  // per row of the chunk: its piece [pa, pz) relative to the chunk's first element (pa == pz: empty row)
+};
+
+__device__ __forceinline__ SegStage seg_stage(uint8_t *smem, const int64_t *rp, const int32_t *cidx, int64_t b, int64_t e,
+                                              uint32_t row_first, uint32_t nri)
 {
-    const uint32_t k = blockIdx.x, lane = threadIdx.x;
+    SegStage st;
+    st.pa = reinterpret_cast<uint32_t *>(smem);
+    st.pz = st.pa + nri;
+    int32_t       *scol = reinterpret_cast<int32_t *>(st.pz + nri);
+    const uint32_t n = (uint32_t)(e - b);
+    for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
+        int64_t a, z;
+        row_piece(rp, row_first + i, b, e, a, z);
+        if (z < a) z = a;
+        st.pa[i] = (uint32_t)(a - b); st.pz[i] = (uint32_t)(z - b);
+    }
+    if (n <= kSegLdsCols) {
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) scol[j] = cidx[b + j];
+        st.cols = scol;
+    } else {
+        st.cols = cidx + b;
+    }
+    __syncthreads();
+    return st;
+}
+
+// pass 1: per chunk, the number of segments of every phase (pcnt[k][p], turned into offsets inside the chunk) and their sum
+__global__ __launch_bounds__(256) void seg_count_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
+                                                        const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
+                                                        uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, uint32_t nchunks,
+                                                        uint32_t pw, uint32_t phases, uint32_t *__restrict__ cnt, uint32_t *__restrict__ pcnt,
+                                                        uint32_t *__restrict__ flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t pc[64], sbad;
+    const uint32_t k = blockIdx.x;
     if (k >= nchunks) return;
     const int64_t  b = nzb[k], e = nzb[k + 1];
     const uint32_t row_first = desc[k].x, nri = desc2[k].y;
-    uint32_t       total = 0, bad = 0;
-    for (uint32_t i = lane; i < nri; i += kLanes) {
-        int64_t a, z;
-        row_piece(rp, row_first + i, b, e, a, z);
-        uint32_t c = 1;                                  // an empty row owns one pad slot
-        if (z > a) {
-            int32_t  prev_col = cidx[a];
-            uint32_t prev = (uint32_t)prev_col / pw;
-            for (int64_t j = a + 1; j < z; j++) {
-                const int32_t  col = cidx[j];
-                const uint32_t ph = (uint32_t)col / pw;
-                if (col < prev_col) bad = 1;
-                if (ph != prev) c++;
-                prev = ph; prev_col = col;
-            }
+    if (threadIdx.x < 64) pc[threadIdx.x] = 0;
+    if (threadIdx.x == 0) sbad = 0;
+    const SegStage st = seg_stage(smem, rp, cidx, b, e, row_first, nri);
+    uint32_t bad = 0;
+    for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
+        const uint32_t a = st.pa[i], z = st.pz[i];
+        if (z <= a) { atomicAdd(&pc[0], 1u); continue; }            // an empty row owns one pad slot, fed with phase 0
+        int32_t  prev_col = st.cols[a];
+        uint32_t prev = (uint32_t)prev_col / pw;
+        atomicAdd(&pc[prev], 1u);
+        for (uint32_t j = a + 1; j < z; j++) {
+            const int32_t  col = st.cols[j];
+            const uint32_t ph = (uint32_t)col / pw;
+            if (col < prev_col) bad = 1;
+            if (ph != prev) atomicAdd(&pc[ph < phases ? ph : phases - 1], 1u);
+            prev = ph; prev_col = col;
         }
-        total += c;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { total += __shfl_xor(total, o); bad |= __shfl_xor(bad, o); }
-    if (lane == 0) {
-        total += pad_cnt[k] > 0 ? 1u : 0u;
-        cnt[k] = total;
-        desc[k].y = total;
-        atomicMax(&flags[1], total);
-        if (bad) atomicOr(&flags[0], 1u);
+    if (bad) sbad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t p = 0; p < phases; p++) { const uint32_t c = pc[p]; pcnt[(size_t)k * phases + p] = run; run += c; }
+        run += pad_cnt[k] > 0 ? 1u : 0u;
+        cnt[k] = run;
+        desc[k].y = run;
+        atomicMax(&flags[1], run);
+        if (sbad) atomicOr(&flags[0], 1u);
     }
 }
 
-// first position in cidx[a, z) whose column is >= bound (columns ascending)
-__device__ __forceinline__ int64_t lower_col(const int32_t *cidx, int64_t a, int64_t z, uint64_t bound)
+// first position in cols[a, z) whose column is >= bound (columns ascending)
+__device__ __forceinline__ uint32_t lower_col(const int32_t *cols, uint32_t a, uint32_t z, uint64_t bound)
 {
     while (a < z) {
-        const int64_t mid = (a + z) >> 1;
-        if ((uint64_t)(uint32_t)cidx[mid] < bound) a = mid + 1; else z = mid;
+        const uint32_t mid = (a + z) >> 1;
+        if ((uint64_t)(uint32_t)cols[mid] < bound) a = mid + 1; else z = mid;
     }
     return a;
 }
 
-__global__ __launch_bounds__(kLanes) void seg_fill_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
+// pass 2: wavefront w of the chunk's workgroup writes the segments of phases w, w + 8, ...: rows in order, ballot compaction
+__global__ __launch_bounds__(kLanes * kSegWaves) void seg_fill_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
                                                           const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
                                                           const uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, uint32_t nchunks,
-                                                          uint32_t pw, uint32_t phases, int64_t *__restrict__ seg_begin,
-                                                          uint32_t *__restrict__ seg_len, uint16_t *__restrict__ seg_row)
+                                                          uint32_t pw, uint32_t phases, const uint32_t *__restrict__ pcnt, int64_t *__restrict__ seg_begin,
+                                                          uint32_t *__restrict__ seg_len, uint16_t *__restrict__ seg_row, const uint32_t *__restrict__ flags)
 {
-    const uint32_t k = blockIdx.x, lane = threadIdx.x;
+    if (flags[0] & 1u) return;      // unsorted rows (found by the count pass): nothing to fill
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t k = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     if (k >= nchunks) return;
     const int64_t  b = nzb[k], e = nzb[k + 1];
-    const uint32_t row_first = desc[k].x, nri = desc2[k].y;
-    uint32_t       q = desc2[k].x;
-    for (uint32_t p = 0; p < phases; p++) {
-        const uint64_t c0 = (uint64_t)p * pw, c1 = c0 + pw;
+    const uint32_t row_first = desc[k].x, nri = desc2[k].y, sbase = desc2[k].x;
+    const SegStage st = seg_stage(smem, rp, cidx, b, e, row_first, nri);
+    for (uint32_t p = wv; p < phases; p += kSegWaves) {
+        const uint64_t c0 = (uint64_t)p * pw, c1 = p + 1 == phases ? ~0ull : c0 + pw;
+        uint32_t       q = sbase + pcnt[(size_t)k * phases + p];
         for (uint32_t r0 = 0; r0 < nri; r0 += kLanes) {
             const uint32_t i = r0 + lane;
             bool           has = false;
             int64_t        beg = -1;
             uint32_t       len = 1;
             if (i < nri) {
-                int64_t a, z;
-                row_piece(rp, row_first + i, b, e, a, z);
+                const uint32_t a = st.pa[i], z = st.pz[i];
                 if (z <= a) has = p == 0;
                 else {
-                    const int64_t lo = lower_col(cidx, a, z, c0), hi = lower_col(cidx, lo, z, c1);
-                    if (hi > lo) { has = true; beg = lo; len = (uint32_t)(hi - lo); }
+                    const uint32_t lo = lower_col(st.cols, a, z, c0), hi = lower_col(st.cols, lo, z, c1);
+                    if (hi > lo) { has = true; beg = b + lo; len = hi - lo; }
                 }
             }
             const uint64_t m = __ballot(has);
@@ -266,7 +310,10 @@ __global__ __launch_bounds__(kLanes) void seg_fill_kernel(const int64_t *__restr
         }
     }
     const uint32_t pc = pad_cnt[k];
-    if (pc > 0 && lane == 0) { seg_begin[q] = -1; seg_len[q] = pc; seg_row[q] = (uint16_t)nri; }
+    if (pc > 0 && threadIdx.x == 0) {
+        const uint32_t q = sbase + desc[k].y - 1;
+        seg_begin[q] = -1; seg_len[q] = pc; seg_row[q] = (uint16_t)nri;
+    }
 }
 
 // exclusive scan of the per-chunk segment counts, one workgroup (a few thousand to a few hundred thousand chunks)
@@ -321,6 +368,41 @@ __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__
         uint32_t       wb = ((*best >> 32) ? s << binshift : 0) & ~3u;       // 16-byte aligned for the staging loads
         if (wb + wn > ncols1) wb = ncols1 > wn ? (ncols1 - wn) & ~3u : 0;   // keep the window inside x_ext, 16-byte aligned
         win_base[blockIdx.x] = wb;
+    }
+}
+
+// Probe for cvr_create's automatic choice of the workgroup layout: over all rows, (a) are the columns of every row in
+// ascending order (column phases need it), (b) how many non-zeros lie within `half` columns of the row's place on the
+// diagonal (row * ncols / nrows): what an LDS window of x per workgroup would serve.  out[0] = unsorted flag,
+// out[1..2] = near-diagonal count (low, high word of a 64-bit counter).
+__global__ __launch_bounds__(256) void probe_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ ci, uint32_t nrows,
+                                                    double col_per_row, uint32_t half, unsigned long long *__restrict__ out)
+{
+    // a workgroup takes 256 consecutive rows: their non-zeros are one contiguous range, read coalesced; the row of an
+    // element is found by binary search in the 257 row pointers staged in LDS
+    __shared__ int64_t srp[257];
+    unsigned long long near = 0;
+    uint32_t           bad = 0;
+    for (uint32_t r0 = blockIdx.x * 256; r0 < nrows; r0 += gridDim.x * 256) {
+        const uint32_t nr = nrows - r0 < 256 ? nrows - r0 : 256;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i <= nr; i += 256) srp[i] = rp[r0 + i];
+        __syncthreads();
+        const int64_t a = srp[0], z = srp[nr];
+        for (int64_t j = a + threadIdx.x; j < z; j += 256) {
+            uint32_t lo = 0, hi = nr;                     // last row whose pointer is <= j
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (srp[mid] <= j) lo = mid; else hi = mid; }
+            const int32_t c = ci[j];
+            if (j > srp[lo] && ci[j - 1] > c) bad = 1;
+            const int64_t d = (int64_t)c - (int64_t)((double)(r0 + lo) * col_per_row);
+            if ((d < 0 ? -d : d) <= (int64_t)half) near++;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { near += __shfl_xor(near, o); bad |= __shfl_xor(bad, o); }
+    if ((threadIdx.x & 63u) == 0) {
+        if (near) atomicAdd(&out[1], near);
+        if (bad) atomicOr(&out[0], 1ull);
     }
 }
 
@@ -391,6 +473,14 @@ __global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ va
 
 }  // namespace
 
+hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st)
+{
+    if (nrows <= 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<int64_t>(4096, (nrows + 255) / 256);
+    hipLaunchKernelGGL(probe_kernel, dim3(blocks), dim3(256), 0, st, rp, ci, (uint32_t)nrows, (double)ncols / (double)nrows, half, out2);
+    return hipGetLastError();
+}
+
 hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st)
 {
     if (n1 <= n0) return hipSuccess;
@@ -409,11 +499,17 @@ hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, 
     return hipGetLastError();
 }
 
+static size_t seg_lds_bytes(const DeviceImage &img)
+{
+    const size_t cap = (size_t)kLanes * img.S;
+    return 8 * (size_t)img.ystage + (cap <= kSegLdsCols ? 4 * cap : 0) + 16;       // row pieces (at most ystage - 1 rows) + columns
+}
+
 hipError_t launch_seg_count(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s)
 {
     if (img.nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(seg_count_kernel, dim3(img.nchunks), dim3(kLanes), 0, s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
-                       img.desc2, img.nchunks, img.phase_width, st.cnt, st.flags);
+    hipLaunchKernelGGL(seg_count_kernel, dim3(img.nchunks), dim3(256), seg_lds_bytes(img), s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
+                       img.desc2, img.nchunks, img.phase_width, img.phases, st.cnt, st.pcnt, st.flags);
     return hipGetLastError();
 }
 
@@ -427,8 +523,8 @@ hipError_t launch_seg_scan(const DeviceImage &img, SegTable &st, hipStream_t s)
 hipError_t launch_seg_fill(const DeviceImage &img, const DeviceCsr &csr, const SegTable &st, hipStream_t s)
 {
     if (img.nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(seg_fill_kernel, dim3(img.nchunks), dim3(kLanes), 0, s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
-                       img.desc2, img.nchunks, img.phase_width, img.phases, st.begin, st.len, st.row);
+    hipLaunchKernelGGL(seg_fill_kernel, dim3(img.nchunks), dim3(kLanes * kSegWaves), seg_lds_bytes(img), s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
+                       img.desc2, img.nchunks, img.phase_width, img.phases, st.pcnt, st.begin, st.len, st.row, st.flags);
     return hipGetLastError();
 }
 
@@ -441,7 +537,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     hipLaunchKernelGGL((convert_kernel<T, DI, SG>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
                        csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
                        static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, \
-                       seg ? seg->row : nullptr, img.col_bits)
+                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr)
 #define CVR_CONVERT_SG(T, DI) do { if (seg) CVR_CONVERT(T, DI, true); else CVR_CONVERT(T, DI, false); } while (0)
     if (img.f32) { if (img.dict) CVR_CONVERT_SG(float, true); else CVR_CONVERT_SG(float, false); }
     else         { if (img.dict) CVR_CONVERT_SG(double, true); else CVR_CONVERT_SG(double, false); }

@@ -20,7 +20,7 @@ struct DeviceImage {
     int64_t *shared = nullptr;   // [nshared][3] {row, c0, c1}
     uint32_t nshared = 0;
     int      xcd_swizzle = 1;       // 0 off, 1 contiguous chunk range per XCD, 2 additionally consecutive chunks per CU (experiment)
-    int      stream_policy = 0;     // buffer-load cache policy of the matrix stream: 0 default, 2 nt
+    int      stream_ahead = 1;      // groups the matrix stream runs ahead of the x gather: 1, or 3 (>= 2)
     uint32_t ystage = 1024;         // row sums a wavefront stages in LDS (multiple of 64, <= kYStageMax)
     int      depth = 1;             // groups the x gather runs ahead of the FMAs (1 or 2)
     const void *dict = nullptr;     // value dictionary: ndict values of T sorted by bit pattern (device), or null
@@ -50,6 +50,7 @@ struct DeviceCsr {
 // column phases: the segment table of every chunk, built on the device from the CSR and the plan
 struct SegTable {
     uint32_t *cnt = nullptr;        // [nchunks + 1] segments per chunk, then (exclusive scan) their offsets
+    uint32_t *pcnt = nullptr;       // [nchunks][phases] where the segments of a phase start inside the chunk's range
     int64_t  *begin = nullptr;      // [nseg_total] first CSR element of the segment, -1 = pad slots
     uint32_t *len = nullptr;        // [nseg_total] slots of the segment
     uint16_t *row = nullptr;        // [nseg_total] the chunk's row of the segment (rows-in-chunk = the pad segment's dump entry)
@@ -96,6 +97,8 @@ hipError_t launch_scale(void *x, const void *y, const double *norm2, int64_t n, 
 // dense[bd.b[p] + i] = padded[p * max_rows + i], i < bd.b[p+1] - bd.b[p]
 hipError_t launch_unpad(void *dense, const void *padded, const IterBounds &bd, int nparts, int64_t max_rows, bool f32, hipStream_t st);
 
+// rows sorted by column? how many non-zeros within `half` columns of the diagonal?  out2 = {unsorted flag, count} (device, zeroed by the caller)
+hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st);
 // min / max of col_idx[n0 .. n1) into minmax[0..1] (device; initialised by the caller to INT_MAX / INT_MIN)
 hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st);
 hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, unsigned long long *table, uint32_t *flags, hipStream_t st);

@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
 }
 
 // Cache-policy bits of a gfx950 buffer load (the `aux` immediate): sc0 = 1, nt = 2, sc1 = 16.
-constexpr int kPolDefault = 0, kPolNt = 2;
+constexpr int kPolDefault = 0;
 
 // Both the matrix stream and x are read through buffer descriptors: 32-bit offsets, the cache policy is an
 // immediate, and a load past num_records returns 0 without touching memory -- which lets the software
@@ -163,10 +163,15 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
                                           T *slot_lane, uint32_t row_first, uint32_t nseg, uint32_t head_dest,
                                           uint32_t last_dest, const T *dict, T *ystage, bool staged, uint32_t col_bits)
 {
+    // the four values first: with a dictionary they are LDS reads, which would otherwise be issued (and waited for) one by
+    // one between the steps' LDS writes
+    T av[kGroupSteps];
+#pragma unroll
+    for (int j = 0; j < kGroupSteps; j++) av[j] = val_of<T, DICT>(Q, j, dict);
 #pragma unroll
     for (int j = 0; j < kGroupSteps; j++) {
         const uint32_t cw = col_of(Q.c, j);
-        s.acc = fma_t(val_of<T, DICT>(Q, j, dict), x_of<T, WIN>(xq, j), s.acc);
+        s.acc = fma_t(av[j], x_of<T, WIN>(xq, j), s.acc);
         const bool     fl = (cw & kEndBit) != 0;
         const uint64_t m = __ballot(fl);
         if (m) {
@@ -199,7 +204,7 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
 
 // MW: more than one wavefront per workgroup (blockDim.x / 64 consecutive chunks share the workgroup's LDS window of x and its
 // dictionary copy); the single-wavefront form needs no barrier.
-template <typename T, int SPOL, int XPOL, int DEPTH, bool WIN, bool DICT, bool MW, bool SEGT>
+template <typename T, int QA, int XPOL, int DEPTH, bool WIN, bool DICT, bool MW, bool SEGT>
 __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv_kernel(
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
     const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
@@ -229,11 +234,13 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes);
     const uint32_t voff = lane * 16;
 
-    // software pipeline: the matrix stream runs DEPTH+1 groups ahead, the x gather DEPTH groups ahead
-    Group<T, DICT> Q[DEPTH + 1];
+    // software pipeline: the x gather runs DEPTH groups ahead of the FMAs, the matrix stream QA groups ahead of the gather
+    constexpr int  QN = DEPTH + QA;
+    constexpr int  SPOL = kPolDefault;
+    Group<T, DICT> Q[QN];
     X4<T>    xs[DEPTH];
 #pragma unroll
-    for (int i = 0; i <= DEPTH; i++) Q[i] = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)i * GB);
+    for (int i = 0; i < QN; i++) Q[i] = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)i * GB);
 
     // stage this workgroup's window of x in LDS: coalesced 16-byte loads, behind the first stream loads
     uint32_t wbase = 0;
@@ -285,12 +292,12 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     // every load is unconditional: past the end of the chunk the stream loads are out of range (zeros, no
     // traffic) and the gathers they feed all read x[0]
     for (int g = 0; g < G; g++) {
-        const Group<T, DICT> Qn = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)(g + DEPTH + 1) * GB);
+        const Group<T, DICT> Qn = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)(g + QN) * GB);
         const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn);
         sum_group<T, WIN, DICT, SEGT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged, col_bits);
 #pragma unroll
-        for (int i = 0; i < DEPTH; i++) Q[i] = Q[i + 1];
-        Q[DEPTH] = Qn;
+        for (int i = 0; i + 1 < QN; i++) Q[i] = Q[i + 1];
+        Q[QN - 1] = Qn;
 #pragma unroll
         for (int i = 0; i + 1 < DEPTH; i++) xs[i] = xs[i + 1];
         xs[DEPTH - 1] = xn;
@@ -442,7 +449,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     const bool   use_dict = img.dict != nullptr;
     const size_t lds = spmv_lds_bytes(img);
     if (lds > kLdsBytes) return hipErrorInvalidValue;      // build_part sizes the stage and the window to fit; never reached
-    // template parameters: <value type, stream cache policy, gather cache policy, gather run-ahead, LDS window, dictionary, multi-wave>
+    // template parameters: <value type, stream run-ahead beyond the gather, gather cache policy, gather run-ahead, LDS window, dictionary, multi-wave, column phases>
 #define CVR_LAUNCH(T, SP, D, W, DI, MW, SG)                                                                       \
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, SG>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
@@ -453,7 +460,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_PICK_MW(T, SP, D, W, true); else CVR_PICK_MW(T, SP, D, W, false); } while (0)
 #define CVR_PICK_W(T, SP, D)     do { if (use_win) CVR_PICK_DI(T, SP, D, true); else CVR_PICK_DI(T, SP, D, false); } while (0)
 #define CVR_PICK_D(T, SP)        do { if (img.depth == 2) CVR_PICK_W(T, SP, 2); else CVR_PICK_W(T, SP, 1); } while (0)
-#define CVR_PICK_SP(T)           do { if (img.stream_policy == kPolNt) CVR_PICK_D(T, kPolNt); else CVR_PICK_D(T, kPolDefault); } while (0)
+#define CVR_PICK_SP(T)           do { if (img.stream_ahead >= 2) CVR_PICK_D(T, 3); else CVR_PICK_D(T, 1); } while (0)
     if (img.f32) CVR_PICK_SP(float); else CVR_PICK_SP(double);
 #undef CVR_PICK_SP
 #undef CVR_PICK_D

@@ -71,7 +71,7 @@ typedef struct {
                                /* and serves its gathers from (cut to what fits the 160 KiB of */
                                /* LDS beside the row-sum stage); 0 = off (<0 = default = off)  */
     /* tuning / profiling knobs (tools/sweep.py); 0 = default */
-    int32_t stream_policy;     /* 2: nontemporal loads of the matrix stream (measured slower)  */
+    int32_t stream_ahead;      /* groups (of 4 steps) the matrix stream runs ahead of the x gather: 0 / 1 = one, >= 2 = three */
     int32_t waves_per_block;   /* wavefronts (= consecutive chunks) per SpMV workgroup, 1..16; 0 = default (1).  More than */
                                /* one pays only with x_window: the chunks of a workgroup share the staged window          */
     int32_t gather_depth;      /* groups (of 4 steps) the x gather runs ahead of the FMAs: 1 or 2 */
@@ -84,9 +84,16 @@ typedef struct {
                                   ranges), so that chunks running at the same time gather from the same slice of x and that
                                   slice stays in the L2s; the sums of a row's pieces are added up in LDS, every row is still
                                   written once.  For matrices whose chunks are all resident at once and whose x is larger
-                                  than an L2 (web-Google: 7.3 MB); needs ascending columns inside every row.  0 / 1 = off  */
-    int32_t reserved1;
+                                  than an L2 (web-Google: 7.3 MB); needs ascending columns inside every row.  0 / 1 = off,
+                                  <0 = auto (default)                                                                     */
+    int32_t layout_auto_resident;   /* internal (set by cvr_create, ignored on input): the automatic layout chose the
+                                  "resident" form -- every workgroup on a CU of its own at once                          */
 } cvr_options;
+/* Automatic layout: with steps_per_chunk = 0, waves_per_block = 0, x_window < 0 and col_phases < 0 (the defaults) cvr_create
+ * looks at the uploaded CSR on the device (are the rows sorted by column? which share of the non-zeros lies near the
+ * diagonal?) and, for matrices whose chunks can all be resident at once, picks 6-8 chunks per workgroup sharing a 64-KiB LDS
+ * window of x and/or column phases; everything else keeps one chunk per workgroup.  CVR_NO_AUTO_LAYOUT=1 in the environment
+ * or any explicit value of those four options switches it off. */
 
 typedef struct {
     int32_t iters;
@@ -113,6 +120,10 @@ typedef struct {
     int32_t lds_bytes;         /* dynamic LDS of one SpMV workgroup                                                     */
     int64_t nsegments;         /* column phases: (row, phase) segments over all chunks (0 otherwise)                    */
     int64_t chunk_row_cap;     /* column phases: most rows the planner gives a chunk (their sums live in LDS); 0 = none */
+    double  near_diagonal_share;   /* automatic layout: share of the non-zeros within a quarter window of the diagonal (0 if not probed) */
+    double  probe_s;               /* automatic layout: the device pass over the CSR (sortedness, near-diagonal share), 0 if not run */
+    double  dict_s;                /* the value-dictionary detection pass over the uploaded values (part of upload_s) */
+    double  preprocess_wall_s;     /* host wall time of cvr_preprocess: convert_s (device events) + its temporary allocations and the final sync */
 } cvr_info;
 
 void        cvr_default_options(cvr_options *opt);
@@ -155,6 +166,10 @@ int cvr_auto_panels(const cvr_csr_view *csr, double *l2_miss_estimate);
  * fastest depends on how the workgroups fall onto the CUs, and measuring beats the rule by 10-20 %.
  * Host arrays are uploaded once and every candidate is built from the device copy; *tuning_s counts as preprocessing time. */
 int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt, int32_t *best_steps, double *best_spmv_s, double *tuning_s);
+/* The same over the whole layout: besides S = 8 .. 64 with one chunk per workgroup it measures, for matrices small enough,
+ * the resident layout (8 or 4 chunks per workgroup, every workgroup on its own CU at once) with and without a 64-KiB LDS
+ * window of x and with and without column phases, and returns the fastest set of options in *best (pass it to cvr_create). */
+int cvr_tune(const cvr_csr_view *csr, const cvr_options *opt, cvr_options *best, double *best_spmv_s, double *tuning_s);
 
 /* ---- rows sharded over GPUs, one process per GPU: the exchange step ------------------------------------
  * The reference's threads share one y in host memory (spmv.cpp:1280-1282, 1640-1649); with one row shard per GPU

@@ -28,29 +28,27 @@ L.cmp_csr_destroy.argtypes = [C.c_void_p]
 KINDS = {0: "csr_vector (own)", 1: "rocsparse adaptive", 2: "rocsparse rowsplit"}
 
 
-def main():
-    name = sys.argv[1] if len(sys.argv) > 1 else "webgoogle"
-    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    if name == "webgoogle":
-        n, nc, rp, ci, va = synth.web_google_like()
-    elif name == "livejournal":
-        n, nc, rp, ci, va = synth.livejournal_like()
-    elif name.startswith("band"):
-        n, nc, rp, ci, va = synth.banded_sym(int(float(name[4:])))
-    elif name.startswith("rmat"):
-        n, nc, rp, ci, va = synth.rmat(int(name[4:]), dtype=np.float64)
-    else:
-        raise SystemExit("unknown matrix")
+def report(n, nc, rp, ci, va, iters=200, name="matrix"):
+    """the amortisation report of one matrix: CVR64 and the CSR comparators on the same GPU, every result checked against
+    the CSR oracle; I_pre with T_pre = planner + layout probe + dictionary scan + conversion (device-resident CSR), and with
+    the host-to-device upload of the CSR on top"""
     nnz = len(ci)
     x = synth.x_rand(nc)
     yref, absy = O.csr_spmv64(rp, ci, va, x)
     A = cvr_amd.CvrMatrix(n, nc, rp, ci, va)
     y, _ = A.spmv(x)
-    assert len(O.tol_check(y, yref, absy)[0]) == 0
+    cvr_ok = len(O.tol_check(y, yref, absy)[0]) == 0
     t_cvr = A.bench(20, iters)
-    t_pre = A.info.plan_s + A.info.convert_s
-    out = {"matrix": name, "rows": n, "nnz": nnz, "cvr": {"spmv_us": t_cvr * 1e6, "gflops": 2 * nnz / t_cvr / 1e9,
-           "preprocess_us": {"plan_host": A.info.plan_s * 1e6, "convert_device": A.info.convert_s * 1e6}}, "baselines": {}}
+    i = A.info
+    t_pre = i.plan_s + i.probe_s + i.dict_s + i.preprocess_wall_s
+    t_pre_h2d = i.plan_s + i.probe_s + i.upload_s + i.preprocess_wall_s          # upload_s holds the H2D copies and the dictionary scan
+    out = {"matrix": name, "rows": n, "nnz": nnz, "cvr": {"spmv_us": t_cvr * 1e6, "gflops": 2 * nnz / t_cvr / 1e9, "result_ok": cvr_ok,
+           "layout": {"steps_per_chunk": i.steps_per_chunk, "waves_per_workgroup": i.waves_per_block, "x_window": i.x_window, "col_phases": i.col_phases,
+                      "col_panels": i.col_panels, "value_dict": i.value_dict},
+           "preprocess_us": {"plan_host": i.plan_s * 1e6, "layout_probe": i.probe_s * 1e6, "dict_scan": i.dict_s * 1e6, "convert_device_events": i.convert_s * 1e6,
+                             "preprocess_wall": i.preprocess_wall_s * 1e6, "upload_incl_dict_scan": i.upload_s * 1e6, "total": t_pre * 1e6, "total_with_h2d": t_pre_h2d * 1e6}},
+           "baselines": {}}
+    A.close()
     h = C.c_void_p()
     rc = L.cmp_csr_create(C.byref(h), n, nc, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, 0, 0)
     assert rc == 0, L.cmp_last_error()
@@ -67,9 +65,26 @@ def main():
         gain = s.value - t_cvr
         out["baselines"][label] = {"spmv_us": s.value * 1e6, "gflops": 2 * nnz / s.value / 1e9, "own_preprocess_us": p.value * 1e6,
                                    "result_ok": ok, "cvr_speedup": s.value / t_cvr,
-                                   "I_pre_iterations": (t_pre / gain) if gain > 0 else None}
+                                   "I_pre_iterations": (t_pre / gain) if gain > 0 else None,
+                                   "I_pre_iterations_with_h2d": (t_pre_h2d / gain) if gain > 0 else None}
     L.cmp_csr_destroy(h)
-    print(json.dumps(out, indent=1))
+    return out
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "webgoogle"
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    if name == "webgoogle":
+        n, nc, rp, ci, va = synth.web_google_like()
+    elif name == "livejournal":
+        n, nc, rp, ci, va = synth.livejournal_like()
+    elif name.startswith("band"):
+        n, nc, rp, ci, va = synth.banded_sym(int(float(name[4:])))
+    elif name.startswith("rmat"):
+        n, nc, rp, ci, va = synth.rmat(int(name[4:]), dtype=np.float64)
+    else:
+        raise SystemExit("unknown matrix")
+    print(json.dumps(report(n, nc, rp, ci, va, iters, name), indent=1))
 
 
 if __name__ == "__main__":

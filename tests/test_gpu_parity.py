@@ -122,11 +122,11 @@ def test_fp32_path(name):
 
 
 @pytest.mark.parametrize("thr", [1, 16, 100000])
-@pytest.mark.parametrize("swz,nt", [(0, 0), (1, 1)])
+@pytest.mark.parametrize("swz,nt", [(0, 0), (1, 2)])
 def test_split_threshold_and_launch_options(thr, swz, nt):
     for name, S in (("power_law_3000", 8), ("two_giants", 16), ("dense_row_plus_singletons", 4)):
         nrows, ncols, rp, ci, va = CASES[name]
-        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, nontemporal=nt)
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, stream_ahead=nt)
         mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0)
         img = A.export_image()
         assert np.array_equal(img["image"], mir.image) and np.array_equal(img["shared"], mir.shared)
@@ -749,3 +749,87 @@ def test_minimal_c_example_builds_and_runs():
         r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
         assert r.stdout.startswith("y = 201 0 5043 600"), r.stdout
+
+
+def test_bench_starts_itself_for_two_ranks_on_one_device():
+    """python bench.py --gpus 2 with no torch.distributed environment starts one rank per GPU itself (here both on cuda:0 over
+    gloo, CVR_BENCH_ONE_DEVICE=1: the plumbing of the N > 1 path) and relays ONE line with n_gpus = 2 and a clean verdict"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVR_BENCH_ONE_DEVICE="1", CVR_BENCH_NO_TUNE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["verdict_wrong_rows"] == 0 and d["scaling"] == "strong"
+    assert len(d["config"]["rows_per_gpu"]) == 2 and sum(d["config"]["nnz_per_gpu"]) == 5105039
+
+
+def test_bench_device_built_workload():
+    """bench.py --workload rmat20: the matrix is built shard by shard on the GPU (cvr_amd/synth_dev.py), handed over as
+    device-resident CSR, and the timed configuration is checked on the device against a torch fp64 segment sum"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "rmat20", "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["verdict_wrong_rows"] == 0 and d["dtype"] == "f32" and d["n_gpus"] == 1
+    assert d["preprocess"]["workload_build_s"] < 20 and "R-MAT scale 20" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("name", ["livejournal", "banded3.5e6", "rmat22"])
+def test_full_size_shapes_every_row(name):
+    """BASELINE.json configs[2] (soc-LiveJournal1 shape, full size, column panels), the nlpkkt240 shape at one GPU's share of
+    8 (3.5 M rows, 94 M nnz) and R-MAT-22 fp32 (67 M nnz): every row against the CSR oracle, bitwise equal reruns"""
+    import time
+    t0 = time.time()
+    if name == "livejournal":
+        nrows, ncols, rp, ci, va = synth.livejournal_like()
+    elif name.startswith("banded"):
+        nrows, ncols, rp, ci, va = synth.banded_sym(int(float(name[6:])))
+    else:
+        from cvr_amd import synth_dev as D
+        import torch
+        t = D.rmat_rows(22, 0, 1 << 22, device="cuda")
+        nrows = ncols = 1 << 22
+        rp, ci, va = (a.cpu().numpy() for a in t)
+        del t
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    f32 = va.dtype == np.float32
+    x = synth.x_rand(ncols, va.dtype)
+    y, _ = A.spmv(x)
+    y2, _ = A.spmv(x)
+    nt = len(os.sched_getaffinity(0))
+    yref = cvr_amd.csr_spmv_host(rp, ci, va.astype(np.float64), x.astype(np.float64), nthreads=nt)      # the reference's CSR loop (spmv.cpp:1843-1850), OpenMP over rows
+    absy = cvr_amd.csr_spmv_host(rp, ci, np.abs(va).astype(np.float64), np.abs(x).astype(np.float64), nthreads=nt)
+    bad = np.nonzero(np.abs(y.astype(np.float64) - yref) > (TOL32 if f32 else TOL64) * absy + 1e-300)[0]
+    assert len(bad) == 0, (name, bad[:8])
+    assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))
+    if name == "livejournal":
+        assert A.info.col_panels > 1
+    A.close()
+    assert time.time() - t0 < 120, "time box"
+
+
+def test_amortisation_report_small():
+    """paper Eq. 1 / Table 4 (reference: run_comparison.sh:20-45): CVR64 against the CSR comparators on the same GPU, every
+    result checked against the oracle; I_pre with T_pre = planner + probe + dictionary scan + conversion, and with H2D"""
+    import compare_csr as R
+    nrows, ncols, rp, ci, va = synth.web_google_like(scale=0.1)
+    out = R.report(nrows, ncols, rp, ci, va, iters=50, name="webgoogle/10")
+    assert out["cvr"]["result_ok"]
+    pre = out["cvr"]["preprocess_us"]
+    assert pre["total"] >= pre["plan_host"] + pre["dict_scan"] + pre["convert_device_events"] and pre["total_with_h2d"] > pre["total"] - pre["dict_scan"]
+    assert len(out["baselines"]) == 3
+    for label, b in out["baselines"].items():
+        assert b.get("result_ok"), (label, b)
+        assert b["spmv_us"] > 0 and ("I_pre_iterations" in b)

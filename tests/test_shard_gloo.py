@@ -93,3 +93,69 @@ def test_sharded_spmv_world2_gloo(name):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _shard_local_worker(rank, world, port, q):
+    """every rank builds only its own row block of the large synthetic workloads (cvr_amd/synth_dev.py) and the blocks,
+    gathered over gloo, must equal the matrix built in one piece"""
+    import torch
+    import torch.distributed as dist
+    from cvr_amd import synth_dev as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scale = 12
+        deg = D.rmat_row_degrees(scale)
+        bounds, grp = D.partition_from_degrees(deg, world)
+        lrp, lci, lva = D.rmat_rows(scale, int(bounds[rank]), int(bounds[rank + 1]))
+        parts = [None] * world
+        dist.all_gather_object(parts, (lrp.numpy(), lci.numpy(), lva.numpy()))
+        nb, nnzb = D.banded_partition(3000, 13, world)
+        brp, bci, bva = D.banded_rows(3000, int(nb[rank]), int(nb[rank + 1]))
+        bparts = [None] * world
+        dist.all_gather_object(bparts, (brp.numpy(), bci.numpy(), bva.numpy()))
+        if rank == 0:
+            wrp, wci, wva = (t.numpy() for t in D.rmat_rows(scale, 0, 1 << scale))
+            ok = int(grp[-1]) == int(wrp[-1]) == 16 << scale
+            for p in range(world):
+                lo, hi = int(bounds[p]), int(bounds[p + 1])
+                a, b = int(wrp[lo]), int(wrp[hi])
+                ok &= np.array_equal(parts[p][0], wrp[lo:hi + 1] - a) and np.array_equal(parts[p][1], wci[a:b]) and np.array_equal(parts[p][2], wva[a:b])
+            nnz_per = [int(grp[bounds[p + 1]] - grp[bounds[p]]) for p in range(world)]
+            ok &= max(nnz_per) - min(nnz_per) <= int(deg.max())          # balanced up to one row
+            wb = [t.numpy() for t in D.banded_rows(3000, 0, 3000)]
+            ok &= int(wb[0][-1]) == nnzb
+            for p in range(world):
+                lo, hi = int(nb[p]), int(nb[p + 1])
+                a, b = int(wb[0][lo]), int(wb[0][hi])
+                ok &= np.array_equal(bparts[p][0], wb[0][lo:hi + 1] - a) and np.array_equal(bparts[p][1], wb[1][a:b]) and np.array_equal(bparts[p][2], wb[2][a:b])
+            q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_local_workloads_equal_slices_of_the_whole():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 1000
+    procs = [ctx.Process(target=_shard_local_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+    assert ok
+
+
+def test_synth_dev_matches_the_numpy_generators_where_defined():
+    import torch
+    from cvr_amd import synth, synth_dev as D
+    assert np.array_equal(D.x_rand(5000).numpy(), synth.x_rand(5000))
+    assert np.array_equal(D.x_rand(777, dtype=torch.float32).numpy(), synth.x_rand(777, np.float32))
+    n, nc, rp, ci, va = synth.banded_sym(400)
+    brp, bci, _ = D.banded_rows(400, 0, 400)
+    assert np.array_equal(brp.numpy(), rp) and np.array_equal(bci.numpy(), ci)
+    y, ay = D.csr_spmv_reference(brp, bci, torch.from_numpy(va), D.x_rand(400))
+    yref = np.array([np.dot(va[rp[r]:rp[r + 1]], synth.x_rand(400)[ci[rp[r]:rp[r + 1]]]) for r in range(400)])
+    assert np.allclose(y.numpy(), yref, rtol=0, atol=1e-13)

@@ -16,16 +16,16 @@ from cvr_amd import synth
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("matrix", nargs="?", default="webgoogle")
-    ap.add_argument("--S", default="8,16,32,64,128")
+    ap.add_argument("--S", default="8,16,32,64,128", help="0 = auto")
     ap.add_argument("--swz", default="1,0")
-    ap.add_argument("--nt", default="1,0")
+    ap.add_argument("--nt", default="0", help="stream run-ahead: 0|1 = one group beyond the gather, 2 = three")
     ap.add_argument("--thr", default="0")
     ap.add_argument("--depth", default="1")
     ap.add_argument("--win", default="-1", help="x window values staged in LDS per workgroup (-1 auto, 0 off)")
     ap.add_argument("--panels", default="-1", help="column panels (-1 auto, 1 off)")
     ap.add_argument("--wpb", default="0", help="wavefronts (consecutive chunks) per SpMV workgroup (0 = default 1)")
     ap.add_argument("--dict", default="-1", help="value dictionary (-1 auto, 0 off)")
-    ap.add_argument("--phases", default="0", help="column phases (0 / 1 off)")
+    ap.add_argument("--phases", default="0", help="column phases (0 / 1 off, -1 auto)")
     ap.add_argument("--check", action="store_true", help="compare y of every configuration with the host CSR loop")
     ap.add_argument("--colmask", default="0", help="comma list of hex masks: folds the x gather onto a small table (timing only)")
     ap.add_argument("--iters", type=int, default=300)
@@ -63,7 +63,7 @@ def main():
                                                    for dp in a.depth.split(",") for w in a.win.split(",") for pn in a.panels.split(",")
                                                    for vd in a.dict.split(",") for php in a.phases.split(",")]:
                     try:
-                        A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, nontemporal=nt,
+                        A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, stream_ahead=nt,
                                               debug_col_mask=cm, depth=dp, x_window=win, col_panels=pan, waves_per_block=wpb, value_dict=vd, col_phases=php)
                     except Exception as e:
                         print(f"  {S:4d} wpb {wpb} win {win}: {e}", flush=True)
@@ -81,7 +81,7 @@ def main():
                     s = A.bench(a.warmup, a.iters)
                     i = A.info
                     print(f"  {S:4d}  {swz}  {nt:2d}  {thr:6d}  {i.nchunks:6d} {i.nshared:5d}  {i.nslots / max(nnz, 1):8.4f}  {i.convert_s * 1e6:9.1f}  "
-                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  depth {dp} wpb {wpb} win {i.x_window} panels {i.col_panels} dict {i.value_dict} phases {i.col_phases} lds {i.lds_bytes}{wrong}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
+                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  depth {dp} wpb {wpb} win {i.x_window} panels {i.col_panels} dict {i.value_dict} phases {i.col_phases} lds {i.lds_bytes} pre_wall_us {i.preprocess_wall_s * 1e6:.0f} plan_us {i.plan_s * 1e6:.0f} probe_us {i.probe_s * 1e6:.0f}{wrong}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
                     A.close()
 
 
