@@ -564,6 +564,7 @@ def main():
                          "streamed_bytes_per_launch": streamed_local, "streamed_gbs": streamed_local / kern_s / 1e9,
                          "kernel_us_value_dict_off": None if kern_nodict_s is None else kern_nodict_s * 1e6,
                          "frac_value_dict_off": None if kern_nodict_s is None else balg_local / kern_nodict_s / 1e9 / HBM_PEAK_GBS},
+            "image_bytes": int(info.image_bytes),
             "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz, vbytes) / per / 1e9,
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
             "spmv_only_ms_max_over_ranks": kern_max_s * 1e3, "gflops_spmv_only_no_exchange": 2.0 * nnz / kern_max_s / 1e9,

@@ -135,6 +135,8 @@ struct cvr_handle {
     void     *d_y = nullptr;            // y_ext (1 part) or y (panels)
     size_t    vsz = 8;
     std::vector<hipEvent_t> events;
+    hipEvent_t z_free = nullptr;         // column panels: recorded after the combine pass; the next SpMV (on any stream) waits for it
+    bool       z_used = false;
 
     bool paneled() const { return parts.size() > 1; }
 };
@@ -142,16 +144,22 @@ struct cvr_handle {
 namespace {
 
 // y_ext = A x for the whole handle on `st`: one SpMV launch, or one per column panel followed by the combine
-hipError_t run_spmv(const cvr_handle *h, const void *x, void *y, hipStream_t st)
+hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
 {
     if (!h->paneled()) return h->parts.empty() ? hipSuccess : cvr::launch_spmv(h->parts[0].img, x, y, st);
+    // the panels' partial sums share one buffer (h->d_z): a launch on another stream must not start before the combine pass of
+    // the previous one has read them
+    if (h->z_used) { const hipError_t e = hipStreamWaitEvent(st, h->z_free, 0); if (e != hipSuccess) return e; }
     for (const Part &p : h->parts) {
         hipError_t e = cvr::launch_spmv(p.img, x, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * h->vsz, st, false);
         if (e != hipSuccess) return e;
     }
     hipError_t e = cvr::launch_fixup_multi(h->d_fixparts, (uint32_t)h->parts.size(), h->max_nshared, h->vsz == 4, st);
     if (e != hipSuccess) return e;
-    return cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st);
+    e = cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st);
+    if (e != hipSuccess) return e;
+    h->z_used = true;
+    return hipEventRecord(h->z_free, st);
 }
 
 }  // namespace
@@ -291,6 +299,7 @@ struct PartPlan {
     int64_t  stage = 64;           // row sums (column phases: row accumulators) per wavefront
     int      col_bits = 31;        // column phases: bits of a column index (the row field of a segment's last column word starts there)
     bool     lds_short = false;    // column phases do not fit beside the window
+    int      plan_threads = 0;     // 0: the planner's own small team; 1: the caller plans several images side by side
 };
 
 static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const cvr_options &opt)
@@ -326,7 +335,7 @@ static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, cons
         if (pp.stage < 64) { pp.lds_short = true; pp.phases = 1; pp.stage = 64; }
         else max_rows = pp.stage - 1;                 // + the dump entry of the pad segment
     }
-    pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold, max_rows);
+    pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold, max_rows, pp.plan_threads);
     const cvr::Plan &plan = pp.plan;
     const int64_t    nchunks = (int64_t)plan.chunks.size();
     pp.yext = nrows + 1 + 2 * nchunks;
@@ -402,14 +411,16 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
     }
     if (!best_w) return CVR_OK;
     const int64_t win = (64 * 1024) / vs;                       // 64 KiB of x per workgroup
-    unsigned long long *d_out = nullptr, out[2] = {0, 0};
-    HIP_TRY(hipMalloc(&d_out, sizeof(out)));
+    unsigned long long *d_out = nullptr;
+    std::vector<unsigned long long> outv(2 * cvr::kProbeBlocks, 0ull);
+    HIP_TRY(hipMalloc(&d_out, sizeof(unsigned long long) * outv.size()));
     HIP_TRY(hipStreamSynchronize(h->stream));          // the upload
     const double tp0 = now_s();
-    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(out), h->stream);
-    if (e == hipSuccess) e = cvr::launch_probe(part.d_rp, part.d_ci, nrows, ncols, (uint32_t)(win / 4), d_out, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, h->stream);
+    hipError_t e = cvr::launch_probe(part.d_rp, part.d_ci, nrows, ncols, (uint32_t)(win / 4), d_out, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(outv.data(), d_out, sizeof(unsigned long long) * outv.size(), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    unsigned long long out[2] = {0, 0};
+    for (uint32_t b = 0; b < cvr::kProbeBlocks; b++) { out[0] |= outv[2 * b]; out[1] += outv[2 * b + 1]; }
     h->info.probe_s = now_s() - tp0;
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(CVR_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
@@ -855,7 +866,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             const double tp = now_s();
             int T = (int)std::thread::hardware_concurrency();
             T = std::max(1, std::min(T, P));
-            auto work = [&](int t) { for (int p = t; p < P; p += T) plan_part(pps[(size_t)p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), panel_opt); };
+            auto work = [&](int t) { for (int p = t; p < P; p += T) { pps[(size_t)p].plan_threads = 1; plan_part(pps[(size_t)p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), panel_opt); } };
             std::vector<std::thread> th;
             for (int t = 1; t < T; t++) th.emplace_back(work, t);
             work(0);
@@ -896,6 +907,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }
         in.plan_s += now_s() - t1;
         clk.lap("  block offsets (host)");
+        CREATE_TRY(hipEventCreateWithFlags(&h->z_free, hipEventDisableTiming));
         CREATE_TRY(hipMalloc(&h->d_z, vsz * (size_t)std::max<int64_t>(zoff, 1)));
         CREATE_TRY(hipMalloc(&h->d_rows, sizeof(uint32_t) * (size_t)std::max<int64_t>(nsub, 1)));
         CREATE_TRY(hipMalloc(&h->d_block_off, sizeof(uint32_t) * block_off.size()));
@@ -1070,6 +1082,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Part &p : h->parts) p.release_all();
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    if (h->z_free) (void)hipEventDestroy(h->z_free);
     for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1084,6 +1097,7 @@ int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream)
 {
     if (!h || !x_dev || !y_dev) return fail(CVR_ERR_INVALID, "null argument");
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_spmv before cvr_preprocess");
+    HIP_TRY(hipSetDevice(h->device));          // the NULL stream means the current device's
     HIP_TRY(run_spmv(h, x_dev, y_dev, (hipStream_t)stream));
     return CVR_OK;
 }
@@ -1093,6 +1107,7 @@ int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *
     if (!h || !x_dev || !y_dev) return fail(CVR_ERR_INVALID, "null argument");
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_spmv before cvr_preprocess");
     const hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(h->device));
     for (int i = 0; i < n; i++) HIP_TRY(run_spmv(h, x_dev, y_dev, st));
     return CVR_OK;
 }
@@ -1239,6 +1254,7 @@ int cvr_spmv_gather_repeat(cvr_handle *h, cvr_comm *c, const void *x_dev, void *
     if (!api) return fail(CVR_ERR_NO_DEVICE, "RCCL not loaded");
     const hipStream_t    st = (hipStream_t)stream;
     const ncclDataType_t dt = h->vsz == 4 ? ncclFloat : ncclDouble;
+    HIP_TRY(hipSetDevice(h->device));
     for (int b = 0; b < 2; b++)     // gathers an earlier overlapped call left on the communicator's stream
         if (c->pending[b]) { HIP_TRY(hipStreamWaitEvent(st, c->done[b], 0)); c->pending[b] = false; }
     if (!overlap) {                 // everything in order on the caller's stream: two enqueues per step, no events

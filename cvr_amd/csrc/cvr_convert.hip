@@ -233,19 +233,42 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const int64_t *__restric
     if (threadIdx.x < 64) pc[threadIdx.x] = 0;
     if (threadIdx.x == 0) sbad = 0;
     const SegStage st = seg_stage(smem, rp, cidx, b, e, row_first, nri);
-    uint32_t bad = 0;
-    for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
-        const uint32_t a = st.pa[i], z = st.pz[i];
-        if (z <= a) { atomicAdd(&pc[0], 1u); continue; }            // an empty row owns one pad slot, fed with phase 0
-        int32_t  prev_col = st.cols[a];
-        uint32_t prev = (uint32_t)prev_col / pw;
-        atomicAdd(&pc[prev], 1u);
-        for (uint32_t j = a + 1; j < z; j++) {
+    uint32_t       bad = 0;
+    const uint32_t n = (uint32_t)(e - b);
+    if (n <= kSegLdsCols) {
+        // one thread per element (a long row would otherwise be walked by a single thread): an element starts a segment if it
+        // starts its row's piece or lies in another phase than its predecessor; row starts are flagged in LDS behind the columns
+        uint8_t *rstart = smem + 8 * (size_t)nri + 4 * (size_t)n;
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) rstart[j] = 0;
+        __syncthreads();
+        uint32_t empty = 0;
+        for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
+            if (st.pz[i] > st.pa[i]) rstart[st.pa[i]] = 1; else empty++;          // an empty row owns one pad slot, fed with phase 0
+        }
+        if (empty) atomicAdd(&pc[0], empty);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
             const int32_t  col = st.cols[j];
             const uint32_t ph = (uint32_t)col / pw;
+            if (rstart[j]) { atomicAdd(&pc[ph], 1u); continue; }
+            const int32_t prev_col = st.cols[j - 1];      // (j > 0 here: element 0 starts a row piece or belongs to no row of the chunk)
             if (col < prev_col) bad = 1;
-            if (ph != prev) atomicAdd(&pc[ph < phases ? ph : phases - 1], 1u);
-            prev = ph; prev_col = col;
+            if (ph != (uint32_t)prev_col / pw) atomicAdd(&pc[ph], 1u);
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
+            const uint32_t a = st.pa[i], z = st.pz[i];
+            if (z <= a) { atomicAdd(&pc[0], 1u); continue; }
+            int32_t  prev_col = st.cols[a];
+            uint32_t prev = (uint32_t)prev_col / pw;
+            atomicAdd(&pc[prev], 1u);
+            for (uint32_t j = a + 1; j < z; j++) {
+                const int32_t  col = st.cols[j];
+                const uint32_t ph = (uint32_t)col / pw;
+                if (col < prev_col) bad = 1;
+                if (ph != prev) atomicAdd(&pc[ph], 1u);
+                prev = ph; prev_col = col;
+            }
         }
     }
     if (bad) sbad = 1;
@@ -256,8 +279,7 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const int64_t *__restric
         run += pad_cnt[k] > 0 ? 1u : 0u;
         cnt[k] = run;
         desc[k].y = run;
-        atomicMax(&flags[1], run);
-        if (sbad) atomicOr(&flags[0], 1u);
+        if (sbad) atomicOr(&flags[0], 1u);      // (rare; no other same-address atomic here: thousands of workgroups on one word cost ~100 ns each)
     }
 }
 
@@ -400,9 +422,15 @@ __global__ __launch_bounds__(256) void probe_kernel(const int64_t *__restrict__ 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { near += __shfl_xor(near, o); bad |= __shfl_xor(bad, o); }
-    if ((threadIdx.x & 63u) == 0) {
-        if (near) atomicAdd(&out[1], near);
-        if (bad) atomicOr(&out[0], 1ull);
+    // one partial result per workgroup, summed by the host: same-address atomics from thousands of workgroups cost ~100 ns each
+    __shared__ unsigned long long wnear[4];
+    __shared__ uint32_t           wbad[4];
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) { wnear[threadIdx.x >> 6] = near; wbad[threadIdx.x >> 6] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = wbad[0] | wbad[1] | wbad[2] | wbad[3];
+        out[2 * blockIdx.x + 1] = wnear[0] + wnear[1] + wnear[2] + wnear[3];
     }
 }
 
@@ -476,7 +504,7 @@ __global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ va
 hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st)
 {
     if (nrows <= 0) return hipSuccess;
-    const uint32_t blocks = (uint32_t)std::min<int64_t>(4096, (nrows + 255) / 256);
+    const uint32_t blocks = kProbeBlocks;
     hipLaunchKernelGGL(probe_kernel, dim3(blocks), dim3(256), 0, st, rp, ci, (uint32_t)nrows, (double)ncols / (double)nrows, half, out2);
     return hipGetLastError();
 }
@@ -502,7 +530,7 @@ hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, 
 static size_t seg_lds_bytes(const DeviceImage &img)
 {
     const size_t cap = (size_t)kLanes * img.S;
-    return 8 * (size_t)img.ystage + (cap <= kSegLdsCols ? 4 * cap : 0) + 16;       // row pieces (at most ystage - 1 rows) + columns
+    return 8 * (size_t)img.ystage + (cap <= kSegLdsCols ? 5 * cap : 0) + 16;       // row pieces (at most ystage - 1 rows) + columns + row-start flags
 }
 
 hipError_t launch_seg_count(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s)

@@ -42,6 +42,7 @@ constexpr int      kGroupBytesDict = kColsBytes + kLanes * 4;  // 1280: column w
 constexpr int      kDictMax = 256;
 constexpr int      kYStageMax = 4096;   // most row sums a wavefront stages in LDS and writes out coalesced at the end of its chunk (32 KB of fp64)
 constexpr int      kWavesPerBlock = 1;   // converter / fix-up launches; the SpMV default: 1 wave per workgroup spreads the chunks most evenly over the CUs (profiles/r01_waves_per_block.log)
+constexpr int64_t  kPlanRowBlock = 65536;   // the planner restarts a chunk at every multiple of this many rows (blocks are planned in parallel)
 constexpr int      kMaxWavesPerBlock = 16;   // SpMV workgroups of several consecutive chunks share an LDS window of x (cvr_options.waves_per_block)
 constexpr size_t   kLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 

@@ -27,6 +27,7 @@ struct Plan {
 };
 
 int64_t plan_bound(int64_t nrows, int64_t nnz, int32_t S);
-Plan    plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_t split_threshold, int64_t max_rows = 0);
+// nthreads: host threads for the row blocks (0 = up to 8; 1 when the caller already runs one planner per thread)
+Plan    plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_t split_threshold, int64_t max_rows = 0, int nthreads = 0);
 
 }  // namespace cvr

@@ -29,6 +29,7 @@
 #include <string.h>
 
 #define W 64
+#define PLAN_ROW_BLOCK 65536
 
 typedef struct { int64_t nzb, row_first, nrows_in, nseg, pad; int head, tail; } chunk_t;
 
@@ -46,7 +47,9 @@ static int64_t plan(int64_t nrows, const int64_t *rp, int64_t cap, int64_t thr, 
         chunk_t c;
         c.row_first = r; c.nzb = rp[r] + off; c.head = off > 0;
         int64_t used = 0;
-        while (r < nrows) {
+        /* the walk restarts at every multiple of 65536 rows (the product plans these blocks in parallel): the chunk ends there */
+        const int64_t block_end = (r / PLAN_ROW_BLOCK + 1) * PLAN_ROW_BLOCK < nrows ? (r / PLAN_ROW_BLOCK + 1) * PLAN_ROW_BLOCK : nrows;
+        while (r < block_end) {
             if (r - c.row_first >= max_rows) break;        /* row cap (column phases): the rest is padding */
             const int64_t len = rp[r + 1] - rp[r] - off;
             const int64_t slots = len > 0 ? len : 1;

@@ -154,3 +154,27 @@ def test_product_planner_equals_mirror_on_random_row_lengths():
         yref, absy = O.csr_spmv64(rp, ci, va, x)
         bad, worst = O.tol_check(m.spmv(x), yref, absy + 1e-30)
         assert len(bad) == 0, (ctx, worst)
+
+
+@pytest.mark.parametrize("S,thr", [(8, 0), (32, 3)])
+def test_row_block_restarts_product_planner_equals_mirror(S, thr):
+    """more than 65 536 rows: the planner restarts at every row block (the blocks are planned by parallel threads in the
+    product, one after the other in the mirror): same chunks, and the mirror's y still equals the CSR oracle's"""
+    import cvr_amd
+    rng = np.random.default_rng(77)
+    lens = rng.integers(0, 9, size=150_000)
+    lens[rng.integers(0, len(lens), size=40)] = rng.integers(300, 3000, size=40)       # rows cut over chunks, some near block ends
+    lens[65535] = 2500
+    lens[131071] = 0
+    nrows, ncols, rp, ci, va = K.csr_from_lengths(lens, 5000, rng, sort=False)
+    m = O.Cvr64(nrows, ncols, rp, ci, va, S, thr)
+    p = cvr_amd.plan_chunks(rp, S, thr)
+    assert len(p["row_first"]) == m.nchunks
+    assert np.array_equal(p["nz_begin"], m.nz_begin) and np.array_equal(p["pad_cnt"], m.pad_cnt)
+    assert np.array_equal(p["row_first"], m.desc[:, 0].astype(np.int64)) and np.array_equal(p["nseg"], m.desc[:, 1].astype(np.int64))
+    starts = set(p["row_first"].tolist())
+    assert 65536 in starts and 131072 in starts                       # a chunk begins at every block boundary
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    bad, worst = O.tol_check(m.spmv(x), yref, absy)
+    assert len(bad) == 0, worst

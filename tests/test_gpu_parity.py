@@ -833,3 +833,30 @@ def test_amortisation_report_small():
     for label, b in out["baselines"].items():
         assert b.get("result_ok"), (label, b)
         assert b["spmv_us"] > 0 and ("I_pre_iterations" in b)
+
+
+def test_panelled_handle_on_two_streams_keeps_its_launches_apart():
+    """a handle with column panels keeps the panels' partial sums in one buffer: launches on two streams with different x must
+    not mix them (the library orders them with an event after the combine pass)"""
+    torch = pytest.importorskip("torch")
+    nrows, ncols, rp, ci, va = synth.livejournal_like(scale=0.05)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=16, col_panels=4)
+    assert A.info.col_panels == 4
+    dev = torch.device("cuda", 0)
+    xs, refs = [], []
+    for seed in (1, 2):
+        xh = np.random.default_rng(seed).random(ncols) * 2 - 1
+        x = torch.zeros(A.info.x_elems, dtype=torch.float64, device=dev)
+        x[:ncols] = torch.from_numpy(xh).to(dev)
+        xs.append(x)
+        refs.append(O.csr_spmv64(rp, ci, va, xh))
+    ys = [torch.zeros(A.info.yext_elems, dtype=torch.float64, device=dev) for _ in range(2)]
+    st = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(30):
+        for k in range(2):
+            A.spmv_device(xs[k].data_ptr(), ys[k].data_ptr(), st[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(2):
+        _assert_close(ys[k][:nrows].cpu().numpy(), refs[k][0], refs[k][1], TOL64, ("two streams", k))
+    A.close()
