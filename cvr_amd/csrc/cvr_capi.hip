@@ -111,6 +111,10 @@ struct Part {
         if (img.shared) (void)hipFree(img.shared);
         if (img.win_base) (void)hipFree(img.win_base);
         if (img.desc2) (void)hipFree(img.desc2);
+        if (img.hub_cols) (void)hipFree(img.hub_cols);
+        if (img.hub_index) (void)hipFree(img.hub_index);
+        if (img.hub_bitmap) (void)hipFree(img.hub_bitmap);
+        if (img.hub_x) (void)hipFree(img.hub_x);
         img = cvr::DeviceImage{};
     }
 };
@@ -146,7 +150,16 @@ namespace {
 // y_ext = A x for the whole handle on `st`: one SpMV launch, or one per column panel followed by the combine
 hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
 {
-    if (!h->paneled()) return h->parts.empty() ? hipSuccess : cvr::launch_spmv(h->parts[0].img, x, y, st);
+    if (!h->paneled()) {
+        if (h->parts.empty()) return hipSuccess;
+        if (h->parts[0].img.hub_n == 0) return cvr::launch_spmv(h->parts[0].img, x, y, st);
+        // the hub table's compacted copy of x is a buffer of the handle: launches on different streams are kept apart
+        if (h->z_used) { const hipError_t e = hipStreamWaitEvent(st, h->z_free, 0); if (e != hipSuccess) return e; }
+        const hipError_t e = cvr::launch_spmv(h->parts[0].img, x, y, st);
+        if (e != hipSuccess) return e;
+        h->z_used = true;
+        return hipEventRecord(h->z_free, st);
+    }
     // the panels' partial sums share one buffer (h->d_z): a launch on another stream must not start before the combine pass of
     // the previous one has read them
     if (h->z_used) { const hipError_t e = hipStreamWaitEvent(st, h->z_free, 0); if (e != hipSuccess) return e; }
@@ -181,6 +194,7 @@ void cvr_default_options(cvr_options *o)
     o->col_panels = -1;
     o->value_dict = -1;
     o->col_phases = -1;
+    o->hub_table = -1;
 }
 
 int cvr_device_count(void)
@@ -300,6 +314,7 @@ struct PartPlan {
     int      col_bits = 31;        // column phases: bits of a column index (the row field of a segment's last column word starts there)
     bool     lds_short = false;    // column phases do not fit beside the window
     int      plan_threads = 0;     // 0: the planner's own small team; 1: the caller plans several images side by side
+    int64_t  hub_n = 0;            // hub table entries staged in LDS in front of the window (decided before planning)
 };
 
 static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const cvr_options &opt)
@@ -312,6 +327,7 @@ static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, cons
     pp.wpb = std::min(std::max(opt.waves_per_block, 1), cvr::kMaxWavesPerBlock);
     pp.phases = std::min(std::max(opt.col_phases, 1), 64);
     if (ncols < 64 * pp.phases) pp.phases = 1;
+    if (pp.hub_n > 0) pp.phases = 1;               // (the hub flag and the row field of a phased image share bits of the column word)
     // LDS window of x per workgroup (off by default): `win` consecutive values of x staged with coalesced loads; gathers
     // inside it are served by ds_read instead of a 128-byte L1 fill each.
     pp.win = std::min<int64_t>(opt.x_window < 0 ? 0 : opt.x_window, ncols + 1) & ~(int64_t)3;      // whole 16-byte loads, inside x_ext
@@ -373,7 +389,7 @@ static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, cons
         // the window takes what it asked for, the stage at least 64 rows per wavefront, and whatever does not fit is cut:
         // first the stage down to 512 rows per wavefront, then the window.
         const int64_t total = (int64_t)cvr::kLdsBytes / vs;
-        const int64_t fixed = (int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + 4;     // dictionary room is reserved before it is known
+        const int64_t fixed = (int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + 4 + ((pp.hub_n + 3) & ~(int64_t)3);     // dictionary room is reserved before it is known
         int64_t stage = std::min<int64_t>(std::max<int64_t>((pp.max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
         if (fixed + pp.wpb * stage + pp.win > total) stage = std::max<int64_t>(std::min<int64_t>(stage, 512), ((total - fixed - pp.win) / pp.wpb) & ~(int64_t)63);
         if (stage < 64) stage = 64;
@@ -439,6 +455,36 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
     return CVR_OK;
 }
 
+// Hub table (cvr_hub.hip): hub_table > 0 asks for that many entries, < 0 decides: matrices too large for the resident layout
+// whose x does not fit an L2 get the columns counted on the device, and the table is used when the columns that fit the LDS
+// (beside 8 chunks' row stages) hold at least half of the (sampled) non-zeros -- R-MAT scale 22 fp32: 0.56, 402 -> 289 us;
+// fp64 (half as many entries fit): 0.41, where the table loses (profiles/r02_hub_table_rmat.log).  The workgroup then has 8 chunks.
+static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, cvr_options &opt, PartPlan &pp)
+{
+    if (opt.hub_table == 0 || opt.layout_auto_resident || opt.col_phases > 1 || nrows <= 0 || ncols >= (int64_t)cvr::kHubBit) return CVR_OK;
+    const int64_t vs = f32 ? 4 : 8, nnz = rp[nrows] - rp[0];
+    const bool    automatic = opt.hub_table < 0;
+    if (automatic && (opt.waves_per_block != 0 || opt.x_window > 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT") || (double)ncols * vs < 6e6 || nnz < (8 << 20))) return CVR_OK;
+    const int     wpb = opt.waves_per_block > 0 ? std::min(opt.waves_per_block, cvr::kMaxWavesPerBlock) : 8;
+    const int64_t win = std::max(opt.x_window, 0);
+    int64_t       room = ((int64_t)cvr::kLdsBytes / vs - (int64_t)wpb * (cvr::kLanes + 512) - cvr::kDictMax - win - 8) & ~(int64_t)1023;      // 512 staged row sums per chunk
+    if (room < 1024) return automatic ? CVR_OK : fail(CVR_ERR_INVALID, "hub_table: no LDS left beside %d chunks per workgroup and the x window", wpb);
+    if (!automatic) room = std::min<int64_t>(room, opt.hub_table);
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the upload
+    const double t0 = now_s();
+    cvr::HubSelection sel;
+    const hipError_t  e = cvr::select_hubs(d_ci, rp[0], rp[nrows], ncols, (uint32_t)room, &sel, h->stream);
+    h->info.hub_select_s += now_s() - t0;
+    if (e != hipSuccess) { cvr::free_hubs(sel); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
+    h->info.hub_share = std::max(h->info.hub_share, sel.share);
+    if (sel.H == 0 || (automatic && sel.share < 0.5)) { cvr::free_hubs(sel); return CVR_OK; }
+    part.img.hub_n = sel.H; part.img.hub_cols = sel.hub_cols; part.img.hub_index = sel.hub_index; part.img.hub_bitmap = sel.hub_bitmap;
+    HIP_TRY(hipMalloc(&part.img.hub_x, (size_t)vs * ((sel.H + 3u) & ~3u)));
+    pp.hub_n = sel.H;
+    if (opt.waves_per_block == 0) opt.waves_per_block = wpb;
+    return CVR_OK;
+}
+
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
 static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
                       hipMemcpyKind civa_kind, bool f32, const cvr_options &opt, double *plan_s, PartPlan *planned = nullptr)
@@ -459,13 +505,15 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     if (!planned) {
         int rc = auto_layout(h, part, nrows, ncols, f32, rp, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
         if (rc) return rc;
+        rc = choose_hubs(h, part, part.d_ci, nrows, ncols, f32, rp, popt, local);
+        if (rc) return rc;
         const double t0 = now_s();
         plan_part(local, nrows, ncols, f32, rp, popt);
         // the resident layout wants every workgroup on a CU of its own at once: one more step per chunk until they fit
         while (popt.layout_auto_resident && !local.too_large && (int64_t)local.plan.chunks.size() > (int64_t)local.wpb * 256 && popt.steps_per_chunk < 4096) {
             popt.steps_per_chunk += 4;
             local = PartPlan();
-            plan_part(local, nrows, ncols, f32, rp, popt);
+            plan_part(local, nrows, ncols, f32, rp, popt);      // (the resident layout has no hub table: nothing of `local` to keep)
         }
         if (plan_s) *plan_s += now_s() - t0;
         planned = &local;
@@ -862,11 +910,18 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         std::vector<PartPlan> pps((size_t)P);
         cvr_options           panel_opt = opt;
         panel_opt.col_phases = 1;          // column phases are for the single image whose chunks are all resident at once
+        std::vector<cvr_options> popts((size_t)P, panel_opt);
+        if (dev_split)                     // hub tables per panel: the most popular columns of the panel's own range
+            for (int p = 0; p < P; p++) {
+                rc = choose_hubs(h, h->parts[(size_t)p], dsg.d.ci + dsg.d.off[p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), popts[(size_t)p], pps[(size_t)p]);
+                if (rc) { cvr_destroy(h); return rc; }
+            }
+        clk.lap("  hub tables of the panels");
         {
             const double tp = now_s();
             int T = (int)std::thread::hardware_concurrency();
             T = std::max(1, std::min(T, P));
-            auto work = [&](int t) { for (int p = t; p < P; p += T) { pps[(size_t)p].plan_threads = 1; plan_part(pps[(size_t)p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), panel_opt); } };
+            auto work = [&](int t) { for (int p = t; p < P; p += T) { pps[(size_t)p].plan_threads = 1; plan_part(pps[(size_t)p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), popts[(size_t)p]); } };
             std::vector<std::thread> th;
             for (int t = 1; t < T; t++) th.emplace_back(work, t);
             work(0);
@@ -879,10 +934,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             Part &part = h->parts[(size_t)p];
             if (dev_split)
                 rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), dsg.d.ci + dsg.d.off[p],
-                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, panel_opt, &in.plan_s, &pps[(size_t)p]);
+                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p]);
             else
                 rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
-                                sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, panel_opt, &in.plan_s, &pps[(size_t)p]);
+                                sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p]);
             if (rc) { cvr_destroy(h); return rc; }
             part.zoff = zoff;
             zoff += part.yext;
@@ -980,6 +1035,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     in.dict_s = now_s() - t_dict0;
     clk.lap("value dictionary scan");
     for (Part &p : h->parts) { rc = finish_part(h, p); if (rc) { cvr_destroy(h); return rc; } }
+    for (const Part &p : h->parts) in.hub_entries = std::max<int32_t>(in.hub_entries, (int32_t)p.img.hub_n);
+    if (!h->z_free && in.hub_entries) CREATE_TRY(hipEventCreateWithFlags(&h->z_free, hipEventDisableTiming));
     in.steps_per_chunk = h->parts[0].img.S;
     in.col_phases = (int32_t)h->parts[0].img.phases; in.waves_per_block = (int32_t)h->parts[0].img.wpb; in.x_window = (int32_t)h->parts[0].img.win_elems;
     in.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     uint8_t *__restrict__ stream, uint8_t *__restrict__ target, uint32_t *__restrict__ err, int G,
     uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
     const uint2 *__restrict__ desc2, const int64_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
-    const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags)
+    const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags, const int32_t *__restrict__ hub_index, const uint32_t *__restrict__ hub_bitmap)
 {
     if constexpr (SEGT) { if (seg_flags[0] & 1u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
     constexpr int GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
@@ -138,7 +138,10 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
             }
             uint32_t c = pad_col;
             T        v = 0;
-            if (pos >= 0) { c = (uint32_t)cidx[pos]; v = vals[pos]; pos++; }
+            if (pos >= 0) {
+                c = (uint32_t)cidx[pos]; v = vals[pos]; pos++;
+                if (hub_index && ((hub_bitmap[c >> 5] >> (c & 31u)) & 1u)) c = kHubBit | (uint32_t)hub_index[c];     // hub column: its index in the LDS table
+            }
             cw[j] = c | (cnt == 1 ? kEndBit | rowtag : 0u);
             vv[j] = v;
             cnt--;
@@ -565,7 +568,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     hipLaunchKernelGGL((convert_kernel<T, DI, SG>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
                        csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
                        static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, \
-                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr)
+                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap)
 #define CVR_CONVERT_SG(T, DI) do { if (seg) CVR_CONVERT(T, DI, true); else CVR_CONVERT(T, DI, false); } while (0)
     if (img.f32) { if (img.dict) CVR_CONVERT_SG(float, true); else CVR_CONVERT_SG(float, false); }
     else         { if (img.dict) CVR_CONVERT_SG(double, true); else CVR_CONVERT_SG(double, false); }

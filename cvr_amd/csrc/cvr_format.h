@@ -34,6 +34,7 @@ namespace cvr {
 constexpr int      kLanes        = 64;
 constexpr uint32_t kEndBit       = 0x80000000u;
 constexpr uint32_t kColMask      = 0x7fffffffu;
+constexpr uint32_t kHubBit       = 0x40000000u;   // hub table: the column field is an index into the LDS copy of x[hub columns]
 constexpr int      kGroupSteps   = 4;
 constexpr int      kColsBytes    = kLanes * 16;            // 1024
 constexpr int      kGroupBytes64 = kColsBytes + kLanes * 32;  // 3072

@@ -21,6 +21,8 @@
 //     fixup_kernel (bitwise reproducible); column panels add their partial sums in panel order (combine_kernel).
 #include "cvr_kernels.h"
 
+#include <algorithm>
+
 namespace cvr {
 namespace {
 
@@ -83,7 +85,7 @@ __device__ __forceinline__ T load_x(__amdgpu_buffer_rsrc_t rx, uint32_t col)
 // where the value is used (x_of), so that both loads stay in flight until then.
 template <typename T, int POL, bool WIN>
 __device__ __forceinline__ X4<T> gather(__amdgpu_buffer_rsrc_t rx, const T *win, const u32x4 c, const uint32_t mask,
-                                        const uint32_t wbase, const uint32_t wn)
+                                        const uint32_t wbase, const uint32_t wn, const uint32_t hub_n)
 {
     X4<T>          r;
     const uint32_t col[4] = {c.x & mask, c.y & mask, c.z & mask, c.w & mask};
@@ -91,12 +93,16 @@ __device__ __forceinline__ X4<T> gather(__amdgpu_buffer_rsrc_t rx, const T *win,
 #pragma unroll
         for (int j = 0; j < 4; j++) r.v[j] = load_x<T, POL>(rx, col[j]);
     } else {
+        // LDS: [hub table (hub_n) | window of x (wn) | zeros].  A slot of a hub column holds kHubBit and the table index.
+        const uint32_t raw[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t rel = col[j] - wbase;
+            const bool     hub = (raw[j] & kHubBit) != 0 && hub_n != 0;
+            const uint32_t cj = hub_n ? col[j] & (kHubBit - 1u) : col[j];
+            const uint32_t rel = cj - wbase;
             const bool     in = rel < wn;
-            r.v[j] = load_x<T, POL>(rx, in ? 0x3fffffffu : col[j]);   // 0x3fffffff * sizeof(T) is past num_records
-            r.w[j] = win[in ? rel : wn];
+            r.v[j] = load_x<T, POL>(rx, hub || in ? 0x3fffffffu : cj);   // 0x3fffffff * sizeof(T) is past num_records
+            r.w[j] = win[hub ? cj : hub_n + (in ? rel : wn)];
         }
     }
     return r;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
     const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
     uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict,
-    uint32_t ystage_n, const uint2 *__restrict__ desc2, uint32_t col_bits)
+    uint32_t ystage_n, const uint2 *__restrict__ desc2, uint32_t col_bits, const T *__restrict__ hub_x, uint32_t hub_n, uint32_t kstride)
 {
     constexpr int  GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     constexpr bool kSync = WIN || (DICT && MW);      // LDS filled by other waves of the workgroup
@@ -225,105 +231,124 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = MW ? threadIdx.x >> 6 : 0u;
     const uint32_t blk = remap_block(blockIdx.x, nblocks_per_xcd, swz);
-    const uint32_t k = __builtin_amdgcn_readfirstlane(blk * nw + wv);
+    uint32_t       k = __builtin_amdgcn_readfirstlane(blk * nw + wv);
     if (!kSync && k >= nchunks) return;
-    const bool live = k < nchunks;
+    bool live = k < nchunks;
 
-    const uint32_t cbytes = live ? (uint32_t)G * GB : 0u;             // a wave past the last chunk streams nothing
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G * GB), cbytes);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes);
     const uint32_t voff = lane * 16;
+    T *const       ystage = ystage_all + wv * ystage_n;
+    T *const       slot_lane = &slots[wv * kLanes + lane];
 
     // software pipeline: the x gather runs DEPTH groups ahead of the FMAs, the matrix stream QA groups ahead of the gather
     constexpr int  QN = DEPTH + QA;
     constexpr int  SPOL = kPolDefault;
     Group<T, DICT> Q[QN];
-    X4<T>    xs[DEPTH];
+    X4<T>          xs[DEPTH];
+    __amdgpu_buffer_rsrc_t rs;
+    uint4          d;
+    uint32_t       nri = 0;                            // SEGT: rows with a segment in this chunk
+    // the first loads of chunk k: its stream (a wave past the last chunk streams nothing), its descriptor
+    auto begin_chunk = [&]() {
+        rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G * GB), live ? (uint32_t)G * GB : 0u);
 #pragma unroll
-    for (int i = 0; i < QN; i++) Q[i] = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)i * GB);
+        for (int i = 0; i < QN; i++) Q[i] = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)i * GB);
+        d = live ? desc[k] : uint4{0, 0, 0, 0};
+        if constexpr (SEGT) {
+            if (live) {
+                nri = desc2[k].y;
+                for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);                 // the row accumulators (+ the dump entry)
+            }
+        }
+    };
+    begin_chunk();
 
-    // stage this workgroup's window of x in LDS: coalesced 16-byte loads, behind the first stream loads
+    // stage the dictionary, the hub table and this workgroup's window of x in LDS: coalesced 16-byte loads, behind the first stream loads
     uint32_t wbase = 0;
     if constexpr (DICT)
         for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += blockDim.x) dict[i] = i < ndict ? dict_g[i] : T(0);
     if constexpr (WIN) {
         constexpr uint32_t kPer = 16 / sizeof(T);                      // values per 16-byte load; wbase and wn are multiples of it
-        wbase = blk * nw < nchunks ? win_base[blk] : 0u;
+        wbase = wn && blk * nw < nchunks ? win_base[blk] : 0u;
+        for (uint32_t i = threadIdx.x * kPer; i < hub_n; i += blockDim.x * kPer)          // the hub table (hub_x is padded to whole 16 bytes)
+            *reinterpret_cast<u32x4 *>(win + i) = *reinterpret_cast<const u32x4 *>(hub_x + i);
+        const uint32_t hpad = (hub_n + 3u) & ~3u;
         for (uint32_t i = threadIdx.x * kPer; i < wn; i += blockDim.x * kPer) {
             const u32x4 q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (wbase + i) * (uint32_t)sizeof(T), 0, kPolDefault));
-            *reinterpret_cast<u32x4 *>(win + i) = q;
+            *reinterpret_cast<u32x4 *>(win + hpad + i) = q;
         }
-        if (threadIdx.x < 4) win[wn + threadIdx.x] = T(0);
-    }
-    const uint4 d = live ? desc[k] : uint4{0, 0, 0, 0};
-    const uint32_t row_first = d.x, nseg = d.y, head_dest = d.z, last_dest = d.w;
-    T *const        ystage = ystage_all + wv * ystage_n;
-    uint32_t        nri = 0;                           // SEGT: rows with a segment in this chunk
-    if constexpr (SEGT) {
-        if (live) {
-            nri = desc2[k].y;
-            for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);                     // the row accumulators (+ the dump entry)
-        }
+        if (threadIdx.x < 4) win[hpad + wn + threadIdx.x] = T(0);
     }
     if constexpr (kSync) {
         __syncthreads();
-        if (!live) return;
     } else if constexpr (DICT || SEGT) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // one wavefront per workgroup: its own LDS writes, in order
     }
-    const uint32_t tg = target[(size_t)k * kLanes + lane];
 
-    ChunkState<T> s;
-    s.acc = 0;
-    s.cur = lane;
-    s.currow = 0;
-    s.fed = nseg < kLanes ? nseg : kLanes;
-    s.feeding = lane < s.fed;
-    s.own = 0;
-    s.tail = s.fed == nseg;
-    T *slot_lane = &slots[wv * kLanes + lane];
-    // Row sums go to LDS and leave as coalesced stores at the end of the chunk (its rows are consecutive): the scattered
-    // 8-byte stores they replace cost 12 % of the kernel (profiles/r01_y_staging.log).  A chunk of more than ystage_n
-    // segments (very short rows) stores directly.
-    const bool staged = SEGT || nseg <= ystage_n;
-#pragma unroll
-    for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL, WIN>(rx, win, Q[i].c, cmask, wbase, wn);
+    // Persistent workgroups (kstride > 0; hub table without a per-workgroup window): the workgroup keeps its LDS tables and
+    // takes chunk groups blk, blk + gridDim.x, ...; no barrier past this point.  Otherwise one chunk per wavefront.
+    for (;;) {
+        if (!live) break;
+        const uint32_t row_first = d.x, nseg = d.y, head_dest = d.z, last_dest = d.w;
+        const uint32_t tg = target[(size_t)k * kLanes + lane];
 
-    // every load is unconditional: past the end of the chunk the stream loads are out of range (zeros, no
-    // traffic) and the gathers they feed all read x[0]
-    for (int g = 0; g < G; g++) {
-        const Group<T, DICT> Qn = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)(g + QN) * GB);
-        const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn);
-        sum_group<T, WIN, DICT, SEGT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged, col_bits);
+        ChunkState<T> s;
+        s.acc = 0;
+        s.cur = lane;
+        s.currow = 0;
+        s.fed = nseg < kLanes ? nseg : kLanes;
+        s.feeding = lane < s.fed;
+        s.own = 0;
+        s.tail = s.fed == nseg;
+        // Row sums go to LDS and leave as coalesced stores at the end of the chunk (its rows are consecutive): the scattered
+        // 8-byte stores they replace cost 12 % of the kernel (profiles/r01_y_staging.log).  A chunk of more than ystage_n
+        // segments (very short rows) stores directly.
+        const bool staged = SEGT || nseg <= ystage_n;
 #pragma unroll
-        for (int i = 0; i + 1 < QN; i++) Q[i] = Q[i + 1];
-        Q[QN - 1] = Qn;
-#pragma unroll
-        for (int i = 0; i + 1 < DEPTH; i++) xs[i] = xs[i + 1];
-        xs[DEPTH - 1] = xn;
-    }
+        for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL, WIN>(rx, win, Q[i].c, cmask, wbase, wn, (hub_n + 3u) & ~3u);
 
-    // tail records (spmv.cpp:1633-1638): stolen partial sums go to the victim's slot, owners store
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (tg != lane) __hip_atomic_fetch_add(&slots[wv * kLanes + tg], s.acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (s.own) {
-        if constexpr (SEGT) {
-            lds_add(ystage + s.currow, *slot_lane);
-        } else if (staged) {
-            ystage[s.cur] = *slot_lane;
-        } else {
-            const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
-            store_y(yext + dst, *slot_lane);
+        // every load is unconditional: past the end of the chunk the stream loads are out of range (zeros, no
+        // traffic) and the gathers they feed all read x[0]
+        for (int g = 0; g < G; g++) {
+            const Group<T, DICT> Qn = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)(g + QN) * GB);
+            const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn, (hub_n + 3u) & ~3u);
+            sum_group<T, WIN, DICT, SEGT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged, col_bits);
+#pragma unroll
+            for (int i = 0; i + 1 < QN; i++) Q[i] = Q[i + 1];
+            Q[QN - 1] = Qn;
+#pragma unroll
+            for (int i = 0; i + 1 < DEPTH; i++) xs[i] = xs[i + 1];
+            xs[DEPTH - 1] = xn;
         }
-    }
-    if (staged) {
+
+        // tail records (spmv.cpp:1633-1638): stolen partial sums go to the victim's slot, owners store
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const uint32_t nout = SEGT ? nri : nseg;      // SEGT: one entry per row of the chunk; else one per segment
-        for (uint32_t i = lane; i < nout; i += kLanes) {
-            const uint32_t dst = i == 0 ? head_dest : i == nout - 1 ? last_dest : row_first + i;
-            store_y(yext + dst, ystage[i]);
+        if (tg != lane) __hip_atomic_fetch_add(&slots[wv * kLanes + tg], s.acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (s.own) {
+            if constexpr (SEGT) {
+                lds_add(ystage + s.currow, *slot_lane);
+            } else if (staged) {
+                ystage[s.cur] = *slot_lane;
+            } else {
+                const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
+                store_y(yext + dst, *slot_lane);
+            }
         }
+        if (staged) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const uint32_t nout = SEGT ? nri : nseg;      // SEGT: one entry per row of the chunk; else one per segment
+            for (uint32_t i = lane; i < nout; i += kLanes) {
+                const uint32_t dst = i == 0 ? head_dest : i == nout - 1 ? last_dest : row_first + i;
+                store_y(yext + dst, ystage[i]);
+            }
+        }
+        if (kstride == 0) break;
+        k += kstride;
+        live = k < nchunks;
+        if (!live) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // this wave's stage and slots are reused by its next chunk
+        begin_chunk();
     }
 }
 
@@ -430,23 +455,31 @@ hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st)
 size_t spmv_lds_bytes(const DeviceImage &img)
 {
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;
-    const bool     use_win = img.win_elems > 0 && img.win_base != nullptr;
-    return (size_t)(wpb * (kLanes + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8) +
-           0;
+    const bool     use_win = (img.win_elems > 0 && img.win_base != nullptr) || img.hub_n > 0;
+    return (size_t)(wpb * (kLanes + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? ((img.hub_n + 3u) & ~3u) + img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8);
 }
 
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup)
 {
     if (img.nchunks == 0) return hipSuccess;
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;                     // consecutive chunks (wavefronts) per workgroup
-    const uint32_t nblocks = (img.nchunks + wpb - 1) / wpb;
+    uint32_t       nblocks = (img.nchunks + wpb - 1) / wpb;
+    // a hub table without a per-workgroup window: persistent workgroups (as many as fit the 256 CUs with this much LDS), each
+    // staging the table once and taking chunk groups blk, blk + grid, ...
+    uint32_t       kstride = 0;
+    if (img.hub_n > 0 && img.win_elems == 0 && img.xcd_swizzle != 2) {
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, kLdsBytes / std::max<size_t>(spmv_lds_bytes(img), 1));
+        const uint32_t resident = 256u * std::min<uint32_t>(per_cu, std::max<uint32_t>(1u, 16u / wpb));
+        if (nblocks > resident) { nblocks = resident; kstride = resident * wpb; }
+    }
     const uint32_t per_xcd = (nblocks + 7) / 8;
     const uint32_t grid = img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;
     const dim3     block(kLanes * wpb);
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
     if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
-    const bool   use_win = img.win_elems > 0 && img.win_base != nullptr;
+    const bool   use_win = (img.win_elems > 0 && img.win_base != nullptr) || img.hub_n > 0;
     const bool   use_dict = img.dict != nullptr;
+    if (img.hub_n) { const hipError_t eh = launch_hub_gather(img, x_ext, st); if (eh != hipSuccess) return eh; }
     const size_t lds = spmv_lds_bytes(img);
     if (lds > kLdsBytes) return hipErrorInvalidValue;      // build_part sizes the stage and the window to fit; never reached
     // template parameters: <value type, stream run-ahead beyond the gather, gather cache policy, gather run-ahead, LDS window, dictionary, multi-wave, column phases>
@@ -454,7 +487,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, SG>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
-                       static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits)
+                       static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(img.hub_x), img.hub_n, kstride)
 #define CVR_PICK_SG(T, SP, D, W, DI, MW) do { if (img.phases > 1) CVR_LAUNCH(T, SP, D, W, DI, MW, true); else CVR_LAUNCH(T, SP, D, W, DI, MW, false); } while (0)
 #define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_PICK_SG(T, SP, D, W, DI, true); else CVR_PICK_SG(T, SP, D, W, DI, false); } while (0)
 #define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_PICK_MW(T, SP, D, W, true); else CVR_PICK_MW(T, SP, D, W, false); } while (0)

@@ -88,6 +88,11 @@ typedef struct {
                                   <0 = auto (default)                                                                     */
     int32_t layout_auto_resident;   /* internal (set by cvr_create, ignored on input): the automatic layout chose the
                                   "resident" form -- every workgroup on a CU of its own at once                          */
+    int32_t hub_table;         /* hub table: the columns with the most non-zeros (at most this many; what fits the LDS) get
+                                  their x values compacted before every SpMV and staged in LDS by every workgroup (8 chunks),
+                                  their gathers become ds_reads.  For power-law matrices whose x does not fit an L2.
+                                  0 = off, <0 = auto (default): on when those columns hold >= 50 % of the non-zeros        */
+    int32_t reserved2;
 } cvr_options;
 /* Automatic layout: with steps_per_chunk = 0, waves_per_block = 0, x_window < 0 and col_phases < 0 (the defaults) cvr_create
  * looks at the uploaded CSR on the device (are the rows sorted by column? which share of the non-zeros lies near the
@@ -121,6 +126,10 @@ typedef struct {
     int64_t nsegments;         /* column phases: (row, phase) segments over all chunks (0 otherwise)                    */
     int64_t chunk_row_cap;     /* column phases: most rows the planner gives a chunk (their sums live in LDS); 0 = none */
     double  near_diagonal_share;   /* automatic layout: share of the non-zeros within a quarter window of the diagonal (0 if not probed) */
+    int32_t hub_entries;           /* hub table: columns staged in LDS (0 = none)                                          */
+    int32_t reserved3;
+    double  hub_share;             /* share of the non-zeros in the hub columns that were (or could have been) chosen      */
+    double  hub_select_s;          /* the device pass that counted and ranked the columns (0 if not run)                  */
     double  probe_s;               /* automatic layout: the device pass over the CSR (sortedness, near-diagonal share), 0 if not run */
     double  dict_s;                /* the value-dictionary detection pass over the uploaded values (part of upload_s) */
     double  preprocess_wall_s;     /* host wall time of cvr_preprocess: convert_s (device events) + its temporary allocations and the final sync */

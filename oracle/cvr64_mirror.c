@@ -110,10 +110,42 @@ int orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rp, const 
  * its rows' pieces phase by phase -- every (row, phase) pair with a non-zero is one segment, in (phase, row) order -- and
  * seg_row tells which of the chunk's rows a segment belongs to.  Needs the columns of every row in ascending order.
  * max_rows caps the rows of a chunk (their sums are accumulated in LDS on the device). */
+typedef struct { uint32_t cnt; int32_t col; } hubkey_t;
+static int cmp_hub(const void *a, const void *b)
+{
+    const hubkey_t *x = (const hubkey_t *)a, *y = (const hubkey_t *)b;
+    if (x->cnt != y->cnt) return x->cnt > y->cnt ? -1 : 1;      /* non-zeros descending */
+    return x->col < y->col ? -1 : x->col > y->col;              /* ties by column        */
+}
+
 int orc_cvr64_build_ex(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
                        int S, int64_t thr, int use_dict, int phases, int64_t max_rows, orc_cvr64 *c)
 {
+    return orc_cvr64_build_hub(nrows, ncols, rp, cols, vals, is_f32, S, thr, use_dict, phases, max_rows, 0, c);
+}
+
+/* hub_max > 0: hub table -- the (at most hub_max) columns with the most non-zeros (at least 2), ranked by non-zeros descending
+ * and column ascending; a slot of such a column holds bit 30 and the column's rank instead of the column index */
+int orc_cvr64_build_hub(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
+                        int S, int64_t thr, int use_dict, int phases, int64_t max_rows, int64_t hub_max, orc_cvr64 *c)
+{
     memset(c, 0, sizeof(*c));
+    int32_t *hub_index = NULL;
+    if (hub_max > 0 && phases <= 1 && ncols > 0 && nrows > 0) {
+        hubkey_t *k = (hubkey_t *)calloc((size_t)ncols, sizeof(hubkey_t));
+        for (int64_t j = 0; j < ncols; j++) k[j].col = (int32_t)j;
+        const int64_t nnz_all = rp[nrows] - rp[0], stride = nnz_all > (1 << 23) ? (nnz_all + (1 << 23) - 1) >> 23 : 1;
+        for (int64_t j = rp[0]; j < rp[nrows]; j += stride) k[cols[j]].cnt++;         /* every stride-th non-zero, as the product counts */
+        qsort(k, (size_t)ncols, sizeof(hubkey_t), cmp_hub);
+        int64_t H = 0;
+        while (H < hub_max && H < ncols && k[H].cnt >= 2) H++;
+        c->hub_n = (int)H;
+        c->hub_cols = (int32_t *)calloc((size_t)H + 1, sizeof(int32_t));
+        hub_index = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
+        for (int64_t j = 0; j < ncols; j++) hub_index[j] = -1;
+        for (int64_t i = 0; i < H; i++) { c->hub_cols[i] = k[i].col; hub_index[k[i].col] = (int32_t)i; }
+        free(k);
+    }
     if (phases < 1) phases = 1;
     c->phases = phases;
     int64_t pw = (ncols + phases - 1) / phases;
@@ -231,6 +263,7 @@ int orc_cvr64_build_ex(int64_t nrows, int64_t ncols, const int64_t *rp, const in
                 uint32_t col = (uint32_t)ncols; double v = 0;
                 if (pos[l] >= 0) {
                     col = (uint32_t)cols[pos[l]];
+                    if (hub_index && hub_index[col] >= 0) col = 0x40000000u | (uint32_t)hub_index[col];
                     v = is_f32 ? (double)((const float *)vals)[pos[l]] : ((const double *)vals)[pos[l]];
                     pos[l]++;
                 }
@@ -252,14 +285,14 @@ int orc_cvr64_build_ex(int64_t nrows, int64_t ncols, const int64_t *rp, const in
             if (cnt[l] != 0) { fprintf(stderr, "cvr64 mirror: lane not drained\n"); rc = -4; }
     }
     if (NC) c->nz_begin[NC] = nrows ? rp[nrows] : 0;
-    free(seg_pos); free(seg_cnt); free(seg_r); free(ch);
+    free(seg_pos); free(seg_cnt); free(seg_r); free(ch); free(hub_index);
     return rc;
 }
 
 void orc_cvr64_free(orc_cvr64 *c)
 {
     free(c->image); free(c->desc); free(c->target); free(c->shared); free(c->nz_begin); free(c->pad_cnt);
-    free(c->seg_off); free(c->seg_row); free(c->nrows_in);
+    free(c->seg_off); free(c->seg_row); free(c->nrows_in); free(c->hub_cols);
     memset(c, 0, sizeof(*c));
 }
 
@@ -298,7 +331,8 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
             int flagged[W];
             for (int l = 0; l < W; l++) {
                 const uint32_t cw = ((const uint32_t *)grp)[l * 4 + j];
-                const uint32_t col = cw & cmask;
+                uint32_t col = cw & cmask;
+                if (c->hub_n && (col & 0x40000000u)) col = (uint32_t)c->hub_cols[col & 0x3fffffffu];     /* hub slot: rank -> column */
                 flagged[l] = cw >> 31;
                 rowtag[l] = ph ? (cw & 0x7fffffffu) >> c->col_bits : 0;
                 if (c->is_f32) {

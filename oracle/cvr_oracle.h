@@ -95,6 +95,8 @@ typedef struct {
     uint16_t *seg_row;       /* phases > 1: the chunk's row (0 .. nrows_in-1; nrows_in = dump) of every segment        */
     uint32_t *nrows_in;      /* phases > 1: [nchunks] rows with a segment in the chunk                                  */
     int       col_bits;      /* phases > 1: the last column word of a segment holds its seg_row in bits [col_bits, 31)   */
+    int       hub_n;         /* hub table entries (0 = none): a column word with bit 30 holds the rank of a hub column      */
+    int32_t  *hub_cols;      /* [hub_n] the hub columns by non-zeros descending, ties by column                             */
 } orc_cvr64;
 
 int  orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
@@ -105,6 +107,9 @@ int  orc_cvr64_build_dict(int64_t nrows, int64_t ncols, const int64_t *rowptr, c
 /* the same with column phases (phases > 1; rows must have ascending columns: -6 otherwise) and a cap on the rows of a chunk */
 int  orc_cvr64_build_ex(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
                         int S, int64_t split_threshold, int use_dict, int phases, int64_t max_rows, orc_cvr64 *out);
+/* the same with a hub table of at most hub_max entries (0 = none; not together with phases) */
+int  orc_cvr64_build_hub(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
+                         int S, int64_t split_threshold, int use_dict, int phases, int64_t max_rows, int64_t hub_max, orc_cvr64 *out);
 void orc_cvr64_free(orc_cvr64 *c);
 /* interpret the image exactly as the HIP kernel does (same per-lane order of operations) */
 void orc_cvr64_spmv(const orc_cvr64 *c, const void *x, void *y);

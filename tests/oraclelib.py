@@ -29,7 +29,7 @@ class OrcCvr64(C.Structure):
                 ("nz_begin", C.POINTER(C.c_int64)), ("pad_cnt", C.POINTER(C.c_int64)),
                 ("ndict", C.c_int), ("dict", C.c_uint64 * 256), ("phases", C.c_int),
                 ("seg_off", C.POINTER(C.c_uint32)), ("seg_row", C.POINTER(C.c_uint16)), ("nrows_in", C.POINTER(C.c_uint32)),
-                ("col_bits", C.c_int)]
+                ("col_bits", C.c_int), ("hub_n", C.c_int), ("hub_cols", C.POINTER(C.c_int32))]
 
 
 def lib():
@@ -51,6 +51,8 @@ def lib():
                                               C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(OrcCvr64)]
         _lib.orc_cvr64_build_ex.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.POINTER(OrcCvr64)]
+        _lib.orc_cvr64_build_hub.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(OrcCvr64)]
         _lib.orc_write_mtx_pattern.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     return _lib
 
@@ -169,14 +171,14 @@ class Cvr8:
 class Cvr64:
     """CPU mirror of the device format (arrays copied to numpy)"""
 
-    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0, use_dict=False, phases=1, max_rows=0):
+    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0, use_dict=False, phases=1, max_rows=0, hub_max=0):
         self.rp = np.ascontiguousarray(rowptr, dtype=np.int64)
         self.cl = np.ascontiguousarray(cols, dtype=np.int32)
         self.f32 = vals.dtype == np.float32
         self.vl = np.ascontiguousarray(vals, dtype=np.float32 if self.f32 else np.float64)
         self.c = OrcCvr64()
-        self.rc = lib().orc_cvr64_build_ex(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data,
-                                           int(self.f32), S, thr, int(use_dict), phases, max_rows, C.byref(self.c))
+        self.rc = lib().orc_cvr64_build_hub(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data,
+                                            int(self.f32), S, thr, int(use_dict), phases, max_rows, hub_max, C.byref(self.c))
         if self.rc:
             raise RuntimeError(f"orc_cvr64_build = {self.rc}")
         c = self.c
@@ -189,6 +191,8 @@ class Cvr64:
         self.pad_cnt = _np(c.pad_cnt, c.nchunks, np.int64)
         self.ndict = c.ndict
         self.phases = c.phases
+        self.hub_n = c.hub_n
+        self.hub_cols = _np(c.hub_cols, c.hub_n, np.int32) if c.hub_n else np.zeros(0, np.int32)
         if c.phases > 1:
             self.seg_off = _np(c.seg_off, c.nchunks + 1, np.uint32)
             self.seg_row = _np(c.seg_row, int(self.seg_off[-1]) if c.nchunks else 0, np.uint16)

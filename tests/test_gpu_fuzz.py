@@ -56,26 +56,29 @@ def test_fuzz_parity():
         win = int(rng.choice([0, 0, 64, 1000]))
         wpb = int(rng.choice([1, 1, 2, 8, 16]))
         ph = int(rng.choice([1, 1, 2, 5])) if P == 1 and ncols >= 320 else 1
-        ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32, wpb=wpb, phases=ph, sorted=srt)
+        hub = int(rng.choice([0, 0, 7, 300])) if ph == 1 else 0
+        ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32, wpb=wpb, phases=ph, sorted=srt, hub=hub)
         from_dev = torch is not None and len(ci) > 0 and rng.integers(0, 4) == 0     # CSR arrays already on the device
         if from_dev:
             keep = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp.astype(np.int64), ci.astype(np.int32), va)]
             torch.cuda.synchronize()
             A = cvr_amd.CvrMatrix.from_device(nrows, ncols, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), is_f32=f32,
                                               steps_per_chunk=S, split_threshold=thr, col_panels=P)
-            win, ph = 0, 1
+            win, ph, hub = 0, 1, 0
         else:
             if ph > 1 and not srt and len(ci) > 0 and np.any((np.diff(ci.astype(np.int64)) < 0) & (np.diff(np.repeat(np.arange(nrows), np.diff(rp))) == 0)):
                 with pytest.raises(cvr_amd.CvrError):      # column phases need ascending columns inside every row
                     cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, col_panels=P, x_window=win,
                                       waves_per_block=wpb, col_phases=ph)
                 ph = 1
+            if ph > 1:
+                hub = 0
             A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, col_panels=P, x_window=win,
-                                  waves_per_block=wpb, col_phases=ph)
+                                  waves_per_block=wpb, col_phases=ph, hub_table=hub)
             ph = A.info.col_phases
         ctx["from_dev"] = bool(from_dev)
         if P == 1:
-            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0, phases=ph, max_rows=A.info.chunk_row_cap)
+            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0, phases=ph, max_rows=A.info.chunk_row_cap, hub_max=A.info.hub_entries)
             img = A.export_image()
             assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc), ctx
             assert np.array_equal(img["target"], mir.target) and np.array_equal(img["shared"], mir.shared), ctx

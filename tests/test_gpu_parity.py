@@ -860,3 +860,52 @@ def test_panelled_handle_on_two_streams_keeps_its_launches_apart():
     for k in range(2):
         _assert_close(ys[k][:nrows].cpu().numpy(), refs[k][0], refs[k][1], TOL64, ("two streams", k))
     A.close()
+
+
+@pytest.mark.parametrize("scale,S,wpb,win,hub,f32", [(12, 8, 1, 0, 500, False), (14, 32, 8, 0, 4000, True), (14, 16, 4, 256, 1000, False), (13, 32, 8, 1024, 100000, True)])
+def test_hub_table(scale, S, wpb, win, hub, f32):
+    """hub table (cvr_hub.hip): the columns with the most non-zeros staged in LDS, their slots carrying bit 30 and the table
+    index -- image against the CPU mirror bit for bit (same ranking of the columns), y against the CSR oracle, bitwise reruns;
+    with and without the value dictionary, with one chunk per workgroup and with persistent multi-chunk workgroups"""
+    nrows, ncols, rp, ci, va = synth.rmat(scale, dtype=np.float32 if f32 else np.float64)
+    for vd in (-1, 0):
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, waves_per_block=wpb, x_window=win, hub_table=hub, value_dict=vd, col_phases=0)
+        i = A.info
+        assert 0 < i.hub_entries <= hub and i.hub_share > 0.3
+        mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=i.value_dict > 0, hub_max=i.hub_entries)
+        assert mir.hub_n == i.hub_entries
+        img = A.export_image()
+        for key in ("desc", "target", "shared", "image"):
+            assert np.array_equal(img[key], getattr(mir, key)), key
+        x = synth.x_rand(ncols, va.dtype)
+        yref, absy = O.csr_spmv64(rp, ci, va.astype(np.float64), x.astype(np.float64))
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL32 if f32 else TOL64, (scale, S, wpb, win, hub, vd))
+        y2, _ = A.spmv(x)
+        assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))
+        A.close()
+
+
+def test_hub_table_in_column_panels_and_automatic_choice():
+    """device-resident CSR with column panels: every panel ranks the columns of its own range; and the automatic rule
+    (a table only when the columns that fit the LDS hold at least half of the sampled non-zeros)"""
+    torch = pytest.importorskip("torch")
+    from cvr_amd import synth_dev as D
+    scale = 18
+    rp, ci, va = D.rmat_rows(scale, 0, 1 << scale, device="cuda")
+    n = 1 << scale
+    A = cvr_amd.CvrMatrix.from_device(n, n, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), is_f32=True, steps_per_chunk=16, col_panels=3, hub_table=2048)
+    assert A.info.hub_entries == 2048
+    A2 = cvr_amd.CvrMatrix(n, n, rp.cpu().numpy(), ci.cpu().numpy(), va.cpu().numpy(), steps_per_chunk=16, col_panels=1, hub_table=0)
+    assert A.info.col_panels == 3
+    x = synth.x_rand(n, np.float32)
+    y, _ = A.spmv(x)
+    y0, _ = A2.spmv(x)
+    yref, absy = O.csr_spmv64(rp.cpu().numpy(), ci.cpu().numpy(), va.cpu().numpy().astype(np.float64), x.astype(np.float64))
+    _assert_close(y, yref, absy, TOL32, "hub + panels")
+    _assert_close(y0, yref, absy, TOL32, "no hub")
+    # R-MAT 18 is too small for the automatic rule (4 M non-zeros, x of 1 MB): no table unless asked for
+    A3 = cvr_amd.CvrMatrix.from_device(n, n, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), is_f32=True, steps_per_chunk=16, col_panels=3)
+    assert A3.info.hub_entries == 0
+    A3.close()
+    A.close(); A2.close()
