@@ -397,21 +397,23 @@ __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__
 }
 
 // Probe for cvr_create's automatic choice of the workgroup layout: over all rows, (a) are the columns of every row in
-// ascending order (column phases need it), (b) how many non-zeros lie within `half` columns of the row's place on the
-// diagonal (row * ncols / nrows): what an LDS window of x per workgroup would serve.  out[0] = unsorted flag,
-// out[1..2] = near-diagonal count (low, high word of a 64-bit counter).
+// ascending order (column phases need it), (b) which share of the non-zeros would an LDS window of x per workgroup serve:
+// every 256 consecutive rows histogram their columns over bins of `bin` columns (LDS) and count the fullest two adjacent
+// bins -- wherever those lie, so a row shard of a larger matrix (its diagonal shifted) and rectangular matrices are judged
+// alike.  Per workgroup b: out[2b] = unsorted flag, out[2b + 1] = non-zeros in those bins (the host adds them up).
 __global__ __launch_bounds__(256) void probe_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ ci, uint32_t nrows,
-                                                    double col_per_row, uint32_t half, unsigned long long *__restrict__ out)
+                                                    uint32_t bin_shift, uint32_t nbins, unsigned long long *__restrict__ out)
 {
-    // a workgroup takes 256 consecutive rows: their non-zeros are one contiguous range, read coalesced; the row of an
-    // element is found by binary search in the 257 row pointers staged in LDS
-    __shared__ int64_t srp[257];
+    extern __shared__ uint32_t hist[];                    // nbins + 1
+    __shared__ int64_t  srp[257];
+    __shared__ uint32_t wbest[4], wbad[4];
     unsigned long long near = 0;
     uint32_t           bad = 0;
     for (uint32_t r0 = blockIdx.x * 256; r0 < nrows; r0 += gridDim.x * 256) {
         const uint32_t nr = nrows - r0 < 256 ? nrows - r0 : 256;
         __syncthreads();
         for (uint32_t i = threadIdx.x; i <= nr; i += 256) srp[i] = rp[r0 + i];
+        for (uint32_t i = threadIdx.x; i <= nbins; i += 256) hist[i] = 0;
         __syncthreads();
         const int64_t a = srp[0], z = srp[nr];
         for (int64_t j = a + threadIdx.x; j < z; j += 256) {
@@ -419,21 +421,25 @@ __global__ __launch_bounds__(256) void probe_kernel(const int64_t *__restrict__ 
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (srp[mid] <= j) lo = mid; else hi = mid; }
             const int32_t c = ci[j];
             if (j > srp[lo] && ci[j - 1] > c) bad = 1;
-            const int64_t d = (int64_t)c - (int64_t)((double)(r0 + lo) * col_per_row);
-            if ((d < 0 ? -d : d) <= (int64_t)half) near++;
+            atomicAdd(&hist[(uint32_t)c >> bin_shift], 1u);
         }
+        __syncthreads();
+        uint32_t best = 0;
+        for (uint32_t i = threadIdx.x; i < nbins; i += 256) { const uint32_t v = hist[i] + hist[i + 1]; best = v > best ? v : best; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(best, o); best = v > best ? v : best; }
+        if ((threadIdx.x & 63u) == 0) wbest[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) near += std::max(std::max(wbest[0], wbest[1]), std::max(wbest[2], wbest[3]));
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { near += __shfl_xor(near, o); bad |= __shfl_xor(bad, o); }
-    // one partial result per workgroup, summed by the host: same-address atomics from thousands of workgroups cost ~100 ns each
-    __shared__ unsigned long long wnear[4];
-    __shared__ uint32_t           wbad[4];
+    for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
     __syncthreads();
-    if ((threadIdx.x & 63u) == 0) { wnear[threadIdx.x >> 6] = near; wbad[threadIdx.x >> 6] = bad; }
+    if ((threadIdx.x & 63u) == 0) wbad[threadIdx.x >> 6] = bad;
     __syncthreads();
     if (threadIdx.x == 0) {
         out[2 * blockIdx.x] = wbad[0] | wbad[1] | wbad[2] | wbad[3];
-        out[2 * blockIdx.x + 1] = wnear[0] + wnear[1] + wnear[2] + wnear[3];
+        out[2 * blockIdx.x + 1] = near;
     }
 }
 
@@ -508,7 +514,11 @@ hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int
 {
     if (nrows <= 0) return hipSuccess;
     const uint32_t blocks = kProbeBlocks;
-    hipLaunchKernelGGL(probe_kernel, dim3(blocks), dim3(256), 0, st, rp, ci, (uint32_t)nrows, (double)ncols / (double)nrows, half, out2);
+    uint32_t       bin_shift = 0;                          // bins of `half` columns (a power of two), at most 8192 of them
+    while ((2u << bin_shift) <= half) bin_shift++;
+    while (((uint64_t)ncols >> bin_shift) + 1 > 8192) bin_shift++;
+    const uint32_t nbins = (uint32_t)(((uint64_t)ncols >> bin_shift) + 1);
+    hipLaunchKernelGGL(probe_kernel, dim3(blocks), dim3(256), sizeof(uint32_t) * (nbins + 1), st, rp, ci, (uint32_t)nrows, bin_shift, nbins, out2);
     return hipGetLastError();
 }
 

@@ -112,7 +112,7 @@ hipError_t launch_scale(void *x, const void *y, const double *norm2, int64_t n, 
 // dense[bd.b[p] + i] = padded[p * max_rows + i], i < bd.b[p+1] - bd.b[p]
 hipError_t launch_unpad(void *dense, const void *padded, const IterBounds &bd, int nparts, int64_t max_rows, bool f32, hipStream_t st);
 
-// rows sorted by column? how many non-zeros within `half` columns of the diagonal?  out2[2 * kProbeBlocks] = {unsorted flag, count} per workgroup
+// rows sorted by column? how many non-zeros in the fullest two adjacent bins of `half` columns of every 256 rows?  out2[2 * kProbeBlocks] = {unsorted flag, count} per workgroup
 constexpr uint32_t kProbeBlocks = 1024;
 hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st);
 // min / max of col_idx[n0 .. n1) into minmax[0..1] (device; initialised by the caller to INT_MAX / INT_MIN)
