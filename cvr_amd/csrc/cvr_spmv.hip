@@ -270,12 +270,28 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     if constexpr (WIN) {
         constexpr uint32_t kPer = 16 / sizeof(T);                      // values per 16-byte load; wbase and wn are multiples of it
         wbase = wn && blk * nw < nchunks ? win_base[blk] : 0u;
-        for (uint32_t i = threadIdx.x * kPer; i < hub_n; i += blockDim.x * kPer)          // the hub table (hub_x is padded to whole 16 bytes)
-            *reinterpret_cast<u32x4 *>(win + i) = *reinterpret_cast<const u32x4 *>(hub_x + i);
+        // eight 16-byte loads in flight per lane before the first LDS store (the 64-KB window takes 1.8 us either way -- all
+        // 256 workgroups fetch theirs at once, ~9 TB/s --, profiles/r02_kernel_timeline.log)
+        constexpr int kBatch = 8;
         const uint32_t hpad = (hub_n + 3u) & ~3u;
-        for (uint32_t i = threadIdx.x * kPer; i < wn; i += blockDim.x * kPer) {
-            const u32x4 q = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (wbase + i) * (uint32_t)sizeof(T), 0, kPolDefault));
-            *reinterpret_cast<u32x4 *>(win + hpad + i) = q;
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(hub_x, hpad * (uint32_t)sizeof(T));
+        const uint32_t tstep = blockDim.x * kPer;
+        for (uint32_t i0 = threadIdx.x * kPer; i0 < hub_n; i0 += tstep * kBatch) {                 // the hub table (hub_x is padded to whole 16 bytes)
+            u32x4 q[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) q[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rh, (i0 + u * tstep) * (uint32_t)sizeof(T), 0, kPolDefault));
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) if (i0 + u * tstep < hub_n) *reinterpret_cast<u32x4 *>(win + i0 + u * tstep) = q[u];
+        }
+        for (uint32_t i0 = threadIdx.x * kPer; i0 < wn; i0 += tstep * kBatch) {
+            u32x4 q[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                const uint32_t i = i0 + u * tstep;
+                q[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, i < wn ? (wbase + i) * (uint32_t)sizeof(T) : 0xfffffff0u, 0, kPolDefault));
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) if (i0 + u * tstep < wn) *reinterpret_cast<u32x4 *>(win + hpad + i0 + u * tstep) = q[u];
         }
         if (threadIdx.x < 4) win[hpad + wn + threadIdx.x] = T(0);
     }
