@@ -111,6 +111,7 @@ struct Part {
         if (img.shared) (void)hipFree(img.shared);
         if (img.win_base) (void)hipFree(img.win_base);
         if (img.desc2) (void)hipFree(img.desc2);
+        if (img.cbase) (void)hipFree(img.cbase);
         if (img.hub_cols) (void)hipFree(img.hub_cols);
         if (img.hub_index) (void)hipFree(img.hub_index);
         if (img.hub_bitmap) (void)hipFree(img.hub_bitmap);
@@ -195,6 +196,7 @@ void cvr_default_options(cvr_options *o)
     o->value_dict = -1;
     o->col_phases = -1;
     o->hub_table = -1;
+    o->narrow_cols = -1;
 }
 
 int cvr_device_count(void)
@@ -566,6 +568,23 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     }
     if (!plan.shared.empty())
         HIP_TRY(hipMemcpyAsync(img.shared, plan.shared.data(), sizeof(cvr::Shared) * plan.shared.size(), hipMemcpyHostToDevice, h->stream));
+    // narrow chunks (plain layout only): if every chunk spans fewer than 32 767 columns -- banded matrices -- the image stores
+    // 16-bit column offsets from the chunk's smallest column: 10 instead of 12 bytes per fp64 slot of a stream-bound SpMV
+    if (popt.narrow_cols != 0 && nchunks > 0 && img.wpb == 1 && img.win_elems == 0 && img.phases <= 1 && img.hub_n == 0 && !opt.debug_col_mask) {
+        uint32_t *d_wide = nullptr, wide = 1;
+        HIP_TRY(hipMalloc(&img.cbase, sizeof(uint32_t) * (size_t)nchunks));
+        HIP_TRY(hipMalloc(&d_wide, sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(d_wide, 0, sizeof(uint32_t), h->stream));
+        cvr::DeviceCsr csr;
+        csr.col_idx = part.d_ci; csr.nz_begin = part.d_nzb;
+        hipError_t e = cvr::launch_chunk_span(img, csr, img.cbase, d_wide, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&wide, d_wide, sizeof(wide), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(d_wide);
+        if (e != hipSuccess) return fail(CVR_ERR_HIP, "chunk column spans: %s", hipGetErrorString(e));
+        img.c16 = wide == 0;
+        if (!img.c16) { (void)hipFree(img.cbase); img.cbase = nullptr; }
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));   // the host staging vectors go out of scope; the caller may free its CSR
     return CVR_OK;
 }
@@ -575,11 +594,12 @@ static int finish_part(cvr_handle *h, Part &part)
 {
     cvr::DeviceImage &img = part.img;
     img.dict = h->d_dict; img.ndict = h->ndict;
-    part.stream_bytes = (size_t)part.nchunks * img.G * cvr::group_bytes(img.f32, h->d_dict != nullptr);
+    if (img.dict) img.c16 = false;                 // (the dictionary layout keeps 32-bit column words)
+    part.stream_bytes = (size_t)part.nchunks * img.G * cvr::group_bytes(img.f32, h->d_dict != nullptr, img.c16);
     // the SpMV kernel's software pipeline issues its stream loads up to 5 groups past the end of a chunk (the buffer
     // descriptor's range check returns zeros for them); the allocation is padded by that much so that the last chunk's
     // run-ahead stays inside it whatever the hardware does with an offset beyond num_records
-    const size_t slack = 8 * (size_t)cvr::group_bytes(img.f32, h->d_dict != nullptr);
+    const size_t slack = 8 * (size_t)cvr::group_bytes(img.f32, h->d_dict != nullptr, img.c16);
     if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
         HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, part.stream_bytes + slack, hipDeviceMallocUncached));
     else
@@ -1040,6 +1060,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     in.steps_per_chunk = h->parts[0].img.S;
     in.col_phases = (int32_t)h->parts[0].img.phases; in.waves_per_block = (int32_t)h->parts[0].img.wpb; in.x_window = (int32_t)h->parts[0].img.win_elems;
     in.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);
+    in.narrow_cols = h->parts[0].img.c16 ? 1 : 0;
     in.chunk_row_cap = h->parts[0].img.phases > 1 ? (int64_t)h->parts[0].img.ystage - 1 : 0;
     for (const Part &p : h->parts) {
         in.nchunks += p.nchunks; in.nshared += p.nshared; in.nslots += p.nchunks * 64 * p.img.S;

@@ -44,17 +44,19 @@ __device__ __forceinline__ uint32_t dict_code(const typename Bits<T>::type *dict
 
 // SEGT: the chunk's segments come from a table (column phases: one segment per (row, phase) pair, launch_seg_fill) instead
 // of being the chunk's rows in order.
-template <typename T, bool DICT, bool SEGT>
+template <typename T, bool DICT, bool SEGT, bool C16>
 __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx, const T *__restrict__ vals,
     const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt, const uint4 *__restrict__ desc,
     uint8_t *__restrict__ stream, uint8_t *__restrict__ target, uint32_t *__restrict__ err, int G,
     uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
     const uint2 *__restrict__ desc2, const int64_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
-    const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags, const int32_t *__restrict__ hub_index, const uint32_t *__restrict__ hub_bitmap)
+    const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags, const int32_t *__restrict__ hub_index, const uint32_t *__restrict__ hub_bitmap,
+    const uint32_t *__restrict__ cbase)
 {
     if constexpr (SEGT) { if (seg_flags[0] & 1u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
-    constexpr int GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
+    constexpr int GB = DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
+    constexpr int CB = C16 ? kCols16Bytes : kColsBytes;      // bytes of the group's column part
     typedef typename Bits<T>::type bits_t;
     __shared__ bits_t dict[DICT ? kDictMax : 1];
     if constexpr (DICT) {
@@ -78,7 +80,9 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     uint32_t tgt = lane;   // lane this one stole from
     uint32_t rowtag = 0;   // SEGT: the chunk's row of the lane's segment, shifted above the column index (goes into its last column word)
     uint32_t bad = 0;
-    uint8_t *out = stream + (size_t)k * G * GB + lane * 16;
+    uint8_t *out = stream + (size_t)k * G * GB + lane * (C16 ? 8 : 16);
+    uint32_t base_col = 0;
+    if constexpr (C16) base_col = cbase[k];
 
     for (int g = 0; g < G; g++) {
         uint32_t cw[4];
@@ -147,8 +151,21 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
             cnt--;
         }
         uint8_t *o = out + (size_t)g * GB;
-        u32x4    cq = {cw[0], cw[1], cw[2], cw[3]};
-        *reinterpret_cast<u32x4 *>(o) = cq;
+        if constexpr (C16) {            // 16-bit offsets from the chunk's smallest column; 0x7fff = the pad column; bit 15 = end of segment
+            uint32_t h[4];
+#pragma unroll
+            for (int j = 0; j < kGroupSteps; j++) {
+                const uint32_t c = cw[j] & kColMask;
+                h[j] = (c == pad_col ? kC16Pad : c - base_col) | ((cw[j] & kEndBit) ? 0x8000u : 0u);
+            }
+            uint2 cq = {h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+            *reinterpret_cast<uint2 *>(o) = cq;
+            o -= lane * 8;              // values are addressed from the group's start + lane * 16 below
+            o += lane * 16;
+        } else {
+            u32x4 cq = {cw[0], cw[1], cw[2], cw[3]};
+            *reinterpret_cast<u32x4 *>(o) = cq;
+        }
         if constexpr (DICT) {
             uint32_t codes = 0;
 #pragma unroll
@@ -157,14 +174,14 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
                 if (cd >= ndict || dict[cd] != __builtin_bit_cast(bits_t, vv[j])) bad |= 4u;   // value missing from the dictionary
                 codes |= (cd & 0xffu) << (8 * j);
             }
-            *reinterpret_cast<uint32_t *>(stream + (size_t)k * G * GB + (size_t)g * GB + kColsBytes + lane * 4) = codes;
+            *reinterpret_cast<uint32_t *>(stream + (size_t)k * G * GB + (size_t)g * GB + CB + lane * 4) = codes;
         } else if constexpr (sizeof(T) == 8) {
             f64x2 lo = {vv[0], vv[1]}, hi = {vv[2], vv[3]};
-            *reinterpret_cast<f64x2 *>(o + kColsBytes) = lo;
-            *reinterpret_cast<f64x2 *>(o + kColsBytes + kLanes * 16) = hi;
+            *reinterpret_cast<f64x2 *>(o + CB) = lo;
+            *reinterpret_cast<f64x2 *>(o + CB + kLanes * 16) = hi;
         } else {
             f32x4 vq = {vv[0], vv[1], vv[2], vv[3]};
-            *reinterpret_cast<f32x4 *>(o + kColsBytes) = vq;
+            *reinterpret_cast<f32x4 *>(o + CB) = vq;
         }
     }
     if (cnt != 0) bad |= 1u;
@@ -443,6 +460,22 @@ __global__ __launch_bounds__(256) void probe_kernel(const int64_t *__restrict__ 
     }
 }
 
+// narrow chunks: the smallest column of every chunk, and whether any chunk spans too many columns for 16-bit offsets
+__global__ __launch_bounds__(kLanes) void chunk_span_kernel(const int32_t *__restrict__ ci, const int64_t *__restrict__ nzb, uint32_t nchunks,
+                                                            uint32_t *__restrict__ cbase, uint32_t *__restrict__ wide)
+{
+    const uint32_t k = blockIdx.x;
+    if (k >= nchunks) return;
+    int32_t lo = 0x7fffffff, hi = -1;
+    for (int64_t j = nzb[k] + threadIdx.x; j < nzb[k + 1]; j += kLanes) { const int32_t c = ci[j]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int32_t a = __shfl_xor(lo, o), b = __shfl_xor(hi, o); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if (threadIdx.x == 0) {
+        cbase[k] = hi >= 0 ? (uint32_t)lo : 0u;
+        if (hi >= 0 && (uint32_t)(hi - lo) >= kC16Pad) *wide = 1u;       // (plain store of the same value from every such chunk)
+    }
+}
+
 // smallest and largest column index of col_idx[n0 .. n1): the range check of cvr_create for CSR arrays that are already
 // on the device (the host loop of check_csr otherwise).  minmax[0] = min, minmax[1] = max; the caller initialises both.
 __global__ __launch_bounds__(256) void col_range_kernel(const int32_t *__restrict__ ci, long long n0, long long n1, int32_t *minmax)
@@ -522,6 +555,13 @@ hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int
     return hipGetLastError();
 }
 
+hipError_t launch_chunk_span(const DeviceImage &img, const DeviceCsr &csr, uint32_t *cbase, uint32_t *wide, hipStream_t st)
+{
+    if (img.nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(chunk_span_kernel, dim3(img.nchunks), dim3(kLanes), 0, st, csr.col_idx, csr.nz_begin, img.nchunks, cbase, wide);
+    return hipGetLastError();
+}
+
 hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st)
 {
     if (n1 <= n0) return hipSuccess;
@@ -575,11 +615,22 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     const uint32_t blocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3     grid(blocks), block(kLanes * kWavesPerBlock);
 #define CVR_CONVERT(T, DI, SG)                                                                                     \
-    hipLaunchKernelGGL((convert_kernel<T, DI, SG>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
+    hipLaunchKernelGGL((convert_kernel<T, DI, SG, false>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
                        csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
                        static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, \
-                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap)
+                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase)
 #define CVR_CONVERT_SG(T, DI) do { if (seg) CVR_CONVERT(T, DI, true); else CVR_CONVERT(T, DI, false); } while (0)
+    if (img.c16 && !img.dict && !seg) {      // narrow chunks: 16-bit column offsets
+        if (img.f32) hipLaunchKernelGGL((convert_kernel<float, false, false, true>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const float *>(csr.vals),
+                                        csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
+                                        (const float *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
+                                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase);
+        else hipLaunchKernelGGL((convert_kernel<double, false, false, true>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const double *>(csr.vals),
+                                csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
+                                (const double *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
+                                (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase);
+        return hipGetLastError();
+    }
     if (img.f32) { if (img.dict) CVR_CONVERT_SG(float, true); else CVR_CONVERT_SG(float, false); }
     else         { if (img.dict) CVR_CONVERT_SG(double, true); else CVR_CONVERT_SG(double, false); }
 #undef CVR_CONVERT_SG

@@ -20,6 +20,9 @@
 //                  [64 lanes][4 x u8 code]  256 B after the column words instead of the values; the
 //                  dictionary (sorted by bit pattern, contains +0.0 for the pad slots) sits in LDS
 //                bit 31 of a column word = "last slot of this lane's current segment"
+//                narrow chunks (every chunk of the matrix spans fewer than 32 767 columns: banded matrices):
+//                  [64 lanes][4 x u16 column - cbase[k]]  512 B instead of the 1024 B of column words (bit 15 = end
+//                  of segment, 0x7fff = the pad column): 10 instead of 12 bytes per fp64 slot
 //   desc[k]    = {row_first, nseg, head_dest, last_dest}: segment q of chunk k writes
 //                y_ext[q == 0 ? head_dest : q == nseg-1 ? last_dest : row_first + q]
 //   y_ext      = [ y[0..nrows) | dump | carry_head(0), carry_tail(0), carry_head(1), ... ]
@@ -40,6 +43,10 @@ constexpr int      kColsBytes    = kLanes * 16;            // 1024
 constexpr int      kGroupBytes64 = kColsBytes + kLanes * 32;  // 3072
 constexpr int      kGroupBytes32 = kColsBytes + kLanes * 16;  // 2048
 constexpr int      kGroupBytesDict = kColsBytes + kLanes * 4;  // 1280: column words + one code byte per slot
+constexpr int      kCols16Bytes  = kLanes * 8;             // 512: narrow chunks store 16-bit column offsets (bit 15 = end of segment, 0x7fff = pad column)
+constexpr int      kGroupBytes64C16 = kCols16Bytes + kLanes * 32;   // 2560: 10 bytes per slot
+constexpr int      kGroupBytes32C16 = kCols16Bytes + kLanes * 16;   // 1536:  6 bytes per slot
+constexpr uint32_t kC16Pad = 0x7fffu;
 constexpr int      kDictMax = 256;
 constexpr int      kYStageMax = 4096;   // most row sums a wavefront stages in LDS and writes out coalesced at the end of its chunk (32 KB of fp64)
 constexpr int      kWavesPerBlock = 1;   // converter / fix-up launches; the SpMV default: 1 wave per workgroup spreads the chunks most evenly over the CUs (profiles/r01_waves_per_block.log)
@@ -47,7 +54,7 @@ constexpr int64_t  kPlanRowBlock = 65536;   // the planner restarts a chunk at e
 constexpr int      kMaxWavesPerBlock = 16;   // SpMV workgroups of several consecutive chunks share an LDS window of x (cvr_options.waves_per_block)
 constexpr size_t   kLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 
-inline int group_bytes(bool f32, bool dict = false) { return dict ? kGroupBytesDict : f32 ? kGroupBytes32 : kGroupBytes64; }
+inline int group_bytes(bool f32, bool dict = false, bool c16 = false) { return dict ? kGroupBytesDict : c16 ? (f32 ? kGroupBytes32C16 : kGroupBytes64C16) : f32 ? kGroupBytes32 : kGroupBytes64; }
 
 struct Shared { int64_t row, c0, c1; };
 

@@ -39,6 +39,8 @@ struct DeviceImage {
                                     // above the column index: bits [col_bits, 31); bit 31 stays the end flag
     // hub table (cvr_hub.hip): the hub_n columns with the most non-zeros; a slot of such a column holds its table index and
     // kHubBit; the workgroup stages hub_x[0 .. hub_n) (= x[hub_cols], compacted before every SpMV) in LDS in front of the window
+    bool      c16 = false;          // narrow chunks: 16-bit column offsets from cbase[k] (plain layout without dictionary only)
+    uint32_t *cbase = nullptr;      // [nchunks] smallest column of the chunk
     uint32_t  hub_n = 0;
     int32_t  *hub_cols = nullptr;   // [hub_n] the hub columns, by non-zeros descending
     int32_t  *hub_index = nullptr;  // [ncols] table index of a column, -1 = none (conversion only)
@@ -115,6 +117,8 @@ hipError_t launch_unpad(void *dense, const void *padded, const IterBounds &bd, i
 // rows sorted by column? how many non-zeros in the fullest two adjacent bins of `half` columns of every 256 rows?  out2[2 * kProbeBlocks] = {unsorted flag, count} per workgroup
 constexpr uint32_t kProbeBlocks = 1024;
 hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st);
+// per chunk: its smallest column into cbase[k]; *wide (device u32, zeroed by the caller) gets 1 if any chunk spans 32 767 columns or more
+hipError_t launch_chunk_span(const DeviceImage &img, const DeviceCsr &csr, uint32_t *cbase, uint32_t *wide, hipStream_t st);
 // min / max of col_idx[n0 .. n1) into minmax[0..1] (device; initialised by the caller to INT_MAX / INT_MIN)
 hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st);
 hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, unsigned long long *table, uint32_t *flags, hipStream_t st);

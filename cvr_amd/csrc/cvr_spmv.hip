@@ -51,10 +51,25 @@ template <> struct Group<double, false> { u32x4 c; f64x2 lo, hi; };
 template <> struct Group<float, false>  { u32x4 c; f32x4 v; };
 template <typename T> struct Group<T, true> { u32x4 c; uint32_t codes; };   // four dictionary codes, one byte per step
 
-template <typename T, int POL, bool DICT>
+// C16 (narrow chunks): the group's column part is [64 lanes][4 x u16 offset from the chunk's smallest column]; the loaded
+// words are widened to the usual column words (end flag in bit 31, the pad column for 0x7fff) by widen_cols once the
+// data has arrived, so the rest of the kernel does not know the difference.
+template <typename T, int POL, bool DICT, bool C16 = false>
 __device__ __forceinline__ Group<T, DICT> load_group(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
     Group<T, DICT> g;
+    if constexpr (C16) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 h = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff >> 1, soff, POL));
+        g.c = u32x4{h.x, h.y, 0u, 0u};
+        if constexpr (sizeof(T) == 8) {
+            g.lo = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, voff + kCols16Bytes, soff, POL));
+            g.hi = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, voff + kCols16Bytes + kLanes * 16, soff, POL));
+        } else {
+            g.v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + kCols16Bytes, soff, POL));
+        }
+        return g;
+    }
     g.c = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, POL));
     if constexpr (DICT) {
         g.codes = __builtin_amdgcn_raw_buffer_load_b32(r, (voff >> 2) + kColsBytes, soff, POL);
@@ -65,6 +80,17 @@ __device__ __forceinline__ Group<T, DICT> load_group(__amdgpu_buffer_rsrc_t r, u
         g.v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + kColsBytes, soff, POL));
     }
     return g;
+}
+
+__device__ __forceinline__ uint32_t widen_col(uint32_t h, uint32_t base, uint32_t pad_col)
+{
+    const uint32_t off = h & kC16Pad;
+    return (off == kC16Pad ? pad_col : base + off) | ((h & 0x8000u) << 16);
+}
+// the two loaded words of a narrow chunk's group (four 16-bit offsets) -> four column words
+__device__ __forceinline__ u32x4 widen_cols(const u32x4 c, uint32_t base, uint32_t pad_col)
+{
+    return u32x4{widen_col(c.x & 0xffffu, base, pad_col), widen_col(c.x >> 16, base, pad_col), widen_col(c.y & 0xffffu, base, pad_col), widen_col(c.y >> 16, base, pad_col)};
 }
 
 template <typename T> struct X4 { T v[4]; T w[4]; };   // v: through the buffer descriptor, w: from the LDS window
@@ -210,14 +236,15 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
 
 // MW: more than one wavefront per workgroup (blockDim.x / 64 consecutive chunks share the workgroup's LDS window of x and its
 // dictionary copy); the single-wavefront form needs no barrier.
-template <typename T, int QA, int XPOL, int DEPTH, bool WIN, bool DICT, bool MW, bool SEGT>
+template <typename T, int QA, int XPOL, int DEPTH, bool WIN, bool DICT, bool MW, bool SEGT, bool C16>
 __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv_kernel(
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
     const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
     uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict,
-    uint32_t ystage_n, const uint2 *__restrict__ desc2, uint32_t col_bits, const T *__restrict__ hub_x, uint32_t hub_n, uint32_t kstride)
+    uint32_t ystage_n, const uint2 *__restrict__ desc2, uint32_t col_bits, const T *__restrict__ hub_x, uint32_t hub_n, uint32_t kstride,
+    const uint32_t *__restrict__ cbase, uint32_t pad_col)
 {
-    constexpr int  GB = DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
+    constexpr int  GB = DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     constexpr bool kSync = WIN || (DICT && MW);      // LDS filled by other waves of the workgroup
     // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums (SEGT: row accumulators), the value dictionary (DICT),
     // the x window and its zero slot (WIN; wn + 4 values)
@@ -248,12 +275,14 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     __amdgpu_buffer_rsrc_t rs;
     uint4          d;
     uint32_t       nri = 0;                            // SEGT: rows with a segment in this chunk
+    uint32_t       cb = 0;                             // C16: the chunk's smallest column
     // the first loads of chunk k: its stream (a wave past the last chunk streams nothing), its descriptor
     auto begin_chunk = [&]() {
         rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G * GB), live ? (uint32_t)G * GB : 0u);
 #pragma unroll
-        for (int i = 0; i < QN; i++) Q[i] = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)i * GB);
+        for (int i = 0; i < QN; i++) Q[i] = load_group<T, SPOL, DICT, C16>(rs, voff, (uint32_t)i * GB);
         d = live ? desc[k] : uint4{0, 0, 0, 0};
+        if constexpr (C16) cb = live ? cbase[k] : 0u;
         if constexpr (SEGT) {
             if (live) {
                 nri = desc2[k].y;
@@ -320,13 +349,18 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
         // 8-byte stores they replace cost 12 % of the kernel (profiles/r01_y_staging.log).  A chunk of more than ystage_n
         // segments (very short rows) stores directly.
         const bool staged = SEGT || nseg <= ystage_n;
+        if constexpr (C16) {
+#pragma unroll
+            for (int i = 0; i < DEPTH; i++) Q[i].c = widen_cols(Q[i].c, cb, pad_col);
+        }
 #pragma unroll
         for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL, WIN>(rx, win, Q[i].c, cmask, wbase, wn, (hub_n + 3u) & ~3u);
 
         // every load is unconditional: past the end of the chunk the stream loads are out of range (zeros, no
         // traffic) and the gathers they feed all read x[0]
         for (int g = 0; g < G; g++) {
-            const Group<T, DICT> Qn = load_group<T, SPOL, DICT>(rs, voff, (uint32_t)(g + QN) * GB);
+            const Group<T, DICT> Qn = load_group<T, SPOL, DICT, C16>(rs, voff, (uint32_t)(g + QN) * GB);
+            if constexpr (C16) Q[DEPTH].c = widen_cols(Q[DEPTH].c, cb, pad_col);       // (arrived an iteration ago: the gather below needs it anyway)
             const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn, (hub_n + 3u) & ~3u);
             sum_group<T, WIN, DICT, SEGT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged, col_bits);
 #pragma unroll
@@ -500,17 +534,27 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     if (lds > kLdsBytes) return hipErrorInvalidValue;      // build_part sizes the stage and the window to fit; never reached
     // template parameters: <value type, stream run-ahead beyond the gather, gather cache policy, gather run-ahead, LDS window, dictionary, multi-wave, column phases>
 #define CVR_LAUNCH(T, SP, D, W, DI, MW, SG)                                                                       \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, SG>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, SG, false>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
-                       static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(img.hub_x), img.hub_n, kstride)
+                       static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(img.hub_x), img.hub_n, kstride, img.cbase, img.pad_col)
 #define CVR_PICK_SG(T, SP, D, W, DI, MW) do { if (img.phases > 1) CVR_LAUNCH(T, SP, D, W, DI, MW, true); else CVR_LAUNCH(T, SP, D, W, DI, MW, false); } while (0)
 #define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_PICK_SG(T, SP, D, W, DI, true); else CVR_PICK_SG(T, SP, D, W, DI, false); } while (0)
 #define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_PICK_MW(T, SP, D, W, true); else CVR_PICK_MW(T, SP, D, W, false); } while (0)
 #define CVR_PICK_W(T, SP, D)     do { if (use_win) CVR_PICK_DI(T, SP, D, true); else CVR_PICK_DI(T, SP, D, false); } while (0)
 #define CVR_PICK_D(T, SP)        do { if (img.depth == 2) CVR_PICK_W(T, SP, 2); else CVR_PICK_W(T, SP, 1); } while (0)
 #define CVR_PICK_SP(T)           do { if (img.stream_ahead >= 2) CVR_PICK_D(T, 3); else CVR_PICK_D(T, 1); } while (0)
-    if (img.f32) CVR_PICK_SP(float); else CVR_PICK_SP(double);
+#define CVR_LAUNCH_C16(T, SP, D)                                                                                  \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, false, false, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
+                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
+                       img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, 0u,          \
+                       static_cast<const T *>(nullptr), 0u, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(nullptr), 0u, 0u, img.cbase, img.pad_col)
+#define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
+                             else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
+    if (img.c16 && !use_win && !use_dict && wpb == 1 && img.phases <= 1) { if (img.f32) CVR_PICK_C16(float); else CVR_PICK_C16(double); }
+    else if (img.f32) CVR_PICK_SP(float); else CVR_PICK_SP(double);
+#undef CVR_PICK_C16
+#undef CVR_LAUNCH_C16
 #undef CVR_PICK_SP
 #undef CVR_PICK_D
 #undef CVR_PICK_W

@@ -92,7 +92,9 @@ typedef struct {
                                   their x values compacted before every SpMV and staged in LDS by every workgroup (8 chunks),
                                   their gathers become ds_reads.  For power-law matrices whose x does not fit an L2.
                                   0 = off, <0 = auto (default): on when those columns hold >= 50 % of the non-zeros        */
-    int32_t reserved2;
+    int32_t narrow_cols;       /* 16-bit column offsets per chunk when every chunk spans fewer than 32 767 columns (banded
+                                  matrices; plain layout without value dictionary): 10 instead of 12 bytes per fp64 slot.
+                                  0 = off, <0 = auto (default)                                                             */
 } cvr_options;
 /* Automatic layout: with steps_per_chunk = 0, waves_per_block = 0, x_window < 0 and col_phases < 0 (the defaults) cvr_create
  * looks at the uploaded CSR on the device (are the rows sorted by column? which share of the non-zeros lies near the
@@ -127,7 +129,7 @@ typedef struct {
     int64_t chunk_row_cap;     /* column phases: most rows the planner gives a chunk (their sums live in LDS); 0 = none */
     double  near_diagonal_share;   /* automatic layout: share of the non-zeros within a quarter window of the diagonal (0 if not probed) */
     int32_t hub_entries;           /* hub table: columns staged in LDS (0 = none)                                          */
-    int32_t reserved3;
+    int32_t narrow_cols;           /* 1: the image stores 16-bit column offsets (narrow chunks)                             */
     double  hub_share;             /* share of the non-zeros in the hub columns that were (or could have been) chosen      */
     double  hub_select_s;          /* the device pass that counted and ranked the columns (0 if not run)                  */
     double  probe_s;               /* automatic layout: the device pass over the CSR (sortedness, near-diagonal share), 0 if not run */

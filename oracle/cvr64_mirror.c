@@ -129,7 +129,18 @@ int orc_cvr64_build_ex(int64_t nrows, int64_t ncols, const int64_t *rp, const in
 int orc_cvr64_build_hub(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
                         int S, int64_t thr, int use_dict, int phases, int64_t max_rows, int64_t hub_max, orc_cvr64 *c)
 {
+    return orc_cvr64_build_all(nrows, ncols, rp, cols, vals, is_f32, S, thr, use_dict, phases, max_rows, hub_max, 0, c);
+}
+
+/* narrow != 0: narrow chunks -- the column part of a group holds 16-bit offsets from the chunk's smallest column (bit 15 = end
+ * of segment, 0x7fff = the pad column); needs every chunk to span fewer than 32 767 columns (-8 otherwise), no dictionary,
+ * no phases, no hub table */
+int orc_cvr64_build_all(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
+                        int S, int64_t thr, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int narrow, orc_cvr64 *c)
+{
     memset(c, 0, sizeof(*c));
+    if (narrow && (use_dict || phases > 1 || hub_max > 0)) return -8;
+    c->narrow = narrow != 0;
     int32_t *hub_index = NULL;
     if (hub_max > 0 && phases <= 1 && ncols > 0 && nrows > 0) {
         hubkey_t *k = (hubkey_t *)calloc((size_t)ncols, sizeof(hubkey_t));
@@ -168,8 +179,10 @@ int orc_cvr64_build_hub(int64_t nrows, int64_t ncols, const int64_t *rp, const i
         c->ndict = build_dict(vals, is_f32, nrows ? rp[0] : 0, nrows ? rp[nrows] : 0, c->dict);
         if (c->ndict < 0) { free(ch); return -5; }
     }
-    const size_t gb = c->ndict ? 1280 : is_f32 ? 2048 : 3072;
+    const size_t gb = c->ndict ? 1280 : c->narrow ? (is_f32 ? 1536 : 2560) : is_f32 ? 2048 : 3072;
+    const size_t cbytes = c->narrow ? 512 : 1024;          /* column part of a group */
     c->image_bytes = (int64_t)((size_t)NC * G * gb);
+    if (c->narrow) c->cbase = (uint32_t *)calloc((size_t)NC + 1, sizeof(uint32_t));
     c->image = (uint8_t *)calloc((size_t)c->image_bytes + 16, 1);
     c->desc = (uint32_t *)calloc((size_t)NC * 4 + 4, sizeof(uint32_t));
     c->target = (uint8_t *)calloc((size_t)NC * W + 1, 1);
@@ -239,6 +252,12 @@ int orc_cvr64_build_hub(int64_t nrows, int64_t ncols, const int64_t *rp, const i
             nsegtot += n;
         }
 
+        if (c->narrow) {                  /* the chunk's smallest column; its span must fit 15 bits minus the pad code */
+            int64_t lo = INT64_MAX, hi = -1;
+            for (int64_t j = b; j < e; j++) { if (cols[j] < lo) lo = cols[j]; if (cols[j] > hi) hi = cols[j]; }
+            c->cbase[k] = hi >= 0 ? (uint32_t)lo : 0u;
+            if (hi >= 0 && hi - lo >= 0x7fff) { rc = -8; break; }
+        }
         int64_t pos[W], cnt[W], fed = 0;
         uint32_t tag[W];
         for (int l = 0; l < W; l++) { pos[l] = -1; cnt[l] = 0; tag[l] = 0; c->target[k * W + l] = (uint8_t)l; }
@@ -268,16 +287,20 @@ int orc_cvr64_build_hub(int64_t nrows, int64_t ncols, const int64_t *rp, const i
                     pos[l]++;
                 }
                 if (cnt[l] == 1) col |= 0x80000000u | tag[l];
+                if (c->narrow) {
+                    const uint32_t cc = col & 0x7fffffffu;
+                    ((uint16_t *)grp)[l * 4 + j] = (uint16_t)((cc == (uint32_t)ncols ? 0x7fffu : cc - c->cbase[k]) | (col >> 31 << 15));
+                } else
                 ((uint32_t *)grp)[l * 4 + j] = col;
                 if (c->ndict) {                               /* one code byte per slot: position in the sorted dictionary */
                     uint64_t b;
                     if (is_f32) { float f = (float)v; uint32_t u; memcpy(&u, &f, 4); b = u; } else memcpy(&b, &v, 8);
                     int code = 0;
                     while (code < c->ndict && c->dict[code] != b) code++;
-                    (grp + 1024)[l * 4 + j] = (uint8_t)code;
+                    (grp + cbytes)[l * 4 + j] = (uint8_t)code;
                 }
-                else if (is_f32) ((float *)(grp + 1024))[l * 4 + j] = (float)v;
-                else ((double *)(grp + 1024 + (j / 2) * 1024))[l * 2 + j % 2] = v;
+                else if (is_f32) ((float *)(grp + cbytes))[l * 4 + j] = (float)v;
+                else ((double *)(grp + cbytes + (j / 2) * 1024))[l * 2 + j % 2] = v;
                 cnt[l]--;
             }
         }
@@ -292,7 +315,7 @@ int orc_cvr64_build_hub(int64_t nrows, int64_t ncols, const int64_t *rp, const i
 void orc_cvr64_free(orc_cvr64 *c)
 {
     free(c->image); free(c->desc); free(c->target); free(c->shared); free(c->nz_begin); free(c->pad_cnt);
-    free(c->seg_off); free(c->seg_row); free(c->nrows_in); free(c->hub_cols);
+    free(c->seg_off); free(c->seg_row); free(c->nrows_in); free(c->hub_cols); free(c->cbase);
     memset(c, 0, sizeof(*c));
 }
 
@@ -306,7 +329,8 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
 {
     const int S = c->S, G = S / 4;
     const int64_t NC = c->nchunks, nrows = c->nrows;
-    const size_t gb = c->ndict ? 1280 : c->is_f32 ? 2048 : 3072;
+    const size_t gb = c->ndict ? 1280 : c->narrow ? (c->is_f32 ? 1536 : 2560) : c->is_f32 ? 2048 : 3072;
+    const size_t cbytes = c->narrow ? 512 : 1024;
     const size_t next = (size_t)(nrows + 1 + 2 * NC);
     const int ph = c->phases > 1;          /* column phases: a segment's sum is ADDED to its row's accumulator (LDS on the device) */
     double *yext = (double *)calloc(next + 1, sizeof(double));
@@ -330,20 +354,24 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
             const int j = i % 4;
             int flagged[W];
             for (int l = 0; l < W; l++) {
-                const uint32_t cw = ((const uint32_t *)grp)[l * 4 + j];
+                uint32_t cw;
+                if (c->narrow) {
+                    const uint32_t h = ((const uint16_t *)grp)[l * 4 + j], off = h & 0x7fffu;
+                    cw = (off == 0x7fffu ? (uint32_t)c->ncols : c->cbase[k] + off) | ((h >> 15) << 31);
+                } else cw = ((const uint32_t *)grp)[l * 4 + j];
                 uint32_t col = cw & cmask;
                 if (c->hub_n && (col & 0x40000000u)) col = (uint32_t)c->hub_cols[col & 0x3fffffffu];     /* hub slot: rank -> column */
                 flagged[l] = cw >> 31;
                 rowtag[l] = ph ? (cw & 0x7fffffffu) >> c->col_bits : 0;
                 if (c->is_f32) {
                     float v;
-                    if (c->ndict) { const uint32_t u = (uint32_t)c->dict[(grp + 1024)[l * 4 + j]]; memcpy(&v, &u, 4); }
-                    else v = ((const float *)(grp + 1024))[l * 4 + j];
+                    if (c->ndict) { const uint32_t u = (uint32_t)c->dict[(grp + cbytes)[l * 4 + j]]; memcpy(&v, &u, 4); }
+                    else v = ((const float *)(grp + cbytes))[l * 4 + j];
                     acc[l] = (double)fmaf(v, ((const float *)xv)[col], (float)acc[l]);
                 } else {
                     double v;
-                    if (c->ndict) memcpy(&v, &c->dict[(grp + 1024)[l * 4 + j]], 8);
-                    else v = ((const double *)(grp + 1024 + (j / 2) * 1024))[l * 2 + j % 2];
+                    if (c->ndict) memcpy(&v, &c->dict[(grp + cbytes)[l * 4 + j]], 8);
+                    else v = ((const double *)(grp + cbytes + (j / 2) * 1024))[l * 2 + j % 2];
                     acc[l] = fma(v, ((const double *)xv)[col], acc[l]);
                 }
             }

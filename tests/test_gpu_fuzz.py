@@ -78,7 +78,7 @@ def test_fuzz_parity():
             ph = A.info.col_phases
         ctx["from_dev"] = bool(from_dev)
         if P == 1:
-            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0, phases=ph, max_rows=A.info.chunk_row_cap, hub_max=A.info.hub_entries)
+            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0, phases=ph, max_rows=A.info.chunk_row_cap, hub_max=A.info.hub_entries, narrow=A.info.narrow_cols)
             img = A.export_image()
             assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc), ctx
             assert np.array_equal(img["target"], mir.target) and np.array_equal(img["shared"], mir.shared), ctx

@@ -44,7 +44,7 @@ def test_library_is_the_hip_build_and_sees_the_gpu():
 def test_converter_image_bit_exact_and_y_parity(name, S):
     nrows, ncols, rp, ci, va = CASES[name]
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S)
-    mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=A.info.value_dict > 0)
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=A.info.value_dict > 0, narrow=A.info.narrow_cols)
     assert (A.info.nchunks, A.info.nshared, A.info.value_dict) == (mir.nchunks, mir.nshared, mir.ndict)
     img = A.export_image()
     assert np.array_equal(img["desc"], mir.desc)
@@ -72,7 +72,7 @@ def test_workgroup_window_and_column_phases(name, S, wpb, win, P):
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, waves_per_block=wpb, x_window=win, col_phases=P)
     i = A.info
     assert (i.col_phases, i.waves_per_block) == (P, wpb)
-    mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=i.value_dict > 0, phases=P, max_rows=i.chunk_row_cap)
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=i.value_dict > 0, phases=P, max_rows=i.chunk_row_cap, narrow=i.narrow_cols)
     img = A.export_image()
     assert (i.nchunks, i.nshared) == (mir.nchunks, mir.nshared)
     for key in ("desc", "target", "shared", "image"):
@@ -112,7 +112,7 @@ def test_column_phases_need_sorted_rows_and_fit_the_row_field():
 def test_fp32_path(name):
     nrows, ncols, rp, ci, va = CASES32[name]
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=8)
-    mir = O.Cvr64(nrows, ncols, rp, ci, va, 8, use_dict=A.info.value_dict > 0)
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, 8, use_dict=A.info.value_dict > 0, narrow=A.info.narrow_cols)
     assert np.array_equal(A.export_image()["image"], mir.image)
     x = O.x_vec_fast(ncols, "rand").astype(np.float32)
     yref, absy = O.csr_spmv64(rp, ci, va, x)
@@ -127,7 +127,7 @@ def test_split_threshold_and_launch_options(thr, swz, nt):
     for name, S in (("power_law_3000", 8), ("two_giants", 16), ("dense_row_plus_singletons", 4)):
         nrows, ncols, rp, ci, va = CASES[name]
         A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, stream_ahead=nt)
-        mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0)
+        mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0, narrow=A.info.narrow_cols)
         img = A.export_image()
         assert np.array_equal(img["image"], mir.image) and np.array_equal(img["shared"], mir.shared)
         x = O.x_vec_fast(ncols, "rand")
@@ -909,3 +909,37 @@ def test_hub_table_in_column_panels_and_automatic_choice():
     assert A3.info.hub_entries == 0
     A3.close()
     A.close(); A2.close()
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_narrow_chunks_store_16_bit_columns(f32):
+    """banded matrix: every chunk spans fewer than 32 767 columns, so the image stores 16-bit column offsets (10 instead of 12
+    bytes per fp64 slot): image against the mirror bit for bit, y against the CSR oracle; a matrix with one far column keeps
+    32-bit column words; the value dictionary takes precedence over narrow columns"""
+    nrows, ncols, rp, ci, va = synth.banded_sym(40_000, dtype=np.float32 if f32 else np.float64)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=16)
+    B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=16, narrow_cols=0)
+    assert A.info.narrow_cols == 1 and B.info.narrow_cols == 0 and A.info.image_bytes < 0.87 * B.info.image_bytes
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, 16, narrow=True)
+    img = A.export_image()
+    for key in ("desc", "target", "shared", "image"):
+        assert np.array_equal(img[key], getattr(mir, key)), key
+    x = synth.x_rand(ncols, va.dtype)
+    yref, absy = O.csr_spmv64(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    ya, _ = A.spmv(x)
+    yb, _ = B.spmv(x)
+    _assert_close(ya, yref, absy, TOL32 if f32 else TOL64, "narrow")
+    assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8))            # same slots, same order of operations
+    A.close(); B.close()
+    ci2 = ci.copy()
+    ci2[rp[100]] = 39_999 if ci2[rp[100]] != 39_999 else 0                  # one entry far from the band: that chunk is wide
+    C2 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci2, va, steps_per_chunk=16)
+    assert C2.info.narrow_cols == 0
+    y2, _ = C2.spmv(x)
+    yref2, absy2 = O.csr_spmv64(rp, ci2, va.astype(np.float64), x.astype(np.float64))
+    _assert_close(y2, yref2, absy2, TOL32 if f32 else TOL64, "wide chunk")
+    C2.close()
+    vd = np.where(np.arange(len(va)) % 2 == 0, 1.0, -0.5).astype(va.dtype)
+    D2 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, vd, steps_per_chunk=16)
+    assert D2.info.value_dict > 0 and D2.info.narrow_cols == 0
+    D2.close()

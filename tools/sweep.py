@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--dict", default="-1", help="value dictionary (-1 auto, 0 off)")
     ap.add_argument("--phases", default="0", help="column phases (0 / 1 off, -1 auto)")
     ap.add_argument("--hub", default="0", help="hub table entries (0 off, -1 auto)")
+    ap.add_argument("--narrow", default="-1", help="16-bit column offsets for narrow chunks (-1 auto, 0 off)")
     ap.add_argument("--check", action="store_true", help="compare y of every configuration with the host CSR loop")
     ap.add_argument("--colmask", default="0", help="comma list of hex masks: folds the x gather onto a small table (timing only)")
     ap.add_argument("--iters", type=int, default=300)
@@ -61,13 +62,13 @@ def main():
     for S in [int(s) for s in a.S.split(",")]:
         for thr in [int(s) for s in a.thr.split(",")]:
             for swz in [int(s) for s in a.swz.split(",")]:
-                for (nt, cm, wpb, dp, win, pan, vd, php, hub) in [(int(s), int(m, 16), int(wp), int(dp), int(w), int(pn), int(vd), int(php), int(hb)) for s in a.nt.split(",")
+                for (nt, cm, wpb, dp, win, pan, vd, php, hub, nar) in [(int(s), int(m, 16), int(wp), int(dp), int(w), int(pn), int(vd), int(php), int(hb), int(na)) for s in a.nt.split(",")
                                                    for m in a.colmask.split(",") for wp in a.wpb.split(",")
                                                    for dp in a.depth.split(",") for w in a.win.split(",") for pn in a.panels.split(",")
-                                                   for vd in a.dict.split(",") for php in a.phases.split(",") for hb in a.hub.split(",")]:
+                                                   for vd in a.dict.split(",") for php in a.phases.split(",") for hb in a.hub.split(",") for na in a.narrow.split(",")]:
                     try:
                         A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, stream_ahead=nt,
-                                              debug_col_mask=cm, depth=dp, x_window=win, col_panels=pan, waves_per_block=wpb, value_dict=vd, col_phases=php, hub_table=hub)
+                                              debug_col_mask=cm, depth=dp, x_window=win, col_panels=pan, waves_per_block=wpb, value_dict=vd, col_phases=php, hub_table=hub, narrow_cols=nar)
                     except Exception as e:
                         print(f"  {S:4d} wpb {wpb} win {win}: {e}", flush=True)
                         continue
@@ -84,7 +85,7 @@ def main():
                     s = A.bench(a.warmup, a.iters)
                     i = A.info
                     print(f"  {S:4d}  {swz}  {nt:2d}  {thr:6d}  {i.nchunks:6d} {i.nshared:5d}  {i.nslots / max(nnz, 1):8.4f}  {i.convert_s * 1e6:9.1f}  "
-                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  depth {dp} wpb {wpb} win {i.x_window} panels {i.col_panels} dict {i.value_dict} phases {i.col_phases} hub {i.hub_entries} ({i.hub_share:.2f}, {i.hub_select_s * 1e3:.1f} ms) lds {i.lds_bytes} pre_wall_us {i.preprocess_wall_s * 1e6:.0f} plan_us {i.plan_s * 1e6:.0f} probe_us {i.probe_s * 1e6:.0f}{wrong}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
+                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  depth {dp} wpb {wpb} win {i.x_window} panels {i.col_panels} dict {i.value_dict} phases {i.col_phases} hub {i.hub_entries} ({i.hub_share:.2f}, {i.hub_select_s * 1e3:.1f} ms) lds {i.lds_bytes} narrow {i.narrow_cols} image_MB {i.image_bytes / 1e6:.0f} pre_wall_us {i.preprocess_wall_s * 1e6:.0f} plan_us {i.plan_s * 1e6:.0f} probe_us {i.probe_s * 1e6:.0f}{wrong}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
                     A.close()
 
 
