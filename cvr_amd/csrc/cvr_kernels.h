@@ -25,6 +25,7 @@ struct DeviceImage {
     int      depth = 1;             // groups the x gather runs ahead of the FMAs (1 or 2)
     const void *dict = nullptr;     // value dictionary: ndict values of T sorted by bit pattern (device), or null
     uint32_t  ndict = 0;
+    uint32_t persist_waves = 0;     // > 0: persistent workgroups, this many wavefronts per CU, each looping over chunk groups (0 = one launch per chunk group)
     uint32_t wpb = 1;               // wavefronts (= consecutive chunks) per SpMV workgroup, 1..kMaxWavesPerBlock
     uint32_t *win_base = nullptr;   // [ceil(nchunks / wpb)] first column of each workgroup's LDS window of x
     uint32_t win_elems = 0;         // window length in values (0 = no window)

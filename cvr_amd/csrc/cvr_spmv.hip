@@ -22,6 +22,7 @@
 #include "cvr_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace cvr {
 namespace {
@@ -517,10 +518,18 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     // a hub table without a per-workgroup window: persistent workgroups (as many as fit the 256 CUs with this much LDS), each
     // staging the table once and taking chunk groups blk, blk + grid, ...
     uint32_t       kstride = 0;
-    if (img.hub_n > 0 && img.win_elems == 0 && img.xcd_swizzle != 2) {
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, kLdsBytes / std::max<size_t>(spmv_lds_bytes(img), 1));
-        const uint32_t resident = 256u * std::min<uint32_t>(per_cu, std::max<uint32_t>(1u, 16u / wpb));
-        if (nblocks > resident) { nblocks = resident; kstride = resident * wpb; }
+    if (img.win_elems == 0 && img.xcd_swizzle != 2 && img.phases <= 1) {
+        // persistent workgroups: as many as are resident at once, each taking chunk groups blk, blk + grid, ...  With a hub
+        // table they stage it once.  Without one they were measured on the banded shape (CVR_PERSIST_WAVES = 8 .. 32
+        // wavefronts per CU: 204-230 us against 204-208 us for one launch per chunk, profiles/r02_persistent_plain_layout.log)
+        // and stay off: the dispatcher is not what limits the plain layout.
+        const uint32_t per_cu_lds = (uint32_t)std::max<size_t>(1, kLdsBytes / std::max<size_t>(spmv_lds_bytes(img), 1));
+        static const int env_waves = [] { const char *e = getenv("CVR_PERSIST_WAVES"); return e ? atoi(e) : -1; }();
+        const uint32_t waves = img.hub_n ? 16u : env_waves >= 0 ? (uint32_t)env_waves : img.persist_waves;       // wavefronts per CU
+        if (waves > 0) {
+            const uint32_t resident = 256u * std::min<uint32_t>(per_cu_lds, std::max<uint32_t>(1u, waves / wpb));
+            if (nblocks > resident) { nblocks = resident; kstride = resident * wpb; }
+        }
     }
     const uint32_t per_xcd = (nblocks + 7) / 8;
     const uint32_t grid = img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;
@@ -548,7 +557,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, false, false, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, 0u,          \
-                       static_cast<const T *>(nullptr), 0u, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(nullptr), 0u, 0u, img.cbase, img.pad_col)
+                       static_cast<const T *>(nullptr), 0u, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col)
 #define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
                              else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
     if (img.c16 && !use_win && !use_dict && wpb == 1 && img.phases <= 1) { if (img.f32) CVR_PICK_C16(float); else CVR_PICK_C16(double); }
