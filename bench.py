@@ -234,6 +234,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--steps-per-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--col-panels", type=int, default=-1, help="column panels (-1 = the library's rule)")
     ap.add_argument("--two-streams", action="store_true", help="also report the throughput of independent SpMVs alternating on two streams "
                     "(off by default: concurrent kernels would distort a rocprofv3 kernel-time summary of this command)")
     ap.add_argument("--workload", default="webgoogle", help="webgoogle (the headline, default) | livejournal | banded[<rows>] | rmat[<scale>] (fp32)")
@@ -303,7 +304,7 @@ def main():
         lrows, lnnz = int(bounds[rank + 1] - bounds[rank]), int(lrp_t[-1])
         build_s = time.perf_counter() - t_build0
         A = cvr_amd.CvrMatrix.from_device(lrows, ncols, lrp_t.data_ptr(), lci_t.data_ptr(), lva_t.data_ptr(), is_f32=f32, device=local_rank,
-                                          steps_per_chunk=args.steps_per_chunk, tune_steps=tune)
+                                          steps_per_chunk=args.steps_per_chunk, tune_steps=tune, col_panels=args.col_panels)
         np_dtype = np.float32 if f32 else np.float64
     else:
         nrows, ncols, rp, ci, va, source = load_host_workload(args.workload)
@@ -314,7 +315,7 @@ def main():
         lnnz = int(lrp[-1])
         build_s = time.perf_counter() - t_build0
         # a shard of this matrix on one of N GPUs is small enough for the layout to matter: measure it (cvr_tune)
-        A = cvr_amd.CvrMatrix(lrows, ncols, lrp, lci, lva, device=local_rank, steps_per_chunk=args.steps_per_chunk, tune_steps=tune)
+        A = cvr_amd.CvrMatrix(lrows, ncols, lrp, lci, lva, device=local_rank, steps_per_chunk=args.steps_per_chunk, tune_steps=tune, col_panels=args.col_panels)
         f32 = va.dtype == np.float32
         np_dtype = va.dtype
     create_s = time.perf_counter() - t_build0 - build_s

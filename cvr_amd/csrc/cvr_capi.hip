@@ -840,6 +840,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // 4..32 (profiles/r01_column_panels_livejournal_sweep2.log); R-MAT-24 fp32 (67 MB, 0.22) -> 8, 1 660 against
     // 2 300 us as one image (profiles/r01_column_panels_rmat24_fp32.log); R-MAT-22 fp64 (33.5 MB, 0.13) and matrices
     // whose x nearly fits (web-Google: profiles/r01_column_panel_probe.log) stay whole.
+    const bool panels_auto = !(opt_in && opt_in->col_panels >= 0);     // (opt.col_panels may already hold the rule's answer for device arrays)
     int P = opt.col_panels;
     clk.lap("device arrays: row_ptr, checks");
     if (P < 0) P = auto_panels(*csr, nullptr);
@@ -904,6 +905,24 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             }
         }
         clk.lap("  staging upload");
+        // Power-law matrices whose popular columns will sit in hub tables need fewer, wider panels: the table takes the hot
+        // half of the gathers off the L2s, and what remains runs best with ~16 MB of x per panel instead of ~4 (R-MAT-26 fp32
+        // on one GPU: 59 panels 6.4 ms, 16 panels 5.4 ms; R-MAT-24: 8 and 4 panels alike; profiles/r02_hub_table_rmat.log)
+        if (dev_split && panels_auto && opt.hub_table < 0 && !getenv("CVR_NO_AUTO_LAYOUT")) {
+            const int64_t room = ((int64_t)cvr::kLdsBytes / (int64_t)vsz - 8 * (cvr::kLanes + 512) - cvr::kDictMax - 8) & ~(int64_t)1023;
+            cvr::HubSelection sel;
+            const double      th0 = now_s();
+            const hipError_t  e = cvr::select_hubs(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &sel, h->stream);
+            in.hub_select_s += now_s() - th0;
+            const double share = sel.share;
+            cvr::free_hubs(sel);
+            if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
+            if (share >= 0.25) {       // (of the whole matrix: the panels' own tables, ranked inside their ranges, hold more)
+                const int Pw = std::max(2, (int)std::ceil((double)ncols * (double)vsz / 16e6));
+                if (Pw < P) { P = Pw; h->parts.resize((size_t)P); in.col_panels = P; }
+            }
+        }
+        clk.lap("  panel count with hub tables");
         if (dev_split) {        // only row pointers and row numbers of the sub-rows come to the host
             const int64_t  width = (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1;
             const hipError_t e = cvr::split_panels_device(rp_d, ci_d, va_d, f32, nrows, sj0, sj1, width, P, &dsg.d, h->stream);
