@@ -27,7 +27,7 @@ class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
                 ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("stream_ahead", C.c_int32),
                 ("waves_per_block", C.c_int32), ("gather_depth", C.c_int32), ("debug_col_mask", C.c_int32),
-                ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("layout_auto_resident", C.c_int32), ("hub_table", C.c_int32), ("narrow_cols", C.c_int32)]
+                ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("layout_auto_resident", C.c_int32), ("hub_table", C.c_int32), ("narrow_cols", C.c_int32), ("hub_reorder", C.c_int32), ("reserved4", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -41,7 +41,7 @@ class Info(C.Structure):
                 ("image_bytes", C.c_int64), ("yext_elems", C.c_int64), ("x_elems", C.c_int64),
                 ("plan_s", C.c_double), ("upload_s", C.c_double), ("convert_s", C.c_double),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("waves_per_block", C.c_int32),
-                ("x_window", C.c_int32), ("lds_bytes", C.c_int32), ("nsegments", C.c_int64), ("chunk_row_cap", C.c_int64), ("near_diagonal_share", C.c_double), ("hub_entries", C.c_int32), ("narrow_cols", C.c_int32), ("hub_share", C.c_double),
+                ("x_window", C.c_int32), ("lds_bytes", C.c_int32), ("nsegments", C.c_int64), ("chunk_row_cap", C.c_int64), ("near_diagonal_share", C.c_double), ("hub_entries", C.c_int32), ("narrow_cols", C.c_int32), ("hub_reorder", C.c_int32), ("reserved5", C.c_int32), ("hub_share", C.c_double),
                 ("hub_select_s", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double)]
 
 
@@ -250,7 +250,7 @@ class CvrMatrix:
 
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
                  xcd_swizzle=-1, x_window=-1, stream_ahead=0, keep_csr=False, debug_col_mask=0, depth=0,
-                 col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1):
+                 col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1):
         """tune_steps: choose steps_per_chunk by measurement first (cvr_tune_steps; its cost is self.tuning_s)"""
         self._h = C.c_void_p()
         self.tuning_s = 0.0
@@ -267,7 +267,7 @@ class CvrMatrix:
             raise ValueError(f"col_idx / vals hold {len(ci)} / {len(va)} entries, row_ptr[nrows] = {int(rp[-1])}")
         view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
-                    debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block, col_phases, hub_table, narrow_cols)
+                    debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block, col_phases, hub_table, narrow_cols, hub_reorder)
 
     @classmethod
     def from_device(cls, nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, is_f32=False, device=0, steps_per_chunk=0,
@@ -285,7 +285,7 @@ class CvrMatrix:
         return self
 
     def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
-               debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1):
+               debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1):
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
@@ -293,6 +293,7 @@ class CvrMatrix:
         # tuning / profiling knobs (tools/sweep.py)
         opt.stream_ahead, opt.gather_depth, opt.debug_col_mask = stream_ahead, depth, debug_col_mask
         opt.waves_per_block, opt.col_phases, opt.hub_table, opt.narrow_cols = waves_per_block, col_phases, hub_table, narrow_cols
+        opt.hub_reorder = hub_reorder
         if tune_steps and steps_per_chunk == 0:          # the layout by measurement (cvr_tune): S, chunks per workgroup, x window, column phases
             best, best_t, tun = Options(), C.c_double(), C.c_double()
             rc = lib().cvr_tune(C.byref(view), C.byref(opt), C.byref(best), C.byref(best_t), C.byref(tun))

@@ -197,6 +197,7 @@ void cvr_default_options(cvr_options *o)
     o->col_phases = -1;
     o->hub_table = -1;
     o->narrow_cols = -1;
+    o->hub_reorder = -1;
 }
 
 int cvr_device_count(void)
@@ -461,7 +462,8 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
 // whose x does not fit an L2 get the columns counted on the device, and the table is used when the columns that fit the LDS
 // (beside 8 chunks' row stages) hold at least half of the (sampled) non-zeros -- R-MAT scale 22 fp32: 0.56, 402 -> 289 us;
 // fp64 (half as many entries fit): 0.41, where the table loses (profiles/r02_hub_table_rmat.log).  The workgroup then has 8 chunks.
-static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, cvr_options &opt, PartPlan &pp)
+static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, cvr_options &opt, PartPlan &pp,
+                       bool allow_reorder)
 {
     if (opt.hub_table == 0 || opt.layout_auto_resident || opt.col_phases > 1 || nrows <= 0 || ncols >= (int64_t)cvr::kHubBit) return CVR_OK;
     const int64_t vs = f32 ? 4 : 8, nnz = rp[nrows] - rp[0];
@@ -475,13 +477,19 @@ static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t n
     HIP_TRY(hipStreamSynchronize(h->stream));          // the upload
     const double t0 = now_s();
     cvr::HubSelection sel;
-    const hipError_t  e = cvr::select_hubs(d_ci, rp[0], rp[nrows], ncols, (uint32_t)room, &sel, h->stream);
+    // The whole of x re-ordered by popularity (every column index of the image becomes its rank, x_perm = x[perm] is built
+    // before every SpMV): the popular columns then share cache lines and stay in the L2s.  R-MAT-22 fp64 (x = 33.5 MB): plain
+    // 487 us, table alone 538, table + re-ordered x 400 us; fp32 (x = 16.8 MB): 288 -> 291 us, so only for a large x; not
+    // inside column panels (a panel ranks its own range).  hub_reorder: < 0 = this rule, 0 off, 1 on.
+    const bool        full_order = allow_reorder && (opt.hub_reorder > 0 || (opt.hub_reorder < 0 && (double)ncols * vs >= 24e6));
+    const hipError_t  e = cvr::select_hubs(d_ci, rp[0], rp[nrows], ncols, (uint32_t)room, &sel, h->stream, full_order);
     h->info.hub_select_s += now_s() - t0;
     if (e != hipSuccess) { cvr::free_hubs(sel); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
     h->info.hub_share = std::max(h->info.hub_share, sel.share);
-    if (sel.H == 0 || (automatic && sel.share < 0.5)) { cvr::free_hubs(sel); return CVR_OK; }
+    if (sel.H == 0 || (automatic && sel.share < (full_order ? 0.3 : 0.5))) { cvr::free_hubs(sel); return CVR_OK; }
     part.img.hub_n = sel.H; part.img.hub_cols = sel.hub_cols; part.img.hub_index = sel.hub_index; part.img.hub_bitmap = sel.hub_bitmap;
-    HIP_TRY(hipMalloc(&part.img.hub_x, (size_t)vs * ((sel.H + 3u) & ~3u)));
+    part.img.order_n = sel.order_n;
+    HIP_TRY(hipMalloc(&part.img.hub_x, (size_t)vs * (sel.order_n ? ((size_t)sel.order_n + 8) : ((sel.H + 3u) & ~3u))));
     pp.hub_n = sel.H;
     if (opt.waves_per_block == 0) opt.waves_per_block = wpb;
     return CVR_OK;
@@ -507,7 +515,7 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     if (!planned) {
         int rc = auto_layout(h, part, nrows, ncols, f32, rp, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
         if (rc) return rc;
-        rc = choose_hubs(h, part, part.d_ci, nrows, ncols, f32, rp, popt, local);
+        rc = choose_hubs(h, part, part.d_ci, nrows, ncols, f32, rp, popt, local, true);
         if (rc) return rc;
         const double t0 = now_s();
         plan_part(local, nrows, ncols, f32, rp, popt);
@@ -952,7 +960,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         std::vector<cvr_options> popts((size_t)P, panel_opt);
         if (dev_split)                     // hub tables per panel: the most popular columns of the panel's own range
             for (int p = 0; p < P; p++) {
-                rc = choose_hubs(h, h->parts[(size_t)p], dsg.d.ci + dsg.d.off[p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), popts[(size_t)p], pps[(size_t)p]);
+                rc = choose_hubs(h, h->parts[(size_t)p], dsg.d.ci + dsg.d.off[p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), popts[(size_t)p], pps[(size_t)p], false);
                 if (rc) { cvr_destroy(h); return rc; }
             }
         clk.lap("  hub tables of the panels");
@@ -1080,6 +1088,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     in.col_phases = (int32_t)h->parts[0].img.phases; in.waves_per_block = (int32_t)h->parts[0].img.wpb; in.x_window = (int32_t)h->parts[0].img.win_elems;
     in.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);
     in.narrow_cols = h->parts[0].img.c16 ? 1 : 0;
+    in.hub_reorder = h->parts[0].img.order_n ? 1 : 0;
     in.chunk_row_cap = h->parts[0].img.phases > 1 ? (int64_t)h->parts[0].img.ystage - 1 : 0;
     for (const Part &p : h->parts) {
         in.nchunks += p.nchunks; in.nshared += p.nshared; in.nslots += p.nchunks * 64 * p.img.S;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
     const uint2 *__restrict__ desc2, const int64_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
     const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags, const int32_t *__restrict__ hub_index, const uint32_t *__restrict__ hub_bitmap,
-    const uint32_t *__restrict__ cbase)
+    const uint32_t *__restrict__ cbase, uint32_t hub_n)
 {
     if constexpr (SEGT) { if (seg_flags[0] & 1u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
     constexpr int GB = DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
@@ -144,7 +144,10 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
             T        v = 0;
             if (pos >= 0) {
                 c = (uint32_t)cidx[pos]; v = vals[pos]; pos++;
-                if (hub_index && ((hub_bitmap[c >> 5] >> (c & 31u)) & 1u)) c = kHubBit | (uint32_t)hub_index[c];     // hub column: its index in the LDS table
+                if (hub_index && ((hub_bitmap[c >> 5] >> (c & 31u)) & 1u)) {      // hub column: its index in the LDS table (full order: every column's rank)
+                    const uint32_t rk = (uint32_t)hub_index[c];
+                    c = rk < hub_n ? kHubBit | rk : rk;
+                }
             }
             cw[j] = c | (cnt == 1 ? kEndBit | rowtag : 0u);
             vv[j] = v;
@@ -618,17 +621,17 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     hipLaunchKernelGGL((convert_kernel<T, DI, SG, false>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
                        csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
                        static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, \
-                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase)
+                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase, img.hub_n)
 #define CVR_CONVERT_SG(T, DI) do { if (seg) CVR_CONVERT(T, DI, true); else CVR_CONVERT(T, DI, false); } while (0)
     if (img.c16 && !img.dict && !seg) {      // narrow chunks: 16-bit column offsets
         if (img.f32) hipLaunchKernelGGL((convert_kernel<float, false, false, true>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const float *>(csr.vals),
                                         csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
                                         (const float *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
-                                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase);
+                                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u);
         else hipLaunchKernelGGL((convert_kernel<double, false, false, true>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const double *>(csr.vals),
                                 csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
                                 (const double *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
-                                (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase);
+                                (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u);
         return hipGetLastError();
     }
     if (img.f32) { if (img.dict) CVR_CONVERT_SG(float, true); else CVR_CONVERT_SG(float, false); }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void hub_gather_kernel(const T *__restrict__ x
 
 }  // namespace
 
-hipError_t select_hubs(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, HubSelection *out, hipStream_t st)
+hipError_t select_hubs(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, HubSelection *out, hipStream_t st, bool full_order)
 {
     *out = HubSelection{};
     if (n1 <= n0 || ncols <= 0 || hmax == 0) return hipSuccess;
@@ -102,14 +102,17 @@ hipError_t select_hubs(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols,
     out->H = (uint32_t)h_out[0];
     out->share = (double)h_out[1] / (double)nsamp;           // of the sampled non-zeros
     if (out->H > 0) {
-        HUB_TRY(hipMalloc(&out->hub_cols, 4 * (size_t)out->H));
+        // full_order: every column gets its rank (the whole of x is re-ordered by popularity before every SpMV), not only the hubs
+        const uint32_t nkeep = full_order ? (uint32_t)nc : out->H;
+        out->order_n = full_order ? (uint32_t)nc : 0;
+        HUB_TRY(hipMalloc(&out->hub_cols, 4 * (size_t)nkeep));
         HUB_TRY(hipMalloc(&out->hub_index, 4 * nc));
-        HUB_TRY(hipMemcpyAsync(out->hub_cols, col_s, 4 * (size_t)out->H, hipMemcpyDeviceToDevice, st));
+        HUB_TRY(hipMemcpyAsync(out->hub_cols, col_s, 4 * (size_t)nkeep, hipMemcpyDeviceToDevice, st));
         HUB_TRY(hipMemsetAsync(out->hub_index, 0xff, 4 * nc, st));
         HUB_TRY(hipMalloc(&out->hub_bitmap, 4 * ((nc + 31) / 32)));
-        HUB_TRY(hipMemsetAsync(out->hub_bitmap, 0, 4 * ((nc + 31) / 32), st));
-        hipLaunchKernelGGL(hub_index_kernel, dim3((out->H + 255) / 256), dim3(256), 0, st, out->hub_cols, out->H, out->hub_index);
-        hipLaunchKernelGGL(hub_bitmap_kernel, dim3((out->H + 255) / 256), dim3(256), 0, st, out->hub_cols, out->H, out->hub_bitmap);
+        HUB_TRY(hipMemsetAsync(out->hub_bitmap, full_order ? 0xff : 0, 4 * ((nc + 31) / 32), st));
+        hipLaunchKernelGGL(hub_index_kernel, dim3(std::min<uint32_t>(4096, (nkeep + 255) / 256)), dim3(256), 0, st, out->hub_cols, nkeep, out->hub_index);
+        if (!full_order) hipLaunchKernelGGL(hub_bitmap_kernel, dim3((out->H + 255) / 256), dim3(256), 0, st, out->hub_cols, out->H, out->hub_bitmap);
         HUB_TRY(hipGetLastError());
         HUB_TRY(hipStreamSynchronize(st));
     }
@@ -126,9 +129,10 @@ void free_hubs(HubSelection &s)
 hipError_t launch_hub_gather(const DeviceImage &img, const void *x_ext, hipStream_t st)
 {
     if (img.hub_n == 0) return hipSuccess;
-    const uint32_t Hpad = (img.hub_n + 3u) & ~3u;
-    if (img.f32) hipLaunchKernelGGL(hub_gather_kernel<float>, dim3((Hpad + 255) / 256), dim3(256), 0, st, static_cast<const float *>(x_ext), img.hub_cols, img.hub_n, Hpad, static_cast<float *>(img.hub_x));
-    else hipLaunchKernelGGL(hub_gather_kernel<double>, dim3((Hpad + 255) / 256), dim3(256), 0, st, static_cast<const double *>(x_ext), img.hub_cols, img.hub_n, Hpad, static_cast<double *>(img.hub_x));
+    const uint32_t n = img.order_n ? img.order_n : img.hub_n;       // order_n: the whole of x, re-ordered; x_perm[ncols] = 0 is the pad slot
+    const uint32_t Hpad = img.order_n ? (img.order_n + 1u + 3u) & ~3u : (img.hub_n + 3u) & ~3u;
+    if (img.f32) hipLaunchKernelGGL(hub_gather_kernel<float>, dim3((Hpad + 255) / 256), dim3(256), 0, st, static_cast<const float *>(x_ext), img.hub_cols, n, Hpad, static_cast<float *>(img.hub_x));
+    else hipLaunchKernelGGL(hub_gather_kernel<double>, dim3((Hpad + 255) / 256), dim3(256), 0, st, static_cast<const double *>(x_ext), img.hub_cols, n, Hpad, static_cast<double *>(img.hub_x));
     return hipGetLastError();
 }
 

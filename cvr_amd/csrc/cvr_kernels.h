@@ -43,17 +43,18 @@ struct DeviceImage {
     bool      c16 = false;          // narrow chunks: 16-bit column offsets from cbase[k] (plain layout without dictionary only)
     uint32_t *cbase = nullptr;      // [nchunks] smallest column of the chunk
     uint32_t  hub_n = 0;
+    uint32_t  order_n = 0;          // > 0 (= ncols): every column index of the image is the column's popularity rank; hub_x holds the whole re-ordered x
     int32_t  *hub_cols = nullptr;   // [hub_n] the hub columns, by non-zeros descending
     int32_t  *hub_index = nullptr;  // [ncols] table index of a column, -1 = none (conversion only)
     uint32_t *hub_bitmap = nullptr; // [ncols / 32] bit c = column c is a hub (conversion only: saves the lookup of the cold columns)
     void     *hub_x = nullptr;      // [hub_n rounded up to 4] values of T
 };
 
-struct HubSelection { int32_t *hub_cols = nullptr, *hub_index = nullptr; uint32_t *hub_bitmap = nullptr; uint32_t H = 0; double share = 0; };
+struct HubSelection { int32_t *hub_cols = nullptr, *hub_index = nullptr; uint32_t *hub_bitmap = nullptr; uint32_t H = 0, order_n = 0; double share = 0; };
 // columns are ranked on every stride-th non-zero: a sample of at most 2^23
 inline int64_t hub_sample_stride(int64_t nnz) { return nnz > (int64_t)(1 << 23) ? (nnz + (1 << 23) - 1) >> 23 : 1; }
 // the (at most hmax) columns with the most non-zeros among col_idx[n0, n1), at least 2 each; share = their part of the non-zeros; synchronises st
-hipError_t select_hubs(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, HubSelection *out, hipStream_t st);
+hipError_t select_hubs(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, HubSelection *out, hipStream_t st, bool full_order = false);
 void       free_hubs(HubSelection &s);
 hipError_t launch_hub_gather(const DeviceImage &img, const void *x_ext, hipStream_t st);     // hub_x = x[hub_cols]
 

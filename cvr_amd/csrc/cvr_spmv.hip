@@ -539,6 +539,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     const bool   use_win = (img.win_elems > 0 && img.win_base != nullptr) || img.hub_n > 0;
     const bool   use_dict = img.dict != nullptr;
     if (img.hub_n) { const hipError_t eh = launch_hub_gather(img, x_ext, st); if (eh != hipSuccess) return eh; }
+    if (img.order_n) x_ext = img.hub_x;            // the kernel gathers from the re-ordered copy of x
     const size_t lds = spmv_lds_bytes(img);
     if (lds > kLdsBytes) return hipErrorInvalidValue;      // build_part sizes the stage and the window to fit; never reached
     // template parameters: <value type, stream run-ahead beyond the gather, gather cache policy, gather run-ahead, LDS window, dictionary, multi-wave, column phases>

@@ -95,6 +95,10 @@ typedef struct {
     int32_t narrow_cols;       /* 16-bit column offsets per chunk when every chunk spans fewer than 32 767 columns (banded
                                   matrices; plain layout without value dictionary): 10 instead of 12 bytes per fp64 slot.
                                   0 = off, <0 = auto (default)                                                             */
+    int32_t hub_reorder;       /* with a hub table: re-order the whole of x by column popularity before every SpMV (every column
+                                  index of the image is the column's rank), so that the popular columns share cache lines.
+                                  0 = off, 1 = on, <0 = auto (default): when x is at least 24 MB; never inside column panels   */
+    int32_t reserved4;
 } cvr_options;
 /* Automatic layout: with steps_per_chunk = 0, waves_per_block = 0, x_window < 0 and col_phases < 0 (the defaults) cvr_create
  * looks at the uploaded CSR on the device (are the rows sorted by column? which share of the non-zeros lies near the
@@ -130,6 +134,8 @@ typedef struct {
     double  near_diagonal_share;   /* automatic layout: share of the non-zeros within a quarter window of the diagonal (0 if not probed) */
     int32_t hub_entries;           /* hub table: columns staged in LDS (0 = none)                                          */
     int32_t narrow_cols;           /* 1: the image stores 16-bit column offsets (narrow chunks)                             */
+    int32_t hub_reorder;           /* 1: the image's column indices are popularity ranks, x is re-ordered before every SpMV  */
+    int32_t reserved5;
     double  hub_share;             /* share of the non-zeros in the hub columns that were (or could have been) chosen      */
     double  hub_select_s;          /* the device pass that counted and ranked the columns (0 if not run)                  */
     double  probe_s;               /* automatic layout: the device pass over the CSR (sortedness, near-diagonal share), 0 if not run */

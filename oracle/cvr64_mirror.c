@@ -138,6 +138,14 @@ int orc_cvr64_build_hub(int64_t nrows, int64_t ncols, const int64_t *rp, const i
 int orc_cvr64_build_all(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
                         int S, int64_t thr, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int narrow, orc_cvr64 *c)
 {
+    return orc_cvr64_build_full(nrows, ncols, rp, cols, vals, is_f32, S, thr, use_dict, phases, max_rows, hub_max, 0, narrow, c);
+}
+
+/* reorder != 0 (with hub_max > 0): EVERY column index of the image is the column's popularity rank (the device re-orders the
+ * whole of x before every SpMV); ranks below the table size also carry bit 30 */
+int orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
+                         int S, int64_t thr, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int reorder, int narrow, orc_cvr64 *c)
+{
     memset(c, 0, sizeof(*c));
     if (narrow && (use_dict || phases > 1 || hub_max > 0)) return -8;
     c->narrow = narrow != 0;
@@ -151,10 +159,12 @@ int orc_cvr64_build_all(int64_t nrows, int64_t ncols, const int64_t *rp, const i
         int64_t H = 0;
         while (H < hub_max && H < ncols && k[H].cnt >= 2) H++;
         c->hub_n = (int)H;
-        c->hub_cols = (int32_t *)calloc((size_t)H + 1, sizeof(int32_t));
+        const int64_t keep = reorder && H > 0 ? ncols : H;
+        c->order_n = reorder && H > 0 ? (int)ncols : 0;
+        c->hub_cols = (int32_t *)calloc((size_t)keep + 1, sizeof(int32_t));
         hub_index = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncols);
         for (int64_t j = 0; j < ncols; j++) hub_index[j] = -1;
-        for (int64_t i = 0; i < H; i++) { c->hub_cols[i] = k[i].col; hub_index[k[i].col] = (int32_t)i; }
+        for (int64_t i = 0; i < keep; i++) { c->hub_cols[i] = k[i].col; hub_index[k[i].col] = (int32_t)i; }
         free(k);
     }
     if (phases < 1) phases = 1;
@@ -282,7 +292,7 @@ int orc_cvr64_build_all(int64_t nrows, int64_t ncols, const int64_t *rp, const i
                 uint32_t col = (uint32_t)ncols; double v = 0;
                 if (pos[l] >= 0) {
                     col = (uint32_t)cols[pos[l]];
-                    if (hub_index && hub_index[col] >= 0) col = 0x40000000u | (uint32_t)hub_index[col];
+                    if (hub_index && hub_index[col] >= 0) col = (hub_index[col] < c->hub_n ? 0x40000000u : 0u) | (uint32_t)hub_index[col];
                     v = is_f32 ? (double)((const float *)vals)[pos[l]] : ((const double *)vals)[pos[l]];
                     pos[l]++;
                 }
@@ -361,6 +371,7 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
                 } else cw = ((const uint32_t *)grp)[l * 4 + j];
                 uint32_t col = cw & cmask;
                 if (c->hub_n && (col & 0x40000000u)) col = (uint32_t)c->hub_cols[col & 0x3fffffffu];     /* hub slot: rank -> column */
+                else if (c->order_n && col < (uint32_t)c->order_n) col = (uint32_t)c->hub_cols[col];      /* re-ordered x: rank -> column (the pad column stays) */
                 flagged[l] = cw >> 31;
                 rowtag[l] = ph ? (cw & 0x7fffffffu) >> c->col_bits : 0;
                 if (c->is_f32) {

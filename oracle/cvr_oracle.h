@@ -97,6 +97,7 @@ typedef struct {
     int       col_bits;      /* phases > 1: the last column word of a segment holds its seg_row in bits [col_bits, 31)   */
     int       hub_n;         /* hub table entries (0 = none): a column word with bit 30 holds the rank of a hub column      */
     int32_t  *hub_cols;      /* [hub_n] the hub columns by non-zeros descending, ties by column                             */
+    int       order_n;       /* 0, or ncols: every column index of the image is a popularity rank (hub_cols then lists all columns) */
     int       narrow;        /* 1: narrow chunks -- groups hold [64][4] u16 column offsets from cbase[k] (512 B) before the values */
     uint32_t *cbase;         /* narrow: [nchunks] smallest column of the chunk                                              */
 } orc_cvr64;
@@ -115,6 +116,9 @@ int  orc_cvr64_build_hub(int64_t nrows, int64_t ncols, const int64_t *rowptr, co
 /* the same with narrow chunks (16-bit column offsets; -8 when a chunk spans too many columns or with dictionary / phases / hubs) */
 int  orc_cvr64_build_all(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
                          int S, int64_t split_threshold, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int narrow, orc_cvr64 *out);
+/* the same with the whole of x re-ordered by popularity (reorder != 0, needs hub_max > 0) */
+int  orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
+                          int S, int64_t split_threshold, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int reorder, int narrow, orc_cvr64 *out);
 void orc_cvr64_free(orc_cvr64 *c);
 /* interpret the image exactly as the HIP kernel does (same per-lane order of operations) */
 void orc_cvr64_spmv(const orc_cvr64 *c, const void *x, void *y);

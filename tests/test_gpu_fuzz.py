@@ -57,6 +57,7 @@ def test_fuzz_parity():
         wpb = int(rng.choice([1, 1, 2, 8, 16]))
         ph = int(rng.choice([1, 1, 2, 5])) if P == 1 and ncols >= 320 else 1
         hub = int(rng.choice([0, 0, 7, 300])) if ph == 1 else 0
+        reo = int(rng.integers(0, 2)) if hub else 0
         ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32, wpb=wpb, phases=ph, sorted=srt, hub=hub)
         from_dev = torch is not None and len(ci) > 0 and rng.integers(0, 4) == 0     # CSR arrays already on the device
         if from_dev:
@@ -74,11 +75,11 @@ def test_fuzz_parity():
             if ph > 1:
                 hub = 0
             A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, col_panels=P, x_window=win,
-                                  waves_per_block=wpb, col_phases=ph, hub_table=hub)
+                                  waves_per_block=wpb, col_phases=ph, hub_table=hub, hub_reorder=reo if P == 1 else 0)
             ph = A.info.col_phases
         ctx["from_dev"] = bool(from_dev)
         if P == 1:
-            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0, phases=ph, max_rows=A.info.chunk_row_cap, hub_max=A.info.hub_entries, narrow=A.info.narrow_cols)
+            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0, phases=ph, max_rows=A.info.chunk_row_cap, hub_max=A.info.hub_entries, narrow=A.info.narrow_cols, reorder=A.info.hub_reorder)
             img = A.export_image()
             assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc), ctx
             assert np.array_equal(img["target"], mir.target) and np.array_equal(img["shared"], mir.shared), ctx

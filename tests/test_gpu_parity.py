@@ -872,8 +872,8 @@ def test_hub_table(scale, S, wpb, win, hub, f32):
         A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, waves_per_block=wpb, x_window=win, hub_table=hub, value_dict=vd, col_phases=0)
         i = A.info
         assert 0 < i.hub_entries <= hub and i.hub_share > 0.3
-        mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=i.value_dict > 0, hub_max=i.hub_entries)
-        assert mir.hub_n == i.hub_entries
+        mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=i.value_dict > 0, hub_max=i.hub_entries, reorder=i.hub_reorder)
+        assert mir.hub_n == i.hub_entries and i.hub_reorder == 0
         img = A.export_image()
         for key in ("desc", "target", "shared", "image"):
             assert np.array_equal(img[key], getattr(mir, key)), key
@@ -943,3 +943,28 @@ def test_narrow_chunks_store_16_bit_columns(f32):
     D2 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, vd, steps_per_chunk=16)
     assert D2.info.value_dict > 0 and D2.info.narrow_cols == 0
     D2.close()
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_hub_table_with_reordered_x(f32):
+    """hub_reorder: every column index of the image is the column's popularity rank and the whole of x is re-ordered before
+    every SpMV -- image against the mirror (same ranking), y against the CSR oracle, bitwise reruns, y equal to the table-only run"""
+    nrows, ncols, rp, ci, va = synth.rmat(14, dtype=np.float32 if f32 else np.float64)
+    x = synth.x_rand(ncols, va.dtype)
+    yref, absy = O.csr_spmv64(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    ys = []
+    for reo in (1, 0):
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=16, waves_per_block=8, hub_table=3000, hub_reorder=reo, col_phases=0)
+        i = A.info
+        assert i.hub_reorder == reo and i.hub_entries == 3000
+        mir = O.Cvr64(nrows, ncols, rp, ci, va, 16, use_dict=i.value_dict > 0, hub_max=3000, reorder=reo)
+        img = A.export_image()
+        for key in ("desc", "target", "shared", "image"):
+            assert np.array_equal(img[key], getattr(mir, key)), (key, reo)
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL32 if f32 else TOL64, ("reorder", reo))
+        y2, _ = A.spmv(x)
+        assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))
+        ys.append(y)
+        A.close()
+    assert np.array_equal(ys[0].view(np.uint8), ys[1].view(np.uint8))      # same slots, same order of operations

@@ -85,7 +85,7 @@ def main():
                     s = A.bench(a.warmup, a.iters)
                     i = A.info
                     print(f"  {S:4d}  {swz}  {nt:2d}  {thr:6d}  {i.nchunks:6d} {i.nshared:5d}  {i.nslots / max(nnz, 1):8.4f}  {i.convert_s * 1e6:9.1f}  "
-                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  depth {dp} wpb {wpb} win {i.x_window} panels {i.col_panels} dict {i.value_dict} phases {i.col_phases} hub {i.hub_entries} ({i.hub_share:.2f}, {i.hub_select_s * 1e3:.1f} ms) lds {i.lds_bytes} narrow {i.narrow_cols} image_MB {i.image_bytes / 1e6:.0f} pre_wall_us {i.preprocess_wall_s * 1e6:.0f} plan_us {i.plan_s * 1e6:.0f} probe_us {i.probe_s * 1e6:.0f}{wrong}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
+                          f"{s * 1e6:9.2f}  {2 * nnz / s / 1e9:8.1f}  {balg / s / 1e9:9.1f}  {balg / s / 8e12 * 100:6.1f}" + f"  depth {dp} wpb {wpb} win {i.x_window} panels {i.col_panels} dict {i.value_dict} phases {i.col_phases} hub {i.hub_entries} ({i.hub_share:.2f}, {i.hub_select_s * 1e3:.1f} ms) lds {i.lds_bytes} narrow {i.narrow_cols} reorder {i.hub_reorder} image_MB {i.image_bytes / 1e6:.0f} pre_wall_us {i.preprocess_wall_s * 1e6:.0f} plan_us {i.plan_s * 1e6:.0f} probe_us {i.probe_s * 1e6:.0f}{wrong}" + (f"  colmask {cm:#x}" if cm else ""), flush=True)
                     A.close()
 
 
