@@ -279,25 +279,21 @@ int64_t cvr_plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_
     return n;
 }
 
-static int pick_steps(int64_t nslots_est)
+static int pick_steps(int64_t nslots_est, int64_t max_row = 0)
 {
-    // One wavefront per chunk, all of them resident at once when there are few.  A CU's chunks share its L1 miss path,
-    // so the kernel lasts about as long as the CU with the most chunks: overhead + S * max(t_wave, t_cu * k) with
-    // k = ceil(chunks / 256 CUs), plus a little per resident chunk.  Fitted on S = 8..80 over row shards of web-Google
-    // for 1..16 GPUs (profiles/r01_steps_rule_fit.log: within 1 % of the best S for 1, 2, 3, 4, 6 shards; cvr_tune_steps
-    // measures instead).  The 0.98 keeps the chunk count a little under k * 256: the dispatcher does not place the
-    // workgroups perfectly evenly.  Matrices of more than 12 chunks per CU at S = 32 run in rounds and take S = 32.
+    // The plain layout (one chunk per workgroup).  Images of more than 12 chunks per CU at S = 32 run in rounds and take
+    // S = 32 (LiveJournal panels, R-MAT, banded: within 1 % of the best S, profiles/r02_steps_rule_check.log,
+    // r01_steps_large_matrices.log).  Smaller ones are resident at once: what decides there is (1) that no row is cut over
+    // chunks -- a cut row brings the fix-up kernel, a second launch worth 1.9 us on a 8-us SpMV -- so 16 S >= the longest
+    // row, and (2) beyond that as many chunks as possible, i.e. the smallest such S (web-Google-shaped matrices of 0.6 M and
+    // 1.3 M non-zeros: S = 28 is the best of 8 .. 64, 7.9 and 9.5 us; the round-1 fit on shards of one matrix took 24 and 44:
+    // 9.8 and 11.8 us).  cvr_tune measures instead.
     const double kCus = 256.0;
-    if ((double)nslots_est / (64.0 * 32.0) > kCus * 12.0) return 32;     // LiveJournal panels (15 per CU): S = 32 beats 24, 48, 64 (r01_steps_large_matrices.log)
-    int    best = 32;
-    double best_t = 1e300;
-    for (int S = 64; S >= 8; S -= 4) {
-        const double chunks = (double)nslots_est * 1.004 / (64.0 * S) + 1.0;      // 1.004: the planner's pad segments
-        const double k = std::ceil(chunks / (kCus * 0.98));
-        const double t = 3.9 + S * std::max(0.10, 0.075 * k) + 0.3 * k;           // microseconds
-        if (t < best_t) { best_t = t; best = S; }
-    }
-    return best;
+    auto chunks = [&](int S) { return (double)nslots_est * 1.004 / (64.0 * S) + 1.0; };
+    if (chunks(32) > kCus * 12.0) return 32;
+    int S = (int)std::min<int64_t>(64, std::max<int64_t>(12, ((max_row + 15) / 16 + 3) / 4 * 4));
+    while (S < 64 && chunks(S) > kCus * 12.0) S += 4;
+    return S;
 }
 
 // plans one part on the host, allocates its device image and uploads its CSR (asynchronously on h->stream)
@@ -324,7 +320,12 @@ static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, cons
 {
     const int64_t nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
     pp.S = opt.steps_per_chunk;
-    if (pp.S == 0) pp.S = pick_steps(nz1 - nz0 + nrows / 4);
+    if (pp.S == 0) {
+        int64_t max_row = 0;
+        if ((double)(nz1 - nz0 + nrows / 4) / (64.0 * 32.0) <= 256.0 * 12.0)      // (only where the rule weighs single launches)
+            for (int64_t r = 0; r < nrows; r++) max_row = std::max(max_row, rp[r + 1] - rp[r]);
+        pp.S = pick_steps(nz1 - nz0 + nrows / 4, max_row);
+    }
     // Wavefronts (consecutive chunks) per SpMV workgroup: 1 by default; more only pay together with an LDS window of x,
     // which the workgroup's chunks then share (profiles/r02_wg_window_sweep.log).
     pp.wpb = std::min(std::max(opt.waves_per_block, 1), cvr::kMaxWavesPerBlock);
