@@ -37,21 +37,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def pmc_traffic(info, kernel):
+def pmc_traffic(info, kernel, workload):
     """HBM bytes per SpMV launch from the rocprofv3 PMC passes of this same command (tools/profile_bench.sh: FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot run the
-    profiler on itself, so it reports the committed summary -- but only if that summary was taken on the very configuration
-    timed here (kernel, chunk length, chunk count, image bytes, workgroup layout); otherwise null."""
-    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    try:
-        d = json.load(open(p))
-        c = d["config"]
-        same = (c["kernel"] == kernel and c["steps_per_chunk"] == info.steps_per_chunk and c["nchunks"] == info.nchunks and
-                c["image_bytes"] == info.image_bytes and c["waves_per_block"] == info.waves_per_block and
-                c["col_phases"] == info.col_phases and c["x_window"] == info.x_window)
-        return float(d["hbm_bytes_per_launch_corrected"]) if same else None
-    except Exception:
-        return None
+    profiler on itself, so it reports a committed summary (profiles/pmc_latest.json or any profiles/*_pmc_summary.json) -- but
+    only one that was taken on the very configuration timed here (workload, kernel, chunk length, chunk count, image bytes,
+    workgroup layout); otherwise null.  Per SpMV: the SpMV kernel's launches only (all panels), without the small combine /
+    fix-up / hub-gather kernels."""
+    import glob
+    for p in [os.path.join(ROOT, "profiles", "pmc_latest.json")] + sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(p))
+            c = d["config"]
+            same = (c["kernel"] == kernel and c["steps_per_chunk"] == info.steps_per_chunk and c["nchunks"] == info.nchunks and
+                    c["image_bytes"] == info.image_bytes and c["waves_per_block"] == info.waves_per_block and
+                    c["col_phases"] == info.col_phases and c["x_window"] == info.x_window and c["workload"] == workload)
+            if same and c.get("col_panels", info.col_panels) == info.col_panels:
+                # the summary averages over launches of the SpMV kernel; a panelled matrix launches it once per panel
+                return float(d["hbm_bytes_per_launch_corrected"]) * info.col_panels
+        except Exception:
+            continue
+    return None
 
 
 def host_cpu():
@@ -534,6 +540,7 @@ def main():
     if rank == 0:
         per = wall / args.steps
         kname = "cvr::spmv_kernel<float>" if f32 else "cvr::spmv_kernel<double>"
+        workload_text = f"{source}: {nrows}x{ncols}, nnz {nnz}, {'fp32' if f32 else 'fp64'}, y = A x with A (CVR64 image), x, y resident in HBM"
         out = {
             "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64" if args.workload == "webgoogle" else f"SpMV GFLOP/s (2*nnz/t), {args.workload} {'fp32' if f32 else 'fp64'}",
             "value": 2.0 * nnz / per / 1e9,
@@ -545,7 +552,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if f32 else "f64",
             "data": "synthetic" if source.startswith("synthetic") else "real",
-            "config": {"workload": f"{source}: {nrows}x{ncols}, nnz {nnz}, {'fp32' if f32 else 'fp64'}, y = A x with A (CVR64 image), x, y resident in HBM",
+            "config": {"workload": workload_text,
                        "rows_per_gpu": [int(v) for v in np.diff(bounds)],
                        "nnz_per_gpu": nnz_per,
                        "nnz_imbalance_max_over_mean": float(max(nnz_per) * world / max(nnz, 1)),
@@ -556,7 +563,7 @@ def main():
                        "value_dictionary_entries": int(info.value_dict),
                        "parallelism": ("rows sharded, x replicated, y all-gathered (%s)" % ("RCCL" if backend == "nccl" else backend)) if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(info, kname) if world == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(info, kname, workload_text) if world == 1 else None,
                          "achieved_is": "algorithmic bytes of SURVEY 8(d) (12 B per non-zero for fp64, whatever the image stores) / kernel time",
                          "kernel": kname, "kernel_us": kern_s * 1e6,
                          "kernel_us_median_single_launches": singles[len(singles) // 2] if singles else None, "kernel_us_min_single_launches": singles[0] if singles else None,

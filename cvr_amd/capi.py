@@ -54,7 +54,7 @@ class MmMatrix(C.Structure):
 # every symbol include/cvr_amd.h declares (tests check the library exports all of them)
 SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_count", "cvr_create", "cvr_preprocess",
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
-           "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
+           "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_plan_selfcheck", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
            "cvr_tune_steps", "cvr_tune", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
 
@@ -86,6 +86,8 @@ def lib():
         L.cvr_spmv_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.cvr_export_image.argtypes = [C.c_void_p] * 5
         L.cvr_device_copy_bench.argtypes = [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)]
+        L.cvr_plan_selfcheck.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvr_plan_selfcheck.restype = C.c_int
         L.cvr_plan_bound.argtypes = [C.c_int64, C.c_int64, C.c_int32]
         L.cvr_plan_bound.restype = C.c_int64
         L.cvr_plan_chunks.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 4
@@ -190,6 +192,17 @@ def plan_chunks(row_ptr, S, thr=0):
     if n < 0:
         raise CvrError(n, "cvr_plan_chunks")
     return dict(nz_begin=nzb[: n + 1].copy(), row_first=rf[:n].copy(), nseg=ns[:n].copy(), pad_cnt=pc[:n].copy())
+
+
+def plan_selfcheck(row_ptr, S, thr=0, max_rows=0, device=0):
+    """plans row_ptr on the device and on the host and compares the plans field by field (raises CvrError if they differ);
+    returns dict(host_s, device_s, nchunks)"""
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    hs, ds, n = C.c_double(), C.c_double(), C.c_int64()
+    rc = lib().cvr_plan_selfcheck(device, len(rp) - 1, rp.ctypes.data, S, thr, max_rows, C.addressof(hs), C.addressof(ds), C.addressof(n))
+    if rc:
+        raise CvrError(rc, "cvr_plan_selfcheck")
+    return dict(host_s=hs.value, device_s=ds.value, nchunks=n.value)
 
 
 def auto_panels(nrows, ncols, row_ptr, col_idx, is_f32=False):

@@ -279,6 +279,52 @@ int64_t cvr_plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_
     return n;
 }
 
+// diagnostics: the plan of the device planner (cvr_plan_dev.hip) against the host planner's for the same row_ptr, field by
+// field; seconds of both (the device figure includes the two synchronisations, not the upload of row_ptr)
+int cvr_plan_selfcheck(int device, int64_t nrows, const int64_t *row_ptr, int32_t S, int64_t thr, int64_t max_rows, double *host_s, double *device_s,
+                       int64_t *nchunks)
+{
+    if (nrows < 0 || (nrows > 0 && !row_ptr) || S < 4 || S % 4) return fail(CVR_ERR_INVALID, "bad planner arguments");
+    if (device < 0 || device >= cvr_device_count()) return fail(CVR_ERR_NO_DEVICE, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    const double    t0 = now_s();
+    const cvr::Plan ph = cvr::plan_chunks(nrows, row_ptr, S, thr, max_rows);
+    const double    t1 = now_s();
+    if (host_s) *host_s = t1 - t0;
+    if (nchunks) *nchunks = (int64_t)ph.chunks.size();
+    int64_t *d_rp = nullptr;
+    HIP_TRY(hipMalloc(&d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
+    hipError_t e = nrows > 0 ? hipMemcpy(d_rp, row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice) : hipSuccess;
+    cvr::Plan pd;
+    bool      fallback = false;
+    double    best = 1e30;
+    for (int rep = 0; rep < 3 && e == hipSuccess; rep++) {
+        const double t2 = now_s();
+        e = cvr::plan_chunks_device(d_rp, nrows, nrows ? row_ptr[nrows] : 0, S, thr, max_rows, &pd, &fallback, nullptr);
+        best = std::min(best, now_s() - t2);
+    }
+    (void)hipFree(d_rp);
+    if (e != hipSuccess) return fail(CVR_ERR_HIP, "device planner: %s", hipGetErrorString(e));
+    if (device_s) *device_s = best;
+    if (fallback) return fail(CVR_ERR_STATE, "device planner declined (row block beyond 32-bit slot positions, or S too large)");
+    if (pd.S != ph.S || pd.thr != ph.thr || pd.max_rows != ph.max_rows || pd.nz_end != ph.nz_end) return fail(CVR_ERR_INTERNAL, "plan parameters differ");
+    if (pd.chunks.size() != ph.chunks.size()) return fail(CVR_ERR_INTERNAL, "device plan has %zu chunks, host plan %zu", pd.chunks.size(), ph.chunks.size());
+    for (size_t k = 0; k < ph.chunks.size(); k++) {
+        const cvr::Chunk &a = ph.chunks[k], &b = pd.chunks[k];
+        if (a.nz_begin != b.nz_begin || a.row_first != b.row_first || a.nrows_in != b.nrows_in || a.nseg != b.nseg || a.pad_cnt != b.pad_cnt ||
+            a.head_shared != b.head_shared || a.tail_shared != b.tail_shared)
+            return fail(CVR_ERR_INTERNAL, "chunk %zu differs: host {nz %lld row %lld rows %lld seg %lld pad %lld %d%d} device {nz %lld row %lld rows %lld seg %lld pad %lld %d%d}", k,
+                        (long long)a.nz_begin, (long long)a.row_first, (long long)a.nrows_in, (long long)a.nseg, (long long)a.pad_cnt, a.head_shared, a.tail_shared,
+                        (long long)b.nz_begin, (long long)b.row_first, (long long)b.nrows_in, (long long)b.nseg, (long long)b.pad_cnt, b.head_shared, b.tail_shared);
+    }
+    if (pd.shared.size() != ph.shared.size()) return fail(CVR_ERR_INTERNAL, "device plan has %zu cut rows, host plan %zu", pd.shared.size(), ph.shared.size());
+    for (size_t k = 0; k < ph.shared.size(); k++)
+        if (pd.shared[k].row != ph.shared[k].row || pd.shared[k].c0 != ph.shared[k].c0 || pd.shared[k].c1 != ph.shared[k].c1)
+            return fail(CVR_ERR_INTERNAL, "cut row %zu differs: host {%lld %lld %lld} device {%lld %lld %lld}", k, (long long)ph.shared[k].row, (long long)ph.shared[k].c0,
+                        (long long)ph.shared[k].c1, (long long)pd.shared[k].row, (long long)pd.shared[k].c0, (long long)pd.shared[k].c1);
+    return CVR_OK;
+}
+
 static int pick_steps(int64_t nslots_est, int64_t max_row = 0)
 {
     // The plain layout (one chunk per workgroup).  Images of more than 12 chunks per CU at S = 32 run in rounds and take
@@ -316,14 +362,19 @@ struct PartPlan {
     int64_t  hub_n = 0;            // hub table entries staged in LDS in front of the window (decided before planning)
 };
 
-static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const cvr_options &opt)
+// rows in device memory (rp == nullptr): row_ptr at dr->rp, first and last entry dr->nz0, dr->nz1; planned on the device
+struct DevRows { const int64_t *rp = nullptr; int64_t nz0 = 0, nz1 = 0; hipStream_t st = nullptr; };
+
+static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const cvr_options &opt, const DevRows *dr = nullptr)
 {
-    const int64_t nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
+    const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
     pp.S = opt.steps_per_chunk;
     if (pp.S == 0) {
         int64_t max_row = 0;
-        if ((double)(nz1 - nz0 + nrows / 4) / (64.0 * 32.0) <= 256.0 * 12.0)      // (only where the rule weighs single launches)
-            for (int64_t r = 0; r < nrows; r++) max_row = std::max(max_row, rp[r + 1] - rp[r]);
+        if ((double)(nz1 - nz0 + nrows / 4) / (64.0 * 32.0) <= 256.0 * 12.0) {    // (only where the rule weighs single launches)
+            if (rp) for (int64_t r = 0; r < nrows; r++) max_row = std::max(max_row, rp[r + 1] - rp[r]);
+            else { const hipError_t e = cvr::max_row_device(dr->rp, nrows, &max_row, dr->st); if (e != hipSuccess) return e; }
+        }
         pp.S = pick_steps(nz1 - nz0 + nrows / 4, max_row);
     }
     // Wavefronts (consecutive chunks) per SpMV workgroup: 1 by default; more only pay together with an LDS window of x,
@@ -355,11 +406,23 @@ static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, cons
         if (pp.stage < 64) { pp.lds_short = true; pp.phases = 1; pp.stage = 64; }
         else max_rows = pp.stage - 1;                 // + the dump entry of the pad segment
     }
-    pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold, max_rows, pp.plan_threads);
+    if (rp) {
+        pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold, max_rows, pp.plan_threads);
+    } else {
+        bool             declined = false;
+        const hipError_t e = cvr::plan_chunks_device(dr->rp, nrows, nz1, pp.S, opt.split_threshold, max_rows, &pp.plan, &declined, dr->st);
+        if (e != hipSuccess) return e;
+        if (declined) {       // (chunks beyond the 15-bit jump, or a row block beyond 32-bit slot positions): the row pointers come to the host after all
+            std::vector<int64_t> hrp((size_t)nrows + 1);
+            const hipError_t     e2 = hipMemcpy(hrp.data(), dr->rp, sizeof(int64_t) * hrp.size(), hipMemcpyDeviceToHost);
+            if (e2 != hipSuccess) return e2;
+            pp.plan = cvr::plan_chunks(nrows, hrp.data(), pp.S, opt.split_threshold, max_rows, pp.plan_threads);
+        }
+    }
     const cvr::Plan &plan = pp.plan;
     const int64_t    nchunks = (int64_t)plan.chunks.size();
     pp.yext = nrows + 1 + 2 * nchunks;
-    if (pp.yext >= (int64_t)0xffffffffu || nchunks >= (int64_t)0x7fffffff) { pp.too_large = true; return; }
+    if (pp.yext >= (int64_t)0xffffffffu || nchunks >= (int64_t)0x7fffffff) { pp.too_large = true; return hipSuccess; }
     pp.desc.resize((size_t)nchunks * 4);
     if (pp.phases > 1) pp.desc2.resize((size_t)nchunks * 2, 0u);
     pp.pad.resize((size_t)nchunks);
@@ -400,6 +463,7 @@ static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, cons
         if (fixed + pp.wpb * stage + pp.win > total) pp.win = std::max<int64_t>(0, total - fixed - pp.wpb * stage) & ~(int64_t)3;
         pp.stage = stage;
     }
+    return hipSuccess;
 }
 
 // The automatic layout (every layout option left at its default; one image, no column panels).  Matrices small enough
@@ -408,7 +472,7 @@ static void plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, cons
 // diagonal, and feed their rows column phase by column phase when x is larger than what an L2 keeps beside the matrix
 // stream (profiles/r02_wg_window_sweep.log, r02_column_phases_sweep.log: 32.5 -> 23.4 us on the web-Google shape).
 // Decided from a device-side pass over the uploaded CSR (sortedness of the rows, near-diagonal share).
-static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, cvr_options &opt)
+static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nnz, cvr_options &opt)
 {
     opt.layout_auto_resident = 0;
     if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT")) {
@@ -418,7 +482,7 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
     opt.col_phases = 0;
     if (nrows < 4096 || ncols < 4096) return CVR_OK;
     const int64_t vs = f32 ? 4 : 8;
-    const double  slots = ((double)(rp[nrows] - rp[0]) + (double)nrows / 4) * 1.006;      // pad slots of empty rows, chunk tails
+    const double  slots = ((double)nnz + (double)nrows / 4) * 1.006;      // pad slots of empty rows, chunk tails
     // candidates: 8, 7 or 6 chunks per workgroup with the smallest S that keeps the workgroups at or under 252; the one
     // that fills the 256 CUs best wins (ties: more waves)
     int best_w = 0, best_S = 0;
@@ -445,7 +509,7 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(CVR_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
     const bool   sorted = out[0] == 0;
-    const double near = (double)out[1] / std::max<double>((double)(rp[nrows] - rp[0]), 1.0);
+    const double near = (double)out[1] / std::max<double>((double)nnz, 1.0);
     const double xbytes = (double)ncols * vs;
     // (a matrix with nearly everything near the diagonal is a band: consecutive rows share their lines of x in L1 already)
     const bool   want_win = near >= 0.15 && near < 0.9, want_phases = sorted && xbytes > 2.5e6 && near < 0.9;
@@ -463,11 +527,11 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
 // whose x does not fit an L2 get the columns counted on the device, and the table is used when the columns that fit the LDS
 // (beside 8 chunks' row stages) hold at least half of the (sampled) non-zeros -- R-MAT scale 22 fp32: 0.56, 402 -> 289 us;
 // fp64 (half as many entries fit): 0.41, where the table loses (profiles/r02_hub_table_rmat.log).  The workgroup then has 8 chunks.
-static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, cvr_options &opt, PartPlan &pp,
+static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, cvr_options &opt, PartPlan &pp,
                        bool allow_reorder)
 {
     if (opt.hub_table == 0 || opt.layout_auto_resident || opt.col_phases > 1 || nrows <= 0 || ncols >= (int64_t)cvr::kHubBit) return CVR_OK;
-    const int64_t vs = f32 ? 4 : 8, nnz = rp[nrows] - rp[0];
+    const int64_t vs = f32 ? 4 : 8, nnz = nz1 - nz0;
     const bool    automatic = opt.hub_table < 0;
     if (automatic && (opt.waves_per_block != 0 || opt.x_window > 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT") || (double)ncols * vs < 6e6 || nnz < (8 << 20))) return CVR_OK;
     const int     wpb = opt.waves_per_block > 0 ? std::min(opt.waves_per_block, cvr::kMaxWavesPerBlock) : 8;
@@ -483,7 +547,7 @@ static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t n
     // 487 us, table alone 538, table + re-ordered x 400 us; fp32 (x = 16.8 MB): 288 -> 291 us, so only for a large x; not
     // inside column panels (a panel ranks its own range).  hub_reorder: < 0 = this rule, 0 off, 1 on.
     const bool        full_order = allow_reorder && (opt.hub_reorder > 0 || (opt.hub_reorder < 0 && (double)ncols * vs >= 24e6));
-    const hipError_t  e = cvr::select_hubs(d_ci, rp[0], rp[nrows], ncols, (uint32_t)room, &sel, h->stream, full_order);
+    const hipError_t  e = cvr::select_hubs(d_ci, nz0, nz1, ncols, (uint32_t)room, &sel, h->stream, full_order);
     h->info.hub_select_s += now_s() - t0;
     if (e != hipSuccess) { cvr::free_hubs(sel); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
     h->info.hub_share = std::max(h->info.hub_share, sel.share);
@@ -497,16 +561,17 @@ static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t n
 }
 
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
+// (rp == nullptr: part.d_rp is already in place -- the row pointers of a column panel split on the device -- and `dr` describes it)
 static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
-                      hipMemcpyKind civa_kind, bool f32, const cvr_options &opt, double *plan_s, PartPlan *planned = nullptr)
+                      hipMemcpyKind civa_kind, bool f32, const cvr_options &opt, double *plan_s, PartPlan *planned = nullptr, const DevRows *dr = nullptr)
 {
-    const int64_t nz0 = nrows ? rp[0] : 0, nz1 = nrows ? rp[nrows] : 0;
+    const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
     const size_t  vsz = f32 ? 4 : 8, nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
     // the CSR goes to the device first (asynchronously): the automatic layout choice below looks at it there
-    HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
+    if (rp) HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
     HIP_TRY(hipMalloc(&part.d_ci, sizeof(int32_t) * std::max<size_t>(nnz_span, 1)));
     HIP_TRY(hipMalloc(&part.d_va, vsz * std::max<size_t>(nnz_span, 1)));
-    if (nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));     // row_ptr is always a host array here
+    if (rp && nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
     if (nnz_span) {
         HIP_TRY(hipMemcpyAsync(part.d_ci, ci, sizeof(int32_t) * nnz_span, civa_kind, h->stream));
         HIP_TRY(hipMemcpyAsync(part.d_va, va, vsz * nnz_span, civa_kind, h->stream));
@@ -514,17 +579,17 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     PartPlan    local;
     cvr_options popt = opt;
     if (!planned) {
-        int rc = auto_layout(h, part, nrows, ncols, f32, rp, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
+        int rc = auto_layout(h, part, nrows, ncols, f32, nz1 - nz0, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
         if (rc) return rc;
-        rc = choose_hubs(h, part, part.d_ci, nrows, ncols, f32, rp, popt, local, true);
+        rc = choose_hubs(h, part, part.d_ci, nrows, ncols, f32, nz0, nz1, popt, local, true);
         if (rc) return rc;
         const double t0 = now_s();
-        plan_part(local, nrows, ncols, f32, rp, popt);
+        HIP_TRY(plan_part(local, nrows, ncols, f32, rp, popt, dr));
         // the resident layout wants every workgroup on a CU of its own at once: one more step per chunk until they fit
         while (popt.layout_auto_resident && !local.too_large && (int64_t)local.plan.chunks.size() > (int64_t)local.wpb * 256 && popt.steps_per_chunk < 4096) {
             popt.steps_per_chunk += 4;
             local = PartPlan();
-            plan_part(local, nrows, ncols, f32, rp, popt);      // (the resident layout has no hub table: nothing of `local` to keep)
+            HIP_TRY(plan_part(local, nrows, ncols, f32, rp, popt, dr));      // (the resident layout has no hub table: nothing of `local` to keep)
         }
         if (plan_s) *plan_s += now_s() - t0;
         planned = &local;
@@ -884,7 +949,6 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (rc) { cvr_destroy(h); return rc; }
         in.yext_elems = h->parts[0].yext;
     } else {
-        const double t0 = now_s();
         PanelSplit   sp;
         struct SplitGuard { cvr::DeviceSplit d; ~SplitGuard() { cvr::free_device_split(d); } } dsg;
         // The split runs on the device (cvr_split.hip).  Host arrays are uploaded once for it: building the split arrays
@@ -914,6 +978,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             }
         }
         clk.lap("  staging upload");
+        const double t0 = now_s();         // (the staging copy is an upload, not planning)
         // Power-law matrices whose popular columns will sit in hub tables need fewer, wider panels: the table takes the hot
         // half of the gathers off the L2s, and what remains runs best with ~16 MB of x per panel instead of ~4 (R-MAT-26 fp32
         // on one GPU: 59 panels 6.4 ms, 16 panels 5.4 ms; R-MAT-24: 8 and 4 panels alike; profiles/r02_hub_table_rmat.log)
@@ -932,59 +997,61 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             }
         }
         clk.lap("  panel count with hub tables");
-        if (dev_split) {        // only row pointers and row numbers of the sub-rows come to the host
+        std::vector<int64_t> nsubs((size_t)P, 0);
+        if (dev_split) {        // nothing but a few counts comes to the host: the sub-rows are planned where they are (cvr_plan_dev.hip)
             const int64_t  width = (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1;
             const hipError_t e = cvr::split_panels_device(rp_d, ci_d, va_d, f32, nrows, sj0, sj1, width, P, &dsg.d, h->stream);
             if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "column-panel split on the device: %s", hipGetErrorString(e)); }
             staged.release();       // the split arrays replace the staging copy
-            sp.rp.resize((size_t)P); sp.rows.resize((size_t)P);
-            for (int p = 0; p < P; p++) {
-                const int64_t k0 = dsg.d.sub0[p], k1 = dsg.d.sub0[p + 1], ns = k1 - k0;
-                sp.rows[(size_t)p].alloc((size_t)ns);
-                sp.rp[(size_t)p].alloc((size_t)ns + 1);
-                if (ns > 0) {
-                    CREATE_TRY(hipMemcpy(sp.rows[(size_t)p].data(), dsg.d.rows + k0, sizeof(uint32_t) * (size_t)ns, hipMemcpyDeviceToHost));
-                    CREATE_TRY(hipMemcpy(sp.rp[(size_t)p].data(), dsg.d.rp + k0, sizeof(int64_t) * (size_t)ns, hipMemcpyDeviceToHost));
-                }
-                for (int64_t i = 0; i < ns; i++) sp.rp[(size_t)p][(size_t)i] -= dsg.d.off[p];      // panel-local positions
-                sp.rp[(size_t)p][(size_t)ns] = dsg.d.off[p + 1] - dsg.d.off[p];
-            }
+            for (int p = 0; p < P; p++) nsubs[(size_t)p] = dsg.d.sub0[p + 1] - dsg.d.sub0[p];
         } else {
             split_panels(*csr, P, sp);
+            for (int p = 0; p < P; p++) nsubs[(size_t)p] = (int64_t)sp.rows[(size_t)p].size();
         }
-        in.plan_s += now_s() - t0;
+        in.plan_s += now_s() - t0 - in.hub_select_s;      // (the hub count that sizes the panels is reported on its own)
         clk.lap("panel split");
-        // the panels' images are planned side by side (the planner is a sequential walk per image), then built one by one
         std::vector<PartPlan> pps((size_t)P);
         cvr_options           panel_opt = opt;
         panel_opt.col_phases = 1;          // column phases are for the single image whose chunks are all resident at once
         std::vector<cvr_options> popts((size_t)P, panel_opt);
-        if (dev_split)                     // hub tables per panel: the most popular columns of the panel's own range
+        std::vector<DevRows>     drs((size_t)P);
+        if (dev_split) {
+            // per panel: its row pointers made panel-local (a slice of the split's, minus the panel's first position), a hub
+            // table of the most popular columns of its own range, and the chunk plan -- all from device arrays
+            const double tp = now_s(), hub0 = in.hub_select_s;
             for (int p = 0; p < P; p++) {
-                rc = choose_hubs(h, h->parts[(size_t)p], dsg.d.ci + dsg.d.off[p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), popts[(size_t)p], pps[(size_t)p], false);
+                Part         &part = h->parts[(size_t)p];
+                const int64_t ns = nsubs[(size_t)p], nzp = dsg.d.off[p + 1] - dsg.d.off[p];
+                CREATE_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)ns + 1)));
+                CREATE_TRY(cvr::launch_shift_rows(dsg.d.rp + dsg.d.sub0[p], ns + 1, dsg.d.off[p], part.d_rp, h->stream));
+                drs[(size_t)p] = DevRows{part.d_rp, 0, nzp, h->stream};
+                rc = choose_hubs(h, part, dsg.d.ci + dsg.d.off[p], ns, ncols, f32, 0, nzp, popts[(size_t)p], pps[(size_t)p], false);
                 if (rc) { cvr_destroy(h); return rc; }
+                CREATE_TRY(plan_part(pps[(size_t)p], ns, ncols, f32, nullptr, popts[(size_t)p], &drs[(size_t)p]));
             }
-        clk.lap("  hub tables of the panels");
-        {
+            in.plan_s += now_s() - tp - (in.hub_select_s - hub0);      // (hub selection is reported on its own)
+            clk.lap("  hub tables, plans (device)");
+        } else {
+            // the panels' images are planned side by side (the host planner is a sequential walk per image), then built one by one
             const double tp = now_s();
             int T = (int)std::thread::hardware_concurrency();
             T = std::max(1, std::min(T, P));
-            auto work = [&](int t) { for (int p = t; p < P; p += T) { pps[(size_t)p].plan_threads = 1; plan_part(pps[(size_t)p], (int64_t)sp.rows[(size_t)p].size(), ncols, f32, sp.rp[(size_t)p].data(), popts[(size_t)p]); } };
+            auto work = [&](int t) { for (int p = t; p < P; p += T) { pps[(size_t)p].plan_threads = 1; (void)plan_part(pps[(size_t)p], nsubs[(size_t)p], ncols, f32, sp.rp[(size_t)p].data(), popts[(size_t)p]); } };
             std::vector<std::thread> th;
             for (int t = 1; t < T; t++) th.emplace_back(work, t);
             work(0);
             for (auto &x : th) x.join();
             in.plan_s += now_s() - tp;
+            clk.lap("  panels planned (parallel)");
         }
-        clk.lap("  panels planned (parallel)");
         int64_t zoff = 0, nsub = 0;
         for (int p = 0; p < P; p++) {
             Part &part = h->parts[(size_t)p];
             if (dev_split)
-                rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), dsg.d.ci + dsg.d.off[p],
-                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p]);
+                rc = build_part(h, part, nsubs[(size_t)p], ncols, nullptr, dsg.d.ci + dsg.d.off[p],
+                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p], &drs[(size_t)p]);
             else
-                rc = build_part(h, part, (int64_t)sp.rows[(size_t)p].size(), ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
+                rc = build_part(h, part, nsubs[(size_t)p], ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
                                 sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p]);
             if (rc) { cvr_destroy(h); return rc; }
             part.zoff = zoff;
@@ -997,37 +1064,48 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         // kCombineRows rows starts among them
         const double   t1 = now_s();
         const uint32_t nblocks = (uint32_t)((nrows + cvr::kCombineRows - 1) / cvr::kCombineRows);
-        std::vector<uint32_t> block_off((size_t)P * (nblocks + 1));
-        for (int p = 0; p < P; p++) {
-            const Raw<uint32_t> &rows = sp.rows[(size_t)p];
-            uint32_t            *bo = block_off.data() + (size_t)p * (nblocks + 1);
-            size_t               u = 0;
-            for (uint32_t b2 = 0; b2 <= nblocks; b2++) {
-                const uint64_t lim = (uint64_t)b2 * cvr::kCombineRows;
-                while (u < rows.size() && rows[u] < lim) u++;
-                bo[b2] = (uint32_t)u;
-            }
-        }
-        in.plan_s += now_s() - t1;
-        clk.lap("  block offsets (host)");
+        const size_t   nboff = (size_t)P * (nblocks + 1);
         CREATE_TRY(hipEventCreateWithFlags(&h->z_free, hipEventDisableTiming));
         CREATE_TRY(hipMalloc(&h->d_z, vsz * (size_t)std::max<int64_t>(zoff, 1)));
-        CREATE_TRY(hipMalloc(&h->d_rows, sizeof(uint32_t) * (size_t)std::max<int64_t>(nsub, 1)));
-        CREATE_TRY(hipMalloc(&h->d_block_off, sizeof(uint32_t) * block_off.size()));
+        CREATE_TRY(hipMalloc(&h->d_block_off, sizeof(uint32_t) * nboff));
         CREATE_TRY(hipMalloc(&h->d_cpanels, sizeof(cvr::CombinePanel) * (size_t)P));
         CREATE_TRY(hipMemsetAsync(h->d_z, 0, vsz * (size_t)std::max<int64_t>(zoff, 1), h->stream));
-        clk.lap("  z, rows: alloc, memset");
         std::vector<cvr::CombinePanel> cps((size_t)P);
-        int64_t roff = 0;
-        for (int p = 0; p < P; p++) {
-            const Raw<uint32_t> &rows = sp.rows[(size_t)p];
-            if (rows.size()) CREATE_TRY(hipMemcpyAsync(h->d_rows + roff, rows.data(), sizeof(uint32_t) * rows.size(), hipMemcpyHostToDevice, h->stream));
-            cps[(size_t)p] = cvr::CombinePanel{static_cast<uint8_t *>(h->d_z) + (size_t)h->parts[(size_t)p].zoff * vsz, h->d_rows + roff};
-            roff += (int64_t)rows.size();
+        std::vector<uint32_t>          block_off;
+        if (dev_split) {
+            h->d_rows = dsg.d.rows;        // the split's row numbers are the combine pass's, as they stand
+            dsg.d.rows = nullptr;
+            int64_t roff = 0;
+            for (int p = 0; p < P; p++) {
+                CREATE_TRY(cvr::launch_block_off(h->d_rows + roff, (uint32_t)nsubs[(size_t)p], nblocks, h->d_block_off + (size_t)p * (nblocks + 1), h->stream));
+                cps[(size_t)p] = cvr::CombinePanel{static_cast<uint8_t *>(h->d_z) + (size_t)h->parts[(size_t)p].zoff * vsz, h->d_rows + roff};
+                roff += nsubs[(size_t)p];
+            }
+        } else {
+            block_off.resize(nboff);
+            for (int p = 0; p < P; p++) {
+                const Raw<uint32_t> &rows = sp.rows[(size_t)p];
+                uint32_t            *bo = block_off.data() + (size_t)p * (nblocks + 1);
+                size_t               u = 0;
+                for (uint32_t b2 = 0; b2 <= nblocks; b2++) {
+                    const uint64_t lim = (uint64_t)b2 * cvr::kCombineRows;
+                    while (u < rows.size() && rows[u] < lim) u++;
+                    bo[b2] = (uint32_t)u;
+                }
+            }
+            CREATE_TRY(hipMalloc(&h->d_rows, sizeof(uint32_t) * (size_t)std::max<int64_t>(nsub, 1)));
+            int64_t roff = 0;
+            for (int p = 0; p < P; p++) {
+                const Raw<uint32_t> &rows = sp.rows[(size_t)p];
+                if (rows.size()) CREATE_TRY(hipMemcpyAsync(h->d_rows + roff, rows.data(), sizeof(uint32_t) * rows.size(), hipMemcpyHostToDevice, h->stream));
+                cps[(size_t)p] = cvr::CombinePanel{static_cast<uint8_t *>(h->d_z) + (size_t)h->parts[(size_t)p].zoff * vsz, h->d_rows + roff};
+                roff += (int64_t)rows.size();
+            }
+            CREATE_TRY(hipMemcpyAsync(h->d_block_off, block_off.data(), sizeof(uint32_t) * block_off.size(), hipMemcpyHostToDevice, h->stream));
         }
-        CREATE_TRY(hipMemcpyAsync(h->d_block_off, block_off.data(), sizeof(uint32_t) * block_off.size(), hipMemcpyHostToDevice, h->stream));
+        in.plan_s += now_s() - t1;
         CREATE_TRY(hipMemcpyAsync(h->d_cpanels, cps.data(), sizeof(cvr::CombinePanel) * (size_t)P, hipMemcpyHostToDevice, h->stream));
-        clk.lap("  rows upload enqueued");
+        clk.lap("  combine tables enqueued");
         std::vector<cvr::FixPart> fp((size_t)P);
         for (int p = 0; p < P; p++) {
             const Part &part = h->parts[(size_t)p];
@@ -1039,7 +1117,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         CREATE_TRY(hipStreamSynchronize(h->stream));
         clk.lap("  tables synchronised");
         in.yext_elems = nrows + 1;
-        in.image_bytes += (int64_t)(sizeof(uint32_t) * ((size_t)nsub + block_off.size()));
+        in.image_bytes += (int64_t)(sizeof(uint32_t) * ((size_t)nsub + nboff));
     }
     clk.lap("combine tables / single part");
     // value dictionary (value_dict: <0 auto, 0 off): one code byte per slot instead of the value when the matrix has at

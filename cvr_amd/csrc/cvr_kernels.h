@@ -103,6 +103,15 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
                                int64_t nz1, int64_t width, int P, DeviceSplit *out, hipStream_t st);
 void       free_device_split(DeviceSplit &s);
 
+// ---- the chunk planner on the device (cvr_plan_dev.hip): the plan of plan_chunks from a device-resident row_ptr ----
+struct Plan;
+bool       plan_on_device_ok(int32_t S);
+hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, Plan *out, bool *fallback,
+                              hipStream_t st);
+hipError_t max_row_device(const int64_t *rp_dev, int64_t nrows, int64_t *out, hipStream_t st);
+hipError_t launch_shift_rows(const int64_t *src, int64_t n, int64_t base, int64_t *dst, hipStream_t st);
+hipError_t launch_block_off(const uint32_t *rows, uint32_t n, uint32_t nblocks, uint32_t *out, hipStream_t st);
+
 // ---- vector kernels of the iterative caller (cvr_iter.hip) ----
 constexpr int kIterMaxParts = 64;
 struct IterBounds { long long b[kIterMaxParts + 1]; };   // row offsets of the shards (by value into the kernel)

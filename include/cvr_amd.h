@@ -251,6 +251,11 @@ int64_t cvr_plan_bound(int64_t nrows, int64_t nnz, int32_t S);
 int64_t cvr_plan_chunks(int64_t nrows, const int64_t *row_ptr, int32_t S, int64_t split_threshold,
                         int64_t *nz_begin /*[n+1]*/, int64_t *row_first, int64_t *nseg, int64_t *pad_cnt);
 
+/* diagnostics (needs a device): plans row_ptr with the device planner (cvr_plan_dev.hip) and with the host planner and
+ * compares the two plans field by field (CVR_OK = identical); seconds of both, chunk count. */
+int cvr_plan_selfcheck(int device, int64_t nrows, const int64_t *row_ptr, int32_t S, int64_t split_threshold, int64_t max_rows,
+                       double *host_seconds, double *device_seconds, int64_t *nchunks);
+
 /* ---- host side of the reference program ------------------------------------------------------ */
 #define CVR_MM_REFCOMPAT 0   /* the reference loader's arrays bit for bit (quirks Q1-Q9)           */
 #define CVR_MM_STRICT    1   /* Matrix-Market semantics: 0-based, fp64 values, no padding, 64-bit  */

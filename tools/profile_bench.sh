@@ -40,7 +40,7 @@ try:      # the configuration the counters belong to, from the bench line of a P
     s["config"] = {"kernel": d["roofline"]["kernel"], "steps_per_chunk": c["steps_per_chunk"], "nchunks": c["chunks_rank0"],
                    "image_bytes": d["roofline"]["streamed_bytes_per_launch"] - d["roofline"]["algorithmic_bytes_per_launch"] * 0,
                    "waves_per_block": c["waves_per_workgroup"], "col_phases": c["col_phases"], "x_window": c["x_window_values"],
-                   "workload": c["workload"], "bench_args": "$ARGS"}
+                   "workload": c["workload"], "col_panels": c["col_panels"], "bench_args": "$ARGS"}
     s["config"]["image_bytes"] = d["image_bytes"]
 except Exception as e:
     s["config_error"] = repr(e)
