@@ -828,7 +828,7 @@ def test_amortisation_report_small():
     out = R.report(nrows, ncols, rp, ci, va, iters=50, name="webgoogle/10")
     assert out["cvr"]["result_ok"]
     pre = out["cvr"]["preprocess_us"]
-    assert pre["total"] >= pre["plan_host"] + pre["dict_scan"] + pre["convert_device_events"] and pre["total_with_h2d"] > pre["total"] - pre["dict_scan"]
+    assert pre["total"] >= pre["plan"] + pre["dict_scan"] + pre["convert_device_events"] and pre["total_with_h2d"] > pre["total"] - pre["dict_scan"]
     assert len(out["baselines"]) == 3
     for label, b in out["baselines"].items():
         assert b.get("result_ok"), (label, b)
