@@ -142,6 +142,13 @@ struct cvr_handle {
     std::vector<hipEvent_t> events;
     hipEvent_t z_free = nullptr;         // column panels: recorded after the combine pass; the next SpMV (on any stream) waits for it
     bool       z_used = false;
+    cvr::PlanScratch plan_ws;            // cvr_create only: scratch of the device planner (released before cvr_create returns)
+    // cvr_create only: 32 KiB of device scratch for the small tables of its analysis passes (layout probe 16 KiB, dictionary
+    // table 8 KiB + flags) and the host copies of the dictionary scan when it ran together with the probe
+    uint8_t                        *d_small = nullptr;
+    bool                            dict_scanned = false;
+    std::vector<unsigned long long> dict_tab;
+    uint32_t                        dict_flags[2] = {0, 0};
 
     bool paneled() const { return parts.size() > 1; }
 };
@@ -295,14 +302,17 @@ int cvr_plan_selfcheck(int device, int64_t nrows, const int64_t *row_ptr, int32_
     int64_t *d_rp = nullptr;
     HIP_TRY(hipMalloc(&d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
     hipError_t e = nrows > 0 ? hipMemcpy(d_rp, row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice) : hipSuccess;
-    cvr::Plan pd;
-    bool      fallback = false;
-    double    best = 1e30;
+    cvr::Plan        pd;
+    bool             fallback = false;
+    double           best = 1e30;
+    cvr::PlanScratch ws;             // as cvr_create keeps it: device scratch re-used, records through a pinned buffer
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ws.pinned), ws.pinned_bytes = (size_t)640 << 10, hipHostMallocDefault);
     for (int rep = 0; rep < 3 && e == hipSuccess; rep++) {
         const double t2 = now_s();
-        e = cvr::plan_chunks_device(d_rp, nrows, nrows ? row_ptr[nrows] : 0, S, thr, max_rows, &pd, &fallback, nullptr);
+        e = cvr::plan_chunks_device(d_rp, nrows, nrows ? row_ptr[nrows] : 0, S, thr, max_rows, &pd, &fallback, nullptr, rep ? &ws : nullptr);
         best = std::min(best, now_s() - t2);
     }
+    cvr::free_plan_scratch(ws);
     (void)hipFree(d_rp);
     if (e != hipSuccess) return fail(CVR_ERR_HIP, "device planner: %s", hipGetErrorString(e));
     if (device_s) *device_s = best;
@@ -363,7 +373,9 @@ struct PartPlan {
 };
 
 // rows in device memory (rp == nullptr): row_ptr at dr->rp, first and last entry dr->nz0, dr->nz1; planned on the device
-struct DevRows { const int64_t *rp = nullptr; int64_t nz0 = 0, nz1 = 0; hipStream_t st = nullptr; };
+struct DevRows { const int64_t *rp = nullptr; int64_t nz0 = 0, nz1 = 0; hipStream_t st = nullptr; cvr::PlanScratch *ws = nullptr; };
+// matrices of at least this many rows whose row_ptr is on the device anyway are planned there (cvr_plan_dev.hip)
+constexpr int64_t kDevicePlanRows = 200000;
 
 static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const cvr_options &opt, const DevRows *dr = nullptr)
 {
@@ -410,7 +422,7 @@ static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32
         pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold, max_rows, pp.plan_threads);
     } else {
         bool             declined = false;
-        const hipError_t e = cvr::plan_chunks_device(dr->rp, nrows, nz1, pp.S, opt.split_threshold, max_rows, &pp.plan, &declined, dr->st);
+        const hipError_t e = cvr::plan_chunks_device(dr->rp, nrows, nz1, pp.S, opt.split_threshold, max_rows, &pp.plan, &declined, dr->st, dr->ws);
         if (e != hipSuccess) return e;
         if (declined) {       // (chunks beyond the 15-bit jump, or a row block beyond 32-bit slot positions): the row pointers come to the host after all
             std::vector<int64_t> hrp((size_t)nrows + 1);
@@ -466,14 +478,37 @@ static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32
     return hipSuccess;
 }
 
+constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24 << 10, kSmallBytes = 32 << 10;
+constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer
+
+// the dictionary scan of the values [nz0, nz1) of a part, enqueued on the handle's stream: table and flags come back into
+// tab_host / flags_host once the stream is synchronised
+static hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64_t nz1, bool f32, bool first, unsigned long long *tab_host, uint32_t *flags_host, bool last)
+{
+    unsigned long long *d_tab = reinterpret_cast<unsigned long long *>(h->d_small + kSmallDictTab);
+    uint32_t           *d_flags = reinterpret_cast<uint32_t *>(h->d_small + kSmallDictFlags);
+    hipError_t          e = hipSuccess;
+    if (first) {
+        e = hipMemsetAsync(d_tab, 0xff, sizeof(unsigned long long) * 1024, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t) * 2, h->stream);
+    }
+    if (e == hipSuccess) e = cvr::launch_dict_scan(d_va, nz0, nz1, f32, d_tab, d_flags, h->stream);
+    if (e == hipSuccess && last) {
+        e = hipMemcpyAsync(tab_host, d_tab, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(flags_host, d_flags, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, h->stream);
+    }
+    return e;
+}
+
 // The automatic layout (every layout option left at its default; one image, no column panels).  Matrices small enough
 // for all their chunks to be resident at once -- 6 to 8 chunks per workgroup, one workgroup per CU -- run in the "resident"
 // layout when it pays: the workgroup's chunks share an LDS window of x if a sizeable share of the non-zeros lies near the
 // diagonal, and feed their rows column phase by column phase when x is larger than what an L2 keeps beside the matrix
 // stream (profiles/r02_wg_window_sweep.log, r02_column_phases_sweep.log: 32.5 -> 23.4 us on the web-Google shape).
 // Decided from a device-side pass over the uploaded CSR (sortedness of the rows, near-diagonal share).
-static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nnz, cvr_options &opt)
+static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, cvr_options &opt)
 {
+    const int64_t nnz = nz1 - nz0;
     opt.layout_auto_resident = 0;
     if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT")) {
         if (opt.col_phases < 0) opt.col_phases = 0;
@@ -495,18 +530,27 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
     }
     if (!best_w) return CVR_OK;
     const int64_t win = (64 * 1024) / vs;                       // 64 KiB of x per workgroup
-    unsigned long long *d_out = nullptr;
-    std::vector<unsigned long long> outv(2 * cvr::kProbeBlocks, 0ull);
-    HIP_TRY(hipMalloc(&d_out, sizeof(unsigned long long) * outv.size()));
+    static_assert(sizeof(unsigned long long) * 2 * cvr::kProbeBlocks <= kSmallDictTab, "probe output fits its part of the small scratch");
+    unsigned long long *d_out = reinterpret_cast<unsigned long long *>(h->d_small + kSmallProbe);
+    std::vector<unsigned long long> pageable;
+    const bool          pin = h->plan_ws.pinned && h->plan_ws.pinned_bytes >= kPinnedSmall;
+    if (!pin) pageable.resize(2 * cvr::kProbeBlocks + 1024 + 1);
+    unsigned long long *outv = pin ? reinterpret_cast<unsigned long long *>(h->plan_ws.pinned + kPinnedProbe) : pageable.data();
+    unsigned long long *tabv = pin ? reinterpret_cast<unsigned long long *>(h->plan_ws.pinned + kPinnedDictTab) : pageable.data() + 2 * cvr::kProbeBlocks;
+    uint32_t           *flagv = pin ? reinterpret_cast<uint32_t *>(h->plan_ws.pinned + kPinnedDictFlags) : reinterpret_cast<uint32_t *>(pageable.data() + 2 * cvr::kProbeBlocks + 1024);
     HIP_TRY(hipStreamSynchronize(h->stream));          // the upload
     const double tp0 = now_s();
     hipError_t e = cvr::launch_probe(part.d_rp, part.d_ci, nrows, ncols, (uint32_t)(win / 4), d_out, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(outv.data(), d_out, sizeof(unsigned long long) * outv.size(), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(outv, d_out, sizeof(unsigned long long) * 2 * cvr::kProbeBlocks, hipMemcpyDeviceToHost, h->stream);
+    // the dictionary scan of the values rides along: it depends on nothing decided here, and a second submission with its own
+    // synchronisation costs more than the scan
+    const bool with_dict = opt.value_dict != 0 && nnz > 0;
+    if (e == hipSuccess && with_dict) e = enqueue_dict_scan(h, part.d_va, nz0, nz1, f32, true, tabv, flagv, true);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     unsigned long long out[2] = {0, 0};
     for (uint32_t b = 0; b < cvr::kProbeBlocks; b++) { out[0] |= outv[2 * b]; out[1] += outv[2 * b + 1]; }
+    if (e == hipSuccess && with_dict) { h->dict_tab.assign(tabv, tabv + 1024); h->dict_flags[0] = flagv[0]; h->dict_flags[1] = flagv[1]; h->dict_scanned = true; }
     h->info.probe_s = now_s() - tp0;
-    (void)hipFree(d_out);
     if (e != hipSuccess) return fail(CVR_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
     const bool   sorted = out[0] == 0;
     const double near = (double)out[1] / std::max<double>((double)nnz, 1.0);
@@ -579,17 +623,21 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     PartPlan    local;
     cvr_options popt = opt;
     if (!planned) {
-        int rc = auto_layout(h, part, nrows, ncols, f32, nz1 - nz0, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
+        int rc = auto_layout(h, part, nrows, ncols, f32, nz0, nz1, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
         if (rc) return rc;
         rc = choose_hubs(h, part, part.d_ci, nrows, ncols, f32, nz0, nz1, popt, local, true);
         if (rc) return rc;
-        const double t0 = now_s();
-        HIP_TRY(plan_part(local, nrows, ncols, f32, rp, popt, dr));
+        const double   t0 = now_s();
+        DevRows        here{part.d_rp, nz0, nz1, h->stream, &h->plan_ws};
+        const bool     on_dev = rp && nrows >= kDevicePlanRows && !getenv("CVR_HOST_PLAN");      // (the upload of row_ptr is in front of the planner's kernels on the stream)
+        const int64_t *prp = on_dev ? nullptr : rp;
+        const DevRows *pdr = on_dev ? &here : dr;
+        HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));
         // the resident layout wants every workgroup on a CU of its own at once: one more step per chunk until they fit
         while (popt.layout_auto_resident && !local.too_large && (int64_t)local.plan.chunks.size() > (int64_t)local.wpb * 256 && popt.steps_per_chunk < 4096) {
             popt.steps_per_chunk += 4;
             local = PartPlan();
-            HIP_TRY(plan_part(local, nrows, ncols, f32, rp, popt, dr));      // (the resident layout has no hub table: nothing of `local` to keep)
+            HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));      // (the resident layout has no hub table: nothing of `local` to keep)
         }
         if (plan_s) *plan_s += now_s() - t0;
         planned = &local;
@@ -941,6 +989,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->plan_ws.pinned), h->plan_ws.pinned_bytes = nrows >= kDevicePlanRows ? (size_t)704 << 10 : kPinnedSmall, hipHostMallocDefault));
+    CREATE_TRY(hipMalloc(&h->d_small, kSmallBytes));
     clk.lap("handle, stream");
     const double t_up0 = now_s();
     h->parts.resize((size_t)P);
@@ -1024,7 +1074,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 const int64_t ns = nsubs[(size_t)p], nzp = dsg.d.off[p + 1] - dsg.d.off[p];
                 CREATE_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)ns + 1)));
                 CREATE_TRY(cvr::launch_shift_rows(dsg.d.rp + dsg.d.sub0[p], ns + 1, dsg.d.off[p], part.d_rp, h->stream));
-                drs[(size_t)p] = DevRows{part.d_rp, 0, nzp, h->stream};
+                drs[(size_t)p] = DevRows{part.d_rp, 0, nzp, h->stream, &h->plan_ws};
                 rc = choose_hubs(h, part, dsg.d.ci + dsg.d.off[p], ns, ncols, f32, 0, nzp, popts[(size_t)p], pps[(size_t)p], false);
                 if (rc) { cvr_destroy(h); return rc; }
                 CREATE_TRY(plan_part(pps[(size_t)p], ns, ncols, f32, nullptr, popts[(size_t)p], &drs[(size_t)p]));
@@ -1126,20 +1176,16 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // on the host).
     const double t_dict0 = now_s();
     if (opt.value_dict != 0 && in.nnz > 0) {
-        unsigned long long *d_tab = nullptr;
-        uint32_t           *d_flags = nullptr;
-        CREATE_TRY(hipMalloc(&d_tab, sizeof(unsigned long long) * 1024));
-        CREATE_TRY(hipMalloc(&d_flags, sizeof(uint32_t) * 2));
-        CREATE_TRY(hipMemsetAsync(d_tab, 0xff, sizeof(unsigned long long) * 1024, h->stream));
-        CREATE_TRY(hipMemsetAsync(d_flags, 0, sizeof(uint32_t) * 2, h->stream));
-        for (const Part &p : h->parts) CREATE_TRY(cvr::launch_dict_scan(p.d_va, p.nnz_span - p.nnz, p.nnz_span, f32, d_tab, d_flags, h->stream));
-        std::vector<unsigned long long> tab(1024);
-        uint32_t                        flags[2] = {0, 0};
-        CREATE_TRY(hipMemcpyAsync(tab.data(), d_tab, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost, h->stream));
-        CREATE_TRY(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
-        CREATE_TRY(hipStreamSynchronize(h->stream));
-        (void)hipFree(d_tab);
-        (void)hipFree(d_flags);
+        if (!h->dict_scanned) {          // (single images with the automatic layout scanned together with the layout probe)
+            h->dict_tab.assign(1024, ~0ull);
+            for (size_t i = 0; i < h->parts.size(); i++) {
+                const Part &p = h->parts[i];
+                CREATE_TRY(enqueue_dict_scan(h, p.d_va, p.nnz_span - p.nnz, p.nnz_span, f32, i == 0, h->dict_tab.data(), h->dict_flags, i + 1 == h->parts.size()));
+            }
+            CREATE_TRY(hipStreamSynchronize(h->stream));
+        }
+        const std::vector<unsigned long long> &tab = h->dict_tab;
+        const uint32_t                        *flags = h->dict_flags;
         if (!(flags[0] & 1u)) {
             std::vector<unsigned long long> d;
             d.push_back(0);                                                  // +0.0: the value of every pad slot
@@ -1181,6 +1227,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
     CREATE_TRY(hipStreamSynchronize(h->stream));   // the caller may free its CSR when this returns
     in.upload_s = now_s() - t_up0 - in.plan_s - in.probe_s;
+    cvr::free_plan_scratch(h->plan_ws);
+    (void)hipFree(h->d_small); h->d_small = nullptr;
+    std::vector<unsigned long long>().swap(h->dict_tab);
     clk.lap("images, x, y");
 #undef CREATE_TRY
     *out = h;
@@ -1266,6 +1315,8 @@ int cvr_destroy(cvr_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Part &p : h->parts) p.release_all();
+    cvr::free_plan_scratch(h->plan_ws);
+    if (h->d_small) (void)hipFree(h->d_small);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->z_free) (void)hipEventDestroy(h->z_free);
     for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);

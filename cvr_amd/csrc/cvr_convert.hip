@@ -509,11 +509,11 @@ __global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ va
     __shared__ unsigned long long tab[512];
     __shared__ uint32_t           cnt, over;
     for (uint32_t i = threadIdx.x; i < 512; i += blockDim.x) tab[i] = kEmpty;
-    if (threadIdx.x == 0) { cnt = 0; over = 0; }
+    if (threadIdx.x == 0) { cnt = 0; over = flags[0] & 1u; }      // (set: another workgroup already found too many values)
     __syncthreads();
     unsigned long long last = kEmpty;
     for (long long j = n0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n1; j += (long long)gridDim.x * blockDim.x) {
-        if (__hip_atomic_load(&over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || (flags[0] & 1u)) break;
+        if (__hip_atomic_load(&over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         const B                  raw = vals[j];
         const unsigned long long b = sizeof(B) == 4 && raw == (B)~(B)0 ? kEmpty : (unsigned long long)raw;
         if (b == last) continue;
@@ -521,7 +521,11 @@ __global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ va
         if (b == kEmpty) { atomicOr(&flags[0], 2u); continue; }
         uint32_t hsh = (uint32_t)((b * 0x9E3779B97F4A7C15ull) >> 55);
         for (;;) {
-            const unsigned long long old = atomicCAS(&tab[hsh], kEmpty, b);
+            // a plain read first: once the table holds the matrix's few values nearly every look-up ends here, and lanes reading
+            // the same slot are served by one broadcast where the same compare-and-swaps would be executed one after the other
+            unsigned long long old = __hip_atomic_load(&tab[hsh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == b) break;
+            if (old == kEmpty) old = atomicCAS(&tab[hsh], kEmpty, b);
             if (old == b) break;
             if (old == kEmpty) { if (atomicAdd(&cnt, 1u) + 1 > (uint32_t)kDictMax) over = 1; break; }
             hsh = (hsh + 1) & 511u;

@@ -106,8 +106,11 @@ void       free_device_split(DeviceSplit &s);
 // ---- the chunk planner on the device (cvr_plan_dev.hip): the plan of plan_chunks from a device-resident row_ptr ----
 struct Plan;
 bool       plan_on_device_ok(int32_t S);
+// scratch the caller may keep across calls: device bytes (grown on demand) and a pinned host buffer for the records coming back
+struct PlanScratch { uint8_t *dev = nullptr; size_t dev_bytes = 0; uint8_t *pinned = nullptr; size_t pinned_bytes = 0; };
+void       free_plan_scratch(PlanScratch &ws);
 hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, Plan *out, bool *fallback,
-                              hipStream_t st);
+                              hipStream_t st, PlanScratch *ws = nullptr);
 hipError_t max_row_device(const int64_t *rp_dev, int64_t nrows, int64_t *out, hipStream_t st);
 hipError_t launch_shift_rows(const int64_t *src, int64_t n, int64_t base, int64_t *dst, hipStream_t st);
 hipError_t launch_block_off(const uint32_t *rows, uint32_t n, uint32_t nblocks, uint32_t *out, hipStream_t st);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstring>
 
 #include "cvr_kernels.h"
 #include "cvr_plan.h"
@@ -270,7 +271,7 @@ bool plan_on_device_ok(int32_t S) { return (int64_t)kLanes * S < (int64_t)kJumpC
 // done) when a row block holds 2^31 slots or more -- the caller then plans on the host.  One stream synchronisation for the
 // counts, one for the records.
 hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, Plan *out, bool *fallback,
-                              hipStream_t st)
+                              hipStream_t st, PlanScratch *ws)
 {
     *fallback = false;
     Plan &p = *out;
@@ -293,9 +294,18 @@ hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_e
     const size_t  o_tile = 0, o_q = o_tile + up(4 * (size_t)ntiles), o_j = o_q + up(4 * (size_t)(nrows + nblocks)),
                   o_st = o_j + up(2 * (size_t)nrows), o_cnt = o_st + up(sizeof(Start) * (size_t)bound), o_ch = o_cnt + up(8 * (size_t)nblocks),
                   o_sh = o_ch + up(sizeof(ChunkRec) * (size_t)bound), o_tot = o_sh + up(sizeof(Shared) * (size_t)bound), total = o_tot + 256;
-    uint8_t   *arena = nullptr;
-    hipError_t e = hipMalloc(&arena, total);
-    if (e != hipSuccess) return e;
+    // device scratch: the caller's (kept across the images of one cvr_create) or one of our own
+    PlanScratch own;
+    if (!ws) ws = &own;
+    hipError_t e = hipSuccess;
+    if (ws->dev_bytes < total) {
+        if (ws->dev) (void)hipFree(ws->dev);
+        ws->dev = nullptr; ws->dev_bytes = 0;
+        e = hipMalloc(&ws->dev, total + total / 4);
+        if (e != hipSuccess) return e;
+        ws->dev_bytes = total + total / 4;
+    }
+    uint8_t *arena = ws->dev;
     PlanArgs a;
     a.rp = reinterpret_cast<const long long *>(rp_dev);
     a.nrows = nrows; a.nblocks = (uint32_t)nblocks; a.cap = (uint32_t)cap; a.thr = (uint32_t)thr;
@@ -308,7 +318,7 @@ hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_e
     a.chunks = reinterpret_cast<ChunkRec *>(arena + o_ch);
     a.shared = reinterpret_cast<Shared *>(arena + o_sh);
     a.totals = reinterpret_cast<unsigned long long *>(arena + o_tot);
-    unsigned long long totals[3] = {0, 0, 0};
+    unsigned long long  totals_pageable[3] = {0, 0, 0};
     e = hipMemsetAsync(a.totals, 0, 24, st);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(tile_kernel, dim3((uint32_t)ntiles), dim3(kTileRows), 0, st, a);
@@ -318,29 +328,56 @@ hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_e
         hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, a);
         e = hipGetLastError();
     }
-    // small plans come back in one go (room for them is known; their counts arrive with them)
-    const bool one_go = (size_t)bound * (sizeof(ChunkRec) + sizeof(Shared)) <= (512u << 10);
+    // Small plans come back in one go, through the caller's pinned buffer if there is one (a copy into pageable memory makes
+    // the runtime wait for the stream and stage the bytes: ~25 us per call): counts first, records behind them.
+    const size_t rec_bytes = (size_t)bound * (sizeof(ChunkRec) + sizeof(Shared));
+    const bool   pinned = ws->pinned && ws->pinned_bytes >= 256 + rec_bytes;
+    const bool   one_go = pinned || rec_bytes <= (512u << 10);
+    unsigned long long *totals = pinned ? reinterpret_cast<unsigned long long *>(ws->pinned) : totals_pageable;
+    uint8_t            *hch = nullptr, *hsh = nullptr;
     if (e == hipSuccess && one_go) {
-        p.chunks.resize((size_t)bound);
-        p.shared.resize((size_t)bound);
-        e = hipMemcpyAsync(p.chunks.data(), a.chunks, sizeof(ChunkRec) * (size_t)bound, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(p.shared.data(), a.shared, sizeof(Shared) * (size_t)bound, hipMemcpyDeviceToHost, st);
+        if (pinned) {
+            hch = ws->pinned + 256; hsh = hch + sizeof(ChunkRec) * (size_t)bound;
+        } else {
+            p.chunks.resize((size_t)bound); p.shared.resize((size_t)bound);
+            hch = reinterpret_cast<uint8_t *>(p.chunks.data()); hsh = reinterpret_cast<uint8_t *>(p.shared.data());
+        }
+        // (chunk and cut-row records are neighbours in the arena: one copy when the destination is one buffer too)
+        if (pinned && o_sh == o_ch + up(sizeof(ChunkRec) * (size_t)bound) && up(sizeof(ChunkRec) * (size_t)bound) == sizeof(ChunkRec) * (size_t)bound) {
+            e = hipMemcpyAsync(hch, a.chunks, rec_bytes, hipMemcpyDeviceToHost, st);
+        } else {
+            e = hipMemcpyAsync(hch, a.chunks, sizeof(ChunkRec) * (size_t)bound, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(hsh, a.shared, sizeof(Shared) * (size_t)bound, hipMemcpyDeviceToHost, st);
+        }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(totals, a.totals, 24, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess && (totals[2] & 1ull)) { *fallback = true; p.chunks.clear(); p.shared.clear(); }
     else if (e == hipSuccess) {
-        if ((int64_t)totals[0] > bound || (int64_t)totals[1] > bound) { (void)hipFree(arena); return hipErrorUnknown; }      // (cannot happen: bound_of)
-        p.chunks.resize((size_t)totals[0]);
-        p.shared.resize((size_t)totals[1]);
+        if ((int64_t)totals[0] > bound || (int64_t)totals[1] > bound) { if (own.dev) (void)hipFree(own.dev); return hipErrorUnknown; }      // (cannot happen: bound_of)
+        const size_t nc = (size_t)totals[0], ns = (size_t)totals[1];
+        if (pinned && one_go) {
+            p.chunks.resize(nc); p.shared.resize(ns);
+            if (nc) memcpy(static_cast<void *>(p.chunks.data()), hch, sizeof(ChunkRec) * nc);
+            if (ns) memcpy(static_cast<void *>(p.shared.data()), hsh, sizeof(Shared) * ns);
+        } else {
+            p.chunks.resize(nc); p.shared.resize(ns);
+        }
         if (!one_go) {
-            if (totals[0]) e = hipMemcpyAsync(p.chunks.data(), a.chunks, sizeof(ChunkRec) * (size_t)totals[0], hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess && totals[1]) e = hipMemcpyAsync(p.shared.data(), a.shared, sizeof(Shared) * (size_t)totals[1], hipMemcpyDeviceToHost, st);
+            if (nc) e = hipMemcpyAsync(p.chunks.data(), a.chunks, sizeof(ChunkRec) * nc, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && ns) e = hipMemcpyAsync(p.shared.data(), a.shared, sizeof(Shared) * ns, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
         }
     }
-    (void)hipFree(arena);
+    if (own.dev) (void)hipFree(own.dev);
     return e;
+}
+
+void free_plan_scratch(PlanScratch &ws)
+{
+    if (ws.dev) (void)hipFree(ws.dev);
+    if (ws.pinned) (void)hipHostFree(ws.pinned);
+    ws = PlanScratch();
 }
 
 // the longest row of a device row_ptr
