@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -478,24 +479,39 @@ static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32
     return hipSuccess;
 }
 
+// A second stream per device, shared by all handles of the process, for the few analysis / conversion kernels that do not
+// depend on each other (layout probe | dictionary scan, conversion | window choice): each of them is too small to fill the
+// GPU and bound by latency, so side by side they take the time of one.  Created on first use (creating a stream costs
+// milliseconds), never destroyed.
+static hipStream_t side_stream(int device)
+{
+    static std::mutex  mu;
+    static hipStream_t streams[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); streams[device] = nullptr; }
+    return streams[device];
+}
+
 constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24 << 10, kSmallBytes = 32 << 10;
 constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer
 
 // the dictionary scan of the values [nz0, nz1) of a part, enqueued on the handle's stream: table and flags come back into
 // tab_host / flags_host once the stream is synchronised
-static hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64_t nz1, bool f32, bool first, unsigned long long *tab_host, uint32_t *flags_host, bool last)
+static hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64_t nz1, bool f32, bool first, unsigned long long *tab_host, uint32_t *flags_host, bool last,
+                                    hipStream_t st)
 {
     unsigned long long *d_tab = reinterpret_cast<unsigned long long *>(h->d_small + kSmallDictTab);
     uint32_t           *d_flags = reinterpret_cast<uint32_t *>(h->d_small + kSmallDictFlags);
     hipError_t          e = hipSuccess;
     if (first) {
-        e = hipMemsetAsync(d_tab, 0xff, sizeof(unsigned long long) * 1024, h->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t) * 2, h->stream);
+        e = hipMemsetAsync(d_tab, 0xff, sizeof(unsigned long long) * 1024, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t) * 2, st);
     }
-    if (e == hipSuccess) e = cvr::launch_dict_scan(d_va, nz0, nz1, f32, d_tab, d_flags, h->stream);
+    if (e == hipSuccess) e = cvr::launch_dict_scan(d_va, nz0, nz1, f32, d_tab, d_flags, st);
     if (e == hipSuccess && last) {
-        e = hipMemcpyAsync(tab_host, d_tab, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(flags_host, d_flags, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, h->stream);
+        e = hipMemcpyAsync(tab_host, d_tab, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(flags_host, d_flags, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, st);
     }
     return e;
 }
@@ -545,8 +561,11 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
     // the dictionary scan of the values rides along: it depends on nothing decided here, and a second submission with its own
     // synchronisation costs more than the scan
     const bool with_dict = opt.value_dict != 0 && nnz > 0;
-    if (e == hipSuccess && with_dict) e = enqueue_dict_scan(h, part.d_va, nz0, nz1, f32, true, tabv, flagv, true);
+    hipStream_t side = with_dict ? side_stream(h->device) : nullptr;       // (the upload is complete: nothing to order between the two streams)
+    if (!side) side = h->stream;
+    if (e == hipSuccess && with_dict) e = enqueue_dict_scan(h, part.d_va, nz0, nz1, f32, true, tabv, flagv, true, side);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && side != h->stream) e = hipStreamSynchronize(side);
     unsigned long long out[2] = {0, 0};
     for (uint32_t b = 0; b < cvr::kProbeBlocks; b++) { out[0] |= outv[2 * b]; out[1] += outv[2 * b + 1]; }
     if (e == hipSuccess && with_dict) { h->dict_tab.assign(tabv, tabv + 1024); h->dict_flags[0] = flagv[0]; h->dict_flags[1] = flagv[1]; h->dict_scanned = true; }
@@ -1180,7 +1199,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             h->dict_tab.assign(1024, ~0ull);
             for (size_t i = 0; i < h->parts.size(); i++) {
                 const Part &p = h->parts[i];
-                CREATE_TRY(enqueue_dict_scan(h, p.d_va, p.nnz_span - p.nnz, p.nnz_span, f32, i == 0, h->dict_tab.data(), h->dict_flags, i + 1 == h->parts.size()));
+                CREATE_TRY(enqueue_dict_scan(h, p.d_va, p.nnz_span - p.nnz, p.nnz_span, f32, i == 0, h->dict_tab.data(), h->dict_flags, i + 1 == h->parts.size(), h->stream));
             }
             CREATE_TRY(hipStreamSynchronize(h->stream));
         }
@@ -1247,7 +1266,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
-    struct SegGuard { cvr::SegTable t; ~SegGuard() { (void)hipFree(t.cnt); (void)hipFree(t.pcnt); (void)hipFree(t.begin); (void)hipFree(t.len); (void)hipFree(t.row); (void)hipFree(t.flags); } } sg;
+    struct SegGuard { cvr::SegTable t; void *arena = nullptr; ~SegGuard() { (void)hipFree(arena); } } sg;      // (one allocation: six cost six times the call)
     Part &p0 = h->parts[0];
     const bool phased = !h->paneled() && p0.img.phases > 1 && p0.nchunks > 0;
     if (phased) {
@@ -1256,19 +1275,26 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
         // back to back on the device without the host in between
         cvr::SegTable &t = sg.t;
         const size_t ub = (size_t)std::min<int64_t>(p0.nchunks * 64 * (int64_t)p0.img.S, (p0.nrows + 2 * p0.nchunks) * (int64_t)p0.img.phases + p0.nchunks);
-        HIP_TRY(hipMalloc(&t.cnt, sizeof(uint32_t) * ((size_t)p0.nchunks + 1)));
-        HIP_TRY(hipMalloc(&t.flags, sizeof(uint32_t) * 2));
-        HIP_TRY(hipMalloc(&t.pcnt, sizeof(uint32_t) * (size_t)p0.nchunks * p0.img.phases));
-        HIP_TRY(hipMalloc(&t.begin, sizeof(int64_t) * std::max<size_t>(ub, 1)));
-        HIP_TRY(hipMalloc(&t.len, sizeof(uint32_t) * std::max<size_t>(ub, 1)));
-        HIP_TRY(hipMalloc(&t.row, sizeof(uint16_t) * std::max<size_t>(ub, 1)));
+        auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t n1 = std::max<size_t>(ub, 1);
+        const size_t o_begin = 0, o_len = o_begin + up(sizeof(int64_t) * n1), o_row = o_len + up(sizeof(uint32_t) * n1), o_cnt = o_row + up(sizeof(uint16_t) * n1),
+                     o_pcnt = o_cnt + up(sizeof(uint32_t) * ((size_t)p0.nchunks + 1)), o_flags = o_pcnt + up(sizeof(uint32_t) * (size_t)p0.nchunks * p0.img.phases);
+        HIP_TRY(hipMalloc(&sg.arena, o_flags + 256));
+        uint8_t *a = static_cast<uint8_t *>(sg.arena);
+        t.begin = reinterpret_cast<int64_t *>(a + o_begin); t.len = reinterpret_cast<uint32_t *>(a + o_len); t.row = reinterpret_cast<uint16_t *>(a + o_row);
+        t.cnt = reinterpret_cast<uint32_t *>(a + o_cnt); t.pcnt = reinterpret_cast<uint32_t *>(a + o_pcnt); t.flags = reinterpret_cast<uint32_t *>(a + o_flags);
         HIP_TRY(hipMemsetAsync(t.flags, 0, sizeof(uint32_t) * 2, h->stream));
     }
+    // the window choice needs nothing of the conversion (and nothing is pending on the handle's stream: cvr_create ended with a
+    // synchronisation): a single image's runs beside it on the side stream
+    hipStream_t wstream = h->paneled() || !p0.img.win_elems ? h->stream : side_stream(h->device);
+    if (!wstream) wstream = h->stream;
     HIP_TRY(hipEventRecord(e0, h->stream));
     uint32_t seg_flags[2] = {0, 0}, seg_total = 0;
     for (Part &p : h->parts) {
         cvr::DeviceCsr csr;
         csr.row_ptr = p.d_rp; csr.col_idx = p.d_ci; csr.vals = p.d_va; csr.nz_begin = p.d_nzb; csr.pad_cnt = p.d_pad;
+        if (wstream != h->stream) HIP_TRY(cvr::launch_window(p.img, csr, wstream));
         if (phased) {
             cvr::SegTable &t = sg.t;
             HIP_TRY(cvr::launch_seg_count(p.img, csr, t, h->stream));
@@ -1280,12 +1306,13 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
         } else {
             HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream));
         }
-        HIP_TRY(cvr::launch_window(p.img, csr, h->stream));
+        if (wstream == h->stream) HIP_TRY(cvr::launch_window(p.img, csr, h->stream));
     }
     HIP_TRY(hipEventRecord(e1, h->stream));
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(&err, h->d_err, sizeof(err), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (wstream != h->stream) HIP_TRY(hipStreamSynchronize(wstream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);

@@ -424,11 +424,14 @@ __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__
 __global__ __launch_bounds__(256) void probe_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ ci, uint32_t nrows,
                                                     uint32_t bin_shift, uint32_t nbins, unsigned long long *__restrict__ out)
 {
+    constexpr uint32_t kTile = 8192;                      // elements per pass: their row-start marks take 1 KiB
     extern __shared__ uint32_t hist[];                    // nbins + 1
     __shared__ int64_t  srp[257];
+    __shared__ uint32_t starts[kTile / 32];
     __shared__ uint32_t wbest[4], wbad[4];
     unsigned long long near = 0;
     uint32_t           bad = 0;
+    const uint32_t     lane = threadIdx.x & 63u;
     for (uint32_t r0 = blockIdx.x * 256; r0 < nrows; r0 += gridDim.x * 256) {
         const uint32_t nr = nrows - r0 < 256 ? nrows - r0 : 256;
         __syncthreads();
@@ -436,30 +439,55 @@ __global__ __launch_bounds__(256) void probe_kernel(const int64_t *__restrict__ 
         for (uint32_t i = threadIdx.x; i <= nbins; i += 256) hist[i] = 0;
         __syncthreads();
         const int64_t a = srp[0], z = srp[nr];
-        for (int64_t j = a + threadIdx.x; j < z; j += 256) {
-            uint32_t lo = 0, hi = nr;                     // last row whose pointer is <= j
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (srp[mid] <= j) lo = mid; else hi = mid; }
-            const int32_t c = ci[j];
-            if (j > srp[lo] && ci[j - 1] > c) bad = 1;
-            atomicAdd(&hist[(uint32_t)c >> bin_shift], 1u);
+        for (int64_t t0 = a; t0 < z; t0 += kTile) {
+            // first elements of the rows inside this pass, as a bit mask (cheaper than a search per element)
+            if (threadIdx.x < kTile / 32) starts[threadIdx.x] = 0;
+            __syncthreads();
+            if (threadIdx.x < nr) {
+                const int64_t p = srp[threadIdx.x] - t0;
+                if (p >= 0 && p < (int64_t)kTile && srp[threadIdx.x + 1] > srp[threadIdx.x]) atomicOr(&starts[p >> 5], 1u << (p & 31));
+            }
+            __syncthreads();
+            const int64_t te = z - t0 < (int64_t)kTile ? z : t0 + kTile;
+            for (int64_t jb = t0; jb < te; jb += 256) {       // (the same trips for every lane: ballots inside)
+                const int64_t  j = jb + threadIdx.x;
+                const bool     valid = j < te;
+                const int32_t  c = valid ? ci[j] : 0;
+                const uint32_t q = (uint32_t)(j - t0);
+                if (valid && j > a && !((starts[q >> 5] >> (q & 31)) & 1u) && ci[j - 1] > c) bad = 1;
+                // the histogram: lanes of a wavefront that hit the bin of the first pending lane add up in one LDS atomic (the
+                // non-zeros near the diagonal fall into one or two bins); after two such rounds the rest goes one by one
+                const uint32_t     bin = (uint32_t)c >> bin_shift;
+                unsigned long long todo = __ballot(valid);
+#pragma unroll 1
+                for (int round = 0; round < 2 && todo; round++) {
+                    const int                lead = __ffsll((long long)todo) - 1;
+                    const uint32_t           lb = __shfl(bin, lead);
+                    const unsigned long long m = __ballot(valid && bin == lb) & todo;
+                    if ((int)lane == lead) atomicAdd(&hist[lb], (uint32_t)__popcll(m));
+                    todo &= ~m;
+                }
+                if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1u);
+            }
+            __syncthreads();
         }
-        __syncthreads();
         uint32_t best = 0;
         for (uint32_t i = threadIdx.x; i < nbins; i += 256) { const uint32_t v = hist[i] + hist[i + 1]; best = v > best ? v : best; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint32_t v = __shfl_xor(best, o); best = v > best ? v : best; }
-        if ((threadIdx.x & 63u) == 0) wbest[threadIdx.x >> 6] = best;
+        if (lane == 0) wbest[threadIdx.x >> 6] = best;
         __syncthreads();
         if (threadIdx.x == 0) near += std::max(std::max(wbest[0], wbest[1]), std::max(wbest[2], wbest[3]));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
     __syncthreads();
-    if ((threadIdx.x & 63u) == 0) wbad[threadIdx.x >> 6] = bad;
+    if (lane == 0) wbad[threadIdx.x >> 6] = bad;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        out[2 * blockIdx.x] = wbad[0] | wbad[1] | wbad[2] | wbad[3];
-        out[2 * blockIdx.x + 1] = near;
+    if (threadIdx.x == 0) {          // a few workgroups share an output slot (the caller zeroes them)
+        const uint32_t slot = blockIdx.x % kProbeBlocks;
+        if (wbad[0] | wbad[1] | wbad[2] | wbad[3]) atomicOr(&out[2 * slot], 1ull);
+        if (near) atomicAdd(&out[2 * slot + 1], near);
     }
 }
 
@@ -539,7 +567,11 @@ __global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ va
         if (b == kEmpty) continue;
         uint32_t hsh = (uint32_t)((b * 0x9E3779B97F4A7C15ull) >> 54);
         for (uint32_t probes = 0; probes < 1024; probes++) {
-            const unsigned long long old = atomicCAS(&table[hsh], kEmpty, b);
+            // (a load first here too: a thousand workgroups merging the same dozen values would otherwise queue up as
+            // compare-and-swaps on a dozen addresses)
+            unsigned long long old = __hip_atomic_load(&table[hsh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == b) break;
+            if (old == kEmpty) old = atomicCAS(&table[hsh], kEmpty, b);
             if (old == b) break;
             if (old == kEmpty) { if (atomicAdd(&flags[1], 1u) + 1 > (uint32_t)kDictMax) atomicOr(&flags[0], 1u); break; }
             hsh = (hsh + 1) & 1023u;
@@ -553,11 +585,13 @@ __global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ va
 hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st)
 {
     if (nrows <= 0) return hipSuccess;
-    const uint32_t blocks = kProbeBlocks;
+    const uint32_t blocks = (uint32_t)std::min<int64_t>(16384, (nrows + 255) / 256);      // one group of 256 rows each (more rows: several)
     uint32_t       bin_shift = 0;                          // bins of `half` columns (a power of two), at most 8192 of them
     while ((2u << bin_shift) <= half) bin_shift++;
     while (((uint64_t)ncols >> bin_shift) + 1 > 8192) bin_shift++;
     const uint32_t nbins = (uint32_t)(((uint64_t)ncols >> bin_shift) + 1);
+    const hipError_t e = hipMemsetAsync(out2, 0, sizeof(unsigned long long) * 2 * kProbeBlocks, st);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(probe_kernel, dim3(blocks), dim3(256), sizeof(uint32_t) * (nbins + 1), st, rp, ci, (uint32_t)nrows, bin_shift, nbins, out2);
     return hipGetLastError();
 }
