@@ -984,7 +984,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     const bool panels_auto = !(opt_in && opt_in->col_panels >= 0);     // (opt.col_panels may already hold the rule's answer for device arrays)
     int P = opt.col_panels;
     clk.lap("device arrays: row_ptr, checks");
+    const double t_rule0 = now_s();
     if (P < 0) P = auto_panels(*csr, nullptr);
+    const double panel_rule_s = now_s() - t_rule0;          // part of the analysis: added to plan_s below
     clk.lap("panel rule");
     if (P < 1) P = 1;
     if (P > 64) P = 64;
@@ -1064,6 +1066,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 const int Pw = std::max(2, (int)std::ceil((double)ncols * (double)vsz / 16e6));
                 if (Pw < P) { P = Pw; h->parts.resize((size_t)P); in.col_panels = P; }
             }
+            // popularity too flat for any panel's table to reach the half it needs (a panel's own top columns hold a few times
+            // the whole matrix's share at most: LiveJournal shape 0.06): the panels skip their own counting passes
+            if (share < 0.08) opt.hub_table = 0;
         }
         clk.lap("  panel count with hub tables");
         std::vector<int64_t> nsubs((size_t)P, 0);
@@ -1246,6 +1251,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
     CREATE_TRY(hipStreamSynchronize(h->stream));   // the caller may free its CSR when this returns
     in.upload_s = now_s() - t_up0 - in.plan_s - in.probe_s;
+    in.plan_s += panel_rule_s;
     cvr::free_plan_scratch(h->plan_ws);
     (void)hipFree(h->d_small); h->d_small = nullptr;
     std::vector<unsigned long long>().swap(h->dict_tab);
