@@ -631,11 +631,12 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
     const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
     const size_t  vsz = f32 ? 4 : 8, nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
     // the CSR goes to the device first (asynchronously): the automatic layout choice below looks at it there
-    if (rp) HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
-    HIP_TRY(hipMalloc(&part.d_ci, sizeof(int32_t) * std::max<size_t>(nnz_span, 1)));
-    HIP_TRY(hipMalloc(&part.d_va, vsz * std::max<size_t>(nnz_span, 1)));
-    if (rp && nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
-    if (nnz_span) {
+    const bool adopted = rp && part.d_rp && part.d_ci && part.d_va;      // cvr_create's staging copy of the whole CSR, handed over
+    if (rp && !adopted) HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
+    if (!adopted) HIP_TRY(hipMalloc(&part.d_ci, sizeof(int32_t) * std::max<size_t>(nnz_span, 1)));
+    if (!adopted) HIP_TRY(hipMalloc(&part.d_va, vsz * std::max<size_t>(nnz_span, 1)));
+    if (rp && !adopted && nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
+    if (nnz_span && !adopted) {
         HIP_TRY(hipMemcpyAsync(part.d_ci, ci, sizeof(int32_t) * nnz_span, civa_kind, h->stream));
         HIP_TRY(hipMemcpyAsync(part.d_va, va, vsz * nnz_span, civa_kind, h->stream));
     }
@@ -900,6 +901,26 @@ static double l2_miss_estimate(const cvr_csr_view &v)
     return refs_all > 0 ? miss_all / refs_all : 0.0;
 }
 
+// the same estimate from a CSR in device memory (cvr_split.hip: l2_hits_device): same windows, same integers
+static hipError_t l2_miss_estimate_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t ncols, bool f32, hipStream_t st, double *miss)
+{
+    *miss = 0.0;
+    const int64_t W = std::min<int64_t>(65536, nrows);
+    if (W <= 0) return hipSuccess;
+    const int nwin = nrows == W ? 1 : 8;
+    int64_t   r0[8];
+    double    refs[8], hits[8];
+    for (int w = 0; w < nwin; w++) r0[w] = nwin == 1 ? 0 : (nrows - W) * w / (nwin - 1);
+    const hipError_t e = cvr::l2_hits_device(rp_dev, ci_dev, r0, nwin, W, ncols, f32, (size_t)(4u << 20) / 128, refs, hits, st);
+    if (e != hipSuccess) return e;
+    double refs_all = 0, miss_all = 0;
+    for (int w = 0; w < nwin; w++) { refs_all += refs[w]; miss_all += refs[w] - hits[w]; }
+    *miss = refs_all > 0 ? miss_all / refs_all : 0.0;
+    return hipSuccess;
+}
+
+static int panels_from_miss(double xb, double miss) { return miss > 0.17 ? std::min(64, std::max(2, (int)(xb * miss / 1.8e6 + 0.5))) : 1; }
+
 static int auto_panels(const cvr_csr_view &v, double *miss_out)
 {
     const double xb = (double)v.ncols * (v.is_f32 ? 4.0 : 8.0);
@@ -907,7 +928,7 @@ static int auto_panels(const cvr_csr_view &v, double *miss_out)
     double       miss = 0;
     if (xb >= 24e6) {
         miss = l2_miss_estimate(v);
-        if (miss > 0.17) P = std::min(64, std::max(2, (int)(xb * miss / 1.8e6 + 0.5)));
+        P = panels_from_miss(xb, miss);
     }
     if (miss_out) *miss_out = miss;
     return P;
@@ -968,7 +989,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (rc) return rc;
         const double xb = (double)hostv.ncols * (hostv.is_f32 ? 4.0 : 8.0);
         civa_kind = hipMemcpyDeviceToDevice;
-        if (opt.col_panels < 0) opt.col_panels = (xb >= 24e6 && j1 > 0) ? auto_panels(hostv, nullptr) : 1;   // fetches only its sample windows of col_idx
+        if (opt.col_panels < 0 && !(xb >= 24e6 && j1 > 0)) opt.col_panels = 1;      // (else: the panel rule runs on the device arrays below)
         // (column panels of device arrays are split on the device: cvr_split.hip)
     }
 
@@ -981,15 +1002,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // 4..32 (profiles/r01_column_panels_livejournal_sweep2.log); R-MAT-24 fp32 (67 MB, 0.22) -> 8, 1 660 against
     // 2 300 us as one image (profiles/r01_column_panels_rmat24_fp32.log); R-MAT-22 fp64 (33.5 MB, 0.13) and matrices
     // whose x nearly fits (web-Google: profiles/r01_column_panel_probe.log) stay whole.
-    const bool panels_auto = !(opt_in && opt_in->col_panels >= 0);     // (opt.col_panels may already hold the rule's answer for device arrays)
-    int P = opt.col_panels;
+    const bool panels_auto = !(opt_in && opt_in->col_panels >= 0);
     clk.lap("device arrays: row_ptr, checks");
-    const double t_rule0 = now_s();
-    if (P < 0) P = auto_panels(*csr, nullptr);
-    const double panel_rule_s = now_s() - t_rule0;          // part of the analysis: added to plan_s below
-    clk.lap("panel rule");
-    if (P < 1) P = 1;
-    if (P > 64) P = 64;
     if (nrows >= (int64_t)0xfffffff0u) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
 
     cvr_handle *h = new (std::nothrow) cvr_handle;
@@ -998,7 +1012,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     h->vsz = vsz;
     cvr_info &in = h->info;
     in.nrows = nrows; in.ncols = ncols; in.nnz = nrows ? csr->row_ptr[nrows] - csr->row_ptr[0] : 0; in.is_f32 = f32 ? 1 : 0;
-    in.x_elems = ncols + 1; in.col_panels = P;
+    in.x_elems = ncols + 1;
 #define CREATE_TRY(expr)                                                                                    \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
@@ -1014,42 +1028,66 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipMalloc(&h->d_small, kSmallBytes));
     clk.lap("handle, stream");
     const double t_up0 = now_s();
+    // Host arrays of a matrix that may get column panels (x of 24 MB or more, or panels asked for) are uploaded once, as they
+    // are: the panel rule and the split run on that copy (building split arrays on the host means allocating, touching and
+    // freeing another copy of the matrix there, which costs more than the PCIe transfer: LiveJournal shape 60 ms to split +
+    // 130 ms to free against 20 ms to upload), and a matrix that stays whole adopts it as its device CSR.  The host split
+    // stays as the fallback for matrices beyond the device split's 32-bit positions or when the copy does not fit.
+    struct Staged {
+        void *rp = nullptr, *ci = nullptr, *va = nullptr;
+        void  release() { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); rp = ci = va = nullptr; }
+        ~Staged() { release(); }
+    } staged;
+    const int64_t  sj0 = nrows ? csr->row_ptr[0] : 0, sj1 = nrows ? csr->row_ptr[nrows] : 0;
+    const int64_t *rp_d = csr_in->row_ptr;
+    const int32_t *ci_d = csr_in->col_idx;
+    const void    *va_d = csr_in->vals;
+    bool           dev_split = on_device;
+    int            P = opt.col_panels;
+    const double   xbytes = (double)ncols * (double)vsz;
+    if (!on_device && (P > 1 || (P < 0 && xbytes >= 24e6)) && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !getenv("CVR_HOST_SPLIT")) {
+        if (hipMalloc(&staged.rp, sizeof(int64_t) * ((size_t)nrows + 1)) == hipSuccess && hipMalloc(&staged.ci, sizeof(int32_t) * (size_t)sj1) == hipSuccess &&
+            hipMalloc(&staged.va, vsz * (size_t)sj1) == hipSuccess &&
+            hipMemcpy(staged.rp, csr->row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(staged.ci, csr->col_idx, sizeof(int32_t) * (size_t)sj1, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(staged.va, csr->vals, vsz * (size_t)sj1, hipMemcpyHostToDevice) == hipSuccess) {
+            rp_d = static_cast<const int64_t *>(staged.rp); ci_d = static_cast<const int32_t *>(staged.ci); va_d = staged.va;
+            dev_split = true;
+        } else {
+            (void)hipGetLastError();      // not enough device memory for the staging copy: rule and split on the host
+            staged.release();
+        }
+    }
+    clk.lap("staging upload");
+    // the panel rule (col_panels < 0): on the device copy when there is one (same windows, same integers as the host form)
+    const double t_rule0 = now_s();
+    if (P < 0) {
+        if (xbytes < 24e6 || sj1 <= sj0) P = 1;
+        else if (dev_split) {
+            double miss = 0;
+            CREATE_TRY(l2_miss_estimate_dev(rp_d, ci_d, nrows, ncols, f32, h->stream, &miss));
+            P = panels_from_miss(xbytes, miss);
+        } else P = auto_panels(*csr, nullptr);
+    }
+    const double panel_rule_s = now_s() - t_rule0;          // part of the analysis: added to plan_s below
+    clk.lap("panel rule");
+    if (P < 1) P = 1;
+    if (P > 64) P = 64;
+    in.col_panels = P;
     h->parts.resize((size_t)P);
     if (P == 1) {
+        if (staged.rp) {          // the staging copy becomes the part's device CSR
+            Part &part = h->parts[0];
+            part.d_rp = static_cast<int64_t *>(staged.rp); part.d_ci = static_cast<int32_t *>(staged.ci); part.d_va = staged.va;
+            staged.rp = staged.ci = staged.va = nullptr;
+        }
         rc = build_part(h, h->parts[0], nrows, ncols, csr->row_ptr, csr->col_idx, csr->vals, civa_kind, f32, opt, &in.plan_s);
         if (rc) { cvr_destroy(h); return rc; }
         in.yext_elems = h->parts[0].yext;
     } else {
         PanelSplit   sp;
         struct SplitGuard { cvr::DeviceSplit d; ~SplitGuard() { cvr::free_device_split(d); } } dsg;
-        // The split runs on the device (cvr_split.hip).  Host arrays are uploaded once for it: building the split arrays
-        // on the host means allocating, touching and freeing another copy of the matrix there, which costs more than the
-        // PCIe transfer (LiveJournal shape: 60 ms to split + 130 ms to free against 20 ms to upload).  The host split stays
-        // as the fallback for matrices beyond the device split's 32-bit positions or when the staging copy does not fit.
-        struct Staged {
-            void *rp = nullptr, *ci = nullptr, *va = nullptr;
-            void  release() { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); rp = ci = va = nullptr; }
-            ~Staged() { release(); }
-        } staged;
-        const int64_t  sj0 = nrows ? csr->row_ptr[0] : 0, sj1 = nrows ? csr->row_ptr[nrows] : 0;
-        const int64_t *rp_d = csr_in->row_ptr;
-        const int32_t *ci_d = csr_in->col_idx;
-        const void    *va_d = csr_in->vals;
-        bool           dev_split = on_device;
-        if (!on_device && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !getenv("CVR_HOST_SPLIT")) {
-            if (hipMalloc(&staged.rp, sizeof(int64_t) * ((size_t)nrows + 1)) == hipSuccess && hipMalloc(&staged.ci, sizeof(int32_t) * (size_t)sj1) == hipSuccess &&
-                hipMalloc(&staged.va, vsz * (size_t)sj1) == hipSuccess &&
-                hipMemcpy(staged.rp, csr->row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice) == hipSuccess &&
-                hipMemcpy(staged.ci, csr->col_idx, sizeof(int32_t) * (size_t)sj1, hipMemcpyHostToDevice) == hipSuccess &&
-                hipMemcpy(staged.va, csr->vals, vsz * (size_t)sj1, hipMemcpyHostToDevice) == hipSuccess) {
-                rp_d = static_cast<const int64_t *>(staged.rp); ci_d = static_cast<const int32_t *>(staged.ci); va_d = staged.va;
-                dev_split = true;
-            } else {
-                (void)hipGetLastError();      // not enough device memory for the staging copy: split on the host
-            }
-        }
-        clk.lap("  staging upload");
-        const double t0 = now_s();         // (the staging copy is an upload, not planning)
+        const double t0 = now_s();
         // Power-law matrices whose popular columns will sit in hub tables need fewer, wider panels: the table takes the hot
         // half of the gathers off the L2s, and what remains runs best with ~16 MB of x per panel instead of ~4 (R-MAT-26 fp32
         // on one GPU: 59 panels 6.4 ms, 16 panels 5.4 ms; R-MAT-24: 8 and 4 panels alike; profiles/r02_hub_table_rmat.log)
@@ -1250,7 +1288,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipMemsetAsync(h->d_y, 0, vsz * (size_t)in.yext_elems, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
     CREATE_TRY(hipStreamSynchronize(h->stream));   // the caller may free its CSR when this returns
-    in.upload_s = now_s() - t_up0 - in.plan_s - in.probe_s;
+    in.upload_s = now_s() - t_up0 - in.plan_s - in.probe_s - panel_rule_s;
     in.plan_s += panel_rule_s;
     cvr::free_plan_scratch(h->plan_ws);
     (void)hipFree(h->d_small); h->d_small = nullptr;

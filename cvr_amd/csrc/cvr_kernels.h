@@ -102,6 +102,9 @@ struct DeviceSplit {
 hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, const void *va_dev, bool f32, int64_t nrows, int64_t nz0,
                                int64_t nz1, int64_t width, int P, DeviceSplit *out, hipStream_t st);
 void       free_device_split(DeviceSplit &s);
+// the panel rule's L2 model for a device-resident CSR (cvr_split.hip): per window of W rows, gathers and hits among the `resident` most used lines
+hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t ncols, bool f32, size_t resident,
+                          double *refs, double *hits, hipStream_t st);
 
 // ---- the chunk planner on the device (cvr_plan_dev.hip): the plan of plan_chunks from a device-resident row_ptr ----
 struct Plan;

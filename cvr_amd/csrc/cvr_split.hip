@@ -71,6 +71,40 @@ __global__ __launch_bounds__(256) void split_emit_kernel(const uint32_t *__restr
     if (blockIdx.x == 0 && threadIdx.x == 0) rp_s[nsub] = n;
 }
 
+// ---- the panel rule's L2 model on the device (the host form: l2_miss_estimate in cvr_capi.hip) ----
+constexpr uint32_t kEstBins = 4096;        // line counts 1 .. 4094 have a bin each; larger ones are summed exactly on the side
+
+// window w = rows [r0[w], r0[w] + W): one count per 128-byte line of x
+__global__ __launch_bounds__(256) void est_count_kernel(const long long *__restrict__ rp, const int32_t *__restrict__ ci, const long long *__restrict__ r0,
+                                                        long long W, uint32_t per_line, long long nlines, uint32_t *__restrict__ cnt,
+                                                        unsigned long long *__restrict__ refs)
+{
+    const uint32_t  w = blockIdx.y;
+    const long long j0 = rp[r0[w]], j1 = rp[r0[w] + W];
+    uint32_t       *c = cnt + (size_t)w * (size_t)nlines;
+    for (long long j = j0 + (long long)blockIdx.x * 256 + threadIdx.x; j < j1; j += (long long)gridDim.x * 256) atomicAdd(&c[(uint32_t)ci[j] / per_line], 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) refs[w] = (unsigned long long)(j1 - j0);
+}
+
+// per window: how many lines were touched c times (c < kEstBins - 1), and number and sum of the larger counts
+__global__ __launch_bounds__(256) void est_hist_kernel(const uint32_t *__restrict__ cnt, long long nlines, uint32_t *__restrict__ hist,
+                                                       unsigned long long *__restrict__ big)
+{
+    __shared__ uint32_t h[kEstBins];
+    const uint32_t  w = blockIdx.y;
+    const uint32_t *c = cnt + (size_t)w * (size_t)nlines;
+    for (uint32_t i = threadIdx.x; i < kEstBins; i += 256) h[i] = 0;
+    __syncthreads();
+    for (long long l = (long long)blockIdx.x * 256 + threadIdx.x; l < nlines; l += (long long)gridDim.x * 256) {
+        const uint32_t v = c[l];
+        if (v == 0) continue;
+        if (v < kEstBins - 1) atomicAdd(&h[v], 1u);
+        else { atomicAdd(&big[2 * w], 1ull); atomicAdd(&big[2 * w + 1], (unsigned long long)v); }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kEstBins; i += 256) if (h[i]) atomicAdd(&hist[(size_t)w * kEstBins + i], h[i]);
+}
+
 uint32_t grid_for(long long n) { return (uint32_t)std::min<long long>(4096, std::max<long long>(1, (n + 255) / 256)); }
 
 struct Tmp {            // frees whatever was allocated, on every path
@@ -80,6 +114,54 @@ struct Tmp {            // frees whatever was allocated, on every path
 };
 
 }  // namespace
+
+// Per window w (rows r0[w] .. r0[w] + W of a device-resident CSR): refs[w] = its non-zeros, hits[w] = the gathers that find their
+// 128-byte line of x among the `resident` most used lines of the window, first touches excluded -- the same integers the host
+// estimator computes (sum of the top counts minus one each), through a histogram of the line counts instead of a selection.
+hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t ncols, bool f32, size_t resident,
+                          double *refs, double *hits, hipStream_t st)
+{
+    if (nwin < 1 || nwin > 64) return hipErrorInvalidValue;
+    const uint32_t  per_line = f32 ? 32 : 16;
+    const long long nlines = ncols / per_line + 1;
+    Tmp             tmp;
+    uint32_t           *cnt = nullptr, *hist = nullptr;
+    unsigned long long *small = nullptr;     // [nwin] refs, [2 nwin] big, then the windows' first rows
+    hipError_t e = tmp.alloc(&cnt, sizeof(uint32_t) * (size_t)nwin * (size_t)nlines);
+    if (e == hipSuccess) e = tmp.alloc(&hist, sizeof(uint32_t) * (size_t)nwin * kEstBins);
+    if (e == hipSuccess) e = tmp.alloc(&small, sizeof(unsigned long long) * 4 * (size_t)nwin);
+    if (e != hipSuccess) return e;
+    unsigned long long *d_refs = small, *d_big = small + nwin;
+    long long          *d_r0 = reinterpret_cast<long long *>(small + 3 * nwin);
+    e = hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)nwin * (size_t)nlines, st);
+    if (e == hipSuccess) e = hipMemsetAsync(hist, 0, sizeof(uint32_t) * (size_t)nwin * kEstBins, st);
+    if (e == hipSuccess) e = hipMemsetAsync(small, 0, sizeof(unsigned long long) * 3 * (size_t)nwin, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_r0, r0_host, sizeof(long long) * (size_t)nwin, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(est_count_kernel, dim3(512, (uint32_t)nwin), dim3(256), 0, st, reinterpret_cast<const long long *>(rp_dev), ci_dev, d_r0, (long long)W, per_line,
+                       nlines, cnt, d_refs);
+    hipLaunchKernelGGL(est_hist_kernel, dim3(64, (uint32_t)nwin), dim3(256), 0, st, cnt, nlines, hist, d_big);
+    std::vector<uint32_t>           h((size_t)nwin * kEstBins);
+    std::vector<unsigned long long> sm(3 * (size_t)nwin);
+    e = hipMemcpyAsync(h.data(), hist, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(sm.data(), small, sizeof(unsigned long long) * sm.size(), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    for (int w = 0; w < nwin; w++) {
+        refs[w] = (double)sm[(size_t)w];
+        unsigned long long left = resident, hit = 0;
+        const unsigned long long nbig = sm[(size_t)nwin + 2 * w], sbig = sm[(size_t)nwin + 2 * w + 1];
+        if (nbig <= left) { hit += sbig - nbig; left -= nbig; }
+        else { hit += (unsigned long long)((double)sbig / (double)nbig * (double)left) - left; left = 0; }      // (more such lines than the cache holds: their mean)
+        for (uint32_t v = kEstBins - 2; v >= 1 && left > 0; v--) {
+            const unsigned long long take = std::min<unsigned long long>(left, h[(size_t)w * kEstBins + v]);
+            hit += take * (v - 1);
+            left -= take;
+        }
+        hits[w] = (double)hit;
+    }
+    return hipSuccess;
+}
 
 void free_device_split(DeviceSplit &s)
 {

@@ -61,3 +61,37 @@ def test_device_planner_declines_what_it_cannot_hold():
         cvr_amd.plan_selfcheck(_rp(np.full(1000, 3)), 512)
     r = cvr_amd.plan_selfcheck(np.zeros(1, dtype=np.int64), 8)     # no rows: no chunks
     assert r["nchunks"] == 0
+
+
+def test_panel_rule_on_the_device_equals_the_host_rule():
+    """cvr_create's automatic panel count for a matrix with a large x comes from the L2 model run on the device copy of the CSR
+    (cvr_split.hip: l2_hits_device): the same count as cvr_auto_panels (the host form) gives -- scattered columns -> panels,
+    a band -> one image (which then adopts the staging copy) -- for host arrays and for arrays already on the device; y checked"""
+    import oraclelib as O
+    from cvr_amd import capi
+    rng = np.random.default_rng(5)
+    n = 3_300_000                                                          # x = 26.4 MB of fp64
+    rp = np.arange(n + 1, dtype=np.int64) * 2
+    scattered = rng.integers(0, n, 2 * n).astype(np.int32)
+    scattered.reshape(n, 2).sort(axis=1)
+    band = (np.repeat(np.arange(n, dtype=np.int64), 2) + np.tile([0, 3], n)).clip(0, n - 1).astype(np.int32)
+    va = ((np.arange(2 * n) % 7) - 2.5).astype(np.float64)
+    x = O.x_vec_fast(n, "rand")
+    for ci in (scattered, band):
+        P_host, _ = capi.auto_panels(n, n, rp, ci)
+        A = cvr_amd.CvrMatrix(n, n, rp, ci, va)
+        assert A.info.col_panels == P_host, (A.info.col_panels, P_host)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        bad, worst = O.tol_check(y, yref, absy + 1e-30)
+        assert len(bad) == 0, worst
+        A.close()
+    assert P_host == 1
+    P_host, _ = capi.auto_panels(n, n, rp, scattered)
+    assert P_host > 4
+    import torch
+    keep = [torch.from_numpy(a).cuda() for a in (rp, scattered, va)]
+    torch.cuda.synchronize()
+    A = cvr_amd.CvrMatrix.from_device(n, n, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr())
+    assert A.info.col_panels == P_host
+    A.close()
