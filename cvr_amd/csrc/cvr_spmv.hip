@@ -110,15 +110,25 @@ __device__ __forceinline__ T load_x(__amdgpu_buffer_rsrc_t rx, uint32_t col)
 // window [wbase, wbase + wn) staged in LDS, lanes whose column falls inside read LDS and send the global load out
 // of range (returns 0, no memory traffic); the other lanes read the zero slot win[wn].  The two halves are OR-ed
 // where the value is used (x_of), so that both loads stay in flight until then.
-template <typename T, int POL, bool WIN>
+// WIN: 0 = no LDS table, 1 = a window of x, 2 = a hub table (with or without a window behind it).
+template <typename T, int POL, int WIN>
 __device__ __forceinline__ X4<T> gather(__amdgpu_buffer_rsrc_t rx, const T *win, const u32x4 c, const uint32_t mask,
                                         const uint32_t wbase, const uint32_t wn, const uint32_t hub_n)
 {
     X4<T>          r;
     const uint32_t col[4] = {c.x & mask, c.y & mask, c.z & mask, c.w & mask};
-    if constexpr (!WIN) {
+    if constexpr (WIN == 0) {
 #pragma unroll
         for (int j = 0; j < 4; j++) r.v[j] = load_x<T, POL>(rx, col[j]);
+    } else if constexpr (WIN == 1) {
+        // LDS: [window of x (wn) | zeros]: five vector instructions per step less than the hub form (the SpMV loop of the resident
+        // layout is bound by instruction issue: two wavefronts per SIMD, ~70 vector instructions per step)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t rel = col[j] - wbase;
+            r.v[j] = load_x<T, POL>(rx, rel < wn ? 0x3fffffffu : col[j]);   // 0x3fffffff * sizeof(T) is past num_records
+            r.w[j] = win[rel < wn ? rel : wn];
+        }
     } else {
         // LDS: [hub table (hub_n) | window of x (wn) | zeros].  A slot of a hub column holds kHubBit and the table index.
         const uint32_t raw[4] = {c.x, c.y, c.z, c.w};
@@ -135,10 +145,10 @@ __device__ __forceinline__ X4<T> gather(__amdgpu_buffer_rsrc_t rx, const T *win,
     return r;
 }
 
-template <typename T, bool WIN>
+template <typename T, int WIN>
 __device__ __forceinline__ T x_of(const X4<T> &x, int j)
 {
-    if constexpr (!WIN) return x.v[j];
+    if constexpr (WIN == 0) return x.v[j];
     else if constexpr (sizeof(T) == 8) return __builtin_bit_cast(double, __builtin_bit_cast(uint64_t, x.v[j]) | __builtin_bit_cast(uint64_t, x.w[j]));
     else return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x.v[j]) | __builtin_bit_cast(uint32_t, x.w[j]));
 }
@@ -191,7 +201,7 @@ template <typename T> __device__ __forceinline__ void lds_add(T *p, T v)
 // four steps of all 64 lanes: FMA, then the write-back of the lanes whose segment ends at the step.  SEGT (column phases):
 // the segment's sum is added to its row's accumulator in LDS (ystage[row of the chunk]); the rows of the segments come
 // in the segment's last column word, above the column index (bits [col_bits, 31)).
-template <typename T, bool WIN, bool DICT, bool SEGT>
+template <typename T, int WIN, bool DICT, bool SEGT>
 __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT> &Q, const X4<T> &xq, T *__restrict__ yext,
                                           T *slot_lane, uint32_t row_first, uint32_t nseg, uint32_t head_dest,
                                           uint32_t last_dest, const T *dict, T *ystage, bool staged, uint32_t col_bits)
@@ -237,7 +247,7 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
 
 // MW: more than one wavefront per workgroup (blockDim.x / 64 consecutive chunks share the workgroup's LDS window of x and its
 // dictionary copy); the single-wavefront form needs no barrier.
-template <typename T, int QA, int XPOL, int DEPTH, bool WIN, bool DICT, bool MW, bool SEGT, bool C16>
+template <typename T, int QA, int XPOL, int DEPTH, int WIN, bool DICT, bool MW, bool SEGT, bool C16>
 __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv_kernel(
     const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
     const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     const uint32_t *__restrict__ cbase, uint32_t pad_col)
 {
     constexpr int  GB = DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
-    constexpr bool kSync = WIN || (DICT && MW);      // LDS filled by other waves of the workgroup
+    constexpr bool kSync = WIN != 0 || (DICT && MW);      // LDS filled by other waves of the workgroup
     // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums (SEGT: row accumulators), the value dictionary (DICT),
     // the x window and its zero slot (WIN; wn + 4 values)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     uint32_t wbase = 0;
     if constexpr (DICT)
         for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += blockDim.x) dict[i] = i < ndict ? dict_g[i] : T(0);
-    if constexpr (WIN) {
+    if constexpr (WIN != 0) {
         constexpr uint32_t kPer = 16 / sizeof(T);                      // values per 16-byte load; wbase and wn are multiples of it
         wbase = wn && blk * nw < nchunks ? win_base[blk] : 0u;
         // eight 16-byte loads in flight per lane before the first LDS store (the 64-KB window takes 1.8 us either way -- all
@@ -551,11 +561,11 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_PICK_SG(T, SP, D, W, DI, MW) do { if (img.phases > 1) CVR_LAUNCH(T, SP, D, W, DI, MW, true); else CVR_LAUNCH(T, SP, D, W, DI, MW, false); } while (0)
 #define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_PICK_SG(T, SP, D, W, DI, true); else CVR_PICK_SG(T, SP, D, W, DI, false); } while (0)
 #define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_PICK_MW(T, SP, D, W, true); else CVR_PICK_MW(T, SP, D, W, false); } while (0)
-#define CVR_PICK_W(T, SP, D)     do { if (use_win) CVR_PICK_DI(T, SP, D, true); else CVR_PICK_DI(T, SP, D, false); } while (0)
+#define CVR_PICK_W(T, SP, D)     do { if (use_win && img.hub_n) CVR_PICK_DI(T, SP, D, 2); else if (use_win) CVR_PICK_DI(T, SP, D, 1); else CVR_PICK_DI(T, SP, D, 0); } while (0)
 #define CVR_PICK_D(T, SP)        do { if (img.depth == 2) CVR_PICK_W(T, SP, 2); else CVR_PICK_W(T, SP, 1); } while (0)
 #define CVR_PICK_SP(T)           do { if (img.stream_ahead >= 2) CVR_PICK_D(T, 3); else CVR_PICK_D(T, 1); } while (0)
 #define CVR_LAUNCH_C16(T, SP, D)                                                                                  \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, false, false, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, 0, false, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, 0u,          \
                        static_cast<const T *>(nullptr), 0u, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col)
