@@ -377,6 +377,8 @@ struct PartPlan {
 struct DevRows { const int64_t *rp = nullptr; int64_t nz0 = 0, nz1 = 0; hipStream_t st = nullptr; cvr::PlanScratch *ws = nullptr; };
 // matrices of at least this many rows whose row_ptr is on the device anyway are planned there (cvr_plan_dev.hip)
 constexpr int64_t kDevicePlanRows = 200000;
+// (CVR_DEVICE_PLAN_ROWS overrides it: the fuzz tests send their small matrices through the device planner with 0)
+static int64_t device_plan_rows() { const char *e = getenv("CVR_DEVICE_PLAN_ROWS"); return e ? atoll(e) : kDevicePlanRows; }
 
 static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const cvr_options &opt, const DevRows *dr = nullptr)
 {
@@ -649,7 +651,7 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
         if (rc) return rc;
         const double   t0 = now_s();
         DevRows        here{part.d_rp, nz0, nz1, h->stream, &h->plan_ws};
-        const bool     on_dev = rp && nrows >= kDevicePlanRows && !getenv("CVR_HOST_PLAN");      // (the upload of row_ptr is in front of the planner's kernels on the stream)
+        const bool     on_dev = rp && nrows > 0 && nrows >= device_plan_rows() && !getenv("CVR_HOST_PLAN");      // (the upload of row_ptr is in front of the planner's kernels on the stream)
         const int64_t *prp = on_dev ? nullptr : rp;
         const DevRows *pdr = on_dev ? &here : dr;
         HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));
@@ -1024,7 +1026,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->plan_ws.pinned), h->plan_ws.pinned_bytes = nrows >= kDevicePlanRows ? (size_t)704 << 10 : kPinnedSmall, hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->plan_ws.pinned), h->plan_ws.pinned_bytes = nrows >= device_plan_rows() ? (size_t)704 << 10 : kPinnedSmall, hipHostMallocDefault));
     CREATE_TRY(hipMalloc(&h->d_small, kSmallBytes));
     clk.lap("handle, stream");
     const double t_up0 = now_s();

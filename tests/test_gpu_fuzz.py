@@ -40,9 +40,19 @@ def _random_case(rng):
     return K.csr_from_lengths(lens, ncols, rng, sort=srt) + (srt,)
 
 
-def test_fuzz_parity():
-    ncases = int(os.environ.get("CVR_FUZZ_CASES", "48"))
-    rng = np.random.default_rng(int(os.environ.get("CVR_FUZZ_SEED", "20261002")))
+def test_fuzz_parity_through_the_device_planner():
+    """the same cases with every matrix planned on the device (cvr_plan_dev.hip; cvr_create uses it from 200 000 rows on):
+    the image is still the mirror's bit for bit"""
+    os.environ["CVR_DEVICE_PLAN_ROWS"] = "0"
+    try:
+        test_fuzz_parity(int(os.environ.get("CVR_FUZZ_CASES", "32")), 20261003)
+    finally:
+        del os.environ["CVR_DEVICE_PLAN_ROWS"]
+
+
+def test_fuzz_parity(ncases=None, seed=None):
+    ncases = int(os.environ.get("CVR_FUZZ_CASES", "48")) if ncases is None else ncases
+    rng = np.random.default_rng(int(os.environ.get("CVR_FUZZ_SEED", "20261002")) if seed is None else seed)
     for case in range(ncases):
         nrows, ncols, rp, ci, va, srt = _random_case(rng)
         f32 = bool(rng.integers(0, 4) == 0)
