@@ -34,7 +34,10 @@ __global__ void split_bounds_kernel(const uint8_t *__restrict__ key, long long n
     off[p] = lo;
 }
 
-// the sorted non-zeros: column, value, row (binary search in row_ptr), and the flag "first entry of a sub-row"
+// the sorted non-zeros: column, value, row (binary search in row_ptr).  One workgroup per 256 elements (no grid-stride loop:
+// the search is a chain of dependent loads).  What bounds it is not the search: a panel's elements are a ninth (1 / P) of every
+// cache line of col_idx and vals, so the CSR is read P times over (LiveJournal shape: 1.8 ms; bracketing the search per
+// wavefront or per run of 8 elements made it 3.1 - 3.8 ms)
 template <typename T>
 __global__ __launch_bounds__(256) void split_gather_kernel(const long long *__restrict__ rp, long long nrows, const int32_t *__restrict__ ci,
                                                            const T *__restrict__ va, long long nz0, long long n,
@@ -179,14 +182,27 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
     if (P < 1 || P > kMaxSplitPanels || width < 1 || n >= (1ll << 32) || nrows >= (1ll << 32)) return hipErrorInvalidValue;
     out->nnz = n;
     const size_t vsz = f32 ? 4 : 8;
+    // the temporaries (22 bytes per non-zero + the sort's work space) in one allocation: on some boxes of the pool a single
+    // hipMalloc / hipFree of such a buffer takes tens of milliseconds
     Tmp tmp;
-    uint8_t  *key_in = nullptr, *key = nullptr;
+    uint8_t  *key_in = nullptr, *key = nullptr, *arena = nullptr;
     uint32_t *idx_in = nullptr, *idx = nullptr, *row_s = nullptr, *head = nullptr, *sidx = nullptr;
     long long *off_dev = nullptr;
-    SPLIT_TRY(tmp.alloc(&key_in, (size_t)n)); SPLIT_TRY(tmp.alloc(&key, (size_t)n));
-    SPLIT_TRY(tmp.alloc(&idx_in, 4 * (size_t)n)); SPLIT_TRY(tmp.alloc(&idx, 4 * (size_t)n));
-    SPLIT_TRY(tmp.alloc(&row_s, 4 * (size_t)n)); SPLIT_TRY(tmp.alloc(&head, 4 * (size_t)n)); SPLIT_TRY(tmp.alloc(&sidx, 4 * (size_t)n));
-    SPLIT_TRY(tmp.alloc(&off_dev, sizeof(long long) * (kMaxSplitPanels + 2)));
+    int       bits = 1;
+    while ((1 << bits) < P) bits++;
+    size_t sort_bytes = 0, scan_bytes = 0;
+    SPLIT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, key_in, key, idx_in, idx, (unsigned int)std::max<long long>(n, 1), 0, bits, st));
+    SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, head, sidx, (unsigned int)std::max<long long>(n, 1), st));
+    auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t nn = (size_t)std::max<long long>(n, 4);
+    const size_t o_key_in = 0, o_key = o_key_in + up(nn), o_idx_in = o_key + up(nn), o_idx = o_idx_in + up(4 * nn), o_row = o_idx + up(4 * nn),
+                 o_head = o_row + up(4 * nn), o_sidx = o_head + up(4 * nn), o_off = o_sidx + up(4 * nn), o_work = o_off + up(sizeof(long long) * (kMaxSplitPanels + 2)),
+                 total = o_work + up(std::max(sort_bytes, scan_bytes));
+    SPLIT_TRY(tmp.alloc(&arena, total));
+    key_in = arena + o_key_in; key = arena + o_key;
+    idx_in = reinterpret_cast<uint32_t *>(arena + o_idx_in); idx = reinterpret_cast<uint32_t *>(arena + o_idx); row_s = reinterpret_cast<uint32_t *>(arena + o_row);
+    head = reinterpret_cast<uint32_t *>(arena + o_head); sidx = reinterpret_cast<uint32_t *>(arena + o_sidx); off_dev = reinterpret_cast<long long *>(arena + o_off);
+    void *work = arena + o_work;
     SPLIT_TRY(hipMalloc(&out->ci, std::max<size_t>(4 * (size_t)n, 16)));
     SPLIT_TRY(hipMalloc(&out->va, std::max<size_t>(vsz * (size_t)n, 16)));
     for (int p = 0; p <= P; p++) { out->off[p] = 0; out->sub0[p] = 0; }
@@ -196,17 +212,10 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
         return hipStreamSynchronize(st);
     }
     hipLaunchKernelGGL(split_key_kernel, dim3(grid_for(n)), dim3(256), 0, st, ci_dev, (long long)nz0, n, (long long)width, key_in, idx_in);
-    int bits = 1;
-    while ((1 << bits) < P) bits++;
-    size_t sort_bytes = 0, scan_bytes = 0;
-    SPLIT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, key_in, key, idx_in, idx, (unsigned int)n, 0, bits, st));
-    SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, head, sidx, (unsigned int)n, st));
-    void *work = nullptr;
-    SPLIT_TRY(tmp.alloc(&work, std::max(sort_bytes, scan_bytes)));
     SPLIT_TRY(hipcub::DeviceRadixSort::SortPairs(work, sort_bytes, key_in, key, idx_in, idx, (unsigned int)n, 0, bits, st));   // stable
     hipLaunchKernelGGL(split_bounds_kernel, dim3(1), dim3(kMaxSplitPanels + 1), 0, st, key, n, P, off_dev);
-    if (f32) hipLaunchKernelGGL(split_gather_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const float *>(va_dev), (long long)nz0, n, idx, out->ci, static_cast<float *>(out->va), row_s);
-    else hipLaunchKernelGGL(split_gather_kernel<double>, dim3(grid_for(n)), dim3(256), 0, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const double *>(va_dev), (long long)nz0, n, idx, out->ci, static_cast<double *>(out->va), row_s);
+    if (f32) hipLaunchKernelGGL(split_gather_kernel<float>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const float *>(va_dev), (long long)nz0, n, idx, out->ci, static_cast<float *>(out->va), row_s);
+    else hipLaunchKernelGGL(split_gather_kernel<double>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const double *>(va_dev), (long long)nz0, n, idx, out->ci, static_cast<double *>(out->va), row_s);
     hipLaunchKernelGGL(split_head_kernel, dim3(grid_for(n)), dim3(256), 0, st, key, row_s, n, head);
     SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(work, scan_bytes, head, sidx, (unsigned int)n, st));
     uint32_t  last[2] = {0, 0};

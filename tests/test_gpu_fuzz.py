@@ -1,6 +1,6 @@
 """GPU: randomised parity -- random row-length distributions (empty rows, giants, uniform, power law), random chunk
 length, split threshold, column panels, waves per workgroup, LDS window and column phases; converter image against the CPU mirror (bit for bit, when one
-image) and y against the CSR oracle.  CVR_FUZZ_CASES raises the number of cases (default 48)."""
+image) and y against the CSR oracle.  CVR_FUZZ_CASES sets the number of cases (default 160, and 96 more through the device planner)."""
 import os
 
 import numpy as np
@@ -45,13 +45,13 @@ def test_fuzz_parity_through_the_device_planner():
     the image is still the mirror's bit for bit"""
     os.environ["CVR_DEVICE_PLAN_ROWS"] = "0"
     try:
-        test_fuzz_parity(int(os.environ.get("CVR_FUZZ_CASES", "32")), 20261003)
+        test_fuzz_parity(int(os.environ.get("CVR_FUZZ_CASES", "96")), 20261003)
     finally:
         del os.environ["CVR_DEVICE_PLAN_ROWS"]
 
 
 def test_fuzz_parity(ncases=None, seed=None):
-    ncases = int(os.environ.get("CVR_FUZZ_CASES", "48")) if ncases is None else ncases
+    ncases = int(os.environ.get("CVR_FUZZ_CASES", "160")) if ncases is None else ncases
     rng = np.random.default_rng(int(os.environ.get("CVR_FUZZ_SEED", "20261002")) if seed is None else seed)
     for case in range(ncases):
         nrows, ncols, rp, ci, va, srt = _random_case(rng)
