@@ -15,6 +15,7 @@
 #include "cvr_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace cvr {
 namespace {
@@ -44,7 +45,12 @@ __device__ __forceinline__ uint32_t dict_code(const typename Bits<T>::type *dict
 
 // SEGT: the chunk's segments come from a table (column phases: one segment per (row, phase) pair, launch_seg_fill) instead
 // of being the chunk's rows in order.
-template <typename T, bool DICT, bool SEGT, bool C16>
+// STAGE: the wavefront first copies its chunk's feed table -- the (begin, length, row) of its segments, or its clamped row
+// pointers -- into LDS with coalesced loads.  The hand-out of a new segment then costs an LDS read instead of a global load that
+// every later load of the step depends on: the converter is a chain of 64 S dependent steps, 75 % of its cycles are waits
+// (SQ_WAIT_ANY), and this removes one of the two round trips per step.  (Staging the chunk's columns and values as well was
+// slower: 34 KB of LDS per chunk leave four chunks per CU where seven want to run; profiles/r02_convert_lds_staging_probe.log.)
+template <typename T, bool DICT, bool SEGT, bool C16, bool STAGE = false>
 __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx, const T *__restrict__ vals,
     const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt, const uint4 *__restrict__ desc,
@@ -52,8 +58,9 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
     const uint2 *__restrict__ desc2, const int64_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
     const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags, const int32_t *__restrict__ hub_index, const uint32_t *__restrict__ hub_bitmap,
-    const uint32_t *__restrict__ cbase, uint32_t hub_n)
+    const uint32_t *__restrict__ cbase, uint32_t hub_n, uint32_t stage_bytes)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t csm[];      // STAGE: stage_bytes per wavefront
     if constexpr (SEGT) { if (seg_flags[0] & 1u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
     constexpr int GB = DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     constexpr int CB = C16 ? kCols16Bytes : kColsBytes;      // bytes of the group's column part
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    const uint32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (k >= nchunks) return;
     const int64_t  b = nzb[k], e = nzb[k + 1];
     const uint4    d = desc[k];
@@ -84,9 +91,57 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     uint32_t base_col = 0;
     if constexpr (C16) base_col = cbase[k];
 
+    // STAGE, per wavefront: SEGT: begin (u16, from the chunk's first element; 0xffff = pad), length (u16), row (u16) x 64 S;
+    // else the row pointers of the chunk's rows, clamped to the chunk, from its first element (u32) x (64 S + 2).  Addressed as
+    // offsets into csm, so that every access is an LDS instruction.
+    const uint32_t cap = (uint32_t)S * kLanes, o_feed = (threadIdx.x >> 6) * stage_bytes;
+#define SBEG(i) (*reinterpret_cast<uint16_t *>(csm + o_feed + 2u * (uint32_t)(i)))
+#define SLEN(i) (*reinterpret_cast<uint16_t *>(csm + o_feed + 2u * cap + 2u * (uint32_t)(i)))
+#define SRW(i)  (*reinterpret_cast<uint16_t *>(csm + o_feed + 4u * cap + 2u * (uint32_t)(i)))
+#define SROW(i) (*reinterpret_cast<uint32_t *>(csm + o_feed + 4u * (uint32_t)(i)))
+    if constexpr (STAGE) {
+        constexpr uint32_t kBatch = 8;              // loads in flight per lane: the copy is a few round trips, not one per 64 entries
+        if constexpr (SEGT) {
+            for (uint32_t q0 = 0; q0 < nseg; q0 += kLanes * kBatch) {
+                int64_t  sb[kBatch];
+                uint32_t sl[kBatch];
+                uint16_t sr[kBatch];
+#pragma unroll
+                for (uint32_t u = 0; u < kBatch; u++) {
+                    const uint32_t q = q0 + u * kLanes + lane;
+                    sb[u] = q < nseg ? seg_begin[sbase + q] : -1;
+                    sl[u] = q < nseg ? seg_len[sbase + q] : 0u;
+                    sr[u] = q < nseg ? seg_row[sbase + q] : (uint16_t)0;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kBatch; u++) {
+                    const uint32_t q = q0 + u * kLanes + lane;
+                    if (q < nseg) { SBEG(q) = sb[u] < 0 ? (uint16_t)0xffffu : (uint16_t)(sb[u] - b); SLEN(q) = (uint16_t)sl[u]; SRW(q) = sr[u]; }
+                }
+            }
+        } else {
+            for (uint32_t i0 = 0; i0 <= nrow_seg; i0 += kLanes * kBatch) {
+                int64_t a[kBatch];
+#pragma unroll
+                for (uint32_t u = 0; u < kBatch; u++) {
+                    const uint32_t i = i0 + u * kLanes + lane;
+                    a[u] = i <= nrow_seg ? rp[(int64_t)row_first + i] : 0;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kBatch; u++) {
+                    const uint32_t i = i0 + u * kLanes + lane;
+                    if (i <= nrow_seg) { int64_t x = a[u] > b ? a[u] : b; x = x < e ? x : e; SROW(i) = (uint32_t)(x - b); }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the wavefront's own LDS writes, in order, before its reads below
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
     for (int g = 0; g < G; g++) {
-        uint32_t cw[4];
+        uint32_t cw[4], cj[4];
         T        vv[4];
+        int64_t  pj[4];
 #pragma unroll
         for (int j = 0; j < kGroupSteps; j++) {
             const uint64_t em = __ballot(cnt == 0);
@@ -97,10 +152,21 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
                 bool           want = cnt == 0;
                 if (want && rank < navail) {                 // feeding, spmv.cpp:821-868
                     const uint32_t q = fed + rank;
-                    if constexpr (SEGT) {
+                    if constexpr (SEGT && STAGE) {
+                        const uint32_t sb = SBEG(q);
+                        pos = sb == 0xffffu ? -1 : b + (int64_t)sb;
+                        cnt = SLEN(q);
+                        rowtag = (uint32_t)SRW(q) << col_bits;
+                    } else if constexpr (SEGT) {
                         pos = seg_begin[sbase + q];
                         cnt = seg_len[sbase + q];
                         rowtag = (uint32_t)seg_row[sbase + q] << col_bits;
+                    } else if constexpr (STAGE) {
+                        if (q < nrow_seg) {
+                            const uint32_t a = SROW(q), z = SROW(q + 1);
+                            if (z > a) { pos = b + (int64_t)a; cnt = z - a; }
+                            else { pos = -1; cnt = 1; }          // empty row: one pad slot
+                        } else { pos = -1; cnt = pc; }           // the chunk's trailing pad segment
                     } else if (q < nrow_seg) {
                         const int64_t r = (int64_t)row_first + q;
                         int64_t       a = rp[r], z = rp[r + 1];
@@ -140,18 +206,26 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
                     }
                 }
             }
-            uint32_t c = pad_col;
-            T        v = 0;
-            if (pos >= 0) {
-                c = (uint32_t)cidx[pos]; v = vals[pos]; pos++;
-                if (hub_index && ((hub_bitmap[c >> 5] >> (c & 31u)) & 1u)) {      // hub column: its index in the LDS table (full order: every column's rank)
-                    const uint32_t rk = (uint32_t)hub_index[c];
-                    c = rk < hub_n ? kHubBit | rk : rk;
-                }
-            }
-            cw[j] = c | (cnt == 1 ? kEndBit | rowtag : 0u);
-            vv[j] = v;
+            // which element the lane emits at this step; the element itself is fetched below, for the four steps together: the
+            // hand-out of the next steps depends on the counts only, not on what was loaded
+            pj[j] = pos;
+            cw[j] = cnt == 1 ? kEndBit | rowtag : 0u;
+            if (pos >= 0) pos++;
             cnt--;
+        }
+#pragma unroll
+        for (int j = 0; j < kGroupSteps; j++) {
+            cj[j] = pj[j] >= 0 ? (uint32_t)cidx[pj[j]] : pad_col;
+            vv[j] = pj[j] >= 0 ? vals[pj[j]] : (T)0;
+        }
+#pragma unroll
+        for (int j = 0; j < kGroupSteps; j++) {
+            uint32_t c = cj[j];
+            if (hub_index && pj[j] >= 0 && ((hub_bitmap[c >> 5] >> (c & 31u)) & 1u)) {      // hub column: its index in the LDS table (full order: every column's rank)
+                const uint32_t rk = (uint32_t)hub_index[c];
+                c = rk < hub_n ? kHubBit | rk : rk;
+            }
+            cw[j] |= c;
         }
         uint8_t *o = out + (size_t)g * GB;
         if constexpr (C16) {            // 16-bit offsets from the chunk's smallest column; 0x7fff = the pad column; bit 15 = end of segment
@@ -190,6 +264,10 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     if (cnt != 0) bad |= 1u;
     if (bad) atomicOr(err, bad);
     target[(size_t)k * kLanes + lane] = (uint8_t)tgt;
+#undef SBEG
+#undef SLEN
+#undef SRW
+#undef SROW
 }
 
 
@@ -655,26 +733,35 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     if (img.nchunks == 0) return hipSuccess;
     const uint32_t blocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3     grid(blocks), block(kLanes * kWavesPerBlock);
-#define CVR_CONVERT(T, DI, SG)                                                                                     \
-    hipLaunchKernelGGL((convert_kernel<T, DI, SG, false>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
+    // the feed table of a chunk in LDS (convert_kernel, STAGE) when eight chunks' tables fit a CU (16-bit positions: 64 S < 65 535)
+    const size_t cap = (size_t)kLanes * img.S;
+    size_t       per = seg ? 6 * cap : 4 * (cap + 2);
+    per = (per + 15) & ~(size_t)15;
+    static const bool direct = getenv("CVR_CONVERT_DIRECT") != nullptr;       // (diagnostics: the unstaged kernel)
+    const bool   stage = !img.c16 && cap < 65535 && per * kWavesPerBlock <= (20u << 10) && !direct;
+    const size_t lds = stage ? per * kWavesPerBlock : 0;
+#define CVR_CONVERT(T, DI, SG, SM)                                                                                     \
+    hipLaunchKernelGGL((convert_kernel<T, DI, SG, false, SM>), grid, block, lds, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
                        csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
                        static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, \
-                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase, img.hub_n)
-#define CVR_CONVERT_SG(T, DI) do { if (seg) CVR_CONVERT(T, DI, true); else CVR_CONVERT(T, DI, false); } while (0)
+                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase, img.hub_n, (uint32_t)per)
+#define CVR_CONVERT_SM(T, DI, SG) do { if (stage) CVR_CONVERT(T, DI, SG, true); else CVR_CONVERT(T, DI, SG, false); } while (0)
+#define CVR_CONVERT_SG(T, DI) do { if (seg) CVR_CONVERT_SM(T, DI, true); else CVR_CONVERT_SM(T, DI, false); } while (0)
     if (img.c16 && !img.dict && !seg) {      // narrow chunks: 16-bit column offsets
-        if (img.f32) hipLaunchKernelGGL((convert_kernel<float, false, false, true>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const float *>(csr.vals),
+        if (img.f32) hipLaunchKernelGGL((convert_kernel<float, false, false, true, false>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const float *>(csr.vals),
                                         csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
                                         (const float *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
-                                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u);
-        else hipLaunchKernelGGL((convert_kernel<double, false, false, true>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const double *>(csr.vals),
+                                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u);
+        else hipLaunchKernelGGL((convert_kernel<double, false, false, true, false>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const double *>(csr.vals),
                                 csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
                                 (const double *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
-                                (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u);
+                                (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u);
         return hipGetLastError();
     }
     if (img.f32) { if (img.dict) CVR_CONVERT_SG(float, true); else CVR_CONVERT_SG(float, false); }
     else         { if (img.dict) CVR_CONVERT_SG(double, true); else CVR_CONVERT_SG(double, false); }
 #undef CVR_CONVERT_SG
+#undef CVR_CONVERT_SM
 #undef CVR_CONVERT
     return hipGetLastError();
 }
