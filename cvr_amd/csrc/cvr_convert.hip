@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ va
 
 }  // namespace
 
-hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st)
+hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st, bool out_zeroed)
 {
     if (nrows <= 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)std::min<int64_t>(16384, (nrows + 255) / 256);      // one group of 256 rows each (more rows: several)
@@ -668,8 +668,10 @@ hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int
     while ((2u << bin_shift) <= half) bin_shift++;
     while (((uint64_t)ncols >> bin_shift) + 1 > 8192) bin_shift++;
     const uint32_t nbins = (uint32_t)(((uint64_t)ncols >> bin_shift) + 1);
-    const hipError_t e = hipMemsetAsync(out2, 0, sizeof(unsigned long long) * 2 * kProbeBlocks, st);
-    if (e != hipSuccess) return e;
+    if (!out_zeroed) {
+        const hipError_t e = hipMemsetAsync(out2, 0, sizeof(unsigned long long) * 2 * kProbeBlocks, st);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(probe_kernel, dim3(blocks), dim3(256), sizeof(uint32_t) * (nbins + 1), st, rp, ci, (uint32_t)nrows, bin_shift, nbins, out2);
     return hipGetLastError();
 }

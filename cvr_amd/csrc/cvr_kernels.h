@@ -133,7 +133,7 @@ hipError_t launch_unpad(void *dense, const void *padded, const IterBounds &bd, i
 
 // rows sorted by column? how many non-zeros in the fullest two adjacent bins of `half` columns of every 256 rows?  out2[2 * kProbeBlocks] = {unsorted flag, count} per workgroup
 constexpr uint32_t kProbeBlocks = 1024;
-hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st);
+hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int64_t ncols, uint32_t half, unsigned long long *out2, hipStream_t st, bool out_zeroed = false);
 // per chunk: its smallest column into cbase[k]; *wide (device u32, zeroed by the caller) gets 1 if any chunk spans 32 767 columns or more
 hipError_t launch_chunk_span(const DeviceImage &img, const DeviceCsr &csr, uint32_t *cbase, uint32_t *wide, hipStream_t st);
 // min / max of col_idx[n0 .. n1) into minmax[0..1] (device; initialised by the caller to INT_MAX / INT_MIN)
