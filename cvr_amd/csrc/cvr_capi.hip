@@ -1034,6 +1034,11 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipMemsetAsync(h->d_small, 0, kSmallBytes, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_small + kSmallDictTab, 0xff, sizeof(unsigned long long) * 1024, h->stream));
     h->small_clean = true;
+    if (nrows >= device_plan_rows()) {     // the device planner's scratch, sized for chunks of 16 steps or more (it grows if the plan needs more)
+        const int64_t nnz0 = nrows ? csr->row_ptr[nrows] : 0, nb = nrows / cvr::kPlanRowBlock + 1;
+        const size_t  want = (size_t)nrows * 6 + (size_t)nb * 16 + (size_t)nrows / 256 + (size_t)(2 * ((nnz0 + nrows) / 1024) + 3 * nb) * 96 + 8192;
+        if (hipMalloc(&h->plan_ws.dev, want) == hipSuccess) h->plan_ws.dev_bytes = want; else (void)hipGetLastError();
+    }
     h->events.resize(2);
     CREATE_TRY(hipEventCreate(&h->events[0]));
     CREATE_TRY(hipEventCreate(&h->events[1]));
