@@ -495,6 +495,31 @@ static hipStream_t side_stream(int device)
     return streams[device];
 }
 
+// The handle's own stream comes from a small per-device pool: creating a stream takes 2-3 ms and destroying one about as long,
+// more than the whole analysis and conversion of a web-Google-sized matrix.  A stream goes back idle (cvr_destroy synchronises
+// it first); at most eight are kept per device.
+static std::mutex               g_pool_mu;
+static std::vector<hipStream_t> g_stream_pool[64];
+
+static hipError_t acquire_stream(int device, hipStream_t *out)
+{
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_stream_pool[device].empty()) { *out = g_stream_pool[device].back(); g_stream_pool[device].pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+static void release_stream(int device, hipStream_t s)
+{
+    if (!s) return;
+    if (device >= 0 && device < 64 && hipStreamSynchronize(s) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_stream_pool[device].size() < 8) { g_stream_pool[device].push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+
 constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24 << 10, kSmallBytes = 32 << 10;
 constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer
 
@@ -1026,7 +1051,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }                                                                                                   \
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
-    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(acquire_stream(h->device, &h->stream));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->plan_ws.pinned), h->plan_ws.pinned_bytes = nrows >= device_plan_rows() ? (size_t)704 << 10 : kPinnedSmall, hipHostMallocDefault));
     CREATE_TRY(hipMalloc(&h->d_small, kSmallBytes));
     // the small scratch starts out as its first users want it (probe output and flags zero, dictionary table all ones), and the
@@ -1409,7 +1434,7 @@ int cvr_destroy(cvr_handle *h)
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->z_free) (void)hipEventDestroy(h->z_free);
     for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    release_stream(h->device, h->stream);
     delete h;
     return CVR_OK;
 }
