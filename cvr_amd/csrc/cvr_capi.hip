@@ -353,9 +353,9 @@ static int pick_steps(int64_t nslots_est, int64_t max_row = 0)
     return S;
 }
 
-// plans one part on the host, allocates its device image and uploads its CSR (asynchronously on h->stream)
-// the host side of one image: chunk plan and the per-chunk tables derived from it.  No device call, no error text:
-// column panels plan their images on parallel threads.
+// the host side of one image: the chunk plan (from the host planner, or fetched from the device planner) and the per-chunk
+// tables derived from it.  With a host row_ptr there is no device call and no error text: the panels of a host split plan
+// their images on parallel threads.
 struct PartPlan {
     int                   S = 0;
     cvr::Plan             plan;
@@ -997,9 +997,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     if (opt.steps_per_chunk != 0 && (opt.steps_per_chunk < 4 || opt.steps_per_chunk % 4 || opt.steps_per_chunk > 4096))
         return fail(CVR_ERR_INVALID, "steps_per_chunk must be a multiple of 4 in [4, 4096]");
 
-    // CSR arrays already in device memory (of opt.device): the planner walks row_ptr on the host, so that array comes
-    // back (8 B per row); col_idx and vals stay where they are and are copied device to device; column panels are
-    // split on the device too (cvr_split.hip); the automatic panel rule fetches the eight sample windows of col_idx it looks at.
+    // CSR arrays already in device memory (of opt.device): row_ptr comes back once for the argument checks (8 B per row);
+    // col_idx and vals stay where they are and are copied device to device; the chunk plan (from 200 000 rows on), the panel
+    // rule and the panel split run on the device arrays (cvr_plan_dev.hip, cvr_split.hip).
     cvr_csr_view          hostv = *csr_in;
     const cvr_csr_view   *csr = &hostv;
     std::vector<int64_t>  rp_host;
