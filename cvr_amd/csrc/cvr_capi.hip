@@ -1692,8 +1692,7 @@ int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int i
             HIP_TRY(cvr::launch_unpad(s.dense, s.yall, bd, nparts, max_rows, f32, st));
             yfull = s.dense;
         }
-        HIP_TRY(cvr::launch_dot2(x_dev, yfull, n, f32, s.partial, s.cells, st));      // [0] = x . y, [1] = y . y, one pass
-        HIP_TRY(cvr::launch_scale(x_dev, yfull, s.cells + 1, n, f32, st));
+        HIP_TRY(cvr::launch_dot2_scale(x_dev, yfull, n, f32, s.partial, s.cells, st));      // cells[0] = x . y, [1] = y . y; x <- y / ||y||: two launches
     }
     HIP_TRY(hipEventRecord(s.e1, st));
     double cells[2] = {0, 0};

@@ -4,6 +4,8 @@
 // spmv.cpp:1024); this is the consumer a web-graph SpMV is built for.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "cvr_kernels.h"
 
 namespace cvr {
@@ -74,6 +76,30 @@ __global__ __launch_bounds__(256) void scale_kernel(T *__restrict__ x, const T *
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] = (T)((double)y[i] * inv);
 }
 
+// x[i] = y[i] / sqrt(y . y) with y . y (and x . y) summed from the partials of dot2_partial_kernel by every workgroup itself, in
+// dot_final_kernel's order (the same bits in every workgroup and in cells[]): one launch less per power-iteration step than
+// dot_final_kernel + scale_kernel.  Workgroup 0 also leaves cells[0] = x . y, cells[1] = y . y.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_from_partials_kernel(T *__restrict__ x, const T *__restrict__ y, const double *__restrict__ partial, int np,
+                                                                  double *__restrict__ cells, long long n)
+{
+    __shared__ double tot[2];
+    if (threadIdx.x < 128) {                               // wavefront 0: x . y, wavefront 1: y . y
+        const int     which = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const double *pp = partial + (size_t)which * np;
+        double        acc = 0;
+        for (int i = lane; i < np; i += 64) acc += pp[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) tot[which] = acc;
+    }
+    __syncthreads();
+    const double nn = tot[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cells[0] = tot[0]; cells[1] = nn; }
+    const double inv = nn > 0 ? 1.0 / sqrt(nn) : 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] = (T)((double)y[i] * inv);
+}
+
 // dense[bounds[p] + i] = padded[p * max_rows + i]: the rows of an equal-count all-gather back in row order
 template <typename T>
 __global__ __launch_bounds__(256) void unpad_kernel(T *__restrict__ dense, const T *__restrict__ padded, IterBounds bd, long long max_rows)
@@ -100,6 +126,17 @@ hipError_t launch_dot2(const void *x, const void *y, int64_t n, bool f32, double
     if (f32) hipLaunchKernelGGL(dot2_partial_kernel<float>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const float *>(x), static_cast<const float *>(y), (long long)n, partial);
     else hipLaunchKernelGGL(dot2_partial_kernel<double>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const double *>(x), static_cast<const double *>(y), (long long)n, partial);
     hipLaunchKernelGGL(dot_final_kernel, dim3(2), dim3(64), 0, st, partial, kDotBlocks, out2);
+    return hipGetLastError();
+}
+
+// one power-iteration step's reductions and normalisation in two launches: cells[0] = x . y, cells[1] = y . y, x <- y / ||y||
+hipError_t launch_dot2_scale(void *x, const void *y, int64_t n, bool f32, double *partial, double *cells, hipStream_t st)
+{
+    if (f32) hipLaunchKernelGGL(dot2_partial_kernel<float>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const float *>(x), static_cast<const float *>(y), (long long)n, partial);
+    else hipLaunchKernelGGL(dot2_partial_kernel<double>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const double *>(x), static_cast<const double *>(y), (long long)n, partial);
+    const uint32_t blocks = (uint32_t)std::min<int64_t>(1024, (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
+    if (f32) hipLaunchKernelGGL(scale_from_partials_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<float *>(x), static_cast<const float *>(y), partial, kDotBlocks, cells, (long long)n);
+    else hipLaunchKernelGGL(scale_from_partials_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<double *>(x), static_cast<const double *>(y), partial, kDotBlocks, cells, (long long)n);
     return hipGetLastError();
 }
 
