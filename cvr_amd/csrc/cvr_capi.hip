@@ -1674,9 +1674,10 @@ int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int i
         HIP_TRY(hipMalloc(&s.yall, h->vsz * std::max<size_t>((size_t)nparts * (size_t)max_rows, 1)));
         HIP_TRY(hipMalloc(&s.dense, h->vsz * std::max<size_t>((size_t)n, 1)));
     }
-    HIP_TRY(hipMalloc(&s.partial, sizeof(double) * (size_t)cvr::dot_partials()));
-    HIP_TRY(hipMalloc(&s.cells, sizeof(double) * 2));            // [0] = x . y (Rayleigh quotient), [1] = y . y
-    HIP_TRY(hipMemsetAsync(s.cells, 0, sizeof(double) * 2, st));
+    const size_t npart = (size_t)std::max(cvr::dot_partials(), cvr::power_partials());
+    HIP_TRY(hipMalloc(&s.partial, sizeof(double) * 2 * npart));      // two steps' partial sums, used in turn
+    HIP_TRY(hipMalloc(&s.cells, sizeof(double) * 3));            // [0] = x . y, [1] = y . y, [2] = x . x of the last step
+    HIP_TRY(hipMemsetAsync(s.cells, 0, sizeof(double) * 3, st));
     HIP_TRY(hipEventCreate(&s.e0));
     HIP_TRY(hipEventCreate(&s.e1));
 
@@ -1692,15 +1693,20 @@ int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int i
             HIP_TRY(cvr::launch_unpad(s.dense, s.yall, bd, nparts, max_rows, f32, st));
             yfull = s.dense;
         }
-        HIP_TRY(cvr::launch_dot2_scale(x_dev, yfull, n, f32, s.partial, s.cells, st));      // cells[0] = x . y, [1] = y . y; x <- y / ||y||: two launches
+        // the step's three dot products and x <- y / ||y of the step before|| in one pass (cvr_iter.hip: power_step_kernel)
+        HIP_TRY(cvr::launch_power_step(x_dev, yfull, n, f32, it > 0 ? s.partial + (size_t)((it - 1) & 1) * npart : nullptr, s.partial + (size_t)(it & 1) * npart, st));
+        if (it + 1 == iters) {       // the last iterate leaves normalised exactly: x <- y / ||y||
+            HIP_TRY(cvr::launch_power_sums(s.partial + (size_t)(it & 1) * npart, s.cells, st));
+            HIP_TRY(cvr::launch_scale(x_dev, yfull, s.cells + 1, n, f32, st));
+        }
     }
     HIP_TRY(hipEventRecord(s.e1, st));
-    double cells[2] = {0, 0};
+    double cells[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(cells, s.cells, sizeof(cells), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s.e0, s.e1));
-    if (lambda) *lambda = iters > 0 ? cells[0] : 0.0;
+    if (lambda) *lambda = iters > 0 && cells[2] > 0 ? cells[0] / cells[2] : 0.0;      // Rayleigh quotient of the last step's x
     if (seconds_per_iter) *seconds_per_iter = iters > 0 ? (double)ms * 1e-3 / iters : 0.0;
     return CVR_OK;
 }

@@ -100,6 +100,47 @@ __global__ __launch_bounds__(256) void scale_from_partials_kernel(T *__restrict_
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] = (T)((double)y[i] * inv);
 }
 
+// One power-iteration step's vector work in ONE pass over x and y = A x: the partial sums of x . y, y . y and x . x of this step, and
+// x <- y * inv with inv = 1 / ||y of the step before|| (each workgroup sums that step's partials itself, in dot_final_kernel's
+// order; the first step has none: inv = 1).  Normalising with the norm of the step before keeps ||x|| between 1/lambda and
+// lambda (a cycle of six steps) without waiting for this step's reduction; the Rayleigh quotient x . y / x . x does not
+// depend on the scale, and cvr_power_iteration normalises the last iterate exactly.
+template <typename T>
+__global__ __launch_bounds__(kDotThreads) void power_step_kernel(T *__restrict__ x, const T *__restrict__ y, long long n,
+                                                                 const double *__restrict__ prev, double *__restrict__ out)
+{
+    __shared__ double wsum[3][kDotThreads / 64];
+    __shared__ double pyy;
+    if (prev && threadIdx.x < 64) {
+        double acc = 0;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) acc += prev[(size_t)gridDim.x + i];      // the y . y partials of the step before
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (threadIdx.x == 0) pyy = acc;
+    }
+    __syncthreads();
+    const double inv = prev ? (pyy > 0 ? 1.0 / sqrt(pyy) : 0.0) : 1.0;
+    double axy = 0, ayy = 0, axx = 0;
+    for (long long i = (long long)blockIdx.x * kDotThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kDotThreads) {
+        const double xv = (double)x[i], yv = (double)y[i];
+        axy += xv * yv;
+        ayy += yv * yv;
+        axx += xv * xv;
+        x[i] = (T)(yv * inv);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { axy += __shfl_xor(axy, o); ayy += __shfl_xor(ayy, o); axx += __shfl_xor(axx, o); }
+    if ((threadIdx.x & 63u) == 0) { wsum[0][threadIdx.x >> 6] = axy; wsum[1][threadIdx.x >> 6] = ayy; wsum[2][threadIdx.x >> 6] = axx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int w = 0; w < kDotThreads / 64; w++) { s0 += wsum[0][w]; s1 += wsum[1][w]; s2 += wsum[2][w]; }
+        out[blockIdx.x] = s0;
+        out[gridDim.x + blockIdx.x] = s1;
+        out[2 * gridDim.x + blockIdx.x] = s2;
+    }
+}
+
 // dense[bounds[p] + i] = padded[p * max_rows + i]: the rows of an equal-count all-gather back in row order
 template <typename T>
 __global__ __launch_bounds__(256) void unpad_kernel(T *__restrict__ dense, const T *__restrict__ padded, IterBounds bd, long long max_rows)
@@ -112,6 +153,21 @@ __global__ __launch_bounds__(256) void unpad_kernel(T *__restrict__ dense, const
 }  // namespace
 
 int dot_partials() { return 2 * kDotBlocks; }
+int power_partials() { return 3 * kDotBlocks; }        // one step's partial sums (x . y, y . y, x . x)
+
+hipError_t launch_power_step(void *x, const void *y, int64_t n, bool f32, const double *prev, double *out, hipStream_t st)
+{
+    if (f32) hipLaunchKernelGGL(power_step_kernel<float>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<float *>(x), static_cast<const float *>(y), (long long)n, prev, out);
+    else hipLaunchKernelGGL(power_step_kernel<double>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<double *>(x), static_cast<const double *>(y), (long long)n, prev, out);
+    return hipGetLastError();
+}
+
+// cells[0 .. 2] = the sums of a step's three sets of partials
+hipError_t launch_power_sums(const double *partial, double *cells, hipStream_t st)
+{
+    hipLaunchKernelGGL(dot_final_kernel, dim3(3), dim3(64), 0, st, partial, kDotBlocks, cells);
+    return hipGetLastError();
+}
 
 hipError_t launch_dot(const void *a, const void *b, int64_t n, bool f32, double *partial, double *out, hipStream_t st)
 {

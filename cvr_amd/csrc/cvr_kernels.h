@@ -127,6 +127,9 @@ hipError_t launch_dot(const void *a, const void *b, int64_t n, bool f32, double 
 // out2[0] = x . y, out2[1] = y . y in one pass (the two reductions of a power-iteration step)
 hipError_t launch_dot2(const void *x, const void *y, int64_t n, bool f32, double *partial, double *out2, hipStream_t st);
 // x[i] = y[i] / sqrt(norm2[0])
+int        power_partials();
+hipError_t launch_power_step(void *x, const void *y, int64_t n, bool f32, const double *prev, double *out, hipStream_t st);
+hipError_t launch_power_sums(const double *partial, double *cells, hipStream_t st);
 hipError_t launch_dot2_scale(void *x, const void *y, int64_t n, bool f32, double *partial, double *cells, hipStream_t st);
 hipError_t launch_scale(void *x, const void *y, const double *norm2, int64_t n, bool f32, hipStream_t st);
 // dense[bd.b[p] + i] = padded[p * max_rows + i], i < bd.b[p+1] - bd.b[p]

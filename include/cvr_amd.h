@@ -219,7 +219,9 @@ int cvr_spmv_gather_repeat(cvr_handle *h, cvr_comm *comm, const void *x_dev, voi
 /* The iterative caller (power iteration): x <- A x / ||A x||, `iters` times, everything on the device and on `stream`
  * with no host round trip inside the loop; dot products use a fixed reduction tree, so results are bitwise reproducible.
  * x_dev: info.x_elems values, in: the start vector (any non-zero), out: the normalised iterate; x_dev[ncols] stays 0.
- * *lambda = x_k . (A x_k) of the last iteration (Rayleigh quotient).  comm = NULL: one GPU, the handle holds the whole
+ * *lambda = x_k . (A x_k) / x_k . x_k of the last iteration (Rayleigh quotient).  Inside the loop a step's dot products and
+ * the scaling of the next x are one pass over the vectors: x is scaled by the norm of the step before (||x|| stays between
+ * 1/lambda and lambda), the last iterate is normalised exactly.  comm = NULL: one GPU, the handle holds the whole
  * square matrix.  comm != NULL: the handle holds this rank's row block of a square matrix of ncols rows, bounds[nranks+1]
  * are the row offsets of all blocks, and every iteration all-gathers y over RCCL and rebuilds the replicated x from
  * it -- the one setting where the exchange step is on the critical path.  Synchronises `stream` before returning.
