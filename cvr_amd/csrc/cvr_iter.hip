@@ -33,30 +33,6 @@ __global__ __launch_bounds__(kDotThreads) void dot_partial_kernel(const T *__res
     }
 }
 
-// both reductions of a power-iteration step in one pass over x and y: partial[b] = x . y, partial[gridDim.x + b] = y . y
-template <typename T>
-__global__ __launch_bounds__(kDotThreads) void dot2_partial_kernel(const T *__restrict__ x, const T *__restrict__ y, long long n,
-                                                                   double *__restrict__ partial)
-{
-    __shared__ double wsum[2][kDotThreads / 64];
-    double axy = 0, ayy = 0;
-    for (long long i = (long long)blockIdx.x * kDotThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kDotThreads) {
-        const double yv = (double)y[i];
-        axy += (double)x[i] * yv;
-        ayy += yv * yv;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { axy += __shfl_xor(axy, o); ayy += __shfl_xor(ayy, o); }
-    if ((threadIdx.x & 63u) == 0) { wsum[0][threadIdx.x >> 6] = axy; wsum[1][threadIdx.x >> 6] = ayy; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s0 = 0, s1 = 0;
-        for (int w = 0; w < kDotThreads / 64; w++) { s0 += wsum[0][w]; s1 += wsum[1][w]; }
-        partial[blockIdx.x] = s0;
-        partial[gridDim.x + blockIdx.x] = s1;
-    }
-}
-
 // out[0] = sum of the partials, one wavefront, fixed order
 __global__ __launch_bounds__(64) void dot_final_kernel(const double *__restrict__ partial, int n, double *__restrict__ out)
 {
@@ -76,33 +52,9 @@ __global__ __launch_bounds__(256) void scale_kernel(T *__restrict__ x, const T *
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] = (T)((double)y[i] * inv);
 }
 
-// x[i] = y[i] / sqrt(y . y) with y . y (and x . y) summed from the partials of dot2_partial_kernel by every workgroup itself, in
-// dot_final_kernel's order (the same bits in every workgroup and in cells[]): one launch less per power-iteration step than
-// dot_final_kernel + scale_kernel.  Workgroup 0 also leaves cells[0] = x . y, cells[1] = y . y.
-template <typename T>
-__global__ __launch_bounds__(256) void scale_from_partials_kernel(T *__restrict__ x, const T *__restrict__ y, const double *__restrict__ partial, int np,
-                                                                  double *__restrict__ cells, long long n)
-{
-    __shared__ double tot[2];
-    if (threadIdx.x < 128) {                               // wavefront 0: x . y, wavefront 1: y . y
-        const int     which = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const double *pp = partial + (size_t)which * np;
-        double        acc = 0;
-        for (int i = lane; i < np; i += 64) acc += pp[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) tot[which] = acc;
-    }
-    __syncthreads();
-    const double nn = tot[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { cells[0] = tot[0]; cells[1] = nn; }
-    const double inv = nn > 0 ? 1.0 / sqrt(nn) : 0.0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] = (T)((double)y[i] * inv);
-}
-
 // One power-iteration step's vector work in ONE pass over x and y = A x: the partial sums of x . y, y . y and x . x of this step, and
 // x <- y * inv with inv = 1 / ||y of the step before|| (each workgroup sums that step's partials itself, in dot_final_kernel's
-// order; the first step has none: inv = 1).  Normalising with the norm of the step before keeps ||x|| between 1/lambda and
+// order: the same bits in every workgroup; the first step has none: inv = 1).  Normalising with the norm of the step before keeps ||x|| between 1/lambda and
 // lambda (a cycle of six steps) without waiting for this step's reduction; the Rayleigh quotient x . y / x . x does not
 // depend on the scale, and cvr_power_iteration normalises the last iterate exactly.
 template <typename T>
@@ -174,25 +126,6 @@ hipError_t launch_dot(const void *a, const void *b, int64_t n, bool f32, double 
     if (f32) hipLaunchKernelGGL(dot_partial_kernel<float>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const float *>(a), static_cast<const float *>(b), (long long)n, partial);
     else hipLaunchKernelGGL(dot_partial_kernel<double>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const double *>(a), static_cast<const double *>(b), (long long)n, partial);
     hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(64), 0, st, partial, kDotBlocks, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_dot2(const void *x, const void *y, int64_t n, bool f32, double *partial, double *out2, hipStream_t st)
-{
-    if (f32) hipLaunchKernelGGL(dot2_partial_kernel<float>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const float *>(x), static_cast<const float *>(y), (long long)n, partial);
-    else hipLaunchKernelGGL(dot2_partial_kernel<double>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const double *>(x), static_cast<const double *>(y), (long long)n, partial);
-    hipLaunchKernelGGL(dot_final_kernel, dim3(2), dim3(64), 0, st, partial, kDotBlocks, out2);
-    return hipGetLastError();
-}
-
-// one power-iteration step's reductions and normalisation in two launches: cells[0] = x . y, cells[1] = y . y, x <- y / ||y||
-hipError_t launch_dot2_scale(void *x, const void *y, int64_t n, bool f32, double *partial, double *cells, hipStream_t st)
-{
-    if (f32) hipLaunchKernelGGL(dot2_partial_kernel<float>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const float *>(x), static_cast<const float *>(y), (long long)n, partial);
-    else hipLaunchKernelGGL(dot2_partial_kernel<double>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<const double *>(x), static_cast<const double *>(y), (long long)n, partial);
-    const uint32_t blocks = (uint32_t)std::min<int64_t>(1024, (n + 255) / 256 > 0 ? (n + 255) / 256 : 1);
-    if (f32) hipLaunchKernelGGL(scale_from_partials_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<float *>(x), static_cast<const float *>(y), partial, kDotBlocks, cells, (long long)n);
-    else hipLaunchKernelGGL(scale_from_partials_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<double *>(x), static_cast<const double *>(y), partial, kDotBlocks, cells, (long long)n);
     return hipGetLastError();
 }
 

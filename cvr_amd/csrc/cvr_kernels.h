@@ -124,13 +124,13 @@ struct IterBounds { long long b[kIterMaxParts + 1]; };   // row offsets of the s
 int        dot_partials();                                // doubles of scratch launch_dot needs
 // out[0] = sum a[i] * b[i] (fp64 accumulation, fixed tree: bitwise reproducible); asynchronous
 hipError_t launch_dot(const void *a, const void *b, int64_t n, bool f32, double *partial, double *out, hipStream_t st);
-// out2[0] = x . y, out2[1] = y . y in one pass (the two reductions of a power-iteration step)
-hipError_t launch_dot2(const void *x, const void *y, int64_t n, bool f32, double *partial, double *out2, hipStream_t st);
-// x[i] = y[i] / sqrt(norm2[0])
-int        power_partials();
+// one power-iteration step in one pass over x and y = A x: out[3 * kDotBlocks] = partial sums of x . y, y . y, x . x;
+// x <- y / sqrt(sum of prev's y . y partials) (prev = the step before's `out`; null: x <- y)
+int        power_partials();                              // doubles of one step's `out`
 hipError_t launch_power_step(void *x, const void *y, int64_t n, bool f32, const double *prev, double *out, hipStream_t st);
+// cells[0 .. 2] = the three sums of a step's partials
 hipError_t launch_power_sums(const double *partial, double *cells, hipStream_t st);
-hipError_t launch_dot2_scale(void *x, const void *y, int64_t n, bool f32, double *partial, double *cells, hipStream_t st);
+// x[i] = y[i] / sqrt(norm2[0])
 hipError_t launch_scale(void *x, const void *y, const double *norm2, int64_t n, bool f32, hipStream_t st);
 // dense[bd.b[p] + i] = padded[p * max_rows + i], i < bd.b[p+1] - bd.b[p]
 hipError_t launch_unpad(void *dense, const void *padded, const IterBounds &bd, int nparts, int64_t max_rows, bool f32, hipStream_t st);
