@@ -1687,15 +1687,15 @@ int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int i
     HIP_TRY(hipEventRecord(s.e0, st));
     for (int it = 0; it < iters; it++) {
         HIP_TRY(run_spmv(h, x_dev, s.y, st));
-        const void *yfull = s.y;
-        if (c) {            // the exchange step is on the critical path here: x of the next iteration is the gathered y
-            RCCL_TRY(api, api->all_gather(s.y, s.yall, (size_t)max_rows, f32 ? ncclFloat : ncclDouble, c->comm, st));
-            HIP_TRY(cvr::launch_unpad(s.dense, s.yall, bd, nparts, max_rows, f32, st));
-            yfull = s.dense;
-        }
+        // the exchange step is on the critical path here: x of the next iteration is the gathered y (read through the shards'
+        // bounds as it lies, padded)
+        if (c) RCCL_TRY(api, api->all_gather(s.y, s.yall, (size_t)max_rows, f32 ? ncclFloat : ncclDouble, c->comm, st));
         // the step's three dot products and x <- y / ||y of the step before|| in one pass (cvr_iter.hip: power_step_kernel)
-        HIP_TRY(cvr::launch_power_step(x_dev, yfull, n, f32, it > 0 ? s.partial + (size_t)((it - 1) & 1) * npart : nullptr, s.partial + (size_t)(it & 1) * npart, st));
+        HIP_TRY(cvr::launch_power_step(x_dev, c ? s.yall : s.y, n, f32, it > 0 ? s.partial + (size_t)((it - 1) & 1) * npart : nullptr,
+                                       s.partial + (size_t)(it & 1) * npart, st, c ? &bd : nullptr, nparts, max_rows));
         if (it + 1 == iters) {       // the last iterate leaves normalised exactly: x <- y / ||y||
+            const void *yfull = s.y;
+            if (c) { HIP_TRY(cvr::launch_unpad(s.dense, s.yall, bd, nparts, max_rows, f32, st)); yfull = s.dense; }
             HIP_TRY(cvr::launch_power_sums(s.partial + (size_t)(it & 1) * npart, s.cells, st));
             HIP_TRY(cvr::launch_scale(x_dev, yfull, s.cells + 1, n, f32, st));
         }

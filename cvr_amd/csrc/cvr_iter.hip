@@ -57,9 +57,12 @@ __global__ __launch_bounds__(256) void scale_kernel(T *__restrict__ x, const T *
 // order: the same bits in every workgroup; the first step has none: inv = 1).  Normalising with the norm of the step before keeps ||x|| between 1/lambda and
 // lambda (a cycle of six steps) without waiting for this step's reduction; the Rayleigh quotient x . y / x . x does not
 // depend on the scale, and cvr_power_iteration normalises the last iterate exactly.
-template <typename T>
+// PADDED: y is the all-gathered vector of equal-count slices (shard p's rows at y[p * max_rows ...]); the element order of the sums is
+// the dense form's, so the sharded loop gives the same bits as the one-GPU loop without an un-padding pass per step.
+template <typename T, bool PADDED>
 __global__ __launch_bounds__(kDotThreads) void power_step_kernel(T *__restrict__ x, const T *__restrict__ y, long long n,
-                                                                 const double *__restrict__ prev, double *__restrict__ out)
+                                                                 const double *__restrict__ prev, double *__restrict__ out, IterBounds bd, int nparts,
+                                                                 long long max_rows)
 {
     __shared__ double wsum[3][kDotThreads / 64];
     __shared__ double pyy;
@@ -74,7 +77,13 @@ __global__ __launch_bounds__(kDotThreads) void power_step_kernel(T *__restrict__
     const double inv = prev ? (pyy > 0 ? 1.0 / sqrt(pyy) : 0.0) : 1.0;
     double axy = 0, ayy = 0, axx = 0;
     for (long long i = (long long)blockIdx.x * kDotThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kDotThreads) {
-        const double xv = (double)x[i], yv = (double)y[i];
+        long long j = i;
+        if constexpr (PADDED) {
+            int lo = 0, hi = nparts - 1;                   // the shard of row i: last p with b[p] <= i
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (bd.b[mid] <= i) lo = mid; else hi = mid - 1; }
+            j = (long long)lo * max_rows + (i - bd.b[lo]);
+        }
+        const double xv = (double)x[i], yv = (double)y[j];
         axy += xv * yv;
         ayy += yv * yv;
         axx += xv * xv;
@@ -107,10 +116,15 @@ __global__ __launch_bounds__(256) void unpad_kernel(T *__restrict__ dense, const
 int dot_partials() { return 2 * kDotBlocks; }
 int power_partials() { return 3 * kDotBlocks; }        // one step's partial sums (x . y, y . y, x . x)
 
-hipError_t launch_power_step(void *x, const void *y, int64_t n, bool f32, const double *prev, double *out, hipStream_t st)
+hipError_t launch_power_step(void *x, const void *y, int64_t n, bool f32, const double *prev, double *out, hipStream_t st, const IterBounds *padded,
+                             int nparts, int64_t max_rows)
 {
-    if (f32) hipLaunchKernelGGL(power_step_kernel<float>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<float *>(x), static_cast<const float *>(y), (long long)n, prev, out);
-    else hipLaunchKernelGGL(power_step_kernel<double>, dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<double *>(x), static_cast<const double *>(y), (long long)n, prev, out);
+    const IterBounds none{};
+#define CVR_STEP(T, P) hipLaunchKernelGGL((power_step_kernel<T, P>), dim3(kDotBlocks), dim3(kDotThreads), 0, st, static_cast<T *>(x), static_cast<const T *>(y), \
+                                          (long long)n, prev, out, padded ? *padded : none, nparts, (long long)max_rows)
+    if (f32) { if (padded) CVR_STEP(float, true); else CVR_STEP(float, false); }
+    else     { if (padded) CVR_STEP(double, true); else CVR_STEP(double, false); }
+#undef CVR_STEP
     return hipGetLastError();
 }
 

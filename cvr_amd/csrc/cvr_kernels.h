@@ -127,7 +127,9 @@ hipError_t launch_dot(const void *a, const void *b, int64_t n, bool f32, double 
 // one power-iteration step in one pass over x and y = A x: out[3 * kDotBlocks] = partial sums of x . y, y . y, x . x;
 // x <- y / sqrt(sum of prev's y . y partials) (prev = the step before's `out`; null: x <- y)
 int        power_partials();                              // doubles of one step's `out`
-hipError_t launch_power_step(void *x, const void *y, int64_t n, bool f32, const double *prev, double *out, hipStream_t st);
+// (padded != null: y is the all-gathered vector of nparts slices of max_rows entries, read in row order through the bounds)
+hipError_t launch_power_step(void *x, const void *y, int64_t n, bool f32, const double *prev, double *out, hipStream_t st, const IterBounds *padded = nullptr,
+                             int nparts = 1, int64_t max_rows = 0);
 // cells[0 .. 2] = the three sums of a step's partials
 hipError_t launch_power_sums(const double *partial, double *cells, hipStream_t st);
 // x[i] = y[i] / sqrt(norm2[0])

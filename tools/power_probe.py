@@ -14,4 +14,4 @@ print("one GPU: lambda %.12g, %.2f us per iteration (SpMV alone %.2f us)" % (lam
 comm = cvr_amd.Comm(cvr_amd.comm_unique_id(), 1, 0, 0)
 power.power_iteration(A, nrows, bounds=[0, nrows], comm=comm, iters=20)
 lam2, x2, sec2 = power.power_iteration(A, nrows, bounds=[0, nrows], comm=comm, iters=200)
-print("sharded form, 1 rank (all-gather + un-padding every iteration): lambda %.12g, %.2f us per iteration; same bits: %s" % (lam2, sec2 * 1e6, bool(torch.equal(x.view(torch.int64), x2.view(torch.int64)))))
+print("sharded form, 1 rank (all-gather every iteration, the gathered y read in place): lambda %.12g, %.2f us per iteration; same bits: %s" % (lam2, sec2 * 1e6, bool(torch.equal(x.view(torch.int64), x2.view(torch.int64)))))
