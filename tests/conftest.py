@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+try:                   # PyTorch (used by a few GPU tests for device arrays and torch.distributed) brings its own copy of the HIP
+    import torch       # runtime; the copy initialised second in a process finds no GPU, so it is loaded before libcvr_amd.so
+except Exception:      # noqa: BLE001 -- those tests skip themselves without it
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -4,6 +4,11 @@ row-length distributions, with and without a row cap, across row-block restarts.
 import numpy as np
 import pytest
 
+try:                   # before the first call into libcvr_amd: PyTorch brings its own copy of the HIP runtime, and whichever copy
+    import torch       # is initialised second in a process finds no GPU
+except Exception:      # noqa: BLE001 -- the device-array case is skipped without torch
+    torch = None
+
 import cvr_amd
 
 pytestmark = pytest.mark.gpu
@@ -89,9 +94,31 @@ def test_panel_rule_on_the_device_equals_the_host_rule():
     assert P_host == 1
     P_host, _ = capi.auto_panels(n, n, rp, scattered)
     assert P_host > 4
-    import torch
+    if torch is None:
+        return
     keep = [torch.from_numpy(a).cuda() for a in (rp, scattered, va)]
     torch.cuda.synchronize()
     A = cvr_amd.CvrMatrix.from_device(n, n, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr())
     assert A.info.col_panels == P_host
+    A.close()
+
+
+def test_large_chunks_fall_back_to_the_host_planner():
+    """chunks of 64 x 512 slots do not fit the device planner's 15-bit jumps: cvr_create (250 000 rows: the device planner's
+    territory) fetches the row pointers and plans on the host; y still equals the CSR oracle's"""
+    import oraclelib as O
+    rng = np.random.default_rng(11)
+    n = 250_000
+    lens = rng.integers(0, 7, n)
+    lens[rng.integers(0, n, 20)] = rng.integers(20_000, 60_000, 20)          # rows cut over several such chunks
+    rp = _rp(lens)
+    ci = rng.integers(0, n, int(rp[-1])).astype(np.int32)
+    va = ((np.arange(len(ci)) % 11) - 4.0).astype(np.float64)
+    A = cvr_amd.CvrMatrix(n, n, rp, ci, va, steps_per_chunk=512)
+    assert A.info.steps_per_chunk == 512
+    x = O.x_vec_fast(n, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    y, _ = A.spmv(x)
+    bad, worst = O.tol_check(y, yref, absy + 1e-30)
+    assert len(bad) == 0, worst
     A.close()
