@@ -1359,19 +1359,18 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     Part &p0 = h->parts[0];
     const bool phased = !h->paneled() && p0.img.phases > 1 && p0.nchunks > 0;
     if (phased) {
-        // column phases: the segment table (conversion-time only) is allocated for the most segments there can be -- one per
-        // slot, or one per (row, phase) pair plus the pad segments -- so that counting, scanning, filling and converting run
-        // back to back on the device without the host in between
+        // column phases: the segment table (conversion-time only) gives every chunk room for as many segments as it has slots, so
+        // that counting and filling are one kernel per chunk and the conversion follows without the host in between
         cvr::SegTable &t = sg.t;
-        const size_t ub = (size_t)std::min<int64_t>(p0.nchunks * 64 * (int64_t)p0.img.S, (p0.nrows + 2 * p0.nchunks) * (int64_t)p0.img.phases + p0.nchunks);
+        const size_t cap = (size_t)cvr::kLanes * (size_t)p0.img.S, n1 = std::max<size_t>((size_t)p0.nchunks * cap, 1);
+        if (n1 >= ((size_t)1 << 32)) return fail(CVR_ERR_INVALID, "col_phases: more than 2^32 slots in one image");
         auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-        const size_t n1 = std::max<size_t>(ub, 1);
         const size_t o_begin = 0, o_len = o_begin + up(sizeof(int64_t) * n1), o_row = o_len + up(sizeof(uint32_t) * n1), o_cnt = o_row + up(sizeof(uint16_t) * n1),
-                     o_pcnt = o_cnt + up(sizeof(uint32_t) * ((size_t)p0.nchunks + 1)), o_flags = o_pcnt + up(sizeof(uint32_t) * (size_t)p0.nchunks * p0.img.phases);
+                     o_flags = o_cnt + up(sizeof(uint32_t) * ((size_t)p0.nchunks + 1));
         HIP_TRY(hipMalloc(&sg.arena, o_flags + 256));
         uint8_t *a = static_cast<uint8_t *>(sg.arena);
         t.begin = reinterpret_cast<int64_t *>(a + o_begin); t.len = reinterpret_cast<uint32_t *>(a + o_len); t.row = reinterpret_cast<uint16_t *>(a + o_row);
-        t.cnt = reinterpret_cast<uint32_t *>(a + o_cnt); t.pcnt = reinterpret_cast<uint32_t *>(a + o_pcnt); t.flags = reinterpret_cast<uint32_t *>(a + o_flags);
+        t.cnt = reinterpret_cast<uint32_t *>(a + o_cnt); t.flags = reinterpret_cast<uint32_t *>(a + o_flags);
         HIP_TRY(hipMemsetAsync(t.flags, 0, sizeof(uint32_t) * 2, h->stream));
     }
     // the window choice needs nothing of the conversion (and nothing is pending on the handle's stream: cvr_create ended with a
@@ -1386,9 +1385,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
         if (wstream != h->stream) HIP_TRY(cvr::launch_window(p.img, csr, wstream));
         if (phased) {
             cvr::SegTable &t = sg.t;
-            HIP_TRY(cvr::launch_seg_count(p.img, csr, t, h->stream));
-            HIP_TRY(cvr::launch_seg_scan(p.img, t, h->stream));
-            HIP_TRY(cvr::launch_seg_fill(p.img, csr, t, h->stream));
+            HIP_TRY(cvr::launch_seg_build(p.img, csr, t, h->stream));
             HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream, &t));
             HIP_TRY(hipMemcpyAsync(seg_flags, t.flags, sizeof(seg_flags), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipMemcpyAsync(&seg_total, t.cnt + p.nchunks, sizeof(seg_total), hipMemcpyDeviceToHost, h->stream));

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t dict_code(const typename Bits<T>::type *dict
     return lo;
 }
 
-// SEGT: the chunk's segments come from a table (column phases: one segment per (row, phase) pair, launch_seg_fill) instead
+// SEGT: the chunk's segments come from a table (column phases: one segment per (row, phase) pair, launch_seg_build) instead
 // of being the chunk's rows in order.
 // STAGE: the wavefront first copies its chunk's feed table -- the (begin, length, row) of its segments, or its clamped row
 // pointers -- into LDS with coalesced loads.  The hand-out of a new segment then costs an LDS read instead of a global load that
@@ -318,27 +318,39 @@ __device__ __forceinline__ SegStage seg_stage(uint8_t *smem, const int64_t *rp, 
     return st;
 }
 
-// pass 1: per chunk, the number of segments of every phase (pcnt[k][p], turned into offsets inside the chunk) and their sum
-__global__ __launch_bounds__(256) void seg_count_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
-                                                        const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
-                                                        uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, uint32_t nchunks,
-                                                        uint32_t pw, uint32_t phases, uint32_t *__restrict__ cnt, uint32_t *__restrict__ pcnt,
-                                                        uint32_t *__restrict__ flags)
+// first position in cols[a, z) whose column is >= bound (columns ascending)
+__device__ __forceinline__ uint32_t lower_col(const int32_t *cols, uint32_t a, uint32_t z, uint64_t bound)
+{
+    while (a < z) {
+        const uint32_t mid = (a + z) >> 1;
+        if ((uint64_t)(uint32_t)cols[mid] < bound) a = mid + 1; else z = mid;
+    }
+    return a;
+}
+
+// The segment table of one chunk, one workgroup (8 wavefronts): (1) the number of segments of every phase, one thread per element
+// (an element starts a segment if it starts its row's piece or lies in another phase than its predecessor; row starts are
+// flagged in LDS behind the columns), turned into offsets inside the chunk; (2) wavefront w writes the segments of phases w,
+// w + 8, ...: rows in order, ballot compaction.  The chunk's segments start at k * 64 S of the table (a chunk has at most 64 S),
+// so no pass over all chunks is needed between counting and filling, and the chunk's columns and row pieces are staged once.
+__global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
+                                                          const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
+                                                          uint4 *__restrict__ desc, uint2 *__restrict__ desc2, uint32_t nchunks,
+                                                          uint32_t pw, uint32_t phases, uint32_t cap, uint32_t *__restrict__ cnt, int64_t *__restrict__ seg_begin,
+                                                          uint32_t *__restrict__ seg_len, uint16_t *__restrict__ seg_row, uint32_t *__restrict__ flags)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ uint32_t pc[64], sbad;
-    const uint32_t k = blockIdx.x;
+    __shared__ uint32_t pc[64], poff[64], sbad, stotal;
+    const uint32_t k = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     if (k >= nchunks) return;
     const int64_t  b = nzb[k], e = nzb[k + 1];
-    const uint32_t row_first = desc[k].x, nri = desc2[k].y;
+    const uint32_t row_first = desc[k].x, nri = desc2[k].y, sbase = k * cap;
     if (threadIdx.x < 64) pc[threadIdx.x] = 0;
     if (threadIdx.x == 0) sbad = 0;
     const SegStage st = seg_stage(smem, rp, cidx, b, e, row_first, nri);
     uint32_t       bad = 0;
     const uint32_t n = (uint32_t)(e - b);
     if (n <= kSegLdsCols) {
-        // one thread per element (a long row would otherwise be walked by a single thread): an element starts a segment if it
-        // starts its row's piece or lies in another phase than its predecessor; row starts are flagged in LDS behind the columns
         uint8_t *rstart = smem + 8 * (size_t)nri + 4 * (size_t)n;
         for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) rstart[j] = 0;
         __syncthreads();
@@ -374,43 +386,22 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const int64_t *__restric
     }
     if (bad) sbad = 1;
     __syncthreads();
+    const uint32_t padc = pad_cnt[k];
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (uint32_t p = 0; p < phases; p++) { const uint32_t c = pc[p]; pcnt[(size_t)k * phases + p] = run; run += c; }
-        run += pad_cnt[k] > 0 ? 1u : 0u;
+        for (uint32_t p = 0; p < phases; p++) { const uint32_t c = pc[p]; poff[p] = run; run += c; }
+        run += padc > 0 ? 1u : 0u;
+        stotal = run;
         cnt[k] = run;
         desc[k].y = run;
+        desc2[k].x = sbase;
         if (sbad) atomicOr(&flags[0], 1u);      // (rare; no other same-address atomic here: thousands of workgroups on one word cost ~100 ns each)
     }
-}
-
-// first position in cols[a, z) whose column is >= bound (columns ascending)
-__device__ __forceinline__ uint32_t lower_col(const int32_t *cols, uint32_t a, uint32_t z, uint64_t bound)
-{
-    while (a < z) {
-        const uint32_t mid = (a + z) >> 1;
-        if ((uint64_t)(uint32_t)cols[mid] < bound) a = mid + 1; else z = mid;
-    }
-    return a;
-}
-
-// pass 2: wavefront w of the chunk's workgroup writes the segments of phases w, w + 8, ...: rows in order, ballot compaction
-__global__ __launch_bounds__(kLanes * kSegWaves) void seg_fill_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
-                                                          const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
-                                                          const uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, uint32_t nchunks,
-                                                          uint32_t pw, uint32_t phases, const uint32_t *__restrict__ pcnt, int64_t *__restrict__ seg_begin,
-                                                          uint32_t *__restrict__ seg_len, uint16_t *__restrict__ seg_row, const uint32_t *__restrict__ flags)
-{
-    if (flags[0] & 1u) return;      // unsorted rows (found by the count pass): nothing to fill
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t k = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    if (k >= nchunks) return;
-    const int64_t  b = nzb[k], e = nzb[k + 1];
-    const uint32_t row_first = desc[k].x, nri = desc2[k].y, sbase = desc2[k].x;
-    const SegStage st = seg_stage(smem, rp, cidx, b, e, row_first, nri);
+    __syncthreads();
+    if (sbad) return;                            // unsorted rows: the table is meaningless (cvr_preprocess reports it)
     for (uint32_t p = wv; p < phases; p += kSegWaves) {
         const uint64_t c0 = (uint64_t)p * pw, c1 = p + 1 == phases ? ~0ull : c0 + pw;
-        uint32_t       q = sbase + pcnt[(size_t)k * phases + p];
+        uint32_t       q = sbase + poff[p];
         for (uint32_t r0 = 0; r0 < nri; r0 += kLanes) {
             const uint32_t i = r0 + lane;
             bool           has = false;
@@ -432,32 +423,23 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_fill_kernel(const int6
             q += (uint32_t)__popcll(m);
         }
     }
-    const uint32_t pc = pad_cnt[k];
-    if (pc > 0 && threadIdx.x == 0) {
-        const uint32_t q = sbase + desc[k].y - 1;
-        seg_begin[q] = -1; seg_len[q] = pc; seg_row[q] = (uint16_t)nri;
+    if (padc > 0 && threadIdx.x == 0) {
+        const uint32_t q = sbase + stotal - 1;
+        seg_begin[q] = -1; seg_len[q] = padc; seg_row[q] = (uint16_t)nri;
     }
 }
 
-// exclusive scan of the per-chunk segment counts, one workgroup (a few thousand to a few hundred thousand chunks)
-__global__ __launch_bounds__(1024) void seg_scan_kernel(uint32_t *__restrict__ cnt, uint2 *__restrict__ desc2, uint32_t nchunks)
+// sum of the chunks' segment counts (cvr_info.nsegments), one workgroup
+__global__ __launch_bounds__(1024) void seg_total_kernel(uint32_t *__restrict__ cnt, uint32_t nchunks)
 {
-    __shared__ uint32_t part[1024];
-    const uint32_t t = threadIdx.x, per = (nchunks + 1023) / 1024;
-    const uint32_t lo = t * per < nchunks ? t * per : nchunks, hi = lo + per < nchunks ? lo + per : nchunks;
-    uint32_t       s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += cnt[i];
-    part[t] = s;
+    __shared__ uint32_t part[16];
+    uint32_t s = 0;
+    for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) s += cnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {            // inclusive scan of the partial sums
-        const uint32_t v = t >= o ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = t ? part[t - 1] : 0;
-    for (uint32_t i = lo; i < hi; i++) { const uint32_t c = cnt[i]; cnt[i] = run; desc2[i].x = run; run += c; }
-    if (t == 1023) cnt[nchunks] = part[1023];
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 16; w++) t += part[w]; cnt[nchunks] = t; }
 }
 
 // Window choice for the SpMV kernel's LDS staging of x: one workgroup per SpMV workgroup (wpb
@@ -707,26 +689,12 @@ static size_t seg_lds_bytes(const DeviceImage &img)
     return 8 * (size_t)img.ystage + (cap <= kSegLdsCols ? 5 * cap : 0) + 16;       // row pieces (at most ystage - 1 rows) + columns + row-start flags
 }
 
-hipError_t launch_seg_count(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s)
+hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s)
 {
     if (img.nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(seg_count_kernel, dim3(img.nchunks), dim3(256), seg_lds_bytes(img), s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
-                       img.desc2, img.nchunks, img.phase_width, img.phases, st.cnt, st.pcnt, st.flags);
-    return hipGetLastError();
-}
-
-hipError_t launch_seg_scan(const DeviceImage &img, SegTable &st, hipStream_t s)
-{
-    if (img.nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.desc2, img.nchunks);
-    return hipGetLastError();
-}
-
-hipError_t launch_seg_fill(const DeviceImage &img, const DeviceCsr &csr, const SegTable &st, hipStream_t s)
-{
-    if (img.nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(seg_fill_kernel, dim3(img.nchunks), dim3(kLanes * kSegWaves), seg_lds_bytes(img), s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
-                       img.desc2, img.nchunks, img.phase_width, img.phases, st.pcnt, st.begin, st.len, st.row, st.flags);
+    hipLaunchKernelGGL(seg_build_kernel, dim3(img.nchunks), dim3(kLanes * kSegWaves), seg_lds_bytes(img), s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
+                       img.desc2, img.nchunks, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, st.begin, st.len, st.row, st.flags);
+    hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.nchunks);
     return hipGetLastError();
 }
 

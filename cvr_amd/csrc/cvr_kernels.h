@@ -68,18 +68,15 @@ struct DeviceCsr {
 
 // column phases: the segment table of every chunk, built on the device from the CSR and the plan
 struct SegTable {
-    uint32_t *cnt = nullptr;        // [nchunks + 1] segments per chunk, then (exclusive scan) their offsets
-    uint32_t *pcnt = nullptr;       // [nchunks][phases] where the segments of a phase start inside the chunk's range
-    int64_t  *begin = nullptr;      // [nseg_total] first CSR element of the segment, -1 = pad slots
-    uint32_t *len = nullptr;        // [nseg_total] slots of the segment
-    uint16_t *row = nullptr;        // [nseg_total] the chunk's row of the segment (rows-in-chunk = the pad segment's dump entry)
-    uint32_t *flags = nullptr;      // [2]: [0] bit 0 = a row's columns are not ascending; [1] = max segments of a chunk
-    uint32_t  total = 0;
+    uint32_t *cnt = nullptr;        // [nchunks + 1] segments per chunk; [nchunks] = their sum
+    int64_t  *begin = nullptr;      // [nchunks * 64 S] chunk k's segments at k * 64 S: first CSR element of the segment, -1 = pad slots
+    uint32_t *len = nullptr;        // same layout: slots of the segment
+    uint16_t *row = nullptr;        // same layout: the chunk's row of the segment (rows-in-chunk = the pad segment's dump entry)
+    uint32_t *flags = nullptr;      // [2]: [0] bit 0 = a row's columns are not ascending
 };
-// pass 1: counts (writes desc[k].y = segments of chunk k, st.cnt, st.flags); pass 2 after the scan: fills begin / len / row
-hipError_t launch_seg_count(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t st_);
-hipError_t launch_seg_scan(const DeviceImage &img, SegTable &st, hipStream_t st_);      // cnt -> offsets (in place), desc2[k].x
-hipError_t launch_seg_fill(const DeviceImage &img, const DeviceCsr &csr, const SegTable &st, hipStream_t st_);
+// the segment table of every chunk (one workgroup each: counts per phase, then (begin, length, row) in (phase, row) order); writes
+// desc[k].y = segments of chunk k, desc2[k].x = where they start, st.cnt, st.flags
+hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t st_);
 
 // CSR -> CVR64 (one wavefront per chunk).  *err_flag (device u32, zeroed by the caller) gets bit 0 if a
 // lane stream did not drain, bit 1 if stealing found no over-full lane, bit 2 if a value is missing from the dictionary.
