@@ -25,9 +25,9 @@ class CsrView(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
-                ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("stream_ahead", C.c_int32),
-                ("waves_per_block", C.c_int32), ("gather_depth", C.c_int32), ("debug_col_mask", C.c_int32),
-                ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("layout_auto_resident", C.c_int32), ("hub_table", C.c_int32), ("narrow_cols", C.c_int32), ("hub_reorder", C.c_int32), ("reserved4", C.c_int32)]
+                ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("waves_per_block", C.c_int32),
+                ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("hub_table", C.c_int32), ("narrow_cols", C.c_int32),
+                ("hub_reorder", C.c_int32), ("row_tags16", C.c_int32), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class Timing(C.Structure):
@@ -41,8 +41,8 @@ class Info(C.Structure):
                 ("image_bytes", C.c_int64), ("yext_elems", C.c_int64), ("x_elems", C.c_int64),
                 ("plan_s", C.c_double), ("upload_s", C.c_double), ("convert_s", C.c_double),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("waves_per_block", C.c_int32),
-                ("x_window", C.c_int32), ("lds_bytes", C.c_int32), ("nsegments", C.c_int64), ("chunk_row_cap", C.c_int64), ("near_diagonal_share", C.c_double), ("hub_entries", C.c_int32), ("narrow_cols", C.c_int32), ("hub_reorder", C.c_int32), ("reserved5", C.c_int32), ("hub_share", C.c_double),
-                ("hub_select_s", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double)]
+                ("x_window", C.c_int32), ("lds_bytes", C.c_int32), ("nsegments", C.c_int64), ("chunk_row_cap", C.c_int64), ("near_diagonal_share", C.c_double), ("hub_entries", C.c_int32), ("narrow_cols", C.c_int32), ("hub_reorder", C.c_int32), ("row_tags16", C.c_int32), ("hub_share", C.c_double),
+                ("hub_select_s", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double), ("row_bands", C.c_int32), ("piece_max", C.c_int32)]
 
 
 class MmMatrix(C.Structure):
@@ -263,8 +263,11 @@ class CvrMatrix:
 
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
                  xcd_swizzle=-1, x_window=-1, stream_ahead=0, keep_csr=False, debug_col_mask=0, depth=0,
-                 col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1):
-        """tune_steps: choose steps_per_chunk by measurement first (cvr_tune_steps; its cost is self.tuning_s)"""
+                 col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1,
+                 row_tags16=-1, row_bands=-1, piece_max=-1):
+        """tune_steps: choose steps_per_chunk by measurement first (cvr_tune_steps; its cost is self.tuning_s).
+        stream_ahead / depth / debug_col_mask are profiling knobs (tools/sweep.py): they travel through the environment
+        (CVR_DEBUG_*), not through cvr_options."""
         self._h = C.c_void_p()
         self.tuning_s = 0.0
         rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
@@ -280,7 +283,8 @@ class CvrMatrix:
             raise ValueError(f"col_idx / vals hold {len(ci)} / {len(va)} entries, row_ptr[nrows] = {int(rp[-1])}")
         view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
-                    debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block, col_phases, hub_table, narrow_cols, hub_reorder)
+                    debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block, col_phases, hub_table, narrow_cols, hub_reorder,
+                    row_tags16, row_bands, piece_max)
 
     @classmethod
     def from_device(cls, nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, is_f32=False, device=0, steps_per_chunk=0,
@@ -298,15 +302,20 @@ class CvrMatrix:
         return self
 
     def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
-               debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1):
+               debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1,
+               row_tags16=-1, row_bands=-1, piece_max=-1):
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
         opt.xcd_swizzle, opt.x_window, opt.col_panels, opt.value_dict = xcd_swizzle, x_window, col_panels, value_dict
-        # tuning / profiling knobs (tools/sweep.py)
-        opt.stream_ahead, opt.gather_depth, opt.debug_col_mask = stream_ahead, depth, debug_col_mask
         opt.waves_per_block, opt.col_phases, opt.hub_table, opt.narrow_cols = waves_per_block, col_phases, hub_table, narrow_cols
-        opt.hub_reorder = hub_reorder
+        opt.hub_reorder, opt.row_tags16, opt.row_bands, opt.piece_max = hub_reorder, row_tags16, row_bands, piece_max
+        # profiling knobs (tools/sweep.py): read from the environment by cvr_create / cvr_tune
+        for name, val in (("CVR_DEBUG_STREAM_AHEAD", stream_ahead), ("CVR_DEBUG_GATHER_DEPTH", depth), ("CVR_DEBUG_COL_MASK", debug_col_mask)):
+            if val:
+                os.environ[name] = str(int(val))
+            else:
+                os.environ.pop(name, None)
         if tune_steps and steps_per_chunk == 0:          # the layout by measurement (cvr_tune): S, chunks per workgroup, x window, column phases
             best, best_t, tun = Options(), C.c_double(), C.c_double()
             rc = lib().cvr_tune(C.byref(view), C.byref(opt), C.byref(best), C.byref(best_t), C.byref(tun))
@@ -392,7 +401,7 @@ class CvrMatrix:
 
     def export_image(self):
         i = self.info
-        gb = 1280 if i.value_dict else (1536 if self.f32 else 2560) if i.narrow_cols else 2048 if self.f32 else 3072
+        gb = (1280 if i.value_dict else (1536 if self.f32 else 2560) if i.narrow_cols else 2048 if self.f32 else 3072) + (512 if i.row_tags16 else 0)
         image = np.zeros(i.nchunks * (i.steps_per_chunk // 4) * gb, dtype=np.uint8)
         desc = np.zeros((i.nchunks, 4), dtype=np.uint32)
         target = np.zeros((i.nchunks, 64), dtype=np.uint8)

@@ -80,6 +80,14 @@ double now_s()
 
 }  // namespace
 
+// cvr_options plus what cvr_create decides on the way and the profiling knobs it reads from the environment
+struct IOpt : cvr_options {
+    int32_t layout_auto_resident = 0;      // the automatic layout chose the "resident" form: every workgroup on a CU of its own at once
+    int32_t stream_ahead = 0;              // CVR_DEBUG_STREAM_AHEAD: groups the matrix stream runs ahead of the x gather: 0 / 1 = one, >= 2 = three
+    int32_t gather_depth = 0;              // CVR_DEBUG_GATHER_DEPTH: groups the x gather runs ahead of the FMAs: 1 or 2
+    int32_t debug_col_mask = 0;            // CVR_DEBUG_COL_MASK: folds the gather onto a 2^k-entry table (timing only: wrong y)
+};
+
 // One CVR64 image on the device: the whole matrix, or one column panel of it (rows compacted to those that
 // have a non-zero in the panel).
 struct Part {
@@ -112,6 +120,8 @@ struct Part {
         if (img.shared) (void)hipFree(img.shared);
         if (img.win_base) (void)hipFree(img.win_base);
         if (img.desc2) (void)hipFree(img.desc2);
+        if (img.pace) (void)hipFree(img.pace);
+        delete img.pace_epoch;
         if (img.cbase) (void)hipFree(img.cbase);
         if (img.hub_cols) (void)hipFree(img.hub_cols);
         if (img.hub_index) (void)hipFree(img.hub_index);
@@ -135,6 +145,10 @@ struct cvr_handle {
     void     *d_dict = nullptr;           // value dictionary (sorted by bit pattern) shared by all parts, or null
     uint32_t  ndict = 0;
     cvr::FixPart *d_fixparts = nullptr;   // panels: the fix-up of every panel in one launch
+    // panels, one per XCD at a time (cvr_kernels.h: PanelArgs): rounds of eight panels per launch; d_multi[round][8]
+    cvr::PanelArgs       *d_multi = nullptr;
+    std::vector<uint32_t> multi_chunks;   // per round: the most chunks any of its panels has
+    uint32_t              multi_ystage = 0;
     uint32_t  max_nshared = 0;
     uint32_t *d_err = nullptr;
     void     *d_x = nullptr;            // x_ext: ncols + 1
@@ -172,10 +186,19 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
     // the panels' partial sums share one buffer (h->d_z): a launch on another stream must not start before the combine pass of
     // the previous one has read them
     if (h->z_used) { const hipError_t e = hipStreamWaitEvent(st, h->z_free, 0); if (e != hipSuccess) return e; }
-    for (const Part &p : h->parts) {
-        hipError_t e = cvr::launch_spmv(p.img, x, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * h->vsz, st, false);
-        if (e != hipSuccess) return e;
-    }
+    if (h->d_multi) {          // eight panels per launch, panel b & 7 on the XCD of the workgroups b
+        cvr::DeviceImage shared = h->parts[0].img;
+        shared.ystage = h->multi_ystage;
+        for (size_t r = 0; r < h->multi_chunks.size(); r++) {
+            if (h->multi_chunks[r] == 0) continue;
+            const hipError_t e = cvr::launch_spmv(shared, x, nullptr, st, false, h->d_multi + 8 * r, h->multi_chunks[r]);
+            if (e != hipSuccess) return e;
+        }
+    } else
+        for (const Part &p : h->parts) {
+            hipError_t e = cvr::launch_spmv(p.img, x, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * h->vsz, st, false);
+            if (e != hipSuccess) return e;
+        }
     hipError_t e = cvr::launch_fixup_multi(h->d_fixparts, (uint32_t)h->parts.size(), h->max_nshared, h->vsz == 4, st);
     if (e != hipSuccess) return e;
     e = cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st);
@@ -206,7 +229,25 @@ void cvr_default_options(cvr_options *o)
     o->hub_table = -1;
     o->narrow_cols = -1;
     o->hub_reorder = -1;
+    o->row_tags16 = -1;
+    o->row_bands = -1;
+    o->piece_max = -1;
 }
+
+}  // extern "C"
+
+static IOpt make_iopt(const cvr_options *in)
+{
+    IOpt o;
+    if (in) static_cast<cvr_options &>(o) = *in; else cvr_default_options(&o);
+    auto env = [](const char *name) { const char *e = getenv(name); return e ? (int32_t)strtol(e, nullptr, 0) : 0; };
+    o.stream_ahead = env("CVR_DEBUG_STREAM_AHEAD");
+    o.gather_depth = env("CVR_DEBUG_GATHER_DEPTH");
+    o.debug_col_mask = env("CVR_DEBUG_COL_MASK");
+    return o;
+}
+
+extern "C" {
 
 int cvr_device_count(void)
 {
@@ -368,6 +409,7 @@ struct PartPlan {
     int64_t  win = 0;              // x window, values
     int64_t  stage = 64;           // row sums (column phases: row accumulators) per wavefront
     int      col_bits = 31;        // column phases: bits of a column index (the row field of a segment's last column word starts there)
+    bool     tag16 = false;        // column phases: the rows of the pieces in 16-bit tags of their own
     bool     lds_short = false;    // column phases do not fit beside the window
     int      plan_threads = 0;     // 0: the planner's own small team; 1: the caller plans several images side by side
     int64_t  hub_n = 0;            // hub table entries staged in LDS in front of the window (decided before planning)
@@ -380,7 +422,7 @@ constexpr int64_t kDevicePlanRows = 200000;
 // (CVR_DEVICE_PLAN_ROWS overrides it: the fuzz tests send their small matrices through the device planner with 0)
 static int64_t device_plan_rows() { const char *e = getenv("CVR_DEVICE_PLAN_ROWS"); return e ? atoll(e) : kDevicePlanRows; }
 
-static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const cvr_options &opt, const DevRows *dr = nullptr)
+static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr = nullptr)
 {
     const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
     pp.S = opt.steps_per_chunk;
@@ -411,13 +453,16 @@ static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32
         while (((int64_t)1 << pp.col_bits) <= ncols) pp.col_bits++;
         const int64_t row_field = pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
         auto rows_for = [&](int64_t win) {
-            const int64_t left = (int64_t)cvr::kLdsBytes - ((int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + win + 4) * vs;
+            const int64_t left = (int64_t)cvr::kLdsBytes - (cvr::kDictMax + win + 4) * vs;      // (no steal slots: spmv_seg_kernel)
             return std::min<int64_t>((left / pp.wpb / vs) & ~(int64_t)3, cvr::kYStageMax);
         };
         while (pp.win > 0 && rows_for(pp.win) < 512) pp.win = (pp.win - 1024 > 0 ? pp.win - 1024 : 0) & ~(int64_t)3;      // the window gives way
-        pp.stage = std::min<int64_t>(rows_for(pp.win), (row_field + 1) & ~(int64_t)3);
         // a chunk of S steps holds at most 64 S rows: no need for more accumulators than that (keeps the LDS small)
-        pp.stage = std::min<int64_t>(pp.stage, ((int64_t)cvr::kLanes * pp.S + 1 + 3) & ~(int64_t)3);
+        const int64_t want = std::min<int64_t>(rows_for(pp.win), ((int64_t)cvr::kLanes * pp.S + 1 + 3) & ~(int64_t)3);
+        // wide row tags (16 bits of their own per slot) when the column word has no room for the rows such a chunk may hold
+        pp.tag16 = opt.row_tags16 > 0 || (opt.row_tags16 < 0 && row_field + 1 < want);
+        if (pp.tag16) pp.col_bits = 31;
+        pp.stage = std::min<int64_t>(want, pp.tag16 ? (int64_t)65532 : (row_field + 1) & ~(int64_t)3);
         if (pp.stage < 64) { pp.lds_short = true; pp.phases = 1; pp.stage = 64; }
         else max_rows = pp.stage - 1;                 // + the dump entry of the pad segment
     }
@@ -549,7 +594,7 @@ static hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0
 // diagonal, and feed their rows column phase by column phase when x is larger than what an L2 keeps beside the matrix
 // stream (profiles/r02_wg_window_sweep.log, r02_column_phases_sweep.log: 32.5 -> 23.4 us on the web-Google shape).
 // Decided from a device-side pass over the uploaded CSR (sortedness of the rows, near-diagonal share).
-static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, cvr_options &opt)
+static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt)
 {
     const int64_t nnz = nz1 - nz0;
     opt.layout_auto_resident = 0;
@@ -618,7 +663,7 @@ static int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
 // whose x does not fit an L2 get the columns counted on the device, and the table is used when the columns that fit the LDS
 // (beside 8 chunks' row stages) hold at least half of the (sampled) non-zeros -- R-MAT scale 22 fp32: 0.56, 402 -> 289 us;
 // fp64 (half as many entries fit): 0.41, where the table loses (profiles/r02_hub_table_rmat.log).  The workgroup then has 8 chunks.
-static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, cvr_options &opt, PartPlan &pp,
+static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt, PartPlan &pp,
                        bool allow_reorder)
 {
     if (opt.hub_table == 0 || opt.layout_auto_resident || opt.col_phases > 1 || nrows <= 0 || ncols >= (int64_t)cvr::kHubBit) return CVR_OK;
@@ -654,7 +699,7 @@ static int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t n
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
 // (rp == nullptr: part.d_rp is already in place -- the row pointers of a column panel split on the device -- and `dr` describes it)
 static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
-                      hipMemcpyKind civa_kind, bool f32, const cvr_options &opt, double *plan_s, PartPlan *planned = nullptr, const DevRows *dr = nullptr)
+                      hipMemcpyKind civa_kind, bool f32, const IOpt &opt, double *plan_s, PartPlan *planned = nullptr, const DevRows *dr = nullptr)
 {
     const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
     const size_t  vsz = f32 ? 4 : 8, nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
@@ -669,7 +714,7 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
         HIP_TRY(hipMemcpyAsync(part.d_va, va, vsz * nnz_span, civa_kind, h->stream));
     }
     PartPlan    local;
-    cvr_options popt = opt;
+    IOpt        popt = opt;
     if (!planned) {
         int rc = auto_layout(h, part, nrows, ncols, f32, nz0, nz1, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
         if (rc) return rc;
@@ -713,7 +758,16 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
         const int64_t pw = ((ncols + pp.phases - 1) / pp.phases + 15) / 16 * 16;
         img.phase_width = (uint32_t)std::max<int64_t>(pw, 16);
         img.col_bits = (uint32_t)pp.col_bits;
-        img.col_mask = (1u << pp.col_bits) - 1u;
+        img.tag16 = pp.tag16;
+        // pieces: a lane that sits on a long row's segment falls behind the column ranges the other lanes have moved on to; with
+        // chunks longer than a few steps per phase the segments are cut (auto: 8 elements once a phase takes 8 steps or more)
+        if (S / pp.phases >= 8 && !getenv("CVR_NO_PACE")) {      // long chunks: the SpMV kernel paces its wavefronts through the phases
+            HIP_TRY(hipMalloc(&img.pace, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases)));
+            HIP_TRY(hipMemsetAsync(img.pace, 0, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases), h->stream));
+            img.pace_epoch = new uint32_t(0);
+        }
+        img.piece_max = opt.piece_max > 0 ? (uint32_t)opt.piece_max : opt.piece_max < 0 && S / pp.phases >= 8 ? 8u : 0u;
+        img.col_mask = pp.tag16 ? cvr::kColMask : (1u << pp.col_bits) - 1u;
     }
     if (popt.col_phases > 1 && pp.lds_short && !popt.layout_auto_resident) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
     const int64_t win = pp.win;
@@ -765,11 +819,11 @@ static int finish_part(cvr_handle *h, Part &part)
     cvr::DeviceImage &img = part.img;
     img.dict = h->d_dict; img.ndict = h->ndict;
     if (img.dict) img.c16 = false;                 // (the dictionary layout keeps 32-bit column words)
-    part.stream_bytes = (size_t)part.nchunks * img.G * cvr::group_bytes(img.f32, h->d_dict != nullptr, img.c16);
+    part.stream_bytes = (size_t)part.nchunks * img.G * cvr::group_bytes(img.f32, h->d_dict != nullptr, img.c16, img.tag16);
     // the SpMV kernel's software pipeline issues its stream loads up to 5 groups past the end of a chunk (the buffer
     // descriptor's range check returns zeros for them); the allocation is padded by that much so that the last chunk's
     // run-ahead stays inside it whatever the hardware does with an offset beyond num_records
-    const size_t slack = 8 * (size_t)cvr::group_bytes(img.f32, h->d_dict != nullptr, img.c16);
+    const size_t slack = 8 * (size_t)cvr::group_bytes(img.f32, h->d_dict != nullptr, img.c16, img.tag16);
     if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
         HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, part.stream_bytes + slack, hipDeviceMallocUncached));
     else
@@ -985,8 +1039,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     *out = nullptr;
     Range range("cvr_create (validate, plan, upload)");
     if (!csr_in) return fail(CVR_ERR_INVALID, "null or negative-size CSR view");
-    cvr_options opt;
-    if (opt_in) opt = *opt_in; else cvr_default_options(&opt);
+    IOpt opt = make_iopt(opt_in);
     const int ndev = cvr_device_count();
     const bool on_device = csr_in->arrays_on_device != 0;
     int rc = on_device ? CVR_OK : check_csr(csr_in);          // host arrays: rejected before any device work
@@ -1112,6 +1165,12 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     }
     const double panel_rule_s = now_s() - t_rule0;          // part of the analysis: added to plan_s below
     clk.lap("panel rule");
+    // Panels in rounds of eight, each on one XCD (run_spmv, d_multi): the count the rule gave is for slices that share every L2 in
+    // turn; with an L2 to itself a slice may be ~2.6 MB, and the count is a multiple of eight (CVR_XCD_PANELS=0: the old form)
+    const char *xp_env = getenv("CVR_XCD_PANELS");
+    const bool  xcd_panels = !(xp_env && atoi(xp_env) == 0);
+    if (P > 1 && panels_auto && xcd_panels && xp_env && atoi(xp_env) > 1) P = atoi(xp_env);          // (experiments: the count itself)
+    else if (P > 1 && panels_auto && xcd_panels) P = 8 * std::max(1, (int)std::ceil(xbytes / (8.0 * 2.6e6)));
     if (P < 1) P = 1;
     if (P > 64) P = 64;
     in.col_panels = P;
@@ -1164,9 +1223,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         in.plan_s += now_s() - t0 - in.hub_select_s;      // (the hub count that sizes the panels is reported on its own)
         clk.lap("panel split");
         std::vector<PartPlan> pps((size_t)P);
-        cvr_options           panel_opt = opt;
+        IOpt                  panel_opt = opt;
         panel_opt.col_phases = 1;          // column phases are for the single image whose chunks are all resident at once
-        std::vector<cvr_options> popts((size_t)P, panel_opt);
+        std::vector<IOpt>        popts((size_t)P, panel_opt);
         std::vector<DevRows>     drs((size_t)P);
         if (dev_split) {
             // per panel: its row pointers made panel-local (a slice of the split's, minus the panel's first position), a hub
@@ -1312,12 +1371,37 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     clk.lap("value dictionary scan");
     for (Part &p : h->parts) { rc = finish_part(h, p); if (rc) { cvr_destroy(h); return rc; } }
     for (const Part &p : h->parts) in.hub_entries = std::max<int32_t>(in.hub_entries, (int32_t)p.img.hub_n);
+    // column panels whose images are plain (one chunk per workgroup, no LDS tables): eight panels per launch, each on the XCD of
+    // its workgroups, so that an L2 holds one slice of x at a time and every line of x is fetched by one XCD only
+    if (h->paneled() && xcd_panels) {
+        bool plain = true;
+        for (const Part &p : h->parts) plain = plain && p.img.wpb <= 1 && p.img.hub_n == 0 && p.img.win_elems == 0 && p.img.phases <= 1 && !p.img.c16 && p.img.S == h->parts[0].img.S;
+        if (plain) {
+            const size_t per_round = getenv("CVR_XCD_PANELS_DEBUG") ? (size_t)atoi(getenv("CVR_XCD_PANELS_DEBUG")) : 8;      // (diagnostics: fewer panels side by side)
+            const size_t rounds = (h->parts.size() + per_round - 1) / per_round;
+            std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u});
+            h->multi_chunks.assign(rounds, 0u);
+            for (size_t j = 0; j < h->parts.size(); j++) {
+                const Part &p = h->parts[j];
+                const size_t i = (j / per_round) * 8 + j % per_round;
+                pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage};
+                h->multi_chunks[i / 8] = std::max(h->multi_chunks[i / 8], p.img.nchunks);
+                h->multi_ystage = std::max(h->multi_ystage, p.img.ystage);
+                if (getenv("CVR_XCD_PANELS_TRACE")) fprintf(stderr, "[xcd panels] part %zu slot %zu nchunks %u ystage %u S %d G %d zoff %lld yext %lld nshared %u stream %p\n", j, i, p.img.nchunks, p.img.ystage, p.img.S, p.img.G, (long long)p.zoff, (long long)p.yext, p.img.nshared, (void *)p.img.stream);
+            }
+            CREATE_TRY(hipMalloc(&h->d_multi, sizeof(cvr::PanelArgs) * pa.size()));
+            CREATE_TRY(hipMemcpy(h->d_multi, pa.data(), sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyHostToDevice));
+        }
+    }
     if (!h->z_free && in.hub_entries) CREATE_TRY(hipEventCreateWithFlags(&h->z_free, hipEventDisableTiming));
     in.steps_per_chunk = h->parts[0].img.S;
     in.col_phases = (int32_t)h->parts[0].img.phases; in.waves_per_block = (int32_t)h->parts[0].img.wpb; in.x_window = (int32_t)h->parts[0].img.win_elems;
     in.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);
     in.narrow_cols = h->parts[0].img.c16 ? 1 : 0;
     in.hub_reorder = h->parts[0].img.order_n ? 1 : 0;
+    in.row_tags16 = h->parts[0].img.tag16 ? 1 : 0;
+    in.row_bands = 1;
+    in.piece_max = (int32_t)h->parts[0].img.piece_max;
     in.chunk_row_cap = h->parts[0].img.phases > 1 ? (int64_t)h->parts[0].img.ystage - 1 : 0;
     for (const Part &p : h->parts) {
         in.nchunks += p.nchunks; in.nshared += p.nshared; in.nslots += p.nchunks * 64 * p.img.S;
@@ -1430,7 +1514,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->d_small) (void)hipFree(h->d_small);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->z_free) (void)hipEventDestroy(h->z_free);
-    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, (void *)h->d_multi, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
     release_stream(h->device, h->stream);
     delete h;
     return CVR_OK;

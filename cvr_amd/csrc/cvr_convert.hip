@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t dict_code(const typename Bits<T>::type *dict
 // every later load of the step depends on: the converter is a chain of 64 S dependent steps, 75 % of its cycles are waits
 // (SQ_WAIT_ANY), and this removes one of the two round trips per step.  (Staging the chunk's columns and values as well was
 // slower: 34 KB of LDS per chunk leave four chunks per CU where seven want to run; profiles/r02_convert_lds_staging_probe.log.)
-template <typename T, bool DICT, bool SEGT, bool C16, bool STAGE = false>
+template <typename T, bool DICT, bool SEGT, bool C16, bool STAGE = false, bool TAG = false>
 __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx, const T *__restrict__ vals,
     const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt, const uint4 *__restrict__ desc,
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t csm[];      // STAGE: stage_bytes per wavefront
     if constexpr (SEGT) { if (seg_flags[0] & 1u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
-    constexpr int GB = DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
-    constexpr int CB = C16 ? kCols16Bytes : kColsBytes;      // bytes of the group's column part
+    constexpr int GB = (DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
+    constexpr int CB = (C16 ? kCols16Bytes : kColsBytes) + (TAG ? kTagBytes : 0);      // bytes of the group in front of the values: column words (+ wide row tags)
     typedef typename Bits<T>::type bits_t;
     __shared__ bits_t dict[DICT ? kDictMax : 1];
     if constexpr (DICT) {
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     }
 
     for (int g = 0; g < G; g++) {
-        uint32_t cw[4], cj[4];
+        uint32_t cw[4], cj[4], tg4[4];
         T        vv[4];
         int64_t  pj[4];
 #pragma unroll
@@ -156,11 +156,11 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
                         const uint32_t sb = SBEG(q);
                         pos = sb == 0xffffu ? -1 : b + (int64_t)sb;
                         cnt = SLEN(q);
-                        rowtag = (uint32_t)SRW(q) << col_bits;
+                        rowtag = TAG ? (uint32_t)SRW(q) : (uint32_t)SRW(q) << col_bits;
                     } else if constexpr (SEGT) {
                         pos = seg_begin[sbase + q];
                         cnt = seg_len[sbase + q];
-                        rowtag = (uint32_t)seg_row[sbase + q] << col_bits;
+                        rowtag = TAG ? (uint32_t)seg_row[sbase + q] : (uint32_t)seg_row[sbase + q] << col_bits;
                     } else if constexpr (STAGE) {
                         if (q < nrow_seg) {
                             const uint32_t a = SROW(q), z = SROW(q + 1);
@@ -189,12 +189,14 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
                         const int      v = __ffsll((unsigned long long)of) - 1;     // FIRST over-full lane (spmv.cpp:876-879)
                         const uint32_t cv = __shfl(cnt, v);
                         const int64_t  pv = __shfl(pos, v);
+                        uint32_t       tv = 0;                        // column phases: what a lane steals keeps the row of the victim's segment
+                        if constexpr (SEGT) tv = __shfl(rowtag, v);
                         const uint32_t m = (cv + ave - 1) / ave - 1;  // steals until v is no longer over-full
                         const uint32_t kk = m < nsteal - base ? m : nsteal - base;
                         if (want && s >= base && s < base + kk) {     // takes the FIRST ave (spmv.cpp:927-931)
                             pos = pv < 0 ? -1 : pv + (int64_t)(s - base) * ave;
                             cnt = ave;
-                            rowtag = 0;
+                            rowtag = tv;
                             tgt = (uint32_t)v;
                             want = false;
                         }
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
             // which element the lane emits at this step; the element itself is fetched below, for the four steps together: the
             // hand-out of the next steps depends on the counts only, not on what was loaded
             pj[j] = pos;
-            cw[j] = cnt == 1 ? kEndBit | rowtag : 0u;
+            if constexpr (TAG) { cw[j] = cnt == 1 ? kEndBit : 0u; tg4[j] = cnt == 1 ? rowtag : 0u; }
+            else cw[j] = cnt == 1 ? kEndBit | rowtag : 0u;
             if (pos >= 0) pos++;
             cnt--;
         }
@@ -242,6 +245,10 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
         } else {
             u32x4 cq = {cw[0], cw[1], cw[2], cw[3]};
             *reinterpret_cast<u32x4 *>(o) = cq;
+            if constexpr (TAG) {
+                const uint2 tq = {tg4[0] | (tg4[1] << 16), tg4[2] | (tg4[3] << 16)};
+                *reinterpret_cast<uint2 *>(stream + (size_t)k * G * GB + (size_t)g * GB + kColsBytes + lane * 8) = tq;
+            }
         }
         if constexpr (DICT) {
             uint32_t codes = 0;
@@ -284,9 +291,9 @@ __device__ __forceinline__ void row_piece(const int64_t *rp, uint32_t row, int64
     z = z < e ? z : e;
 }
 
-// Both passes stage the chunk's column indices (when the chunk has at most kSegLdsCols slots) and its row pieces in LDS:
+// Both passes stage the chunk's column indices (as many of the chunk's elements as the launch reserved room for: lds_cols) and its row pieces in LDS:
 // the per-row scans and binary searches then run at LDS latency instead of as chains of dependent global loads.
-constexpr uint32_t kSegLdsCols = 16384;     // 64 KiB of column indices
+// (the launch reserves 5 bytes per element of the chunk: column index + row-start flag, for as many elements as the LDS holds beside the row pieces: `lds_cols`)
 constexpr uint32_t kSegWaves = 8;           // wavefronts per chunk in the fill pass (each takes every 8th phase)
 
 struct SegStage {
@@ -295,7 +302,7 @@ struct SegStage {
 };
 
 __device__ __forceinline__ SegStage seg_stage(uint8_t *smem, const int64_t *rp, const int32_t *cidx, int64_t b, int64_t e,
-                                              uint32_t row_first, uint32_t nri)
+                                              uint32_t row_first, uint32_t nri, uint32_t lds_cols)
 {
     SegStage st;
     st.pa = reinterpret_cast<uint32_t *>(smem);
@@ -308,7 +315,7 @@ __device__ __forceinline__ SegStage seg_stage(uint8_t *smem, const int64_t *rp, 
         if (z < a) z = a;
         st.pa[i] = (uint32_t)(a - b); st.pz[i] = (uint32_t)(z - b);
     }
-    if (n <= kSegLdsCols) {
+    if (n <= lds_cols) {
         for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) scol[j] = cidx[b + j];
         st.cols = scol;
     } else {
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
                                                           const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
                                                           uint4 *__restrict__ desc, uint2 *__restrict__ desc2, uint32_t nchunks,
                                                           uint32_t pw, uint32_t phases, uint32_t cap, uint32_t *__restrict__ cnt, int64_t *__restrict__ seg_begin,
-                                                          uint32_t *__restrict__ seg_len, uint16_t *__restrict__ seg_row, uint32_t *__restrict__ flags)
+                                                          uint32_t *__restrict__ seg_len, uint16_t *__restrict__ seg_row, uint32_t *__restrict__ flags, uint32_t lds_cols, uint32_t pmax)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t pc[64], poff[64], sbad, stotal;
@@ -347,10 +354,10 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
     const uint32_t row_first = desc[k].x, nri = desc2[k].y, sbase = k * cap;
     if (threadIdx.x < 64) pc[threadIdx.x] = 0;
     if (threadIdx.x == 0) sbad = 0;
-    const SegStage st = seg_stage(smem, rp, cidx, b, e, row_first, nri);
+    const SegStage st = seg_stage(smem, rp, cidx, b, e, row_first, nri, lds_cols);
     uint32_t       bad = 0;
     const uint32_t n = (uint32_t)(e - b);
-    if (n <= kSegLdsCols) {
+    if (n <= lds_cols) {
         uint8_t *rstart = smem + 8 * (size_t)nri + 4 * (size_t)n;
         for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) rstart[j] = 0;
         __syncthreads();
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
             if (rstart[j]) { atomicAdd(&pc[ph], 1u); continue; }
             const int32_t prev_col = st.cols[j - 1];      // (j > 0 here: element 0 starts a row piece or belongs to no row of the chunk)
             if (col < prev_col) bad = 1;
-            if (ph != (uint32_t)prev_col / pw) atomicAdd(&pc[ph], 1u);
+            if (ph != (uint32_t)prev_col / pw || j % pmax == 0) atomicAdd(&pc[ph], 1u);      // (pieces are cut at the multiples of pmax from the chunk's first element)
         }
     } else {
         for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
                 const int32_t  col = st.cols[j];
                 const uint32_t ph = (uint32_t)col / pw;
                 if (col < prev_col) bad = 1;
-                if (ph != prev) atomicAdd(&pc[ph], 1u);
+                if (ph != prev || j % pmax == 0) atomicAdd(&pc[ph], 1u);
                 prev = ph; prev_col = col;
             }
         }
@@ -404,23 +411,28 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
         uint32_t       q = sbase + poff[p];
         for (uint32_t r0 = 0; r0 < nri; r0 += kLanes) {
             const uint32_t i = r0 + lane;
-            bool           has = false;
-            int64_t        beg = -1;
-            uint32_t       len = 1;
+            uint32_t       np = 0, lo = 0, hi = 0;              // pieces of row i in this phase: [lo, hi) cut at the multiples of pmax
+            bool           pad = false;
             if (i < nri) {
                 const uint32_t a = st.pa[i], z = st.pz[i];
-                if (z <= a) has = p == 0;
+                if (z <= a) { pad = p == 0; np = pad ? 1u : 0u; }
                 else {
-                    const uint32_t lo = lower_col(st.cols, a, z, c0), hi = lower_col(st.cols, lo, z, c1);
-                    if (hi > lo) { has = true; beg = b + lo; len = hi - lo; }
+                    lo = lower_col(st.cols, a, z, c0); hi = lower_col(st.cols, lo, z, c1);
+                    if (hi > lo) np = (hi - 1) / pmax - lo / pmax + 1;
                 }
             }
-            const uint64_t m = __ballot(has);
-            if (has) {
-                const uint32_t idx = q + lane_rank(m);
-                seg_begin[idx] = beg; seg_len[idx] = len; seg_row[idx] = (uint16_t)i;
-            }
-            q += (uint32_t)__popcll(m);
+            uint32_t incl = np;                                   // inclusive scan over the wavefront
+#pragma unroll
+            for (int o = 1; o < kLanes; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
+            uint32_t idx = q + incl - np;
+            if (pad) { seg_begin[idx] = -1; seg_len[idx] = 1; seg_row[idx] = (uint16_t)i; }
+            else
+                for (uint32_t u = lo; u < hi;) {
+                    const uint32_t nxt = (u / pmax + 1) * pmax, v = nxt < hi ? nxt : hi;
+                    seg_begin[idx] = b + u; seg_len[idx] = v - u; seg_row[idx] = (uint16_t)i;
+                    idx++; u = v;
+                }
+            q += __shfl(incl, kLanes - 1);
         }
     }
     if (padc > 0 && threadIdx.x == 0) {
@@ -683,17 +695,19 @@ hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, 
     return hipGetLastError();
 }
 
-static size_t seg_lds_bytes(const DeviceImage &img)
+// elements of a chunk whose column indices and row-start flags (5 bytes each) fit the LDS beside the row pieces (at most ystage - 1 rows, 8 bytes each)
+static uint32_t seg_lds_cols(const DeviceImage &img)
 {
-    const size_t cap = (size_t)kLanes * img.S;
-    return 8 * (size_t)img.ystage + (cap <= kSegLdsCols ? 5 * cap : 0) + 16;       // row pieces (at most ystage - 1 rows) + columns + row-start flags
+    const size_t cap = (size_t)kLanes * img.S, room = (kLdsBytes - 8 * (size_t)img.ystage - 1024) / 5;      // (1 KiB: the kernel's static tables)
+    return (uint32_t)std::min(cap, room);
 }
+static size_t seg_lds_bytes(const DeviceImage &img) { return 8 * (size_t)img.ystage + 5 * (size_t)seg_lds_cols(img) + 16; }
 
 hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s)
 {
     if (img.nchunks == 0) return hipSuccess;
     hipLaunchKernelGGL(seg_build_kernel, dim3(img.nchunks), dim3(kLanes * kSegWaves), seg_lds_bytes(img), s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
-                       img.desc2, img.nchunks, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, st.begin, st.len, st.row, st.flags);
+                       img.desc2, img.nchunks, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, st.begin, st.len, st.row, st.flags, seg_lds_cols(img), img.piece_max ? img.piece_max : 0xffffffffu);
     hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.nchunks);
     return hipGetLastError();
 }
@@ -710,11 +724,15 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     static const bool direct = getenv("CVR_CONVERT_DIRECT") != nullptr;       // (diagnostics: the unstaged kernel)
     const bool   stage = !img.c16 && cap < 65535 && per * kWavesPerBlock <= (20u << 10) && !direct;
     const size_t lds = stage ? per * kWavesPerBlock : 0;
+#define CVR_CONVERT_ARGS(T)                                                                                            \
+    csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
+    static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, seg ? seg->row : nullptr, img.col_bits,           \
+    seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase, img.hub_n, (uint32_t)per
 #define CVR_CONVERT(T, DI, SG, SM)                                                                                     \
-    hipLaunchKernelGGL((convert_kernel<T, DI, SG, false, SM>), grid, block, lds, st, csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), \
-                       csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
-                       static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, \
-                       seg ? seg->row : nullptr, img.col_bits, seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase, img.hub_n, (uint32_t)per)
+    do {                                                                                                               \
+        if (SG && img.tag16) hipLaunchKernelGGL((convert_kernel<T, DI, SG, false, SM, SG>), grid, block, lds, st, CVR_CONVERT_ARGS(T)); \
+        else hipLaunchKernelGGL((convert_kernel<T, DI, SG, false, SM, false>), grid, block, lds, st, CVR_CONVERT_ARGS(T)); \
+    } while (0)
 #define CVR_CONVERT_SM(T, DI, SG) do { if (stage) CVR_CONVERT(T, DI, SG, true); else CVR_CONVERT(T, DI, SG, false); } while (0)
 #define CVR_CONVERT_SG(T, DI) do { if (seg) CVR_CONVERT_SM(T, DI, true); else CVR_CONVERT_SM(T, DI, false); } while (0)
     if (img.c16 && !img.dict && !seg) {      // narrow chunks: 16-bit column offsets
@@ -732,6 +750,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     else         { if (img.dict) CVR_CONVERT_SG(double, true); else CVR_CONVERT_SG(double, false); }
 #undef CVR_CONVERT_SG
 #undef CVR_CONVERT_SM
+#undef CVR_CONVERT_ARGS
 #undef CVR_CONVERT
     return hipGetLastError();
 }

@@ -23,6 +23,10 @@
 //                narrow chunks (every chunk of the matrix spans fewer than 32 767 columns: banded matrices):
 //                  [64 lanes][4 x u16 column - cbase[k]]  512 B instead of the 1024 B of column words (bit 15 = end
 //                  of segment, 0x7fff = the pad column): 10 instead of 12 bytes per fp64 slot
+//                column phases: the LAST column word of every piece of a lane stream (a (row, phase) segment or what a lane stole
+//                  of one) carries the chunk's row of the piece in bits [col_bits, 31); when column index and row do not fit 31
+//                  bits together (wide matrices, long chunks) the rows stand in a block of their own instead (wide row tags):
+//                  [64 lanes][4 x u16 row]  512 B between the column words and the values / codes
 //   desc[k]    = {row_first, nseg, head_dest, last_dest}: segment q of chunk k writes
 //                y_ext[q == 0 ? head_dest : q == nseg-1 ? last_dest : row_first + q]
 //   y_ext      = [ y[0..nrows) | dump | carry_head(0), carry_tail(0), carry_head(1), ... ]
@@ -47,6 +51,7 @@ constexpr int      kCols16Bytes  = kLanes * 8;             // 512: narrow chunks
 constexpr int      kGroupBytes64C16 = kCols16Bytes + kLanes * 32;   // 2560: 10 bytes per slot
 constexpr int      kGroupBytes32C16 = kCols16Bytes + kLanes * 16;   // 1536:  6 bytes per slot
 constexpr uint32_t kC16Pad = 0x7fffu;
+constexpr int      kTagBytes = kLanes * 8;               // 512: wide row tags (column phases): [64 lanes][4 x u16 row of the chunk] between the column words and the values
 constexpr int      kDictMax = 256;
 constexpr int      kYStageMax = 4096;   // most row sums a wavefront stages in LDS and writes out coalesced at the end of its chunk (32 KB of fp64)
 constexpr int      kWavesPerBlock = 1;   // converter / fix-up launches; the SpMV default: 1 wave per workgroup spreads the chunks most evenly over the CUs (profiles/r01_waves_per_block.log)
@@ -54,7 +59,7 @@ constexpr int64_t  kPlanRowBlock = 65536;   // the planner restarts a chunk at e
 constexpr int      kMaxWavesPerBlock = 16;   // SpMV workgroups of several consecutive chunks share an LDS window of x (cvr_options.waves_per_block)
 constexpr size_t   kLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 
-inline int group_bytes(bool f32, bool dict = false, bool c16 = false) { return dict ? kGroupBytesDict : c16 ? (f32 ? kGroupBytes32C16 : kGroupBytes64C16) : f32 ? kGroupBytes32 : kGroupBytes64; }
+inline int group_bytes(bool f32, bool dict = false, bool c16 = false, bool tag16 = false) { return (dict ? kGroupBytesDict : c16 ? (f32 ? kGroupBytes32C16 : kGroupBytes64C16) : f32 ? kGroupBytes32 : kGroupBytes64) + (tag16 ? kTagBytes : 0); }
 
 struct Shared { int64_t row, c0, c1; };
 

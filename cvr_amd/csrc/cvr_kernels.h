@@ -36,6 +36,10 @@ struct DeviceImage {
     uint32_t  phases = 1;
     uint32_t  phase_width = 0;      // columns per phase (multiple of 16)
     uint2    *desc2 = nullptr;      // [nchunks] {first entry of the chunk in the conversion-time segment table, rows with a segment in the chunk}
+    bool      tag16 = false;        // column phases: the rows of the pieces stand in 16-bit tags of their own (col_bits = 31)
+    uint32_t *pace = nullptr;       // column phases with long chunks: [8][phases][512] words of the SpMV kernel's pacing (spmv_seg_kernel; zeroed once), or null
+    uint32_t *pace_epoch = nullptr; // host: launches so far (the value a launch marks with)
+    uint32_t  piece_max = 0;        // column phases: (row, phase) segments are cut into pieces at the multiples of this many elements from the chunk's first (0 = whole segments)
     uint32_t  col_bits = 31;        // column phases: the LAST column word of a segment carries the chunk's row of the segment
                                     // above the column index: bits [col_bits, 31); bit 31 stays the end flag
     // hub table (cvr_hub.hip): the hub_n columns with the most non-zeros; a slot of such a column holds its table index and
@@ -147,9 +151,14 @@ hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, 
 // of its non-zeros (LDS histogram over coarse column bins); writes img.win_base
 hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st);
 
+// column panels, one panel per XCD at a time: what differs between the eight panels of one launch (device array of 8; nchunks = 0: none)
+struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *target; void *yext; uint32_t nchunks, ystage; };
 // y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0 and with_fixup)
-hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup = true);
+// multi != null: eight panels in one launch (plain layout, one chunk per workgroup, no LDS tables): workgroup b takes chunk b >> 3 of
+// panel b & 7; multi_chunks = the most chunks any of them has; img = any of them (for what they share); y_ext and with_fixup unused
+hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup = true, const PanelArgs *multi = nullptr, uint32_t multi_chunks = 0);
 size_t     spmv_lds_bytes(const DeviceImage &img);      // dynamic LDS of that launch
+inline size_t pace_words(uint32_t phases) { return (size_t)8 * phases * 512; }      // pacing buffer of an image with column phases
 
 // column panels: one fix-up launch for all panels (each with its own y_ext inside the partial-sum buffer)
 struct FixPart { const int64_t *shared; void *yext; uint32_t nshared, nrows; };

@@ -113,7 +113,7 @@ __device__ __forceinline__ T load_x(__amdgpu_buffer_rsrc_t rx, uint32_t col)
 // WIN: 0 = no LDS table, 1 = a window of x, 2 = a hub table (with or without a window behind it).
 template <typename T, int POL, int WIN>
 __device__ __forceinline__ X4<T> gather(__amdgpu_buffer_rsrc_t rx, const T *win, const u32x4 c, const uint32_t mask,
-                                        const uint32_t wbase, const uint32_t wn, const uint32_t hub_n)
+                                        const uint32_t wbase, const uint32_t wn, const uint32_t hub_n, const uint32_t zero_at)
 {
     X4<T>          r;
     const uint32_t col[4] = {c.x & mask, c.y & mask, c.z & mask, c.w & mask};
@@ -127,7 +127,7 @@ __device__ __forceinline__ X4<T> gather(__amdgpu_buffer_rsrc_t rx, const T *win,
         for (int j = 0; j < 4; j++) {
             const uint32_t rel = col[j] - wbase;
             r.v[j] = load_x<T, POL>(rx, rel < wn ? 0x3fffffffu : col[j]);   // 0x3fffffff * sizeof(T) is past num_records
-            r.w[j] = win[rel < wn ? rel : wn];
+            r.w[j] = win[rel < wn ? rel : zero_at];        // (zero_at = wn, except while the window is still on its way: then wn here is 0)
         }
     } else {
         // LDS: [hub table (hub_n) | window of x (wn) | zeros].  A slot of a hub column holds kHubBit and the table index.
@@ -247,14 +247,26 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
 
 // MW: more than one wavefront per workgroup (blockDim.x / 64 consecutive chunks share the workgroup's LDS window of x and its
 // dictionary copy); the single-wavefront form needs no barrier.
+// multi != null (column panels, one panel per XCD at a time): workgroup b works on panel b & 7 of the eight the launch covers --
+// the workgroups with equal b & 7 share an XCD under round-robin dealing, so that XCD's L2 only ever holds that panel's slice
+// of x -- and takes the panel's chunk b >> 3; what differs between the panels comes from multi[b & 7].
 template <typename T, int QA, int XPOL, int DEPTH, int WIN, bool DICT, bool MW, bool SEGT, bool C16>
 __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv_kernel(
-    const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint8_t *__restrict__ target,
-    const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks, uint32_t nblocks_per_xcd, int swz,
+    const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint8_t *__restrict__ target_a,
+    const T *__restrict__ x, T *__restrict__ yext_a, int G, uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz,
     uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict,
-    uint32_t ystage_n, const uint2 *__restrict__ desc2, uint32_t col_bits, const T *__restrict__ hub_x, uint32_t hub_n, uint32_t kstride,
-    const uint32_t *__restrict__ cbase, uint32_t pad_col)
+    uint32_t ystage_a, const uint2 *__restrict__ desc2, uint32_t col_bits, const T *__restrict__ hub_x, uint32_t hub_n, uint32_t kstride,
+    const uint32_t *__restrict__ cbase, uint32_t pad_col, const PanelArgs *__restrict__ multi)
 {
+    const uint8_t *__restrict__ stream = stream_a, *__restrict__ target = target_a;
+    const uint4 *__restrict__   desc = desc_a;
+    T *__restrict__             yext = yext_a;
+    uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = blockIdx.x;
+    if (multi) {
+        const PanelArgs pa = multi[blockIdx.x & 7u];
+        stream = pa.stream; desc = pa.desc; target = pa.target; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
+        bidx = blockIdx.x >> 3;
+    }
     constexpr int  GB = DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     constexpr bool kSync = WIN != 0 || (DICT && MW);      // LDS filled by other waves of the workgroup
     // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums (SEGT: row accumulators), the value dictionary (DICT),
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = MW ? threadIdx.x >> 6 : 0u;
-    const uint32_t blk = remap_block(blockIdx.x, nblocks_per_xcd, swz);
+    const uint32_t blk = remap_block(bidx, nblocks_per_xcd, swz);
     uint32_t       k = __builtin_amdgcn_readfirstlane(blk * nw + wv);
     if (!kSync && k >= nchunks) return;
     bool live = k < nchunks;
@@ -365,14 +377,14 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
             for (int i = 0; i < DEPTH; i++) Q[i].c = widen_cols(Q[i].c, cb, pad_col);
         }
 #pragma unroll
-        for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL, WIN>(rx, win, Q[i].c, cmask, wbase, wn, (hub_n + 3u) & ~3u);
+        for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, XPOL, WIN>(rx, win, Q[i].c, cmask, wbase, wn, (hub_n + 3u) & ~3u, wn);
 
         // every load is unconditional: past the end of the chunk the stream loads are out of range (zeros, no
         // traffic) and the gathers they feed all read x[0]
         for (int g = 0; g < G; g++) {
             const Group<T, DICT> Qn = load_group<T, SPOL, DICT, C16>(rs, voff, (uint32_t)(g + QN) * GB);
             if constexpr (C16) Q[DEPTH].c = widen_cols(Q[DEPTH].c, cb, pad_col);       // (arrived an iteration ago: the gather below needs it anyway)
-            const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn, (hub_n + 3u) & ~3u);
+            const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn, (hub_n + 3u) & ~3u, wn);
             sum_group<T, WIN, DICT, SEGT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged, col_bits);
 #pragma unroll
             for (int i = 0; i + 1 < QN; i++) Q[i] = Q[i + 1];
@@ -410,6 +422,221 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
         if (!live) break;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // this wave's stage and slots are reused by its next chunk
         begin_chunk();
+    }
+}
+
+// ---- column phases: the kernel of the resident layout -------------------------------------------------------------------
+// With column phases the last column word of EVERY piece of a lane stream -- a (row, phase) segment, or what a lane stole of
+// one -- carries the chunk's row it belongs to (bits [col_bits, 31)), so a lane needs no state but its running sum: when a
+// piece ends, the sum is added to the row's accumulator in LDS (ds_add, lanes in order, steps in order: reproducible) and
+// the rows leave coalesced at the end of the chunk.  No ballot, no rank, no hand-out counter, no steal slots, no `target`
+// (what spmv.cpp:1197-1224 and 1579-1651 do with records and t_rets): ~20 vector instructions per step where the general
+// kernel above issues ~70, which is what bounds a loop of 12 groups per wavefront with two wavefronts per SIMD.
+// TAG (wide row tags): the rows stand in 16-bit tags of their own, four per lane and group, instead of above the column index
+constexpr uint32_t kPaceSlots = 512;      // pacing buffer: [8 groups][phases][kPaceSlots] words, one per wavefront of a group (cvr_kernels.h: pace_words)
+template <typename T, bool DICT, bool TAG> struct SegGroup : Group<T, DICT> { uint32_t t01, t23; };
+
+template <typename T, bool DICT, bool TAG>
+__device__ __forceinline__ SegGroup<T, DICT, TAG> load_seg_group(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+    SegGroup<T, DICT, TAG> g;
+    constexpr uint32_t VB = kColsBytes + (TAG ? kTagBytes : 0);         // where the values / codes start
+    g.c = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kPolDefault));
+    if constexpr (TAG) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (voff >> 1) + kColsBytes, soff, kPolDefault));
+        g.t01 = t.x; g.t23 = t.y;
+    } else { g.t01 = 0; g.t23 = 0; }
+    if constexpr (DICT) {
+        g.codes = __builtin_amdgcn_raw_buffer_load_b32(r, (voff >> 2) + VB, soff, kPolDefault);
+    } else if constexpr (sizeof(T) == 8) {
+        g.lo = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, voff + VB, soff, kPolDefault));
+        g.hi = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, voff + VB + kLanes * 16, soff, kPolDefault));
+    } else {
+        g.v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + VB, soff, kPolDefault));
+    }
+    return g;
+}
+
+template <typename T, int WIN, bool DICT, bool TAG>
+__device__ __forceinline__ void sum_group_seg(T &acc, const SegGroup<T, DICT, TAG> &Q, const X4<T> &xq, const T *dict, T *ystage, uint32_t col_bits)
+{
+    T av[kGroupSteps];
+#pragma unroll
+    for (int j = 0; j < kGroupSteps; j++) av[j] = val_of<T, DICT>(Q, j, dict);
+#pragma unroll
+    for (int j = 0; j < kGroupSteps; j++) {
+        const uint32_t cw = col_of(Q.c, j);
+        acc = fma_t(av[j], x_of<T, WIN>(xq, j), acc);
+        if (cw & kEndBit) {
+            uint32_t row;
+            if constexpr (TAG) row = j == 0 ? Q.t01 & 0xffffu : j == 1 ? Q.t01 >> 16 : j == 2 ? Q.t23 & 0xffffu : Q.t23 >> 16;
+            else row = (cw & kColMask) >> col_bits;
+            lds_add(ystage + row, acc);
+            acc = 0;
+        }
+    }
+}
+
+// LOADER: the workgroup has extra wavefronts (behind its `nw` computing ones) that do nothing but bring the window of x into
+// LDS with LDS-direct loads (global_load_lds_dwordx4: 1 KiB per wave instruction, no registers) and leave.  The computing
+// wavefronts start their loop at once, gathering everything from global memory, and meet the loaders at one s_barrier in
+// front of group `gb`; from then on gathers inside the window are ds_reads.  (The window's 64 KiB take ~1.8 us to arrive --
+// bandwidth, not latency -- which every wavefront used to wait out in front of its first gather; and a wavefront's own loads
+// complete in order, so it cannot overlap that wait itself.)  Dictionary and zero slot are written by every computing
+// wavefront for itself (the same values to the same addresses), so nothing else needs a barrier.
+template <typename T, int QA, int DEPTH, int WIN, bool DICT, bool LOADER, bool TAG>
+__global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
+    const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks,
+    uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn,
+    const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_n, const uint2 *__restrict__ desc2, uint32_t col_bits, uint32_t nw_arg, int gb,
+    uint32_t *__restrict__ pace, uint32_t pw, uint32_t pad_col, int pace_lag, uint32_t nphases, uint32_t epoch)
+{
+    constexpr int GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
+    // LDS: [waves][ystage_n] row accumulators, the value dictionary (DICT), the x window and its zero slot (WIN; wn + 4 values)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t nw = LOADER ? nw_arg : blockDim.x >> 6;                // computing wavefronts = chunks of this workgroup
+    T *const ystage_all = reinterpret_cast<T *>(smem);
+    T *const dict = ystage_all + nw * ystage_n;
+    T *const win = dict + (DICT ? kDictMax : 0);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t blk = remap_block(blockIdx.x, nblocks_per_xcd, swz);
+    const uint32_t wbase = WIN != 0 && wn && blk * nw < nchunks ? win_base[blk] : 0u;
+
+    if constexpr (LOADER && WIN != 0) {
+        if (wv >= nw) {                                                   // a loader
+            constexpr uint32_t kPerLane = 16 / sizeof(T), kPerInst = kLanes * kPerLane;
+            const uint32_t lw = wv - nw, nl = (blockDim.x >> 6) - nw;
+            if (blk * nw < nchunks)
+                for (uint32_t i0 = lw * kPerInst; i0 < wn; i0 += nl * kPerInst) {
+                    const uint32_t i = i0 + lane * kPerLane;             // (wn and wbase are multiples of kPerLane: whole 16-byte pieces)
+                    if (i < wn)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + wbase + i),
+                                                         (__attribute__((address_space(3))) void *)(win + i0), 16, 0, 0);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            return;
+        }
+    }
+
+    const uint32_t k = __builtin_amdgcn_readfirstlane(blk * nw + wv);
+    const bool     live = k < nchunks;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes);
+    const uint32_t voff = lane * 16;
+    T *const       ystage = ystage_all + wv * ystage_n;
+
+    constexpr int  QN = DEPTH + QA;
+    SegGroup<T, DICT, TAG> Q[QN];
+    X4<T>          xs[DEPTH];
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G * GB), live ? (uint32_t)G * GB : 0u);
+#pragma unroll
+    for (int i = 0; i < QN; i++) Q[i] = load_seg_group<T, DICT, TAG>(rs, voff, (uint32_t)i * GB);
+    const uint4    d = live ? desc[k] : uint4{0, 0, 0, 0};
+    const uint32_t nri = live ? desc2[k].y : 0u;                      // rows with a piece in this chunk
+    if (live) for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);      // the row accumulators (+ the dump entry of the pad pieces)
+
+    if constexpr (LOADER && WIN != 0) {
+        if constexpr (DICT)
+            for (uint32_t i = lane; i < (uint32_t)kDictMax; i += kLanes) dict[i] = i < ndict ? dict_g[i] : T(0);
+        if (lane < 4) win[wn + lane] = T(0);
+    } else {
+        if constexpr (DICT)
+            for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += blockDim.x) dict[i] = i < ndict ? dict_g[i] : T(0);
+        if constexpr (WIN != 0) {
+            constexpr uint32_t kPer = 16 / sizeof(T);
+            constexpr int  kBatch = 8;
+            const uint32_t tstep = blockDim.x * kPer;
+            for (uint32_t i0 = threadIdx.x * kPer; i0 < wn; i0 += tstep * kBatch) {
+                u32x4 q[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) {
+                    const uint32_t i = i0 + u * tstep;
+                    q[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, i < wn ? (wbase + i) * (uint32_t)sizeof(T) : 0xfffffff0u, 0, kPolDefault));
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) if (i0 + u * tstep < wn) *reinterpret_cast<u32x4 *>(win + i0 + u * tstep) = q[u];
+            }
+            if (threadIdx.x < 4) win[wn + threadIdx.x] = T(0);
+        }
+        __syncthreads();
+    }
+    uint32_t wn_eff = LOADER ? 0u : wn;             // LOADER: the window is not there yet: everything through the buffer descriptor
+    if (!live && pace && lane == 0 && ((gridDim.x - (blockIdx.x & 7u) + 7u) >> 3) * nw <= kPaceSlots)       // (a wavefront without a chunk is out of every phase at once)
+        for (uint32_t p = 0; p < nphases; p++)
+            __hip_atomic_store(pace + ((size_t)(blockIdx.x & 7u) * nphases + p) * kPaceSlots + (blockIdx.x >> 3) * nw + wv, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (LOADER && WIN != 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // this wavefront's own dictionary / zero-slot writes before its reads
+        if (!live) { __builtin_amdgcn_s_barrier(); return; }
+    } else {
+        if (!live) return;
+    }
+
+    // Pacing (long chunks: `pace` != null).  Column phases keep an XCD's L2 on one slice of x only while its wavefronts walk
+    // through the phases together; over hundreds of steps they drift apart.  The wavefronts of the workgroups with equal
+    // blockIdx & 7 (one XCD under round-robin dealing: for speed only) therefore form a group: a wavefront marks every phase
+    // it has left (one word per wavefront and phase, plain write-through stores of the launch's epoch: no atomics, nothing to
+    // zero between launches; the phase is read off lane 0's column) and, before it gathers from phase q, looks whether the
+    // whole group has left phase q - pace_lag, sleeping a little while it has not.  A hint, never a dependency: the wait is
+    // bounded and y does not depend on it.
+    const uint32_t pace_slot = (blockIdx.x >> 3) * nw + wv, pace_n = ((gridDim.x - (blockIdx.x & 7u) + 7u) >> 3) * nw;
+    uint32_t      *pace_g = pace ? pace + (size_t)(blockIdx.x & 7u) * nphases * kPaceSlots : nullptr;
+    if (pace && pace_n > kPaceSlots) pace_g = nullptr;
+    uint32_t       cur_phase = 0, next_bound = pw;
+    T acc = 0;
+#pragma unroll
+    for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, kPolDefault, WIN>(rx, win, Q[i].c, cmask, wbase, wn_eff, 0u, wn);
+    for (int g = 0; g < G; g++) {
+        if (pace_g) {
+            const uint32_t c0 = __builtin_amdgcn_readfirstlane(Q[DEPTH].c.x & cmask);
+            if (c0 != pad_col && c0 >= next_bound) {                  // lane 0 has moved on to a later phase
+                uint32_t q = cur_phase;
+                while (c0 >= next_bound) { q++; next_bound += pw; }
+                if (lane == 0)
+                    for (uint32_t p = cur_phase; p < q; p++) __hip_atomic_store(pace_g + (size_t)p * kPaceSlots + pace_slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cur_phase = q;
+                if ((int)q >= pace_lag) {
+                    const uint32_t *row = pace_g + (size_t)(q - (uint32_t)pace_lag) * kPaceSlots;
+                    for (int spin = 0; spin < 64; spin++) {
+                        bool behind = false;
+#pragma unroll
+                        for (uint32_t u = 0; u < kPaceSlots / kLanes; u++) {
+                            const uint32_t i = u * kLanes + lane;
+                            const uint32_t v = __hip_atomic_load(row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            behind |= i < pace_n && v != epoch;
+                        }
+                        if (!__ballot(behind)) break;
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                }
+            }
+        }
+        if constexpr (LOADER && WIN != 0) {
+            if (g == gb) {                          // the window has arrived (the loaders waited for their loads in front of this barrier)
+                asm volatile("s_barrier" ::: "memory");
+                wn_eff = wn;
+            }
+        }
+        const SegGroup<T, DICT, TAG> Qn = load_seg_group<T, DICT, TAG>(rs, voff, (uint32_t)(g + QN) * GB);
+        const X4<T>          xn = gather<T, kPolDefault, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn_eff, 0u, wn);
+        sum_group_seg<T, WIN, DICT, TAG>(acc, Q[0], xs[0], dict, ystage, col_bits);
+#pragma unroll
+        for (int i = 0; i + 1 < QN; i++) Q[i] = Q[i + 1];
+        Q[QN - 1] = Qn;
+#pragma unroll
+        for (int i = 0; i + 1 < DEPTH; i++) xs[i] = xs[i + 1];
+        xs[DEPTH - 1] = xn;
+    }
+    if constexpr (LOADER && WIN != 0) { if (gb >= G) asm volatile("s_barrier" ::: "memory"); }
+    if (pace_g && lane == 0)        // out of every phase
+        for (uint32_t p = cur_phase; p < nphases; p++) __hip_atomic_store(pace_g + (size_t)p * kPaceSlots + pace_slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t i = lane; i < nri; i += kLanes) {
+        const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
+        store_y(yext + dst, ystage[i]);
     }
 }
 
@@ -517,18 +744,19 @@ size_t spmv_lds_bytes(const DeviceImage &img)
 {
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;
     const bool     use_win = (img.win_elems > 0 && img.win_base != nullptr) || img.hub_n > 0;
-    return (size_t)(wpb * (kLanes + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? ((img.hub_n + 3u) & ~3u) + img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8);
+    const uint32_t slots = img.phases > 1 ? 0u : (uint32_t)kLanes;      // (column phases: no steal slots, spmv_seg_kernel)
+    return (size_t)(wpb * (slots + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? ((img.hub_n + 3u) & ~3u) + img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8);
 }
 
-hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup)
+hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup, const PanelArgs *multi, uint32_t multi_chunks)
 {
-    if (img.nchunks == 0) return hipSuccess;
+    if (img.nchunks == 0 && !multi) return hipSuccess;
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;                     // consecutive chunks (wavefronts) per workgroup
     uint32_t       nblocks = (img.nchunks + wpb - 1) / wpb;
     // a hub table without a per-workgroup window: persistent workgroups (as many as fit the 256 CUs with this much LDS), each
     // staging the table once and taking chunk groups blk, blk + grid, ...
     uint32_t       kstride = 0;
-    if (img.win_elems == 0 && img.xcd_swizzle != 2 && img.phases <= 1) {
+    if (img.win_elems == 0 && img.xcd_swizzle != 2 && img.phases <= 1 && !multi) {
         // persistent workgroups: as many as are resident at once, each taking chunk groups blk, blk + grid, ...  With a hub
         // table they stage it once.  Without one they were measured on the banded shape (CVR_PERSIST_WAVES = 8 .. 32
         // wavefronts per CU: 204-230 us against 204-208 us for one launch per chunk, profiles/r02_persistent_plain_layout.log)
@@ -542,7 +770,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
         }
     }
     const uint32_t per_xcd = (nblocks + 7) / 8;
-    const uint32_t grid = img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;
+    const uint32_t grid = multi ? multi_chunks * 8 : img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;      // (multi: `img` is one of the eight panels: what they share comes from it)
     const dim3     block(kLanes * wpb);
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
     if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
@@ -556,9 +784,9 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_LAUNCH(T, SP, D, W, DI, MW, SG)                                                                       \
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, SG, false>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
-                       img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
-                       static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(img.hub_x), img.hub_n, kstride, img.cbase, img.pad_col)
-#define CVR_PICK_SG(T, SP, D, W, DI, MW) do { if (img.phases > 1) CVR_LAUNCH(T, SP, D, W, DI, MW, true); else CVR_LAUNCH(T, SP, D, W, DI, MW, false); } while (0)
+                       multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
+                       static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(img.hub_x), img.hub_n, kstride, img.cbase, img.pad_col, multi)
+#define CVR_PICK_SG(T, SP, D, W, DI, MW) CVR_LAUNCH(T, SP, D, W, DI, MW, false)
 #define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_PICK_SG(T, SP, D, W, DI, true); else CVR_PICK_SG(T, SP, D, W, DI, false); } while (0)
 #define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_PICK_MW(T, SP, D, W, true); else CVR_PICK_MW(T, SP, D, W, false); } while (0)
 #define CVR_PICK_W(T, SP, D)     do { if (use_win && img.hub_n) CVR_PICK_DI(T, SP, D, 2); else if (use_win) CVR_PICK_DI(T, SP, D, 1); else CVR_PICK_DI(T, SP, D, 0); } while (0)
@@ -568,11 +796,41 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, 0, false, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, 0u,          \
-                       static_cast<const T *>(nullptr), 0u, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col)
+                       static_cast<const T *>(nullptr), 0u, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col, (const PanelArgs *)nullptr)
 #define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
                              else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
-    if (img.c16 && !use_win && !use_dict && wpb == 1 && img.phases <= 1) { if (img.f32) CVR_PICK_C16(float); else CVR_PICK_C16(double); }
+#define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd, img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
+                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch
+#define CVR_SEG(T, SP, D, W, DI, LD)                                                                               \
+    do {                                                                                                           \
+        const dim3 sblock(kLanes * (wpb + (LD ? loaders : 0u)));                                                   \
+        if (img.tag16) hipLaunchKernelGGL((spmv_seg_kernel<T, SP, D, W, DI, LD, true>), dim3(grid), sblock, lds, st, CVR_SEG_ARGS(T)); \
+        else hipLaunchKernelGGL((spmv_seg_kernel<T, SP, D, W, DI, LD, false>), dim3(grid), sblock, lds, st, CVR_SEG_ARGS(T)); \
+    } while (0)
+#define CVR_SEG_DI(T, SP, D, W, LD) do { if (use_dict) CVR_SEG(T, SP, D, W, true, LD); else CVR_SEG(T, SP, D, W, false, LD); } while (0)
+#define CVR_SEG_W(T, SP, D)     do { if (use_win && loaders) CVR_SEG_DI(T, SP, D, 1, true); else if (use_win) CVR_SEG_DI(T, SP, D, 1, false); else CVR_SEG_DI(T, SP, D, 0, false); } while (0)
+#define CVR_SEG_D(T, SP)        do { if (img.depth == 2) CVR_SEG_W(T, SP, 2); else CVR_SEG_W(T, SP, 1); } while (0)
+#define CVR_SEG_SP(T)           do { if (img.stream_ahead >= 2) CVR_SEG_D(T, 3); else CVR_SEG_D(T, 1); } while (0)
+    // column phases with a window: `loaders` extra wavefronts per workgroup bring the window in while the others start (spmv_seg_kernel)
+    static const int env_loaders = [] { const char *e = getenv("CVR_WIN_LOADERS"); return e ? atoi(e) : -1; }();
+    static const int env_group = [] { const char *e = getenv("CVR_WIN_GROUP"); return e ? atoi(e) : -1; }();
+    uint32_t  loaders = img.phases > 1 && use_win ? (env_loaders >= 0 ? (uint32_t)env_loaders : 2u) : 0u;
+    if (wpb + loaders > (uint32_t)kMaxWavesPerBlock) loaders = wpb < (uint32_t)kMaxWavesPerBlock ? (uint32_t)kMaxWavesPerBlock - wpb : 0u;
+    const int win_group = env_group >= 0 ? env_group : 1;
+    // pacing of long chunks (spmv_seg_kernel): the counters are zeroed in front of every launch
+    static const int env_pace = [] { const char *e = getenv("CVR_PACE_LAG"); return e ? atoi(e) : -1; }();
+    const int pace_lag = env_pace >= 0 ? env_pace : 2;
+    uint32_t *pace = img.phases > 1 && img.pace && pace_lag > 0 ? img.pace : nullptr;
+    const uint32_t epoch = pace ? ++*img.pace_epoch : 0u;        // (a launch marks with its own number: nothing to zero in between)
+    if (img.phases > 1) { if (img.f32) CVR_SEG_SP(float); else CVR_SEG_SP(double); }
+    else if (img.c16 && !use_win && !use_dict && wpb == 1 && img.phases <= 1 && !multi) { if (img.f32) CVR_PICK_C16(float); else CVR_PICK_C16(double); }
     else if (img.f32) CVR_PICK_SP(float); else CVR_PICK_SP(double);
+#undef CVR_SEG_SP
+#undef CVR_SEG_D
+#undef CVR_SEG_W
+#undef CVR_SEG_DI
+#undef CVR_SEG
+#undef CVR_SEG_ARGS
 #undef CVR_PICK_C16
 #undef CVR_LAUNCH_C16
 #undef CVR_PICK_SP

@@ -70,12 +70,8 @@ typedef struct {
     int32_t x_window;          /* values of x each workgroup stages in LDS with coalesced loads */
                                /* and serves its gathers from (cut to what fits the 160 KiB of */
                                /* LDS beside the row-sum stage); 0 = off (<0 = default = off)  */
-    /* tuning / profiling knobs (tools/sweep.py); 0 = default */
-    int32_t stream_ahead;      /* groups (of 4 steps) the matrix stream runs ahead of the x gather: 0 / 1 = one, >= 2 = three */
     int32_t waves_per_block;   /* wavefronts (= consecutive chunks) per SpMV workgroup, 1..16; 0 = default (1).  More than */
                                /* one pays only with x_window: the chunks of a workgroup share the staged window          */
-    int32_t gather_depth;      /* groups (of 4 steps) the x gather runs ahead of the FMAs: 1 or 2 */
-    int32_t debug_col_mask;    /* profiling only: folds the gather onto a 2^k-entry table (wrong y) */
     int32_t col_panels;        /* column panels (each with its slice of x L2-resident, partial sums combined by a second
                                   kernel): 1 = off, <0 = auto (only when x is several times the L2), else the count   */
     int32_t value_dict;        /* value dictionary: one byte per slot instead of the value when the matrix has at most
@@ -86,8 +82,6 @@ typedef struct {
                                   written once.  For matrices whose chunks are all resident at once and whose x is larger
                                   than an L2 (web-Google: 7.3 MB); needs ascending columns inside every row.  0 / 1 = off,
                                   <0 = auto (default)                                                                     */
-    int32_t layout_auto_resident;   /* internal (set by cvr_create, ignored on input): the automatic layout chose the
-                                  "resident" form -- every workgroup on a CU of its own at once                          */
     int32_t hub_table;         /* hub table: the columns with the most non-zeros (at most this many; what fits the LDS) get
                                   their x values compacted before every SpMV and staged in LDS by every workgroup (8 chunks),
                                   their gathers become ds_reads.  For power-law matrices whose x does not fit an L2.
@@ -98,13 +92,27 @@ typedef struct {
     int32_t hub_reorder;       /* with a hub table: re-order the whole of x by column popularity before every SpMV (every column
                                   index of the image is the column's rank), so that the popular columns share cache lines.
                                   0 = off, 1 = on, <0 = auto (default): when x is at least 24 MB; never inside column panels   */
-    int32_t reserved4;
+    int32_t row_tags16;        /* column phases: the chunk's row of every piece in a 16-bit tag of its own (2 more bytes per slot)
+                                  instead of above the column index in the piece's last column word: lifts the limit of
+                                  2^(31 - bits of ncols) rows per chunk.  0 = off, 1 = on, <0 = auto (default): when the
+                                  chunks the layout wants hold more rows than the column word has room for                  */
+    int32_t row_bands;         /* row bands: the rows are cut into this many consecutive bands, each a resident launch of its own
+                                  (every workgroup on a CU of its own, its rows' sums in LDS, column phases over the whole of x):
+                                  the 2-D form for matrices too large for one resident pass.  1 = off, <0 = auto (default)   */
+    int32_t piece_max;         /* column phases: (row, phase) segments are cut into pieces of at most this many elements (at the
+                                  multiples of it from the chunk's first element), so that no lane sits on one long row's
+                                  segment while the others move on to the next column ranges.  0 = whole segments,
+                                  <0 = auto (default): 8 when the chunks are long enough for a lane to fall a phase behind     */
+    int32_t reserved[5];       /* 0 */
 } cvr_options;
 /* Automatic layout: with steps_per_chunk = 0, waves_per_block = 0, x_window < 0 and col_phases < 0 (the defaults) cvr_create
  * looks at the uploaded CSR on the device (are the rows sorted by column? which share of the non-zeros lies near the
  * diagonal?) and, for matrices whose chunks can all be resident at once, picks 6-8 chunks per workgroup sharing a 64-KiB LDS
  * window of x and/or column phases; everything else keeps one chunk per workgroup.  CVR_NO_AUTO_LAYOUT=1 in the environment
- * or any explicit value of those four options switches it off. */
+ * or any explicit value of those four options switches it off.
+ * Profiling knobs are not part of this struct: CVR_DEBUG_STREAM_AHEAD (groups the matrix stream runs ahead of the gather: 1 or
+ * 3), CVR_DEBUG_GATHER_DEPTH (1 or 2 gather batches in flight) and CVR_DEBUG_COL_MASK (folds the gather onto a 2^k-entry
+ * table: wrong results, timing only) are read from the environment by cvr_create. */
 
 typedef struct {
     int32_t iters;
@@ -135,12 +143,14 @@ typedef struct {
     int32_t hub_entries;           /* hub table: columns staged in LDS (0 = none)                                          */
     int32_t narrow_cols;           /* 1: the image stores 16-bit column offsets (narrow chunks)                             */
     int32_t hub_reorder;           /* 1: the image's column indices are popularity ranks, x is re-ordered before every SpMV  */
-    int32_t reserved5;
+    int32_t row_tags16;            /* 1: the image carries 16-bit row tags (column phases with long chunks / wide matrices)   */
     double  hub_share;             /* share of the non-zeros in the hub columns that were (or could have been) chosen      */
     double  hub_select_s;          /* the device pass that counted and ranked the columns (0 if not run)                  */
     double  probe_s;               /* automatic layout: the device pass over the CSR (sortedness, near-diagonal share), 0 if not run */
     double  dict_s;                /* the value-dictionary detection pass over the uploaded values (part of upload_s) */
     double  preprocess_wall_s;     /* host wall time of cvr_preprocess: convert_s (device events) + its temporary allocations and the final sync */
+    int32_t row_bands;             /* 1, or the number of row bands (resident launches per SpMV)                                           */
+    int32_t piece_max;             /* column phases: longest piece of a lane stream (0 = whole (row, phase) segments)                     */
 } cvr_info;
 
 void        cvr_default_options(cvr_options *opt);
@@ -149,8 +159,9 @@ const char *cvr_version(void);
 int         cvr_device_count(void);                     /* 0 when there is no usable HIP device */
 
 /* ---- the handle: one matrix (or one row shard of it) on one GPU ------------------------------ */
-/* Validates the CSR, plans the chunks on the host, uploads the CSR.  (pre_processing's setup half:
- * chunk partition + row search, spmv.cpp:584-694.) */
+/* Validates the CSR, uploads it, looks at it on the device to choose the layout, plans the chunks (on the device from
+ * 200 000 rows on, else on the host: the same plan).  (pre_processing's setup half: chunk partition + row search,
+ * spmv.cpp:584-694.) */
 int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt);
 /* CSR -> CVR64 on the device (the tracker loop, spmv.cpp:711-1000); `seconds` = what the reference
  * prints at spmv.cpp:1009.  Frees the device copy of the CSR unless keep_csr != 0. */

@@ -146,7 +146,19 @@ int orc_cvr64_build_all(int64_t nrows, int64_t ncols, const int64_t *rp, const i
 int orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
                          int S, int64_t thr, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int reorder, int narrow, orc_cvr64 *c)
 {
+    return orc_cvr64_build_tag(nrows, ncols, rp, cols, vals, is_f32, S, thr, use_dict, phases, max_rows, hub_max, reorder, narrow, 0, 0, c);
+}
+
+/* tag16 != 0 (phases > 1): wide row tags -- the chunk's row of every piece stands in a 16-bit tag of its own ([64 lanes][4 x u16]
+ * behind the group's column words) instead of above the column index: no limit from the width of the column index.
+ * piece_max > 0 (phases > 1): a (row, phase) segment is cut into pieces at the multiples of piece_max elements counted from the
+ * chunk's first element, so that no lane holds a piece for longer than that many steps */
+int orc_cvr64_build_tag(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
+                        int S, int64_t thr, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int reorder, int narrow, int tag16, int64_t piece_max, orc_cvr64 *c)
+{
     memset(c, 0, sizeof(*c));
+    if (tag16 && phases <= 1) tag16 = 0;
+    c->tag16 = tag16 != 0;
     if (narrow && (use_dict || phases > 1 || hub_max > 0)) return -8;
     c->narrow = narrow != 0;
     int32_t *hub_index = NULL;
@@ -174,8 +186,10 @@ int orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rp, const 
     if (pw < 16) pw = 16;
     int col_bits = 1;                      /* phases: the last column word of a segment carries the chunk's row above the column index */
     while (((int64_t)1 << col_bits) <= ncols) col_bits++;
+    if (c->tag16) col_bits = 31;
     c->col_bits = phases > 1 ? col_bits : 31;
-    if (phases > 1 && (col_bits >= 31 || max_rows > (((int64_t)1 << (31 - col_bits)) - 1) || max_rows <= 0)) return -7;
+    if (phases > 1 && !c->tag16 && (col_bits >= 31 || max_rows > (((int64_t)1 << (31 - col_bits)) - 1) || max_rows <= 0)) return -7;
+    if (c->tag16 && (max_rows <= 0 || max_rows > 65534)) return -7;
     if (S < 4 || S % 4) return -1;
     const int64_t cap = (int64_t)W * S;
     if (thr <= 0) thr = cap / 4;
@@ -189,8 +203,8 @@ int orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rp, const 
         c->ndict = build_dict(vals, is_f32, nrows ? rp[0] : 0, nrows ? rp[nrows] : 0, c->dict);
         if (c->ndict < 0) { free(ch); return -5; }
     }
-    const size_t gb = c->ndict ? 1280 : c->narrow ? (is_f32 ? 1536 : 2560) : is_f32 ? 2048 : 3072;
-    const size_t cbytes = c->narrow ? 512 : 1024;          /* column part of a group */
+    const size_t gb = (c->ndict ? 1280 : c->narrow ? (is_f32 ? 1536 : 2560) : is_f32 ? 2048 : 3072) + (c->tag16 ? 512 : 0);
+    const size_t cbytes = (c->narrow ? 512 : 1024) + (c->tag16 ? 512 : 0);          /* what stands in front of a group's values: column part (+ wide row tags) */
     c->image_bytes = (int64_t)((size_t)NC * G * gb);
     if (c->narrow) c->cbase = (uint32_t *)calloc((size_t)NC + 1, sizeof(uint32_t));
     c->image = (uint8_t *)calloc((size_t)c->image_bytes + 16, 1);
@@ -248,7 +262,12 @@ int orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rp, const 
                     hi = lo;
                     while (hi < z && cols[hi] < (int64_t)(p + 1) * pw) hi++;
                     for (int64_t j = a + 1; j < z; j++) if (cols[j] < cols[j - 1]) rc = -6;      /* unsorted row */
-                    if (hi > lo) { seg_pos[n] = lo; seg_cnt[n] = hi - lo; seg_r[n] = r - q->row_first; tot += hi - lo; n++; }
+                    for (int64_t u = lo; u < hi;) {
+                        int64_t v = hi;
+                        if (piece_max > 0) { const int64_t nxt = ((u - b) / piece_max + 1) * piece_max + b; if (nxt < v) v = nxt; }
+                        seg_pos[n] = u; seg_cnt[n] = v - u; seg_r[n] = r - q->row_first; tot += v - u; n++;
+                        u = v;
+                    }
                 }
         }
         if (q->pad > 0) { seg_pos[n] = -1; seg_cnt[n] = q->pad; seg_r[n] = q->nrows_in; tot += q->pad; n++; }
@@ -275,12 +294,12 @@ int orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rp, const 
             const int64_t ave = S - i;      /* == sum(cnt)/64 */
             for (int l = 0; l < W; l++) {   /* empty lanes in lane order (spmv.cpp:814-816) */
                 if (cnt[l] != 0) continue;
-                if (fed < n) { pos[l] = seg_pos[fed]; cnt[l] = seg_cnt[fed]; tag[l] = phases > 1 ? (uint32_t)seg_r[fed] << col_bits : 0; fed++; }     /* spmv.cpp:821-868 */
+                if (fed < n) { pos[l] = seg_pos[fed]; cnt[l] = seg_cnt[fed]; tag[l] = phases > 1 ? (c->tag16 ? (uint32_t)seg_r[fed] : (uint32_t)seg_r[fed] << col_bits) : 0; fed++; }     /* spmv.cpp:821-868 */
                 else {
                     int v = 0;
                     while (v < W && cnt[v] <= ave) v++;      /* first over-full lane (spmv.cpp:876-879) */
                     if (v == W) { fprintf(stderr, "cvr64 mirror: no victim\n"); rc = -3; break; }
-                    pos[l] = pos[v]; cnt[l] = ave; tag[l] = 0;   /* the stealer takes the FIRST ave (spmv.cpp:927-931) */
+                    pos[l] = pos[v]; cnt[l] = ave; tag[l] = tag[v];   /* the stealer takes the FIRST ave (spmv.cpp:927-931); phases: the stolen piece keeps the row of the victim's segment */
                     if (pos[v] >= 0) pos[v] += ave;
                     cnt[v] -= ave;
                     c->target[k * W + l] = (uint8_t)v;
@@ -296,7 +315,8 @@ int orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rp, const 
                     v = is_f32 ? (double)((const float *)vals)[pos[l]] : ((const double *)vals)[pos[l]];
                     pos[l]++;
                 }
-                if (cnt[l] == 1) col |= 0x80000000u | tag[l];
+                if (cnt[l] == 1) col |= 0x80000000u | (c->tag16 ? 0u : tag[l]);
+                if (c->tag16) ((uint16_t *)(grp + 1024))[l * 4 + j] = (uint16_t)(cnt[l] == 1 ? tag[l] : 0u);
                 if (c->narrow) {
                     const uint32_t cc = col & 0x7fffffffu;
                     ((uint16_t *)grp)[l * 4 + j] = (uint16_t)((cc == (uint32_t)ncols ? 0x7fffu : cc - c->cbase[k]) | (col >> 31 << 15));
@@ -334,13 +354,16 @@ void orc_cvr64_free(orc_cvr64 *c)
  *   ... ends as the last segments are handed out  -> y_ext[dest(cur)] = acc; the lane turns stealer
  *   ... ends after the last segment was handed out-> slot[lane] = acc;      the lane turns stealer
  *   end of chunk: slot[target[lane]] += acc of lanes that stole; owners store their slot
+ *   column phases: none of the above -- the last column word of EVERY piece (a segment, or what a lane stole of one) carries
+ *   the chunk's row it belongs to, and the piece's sum is added to that row's accumulator when the piece ends (step by step,
+ *   lanes in order), the accumulators are written out at the end of the chunk
  *   fix-up: y[row] = carry_tail(c0) + sum of carry_head(c) for c0 < c <= c1, in chunk order */
 void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
 {
     const int S = c->S, G = S / 4;
     const int64_t NC = c->nchunks, nrows = c->nrows;
-    const size_t gb = c->ndict ? 1280 : c->narrow ? (c->is_f32 ? 1536 : 2560) : c->is_f32 ? 2048 : 3072;
-    const size_t cbytes = c->narrow ? 512 : 1024;
+    const size_t gb = (c->ndict ? 1280 : c->narrow ? (c->is_f32 ? 1536 : 2560) : c->is_f32 ? 2048 : 3072) + (c->tag16 ? 512 : 0);
+    const size_t cbytes = (c->narrow ? 512 : 1024) + (c->tag16 ? 512 : 0);
     const size_t next = (size_t)(nrows + 1 + 2 * NC);
     const int ph = c->phases > 1;          /* column phases: a segment's sum is ADDED to its row's accumulator (LDS on the device) */
     double *yext = (double *)calloc(next + 1, sizeof(double));
@@ -348,12 +371,12 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
     for (int64_t k = 0; k < NC; k++) {
         const uint32_t row_first = c->desc[4 * k], n = c->desc[4 * k + 1], hd = c->desc[4 * k + 2], ld = c->desc[4 * k + 3];
         const uint32_t nri = ph ? c->nrows_in[k] : 0;
-        const uint32_t cmask = ph ? (1u << c->col_bits) - 1u : 0x7fffffffu;
+        const uint32_t cmask = ph && !c->tag16 ? (1u << c->col_bits) - 1u : 0x7fffffffu;
         const uint32_t nd = ph ? nri : n;      /* DEST is indexed by the segment (implicit rows) or by the chunk's row (phases) */
 #define DEST(q) ((q) == 0 ? hd : (q) == nd - 1 ? ld : row_first + (q))
 #define ADDTO(dst, v) do { if (c->is_f32) (dst) = (double)((float)(dst) + (float)(v)); else (dst) += (v); } while (0)
         double acc[W], slot[W];
-        uint32_t cur[W], rowtag[W], ownrow[W];
+        uint32_t cur[W], rowtag[W];
         int feeding[W], own[W];
         uint32_t fed = n < W ? n : W;
         for (int l = 0; l < W; l++) { acc[l] = 0; slot[l] = 0; feeding[l] = (uint32_t)l < fed; own[l] = 0; cur[l] = (uint32_t)l; }
@@ -373,7 +396,7 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
                 if (c->hub_n && (col & 0x40000000u)) col = (uint32_t)c->hub_cols[col & 0x3fffffffu];     /* hub slot: rank -> column */
                 else if (c->order_n && col < (uint32_t)c->order_n) col = (uint32_t)c->hub_cols[col];      /* re-ordered x: rank -> column (the pad column stays) */
                 flagged[l] = cw >> 31;
-                rowtag[l] = ph ? (cw & 0x7fffffffu) >> c->col_bits : 0;
+                rowtag[l] = !ph ? 0 : c->tag16 ? ((const uint16_t *)(grp + 1024))[l * 4 + j] : (cw & 0x7fffffffu) >> c->col_bits;
                 if (c->is_f32) {
                     float v;
                     if (c->ndict) { const uint32_t u = (uint32_t)c->dict[(grp + cbytes)[l * 4 + j]]; memcpy(&v, &u, 4); }
@@ -386,11 +409,14 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
                     acc[l] = fma(v, ((const double *)xv)[col], acc[l]);
                 }
             }
-            if (!tail) {
+            if (ph) {          /* column phases: every piece -- fed or stolen -- carries its row and adds its sum to that row's accumulator when it ends */
+                for (int l = 0; l < W; l++)
+                    if (flagged[l]) { ADDTO(yloc[rowtag[l]], acc[l]); acc[l] = 0; }
+            } else if (!tail) {
                 uint32_t rank = 0;
                 for (int l = 0; l < W; l++) {
                     if (!flagged[l]) continue;
-                    if (ph) ADDTO(yloc[rowtag[l]], acc[l]); else yext[DEST(cur[l])] = acc[l];
+                    yext[DEST(cur[l])] = acc[l];
                     acc[l] = 0;
                     if (fed + rank < n) cur[l] = fed + rank; else feeding[l] = 0;
                     rank++;
@@ -399,16 +425,16 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
                 if (fed >= n) { fed = n; tail = 1; }
             } else {
                 for (int l = 0; l < W; l++)
-                    if (flagged[l] && feeding[l]) { slot[l] = acc[l]; acc[l] = 0; feeding[l] = 0; own[l] = 1; ownrow[l] = rowtag[l]; }
+                    if (flagged[l] && feeding[l]) { slot[l] = acc[l]; acc[l] = 0; feeding[l] = 0; own[l] = 1; }
             }
         }
-        for (int l = 0; l < W; l++) {
+        for (int l = 0; l < W && !ph; l++) {
             const int t = c->target[k * W + l];
             if (t == l) continue;
             ADDTO(slot[t], acc[l]);
         }
-        for (int l = 0; l < W; l++)
-            if (own[l]) { if (ph) ADDTO(yloc[ownrow[l]], slot[l]); else yext[DEST(cur[l])] = slot[l]; }
+        for (int l = 0; l < W && !ph; l++)
+            if (own[l]) yext[DEST(cur[l])] = slot[l];
         if (ph) for (uint32_t i = 0; i < nri; i++) yext[DEST(i)] = yloc[i];
 #undef DEST
 #undef ADDTO

@@ -100,6 +100,7 @@ typedef struct {
     int       order_n;       /* 0, or ncols: every column index of the image is a popularity rank (hub_cols then lists all columns) */
     int       narrow;        /* 1: narrow chunks -- groups hold [64][4] u16 column offsets from cbase[k] (512 B) before the values */
     uint32_t *cbase;         /* narrow: [nchunks] smallest column of the chunk                                              */
+    int       tag16;         /* phases > 1: the rows of the pieces stand in [64][4] u16 tags (512 B) behind the column words (col_bits = 31) */
 } orc_cvr64;
 
 int  orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
@@ -119,6 +120,10 @@ int  orc_cvr64_build_all(int64_t nrows, int64_t ncols, const int64_t *rowptr, co
 /* the same with the whole of x re-ordered by popularity (reorder != 0, needs hub_max > 0) */
 int  orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
                           int S, int64_t split_threshold, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int reorder, int narrow, orc_cvr64 *out);
+/* the same with wide row tags (tag16 != 0, phases > 1 only): rows of the pieces in 16-bit tags of their own; and with the
+ * (row, phase) segments cut into pieces of at most piece_max elements (piece_max > 0) */
+int  orc_cvr64_build_tag(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
+                         int S, int64_t split_threshold, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int reorder, int narrow, int tag16, int64_t piece_max, orc_cvr64 *out);
 void orc_cvr64_free(orc_cvr64 *c);
 /* interpret the image exactly as the HIP kernel does (same per-lane order of operations) */
 void orc_cvr64_spmv(const orc_cvr64 *c, const void *x, void *y);

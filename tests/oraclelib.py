@@ -30,7 +30,7 @@ class OrcCvr64(C.Structure):
                 ("ndict", C.c_int), ("dict", C.c_uint64 * 256), ("phases", C.c_int),
                 ("seg_off", C.POINTER(C.c_uint32)), ("seg_row", C.POINTER(C.c_uint16)), ("nrows_in", C.POINTER(C.c_uint32)),
                 ("col_bits", C.c_int), ("hub_n", C.c_int), ("hub_cols", C.POINTER(C.c_int32)),
-                ("order_n", C.c_int), ("narrow", C.c_int), ("cbase", C.POINTER(C.c_uint32))]
+                ("order_n", C.c_int), ("narrow", C.c_int), ("cbase", C.POINTER(C.c_uint32)), ("tag16", C.c_int)]
 
 
 def lib():
@@ -58,6 +58,8 @@ def lib():
                                              C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.POINTER(OrcCvr64)]
         _lib.orc_cvr64_build_full.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(OrcCvr64)]
+        _lib.orc_cvr64_build_tag.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(OrcCvr64)]
         _lib.orc_write_mtx_pattern.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     return _lib
 
@@ -176,14 +178,14 @@ class Cvr8:
 class Cvr64:
     """CPU mirror of the device format (arrays copied to numpy)"""
 
-    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0, use_dict=False, phases=1, max_rows=0, hub_max=0, narrow=False, reorder=False):
+    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0, use_dict=False, phases=1, max_rows=0, hub_max=0, narrow=False, reorder=False, tag16=False, piece_max=0):
         self.rp = np.ascontiguousarray(rowptr, dtype=np.int64)
         self.cl = np.ascontiguousarray(cols, dtype=np.int32)
         self.f32 = vals.dtype == np.float32
         self.vl = np.ascontiguousarray(vals, dtype=np.float32 if self.f32 else np.float64)
         self.c = OrcCvr64()
-        self.rc = lib().orc_cvr64_build_full(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data,
-                                             int(self.f32), S, thr, int(use_dict), phases, max_rows, hub_max, int(bool(reorder)), int(bool(narrow)), C.byref(self.c))
+        self.rc = lib().orc_cvr64_build_tag(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data,
+                                            int(self.f32), S, thr, int(use_dict), phases, max_rows, hub_max, int(bool(reorder)), int(bool(narrow)), int(bool(tag16)), int(piece_max), C.byref(self.c))
         if self.rc:
             raise RuntimeError(f"orc_cvr64_build = {self.rc}")
         c = self.c

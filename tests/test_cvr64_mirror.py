@@ -178,3 +178,26 @@ def test_row_block_restarts_product_planner_equals_mirror(S, thr):
     yref, absy = O.csr_spmv64(rp, ci, va, x)
     bad, worst = O.tol_check(m.spmv(x), yref, absy)
     assert len(bad) == 0, worst
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("S,P,tags,pmax", [(8, 3, 0, 0), (32, 5, 0, 4), (8, 3, 1, 1), (64, 7, 1, 8)])
+def test_mirror_column_phases_match_csr_oracle(name, S, P, tags, pmax):
+    """column phases: every piece of a lane stream (a (row, phase) segment, or what a lane stole of one) carries its row -- above
+    the column index, or in a 16-bit tag of its own -- and adds its sum to that row; the mirror's y against the CSR oracle"""
+    nrows, ncols, rp, ci, va = CASES[name]
+    if ncols < 64 * P:
+        pytest.skip("too few columns for that many phases")
+    m = O.Cvr64(nrows, ncols, rp, ci, va, S, phases=P, max_rows=min(64 * S, 2000), tag16=tags, piece_max=pmax)
+    gb = 3072 + (512 if tags else 0)
+    assert m.image.size == m.nchunks * (S // 4) * gb
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(ncols, mode)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        bad, worst = O.tol_check(m.spmv(x), yref, absy, tol=1e-12)
+        assert len(bad) == 0, (mode, worst, bad[:5])
+    if tags:      # the two encodings hold the same pieces: the column words differ only in the row field
+        m0 = O.Cvr64(nrows, ncols, rp, ci, va, S, phases=P, max_rows=min(64 * S, 2000), tag16=0, piece_max=pmax)
+        assert np.array_equal(m.desc, m0.desc) and np.array_equal(m.target, m0.target)
+        x = O.x_vec_fast(ncols, "rand")
+        assert np.array_equal(m.spmv(x), m0.spmv(x))

@@ -60,8 +60,10 @@ def test_converter_image_bit_exact_and_y_parity(name, S):
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-@pytest.mark.parametrize("S,wpb,win,P", [(8, 1, 0, 3), (4, 8, 64, 2), (32, 4, 1024, 5), (16, 16, 0, 1), (8, 2, 256, 1)])
-def test_workgroup_window_and_column_phases(name, S, wpb, win, P):
+@pytest.mark.parametrize("S,wpb,win,P,tags", [(8, 1, 0, 3, 0), (4, 8, 64, 2, 0), (32, 4, 1024, 5, 0), (16, 16, 0, 1, 0), (8, 2, 256, 1, 0),
+                                              (8, 1, 0, 3, 1), (32, 4, 1024, 5, 1), (64, 14, 512, 7, 1)])
+@pytest.mark.parametrize("pmax", [0, 3])
+def test_workgroup_window_and_column_phases(name, S, wpb, win, P, tags, pmax):
     """Several chunks per workgroup sharing an LDS window of x, and column phases (a chunk feeds its rows' pieces column
     range by column range; their sums are added up in LDS): the image against the CPU mirror bit for bit, y against the CSR
     oracle, and -- when no row is cut over chunks -- y bitwise equal to the mirror's interpretation of the image (same
@@ -69,10 +71,10 @@ def test_workgroup_window_and_column_phases(name, S, wpb, win, P):
     nrows, ncols, rp, ci, va = CASES[name]
     if P > 1 and ncols < 64 * P:
         pytest.skip("too few columns for phases: the library falls back to one phase")
-    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, waves_per_block=wpb, x_window=win, col_phases=P)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, waves_per_block=wpb, x_window=win, col_phases=P, row_tags16=tags, piece_max=pmax)
     i = A.info
-    assert (i.col_phases, i.waves_per_block) == (P, wpb)
-    mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=i.value_dict > 0, phases=P, max_rows=i.chunk_row_cap, narrow=i.narrow_cols)
+    assert (i.col_phases, i.waves_per_block, i.row_tags16, i.piece_max) == (P, wpb, tags if P > 1 else 0, pmax if P > 1 else 0)
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=i.value_dict > 0, phases=P, max_rows=i.chunk_row_cap, narrow=i.narrow_cols, tag16=tags, piece_max=pmax)
     img = A.export_image()
     assert (i.nchunks, i.nshared) == (mir.nchunks, mir.nshared)
     for key in ("desc", "target", "shared", "image"):
@@ -81,9 +83,9 @@ def test_workgroup_window_and_column_phases(name, S, wpb, win, P):
         x = O.x_vec_fast(ncols, mode)
         yref, absy = O.csr_spmv64(rp, ci, va, x)
         y, _ = A.spmv(x)
-        _assert_close(y, yref, absy, TOL64, (name, S, wpb, win, P, mode))
+        _assert_close(y, yref, absy, TOL64, (name, S, wpb, win, P, tags, mode))
         if i.nshared == 0:          # (the fix-up of rows cut over chunks adds the carries as a tree, the mirror one by one)
-            assert np.array_equal(y, mir.spmv(x)), (name, S, wpb, win, P, mode)
+            assert np.array_equal(y, mir.spmv(x)), (name, S, wpb, win, P, tags, mode)
         y2, _ = A.spmv(x)
         assert np.array_equal(y, y2)
     A.close()
@@ -183,6 +185,42 @@ def test_full_size_web_google_parity(web_google):
         y, _ = A.spmv(x, iters=2)
         _assert_close(y, yref, absy, TOL64, mode)
         assert np.all(y[np.diff(rp) == 0] == 0)         # rows without non-zeros are written as +0
+
+
+# The layout cvr_create's automatic rule gives the full-size web-Google shape on an MI355X: what bench.py times (its JSON line
+# repeats these numbers under config).  Change it together with the rule (cvr_layout.hip, choose_layout).
+TIMED_LAYOUT = dict(steps_per_chunk=48, waves_per_block=7, x_window=8192, col_phases=12, value_dict=13)
+
+
+@pytest.mark.parametrize("value_dict", [-1, 0])
+def test_timed_configuration_full_size_strict(value_dict):
+    """The configuration bench.py TIMES -- the web-Google shape with DEFAULT options (automatic layout: resident workgroups, LDS
+    window of x, column phases, value dictionary) and the same with full fp64 values in the stream -- against the pinned CSR
+    oracle at 1e-12 * sum |a x| per row (spmv.cpp:1843-1850), the converter image against the CPU mirror bit for bit, and
+    bitwise reproducibility.  (The other full-size tests pass an explicit S, which switches the automatic layout off.)"""
+    nrows, ncols, rp, ci, va = synth.web_google_like()
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, value_dict=value_dict)
+    i = A.info
+    got = dict(steps_per_chunk=i.steps_per_chunk, waves_per_block=i.waves_per_block, x_window=i.x_window, col_phases=i.col_phases,
+               value_dict=i.value_dict)
+    assert got == dict(TIMED_LAYOUT, value_dict=13 if value_dict else 0), got
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, i.steps_per_chunk, use_dict=i.value_dict > 0, phases=i.col_phases, max_rows=i.chunk_row_cap,
+                  tag16=i.row_tags16, piece_max=i.piece_max)
+    img = A.export_image()
+    assert (i.nchunks, i.nshared) == (mir.nchunks, mir.nshared)
+    for key in ("desc", "target", "shared", "image"):
+        assert np.array_equal(img[key], getattr(mir, key)), key
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(ncols, mode)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x, iters=2)
+        _assert_close(y, yref, absy, TOL64, (value_dict, mode))
+        y2, _ = A.spmv(x)
+        assert np.array_equal(y.view(np.uint64), y2.view(np.uint64))
+        assert cvr_amd.verdict(y, yref, nrows) == 0                       # the reference's own criterion (spmv.cpp:1916-1938)
+        if i.nshared == 0:
+            assert np.array_equal(y, mir.spmv(x)), (value_dict, mode)      # same order of additions as the mirror
+    A.close()
 
 
 def test_full_size_properties(web_google):
