@@ -207,12 +207,32 @@ def cpu_baseline(nrows, ncols, rp, ci, va):
     return r
 
 
+def _visible_gpus():
+    """GPUs this process could open, from the KFD topology in sysfs (nodes with SIMDs) and the *_VISIBLE_DEVICES masks -- no HIP
+    or HSA call, so the parent of the ranks never initialises the GPU.  None when sysfs does not tell (the ranks then report)."""
+    import glob
+    n = 0
+    try:
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(f):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except Exception:
+        return None
+    if n == 0:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """N > 1 without a torch.distributed environment: one child per GPU via torch.distributed.run, started before this
     process has touched the GPU (the box refuses an exec / fork from a process that has); rank 0's JSON line is relayed."""
-    import torch
-    have = torch.cuda.device_count()          # does not initialise the GPU on this image
-    if have < args.gpus and not os.environ.get("CVR_BENCH_ONE_DEVICE"):
+    have = _visible_gpus()                    # counted without a HIP call: this process must stay off the GPU
+    if have is not None and have < args.gpus and not os.environ.get("CVR_BENCH_ONE_DEVICE"):
         sys.exit(f"bench.py --gpus {args.gpus}: {have} GPU(s) visible (CVR_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 as a plumbing check)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -311,7 +331,7 @@ def main():
         lrows, lnnz = int(bounds[rank + 1] - bounds[rank]), int(lrp_t[-1])
         build_s = time.perf_counter() - t_build0
         A = cvr_amd.CvrMatrix.from_device(lrows, ncols, lrp_t.data_ptr(), lci_t.data_ptr(), lva_t.data_ptr(), is_f32=f32, device=local_rank,
-                                          steps_per_chunk=args.steps_per_chunk, tune_steps=tune, col_panels=args.col_panels)
+                                          steps_per_chunk=args.steps_per_chunk, tune_steps=False, col_panels=args.col_panels)      # (device-built large workloads keep the library's rules: hub tables, panels; tuning is for shards of the small headline matrix)
         np_dtype = np.float32 if f32 else np.float64
     else:
         nrows, ncols, rp, ci, va, source = load_host_workload(args.workload)

@@ -70,6 +70,17 @@ def lib():
         p = lib_path()
         if not os.path.exists(p):
             raise ImportError(f"{p} is missing: build it with `make -C cvr_amd/csrc` (or __graft_entry__.build())")
+        # A process that also uses PyTorch must load torch FIRST: its wheel carries its own copy of the HIP runtime, and whichever
+        # copy is loaded second finds no GPU.  If torch is importable but not yet imported, import it here; if
+        # that is not wanted (CVR_NO_TORCH_PRELOAD=1) the library's own runtime is used and a later `import torch` sees no device.
+        import sys as _sys
+        if "torch" not in _sys.modules and not os.environ.get("CVR_NO_TORCH_PRELOAD"):
+            import importlib.util as _ilu
+            if _ilu.find_spec("torch") is not None:
+                try:
+                    import torch  # noqa: F401
+                except Exception:  # noqa: BLE001
+                    pass
         L = C.CDLL(p)
         L.cvr_last_error.restype = C.c_char_p
         L.cvr_version.restype = C.c_char_p

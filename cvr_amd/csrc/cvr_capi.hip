@@ -86,6 +86,7 @@ struct IOpt : cvr_options {
     int32_t stream_ahead = 0;              // CVR_DEBUG_STREAM_AHEAD: groups the matrix stream runs ahead of the x gather: 0 / 1 = one, >= 2 = three
     int32_t gather_depth = 0;              // CVR_DEBUG_GATHER_DEPTH: groups the x gather runs ahead of the FMAs: 1 or 2
     int32_t debug_col_mask = 0;            // CVR_DEBUG_COL_MASK: folds the gather onto a 2^k-entry table (timing only: wrong y)
+    int32_t panel_on_one_xcd = 0;          // this image is a column panel that will run on the workgroups of one XCD (run_spmv, d_multi)
 };
 
 // One CVR64 image on the device: the whole matrix, or one column panel of it (rows compacted to those that
@@ -377,7 +378,7 @@ int cvr_plan_selfcheck(int device, int64_t nrows, const int64_t *row_ptr, int32_
     return CVR_OK;
 }
 
-static int pick_steps(int64_t nslots_est, int64_t max_row = 0)
+static int pick_steps(int64_t nslots_est, int64_t max_row = 0, double cus = 256.0)
 {
     // The plain layout (one chunk per workgroup).  Images of more than 12 chunks per CU at S = 32 run in rounds and take
     // S = 32 (LiveJournal panels, R-MAT, banded: within 1 % of the best S, profiles/r02_steps_rule_check.log,
@@ -386,7 +387,7 @@ static int pick_steps(int64_t nslots_est, int64_t max_row = 0)
     // row, and (2) beyond that as many chunks as possible, i.e. the smallest such S (web-Google-shaped matrices of 0.6 M and
     // 1.3 M non-zeros: S = 28 is the best of 8 .. 64, 7.9 and 9.5 us; the round-1 fit on shards of one matrix took 24 and 44:
     // 9.8 and 11.8 us).  cvr_tune measures instead.
-    const double kCus = 256.0;
+    const double kCus = cus;             // (a column panel that runs on one XCD counts its chunks against that XCD's 32 CUs)
     auto chunks = [&](int S) { return (double)nslots_est * 1.004 / (64.0 * S) + 1.0; };
     if (chunks(32) > kCus * 12.0) return 32;
     int S = (int)std::min<int64_t>(64, std::max<int64_t>(12, ((max_row + 15) / 16 + 3) / 4 * 4));
@@ -428,11 +429,12 @@ static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32
     pp.S = opt.steps_per_chunk;
     if (pp.S == 0) {
         int64_t max_row = 0;
-        if ((double)(nz1 - nz0 + nrows / 4) / (64.0 * 32.0) <= 256.0 * 12.0) {    // (only where the rule weighs single launches)
+        const double cus = opt.panel_on_one_xcd ? 32.0 : 256.0;
+        if ((double)(nz1 - nz0 + nrows / 4) / (64.0 * 32.0) <= cus * 12.0) {    // (only where the rule weighs single launches)
             if (rp) for (int64_t r = 0; r < nrows; r++) max_row = std::max(max_row, rp[r + 1] - rp[r]);
             else { const hipError_t e = cvr::max_row_device(dr->rp, nrows, &max_row, dr->st); if (e != hipSuccess) return e; }
         }
-        pp.S = pick_steps(nz1 - nz0 + nrows / 4, max_row);
+        pp.S = pick_steps(nz1 - nz0 + nrows / 4, max_row, cus);
     }
     // Wavefronts (consecutive chunks) per SpMV workgroup: 1 by default; more only pay together with an LDS window of x,
     // which the workgroup's chunks then share (profiles/r02_wg_window_sweep.log).
@@ -510,6 +512,11 @@ static hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32
         pp.nzb[(size_t)k] = c.nz_begin;
     }
     pp.nzb[(size_t)nchunks] = plan.nz_end;
+    if (pp.phases > 1) {          // no more accumulators than the fullest chunk has rows (+ the dump entry): the cap stays what no chunk exceeds
+        int64_t most = 0;
+        for (const cvr::Chunk &c : plan.chunks) most = std::max(most, c.nrows_in);
+        pp.stage = std::min<int64_t>(pp.stage, std::max<int64_t>(64, (most + 1 + 3) & ~(int64_t)3));
+    }
     if (pp.phases == 1) {
         // LDS budget without phases: steal slots and dictionary are fixed; the row-sum stage is sized for the chunk with the
         // most segments, so every chunk writes its y coalesced (chunks of very short rows beyond the stage store directly);
@@ -761,12 +768,12 @@ static int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, c
         img.tag16 = pp.tag16;
         // pieces: a lane that sits on a long row's segment falls behind the column ranges the other lanes have moved on to; with
         // chunks longer than a few steps per phase the segments are cut (auto: 8 elements once a phase takes 8 steps or more)
-        if (S / pp.phases >= 8 && !getenv("CVR_NO_PACE")) {      // long chunks: the SpMV kernel paces its wavefronts through the phases
+        if (S / pp.phases >= 8 && !opt.panel_on_one_xcd && !getenv("CVR_NO_PACE")) {      // long chunks: the SpMV kernel paces its wavefronts through the phases
             HIP_TRY(hipMalloc(&img.pace, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases)));
             HIP_TRY(hipMemsetAsync(img.pace, 0, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases), h->stream));
             img.pace_epoch = new uint32_t(0);
         }
-        img.piece_max = opt.piece_max > 0 ? (uint32_t)opt.piece_max : opt.piece_max < 0 && S / pp.phases >= 8 ? 8u : 0u;
+        img.piece_max = opt.piece_max > 0 ? (uint32_t)opt.piece_max : opt.piece_max < 0 && S / pp.phases >= 8 && !opt.panel_on_one_xcd ? 8u : 0u;
         img.col_mask = pp.tag16 ? cvr::kColMask : (1u << pp.col_bits) - 1u;
     }
     if (popt.col_phases > 1 && pp.lds_short && !popt.layout_auto_resident) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
@@ -1191,7 +1198,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         // Power-law matrices whose popular columns will sit in hub tables need fewer, wider panels: the table takes the hot
         // half of the gathers off the L2s, and what remains runs best with ~16 MB of x per panel instead of ~4 (R-MAT-26 fp32
         // on one GPU: 59 panels 6.4 ms, 16 panels 5.4 ms; R-MAT-24: 8 and 4 panels alike; profiles/r02_hub_table_rmat.log)
-        if (dev_split && panels_auto && opt.hub_table < 0 && !getenv("CVR_NO_AUTO_LAYOUT")) {
+        if (dev_split && panels_auto && opt.hub_table < 0 && opt.waves_per_block == 0 && opt.x_window <= 0 && !getenv("CVR_NO_AUTO_LAYOUT")) {      // (the predicate of choose_hubs: only panels that will get tables are widened)
             const int64_t room = ((int64_t)cvr::kLdsBytes / (int64_t)vsz - 8 * (cvr::kLanes + 512) - cvr::kDictMax - 8) & ~(int64_t)1023;
             cvr::HubSelection sel;
             const double      th0 = now_s();
@@ -1224,7 +1231,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         clk.lap("panel split");
         std::vector<PartPlan> pps((size_t)P);
         IOpt                  panel_opt = opt;
-        panel_opt.col_phases = 1;          // column phases are for the single image whose chunks are all resident at once
+        panel_opt.col_phases = getenv("CVR_PANEL_PHASES") ? atoi(getenv("CVR_PANEL_PHASES")) : 1;          // column phases are for the single image whose chunks are all resident at once
+        panel_opt.panel_on_one_xcd = xcd_panels ? 1 : 0;
         std::vector<IOpt>        popts((size_t)P, panel_opt);
         std::vector<DevRows>     drs((size_t)P);
         if (dev_split) {
@@ -1375,16 +1383,16 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // its workgroups, so that an L2 holds one slice of x at a time and every line of x is fetched by one XCD only
     if (h->paneled() && xcd_panels) {
         bool plain = true;
-        for (const Part &p : h->parts) plain = plain && p.img.wpb <= 1 && p.img.hub_n == 0 && p.img.win_elems == 0 && p.img.phases <= 1 && !p.img.c16 && p.img.S == h->parts[0].img.S;
+        for (const Part &p : h->parts) plain = plain && p.img.wpb <= 1 && p.img.hub_n == 0 && p.img.win_elems == 0 && p.img.phases == h->parts[0].img.phases && p.img.tag16 == h->parts[0].img.tag16 && !p.img.c16 && p.img.S == h->parts[0].img.S;
         if (plain) {
             const size_t per_round = getenv("CVR_XCD_PANELS_DEBUG") ? (size_t)atoi(getenv("CVR_XCD_PANELS_DEBUG")) : 8;      // (diagnostics: fewer panels side by side)
             const size_t rounds = (h->parts.size() + per_round - 1) / per_round;
-            std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u});
+            std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr});
             h->multi_chunks.assign(rounds, 0u);
             for (size_t j = 0; j < h->parts.size(); j++) {
                 const Part &p = h->parts[j];
                 const size_t i = (j / per_round) * 8 + j % per_round;
-                pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage};
+                pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2};
                 h->multi_chunks[i / 8] = std::max(h->multi_chunks[i / 8], p.img.nchunks);
                 h->multi_ystage = std::max(h->multi_ystage, p.img.ystage);
                 if (getenv("CVR_XCD_PANELS_TRACE")) fprintf(stderr, "[xcd panels] part %zu slot %zu nchunks %u ystage %u S %d G %d zoff %lld yext %lld nshared %u stream %p\n", j, i, p.img.nchunks, p.img.ystage, p.img.S, p.img.G, (long long)p.zoff, (long long)p.yext, p.img.nshared, (void *)p.img.stream);
@@ -1414,7 +1422,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipMemsetAsync(h->d_y, 0, vsz * (size_t)in.yext_elems, h->stream));
     CREATE_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
     CREATE_TRY(hipStreamSynchronize(h->stream));   // the caller may free its CSR when this returns
-    in.upload_s = now_s() - t_up0 - in.plan_s - in.probe_s - panel_rule_s;
+    in.upload_s = now_s() - t_up0 - in.plan_s - in.probe_s - panel_rule_s - in.hub_select_s;      // (hub selection and the layout probe are reported on their own)
     in.plan_s += panel_rule_s;
     cvr::free_plan_scratch(h->plan_ws);
     (void)hipFree(h->d_small); h->d_small = nullptr;
@@ -1441,16 +1449,23 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
     struct SegGuard { cvr::SegTable t; void *arena = nullptr; ~SegGuard() { (void)hipFree(arena); } } sg;      // (one allocation: six cost six times the call)
     Part &p0 = h->parts[0];
-    const bool phased = !h->paneled() && p0.img.phases > 1 && p0.nchunks > 0;
+    // column phases: the segment table (conversion-time only) gives every chunk room for as many segments as it has slots, so
+    // that counting and filling are one kernel per chunk and the conversion follows without the host in between; the images of a
+    // handle (column panels) are converted one after the other and share the table, sized for the largest
+    size_t seg_n1 = 0, seg_chunks = 0;
+    for (const Part &p : h->parts)
+        if (p.img.phases > 1 && p.nchunks > 0) {
+            seg_n1 = std::max(seg_n1, (size_t)p.nchunks * (size_t)cvr::kLanes * (size_t)p.img.S);
+            seg_chunks = std::max(seg_chunks, (size_t)p.nchunks);
+        }
+    const bool phased = seg_n1 > 0;
     if (phased) {
-        // column phases: the segment table (conversion-time only) gives every chunk room for as many segments as it has slots, so
-        // that counting and filling are one kernel per chunk and the conversion follows without the host in between
         cvr::SegTable &t = sg.t;
-        const size_t cap = (size_t)cvr::kLanes * (size_t)p0.img.S, n1 = std::max<size_t>((size_t)p0.nchunks * cap, 1);
+        const size_t n1 = seg_n1;
         if (n1 >= ((size_t)1 << 32)) return fail(CVR_ERR_INVALID, "col_phases: more than 2^32 slots in one image");
         auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t o_begin = 0, o_len = o_begin + up(sizeof(int64_t) * n1), o_row = o_len + up(sizeof(uint32_t) * n1), o_cnt = o_row + up(sizeof(uint16_t) * n1),
-                     o_flags = o_cnt + up(sizeof(uint32_t) * ((size_t)p0.nchunks + 1));
+                     o_flags = o_cnt + up(sizeof(uint32_t) * (seg_chunks + 1));
         HIP_TRY(hipMalloc(&sg.arena, o_flags + 256));
         uint8_t *a = static_cast<uint8_t *>(sg.arena);
         t.begin = reinterpret_cast<int64_t *>(a + o_begin); t.len = reinterpret_cast<uint32_t *>(a + o_len); t.row = reinterpret_cast<uint16_t *>(a + o_row);
@@ -1462,17 +1477,18 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     hipStream_t wstream = h->paneled() || !p0.img.win_elems ? h->stream : side_stream(h->device);
     if (!wstream) wstream = h->stream;
     HIP_TRY(hipEventRecord(e0, h->stream));
-    uint32_t seg_flags[2] = {0, 0}, seg_total = 0;
+    uint32_t              seg_flags[2] = {0, 0};
+    std::vector<uint32_t> seg_totals(h->parts.size(), 0u);
     for (Part &p : h->parts) {
         cvr::DeviceCsr csr;
         csr.row_ptr = p.d_rp; csr.col_idx = p.d_ci; csr.vals = p.d_va; csr.nz_begin = p.d_nzb; csr.pad_cnt = p.d_pad;
         if (wstream != h->stream) HIP_TRY(cvr::launch_window(p.img, csr, wstream));
-        if (phased) {
+        if (p.img.phases > 1 && p.nchunks > 0) {
             cvr::SegTable &t = sg.t;
             HIP_TRY(cvr::launch_seg_build(p.img, csr, t, h->stream));
             HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream, &t));
-            HIP_TRY(hipMemcpyAsync(seg_flags, t.flags, sizeof(seg_flags), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipMemcpyAsync(&seg_total, t.cnt + p.nchunks, sizeof(seg_total), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(seg_flags, t.flags, sizeof(seg_flags), hipMemcpyDeviceToHost, h->stream));      // (the flags of all images so far)
+            HIP_TRY(hipMemcpyAsync(&seg_totals[(size_t)(&p - h->parts.data())], t.cnt + p.nchunks, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         } else {
             HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream));
         }
@@ -1490,7 +1506,8 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     if (seconds) *seconds = ms * 1e-3;
     if (seg_flags[0] & 1u) return fail(CVR_ERR_INVALID, "col_phases needs the column indices of every row in ascending order");
     if (err) return fail(CVR_ERR_INTERNAL, "device converter self-check failed (flags 0x%x)", err);
-    h->info.nsegments = seg_total;
+    h->info.nsegments = 0;
+    for (uint32_t v : seg_totals) h->info.nsegments += v;
     h->info.preprocess_wall_s = now_s() - t_wall0;
     h->converted = true;
     if (!keep_csr) for (Part &p : h->parts) p.release_csr();
@@ -1766,7 +1783,26 @@ int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int i
     HIP_TRY(cvr::launch_dot(x_dev, x_dev, n, f32, s.partial, s.cells + 1, st));
     HIP_TRY(cvr::launch_scale(x_dev, x_dev, s.cells + 1, n, f32, st));
     HIP_TRY(hipEventRecord(s.e0, st));
+    // The one-pass step scales x by the norm of the step BEFORE, so |x| swings up to ~lambda and y = A x up to ~lambda^2: fine in
+    // fp64, but an fp32 handle whose dominant eigenvalue lies beyond ~1e15 (or below ~1e-15) would overflow (underflow) on the
+    // way.  After the first step of such a handle the estimate |A x| / |x| is read back once; out of that range every further
+    // step normalises exactly (two more passes over the vectors per step, |x| = 1 throughout).
+    bool exact = false;
     for (int it = 0; it < iters; it++) {
+        if (exact) {
+            HIP_TRY(run_spmv(h, x_dev, s.y, st));
+            const void *yfull = s.y;
+            if (c) {
+                RCCL_TRY(api, api->all_gather(s.y, s.yall, (size_t)max_rows, f32 ? ncclFloat : ncclDouble, c->comm, st));
+                HIP_TRY(cvr::launch_unpad(s.dense, s.yall, bd, nparts, max_rows, f32, st));
+                yfull = s.dense;
+            }
+            HIP_TRY(cvr::launch_dot(x_dev, yfull, n, f32, s.partial, s.cells + 0, st));
+            HIP_TRY(cvr::launch_dot(x_dev, x_dev, n, f32, s.partial, s.cells + 2, st));
+            HIP_TRY(cvr::launch_dot(yfull, yfull, n, f32, s.partial, s.cells + 1, st));
+            HIP_TRY(cvr::launch_scale(x_dev, yfull, s.cells + 1, n, f32, st));
+            continue;
+        }
         HIP_TRY(run_spmv(h, x_dev, s.y, st));
         // the exchange step is on the critical path here: x of the next iteration is the gathered y (read through the shards'
         // bounds as it lies, padded)
@@ -1774,6 +1810,20 @@ int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int i
         // the step's three dot products and x <- y / ||y of the step before|| in one pass (cvr_iter.hip: power_step_kernel)
         HIP_TRY(cvr::launch_power_step(x_dev, c ? s.yall : s.y, n, f32, it > 0 ? s.partial + (size_t)((it - 1) & 1) * npart : nullptr,
                                        s.partial + (size_t)(it & 1) * npart, st, c ? &bd : nullptr, nparts, max_rows));
+        if (f32 && it == 0 && iters > 1) {      // (one read-back per call, fp32 handles only)
+            double part[3] = {0, 0, 0};
+            HIP_TRY(cvr::launch_power_sums(s.partial, s.cells, st));
+            HIP_TRY(hipMemcpyAsync(part, s.cells, sizeof(part), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const double est = part[2] > 0 ? sqrt(part[1] / part[2]) : 0.0;      // |A x| / |x|
+            if (!(est > 1e-15 && est < 1e15)) {
+                exact = true;                                                     // x holds y unscaled (prev was null): normalise it now
+                const void *yfull = s.y;
+                if (c) { HIP_TRY(cvr::launch_unpad(s.dense, s.yall, bd, nparts, max_rows, f32, st)); yfull = s.dense; }
+                HIP_TRY(cvr::launch_scale(x_dev, yfull, s.cells + 1, n, f32, st));
+                continue;
+            }
+        }
         if (it + 1 == iters) {       // the last iterate leaves normalised exactly: x <- y / ||y||
             const void *yfull = s.y;
             if (c) { HIP_TRY(cvr::launch_unpad(s.dense, s.yall, bd, nparts, max_rows, f32, st)); yfull = s.dense; }
@@ -1907,7 +1957,9 @@ static int tune_impl(const cvr_csr_view *csr, const cvr_options *opt_in, bool fu
     double      best_t = 0;
     bool        have = false;
     // (1) one chunk per workgroup, S = 8 .. 64
-    opt.waves_per_block = 1; opt.x_window = 0; opt.col_phases = 1;
+    // (waves_per_block stays 0 = default: an explicit 1 would switch the automatic hub table off, cvr_layout: choose_hubs, and a
+    // tuned handle of a power-law shard would lose its tables)
+    opt.waves_per_block = 0; opt.x_window = 0; opt.col_phases = 1;
     for (int32_t S = 8; S <= 64; S += 4) {
         opt.steps_per_chunk = S;
         double t = 0;

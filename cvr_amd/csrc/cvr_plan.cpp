@@ -8,6 +8,8 @@
 // segment of zeros (the reference pads nnz to a multiple of 16 instead, spmv.cpp:474-482).
 #include "cvr_plan.h"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -38,6 +40,9 @@ public:
     // runs fn(0 .. n-1) on up to `team` threads including the caller; one batch at a time
     void run(int64_t n, int team, const std::function<void(int64_t)> &fn)
     {
+        // After fork() the child inherits this object but none of its threads (and possibly a mutex locked by a thread that no
+        // longer exists): a child runs the blocks on the calling thread and never touches the pool's state.
+        if (getpid() != owner_) { for (int64_t i = 0; i < n; i++) fn(i); return; }
         std::lock_guard<std::mutex> batch(batch_mu_);
         if (team > (int)workers_.size() + 1) team = (int)workers_.size() + 1;
         {
@@ -60,6 +65,7 @@ private:
     }
     ~BlockPool()
     {
+        if (getpid() != owner_) { for (auto &t : workers_) t.detach(); return; }      // (a forked child: there is nothing to join)
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
         cv_.notify_all();
         for (auto &t : workers_) t.join();
@@ -88,6 +94,7 @@ private:
             if (running_ == 0 && want_ <= 0) done_.notify_all();
         }
     }
+    const pid_t              owner_ = getpid();      // the process that created the threads
     std::vector<std::thread> workers_;
     std::mutex               mu_, batch_mu_;
     std::condition_variable  cv_, done_;

@@ -487,11 +487,21 @@ __device__ __forceinline__ void sum_group_seg(T &acc, const SegGroup<T, DICT, TA
 // wavefront for itself (the same values to the same addresses), so nothing else needs a barrier.
 template <typename T, int QA, int DEPTH, int WIN, bool DICT, bool LOADER, bool TAG>
 __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
-    const uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const T *__restrict__ x, T *__restrict__ yext, int G, uint32_t nchunks,
+    const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const T *__restrict__ x, T *__restrict__ yext_a, int G, uint32_t nchunks_a,
     uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn,
-    const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_n, const uint2 *__restrict__ desc2, uint32_t col_bits, uint32_t nw_arg, int gb,
-    uint32_t *__restrict__ pace, uint32_t pw, uint32_t pad_col, int pace_lag, uint32_t nphases, uint32_t epoch)
+    const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, const uint2 *__restrict__ desc2_a, uint32_t col_bits, uint32_t nw_arg, int gb,
+    uint32_t *__restrict__ pace, uint32_t pw, uint32_t pad_col, int pace_lag, uint32_t nphases, uint32_t epoch, const PanelArgs *__restrict__ multi)
 {
+    const uint8_t *__restrict__ stream = stream_a;
+    const uint4 *__restrict__   desc = desc_a;
+    const uint2 *__restrict__   desc2 = desc2_a;
+    T *__restrict__             yext = yext_a;
+    uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = blockIdx.x;
+    if (multi) {          // column panels, one per XCD at a time: panel blockIdx & 7, its chunk group blockIdx >> 3 (spmv_kernel)
+        const PanelArgs pa = multi[blockIdx.x & 7u];
+        stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
+        bidx = blockIdx.x >> 3;
+    }
     constexpr int GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
     // LDS: [waves][ystage_n] row accumulators, the value dictionary (DICT), the x window and its zero slot (WIN; wn + 4 values)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t blk = remap_block(blockIdx.x, nblocks_per_xcd, swz);
+    const uint32_t blk = remap_block(bidx, nblocks_per_xcd, swz);
     const uint32_t wbase = WIN != 0 && wn && blk * nw < nchunks ? win_base[blk] : 0u;
 
     if constexpr (LOADER && WIN != 0) {
@@ -586,6 +596,9 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     if (pace && pace_n > kPaceSlots) pace_g = nullptr;
     uint32_t       cur_phase = 0, next_bound = pw;
     T acc = 0;
+    if constexpr (LOADER && WIN != 0) {
+        if (gb < 0) { asm volatile("s_barrier" ::: "memory"); wn_eff = wn; }      // (meet the loaders in front of the first gather)
+    }
 #pragma unroll
     for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, kPolDefault, WIN>(rx, win, Q[i].c, cmask, wbase, wn_eff, 0u, wn);
     for (int g = 0; g < G; g++) {
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
         for (int i = 0; i + 1 < DEPTH; i++) xs[i] = xs[i + 1];
         xs[DEPTH - 1] = xn;
     }
-    if constexpr (LOADER && WIN != 0) { if (gb >= G) asm volatile("s_barrier" ::: "memory"); }
+    if constexpr (LOADER && WIN != 0) { if (gb >= G) asm volatile("s_barrier" ::: "memory"); }      // (every wavefront meets the loaders exactly once)
     if (pace_g && lane == 0)        // out of every phase
         for (uint32_t p = cur_phase; p < nphases; p++) __hip_atomic_store(pace_g + (size_t)p * kPaceSlots + pace_slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -666,16 +679,48 @@ template <typename T>
 __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off,
                                                       uint32_t nblocks, T *__restrict__ y, uint32_t nrows)
 {
+    // The loads of kBatch panels are issued together (kEach entries per thread and panel in registers), then added panel by panel:
+    // one memory round trip per batch instead of one per panel in front of every barrier (16 panels: 54 -> 3x us on the
+    // soc-LiveJournal1 shape); what a panel holds beyond 256 * kEach entries for this block is added behind them.
+    constexpr int kBatch = 4, kEach = 4;
     __shared__ T acc[kCombineRows];
     const uint32_t b = blockIdx.x, r0 = b * kCombineRows;
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCombineRows; i += blockDim.x) acc[i] = 0;
     __syncthreads();
-    for (uint32_t p = 0; p < npanels; p++) {
-        const CombinePanel cp = panels[p];
-        const uint32_t     lo = block_off[(size_t)p * (nblocks + 1) + b], hi = block_off[(size_t)p * (nblocks + 1) + b + 1];
-        const T           *z = static_cast<const T *>(cp.z);
-        for (uint32_t u = lo + threadIdx.x; u < hi; u += blockDim.x) acc[cp.rows[u] - r0] += z[u];
-        __syncthreads();
+    for (uint32_t p0 = 0; p0 < npanels; p0 += kBatch) {
+        T        v[kBatch][kEach];
+        uint32_t rw[kBatch][kEach];
+#pragma unroll
+        for (int q = 0; q < kBatch; q++) {
+            const uint32_t p = p0 + q;
+            uint32_t       lo = 0, hi = 0;
+            const T       *z = nullptr;
+            const uint32_t *rows = nullptr;
+            if (p < npanels) {
+                const CombinePanel cp = panels[p];
+                lo = block_off[(size_t)p * (nblocks + 1) + b]; hi = block_off[(size_t)p * (nblocks + 1) + b + 1];
+                z = static_cast<const T *>(cp.z); rows = cp.rows;
+            }
+#pragma unroll
+            for (int e = 0; e < kEach; e++) {
+                const uint32_t u = lo + threadIdx.x + (uint32_t)e * 256u;
+                rw[q][e] = u < hi ? rows[u] : 0xffffffffu;
+                v[q][e] = u < hi ? z[u] : T(0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kBatch; q++) {
+            const uint32_t p = p0 + q;
+            if (p < npanels) {                                 // (uniform)
+#pragma unroll
+                for (int e = 0; e < kEach; e++) if (rw[q][e] != 0xffffffffu) acc[rw[q][e] - r0] += v[q][e];
+                const CombinePanel cp = panels[p];
+                const uint32_t     lo = block_off[(size_t)p * (nblocks + 1) + b], hi = block_off[(size_t)p * (nblocks + 1) + b + 1];
+                const T           *z = static_cast<const T *>(cp.z);
+                for (uint32_t u = lo + threadIdx.x + (uint32_t)kEach * 256u; u < hi; u += 256u) acc[cp.rows[u] - r0] += z[u];
+            }
+            __syncthreads();
+        }
     }
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCombineRows && r0 + i < nrows; i += blockDim.x) y[r0 + i] = acc[i];
 }
@@ -799,8 +844,8 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                        static_cast<const T *>(nullptr), 0u, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col, (const PanelArgs *)nullptr)
 #define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
                              else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
-#define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd, img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
-                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch
+#define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
+                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi
 #define CVR_SEG(T, SP, D, W, DI, LD)                                                                               \
     do {                                                                                                           \
         const dim3 sblock(kLanes * (wpb + (LD ? loaders : 0u)));                                                   \
@@ -813,14 +858,14 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_SEG_SP(T)           do { if (img.stream_ahead >= 2) CVR_SEG_D(T, 3); else CVR_SEG_D(T, 1); } while (0)
     // column phases with a window: `loaders` extra wavefronts per workgroup bring the window in while the others start (spmv_seg_kernel)
     static const int env_loaders = [] { const char *e = getenv("CVR_WIN_LOADERS"); return e ? atoi(e) : -1; }();
-    static const int env_group = [] { const char *e = getenv("CVR_WIN_GROUP"); return e ? atoi(e) : -1; }();
-    uint32_t  loaders = img.phases > 1 && use_win ? (env_loaders >= 0 ? (uint32_t)env_loaders : 2u) : 0u;
+    static const int env_group = [] { const char *e = getenv("CVR_WIN_GROUP"); return e ? atoi(e) : -2; }();
+    uint32_t  loaders = img.phases > 1 && use_win ? (env_loaders >= 0 ? (uint32_t)env_loaders : 4u) : 0u;
     if (wpb + loaders > (uint32_t)kMaxWavesPerBlock) loaders = wpb < (uint32_t)kMaxWavesPerBlock ? (uint32_t)kMaxWavesPerBlock - wpb : 0u;
-    const int win_group = env_group >= 0 ? env_group : 1;
+    const int win_group = env_group >= -1 ? env_group : 0;      // group in front of which the computing wavefronts meet the loaders (-1: in front of the first gather)
     // pacing of long chunks (spmv_seg_kernel): the counters are zeroed in front of every launch
     static const int env_pace = [] { const char *e = getenv("CVR_PACE_LAG"); return e ? atoi(e) : -1; }();
     const int pace_lag = env_pace >= 0 ? env_pace : 2;
-    uint32_t *pace = img.phases > 1 && img.pace && pace_lag > 0 ? img.pace : nullptr;
+    uint32_t *pace = img.phases > 1 && img.pace && pace_lag > 0 && !multi ? img.pace : nullptr;
     const uint32_t epoch = pace ? ++*img.pace_epoch : 0u;        // (a launch marks with its own number: nothing to zero in between)
     if (img.phases > 1) { if (img.f32) CVR_SEG_SP(float); else CVR_SEG_SP(double); }
     else if (img.c16 && !use_win && !use_dict && wpb == 1 && img.phases <= 1 && !multi) { if (img.f32) CVR_PICK_C16(float); else CVR_PICK_C16(double); }

@@ -398,6 +398,13 @@ def test_power_iteration_device_resident():
     assert abs(lam32 - lam_ref) <= 1e-4 * abs(lam_ref)
     assert np.allclose(x32.cpu().numpy().astype(np.float64), x_ref, rtol=0, atol=1e-5)
     A32.close()
+    # an fp32 matrix whose dominant eigenvalue (~1e21) squared is beyond fp32: the loop falls back to exact normalisation
+    # after its first step instead of overflowing on lambda^2
+    Abig = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, (va * 1e19).astype(np.float32))
+    lamb, xb, _ = power.power_iteration(Abig, nrows, iters=30)
+    assert np.isfinite(lamb) and abs(lamb - lam_ref * 1e19) <= 1e-4 * abs(lam_ref) * 1e19
+    assert np.allclose(xb.cpu().numpy().astype(np.float64), x_ref, rtol=0, atol=1e-5)
+    Abig.close()
     nr, nc, rp2, ci2, va2 = CASES["few_rows_lt_lanes"]
     if nr != nc:                                                         # not square: refused with a code
         B = cvr_amd.CvrMatrix(nr, nc, rp2, ci2, va2)
