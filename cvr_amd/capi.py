@@ -32,7 +32,9 @@ class Options(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("iters", C.c_int32), ("mean_s", C.c_double), ("min_s", C.c_double), ("max_s", C.c_double),
-                ("total_s", C.c_double), ("h2d_s", C.c_double), ("d2h_s", C.c_double)]
+                ("total_s", C.c_double), ("h2d_s", C.c_double), ("d2h_s", C.c_double), ("median_s", C.c_double),
+                ("step_mean_s", C.c_double), ("step_min_s", C.c_double), ("step_median_s", C.c_double), ("step_max_s", C.c_double),
+                ("gather_mean_s", C.c_double)]
 
 
 class Info(C.Structure):
@@ -56,7 +58,8 @@ SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_c
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
            "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_plan_selfcheck", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
-           "cvr_tune_steps", "cvr_tune", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat"]
+           "cvr_tune_steps", "cvr_tune", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat",
+           "cvr_row_partition", "cvr_create_multi", "cvr_preprocess_multi", "cvr_spmv_multi", "cvr_multi_shards", "cvr_multi_info", "cvr_multi_uses_rccl", "cvr_destroy_multi"]
 
 
 def lib_path():
@@ -121,8 +124,27 @@ def lib():
         L.cvr_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.cvr_spmv_gather_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                              C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.cvr_row_partition.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+        L.cvr_row_partition.restype = C.c_int64
+        L.cvr_create_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CsrView), C.POINTER(Options), C.c_void_p, C.c_int32]
+        L.cvr_preprocess_multi.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.cvr_spmv_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Timing)]
+        L.cvr_multi_shards.argtypes = [C.c_void_p]
+        L.cvr_multi_uses_rccl.argtypes = [C.c_void_p]
+        L.cvr_multi_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Info), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.cvr_destroy_multi.argtypes = [C.c_void_p]
         _lib = L
     return _lib
+
+
+def row_partition(row_ptr, nparts):
+    """cvr_row_partition: bounds[nparts + 1] of contiguous row blocks with balanced non-zeros, cut at row boundaries (host only)"""
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    bounds = np.zeros(nparts + 1, dtype=np.int64)
+    rc = lib().cvr_row_partition(len(rp) - 1, rp.ctypes.data, nparts, bounds.ctypes.data)
+    if rc < 0:
+        raise CvrError(int(rc), "cvr_row_partition")
+    return bounds
 
 
 def last_error():
@@ -426,6 +448,70 @@ class CvrMatrix:
         if self._h:
             lib().cvr_destroy(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiMatrix:
+    """One matrix over several GPUs of this process (cvr_create_multi): rows sharded, x replicated, y all-gathered inside the
+    library.  devices may name one GPU several times (copies then stand in for RCCL)."""
+
+    def __init__(self, nrows, ncols, row_ptr, col_idx, vals, devices, **options):
+        self._m = C.c_void_p()
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        ci = np.ascontiguousarray(col_idx, dtype=np.int32)
+        self.f32 = np.asarray(vals).dtype == np.float32
+        self.dtype = np.float32 if self.f32 else np.float64
+        va = np.ascontiguousarray(vals, dtype=self.dtype)
+        if len(rp) != nrows + 1:
+            raise ValueError("row_ptr must have nrows + 1 entries")
+        view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
+        opt = Options()
+        lib().cvr_default_options(C.byref(opt))
+        for k, v in options.items():
+            setattr(opt, k, v)
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        rc = lib().cvr_create_multi(C.byref(self._m), C.byref(view), C.byref(opt), devs.ctypes.data, len(devs))
+        if rc:
+            self._m = C.c_void_p()
+            raise CvrError(rc, "cvr_create_multi")
+        sec = C.c_double()
+        rc = lib().cvr_preprocess_multi(self._m, 0, C.byref(sec))
+        if rc:
+            err = CvrError(rc, "cvr_preprocess_multi")
+            self.close()
+            raise err
+        self.preprocess_s = sec.value
+        self.nrows, self.ncols = nrows, ncols
+        self.shards = lib().cvr_multi_shards(self._m)
+        self.uses_rccl = bool(lib().cvr_multi_uses_rccl(self._m))
+
+    def shard_info(self, p):
+        info, b, e, d = Info(), C.c_int64(), C.c_int64(), C.c_int32()
+        rc = lib().cvr_multi_info(self._m, p, C.byref(info), C.byref(b), C.byref(e), C.byref(d))
+        if rc:
+            raise CvrError(rc, "cvr_multi_info")
+        return info, b.value, e.value, d.value
+
+    def spmv(self, x, iters=1):
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        if len(x) < self.ncols:
+            raise ValueError("x is shorter than ncols")
+        y = np.zeros(max(self.nrows, 1), dtype=self.dtype)
+        t = Timing()
+        rc = lib().cvr_spmv_multi(self._m, x.ctypes.data, y.ctypes.data, iters, C.byref(t))
+        if rc:
+            raise CvrError(rc, "cvr_spmv_multi")
+        return y[: self.nrows], t
+
+    def close(self):
+        if self._m:
+            lib().cvr_destroy_multi(self._m)
+            self._m = C.c_void_p()
 
     def __del__(self):
         try:

@@ -1,0 +1,282 @@
+// cvr_internal.h -- what the translation units behind the C ABI share (cvr_capi / cvr_layout / cvr_panels / cvr_comm / cvr_tune /
+// cvr_multi .hip): the handle, the per-image state, error helpers, and the declarations of each other's entry points.  Nothing
+// here is part of include/cvr_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library itself is loaded on first use (rccl_api)
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/cvr_amd.h"
+#include "cvr_kernels.h"
+#include "cvr_plan.h"
+
+namespace cvrh {
+
+extern thread_local char g_err[512];                 // cvr_last_error() of the calling thread
+int fail(int code, const char *fmt, ...);           // formats g_err, returns code
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(CVR_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// roctx ranges around the phases of the path (the reference times them with microtime(), spmv.cpp:575/1009,
+// 1033/1656), visible with `rocprofv3 --marker-trace`.  The roctx library is only loaded when CVR_ROCTX=1:
+// linking it unconditionally costs every process seconds of profiler start-up.
+struct Range {
+    typedef int (*push_t)(const char *);
+    typedef int (*pop_t)(void);
+    static void resolve(push_t &push, pop_t &pop)
+    {
+        struct Fns { push_t p = nullptr; pop_t q = nullptr; };
+        static const Fns f = [] {              // once, thread-safe
+            Fns r;
+            const char *e = getenv("CVR_ROCTX");
+            if (e && atoi(e)) {
+                void *lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+                if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+                if (lib) { r.p = (push_t)dlsym(lib, "roctxRangePushA"); r.q = (pop_t)dlsym(lib, "roctxRangePop"); }
+            }
+            return r;
+        }();
+        push = f.p; pop = f.q;
+    }
+    pop_t pop_ = nullptr;
+    explicit Range(const char *name)
+    {
+        push_t push;
+        resolve(push, pop_);
+        if (push && pop_) push(name); else pop_ = nullptr;
+    }
+    ~Range() { if (pop_) pop_(); }
+};
+
+inline double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace cvrh
+
+// cvr_options plus what cvr_create decides on the way and the profiling knobs it reads from the environment
+struct IOpt : cvr_options {
+    int32_t layout_auto_resident = 0;      // the automatic layout chose the "resident" form: every workgroup on a CU of its own at once
+    int32_t stream_ahead = 0;              // CVR_DEBUG_STREAM_AHEAD: groups the matrix stream runs ahead of the x gather: 0 / 1 = one, >= 2 = three
+    int32_t gather_depth = 0;              // CVR_DEBUG_GATHER_DEPTH: groups the x gather runs ahead of the FMAs: 1 or 2
+    int32_t debug_col_mask = 0;            // CVR_DEBUG_COL_MASK: folds the gather onto a 2^k-entry table (timing only: wrong y)
+    int32_t panel_on_one_xcd = 0;          // this image is a column panel that will run on the workgroups of one XCD (run_spmv, d_multi)
+    int32_t cus = 256, xcds = 8;           // the device's geometry (chip_of)
+};
+
+// One CVR64 image on the device: the whole matrix, or one column panel of it (rows compacted to those that
+// have a non-zero in the panel).
+struct Part {
+    cvr::DeviceImage img{};
+    // device CSR + plan (dropped after conversion unless keep_csr)
+    int64_t  *d_rp = nullptr;
+    int32_t  *d_ci = nullptr;
+    void     *d_va = nullptr;
+    int64_t  *d_nzb = nullptr;
+    uint32_t *d_pad = nullptr;
+    size_t    stream_bytes = 0;
+    int64_t   nrows = 0, nnz = 0, nnz_span = 0, nchunks = 0, nshared = 0, yext = 0;
+    int64_t   zoff = 0;        // panels: where this part's y_ext starts in the partial-sum buffer z
+
+    void release_csr()
+    {
+        if (d_rp) (void)hipFree(d_rp);
+        if (d_ci) (void)hipFree(d_ci);
+        if (d_va) (void)hipFree(d_va);
+        if (d_nzb) (void)hipFree(d_nzb);
+        if (d_pad) (void)hipFree(d_pad);
+        d_rp = nullptr; d_ci = nullptr; d_va = nullptr; d_nzb = nullptr; d_pad = nullptr;
+    }
+    void release_all()
+    {
+        release_csr();
+        if (img.stream) (void)hipFree(img.stream);
+        if (img.desc) (void)hipFree(img.desc);
+        if (img.target) (void)hipFree(img.target);
+        if (img.shared) (void)hipFree(img.shared);
+        if (img.win_base) (void)hipFree(img.win_base);
+        if (img.desc2) (void)hipFree(img.desc2);
+        if (img.pace) (void)hipFree(img.pace);
+        delete img.pace_epoch;
+        if (img.cbase) (void)hipFree(img.cbase);
+        if (img.hub_cols) (void)hipFree(img.hub_cols);
+        if (img.hub_index) (void)hipFree(img.hub_index);
+        if (img.hub_bitmap) (void)hipFree(img.hub_bitmap);
+        if (img.hub_x) (void)hipFree(img.hub_x);
+        img = cvr::DeviceImage{};
+    }
+};
+
+struct cvr_handle {
+    int               device = 0;
+    hipStream_t       stream = nullptr;
+    bool              converted = false;
+    cvr_info          info{};
+    std::vector<Part> parts;            // 1 part, or one per column panel
+    // column panels: partial sums z (the panels' y_ext buffers, concatenated), per panel the rows of its sub-rows, and
+    // where each block of kCombineRows rows starts in every panel (combine_kernel)
+    void     *d_z = nullptr;
+    uint32_t *d_rows = nullptr, *d_block_off = nullptr;
+    cvr::CombinePanel *d_cpanels = nullptr;
+    void     *d_dict = nullptr;           // value dictionary (sorted by bit pattern) shared by all parts, or null
+    uint32_t  ndict = 0;
+    cvr::FixPart *d_fixparts = nullptr;   // panels: the fix-up of every panel in one launch
+    // panels, one per XCD at a time (cvr_kernels.h: PanelArgs): rounds of eight panels per launch; d_multi[round][8]
+    cvr::PanelArgs       *d_multi = nullptr;
+    std::vector<uint32_t> multi_chunks;   // per round: the most chunks any of its panels has
+    uint32_t              multi_ystage = 0;
+    uint32_t  max_nshared = 0;
+    uint32_t *d_err = nullptr;
+    void     *d_x = nullptr;            // x_ext: ncols + 1
+    void     *d_y = nullptr;            // y_ext (1 part) or y (panels)
+    size_t    vsz = 8;
+    std::vector<hipEvent_t> events;
+    hipEvent_t z_free = nullptr;         // column panels: recorded after the combine pass; the next SpMV (on any stream) waits for it
+    bool       z_used = false;
+    cvr::PlanScratch plan_ws;            // cvr_create only: scratch of the device planner (released before cvr_create returns)
+    // cvr_create only: 32 KiB of device scratch for the small tables of its analysis passes (layout probe 16 KiB, dictionary
+    // table 8 KiB + flags) and the host copies of the dictionary scan when it ran together with the probe
+    uint8_t                        *d_small = nullptr;
+    bool                            dict_scanned = false, small_clean = false;
+    std::vector<unsigned long long> dict_tab;
+    uint32_t                        dict_flags[2] = {0, 0};
+
+    bool paneled() const { return parts.size() > 1; }
+};
+
+namespace cvrh {
+
+// ---- cvr_capi.hip
+// Geometry of a device as the layout rules need it: CUs from hipDeviceProp_t::multiProcessorCount; XCDs = CUs / 32 (gfx950 has 32
+// CUs per XCD; the runtime reports no XCD count of its own), so a partitioned device (CPX: one XCD of 32 CUs) gets the arithmetic
+// of its own size.  The XCD-aware parts (contiguous chunk ranges per XCD, one column panel per XCD) assume the eight XCDs of the
+// whole chip and switch themselves off otherwise.  Cached per device; {256, 8} if the query fails.
+struct Chip { int cus = 256, xcds = 8; };
+Chip       chip_of(int device);
+hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st);      // y_ext = A x for the whole handle on `st`
+IOpt       make_iopt(const cvr_options *in);
+int        check_csr(const cvr_csr_view *c, bool columns_on_host = true);
+int        check_columns_device(const int32_t *ci_dev, int64_t j0, int64_t j1, int64_t ncols);
+
+// ---- cvr_layout.hip: the layout of one image (chunk length, workgroup shape, LDS budget, column phases, hub tables) and its device side
+// the host side of one image: the chunk plan (from the host planner, or fetched from the device planner) and the per-chunk
+// tables derived from it.  With a host row_ptr there is no device call and no error text: the panels of a host split plan
+// their images on parallel threads.
+struct PartPlan {
+    int                   S = 0;
+    cvr::Plan             plan;
+    std::vector<uint32_t> desc, pad, desc2;
+    std::vector<int64_t>  nzb;
+    int64_t               max_nseg = 0, yext = 0;
+    bool                  too_large = false;
+    // LDS of the SpMV workgroup (160 KiB per CU)
+    int      wpb = 1, phases = 1;
+    int64_t  win = 0;              // x window, values
+    int64_t  stage = 64;           // row sums (column phases: row accumulators) per wavefront
+    int      col_bits = 31;        // column phases: bits of a column index (the row field of a segment's last column word starts there)
+    bool     tag16 = false;        // column phases: the rows of the pieces in 16-bit tags of their own
+    bool     lds_short = false;    // column phases do not fit beside the window
+    int      plan_threads = 0;     // 0: the planner's own small team; 1: the caller plans several images side by side
+    int64_t  hub_n = 0;            // hub table entries staged in LDS in front of the window (decided before planning)
+};
+
+// rows in device memory (rp == nullptr): row_ptr at dr->rp, first and last entry dr->nz0, dr->nz1; planned on the device
+struct DevRows { const int64_t *rp = nullptr; int64_t nz0 = 0, nz1 = 0; hipStream_t st = nullptr; cvr::PlanScratch *ws = nullptr; };
+// matrices of at least this many rows whose row_ptr is on the device anyway are planned there (cvr_plan_dev.hip)
+constexpr int64_t kDevicePlanRows = 200000;
+// (CVR_DEVICE_PLAN_ROWS overrides it: the fuzz tests send their small matrices through the device planner with 0)
+inline int64_t device_plan_rows() { const char *e = getenv("CVR_DEVICE_PLAN_ROWS"); return e ? atoll(e) : kDevicePlanRows; }
+
+constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24 << 10, kSmallBytes = 32 << 10;
+constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer
+int        pick_steps(int64_t nslots_est, int64_t max_row = 0, double cus = 256.0);
+hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr = nullptr);
+hipStream_t side_stream(int device);
+hipError_t acquire_stream(int device, hipStream_t *out);
+void       release_stream(int device, hipStream_t s);
+hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64_t nz1, bool f32, bool first, unsigned long long *tab_host, uint32_t *flags_host, bool last,
+                             hipStream_t st);
+int        auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt);
+int        choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt, PartPlan &pp,
+                       bool allow_reorder);
+int        build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
+                      hipMemcpyKind civa_kind, bool f32, const IOpt &opt, double *plan_s, PartPlan *planned = nullptr, const DevRows *dr = nullptr);
+int        finish_part(cvr_handle *h, Part &part);
+
+// ---- cvr_panels.hip: column panels from host arrays, the panel rule
+// host arrays without value-initialisation (hundreds of MB: a zero-fill pass per array is measurable)
+template <typename T> struct Raw {
+    std::unique_ptr<T[]> p;
+    size_t               n = 0;
+    void     alloc(size_t m) { p.reset(new T[m ? m : 1]); n = m; }
+    T       *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+    size_t   size() const { return n; }
+    T       &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
+struct PanelSplit {
+    std::vector<Raw<int64_t>>  rp;
+    std::vector<Raw<int32_t>>  ci;
+    std::vector<Raw<uint64_t>> va;     // values as raw 8-byte words (fp32: two per word)
+    std::vector<Raw<uint32_t>> rows;   // compact sub-row -> row
+};
+
+void       split_panels(const cvr_csr_view &v, int P, PanelSplit &out);
+double     l2_miss_estimate(const cvr_csr_view &v);
+hipError_t l2_miss_estimate_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t ncols, bool f32, hipStream_t st, double *miss);
+int        panels_from_miss(double xb, double miss);
+int        auto_panels(const cvr_csr_view &v, double *miss_out);
+int        xcd_panel_count(int P, double xbytes);
+
+// ---- cvr_comm.hip: RCCL, loaded on first use
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId)    get_unique_id = nullptr;
+    decltype(&ncclCommInitRank)   comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy)    comm_destroy = nullptr;
+    decltype(&ncclAllGather)      all_gather = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclCommInitAll)    comm_init_all = nullptr;      // one process driving several GPUs (cvr_multi.hip)
+    decltype(&ncclGroupStart)     group_start = nullptr;
+    decltype(&ncclGroupEnd)       group_end = nullptr;
+};
+const RcclApi *rccl_api();      // null when librccl cannot be loaded
+
+#define RCCL_TRY(api, expr)                                                                                       \
+    do {                                                                                                          \
+        ncclResult_t r_ = (expr);                                                                                 \
+        if (r_ != ncclSuccess) return fail(CVR_ERR_HIP, "%s: %s (%s:%d)", #expr, (api)->error_string(r_), __FILE__, __LINE__); \
+    } while (0)
+
+
+}  // namespace cvrh
+
+struct cvr_comm {
+    ncclComm_t  comm = nullptr;
+    int         nranks = 0, rank = 0, device = 0;
+    hipStream_t stream = nullptr;                 // the collectives of cvr_spmv_gather_repeat run here
+    hipEvent_t  ready[2] = {nullptr, nullptr};    // y_dev[b] computed
+    hipEvent_t  done[2] = {nullptr, nullptr};     // gather of y_dev[b] into yall_dev[b] finished
+    bool        pending[2] = {false, false};
+};

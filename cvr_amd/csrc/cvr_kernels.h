@@ -19,6 +19,7 @@ struct DeviceImage {
     uint8_t *target = nullptr;   // [nchunks][64]
     int64_t *shared = nullptr;   // [nshared][3] {row, c0, c1}
     uint32_t nshared = 0;
+    uint32_t ncus = 256;            // CUs of the device (hipDeviceProp_t::multiProcessorCount)
     int      xcd_swizzle = 1;       // 0 off, 1 contiguous chunk range per XCD, 2 additionally consecutive chunks per CU (experiment)
     int      stream_ahead = 1;      // groups the matrix stream runs ahead of the x gather: 1, or 3 (>= 2)
     uint32_t ystage = 1024;         // row sums a wavefront stages in LDS (multiple of 64, <= kYStageMax)

@@ -1,0 +1,442 @@
+// cvr_layout.hip -- the layout of one CVR64 image and its device side: chunk length (pick_steps), the chunk plan with the LDS budget of
+// the SpMV workgroup (plan_part), the automatic choice of the workgroup layout from a device-side look at the CSR (auto_layout), hub
+// tables (choose_hubs), allocation and upload (build_part, finish_part).  Called by cvr_create (cvr_capi.hip).
+#include "cvr_internal.h"
+
+using namespace cvrh;
+
+namespace cvrh {
+
+int pick_steps(int64_t nslots_est, int64_t max_row, double cus)
+{
+    // The plain layout (one chunk per workgroup).  Images of more than 12 chunks per CU at S = 32 run in rounds and take
+    // S = 32 (LiveJournal panels, R-MAT, banded: within 1 % of the best S, profiles/r02_steps_rule_check.log,
+    // r01_steps_large_matrices.log).  Smaller ones are resident at once: what decides there is (1) that no row is cut over
+    // chunks -- a cut row brings the fix-up kernel, a second launch worth 1.9 us on a 8-us SpMV -- so 16 S >= the longest
+    // row, and (2) beyond that as many chunks as possible, i.e. the smallest such S (web-Google-shaped matrices of 0.6 M and
+    // 1.3 M non-zeros: S = 28 is the best of 8 .. 64, 7.9 and 9.5 us; the round-1 fit on shards of one matrix took 24 and 44:
+    // 9.8 and 11.8 us).  cvr_tune measures instead.
+    const double kCus = cus;             // (a column panel that runs on one XCD counts its chunks against that XCD's 32 CUs)
+    auto chunks = [&](int S) { return (double)nslots_est * 1.004 / (64.0 * S) + 1.0; };
+    if (chunks(32) > kCus * 12.0) return 32;
+    int S = (int)std::min<int64_t>(64, std::max<int64_t>(12, ((max_row + 15) / 16 + 3) / 4 * 4));
+    while (S < 64 && chunks(S) > kCus * 12.0) S += 4;
+    return S;
+}
+
+hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr)
+{
+    const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
+    pp.S = opt.steps_per_chunk;
+    if (pp.S == 0) {
+        int64_t max_row = 0;
+        const double cus = opt.panel_on_one_xcd ? (double)opt.cus / opt.xcds : (double)opt.cus;
+        if ((double)(nz1 - nz0 + nrows / 4) / (64.0 * 32.0) <= cus * 12.0) {    // (only where the rule weighs single launches)
+            if (rp) for (int64_t r = 0; r < nrows; r++) max_row = std::max(max_row, rp[r + 1] - rp[r]);
+            else { const hipError_t e = cvr::max_row_device(dr->rp, nrows, &max_row, dr->st); if (e != hipSuccess) return e; }
+        }
+        pp.S = pick_steps(nz1 - nz0 + nrows / 4, max_row, cus);
+    }
+    // Wavefronts (consecutive chunks) per SpMV workgroup: 1 by default; more only pay together with an LDS window of x,
+    // which the workgroup's chunks then share (profiles/r02_wg_window_sweep.log).
+    pp.wpb = std::min(std::max(opt.waves_per_block, 1), cvr::kMaxWavesPerBlock);
+    pp.phases = std::min(std::max(opt.col_phases, 1), 64);
+    if (ncols < 64 * pp.phases) pp.phases = 1;
+    if (pp.hub_n > 0) pp.phases = 1;               // (the hub flag and the row field of a phased image share bits of the column word)
+    // LDS window of x per workgroup (off by default): `win` consecutive values of x staged with coalesced loads; gathers
+    // inside it are served by ds_read instead of a 128-byte L1 fill each.
+    pp.win = std::min<int64_t>(opt.x_window < 0 ? 0 : opt.x_window, ncols + 1) & ~(int64_t)3;      // whole 16-byte loads, inside x_ext
+    const int64_t vs = f32 ? 4 : 8;
+    int64_t       max_rows = 0;
+    if (pp.phases > 1) {
+        // column phases: every chunk accumulates its rows in LDS, so the planner caps the rows of a chunk at what is left of
+        // the 160 KiB beside steal slots, dictionary and window -- and at what the row field of a segment's last column
+        // word can hold (the bits between the column index and the end flag)
+        pp.col_bits = 1;
+        while (((int64_t)1 << pp.col_bits) <= ncols) pp.col_bits++;
+        const int64_t row_field = pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
+        auto rows_for = [&](int64_t win) {
+            const int64_t left = (int64_t)cvr::kLdsBytes - (cvr::kDictMax + win + 4) * vs;      // (no steal slots: spmv_seg_kernel)
+            return std::min<int64_t>((left / pp.wpb / vs) & ~(int64_t)3, cvr::kYStageMax);
+        };
+        while (pp.win > 0 && rows_for(pp.win) < 512) pp.win = (pp.win - 1024 > 0 ? pp.win - 1024 : 0) & ~(int64_t)3;      // the window gives way
+        // a chunk of S steps holds at most 64 S rows: no need for more accumulators than that (keeps the LDS small)
+        const int64_t want = std::min<int64_t>(rows_for(pp.win), ((int64_t)cvr::kLanes * pp.S + 1 + 3) & ~(int64_t)3);
+        // wide row tags (16 bits of their own per slot) when the column word has no room for the rows such a chunk may hold
+        pp.tag16 = opt.row_tags16 > 0 || (opt.row_tags16 < 0 && row_field + 1 < want);
+        if (pp.tag16) pp.col_bits = 31;
+        pp.stage = std::min<int64_t>(want, pp.tag16 ? (int64_t)65532 : (row_field + 1) & ~(int64_t)3);
+        if (pp.stage < 64) { pp.lds_short = true; pp.phases = 1; pp.stage = 64; }
+        else max_rows = pp.stage - 1;                 // + the dump entry of the pad segment
+    }
+    if (rp) {
+        pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold, max_rows, pp.plan_threads);
+    } else {
+        bool             declined = false;
+        const hipError_t e = cvr::plan_chunks_device(dr->rp, nrows, nz1, pp.S, opt.split_threshold, max_rows, &pp.plan, &declined, dr->st, dr->ws);
+        if (e != hipSuccess) return e;
+        if (declined) {       // (chunks beyond the 15-bit jump, or a row block beyond 32-bit slot positions): the row pointers come to the host after all
+            std::vector<int64_t> hrp((size_t)nrows + 1);
+            const hipError_t     e2 = hipMemcpy(hrp.data(), dr->rp, sizeof(int64_t) * hrp.size(), hipMemcpyDeviceToHost);
+            if (e2 != hipSuccess) return e2;
+            pp.plan = cvr::plan_chunks(nrows, hrp.data(), pp.S, opt.split_threshold, max_rows, pp.plan_threads);
+        }
+    }
+    const cvr::Plan &plan = pp.plan;
+    const int64_t    nchunks = (int64_t)plan.chunks.size();
+    pp.yext = nrows + 1 + 2 * nchunks;
+    if (pp.yext >= (int64_t)0xffffffffu || nchunks >= (int64_t)0x7fffffff) { pp.too_large = true; return hipSuccess; }
+    pp.desc.resize((size_t)nchunks * 4);
+    if (pp.phases > 1) pp.desc2.resize((size_t)nchunks * 2, 0u);
+    pp.pad.resize((size_t)nchunks);
+    pp.nzb.resize((size_t)nchunks + 1);
+    for (int64_t k = 0; k < nchunks; k++) {
+        const cvr::Chunk &c = plan.chunks[(size_t)k];
+        pp.max_nseg = std::max(pp.max_nseg, c.nseg);
+        pp.desc[4 * k + 0] = (uint32_t)c.row_first;
+        pp.desc[4 * k + 1] = (uint32_t)c.nseg;
+        // where segment q writes: a row begun earlier -> carry_head(k); a row continued later -> carry_tail(k);
+        // the pad segment -> dump; else its row.  head_dest / last_dest are that rule at q = 0 and q = nseg-1.
+        auto dest = [&](int64_t q) -> uint32_t {
+            if (q >= c.nrows_in) return (uint32_t)nrows;
+            if (q == 0 && c.head_shared) return (uint32_t)(nrows + 1 + 2 * k);
+            if (q == c.nrows_in - 1 && c.tail_shared) return (uint32_t)(nrows + 1 + 2 * k + 1);
+            return (uint32_t)(c.row_first + q);
+        };
+        pp.desc[4 * k + 2] = dest(0);
+        pp.desc[4 * k + 3] = dest(c.nseg - 1);
+        if (pp.phases > 1) {            // column phases: head / last_dest belong to the first / last ROW; desc.y and desc2.x come from the device
+            pp.desc[4 * k + 3] = dest(c.nrows_in - 1);
+            pp.desc2[2 * k + 1] = (uint32_t)c.nrows_in;
+        }
+        pp.pad[(size_t)k] = (uint32_t)c.pad_cnt;
+        pp.nzb[(size_t)k] = c.nz_begin;
+    }
+    pp.nzb[(size_t)nchunks] = plan.nz_end;
+    if (pp.phases > 1) {          // no more accumulators than the fullest chunk has rows (+ the dump entry): the cap stays what no chunk exceeds
+        int64_t most = 0;
+        for (const cvr::Chunk &c : plan.chunks) most = std::max(most, c.nrows_in);
+        pp.stage = std::min<int64_t>(pp.stage, std::max<int64_t>(64, (most + 1 + 3) & ~(int64_t)3));
+    }
+    if (pp.phases == 1) {
+        // LDS budget without phases: steal slots and dictionary are fixed; the row-sum stage is sized for the chunk with the
+        // most segments, so every chunk writes its y coalesced (chunks of very short rows beyond the stage store directly);
+        // the window takes what it asked for, the stage at least 64 rows per wavefront, and whatever does not fit is cut:
+        // first the stage down to 512 rows per wavefront, then the window.
+        const int64_t total = (int64_t)cvr::kLdsBytes / vs;
+        const int64_t fixed = (int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + 4 + ((pp.hub_n + 3) & ~(int64_t)3);     // dictionary room is reserved before it is known
+        int64_t stage = std::min<int64_t>(std::max<int64_t>((pp.max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
+        if (fixed + pp.wpb * stage + pp.win > total) stage = std::max<int64_t>(std::min<int64_t>(stage, 512), ((total - fixed - pp.win) / pp.wpb) & ~(int64_t)63);
+        if (stage < 64) stage = 64;
+        if (fixed + pp.wpb * stage + pp.win > total) pp.win = std::max<int64_t>(0, total - fixed - pp.wpb * stage) & ~(int64_t)3;
+        pp.stage = stage;
+    }
+    return hipSuccess;
+}
+
+// A second stream per device, shared by all handles of the process, for the few analysis / conversion kernels that do not
+// depend on each other (layout probe | dictionary scan, conversion | window choice): each of them is too small to fill the
+// GPU and bound by latency, so side by side they take the time of one.  Created on first use (creating a stream costs
+// milliseconds), never destroyed.
+hipStream_t side_stream(int device)
+{
+    static std::mutex  mu;
+    static hipStream_t streams[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); streams[device] = nullptr; }
+    return streams[device];
+}
+
+// The handle's own stream comes from a small per-device pool: creating a stream takes 2-3 ms and destroying one about as long,
+// more than the whole analysis and conversion of a web-Google-sized matrix.  A stream goes back idle (cvr_destroy synchronises
+// it first); at most eight are kept per device.
+static std::mutex               g_pool_mu;
+static std::vector<hipStream_t> g_stream_pool[64];
+
+hipError_t acquire_stream(int device, hipStream_t *out)
+{
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_stream_pool[device].empty()) { *out = g_stream_pool[device].back(); g_stream_pool[device].pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void release_stream(int device, hipStream_t s)
+{
+    if (!s) return;
+    if (device >= 0 && device < 64 && hipStreamSynchronize(s) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_stream_pool[device].size() < 8) { g_stream_pool[device].push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+
+
+// the dictionary scan of the values [nz0, nz1) of a part, enqueued on the handle's stream: table and flags come back into
+// tab_host / flags_host once the stream is synchronised
+hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64_t nz1, bool f32, bool first, unsigned long long *tab_host, uint32_t *flags_host, bool last,
+                                    hipStream_t st)
+{
+    unsigned long long *d_tab = reinterpret_cast<unsigned long long *>(h->d_small + kSmallDictTab);
+    uint32_t           *d_flags = reinterpret_cast<uint32_t *>(h->d_small + kSmallDictFlags);
+    hipError_t          e = hipSuccess;
+    if (first && !h->small_clean) {        // (cvr_create left the table and the flags ready for the first scan)
+        e = hipMemsetAsync(d_tab, 0xff, sizeof(unsigned long long) * 1024, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t) * 2, st);
+    }
+    if (e == hipSuccess) e = cvr::launch_dict_scan(d_va, nz0, nz1, f32, d_tab, d_flags, st);
+    if (e == hipSuccess && last) {
+        e = hipMemcpyAsync(tab_host, d_tab, sizeof(unsigned long long) * 1024, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(flags_host, d_flags, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, st);
+    }
+    return e;
+}
+
+// The automatic layout (every layout option left at its default; one image, no column panels).  Matrices small enough
+// for all their chunks to be resident at once -- 6 to 8 chunks per workgroup, one workgroup per CU -- run in the "resident"
+// layout when it pays: the workgroup's chunks share an LDS window of x if a sizeable share of the non-zeros lies near the
+// diagonal, and feed their rows column phase by column phase when x is larger than what an L2 keeps beside the matrix
+// stream (profiles/r02_wg_window_sweep.log, r02_column_phases_sweep.log: 32.5 -> 23.4 us on the web-Google shape).
+// Decided from a device-side pass over the uploaded CSR (sortedness of the rows, near-diagonal share).
+int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt)
+{
+    const int64_t nnz = nz1 - nz0;
+    opt.layout_auto_resident = 0;
+    if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT")) {
+        if (opt.col_phases < 0) opt.col_phases = 0;
+        return CVR_OK;
+    }
+    opt.col_phases = 0;
+    if (nrows < 4096 || ncols < 4096) return CVR_OK;
+    const int64_t vs = f32 ? 4 : 8;
+    const double  slots = ((double)nnz + (double)nrows / 4) * 1.006;      // pad slots of empty rows, chunk tails
+    // candidates: 8, 7 or 6 chunks per workgroup with the smallest S that keeps the workgroups a few under the CU count; the one
+    // that fills the CUs best wins (ties: more waves)
+    int best_w = 0, best_S = 0;
+    double best_fill = 0;
+    for (int w = 8; w >= 6; w--) {
+        int S = (int)std::ceil(slots / (64.0 * w * (double)(opt.cus - 4)) / 4.0) * 4;
+        if (S < 24 || S > 128) continue;                       // tiny shards and matrices beyond one resident pass keep the plain layout
+        const double wgs = std::ceil(slots / (64.0 * w * S));
+        if (wgs > best_fill) { best_fill = wgs; best_w = w; best_S = S; }
+    }
+    if (!best_w) return CVR_OK;
+    const int64_t win = (64 * 1024) / vs;                       // 64 KiB of x per workgroup
+    static_assert(sizeof(unsigned long long) * 2 * cvr::kProbeBlocks <= kSmallDictTab, "probe output fits its part of the small scratch");
+    unsigned long long *d_out = reinterpret_cast<unsigned long long *>(h->d_small + kSmallProbe);
+    std::vector<unsigned long long> pageable;
+    const bool          pin = h->plan_ws.pinned && h->plan_ws.pinned_bytes >= kPinnedSmall;
+    if (!pin) pageable.resize(2 * cvr::kProbeBlocks + 1024 + 1);
+    unsigned long long *outv = pin ? reinterpret_cast<unsigned long long *>(h->plan_ws.pinned + kPinnedProbe) : pageable.data();
+    unsigned long long *tabv = pin ? reinterpret_cast<unsigned long long *>(h->plan_ws.pinned + kPinnedDictTab) : pageable.data() + 2 * cvr::kProbeBlocks;
+    uint32_t           *flagv = pin ? reinterpret_cast<uint32_t *>(h->plan_ws.pinned + kPinnedDictFlags) : reinterpret_cast<uint32_t *>(pageable.data() + 2 * cvr::kProbeBlocks + 1024);
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the upload
+    const double tp0 = now_s();
+    hipError_t e = cvr::launch_probe(part.d_rp, part.d_ci, nrows, ncols, (uint32_t)(win / 4), d_out, h->stream, h->small_clean);
+    if (e == hipSuccess) e = hipMemcpyAsync(outv, d_out, sizeof(unsigned long long) * 2 * cvr::kProbeBlocks, hipMemcpyDeviceToHost, h->stream);
+    // the dictionary scan of the values rides along: it depends on nothing decided here, and a second submission with its own
+    // synchronisation costs more than the scan
+    const bool with_dict = opt.value_dict != 0 && nnz > 0;
+    hipStream_t side = with_dict ? side_stream(h->device) : nullptr;       // (the upload is complete: nothing to order between the two streams)
+    if (!side) side = h->stream;
+    if (e == hipSuccess && with_dict) e = enqueue_dict_scan(h, part.d_va, nz0, nz1, f32, true, tabv, flagv, true, side);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && side != h->stream) e = hipStreamSynchronize(side);
+    unsigned long long out[2] = {0, 0};
+    for (uint32_t b = 0; b < cvr::kProbeBlocks; b++) { out[0] |= outv[2 * b]; out[1] += outv[2 * b + 1]; }
+    h->small_clean = false;
+    if (e == hipSuccess && with_dict) { h->dict_tab.assign(tabv, tabv + 1024); h->dict_flags[0] = flagv[0]; h->dict_flags[1] = flagv[1]; h->dict_scanned = true; }
+    h->info.probe_s = now_s() - tp0;
+    if (e != hipSuccess) return fail(CVR_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
+    const bool   sorted = out[0] == 0;
+    const double near = (double)out[1] / std::max<double>((double)nnz, 1.0);
+    const double xbytes = (double)ncols * vs;
+    // (a matrix with nearly everything near the diagonal is a band: consecutive rows share their lines of x in L1 already)
+    const bool   want_win = near >= 0.15 && near < 0.9, want_phases = sorted && xbytes > 2.5e6 && near < 0.9;
+    h->info.near_diagonal_share = near;
+    if (!want_win && !want_phases) return CVR_OK;
+    opt.layout_auto_resident = 1;
+    opt.waves_per_block = best_w;
+    opt.steps_per_chunk = best_S;
+    opt.x_window = want_win ? (int32_t)win : 0;
+    opt.col_phases = want_phases ? (int32_t)std::min(32.0, std::max(2.0, std::floor(xbytes / 600e3 + 0.5))) : 1;
+    return CVR_OK;
+}
+
+// Hub table (cvr_hub.hip): hub_table > 0 asks for that many entries, < 0 decides: matrices too large for the resident layout
+// whose x does not fit an L2 get the columns counted on the device, and the table is used when the columns that fit the LDS
+// (beside 8 chunks' row stages) hold at least half of the (sampled) non-zeros -- R-MAT scale 22 fp32: 0.56, 402 -> 289 us;
+// fp64 (half as many entries fit): 0.41, where the table loses (profiles/r02_hub_table_rmat.log).  The workgroup then has 8 chunks.
+int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt, PartPlan &pp,
+                       bool allow_reorder)
+{
+    if (opt.hub_table == 0 || opt.layout_auto_resident || opt.col_phases > 1 || nrows <= 0 || ncols >= (int64_t)cvr::kHubBit) return CVR_OK;
+    const int64_t vs = f32 ? 4 : 8, nnz = nz1 - nz0;
+    const bool    automatic = opt.hub_table < 0;
+    if (automatic && (opt.waves_per_block != 0 || opt.x_window > 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT") || (double)ncols * vs < 6e6 || nnz < (8 << 20))) return CVR_OK;
+    const int     wpb = opt.waves_per_block > 0 ? std::min(opt.waves_per_block, cvr::kMaxWavesPerBlock) : 8;
+    const int64_t win = std::max(opt.x_window, 0);
+    int64_t       room = ((int64_t)cvr::kLdsBytes / vs - (int64_t)wpb * (cvr::kLanes + 512) - cvr::kDictMax - win - 8) & ~(int64_t)1023;      // 512 staged row sums per chunk
+    if (room < 1024) return automatic ? CVR_OK : fail(CVR_ERR_INVALID, "hub_table: no LDS left beside %d chunks per workgroup and the x window", wpb);
+    if (!automatic) room = std::min<int64_t>(room, opt.hub_table);
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the upload
+    const double t0 = now_s();
+    cvr::HubSelection sel;
+    // The whole of x re-ordered by popularity (every column index of the image becomes its rank, x_perm = x[perm] is built
+    // before every SpMV): the popular columns then share cache lines and stay in the L2s.  R-MAT-22 fp64 (x = 33.5 MB): plain
+    // 487 us, table alone 538, table + re-ordered x 400 us; fp32 (x = 16.8 MB): 288 -> 291 us, so only for a large x; not
+    // inside column panels (a panel ranks its own range).  hub_reorder: < 0 = this rule, 0 off, 1 on.
+    const bool        full_order = allow_reorder && (opt.hub_reorder > 0 || (opt.hub_reorder < 0 && (double)ncols * vs >= 24e6));
+    const hipError_t  e = cvr::select_hubs(d_ci, nz0, nz1, ncols, (uint32_t)room, &sel, h->stream, full_order);
+    h->info.hub_select_s += now_s() - t0;
+    if (e != hipSuccess) { cvr::free_hubs(sel); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
+    h->info.hub_share = std::max(h->info.hub_share, sel.share);
+    if (sel.H == 0 || (automatic && sel.share < (full_order ? 0.3 : 0.5))) { cvr::free_hubs(sel); return CVR_OK; }
+    part.img.hub_n = sel.H; part.img.hub_cols = sel.hub_cols; part.img.hub_index = sel.hub_index; part.img.hub_bitmap = sel.hub_bitmap;
+    part.img.order_n = sel.order_n;
+    HIP_TRY(hipMalloc(&part.img.hub_x, (size_t)vs * (sel.order_n ? ((size_t)sel.order_n + 8) : ((sel.H + 3u) & ~3u))));
+    pp.hub_n = sel.H;
+    if (opt.waves_per_block == 0) opt.waves_per_block = wpb;
+    return CVR_OK;
+}
+
+// device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
+// (rp == nullptr: part.d_rp is already in place -- the row pointers of a column panel split on the device -- and `dr` describes it)
+int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
+                      hipMemcpyKind civa_kind, bool f32, const IOpt &opt, double *plan_s, PartPlan *planned, const DevRows *dr)
+{
+    const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
+    const size_t  vsz = f32 ? 4 : 8, nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
+    // the CSR goes to the device first (asynchronously): the automatic layout choice below looks at it there
+    const bool adopted = rp && part.d_rp && part.d_ci && part.d_va;      // cvr_create's staging copy of the whole CSR, handed over
+    if (rp && !adopted) HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
+    if (!adopted) HIP_TRY(hipMalloc(&part.d_ci, sizeof(int32_t) * std::max<size_t>(nnz_span, 1)));
+    if (!adopted) HIP_TRY(hipMalloc(&part.d_va, vsz * std::max<size_t>(nnz_span, 1)));
+    if (rp && !adopted && nrows > 0) HIP_TRY(hipMemcpyAsync(part.d_rp, rp, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice, h->stream));
+    if (nnz_span && !adopted) {
+        HIP_TRY(hipMemcpyAsync(part.d_ci, ci, sizeof(int32_t) * nnz_span, civa_kind, h->stream));
+        HIP_TRY(hipMemcpyAsync(part.d_va, va, vsz * nnz_span, civa_kind, h->stream));
+    }
+    PartPlan    local;
+    IOpt        popt = opt;
+    if (!planned) {
+        int rc = auto_layout(h, part, nrows, ncols, f32, nz0, nz1, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
+        if (rc) return rc;
+        rc = choose_hubs(h, part, part.d_ci, nrows, ncols, f32, nz0, nz1, popt, local, true);
+        if (rc) return rc;
+        const double   t0 = now_s();
+        DevRows        here{part.d_rp, nz0, nz1, h->stream, &h->plan_ws};
+        const bool     on_dev = rp && nrows > 0 && nrows >= device_plan_rows() && !getenv("CVR_HOST_PLAN");      // (the upload of row_ptr is in front of the planner's kernels on the stream)
+        const int64_t *prp = on_dev ? nullptr : rp;
+        const DevRows *pdr = on_dev ? &here : dr;
+        HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));
+        // the resident layout wants every workgroup on a CU of its own at once: one more step per chunk until they fit
+        while (popt.layout_auto_resident && !local.too_large && (int64_t)local.plan.chunks.size() > (int64_t)local.wpb * popt.cus && popt.steps_per_chunk < 4096) {
+            popt.steps_per_chunk += 4;
+            local = PartPlan();
+            HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));      // (the resident layout has no hub table: nothing of `local` to keep)
+        }
+        if (plan_s) *plan_s += now_s() - t0;
+        planned = &local;
+    }
+    PartPlan &pp = *planned;
+    if (pp.too_large) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
+    const int        S = pp.S;
+    const cvr::Plan &plan = pp.plan;
+    const int64_t    nchunks = (int64_t)plan.chunks.size(), yext = pp.yext;
+    const std::vector<uint32_t> &desc = pp.desc, &pad = pp.pad;
+    const std::vector<int64_t>  &nzb = pp.nzb;
+
+    part.nrows = nrows; part.nnz = nz1 - nz0; part.nnz_span = nz1; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
+    const int G = S / 4;
+    cvr::DeviceImage &img = part.img;
+    img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
+    img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)plan.shared.size();
+    img.xcd_swizzle = opt.xcds != 8 ? 0 : opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
+    img.ncus = (uint32_t)opt.cus;
+    img.stream_ahead = opt.stream_ahead >= 2 ? 3 : 1;
+    img.depth = opt.gather_depth == 2 ? 2 : 1;
+    img.wpb = (uint32_t)pp.wpb;
+    img.ystage = (uint32_t)pp.stage;
+    img.phases = (uint32_t)pp.phases;
+    if (pp.phases > 1) {
+        const int64_t pw = ((ncols + pp.phases - 1) / pp.phases + 15) / 16 * 16;
+        img.phase_width = (uint32_t)std::max<int64_t>(pw, 16);
+        img.col_bits = (uint32_t)pp.col_bits;
+        img.tag16 = pp.tag16;
+        // pieces: a lane that sits on a long row's segment falls behind the column ranges the other lanes have moved on to; with
+        // chunks longer than a few steps per phase the segments are cut (auto: 8 elements once a phase takes 8 steps or more)
+        if (S / pp.phases >= 8 && !opt.panel_on_one_xcd && !getenv("CVR_NO_PACE")) {      // long chunks: the SpMV kernel paces its wavefronts through the phases
+            HIP_TRY(hipMalloc(&img.pace, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases)));
+            HIP_TRY(hipMemsetAsync(img.pace, 0, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases), h->stream));
+            img.pace_epoch = new uint32_t(0);
+        }
+        img.piece_max = opt.piece_max > 0 ? (uint32_t)opt.piece_max : opt.piece_max < 0 && S / pp.phases >= 8 && !opt.panel_on_one_xcd ? 8u : 0u;
+        img.col_mask = pp.tag16 ? cvr::kColMask : (1u << pp.col_bits) - 1u;
+    }
+    if (popt.col_phases > 1 && pp.lds_short && !popt.layout_auto_resident) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
+    const int64_t win = pp.win;
+    img.win_elems = (uint32_t)win;
+    if (opt.debug_col_mask) img.col_mask &= (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
+
+    HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nchunks + 1)));
+    HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nchunks, 1)));
+    HIP_TRY(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
+    HIP_TRY(hipMalloc(&img.target, 64 * std::max<size_t>((size_t)nchunks, 1)));
+    HIP_TRY(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
+    if (pp.phases > 1) {
+        HIP_TRY(hipMalloc(&img.desc2, 8 * std::max<size_t>((size_t)nchunks, 1)));
+        if (nchunks) HIP_TRY(hipMemcpyAsync(img.desc2, pp.desc2.data(), sizeof(uint32_t) * pp.desc2.size(), hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1)));
+    HIP_TRY(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1), h->stream));
+    if (nchunks) {
+        HIP_TRY(hipMemcpyAsync(part.d_nzb, nzb.data(), sizeof(int64_t) * nzb.size(), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(part.d_pad, pad.data(), sizeof(uint32_t) * pad.size(), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(img.desc, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, h->stream));
+    }
+    if (!plan.shared.empty())
+        HIP_TRY(hipMemcpyAsync(img.shared, plan.shared.data(), sizeof(cvr::Shared) * plan.shared.size(), hipMemcpyHostToDevice, h->stream));
+    // narrow chunks (plain layout only): if every chunk spans fewer than 32 767 columns -- banded matrices -- the image stores
+    // 16-bit column offsets from the chunk's smallest column: 10 instead of 12 bytes per fp64 slot of a stream-bound SpMV
+    if (popt.narrow_cols != 0 && nchunks > 0 && img.wpb == 1 && img.win_elems == 0 && img.phases <= 1 && img.hub_n == 0 && !opt.debug_col_mask) {
+        uint32_t *d_wide = nullptr, wide = 1;
+        HIP_TRY(hipMalloc(&img.cbase, sizeof(uint32_t) * (size_t)nchunks));
+        HIP_TRY(hipMalloc(&d_wide, sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(d_wide, 0, sizeof(uint32_t), h->stream));
+        cvr::DeviceCsr csr;
+        csr.col_idx = part.d_ci; csr.nz_begin = part.d_nzb;
+        hipError_t e = cvr::launch_chunk_span(img, csr, img.cbase, d_wide, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&wide, d_wide, sizeof(wide), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(d_wide);
+        if (e != hipSuccess) return fail(CVR_ERR_HIP, "chunk column spans: %s", hipGetErrorString(e));
+        img.c16 = wide == 0;
+        if (!img.c16) { (void)hipFree(img.cbase); img.cbase = nullptr; }
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));   // the host staging vectors go out of scope; the caller may free its CSR
+    return CVR_OK;
+}
+
+// second half of build_part, once it is known whether the values go through a dictionary: the stream image
+int finish_part(cvr_handle *h, Part &part)
+{
+    cvr::DeviceImage &img = part.img;
+    img.dict = h->d_dict; img.ndict = h->ndict;
+    if (img.dict) img.c16 = false;                 // (the dictionary layout keeps 32-bit column words)
+    part.stream_bytes = (size_t)part.nchunks * img.G * cvr::group_bytes(img.f32, h->d_dict != nullptr, img.c16, img.tag16);
+    // the SpMV kernel's software pipeline issues its stream loads up to 5 groups past the end of a chunk (the buffer
+    // descriptor's range check returns zeros for them); the allocation is padded by that much so that the last chunk's
+    // run-ahead stays inside it whatever the hardware does with an offset beyond num_records
+    const size_t slack = 8 * (size_t)cvr::group_bytes(img.f32, h->d_dict != nullptr, img.c16, img.tag16);
+    if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
+        HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, part.stream_bytes + slack, hipDeviceMallocUncached));
+    else
+        HIP_TRY(hipMalloc(&img.stream, part.stream_bytes + slack));
+    return CVR_OK;
+}
+
+
+}  // namespace cvrh

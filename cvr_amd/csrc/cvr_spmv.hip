@@ -810,7 +810,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
         static const int env_waves = [] { const char *e = getenv("CVR_PERSIST_WAVES"); return e ? atoi(e) : -1; }();
         const uint32_t waves = img.hub_n ? 16u : env_waves >= 0 ? (uint32_t)env_waves : img.persist_waves;       // wavefronts per CU
         if (waves > 0) {
-            const uint32_t resident = 256u * std::min<uint32_t>(per_cu_lds, std::max<uint32_t>(1u, waves / wpb));
+            const uint32_t resident = img.ncus * std::min<uint32_t>(per_cu_lds, std::max<uint32_t>(1u, waves / wpb));
             if (nblocks > resident) { nblocks = resident; kstride = resident * wpb; }
         }
     }

@@ -14,7 +14,6 @@
 //     CVR_CACHE=1         keep / reuse a binary image of the parsed matrix (<mtx>.ref.cvrbin / .strict.cvrbin)
 // Exit code 0 as the reference (spmv.cpp:1947), 1 on loader errors (spmv.cpp:325-355), 2 on usage / device errors.
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -26,7 +25,6 @@
 #include "../../include/cvr_amd.h"
 
 #define HIP_OK(e)  do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
-#define NCCL_OK(e) do { ncclResult_t e_ = (e); if (e_ != ncclSuccess) { fprintf(stderr, "RCCL error %s at %s:%d\n", ncclGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
 #define CVR_OKAY(e) do { int e_ = (e); if (e_ != CVR_OK) { fprintf(stderr, "cvr error %d: %s (%s:%d)\n", e_, cvr_last_error(), __FILE__, __LINE__); return 2; } } while (0)
 
 static std::vector<int> parse_devices(const char *s)
@@ -79,115 +77,24 @@ int main(int argc, char **argv)
     cvr_fill_x(x.data(), m.ncols, xmode);   // spmv.cpp:1788
     cvr_csr_spmv_host(m.nrows, m.row_ptr, m.col_idx, m.vals, x.data(), yref.data(), nthreads);   // spmv.cpp:1843-1850
 
-    // rows sharded over the GPUs: contiguous blocks with balanced nnz, cut at row boundaries
-    // (the reference balances nnz per thread the same way, spmv.cpp:584-667)
-    std::vector<int64_t> bounds((size_t)G + 1, 0);
-    bounds[(size_t)G] = m.nrows;
-    for (int g = 1; g < G; g++) {
-        const int64_t target = m.row_ptr[0] + (m.row_ptr[m.nrows] - m.row_ptr[0]) / G * g;
-        bounds[(size_t)g] = std::lower_bound(m.row_ptr, m.row_ptr + m.nrows + 1, target) - m.row_ptr;
-        bounds[(size_t)g] = std::min<int64_t>(std::max(bounds[(size_t)g], bounds[(size_t)g - 1]), m.nrows);
-    }
-    int64_t max_rows = 0;
-    for (int g = 0; g < G; g++) max_rows = std::max(max_rows, bounds[(size_t)g + 1] - bounds[(size_t)g]);
-
-    std::vector<cvr_handle *> H((size_t)G, nullptr);
-    std::vector<cvr_info>     info((size_t)G);
-    std::vector<std::vector<int64_t>> lrp((size_t)G);
+    // One call = all GPUs (include/cvr_amd.h, cvr_create_multi): the library cuts the rows into one block per device (balanced
+    // non-zeros, at row boundaries), builds the shards, replicates x and all-gathers y -- this program only names the devices,
+    // as the reference's main only names the thread count (spmv.cpp:1857, 1882).
+    cvr_csr_view view = {};
+    view.nrows = m.nrows; view.ncols = m.ncols; view.row_ptr = m.row_ptr; view.col_idx = m.col_idx; view.vals = m.vals; view.is_f32 = 0;
+    cvr_options opt;
+    cvr_default_options(&opt);
+    if (senv) opt.steps_per_chunk = atoi(senv);
+    std::vector<int32_t> dev32(devs.begin(), devs.end());
+    cvr_multi *M = nullptr;
+    CVR_OKAY(cvr_create_multi(&M, &view, &opt, dev32.data(), G));
     double pre_s = 0;
-    for (int g = 0; g < G; g++) {
-        const int64_t b = bounds[(size_t)g], e = bounds[(size_t)g + 1], lo = m.row_ptr[b];
-        lrp[(size_t)g].resize((size_t)(e - b) + 1);
-        for (int64_t r = b; r <= e; r++) lrp[(size_t)g][(size_t)(r - b)] = m.row_ptr[r] - lo;
-        cvr_csr_view v = {};
-        v.nrows = e - b; v.ncols = m.ncols; v.row_ptr = lrp[(size_t)g].data(); v.col_idx = m.col_idx + lo; v.vals = m.vals + lo; v.is_f32 = 0;
-        cvr_options o;
-        cvr_default_options(&o);
-        o.device = devs[(size_t)g];
-        if (senv) o.steps_per_chunk = atoi(senv);
-        CVR_OKAY(cvr_create(&H[(size_t)g], &v, &o));
-        double s = 0;
-        CVR_OKAY(cvr_preprocess(H[(size_t)g], 0, &s));   // spmv.cpp:1857
-        CVR_OKAY(cvr_get_info(H[(size_t)g], &info[(size_t)g]));
-        pre_s = std::max(pre_s, s + info[(size_t)g].plan_s);
-    }
+    CVR_OKAY(cvr_preprocess_multi(M, 0, &pre_s));   // spmv.cpp:1857
     printf("The Pre-processing(CSR->CVR)   Time of CVR   is %g seconds.   [file: %s] [threads: %d]\n", pre_s, fn, nthreads);   // spmv.cpp:1009
 
-    // device vectors: x replicated; per GPU its y_ext; with G > 1 a gathered y of G * max_rows
-    std::vector<double *>    dx((size_t)G), dy((size_t)G), dall((size_t)G, nullptr);
-    std::vector<hipStream_t> st((size_t)G);
-    std::vector<hipEvent_t>  e0((size_t)G), e1((size_t)G);
-    std::vector<ncclComm_t>  comm((size_t)G);
-    for (int g = 0; g < G; g++) {
-        HIP_OK(hipSetDevice(devs[(size_t)g]));
-        const size_t ny = (size_t)std::max<int64_t>(info[(size_t)g].yext_elems, max_rows);
-        HIP_OK(hipMalloc(&dx[(size_t)g], sizeof(double) * (size_t)info[(size_t)g].x_elems));
-        HIP_OK(hipMalloc(&dy[(size_t)g], sizeof(double) * ny));
-        HIP_OK(hipMemset(dx[(size_t)g], 0, sizeof(double) * (size_t)info[(size_t)g].x_elems));
-        HIP_OK(hipMemset(dy[(size_t)g], 0, sizeof(double) * ny));
-        HIP_OK(hipMemcpy(dx[(size_t)g], x.data(), sizeof(double) * (size_t)m.ncols, hipMemcpyHostToDevice));
-        if (G > 1) HIP_OK(hipMalloc(&dall[(size_t)g], sizeof(double) * (size_t)G * (size_t)max_rows));
-        HIP_OK(hipStreamCreateWithFlags(&st[(size_t)g], hipStreamNonBlocking));
-        HIP_OK(hipEventCreate(&e0[(size_t)g]));
-        HIP_OK(hipEventCreate(&e1[(size_t)g]));
-    }
-    // RCCL needs distinct devices.  CVR_DEVICES=0,0,.. (the same GPU listed several times) keeps the sharding, the
-    // per-shard handles and the gather layout but moves the slices with device-to-device copies: a plumbing check
-    // of the multi-GPU path on a 1-GPU box.
-    bool distinct = true;
-    for (int a = 0; a < G; a++) for (int b2 = a + 1; b2 < G; b2++) if (devs[(size_t)a] == devs[(size_t)b2]) distinct = false;
-    const bool use_rccl = G > 1 && distinct;
-    if (use_rccl) NCCL_OK(ncclCommInitAll(comm.data(), G, devs.data()));
-
-    auto spmv_all = [&](bool gather) -> int {
-        for (int g = 0; g < G; g++) {
-            HIP_OK(hipSetDevice(devs[(size_t)g]));
-            CVR_OKAY(cvr_spmv_device(H[(size_t)g], dx[(size_t)g], dy[(size_t)g], st[(size_t)g]));   // spmv.cpp:1882
-        }
-        if (gather && G > 1 && !use_rccl) {
-            for (int g = 0; g < G; g++) {          // every "rank" receives every slice, as the all-gather would deliver
-                HIP_OK(hipSetDevice(devs[(size_t)g]));
-                for (int src = 0; src < G; src++)
-                    HIP_OK(hipMemcpyAsync(dall[(size_t)g] + (size_t)src * (size_t)max_rows, dy[(size_t)src], sizeof(double) * (size_t)max_rows,
-                                          hipMemcpyDeviceToDevice, st[(size_t)src]));
-            }
-        }
-        if (gather && use_rccl) {
-            NCCL_OK(ncclGroupStart());
-            for (int g = 0; g < G; g++)
-                NCCL_OK(ncclAllGather(dy[(size_t)g], dall[(size_t)g], (size_t)max_rows, ncclDouble, comm[(size_t)g], st[(size_t)g]));
-            NCCL_OK(ncclGroupEnd());
-        }
-        return 0;
-    };
-    auto sync_all = [&]() -> int {
-        for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(devs[(size_t)g])); HIP_OK(hipStreamSynchronize(st[(size_t)g])); }
-        return 0;
-    };
-    auto timed = [&](bool gather, double *sec) -> int {
-        for (int w = 0; w < 10; w++) if (spmv_all(gather)) return 2;
-        if (sync_all()) return 2;
-        for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(devs[(size_t)g])); HIP_OK(hipEventRecord(e0[(size_t)g], st[(size_t)g])); }
-        for (int k = 0; k < niters; k++) if (spmv_all(gather)) return 2;
-        for (int g = 0; g < G; g++) { HIP_OK(hipSetDevice(devs[(size_t)g])); HIP_OK(hipEventRecord(e1[(size_t)g], st[(size_t)g])); }
-        if (sync_all()) return 2;
-        double worst = 0;
-        for (int g = 0; g < G; g++) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, e0[(size_t)g], e1[(size_t)g])); worst = std::max(worst, (double)ms * 1e-3 / niters); }
-        *sec = worst;
-        return 0;
-    };
-    double t_compute = 0, t_total = 0;
-    if (timed(false, &t_compute)) return 2;
-    t_total = t_compute;
-    if (G > 1 && timed(true, &t_total)) return 2;
-
-    // y back for the verdict (from the gathered copy of GPU 0 when sharded)
-    for (int g = 0; g < G; g++) {
-        const int64_t b = bounds[(size_t)g], n = bounds[(size_t)g + 1] - b;
-        HIP_OK(hipSetDevice(devs[G > 1 ? 0 : (size_t)g]));
-        const double *src = G > 1 ? dall[0] + (size_t)g * (size_t)max_rows : dy[(size_t)g];
-        if (n) HIP_OK(hipMemcpy(y.data() + b, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
-    }
+    cvr_timing tm;
+    CVR_OKAY(cvr_spmv_multi(M, x.data(), y.data(), niters, &tm));   // spmv.cpp:1882
+    const double t_compute = tm.mean_s, t_total = tm.step_mean_s;
 
     const double nItems = (double)m.ref_nItems;
     printf("The SpMV Execution Time of CVR    is %g seconds.   [file: %s] [threads: %d]\n", t_total, fn, nthreads);   // spmv.cpp:1662
@@ -201,29 +108,34 @@ int main(int argc, char **argv)
     const double nnz_true = (double)m.ref_nItemsRaw;
     const double balg = nnz_true * 12.0 + ((double)m.ref_numRows + 1) * 4.0 + (double)m.ref_numCols * 8.0 + (double)m.ref_numRows * 8.0;
     int64_t      chunks = 0, cut = 0;
-    for (int g = 0; g < G; g++) { chunks += info[(size_t)g].nchunks; cut += info[(size_t)g].nshared; }
-    printf("{\"backend\":\"hip-gfx950\",\"gpus\":%d,\"iters\":%d,\"nnz\":%.0f,\"rows\":%lld,\"steps_per_chunk\":%d,\"chunks\":%lld,\"rows_cut\":%lld,"
-           "\"preprocess_s\":%.6g,\"spmv_compute_s\":%.6g,\"spmv_with_gather_s\":%.6g,\"gflops_2nnz\":%.6g,\"gbs_alg\":%.6g,"
+    int          S0 = 0;
+    for (int g = 0; g < G; g++) {
+        cvr_info info;
+        CVR_OKAY(cvr_multi_info(M, g, &info, nullptr, nullptr, nullptr));
+        chunks += info.nchunks; cut += info.nshared;
+        if (g == 0) S0 = info.steps_per_chunk;
+    }
+    printf("{\"backend\":\"hip-gfx950\",\"gpus\":%d,\"exchange\":\"%s\",\"iters\":%d,\"nnz\":%.0f,\"rows\":%lld,\"steps_per_chunk\":%d,\"chunks\":%lld,\"rows_cut\":%lld,"
+           "\"preprocess_s\":%.6g,\"spmv_compute_s\":%.6g,\"spmv_compute_median_s\":%.6g,\"spmv_with_gather_s\":%.6g,\"spmv_with_gather_median_s\":%.6g,\"gflops_2nnz\":%.6g,\"gbs_alg\":%.6g,"
            "\"frac_of_8TBs_per_gpu\":%.4f,\"wrong\":%lld}\n",
-           G, niters, nnz_true, (long long)m.ref_numRows, info[0].steps_per_chunk, (long long)chunks, (long long)cut, pre_s, t_compute, t_total,
-           2.0 * nnz_true / t_total / 1e9, balg / t_total / 1e9, balg / t_compute / (8e12 * G), (long long)wrong);
+           G, G == 1 ? "none" : cvr_multi_uses_rccl(M) ? "rccl" : "copies", niters, nnz_true, (long long)m.ref_numRows, S0, (long long)chunks, (long long)cut, pre_s, t_compute,
+           tm.median_s, t_total, tm.step_median_s, 2.0 * nnz_true / t_total / 1e9, balg / t_total / 1e9, balg / t_compute / (8e12 * G), (long long)wrong);
+    cvr_destroy_multi(M);
 
-    // CVR_POWER=<iterations>: the iterative caller on the same handle (one GPU, square matrix): x <- A x / ||A x||
+    // CVR_POWER=<iterations>: the iterative caller (one GPU, square matrix): x <- A x / ||A x||
     const char *penv = getenv("CVR_POWER");
     if (penv && atoi(penv) > 0 && G == 1 && m.nrows == m.ncols) {
+        cvr_handle *H = nullptr;
+        opt.device = devs[0];
+        CVR_OKAY(cvr_create(&H, &view, &opt));
+        CVR_OKAY(cvr_preprocess(H, 0, nullptr));
         std::vector<double> ones((size_t)m.ncols, 1.0);
-        HIP_OK(hipMemcpy(dx[0], ones.data(), sizeof(double) * (size_t)m.ncols, hipMemcpyHostToDevice));
+        HIP_OK(hipSetDevice(devs[0]));
+        HIP_OK(hipMemcpy(cvr_x_device(H), ones.data(), sizeof(double) * (size_t)m.ncols, hipMemcpyHostToDevice));
         double lambda = 0, sec = 0;
-        CVR_OKAY(cvr_power_iteration(H[0], nullptr, nullptr, atoi(penv), dx[0], &lambda, &sec, st[0]));
+        CVR_OKAY(cvr_power_iteration(H, nullptr, nullptr, atoi(penv), cvr_x_device(H), &lambda, &sec, cvr_stream(H)));
         printf("{\"power_iterations\":%d,\"rayleigh_quotient\":%.15g,\"seconds_per_iteration\":%.6g}\n", atoi(penv), lambda, sec);
-    }
-
-    for (int g = 0; g < G; g++) {
-        (void)hipSetDevice(devs[(size_t)g]);
-        if (use_rccl) ncclCommDestroy(comm[(size_t)g]);
-        (void)hipFree(dx[(size_t)g]); (void)hipFree(dy[(size_t)g]);
-        if (dall[(size_t)g]) (void)hipFree(dall[(size_t)g]);
-        cvr_destroy(H[(size_t)g]);
+        cvr_destroy(H);
     }
     cvr_mm_free(&m);
     return 0;

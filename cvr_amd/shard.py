@@ -7,13 +7,8 @@ import numpy as np
 def row_partition(row_ptr, nparts):
     """bounds[nparts+1]: part p owns rows bounds[p] .. bounds[p+1]-1; nnz per part as equal as row
     boundaries allow"""
-    rp = np.asarray(row_ptr, dtype=np.int64)
-    nrows = len(rp) - 1
-    nnz = int(rp[-1] - rp[0])
-    targets = rp[0] + (np.arange(1, nparts, dtype=np.int64) * nnz) // nparts
-    cuts = np.searchsorted(rp, targets, side="left")
-    bounds = np.concatenate([[0], np.clip(cuts, 0, nrows), [nrows]]).astype(np.int64)
-    return np.maximum.accumulate(bounds)
+    from . import capi
+    return capi.row_partition(row_ptr, nparts)      # the library's one partition rule (cvr_row_partition, cvr_multi.hip)
 
 
 def local_csr(row_ptr, col_idx, vals, bounds, p):

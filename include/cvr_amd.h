@@ -116,9 +116,14 @@ typedef struct {
 
 typedef struct {
     int32_t iters;
-    double  mean_s, min_s, max_s;   /* per-SpMV seconds over `iters` timed launches (HIP events)     */
+    double  mean_s, min_s, max_s;   /* per-SpMV seconds over `iters` timed launches (HIP events): the SpMV alone (compute only)  */
     double  total_s;                /* events around the whole back-to-back loop                      */
     double  h2d_s, d2h_s;           /* host<->device copies of x and y (outside mean_s)               */
+    double  median_s;               /* median of the per-SpMV times                                   */
+    /* rows sharded over several GPUs (cvr_spmv_multi): one step = every shard's SpMV + the all-gather of y; the slowest device
+     * counts.  On one GPU there is no exchange: step_* repeat the compute figures and gather_mean_s is 0. */
+    double  step_mean_s, step_min_s, step_median_s, step_max_s;
+    double  gather_mean_s;          /* step_mean_s - mean_s: what the exchange adds                   */
 } cvr_timing;
 
 typedef struct {
@@ -200,6 +205,30 @@ int cvr_tune_steps(const cvr_csr_view *csr, const cvr_options *opt, int32_t *bes
  * the resident layout (8 or 4 chunks per workgroup, every workgroup on its own CU at once) with and without a 64-KiB LDS
  * window of x and with and without column phases, and returns the fastest set of options in *best (pass it to cvr_create). */
 int cvr_tune(const cvr_csr_view *csr, const cvr_options *opt, cvr_options *best, double *best_spmv_s, double *tuning_s);
+
+/* ---- one call = all GPUs of the process ------------------------------------------------------------------
+ * In the reference ONE call drives all threads (pre_processing spmv.cpp:1857 -> omp parallel num_threads at :577;
+ * spmv_compute_kernel :1882 -> :1034).  The multi-device handle is that for GPUs: it cuts the rows into one contiguous block
+ * per device with balanced non-zeros (cvr_row_partition: binary search on row_ptr, the reference's per-thread trick of
+ * spmv.cpp:631-667, but at row boundaries, so no row spans devices and nothing is reduced across them), builds one shard
+ * handle per device (x replicated), owns the device vectors, the communicators (ncclCommInitAll) and the all-gather of y.
+ * A device may be listed several times (CVR_DEVICES=0,0,0 on a one-GPU box): sharding, handles and gather layout stay,
+ * device-to-device copies stand in for RCCL, which needs distinct devices. */
+typedef struct cvr_multi cvr_multi;
+/* bounds[nparts + 1]: rows [bounds[p], bounds[p+1]) go to part p; returns the largest part's row count (>= 0) or < 0 on error.
+ * Host only, no device needed.  The one partition rule of this library (the host program, bench.py and cvr_amd/shard.py use it). */
+int64_t cvr_row_partition(int64_t nrows, const int64_t *row_ptr, int32_t nparts, int64_t *bounds);
+/* csr: host arrays of the whole matrix; opt: as for cvr_create (opt->device is ignored); devices[ndevices]: HIP ordinals */
+int cvr_create_multi(cvr_multi **out, const cvr_csr_view *csr, const cvr_options *opt, const int32_t *devices, int32_t ndevices);
+int cvr_preprocess_multi(cvr_multi *m, int keep_csr, double *seconds);      /* seconds: the slowest shard's conversion + planning */
+/* y = A x through host buffers: x is replicated to every device, every shard computes its rows, the y slices are all-gathered
+ * (every device ends up with the whole y), y comes back from the first device's gathered copy.  `iters` timed steps
+ * compute-only, then `iters` with the gather (timing->mean_s ... and timing->step_*). */
+int cvr_spmv_multi(cvr_multi *m, const void *x_host, void *y_host, int iters, cvr_timing *timing);
+int cvr_multi_shards(const cvr_multi *m);                                    /* number of shards (= ndevices) */
+int cvr_multi_info(const cvr_multi *m, int32_t shard, cvr_info *info, int64_t *row_begin, int64_t *row_end, int32_t *device);
+int cvr_multi_uses_rccl(const cvr_multi *m);                                 /* 1: ncclAllGather; 0: device-to-device copies (or one shard) */
+int cvr_destroy_multi(cvr_multi *m);
 
 /* ---- rows sharded over GPUs, one process per GPU: the exchange step ------------------------------------
  * The reference's threads share one y in host memory (spmv.cpp:1280-1282, 1640-1649); with one row shard per GPU

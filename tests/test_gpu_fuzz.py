@@ -68,7 +68,9 @@ def test_fuzz_parity(ncases=None, seed=None):
         ph = int(rng.choice([1, 1, 2, 5])) if P == 1 and ncols >= 320 else 1
         hub = int(rng.choice([0, 0, 7, 300])) if ph == 1 else 0
         reo = int(rng.integers(0, 2)) if hub else 0
-        ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32, wpb=wpb, phases=ph, sorted=srt, hub=hub)
+        tags = int(rng.choice([-1, 0, 1])) if ph > 1 else -1        # wide row tags, bounded pieces (column phases only)
+        pmax = int(rng.choice([-1, 0, 3, 8])) if ph > 1 else -1
+        ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32, wpb=wpb, phases=ph, sorted=srt, hub=hub, tags=tags, pmax=pmax)
         from_dev = torch is not None and len(ci) > 0 and rng.integers(0, 4) == 0     # CSR arrays already on the device
         if from_dev:
             keep = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp.astype(np.int64), ci.astype(np.int32), va)]
@@ -85,11 +87,12 @@ def test_fuzz_parity(ncases=None, seed=None):
             if ph > 1:
                 hub = 0
             A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, col_panels=P, x_window=win,
-                                  waves_per_block=wpb, col_phases=ph, hub_table=hub, hub_reorder=reo if P == 1 else 0)
+                                  waves_per_block=wpb, col_phases=ph, hub_table=hub, hub_reorder=reo if P == 1 else 0, row_tags16=tags, piece_max=pmax)
             ph = A.info.col_phases
         ctx["from_dev"] = bool(from_dev)
         if P == 1:
-            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0, phases=ph, max_rows=A.info.chunk_row_cap, hub_max=A.info.hub_entries, narrow=A.info.narrow_cols, reorder=A.info.hub_reorder)
+            mir = O.Cvr64(nrows, ncols, rp, ci, va, S, thr, use_dict=A.info.value_dict > 0, phases=ph, max_rows=A.info.chunk_row_cap, hub_max=A.info.hub_entries, narrow=A.info.narrow_cols, reorder=A.info.hub_reorder,
+                          tag16=A.info.row_tags16, piece_max=A.info.piece_max)
             img = A.export_image()
             assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc), ctx
             assert np.array_equal(img["target"], mir.target) and np.array_equal(img["shared"], mir.shared), ctx

@@ -323,6 +323,39 @@ def test_cli_prints_the_reference_lines():
     assert r.returncode == 1                                   # loader errors exit 1 as the reference (spmv.cpp:325)
 
 
+def test_multi_device_handle_one_call_all_gpus():
+    """cvr_create_multi / cvr_spmv_multi: the library owns the row partition, the shard handles, the replicated x and the gather of y
+    (the reference's one call drives all its threads, spmv.cpp:1857, 1882).  On a one-GPU box the device is listed three times:
+    same sharding and gather layout, device-to-device copies in place of RCCL."""
+    nrows, ncols, rp, ci, va = synth.web_google_like(scale=0.05)
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    for devices in ([0], [0, 0, 0]):
+        M = cvr_amd.MultiMatrix(nrows, ncols, rp, ci, va, devices)
+        assert M.shards == len(devices) and not M.uses_rccl
+        b = cvr_amd.row_partition(rp, len(devices))
+        seen = 0
+        for p in range(M.shards):
+            info, r0, r1, dev = M.shard_info(p)
+            assert (r0, r1, dev) == (b[p], b[p + 1], devices[p]) and info.nrows == r1 - r0 and info.nnz == rp[r1] - rp[r0]
+            seen += info.nnz
+        assert seen == len(ci)
+        y, t = M.spmv(x, iters=5)
+        _assert_close(y, yref, absy, TOL64, ("multi", devices))
+        assert t.iters == 5 and 0 < t.min_s <= t.median_s <= t.max_s and t.step_mean_s >= 0.5 * t.mean_s
+        assert (t.gather_mean_s == 0) == (len(devices) == 1)
+        y2, _ = M.spmv(x)
+        assert np.array_equal(y.view(np.uint64), y2.view(np.uint64))
+        M.close()
+    with pytest.raises(cvr_amd.CvrError):
+        cvr_amd.MultiMatrix(nrows, ncols, rp, ci, va, [0, 99])
+    # single-device timing carries the same fields
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    _, t = A.spmv(x, iters=7)
+    assert t.min_s <= t.median_s <= t.max_s and t.step_median_s == t.median_s and t.gather_mean_s == 0
+    A.close()
+
+
 def test_banded_and_rmat_shapes():
     """the other BASELINE.json shapes at reduced size: banded symmetric (nlpkkt240's shape) fp64, R-MAT fp32"""
     nrows, ncols, rp, ci, va = synth.banded_sym(300_000)

@@ -29,6 +29,17 @@ def test_row_partition_properties():
                 assert lrp[0] == 0 and len(lrp) == n + 1 and len(lci) == lrp[-1]
                 tot += len(lci)
             assert tot == len(ci)
+    # the library's routine (cvr_row_partition: the one rule behind cvr_create_multi, spmv.cvr, bench.py) against its definition:
+    # the first row whose start reaches p / nparts of the non-zeros
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        n = int(rng.integers(1, 400))
+        rp = np.concatenate([[int(rng.integers(0, 5))], np.cumsum(rng.integers(0, 9, size=n))]).astype(np.int64)
+        rp[1:] += rp[0]
+        for nparts in (1, 2, 5, 8, 13):
+            nnz = int(rp[-1] - rp[0])
+            want = np.concatenate([[0], np.clip(np.searchsorted(rp, rp[0] + (np.arange(1, nparts) * nnz) // nparts, side="left"), 0, n), [n]])
+            assert np.array_equal(shard.row_partition(rp, nparts), np.maximum.accumulate(want)), (trial, nparts)
     # balance on a matrix with many rows: within one max row of the ideal
     nrows, ncols, rp, ci, va = K.cases()["uniform_2000"]
     b = shard.row_partition(rp, 8)
