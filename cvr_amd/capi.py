@@ -59,7 +59,8 @@ SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_c
            "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_plan_selfcheck", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
            "cvr_tune_steps", "cvr_tune", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat",
-           "cvr_row_partition", "cvr_create_multi", "cvr_preprocess_multi", "cvr_spmv_multi", "cvr_multi_shards", "cvr_multi_info", "cvr_multi_uses_rccl", "cvr_destroy_multi"]
+           "cvr_source_key_of", "cvr_mm_write_bin_keyed", "cvr_mm_read_bin_keyed", "cvr_mm_read_cached", "cvr_save_image", "cvr_load_image",
+           "cvr_row_partition", "cvr_create_multi", "cvr_preprocess_multi", "cvr_spmv_multi", "cvr_multi_shards", "cvr_multi_info", "cvr_multi_uses_rccl", "cvr_destroy_multi", "cvr_multi_from_handles", "cvr_multi_handle"]
 
 
 def lib_path():
@@ -124,6 +125,12 @@ def lib():
         L.cvr_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.cvr_spmv_gather_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                              C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.cvr_source_key_of.argtypes = [C.c_char_p, C.c_int, C.POINTER(SourceKey)]
+        L.cvr_mm_write_bin_keyed.argtypes = [C.c_char_p, C.POINTER(MmMatrix), C.POINTER(SourceKey)]
+        L.cvr_mm_read_bin_keyed.argtypes = [C.c_char_p, C.POINTER(SourceKey), C.POINTER(MmMatrix)]
+        L.cvr_mm_read_cached.argtypes = [C.c_char_p, C.c_int, C.POINTER(MmMatrix), C.POINTER(C.c_int)]
+        L.cvr_save_image.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(SourceKey)]
+        L.cvr_load_image.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.POINTER(SourceKey), C.POINTER(Options), C.POINTER(C.c_double)]
         L.cvr_row_partition.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
         L.cvr_row_partition.restype = C.c_int64
         L.cvr_create_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CsrView), C.POINTER(Options), C.c_void_p, C.c_int32]
@@ -168,11 +175,33 @@ def device_copy_gbs(device=0, nbytes=1 << 30, iters=20):
     return g.value
 
 
+class SourceKey(C.Structure):
+    _fields_ = [("size", C.c_int64), ("mtime_ns", C.c_int64), ("hash", C.c_uint64), ("mode", C.c_int32), ("reserved", C.c_int32)]
+
+
+def source_key(path, mode=MM_REFCOMPAT):
+    k = SourceKey()
+    rc = lib().cvr_source_key_of(os.fsencode(path), mode, C.byref(k))
+    if rc:
+        raise CvrError(rc, f"cvr_source_key_of({path})")
+    return k
+
+
 def load_mm(path, mode=MM_REFCOMPAT, cache=None):
     """cvr_mm_read -> dict(nrows, ncols, nnz, ref_*, row_ptr int64, col_idx int32, vals float64) (numpy copies).
-    cache: path of a binary image; read when it exists, written after a text parse otherwise."""
+    cache=True: through the keyed cache beside the file (cvr_mm_read_cached: <path>.ref.csrbin / .strict.csrbin, read only while
+    its key -- size, mtime, hash of the first and last MiB -- is the file's); out["cache_hit"] says which.
+    cache=<path>: an UNKEYED binary image; read when it exists, written after a text parse otherwise (the caller answers for
+    its freshness)."""
     m = MmMatrix()
-    if cache and os.path.exists(cache):
+    hit = None
+    if cache is True:
+        h = C.c_int()
+        rc = lib().cvr_mm_read_cached(os.fsencode(path), mode, C.byref(m), C.byref(h))
+        if rc:
+            raise CvrError(rc, f"cvr_mm_read_cached({path})")
+        hit = bool(h.value)
+    elif cache and os.path.exists(cache):
         rc = lib().cvr_mm_read_bin(os.fsencode(cache), C.byref(m))
         if rc:
             raise CvrError(rc, f"cvr_mm_read_bin({cache})")
@@ -189,6 +218,8 @@ def load_mm(path, mode=MM_REFCOMPAT, cache=None):
                col_idx=np.ctypeslib.as_array(m.col_idx, shape=(max(n, 1),))[:n].copy(),
                vals=np.ctypeslib.as_array(m.vals, shape=(max(n, 1),))[:n].copy())
     lib().cvr_mm_free(C.byref(m))
+    if hit is not None:
+        out["cache_hit"] = hit
     return out
 
 
@@ -318,6 +349,38 @@ class CvrMatrix:
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
                     debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block, col_phases, hub_table, narrow_cols, hub_reorder,
                     row_tags16, row_bands, piece_max)
+
+    def save_image(self, path, key=None):
+        """cvr_save_image: the converted image on disk, keyed by `key` (capi.source_key of the .mtx file; None = no source key),
+        the options and the device geometry"""
+        rc = lib().cvr_save_image(self._h, os.fsencode(path), C.byref(key) if key is not None else None)
+        if rc:
+            raise CvrError(rc, "cvr_save_image")
+
+    @classmethod
+    def from_image(cls, path, key=None, device=0, **options):
+        """cvr_load_image: a handle from a saved image (CvrError with code ERR_STATE when the file was written for another source,
+        other options, another device geometry or library version)"""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.tuning_s = 0.0
+        opt = Options()
+        lib().cvr_default_options(C.byref(opt))
+        opt.device = device
+        for k, v in options.items():
+            setattr(opt, k, v)
+        sec = C.c_double()
+        rc = lib().cvr_load_image(C.byref(self._h), os.fsencode(path), C.byref(key) if key is not None else None, C.byref(opt), C.byref(sec))
+        if rc:
+            self._h = C.c_void_p()
+            raise CvrError(rc, "cvr_load_image")
+        self.load_s = self.preprocess_s = sec.value
+        self.info = Info()
+        lib().cvr_get_info(self._h, C.byref(self.info))
+        self.nrows, self.ncols = self.info.nrows, self.info.ncols
+        self.f32 = bool(self.info.is_f32)
+        self.dtype = np.float32 if self.f32 else np.float64
+        return self
 
     @classmethod
     def from_device(cls, nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, is_f32=False, device=0, steps_per_chunk=0,

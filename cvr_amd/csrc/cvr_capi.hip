@@ -324,6 +324,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     if (!h) return fail(CVR_ERR_NOMEM, "out of host memory");
     h->device = opt.device;
     h->vsz = vsz;
+    h->opt_used = make_iopt(opt_in);
+    h->opt_used.cus = opt.cus; h->opt_used.xcds = opt.xcds;
     cvr_info &in = h->info;
     in.nrows = nrows; in.ncols = ncols; in.nnz = nrows ? csr->row_ptr[nrows] - csr->row_ptr[0] : 0; in.is_f32 = f32 ? 1 : 0;
     in.x_elems = ncols + 1;

@@ -160,6 +160,8 @@ struct cvr_handle {
     std::vector<unsigned long long> dict_tab;
     uint32_t                        dict_flags[2] = {0, 0};
 
+    IOpt opt_used;                       // the options the handle was created with (the image cache keys on them: cvr_image_io.hip)
+
     bool paneled() const { return parts.size() > 1; }
 };
 

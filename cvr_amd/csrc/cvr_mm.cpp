@@ -17,6 +17,7 @@
 // row -- the order libc's (merge-sort) qsort produces: entries with equal coordinates stay in file order.
 // A binary image of the parsed CSR (cvr_mm_write_bin / cvr_mm_read_bin) skips the text altogether.
 #include <omp.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -306,6 +307,13 @@ int read_strict(const char *p, const char *end, cvr_mm_matrix *out)
 }
 
 constexpr uint64_t kBinMagic = 0x3152534352564331ull;   // "1CVRCSR1"
+constexpr uint64_t kBinMagicKeyed = 0x3252534352564332ull;   // "2CVRCSR2": the same image behind the key of its source file
+
+uint64_t fnv1a(const unsigned char *p, size_t n, uint64_t h)
+{
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
 
 }  // namespace
 
@@ -328,29 +336,102 @@ extern "C" void cvr_mm_free(cvr_mm_matrix *m)
     memset(m, 0, sizeof(*m));
 }
 
-// Binary image of a parsed matrix: header {magic, 7 x int64}, then row_ptr, col_idx, vals.
-extern "C" int cvr_mm_write_bin(const char *path, const cvr_mm_matrix *m)
+// The identity of a source file, cheap to take: size, modification time, and a 64-bit FNV-1a hash over the first and the last MiB
+// (a matrix edited in the middle without changing size or mtime escapes it; size and mtime catch what editors and downloads do).
+extern "C" int cvr_source_key_of(const char *path, int mode, cvr_source_key *key)
+{
+    if (!path || !key) return CVR_ERR_INVALID;
+    memset(key, 0, sizeof(*key));
+    struct stat st;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return CVR_ERR_IO;
+    FILE *f = fopen(path, "rb");
+    if (!f) return CVR_ERR_IO;
+    const size_t               kMiB = (size_t)1 << 20;
+    std::vector<unsigned char> buf(kMiB);
+    uint64_t                   h = 0xcbf29ce484222325ull;
+    size_t                     n = fread(buf.data(), 1, kMiB, f);
+    h = fnv1a(buf.data(), n, h);
+    if ((int64_t)st.st_size > (int64_t)kMiB) {
+        const int64_t off = std::max<int64_t>((int64_t)kMiB, (int64_t)st.st_size - (int64_t)kMiB);
+        if (fseeko(f, (off_t)off, SEEK_SET) == 0) { n = fread(buf.data(), 1, kMiB, f); h = fnv1a(buf.data(), n, h); }
+    }
+    fclose(f);
+    key->size = (int64_t)st.st_size;
+    key->mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+    key->hash = h;
+    key->mode = mode;
+    return CVR_OK;
+}
+
+static int write_bin_impl(const char *path, const cvr_mm_matrix *m, const cvr_source_key *key);
+static int read_bin_impl(const char *path, const cvr_source_key *expect, cvr_mm_matrix *out);
+
+extern "C" int cvr_mm_write_bin_keyed(const char *path, const cvr_mm_matrix *m, const cvr_source_key *key)
+{
+    if (!key) return CVR_ERR_INVALID;
+    return write_bin_impl(path, m, key);
+}
+
+extern "C" int cvr_mm_read_bin_keyed(const char *path, const cvr_source_key *expect, cvr_mm_matrix *out)
+{
+    if (!expect) return CVR_ERR_INVALID;
+    return read_bin_impl(path, expect, out);
+}
+
+// readMatrix through the cache next to the file: <mtx>.ref.csrbin / <mtx>.strict.csrbin is read when its key is the file's, else
+// the text is parsed and the cache rewritten (a cache that cannot be written is not an error)
+extern "C" int cvr_mm_read_cached(const char *mtx_path, int mode, cvr_mm_matrix *out, int *cache_hit)
+{
+    if (cache_hit) *cache_hit = 0;
+    if (!mtx_path || !out) return CVR_ERR_INVALID;
+    cvr_source_key key;
+    int            rc = cvr_source_key_of(mtx_path, mode, &key);
+    if (rc) { memset(out, 0, sizeof(*out)); return rc; }
+    const std::string bin = std::string(mtx_path) + (mode == CVR_MM_STRICT ? ".strict.csrbin" : ".ref.csrbin");
+    if (read_bin_impl(bin.c_str(), &key, out) == CVR_OK) { if (cache_hit) *cache_hit = 1; return CVR_OK; }
+    rc = cvr_mm_read(mtx_path, mode, out);
+    if (rc == CVR_OK) (void)write_bin_impl(bin.c_str(), out, &key);
+    return rc;
+}
+
+// Binary image of a parsed matrix: header {magic, 7 x int64}[, the source key], then row_ptr, col_idx, vals.
+extern "C" int cvr_mm_write_bin(const char *path, const cvr_mm_matrix *m) { return write_bin_impl(path, m, nullptr); }
+
+static int write_bin_impl(const char *path, const cvr_mm_matrix *m, const cvr_source_key *key)
 {
     if (!path || !m || !m->row_ptr) return CVR_ERR_INVALID;
-    FILE *f = fopen(path, "wb");
+    const std::string tmp = std::string(path) + ".tmp";        // (written beside and renamed: a reader never sees half a file)
+    FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return CVR_ERR_IO;
     const int64_t n = m->ref_nItems > m->nnz ? m->ref_nItems : m->nnz;   // refcompat keeps the excluded last element (Q9)
-    const int64_t hdr[8] = {(int64_t)kBinMagic, m->nrows, m->ncols, m->nnz, m->ref_numRows, m->ref_numCols, m->ref_nItems, m->ref_nItemsRaw};
+    const int64_t hdr[8] = {(int64_t)(key ? kBinMagicKeyed : kBinMagic), m->nrows, m->ncols, m->nnz, m->ref_numRows, m->ref_numCols, m->ref_nItems, m->ref_nItemsRaw};
     bool ok = fwrite(hdr, sizeof(hdr), 1, f) == 1;
+    if (key) ok = ok && fwrite(key, sizeof(*key), 1, f) == 1;
     ok = ok && fwrite(m->row_ptr, sizeof(int64_t), (size_t)m->nrows + 1, f) == (size_t)m->nrows + 1;
     ok = ok && (n == 0 || fwrite(m->col_idx, sizeof(int32_t), (size_t)n, f) == (size_t)n);
     ok = ok && (n == 0 || fwrite(m->vals, sizeof(double), (size_t)n, f) == (size_t)n);
-    return (fclose(f) == 0 && ok) ? CVR_OK : CVR_ERR_IO;
+    ok = fclose(f) == 0 && ok;
+    if (ok) ok = rename(tmp.c_str(), path) == 0;
+    if (!ok) (void)remove(tmp.c_str());
+    return ok ? CVR_OK : CVR_ERR_IO;
 }
 
-extern "C" int cvr_mm_read_bin(const char *path, cvr_mm_matrix *out)
+extern "C" int cvr_mm_read_bin(const char *path, cvr_mm_matrix *out) { return read_bin_impl(path, nullptr, out); }
+
+// expect != null: only an image written with that very key is accepted (CVR_ERR_STATE for any other: stale or unkeyed)
+static int read_bin_impl(const char *path, const cvr_source_key *expect, cvr_mm_matrix *out)
 {
     if (!path || !out) return CVR_ERR_INVALID;
     memset(out, 0, sizeof(*out));
     FILE *f = fopen(path, "rb");
     if (!f) return CVR_ERR_IO;
     int64_t hdr[8];
-    if (fread(hdr, sizeof(hdr), 1, f) != 1 || (uint64_t)hdr[0] != kBinMagic || hdr[1] < 0 || hdr[3] < 0 || hdr[6] < 0) { fclose(f); return CVR_ERR_IO; }
+    if (fread(hdr, sizeof(hdr), 1, f) != 1 || ((uint64_t)hdr[0] != kBinMagic && (uint64_t)hdr[0] != kBinMagicKeyed) || hdr[1] < 0 || hdr[3] < 0 || hdr[6] < 0) { fclose(f); return CVR_ERR_IO; }
+    if ((uint64_t)hdr[0] == kBinMagicKeyed) {
+        cvr_source_key have;
+        if (fread(&have, sizeof(have), 1, f) != 1) { fclose(f); return CVR_ERR_IO; }
+        if (expect && memcmp(&have, expect, sizeof(have)) != 0) { fclose(f); return CVR_ERR_STATE; }      // the source has changed since
+    } else if (expect) { fclose(f); return CVR_ERR_STATE; }
     out->nrows = hdr[1]; out->ncols = hdr[2]; out->nnz = hdr[3];
     out->ref_numRows = hdr[4]; out->ref_numCols = hdr[5]; out->ref_nItems = hdr[6]; out->ref_nItemsRaw = hdr[7];
     const int64_t n = out->ref_nItems > out->nnz ? out->ref_nItems : out->nnz;

@@ -97,6 +97,37 @@ int multi_timed(cvr_multi *m, bool gather, int iters, double *mean, double *mn, 
     return CVR_OK;
 }
 
+// device vectors, streams and communicators of a multi handle whose shards exist (m->H, m->dev, m->max_rows are set)
+int multi_device_side(cvr_multi *m)
+{
+    const int G = m->G;
+#define MD_TRY(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
+    // RCCL needs distinct devices; entries naming the same device are served by copies
+    bool distinct = true;
+    for (int a = 0; a < G; a++) for (int b = a + 1; b < G; b++) if (m->dev[(size_t)a] == m->dev[(size_t)b]) distinct = false;
+    m->use_rccl = G > 1 && distinct;
+    for (int g = 0; g < G; g++) {
+        cvr_info info;
+        MD_TRY(cvr_get_info(m->H[(size_t)g], &info));
+        HIP_TRY(hipSetDevice(m->dev[(size_t)g]));
+        const size_t ny = (size_t)std::max<int64_t>(info.yext_elems, m->max_rows), nx = (size_t)info.x_elems;
+        HIP_TRY(hipMalloc(&m->dx[(size_t)g], m->vsz * std::max<size_t>(nx, 1)));
+        HIP_TRY(hipMalloc(&m->dy[(size_t)g], m->vsz * std::max<size_t>(ny, 1)));
+        HIP_TRY(hipMemset(m->dx[(size_t)g], 0, m->vsz * std::max<size_t>(nx, 1)));
+        HIP_TRY(hipMemset(m->dy[(size_t)g], 0, m->vsz * std::max<size_t>(ny, 1)));
+        if (G > 1) HIP_TRY(hipMalloc(&m->dall[(size_t)g], m->vsz * std::max<size_t>((size_t)G * (size_t)m->max_rows, 1)));
+        HIP_TRY(hipStreamCreateWithFlags(&m->st[(size_t)g], hipStreamNonBlocking));
+    }
+    if (m->use_rccl) {
+        const RcclApi *api = rccl_api();
+        if (!api) { return fail(CVR_ERR_NO_DEVICE, "RCCL not found (librccl.so; set CVR_RCCL_LIB): %s", dlerror()); }
+        const ncclResult_t r = api->comm_init_all(m->comm.data(), G, m->dev.data());
+        if (r != ncclSuccess) { for (auto &c : m->comm) c = nullptr; return fail(CVR_ERR_HIP, "ncclCommInitAll: %s", api->error_string(r)); }
+    }
+#undef MD_TRY
+    return CVR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -174,33 +205,43 @@ int cvr_create_multi(cvr_multi **out, const cvr_csr_view *csr, const cvr_options
         o.device = m->dev[(size_t)g];
         MULTI_TRY(cvr_create(&m->H[(size_t)g], &v, &o));
     }
-    // RCCL needs distinct devices; entries naming the same device are served by copies
-    bool distinct = true;
-    for (int a = 0; a < G; a++) for (int b = a + 1; b < G; b++) if (m->dev[(size_t)a] == m->dev[(size_t)b]) distinct = false;
-    m->use_rccl = G > 1 && distinct;
-    for (int g = 0; g < G; g++) {
-        cvr_info info;
-        MULTI_TRY(cvr_get_info(m->H[(size_t)g], &info));
-        MULTI_HIP(hipSetDevice(m->dev[(size_t)g]));
-        const size_t ny = (size_t)std::max<int64_t>(info.yext_elems, m->max_rows), nx = (size_t)info.x_elems;
-        MULTI_HIP(hipMalloc(&m->dx[(size_t)g], m->vsz * std::max<size_t>(nx, 1)));
-        MULTI_HIP(hipMalloc(&m->dy[(size_t)g], m->vsz * std::max<size_t>(ny, 1)));
-        MULTI_HIP(hipMemset(m->dx[(size_t)g], 0, m->vsz * std::max<size_t>(nx, 1)));
-        MULTI_HIP(hipMemset(m->dy[(size_t)g], 0, m->vsz * std::max<size_t>(ny, 1)));
-        if (G > 1) MULTI_HIP(hipMalloc(&m->dall[(size_t)g], m->vsz * std::max<size_t>((size_t)G * (size_t)m->max_rows, 1)));
-        MULTI_HIP(hipStreamCreateWithFlags(&m->st[(size_t)g], hipStreamNonBlocking));
-    }
-    if (m->use_rccl) {
-        const RcclApi *api = rccl_api();
-        if (!api) { cvr_destroy_multi(m); return fail(CVR_ERR_NO_DEVICE, "RCCL not found (librccl.so; set CVR_RCCL_LIB): %s", dlerror()); }
-        const ncclResult_t r = api->comm_init_all(m->comm.data(), G, m->dev.data());
-        if (r != ncclSuccess) { for (auto &c : m->comm) c = nullptr; fail(CVR_ERR_HIP, "ncclCommInitAll: %s", api->error_string(r)); cvr_destroy_multi(m); return CVR_ERR_HIP; }
-    }
+    MULTI_TRY(multi_device_side(m));
 #undef MULTI_TRY
 #undef MULTI_HIP
     *out = m;
     return CVR_OK;
 }
+
+// shard handles that exist already (loaded from their image caches, or built by the caller): adopted, with everything else of
+// cvr_create_multi.  bounds[n + 1], devices[n]; handle g must hold rows [bounds[g], bounds[g+1]) and be preprocessed.
+int cvr_multi_from_handles(cvr_multi **out, cvr_handle **shards, const int64_t *bounds, const int32_t *devices, int32_t n)
+{
+    if (!out) return fail(CVR_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!shards || !bounds || !devices || n < 1 || n > 64) return fail(CVR_ERR_INVALID, "bad multi-device arguments");
+    for (int g = 0; g < n; g++) {
+        if (!shards[g] || !shards[g]->converted) return fail(CVR_ERR_STATE, "shard %d is missing or not preprocessed", g);
+        if (shards[g]->info.nrows != bounds[g + 1] - bounds[g] || shards[g]->device != devices[g] || shards[g]->vsz != shards[0]->vsz || shards[g]->info.ncols != shards[0]->info.ncols)
+            return fail(CVR_ERR_INVALID, "shard %d does not match its bounds / device / type", g);
+    }
+    cvr_multi *m = new (std::nothrow) cvr_multi;
+    if (!m) return fail(CVR_ERR_NOMEM, "out of host memory");
+    const int G = n;
+    m->G = G; m->vsz = shards[0]->vsz; m->f32 = m->vsz == 4; m->nrows = bounds[n]; m->ncols = shards[0]->info.ncols;
+    m->dev.assign(devices, devices + G);
+    m->bounds.assign(bounds, bounds + G + 1);
+    for (int g = 0; g < G; g++) m->max_rows = std::max(m->max_rows, bounds[g + 1] - bounds[g]);
+    m->H.assign(shards, shards + G);
+    m->dx.assign((size_t)G, nullptr); m->dy.assign((size_t)G, nullptr); m->dall.assign((size_t)G, nullptr);
+    m->st.assign((size_t)G, nullptr); m->comm.assign((size_t)G, nullptr); m->ev.resize((size_t)G);
+    const int rc = multi_device_side(m);
+    if (rc) { for (auto &h : m->H) h = nullptr; cvr_destroy_multi(m); return rc; }      // (the caller keeps its handles on failure)
+    m->converted = true;
+    *out = m;
+    return CVR_OK;
+}
+
+cvr_handle *cvr_multi_handle(cvr_multi *m, int32_t shard) { return m && shard >= 0 && shard < m->G ? m->H[(size_t)shard] : nullptr; }
 
 int cvr_preprocess_multi(cvr_multi *m, int keep_csr, double *seconds)
 {

@@ -11,7 +11,7 @@
 //     CVR_X=ones|rand     x = 1.0 as the reference (spmv.cpp:556-563) or the seeded non-constant x
 //     CVR_MM=refcompat|strict   loader mode (default refcompat = the reference loader's arrays)
 //     CVR_S=<steps>       lane-stream length per chunk (default: chosen from the matrix size)
-//     CVR_CACHE=1         keep / reuse a binary image of the parsed matrix (<mtx>.ref.cvrbin / .strict.cvrbin)
+//     CVR_CACHE=1         caches keyed to the .mtx file beside it: the parsed CSR (.csrbin) and, on one GPU, the converted image (.cvrimg)
 // Exit code 0 as the reference (spmv.cpp:1947), 1 on loader errors (spmv.cpp:325-355), 2 on usage / device errors.
 #include <hip/hip_runtime_api.h>
 
@@ -59,16 +59,13 @@ int main(int argc, char **argv)
     std::vector<int>  devs = parse_devices(getenv("CVR_DEVICES"));
     const int         G = (int)devs.size();
 
-    // CVR_CACHE=1: keep / reuse a binary image of the parsed matrix next to the .mtx file
+    // CVR_CACHE=1: caches beside the .mtx file, both keyed to it (size, mtime, hash of the first and last MiB: a changed file is
+    // parsed and converted again): the parsed CSR (<mtx>.ref.csrbin / .strict.csrbin) and, on one GPU, the converted CVR64 image
+    // (<mtx>.ref.cvrimg / .strict.cvrimg, keyed by the options and the device geometry as well)
     cvr_mm_matrix     m;
-    const std::string bin = std::string(fn) + (mmmode == CVR_MM_STRICT ? ".strict.cvrbin" : ".ref.cvrbin");
-    int               rc = CVR_ERR_IO;
     const bool        use_cache = getenv("CVR_CACHE") && atoi(getenv("CVR_CACHE"));
-    if (use_cache) rc = cvr_mm_read_bin(bin.c_str(), &m);
-    if (rc) {
-        rc = cvr_mm_read(fn, mmmode, &m);   // spmv.cpp:1771
-        if (!rc && use_cache) (void)cvr_mm_write_bin(bin.c_str(), &m);
-    }
+    int               csr_hit = 0;
+    int               rc = use_cache ? cvr_mm_read_cached(fn, mmmode, &m, &csr_hit) : cvr_mm_read(fn, mmmode, &m);   // spmv.cpp:1771
     if (rc) { fprintf(stderr, "Error: unable to read matrix file %s (%d)\n", fn, rc); return 1; }
     printf("Matrix %s: %lld rows, %lld columns, %lld stored entries (%s loader)\n", fn, (long long)m.ref_numRows,
            (long long)m.ref_numCols, (long long)m.ref_nItems, mmmode == CVR_MM_STRICT ? "strict" : "reference-compatible");
@@ -87,9 +84,27 @@ int main(int argc, char **argv)
     if (senv) opt.steps_per_chunk = atoi(senv);
     std::vector<int32_t> dev32(devs.begin(), devs.end());
     cvr_multi *M = nullptr;
-    CVR_OKAY(cvr_create_multi(&M, &view, &opt, dev32.data(), G));
-    double pre_s = 0;
-    CVR_OKAY(cvr_preprocess_multi(M, 0, &pre_s));   // spmv.cpp:1857
+    double     pre_s = 0;
+    const char *image_cache = "off";
+    cvr_source_key key;
+    const std::string img = std::string(fn) + (mmmode == CVR_MM_STRICT ? ".strict.cvrimg" : ".ref.cvrimg");
+    const bool        try_image = use_cache && G == 1 && cvr_source_key_of(fn, mmmode, &key) == CVR_OK;
+    if (try_image) {      // the converted image from an earlier run: no analysis, no planner, no converter
+        cvr_handle *H = nullptr;
+        opt.device = devs[0];
+        double load_s = 0;
+        if (cvr_load_image(&H, img.c_str(), &key, &opt, &load_s) == CVR_OK) {
+            const int64_t b2[2] = {0, m.nrows};
+            CVR_OKAY(cvr_multi_from_handles(&M, &H, b2, dev32.data(), 1));
+            pre_s = load_s;
+            image_cache = "hit";
+        } else image_cache = "miss";
+    }
+    if (!M) {
+        CVR_OKAY(cvr_create_multi(&M, &view, &opt, dev32.data(), G));
+        CVR_OKAY(cvr_preprocess_multi(M, 0, &pre_s));   // spmv.cpp:1857
+        if (try_image && cvr_save_image(cvr_multi_handle(M, 0), img.c_str(), &key) != CVR_OK) fprintf(stderr, "note: image cache not written: %s\n", cvr_last_error());
+    }
     printf("The Pre-processing(CSR->CVR)   Time of CVR   is %g seconds.   [file: %s] [threads: %d]\n", pre_s, fn, nthreads);   // spmv.cpp:1009
 
     cvr_timing tm;
@@ -115,10 +130,10 @@ int main(int argc, char **argv)
         chunks += info.nchunks; cut += info.nshared;
         if (g == 0) S0 = info.steps_per_chunk;
     }
-    printf("{\"backend\":\"hip-gfx950\",\"gpus\":%d,\"exchange\":\"%s\",\"iters\":%d,\"nnz\":%.0f,\"rows\":%lld,\"steps_per_chunk\":%d,\"chunks\":%lld,\"rows_cut\":%lld,"
+    printf("{\"backend\":\"hip-gfx950\",\"gpus\":%d,\"csr_cache\":\"%s\",\"image_cache\":\"%s\",\"exchange\":\"%s\",\"iters\":%d,\"nnz\":%.0f,\"rows\":%lld,\"steps_per_chunk\":%d,\"chunks\":%lld,\"rows_cut\":%lld,"
            "\"preprocess_s\":%.6g,\"spmv_compute_s\":%.6g,\"spmv_compute_median_s\":%.6g,\"spmv_with_gather_s\":%.6g,\"spmv_with_gather_median_s\":%.6g,\"gflops_2nnz\":%.6g,\"gbs_alg\":%.6g,"
            "\"frac_of_8TBs_per_gpu\":%.4f,\"wrong\":%lld}\n",
-           G, G == 1 ? "none" : cvr_multi_uses_rccl(M) ? "rccl" : "copies", niters, nnz_true, (long long)m.ref_numRows, S0, (long long)chunks, (long long)cut, pre_s, t_compute,
+           G, !use_cache ? "off" : csr_hit ? "hit" : "miss", image_cache, G == 1 ? "none" : cvr_multi_uses_rccl(M) ? "rccl" : "copies", niters, nnz_true, (long long)m.ref_numRows, S0, (long long)chunks, (long long)cut, pre_s, t_compute,
            tm.median_s, t_total, tm.step_median_s, 2.0 * nnz_true / t_total / 1e9, balg / t_total / 1e9, balg / t_compute / (8e12 * G), (long long)wrong);
     cvr_destroy_multi(M);
 

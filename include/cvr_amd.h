@@ -228,6 +228,10 @@ int cvr_spmv_multi(cvr_multi *m, const void *x_host, void *y_host, int iters, cv
 int cvr_multi_shards(const cvr_multi *m);                                    /* number of shards (= ndevices) */
 int cvr_multi_info(const cvr_multi *m, int32_t shard, cvr_info *info, int64_t *row_begin, int64_t *row_end, int32_t *device);
 int cvr_multi_uses_rccl(const cvr_multi *m);                                 /* 1: ncclAllGather; 0: device-to-device copies (or one shard) */
+/* shard handles that exist already (loaded from image caches, or built by the caller): adopted by a multi handle, which then owns
+ * them; bounds[n + 1], devices[n]; handle g holds rows [bounds[g], bounds[g+1]) and is preprocessed */
+int cvr_multi_from_handles(cvr_multi **out, cvr_handle **shards, const int64_t *bounds, const int32_t *devices, int32_t n);
+cvr_handle *cvr_multi_handle(cvr_multi *m, int32_t shard);                   /* shard's handle (owned by m), e.g. for cvr_save_image */
 int cvr_destroy_multi(cvr_multi *m);
 
 /* ---- rows sharded over GPUs, one process per GPU: the exchange step ------------------------------------
@@ -314,6 +318,24 @@ void cvr_mm_free(cvr_mm_matrix *m);
 /* binary image of a parsed matrix (all fields of cvr_mm_matrix): skips the text parse on the next run */
 int  cvr_mm_write_bin(const char *path, const cvr_mm_matrix *m);
 int  cvr_mm_read_bin(const char *path, cvr_mm_matrix *out);
+/* The same, keyed to the source: the identity of a file is its size, its modification time (ns) and a 64-bit FNV-1a hash of its
+ * first and last MiB, together with the loader mode.  A keyed image is only read back under the key it was written with:
+ * CVR_ERR_STATE says the source has changed since (or the image carries no key) and the caller parses the text again. */
+typedef struct { int64_t size, mtime_ns; uint64_t hash; int32_t mode, reserved; } cvr_source_key;
+int  cvr_source_key_of(const char *path, int mode, cvr_source_key *key);
+int  cvr_mm_write_bin_keyed(const char *path, const cvr_mm_matrix *m, const cvr_source_key *key);
+int  cvr_mm_read_bin_keyed(const char *path, const cvr_source_key *expect, cvr_mm_matrix *out);
+/* readMatrix through the cache beside the file (<mtx>.ref.csrbin / <mtx>.strict.csrbin): the cache when its key is the file's,
+ * else the text, after which the cache is rewritten; *cache_hit (may be NULL) says which */
+int  cvr_mm_read_cached(const char *mtx_path, int mode, cvr_mm_matrix *out, int *cache_hit);
+/* The converted CVR64 image of a handle on disk (after cvr_preprocess; single images, column panels, hub tables alike): a second run
+ * on the same matrix loads it straight into device memory and skips analysis, planner and converter (the reference repeats its
+ * pre_processing on every run, spmv.cpp:1857).  The file is keyed by the source file's identity (`key`; NULL = none), the options,
+ * the device's CU / XCD counts, the format and library version; cvr_load_image returns CVR_ERR_STATE when any of them differs
+ * (the caller then runs cvr_create + cvr_preprocess and saves again).  The loaded handle computes the same y, bit for bit.
+ * opt: the options the image must have been built with (NULL = defaults; opt->device = where to load it).  *seconds: load time. */
+int  cvr_save_image(cvr_handle *h, const char *path, const cvr_source_key *key);
+int  cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *expect, const cvr_options *opt, double *seconds);
 /* x[j] = 1.0 (mode 0; fill, spmv.cpp:556-563) or splitmix64(0xC0FFEE, j) -> [-1,1) (mode 1) */
 void cvr_fill_x(double *x, int64_t n, int mode);
 /* the reference's self-check loop, OpenMP over rows, j ascending (spmv.cpp:1843-1850) */

@@ -356,6 +356,75 @@ def test_multi_device_handle_one_call_all_gpus():
     A.close()
 
 
+@pytest.mark.parametrize("kind", ["resident_phases", "plain", "panels", "hub"])
+def test_image_cache_roundtrip_and_staleness(tmp_path, kind):
+    """cvr_save_image / cvr_load_image: the converted image from disk gives the same y bit for bit without analysis, planner or
+    converter; a file written for another source file, other options or a damaged file is refused with a code"""
+    if kind == "hub":
+        nrows, ncols, rp, ci, va = synth.rmat(16, dtype=np.float32)
+        opts = dict(hub_table=300, steps_per_chunk=16)
+    else:
+        nrows, ncols, rp, ci, va = synth.web_google_like(scale=0.05)
+        opts = dict(resident_phases=dict(steps_per_chunk=12, waves_per_block=8, x_window=2048, col_phases=6), plain=dict(steps_per_chunk=16),
+                    panels=dict(col_panels=3, steps_per_chunk=16))[kind]
+    x = O.x_vec_fast(ncols, "rand").astype(va.dtype)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, **opts)
+    y, _ = A.spmv(x)
+    path = str(tmp_path / "m.cvrimg")
+    key = capi.SourceKey(size=123, mtime_ns=456, hash=789, mode=0)
+    A.save_image(path, key)
+    B = cvr_amd.CvrMatrix.from_image(path, key, **opts)
+    assert (B.info.nchunks, B.info.nshared, B.info.col_panels, B.info.col_phases, B.info.value_dict, B.info.hub_entries) == \
+           (A.info.nchunks, A.info.nshared, A.info.col_panels, A.info.col_phases, A.info.value_dict, A.info.hub_entries)
+    assert B.info.plan_s == 0 and B.info.convert_s == 0
+    y2, _ = B.spmv(x)
+    assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))
+    if kind in ("resident_phases", "plain"):
+        ia, ib = A.export_image(), B.export_image()
+        for k in ("image", "desc", "target", "shared"):
+            assert np.array_equal(ia[k], ib[k]), k
+    B.close()
+    A.close()
+    other = capi.SourceKey(size=123, mtime_ns=457, hash=789, mode=0)              # the source file has changed
+    with pytest.raises(cvr_amd.CvrError) as e:
+        cvr_amd.CvrMatrix.from_image(path, other, **opts)
+    assert e.value.code == capi.ERR_STATE
+    with pytest.raises(cvr_amd.CvrError) as e:                                    # other options
+        cvr_amd.CvrMatrix.from_image(path, key, **dict(opts, split_threshold=7))
+    assert e.value.code == capi.ERR_STATE
+    with open(path, "r+b") as f:                                                  # a truncated file
+        f.truncate(os.path.getsize(path) - 100)
+    with pytest.raises(cvr_amd.CvrError) as e:
+        cvr_amd.CvrMatrix.from_image(path, key, **opts)
+    assert e.value.code == capi.ERR_IO
+
+
+def test_cli_caches_keyed_to_the_file(tmp_path):
+    """CVR_CACHE=1: second run of spmv.cvr on the same file takes the parsed CSR and the converted image from the caches beside
+    it (no text parse, no conversion); once the file changes both are refused and rebuilt"""
+    import json
+    import shutil
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "spmv.cvr")
+    mtx = str(tmp_path / "m.mtx")
+    shutil.copy(os.path.join(GOLD, "mtx", "pl2000_pattern.mtx"), mtx)
+
+    def run():
+        r = subprocess.run([exe, mtx, "2", "5"], capture_output=True, text=True, timeout=120, env=dict(os.environ, CVR_CACHE="1", CVR_X="rand"))
+        assert r.returncode == 0 and "Very Good! Your result is correct" in r.stdout, r.stdout + r.stderr
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"backend"')][0])
+    a, b = run(), run()
+    assert (a["csr_cache"], a["image_cache"]) == ("miss", "miss") and (b["csr_cache"], b["image_cache"]) == ("hit", "hit")
+    assert b["wrong"] == 0 and b["chunks"] == a["chunks"]
+    time.sleep(0.01)
+    shutil.copy(os.path.join(GOLD, "mtx", "skew12.mtx"), mtx)                 # another matrix under the same name
+    c = run()
+    assert (c["csr_cache"], c["image_cache"]) == ("miss", "miss") and c["rows"] != a["rows"] and c["wrong"] == 0
+    assert run()["image_cache"] == "hit"
+
+
 def test_banded_and_rmat_shapes():
     """the other BASELINE.json shapes at reduced size: banded symmetric (nlpkkt240's shape) fp64, R-MAT fp32"""
     nrows, ncols, rp, ci, va = synth.banded_sym(300_000)

@@ -138,6 +138,43 @@ def test_binary_cache_roundtrip(tmp_path, mode):
         cvr_amd.load_mm(src, mode, cache=cache)
 
 
+def test_keyed_cache_refuses_a_stale_image(tmp_path):
+    """the cache beside a .mtx file is keyed to it (size, mtime, hash of the first and last MiB, loader mode): it is read while the
+    file is what it was, and the text is parsed again -- and the cache rewritten -- once the file has changed (the reference
+    parses on every run, spmv.cpp:411-451; an unkeyed cache silently returned the old arrays)"""
+    import shutil
+    import time
+    src = str(tmp_path / "m.mtx")
+    shutil.copy(os.path.join(GOLD, "mtx", "pl2000_pattern.mtx"), src)
+    a = cvr_amd.load_mm(src, capi.MM_REFCOMPAT, cache=True)
+    assert a["cache_hit"] is False and os.path.exists(src + ".ref.csrbin")
+    b = cvr_amd.load_mm(src, capi.MM_REFCOMPAT, cache=True)
+    assert b["cache_hit"] is True
+    for k in ("row_ptr", "col_idx", "vals"):
+        assert np.array_equal(a[k], b[k]), k
+    assert cvr_amd.load_mm(src, capi.MM_STRICT, cache=True)["cache_hit"] is False      # the other mode has a cache of its own
+    # the file changes (another matrix under the same name): the key no longer matches
+    time.sleep(0.01)
+    shutil.copy(os.path.join(GOLD, "mtx", "sym250_real.mtx"), src)
+    c = cvr_amd.load_mm(src, capi.MM_REFCOMPAT, cache=True)
+    fresh = cvr_amd.load_mm(src, capi.MM_REFCOMPAT)
+    assert c["cache_hit"] is False and c["ref_numRows"] == fresh["ref_numRows"] != a["ref_numRows"]
+    assert np.array_equal(c["vals"], fresh["vals"])
+    assert cvr_amd.load_mm(src, capi.MM_REFCOMPAT, cache=True)["cache_hit"] is True      # rewritten under the new key
+    # same size, same bytes, touched: mtime is part of the key
+    os.utime(src, ns=(1, 1))
+    assert cvr_amd.load_mm(src, capi.MM_REFCOMPAT, cache=True)["cache_hit"] is False
+    # the keyed reader itself: a key that is not the image's is CVR_ERR_STATE, an unkeyed image too
+    k = capi.source_key(src, capi.MM_REFCOMPAT)
+    m = capi.MmMatrix()
+    assert capi.lib().cvr_mm_read_bin_keyed(os.fsencode(src + ".ref.csrbin"), C.byref(k), C.byref(m)) == 0
+    capi.lib().cvr_mm_free(C.byref(m))
+    k.hash ^= 1
+    assert capi.lib().cvr_mm_read_bin_keyed(os.fsencode(src + ".ref.csrbin"), C.byref(k), C.byref(m)) == capi.ERR_STATE
+    with pytest.raises(cvr_amd.CvrError):
+        capi.source_key(str(tmp_path / "missing.mtx"))
+
+
 def test_parallel_parse_matches_on_a_large_file(tmp_path):
     """a file large enough to be cut into one text segment per thread: both loader modes against numpy"""
     from cvr_amd import synth
@@ -226,14 +263,21 @@ def test_size_limits_are_rejected_with_a_message():
 
 
 def test_auto_panel_rule_on_the_host():
-    """cvr_auto_panels: x small -> 1; x large and banded (lines re-used) -> 1; x large and scattered -> one panel per
-    1.8 MB of missing x; comm / tuning entry points fail with codes (no device here)"""
+    """cvr_auto_panels: x small -> 1; x large and banded (lines re-used) -> 1; x large and scattered -> panels: in rounds of
+    eight with ~2.6 MB of x each (one panel per XCD at a time), or, with CVR_XCD_PANELS=0 (every panel over the whole chip), one
+    per 1.8 MB of missing x; comm / tuning entry points fail with codes (no device here)"""
     rng = np.random.default_rng(5)
     n = 4_000_000                                                          # x = 32 MB of fp64
     rp = np.arange(n + 1, dtype=np.int64) * 2
     scattered = rng.integers(0, n, 2 * n).astype(np.int32)
     P, miss = capi.auto_panels(n, n, rp, scattered)
-    assert miss > 0.6 and P == int(n * 8 * miss / 1.8e6 + 0.5)
+    assert miss > 0.6 and P == 8 * int(np.ceil(n * 8 / (8 * 2.6e6)))
+    os.environ["CVR_XCD_PANELS"] = "0"
+    try:
+        P0, miss0 = capi.auto_panels(n, n, rp, scattered)
+    finally:
+        del os.environ["CVR_XCD_PANELS"]
+    assert miss0 == miss and P0 == int(n * 8 * miss / 1.8e6 + 0.5)
     band = (np.repeat(np.arange(n, dtype=np.int64), 2) + np.tile([0, 3], n)).clip(0, n - 1).astype(np.int32)
     P, miss = capi.auto_panels(n, n, rp, band)
     assert P == 1 and miss < 0.2                                           # first touches only: 2 of 32 gathers per line
