@@ -265,6 +265,8 @@ def main():
     ap.add_argument("--two-streams", action="store_true", help="also report the throughput of independent SpMVs alternating on two streams "
                     "(off by default: concurrent kernels would distort a rocprofv3 kernel-time summary of this command)")
     ap.add_argument("--workload", default="webgoogle", help="webgoogle (the headline, default) | livejournal | banded[<rows>] | rmat[<scale>] (fp32)")
+    ap.add_argument("--emulate-rank", default="", help="r/N with --gpus 1 and a device-built workload (rmat<scale>, banded<rows>): build and time ONLY rank r's "
+                    "row shard of an N-way partition (x replicated, as on N GPUs); no exchange.  The per-rank regime of the 8-GPU configurations on one GPU")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -304,31 +306,38 @@ def main():
     device_built = args.workload.startswith("rmat") or args.workload.startswith("banded")
     tune = world > 1 and args.steps_per_chunk == 0 and not os.environ.get("CVR_BENCH_NO_TUNE")
     rp = ci = va = None
+    pworld, prank = world, rank           # the partition the shard belongs to (--emulate-rank: one rank of N on this one GPU)
+    if args.emulate_rank:
+        if world != 1 or not device_built:
+            sys.exit("--emulate-rank needs --gpus 1 and a device-built workload (rmat<scale> / banded<rows>)")
+        prank, pworld = (int(v) for v in args.emulate_rank.split("/"))
+        if not 0 <= prank < pworld:
+            sys.exit("--emulate-rank r/N: 0 <= r < N")
     if device_built:
         from cvr_amd import synth_dev as D
         if args.workload.startswith("rmat"):
             scale = int(args.workload[4:] or 22)
             nrows = ncols = 1 << scale
             deg = D.rmat_row_degrees(scale, device=dev)
-            bounds, grp = D.partition_from_degrees(deg, world)
+            bounds, grp = D.partition_from_degrees(deg, pworld)
             nnz = int(grp[-1])
-            nnz_per = [int(grp[bounds[p + 1]] - grp[bounds[p]]) for p in range(world)]
+            nnz_per = [int(grp[bounds[p + 1]] - grp[bounds[p]]) for p in range(pworld)]
             del deg, grp
-            lrp_t, lci_t, lva_t = D.rmat_rows(scale, int(bounds[rank]), int(bounds[rank + 1]), device=dev)
+            lrp_t, lci_t, lva_t = D.rmat_rows(scale, int(bounds[prank]), int(bounds[prank + 1]), device=dev)
             source = f"synthetic R-MAT scale {scale}, edge factor 16, fp32, built shard by shard on the GPU (torch generator streams: cvr_amd/synth_dev.py)"
             f32 = True
         else:
             nrows = ncols = int(float(args.workload[6:] or 3.5e6))
-            bounds, nnz = D.banded_partition(nrows, 13, world)
-            lrp_t, lci_t, lva_t = D.banded_rows(nrows, int(bounds[rank]), int(bounds[rank + 1]), device=dev)
+            bounds, nnz = D.banded_partition(nrows, 13, pworld)
+            lrp_t, lci_t, lva_t = D.banded_rows(nrows, int(bounds[prank]), int(bounds[prank + 1]), device=dev)
             r = np.arange(nrows, dtype=np.int64)
             pre = np.concatenate([[0], np.cumsum(np.minimum(r, 13) + 1 + np.minimum(nrows - 1 - r, 13))])
-            nnz_per = [int(pre[bounds[p + 1]] - pre[bounds[p]]) for p in range(world)]
+            nnz_per = [int(pre[bounds[p + 1]] - pre[bounds[p]]) for p in range(pworld)]
             del r, pre
             source = "synthetic banded symmetric (27 nnz/row, nlpkkt240's shape), built shard by shard on the GPU (cvr_amd/synth_dev.py)"
             f32 = False
         torch.cuda.synchronize()
-        lrows, lnnz = int(bounds[rank + 1] - bounds[rank]), int(lrp_t[-1])
+        lrows, lnnz = int(bounds[prank + 1] - bounds[prank]), int(lrp_t[-1])
         build_s = time.perf_counter() - t_build0
         A = cvr_amd.CvrMatrix.from_device(lrows, ncols, lrp_t.data_ptr(), lci_t.data_ptr(), lva_t.data_ptr(), is_f32=f32, device=local_rank,
                                           steps_per_chunk=args.steps_per_chunk, tune_steps=False, col_panels=args.col_panels)      # (device-built large workloads keep the library's rules: hub tables, panels; tuning is for shards of the small headline matrix)
@@ -561,11 +570,14 @@ def main():
             copy_gbs = None
     if rank == 0:
         per = wall / args.steps
+        emu = bool(args.emulate_rank)
+        job_nnz = lnnz if emu else nnz            # (an emulated rank: the flops of its shard)
         kname = "cvr::spmv_kernel<float>" if f32 else "cvr::spmv_kernel<double>"
         workload_text = f"{source}: {nrows}x{ncols}, nnz {nnz}, {'fp32' if f32 else 'fp64'}, y = A x with A (CVR64 image), x, y resident in HBM"
         out = {
-            "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64" if args.workload == "webgoogle" else f"SpMV GFLOP/s (2*nnz/t), {args.workload} {'fp32' if f32 else 'fp64'}",
-            "value": 2.0 * nnz / per / 1e9,
+            "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64" if args.workload == "webgoogle" else f"SpMV GFLOP/s (2*nnz/t), {args.workload} {'fp32' if f32 else 'fp64'}"
+                      + (f", rank {prank} of {pworld} alone on one GPU (its row shard, x replicated, no exchange)" if emu else ""),
+            "value": 2.0 * job_nnz / per / 1e9,
             "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per * 1e3,
@@ -577,7 +589,8 @@ def main():
             "config": {"workload": workload_text,
                        "rows_per_gpu": [int(v) for v in np.diff(bounds)],
                        "nnz_per_gpu": nnz_per,
-                       "nnz_imbalance_max_over_mean": float(max(nnz_per) * world / max(nnz, 1)),
+                       "nnz_imbalance_max_over_mean": float(max(nnz_per) * pworld / max(nnz, 1)),
+                       "emulated_rank": [prank, pworld] if emu else None, "rank_rows": lrows, "rank_nnz": lnnz,
                        "steps_per_chunk": int(info.steps_per_chunk), "chunks_rank0": int(info.nchunks),
                        "rows_cut_rank0": int(info.nshared), "col_panels": int(info.col_panels),
                        "waves_per_workgroup": int(info.waves_per_block), "x_window_values": int(info.x_window), "col_phases": int(info.col_phases),
@@ -595,9 +608,9 @@ def main():
                          "kernel_us_value_dict_off": None if kern_nodict_s is None else kern_nodict_s * 1e6,
                          "frac_value_dict_off": None if kern_nodict_s is None else balg_local / kern_nodict_s / 1e9 / HBM_PEAK_GBS},
             "image_bytes": int(info.image_bytes),
-            "gbs_alg_whole_job": synth.b_alg(nrows, ncols, nnz, vbytes) / per / 1e9,
+            "gbs_alg_whole_job": synth.b_alg(lrows if emu else nrows, ncols, job_nnz, vbytes) / per / 1e9,
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
-            "spmv_only_ms_max_over_ranks": kern_max_s * 1e3, "gflops_spmv_only_no_exchange": 2.0 * nnz / kern_max_s / 1e9,
+            "spmv_only_ms_max_over_ranks": kern_max_s * 1e3, "gflops_spmv_only_no_exchange": 2.0 * job_nnz / kern_max_s / 1e9,
             "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
             "preprocess": {"plan_s": info.plan_s, "probe_s": info.probe_s, "upload_s": info.upload_s, "convert_s": info.convert_s,
                            "preprocess_wall_s": info.preprocess_wall_s, "tune_s": A.tuning_s,

@@ -12,10 +12,18 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_IO, ERR_NOMEM, ERR_STATE, ERR_INTER
 MM_REFCOMPAT, MM_STRICT = 0, 1
 
 
+_torch_first = None      # was torch already imported when libcvr_amd.so was loaded?
+
+
 class CvrError(RuntimeError):
     def __init__(self, code, where):
+        import sys as _sys
         self.code = code
-        super().__init__(f"{where}: error {code}: {last_error()}")
+        hint = ""
+        if code == ERR_NO_DEVICE and _torch_first is False and "torch" in _sys.modules:
+            hint = (" -- PyTorch was imported AFTER libcvr_amd.so: two copies of the HIP runtime share the process and the second one"
+                    " finds no GPU; import torch first (or set CVR_TORCH_PRELOAD=1)")
+        super().__init__(f"{where}: error {code}: {last_error()}{hint}")
 
 
 class CsrView(C.Structure):
@@ -75,16 +83,17 @@ def lib():
         if not os.path.exists(p):
             raise ImportError(f"{p} is missing: build it with `make -C cvr_amd/csrc` (or __graft_entry__.build())")
         # A process that also uses PyTorch must load torch FIRST: its wheel carries its own copy of the HIP runtime, and whichever
-        # copy is loaded second finds no GPU.  If torch is importable but not yet imported, import it here; if
-        # that is not wanted (CVR_NO_TORCH_PRELOAD=1) the library's own runtime is used and a later `import torch` sees no device.
+        # copy is loaded second finds no GPU.  The order is the caller's (importing torch here would put a second
+        # runtime into processes that never wanted one: the CSR comparators and rocprofv3 crash on that); what this module does is
+        # say so when it sees the wrong order behind a "no device" error (CvrError), and CVR_TORCH_PRELOAD=1 imports torch here.
         import sys as _sys
-        if "torch" not in _sys.modules and not os.environ.get("CVR_NO_TORCH_PRELOAD"):
-            import importlib.util as _ilu
-            if _ilu.find_spec("torch") is not None:
-                try:
-                    import torch  # noqa: F401
-                except Exception:  # noqa: BLE001
-                    pass
+        global _torch_first
+        if "torch" not in _sys.modules and os.environ.get("CVR_TORCH_PRELOAD"):      # opt-in: a caller that will import torch later
+            try:
+                import torch  # noqa: F401
+            except Exception:  # noqa: BLE001
+                pass
+        _torch_first = "torch" in _sys.modules
         L = C.CDLL(p)
         L.cvr_last_error.restype = C.c_char_p
         L.cvr_version.restype = C.c_char_p

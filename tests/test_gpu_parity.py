@@ -425,6 +425,23 @@ def test_cli_caches_keyed_to_the_file(tmp_path):
     assert run()["image_cache"] == "hit"
 
 
+@pytest.mark.parametrize("workload,rank", [("rmat26", "3/8"), ("banded28e6", "0/8")])
+def test_one_rank_of_the_eight_gpu_configurations(workload, rank):
+    """BASELINE.json configs[3] / [4] (nlpkkt240's shape and R-MAT scale 26 over 8 GPUs) cannot run here (one GPU per box): one
+    rank's row shard of each, built on the device with the full replicated x (268 MB / 224 MB), timed and checked row by row
+    against a torch fp64 segment sum inside bench.py (--emulate-rank; the eight per-rank times: profiles/r03_rank_emulation_*.json)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--emulate-rank", rank, "--steps", "20", "--warmup", "3", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["verdict_wrong_rows"] == 0 and d["config"]["emulated_rank"] == [int(v) for v in rank.split("/")]
+    assert d["config"]["rank_nnz"] > 9e7 and d["roofline"]["kernel_us"] > 0
+
+
 def test_banded_and_rmat_shapes():
     """the other BASELINE.json shapes at reduced size: banded symmetric (nlpkkt240's shape) fp64, R-MAT fp32"""
     nrows, ncols, rp, ci, va = synth.banded_sym(300_000)
