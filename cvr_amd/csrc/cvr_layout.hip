@@ -223,7 +223,10 @@ int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f3
         if (wgs > best_fill) { best_fill = wgs; best_w = w; best_S = S; }
     }
     if (!best_w) return CVR_OK;
-    const int64_t win = (64 * 1024) / vs;                       // 64 KiB of x per workgroup
+    // 96 KiB of x per workgroup: the gathers that stay outside the window are what loads the L2s (one request per gather, an XCD's
+    // L2 takes ~16 per clock: profiles/r03_gather_rate_ubench.log), so the window takes what the row accumulators leave
+    // (64 -> 96 KiB: 21.4 -> 20.9 us on the web-Google shape, profiles/r03_window_sizes.log)
+    const int64_t win = (96 * 1024) / vs;
     static_assert(sizeof(unsigned long long) * 2 * cvr::kProbeBlocks <= kSmallDictTab, "probe output fits its part of the small scratch");
     unsigned long long *d_out = reinterpret_cast<unsigned long long *>(h->d_small + kSmallProbe);
     std::vector<unsigned long long> pageable;
@@ -261,7 +264,7 @@ int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f3
     opt.waves_per_block = best_w;
     opt.steps_per_chunk = best_S;
     opt.x_window = want_win ? (int32_t)win : 0;
-    opt.col_phases = want_phases ? (int32_t)std::min(32.0, std::max(2.0, std::floor(xbytes / 600e3 + 0.5))) : 1;
+    opt.col_phases = want_phases ? (int32_t)std::min(32.0, std::max(2.0, std::floor(xbytes / 450e3 + 0.5))) : 1;
     return CVR_OK;
 }
 

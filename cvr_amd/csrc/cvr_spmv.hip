@@ -169,7 +169,13 @@ __device__ __forceinline__ uint32_t remap_block(uint32_t b, uint32_t nblocks_per
     // XCD one contiguous range of chunks so that neighbouring rows' x lines meet in one L2.  Speed only.
     if (swz == 0) return b;
     const uint32_t xcd = b & 7u, j = b >> 3;
-    if (swz == 1) return xcd * nblocks_per_xcd + j;
+    if (swz == 1) {
+        // (here the argument is the TOTAL number of blocks n = 8 q + r: the first r XCDs take q + 1 consecutive blocks, the others q,
+        // so that no XCD's L2 serves more workgroups than another's by more than one -- the resident layout is bound by the L2s)
+        const uint32_t n = nblocks_per_xcd, q = n >> 3, r = n & 7u;
+        const uint32_t cnt = q + (xcd < r ? 1u : 0u), base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+        return j < cnt ? base + j : 0x00ffffffu;
+    }
     // swz = 2 (experiment): within the XCD, blocks j, j+32, j+64, .. (one CU under round-robin placement) take
     // consecutive chunks, so that the waves resident on a CU work on neighbouring rows and share x lines in its L1
     const uint32_t per_cu = (nblocks_per_xcd + 31) / 32;
@@ -828,7 +834,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     // template parameters: <value type, stream run-ahead beyond the gather, gather cache policy, gather run-ahead, LDS window, dictionary, multi-wave, column phases>
 #define CVR_LAUNCH(T, SP, D, W, DI, MW, SG)                                                                       \
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, SG, false>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
-                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
+                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
                        multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
                        static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(img.hub_x), img.hub_n, kstride, img.cbase, img.pad_col, multi)
 #define CVR_PICK_SG(T, SP, D, W, DI, MW) CVR_LAUNCH(T, SP, D, W, DI, MW, false)
@@ -839,12 +845,12 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_PICK_SP(T)           do { if (img.stream_ahead >= 2) CVR_PICK_D(T, 3); else CVR_PICK_D(T, 1); } while (0)
 #define CVR_LAUNCH_C16(T, SP, D)                                                                                  \
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, 0, false, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
-                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd,       \
+                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, 0u,          \
                        static_cast<const T *>(nullptr), 0u, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col, (const PanelArgs *)nullptr)
 #define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
                              else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
-#define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
+#define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
                         img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi
 #define CVR_SEG(T, SP, D, W, DI, LD)                                                                               \
     do {                                                                                                           \

@@ -62,12 +62,12 @@ static int tune_impl(const cvr_csr_view *csr, const cvr_options *opt_in, bool fu
         const int64_t vs = csr->is_f32 ? 4 : 8;
         const double  slots = ((double)(csr->row_ptr[csr->nrows] - csr->row_ptr[0]) + (double)csr->nrows / 4) * 1.006;
         const double  xbytes = (double)csr->ncols * vs;
-        const int     P = (int)std::min(32.0, std::max(2.0, std::floor(xbytes / 600e3 + 0.5)));
+        const int     P = (int)std::min(32.0, std::max(2.0, std::floor(xbytes / 450e3 + 0.5)));
         for (int w : {8, 7, 4}) {
             int S = (int)std::ceil(slots / (64.0 * w * (double)(chip_of(opt.device).cus - 4)) / 4.0) * 4;
             if (S < 8) S = 8;
             if (S > 128) continue;
-            for (int win : {(int)(65536 / vs), 0})
+            for (int win : {(int)(98304 / vs), 0})
                 for (int ph : {P, 1}) {
                     if (xbytes <= 2.5e6 && ph > 1) continue;
                     cvr_options o = opt;

@@ -189,7 +189,7 @@ def test_full_size_web_google_parity(web_google):
 
 # The layout cvr_create's automatic rule gives the full-size web-Google shape on an MI355X: what bench.py times (its JSON line
 # repeats these numbers under config).  Change it together with the rule (cvr_layout.hip, choose_layout).
-TIMED_LAYOUT = dict(steps_per_chunk=48, waves_per_block=7, x_window=8192, col_phases=12, value_dict=13)
+TIMED_LAYOUT = dict(steps_per_chunk=48, waves_per_block=7, x_window=12288, col_phases=16, value_dict=13)
 
 
 @pytest.mark.parametrize("value_dict", [-1, 0])
