@@ -641,6 +641,16 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         in.nchunks += p.nchunks; in.nshared += p.nshared; in.nslots += p.nchunks * 64 * p.img.S;
         in.image_bytes += (int64_t)(p.stream_bytes + (size_t)p.nchunks * (16 + 64) + (size_t)p.nshared * 24);
     }
+    {   // room for the conversion-time segment table of images with column phases (cvr_preprocess takes it over and releases it)
+        size_t n1 = 0, nch = 0;
+        for (const Part &p : h->parts)
+            if (p.img.phases > 1 && p.nchunks > 0) { n1 = std::max(n1, (size_t)p.nchunks * (size_t)cvr::kLanes * (size_t)p.img.S); nch = std::max(nch, (size_t)p.nchunks); }
+        if (n1 > 0 && n1 < ((size_t)1 << 32)) {
+            auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t bytes = up(sizeof(int64_t) * n1) + up(sizeof(uint32_t) * n1) + up(sizeof(uint16_t) * n1) + up(sizeof(uint32_t) * (nch + 1)) + 256;
+            if (hipMalloc(&h->seg_arena, bytes) == hipSuccess) h->seg_arena_bytes = bytes; else { (void)hipGetLastError(); h->seg_arena = nullptr; }
+        }
+    }
     CREATE_TRY(hipMalloc(&h->d_err, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&h->d_x, vsz * (size_t)in.x_elems));
     CREATE_TRY(hipMalloc(&h->d_y, vsz * (size_t)in.yext_elems));
@@ -692,7 +702,8 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
         auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t o_begin = 0, o_len = o_begin + up(sizeof(int64_t) * n1), o_row = o_len + up(sizeof(uint32_t) * n1), o_cnt = o_row + up(sizeof(uint16_t) * n1),
                      o_flags = o_cnt + up(sizeof(uint32_t) * (seg_chunks + 1));
-        HIP_TRY(hipMalloc(&sg.arena, o_flags + 256));
+        if (h->seg_arena && h->seg_arena_bytes >= o_flags + 256) { sg.arena = h->seg_arena; h->seg_arena = nullptr; h->seg_arena_bytes = 0; }      // (cvr_create made room)
+        else HIP_TRY(hipMalloc(&sg.arena, o_flags + 256));
         uint8_t *a = static_cast<uint8_t *>(sg.arena);
         t.begin = reinterpret_cast<int64_t *>(a + o_begin); t.len = reinterpret_cast<uint32_t *>(a + o_len); t.row = reinterpret_cast<uint16_t *>(a + o_row);
         t.cnt = reinterpret_cast<uint32_t *>(a + o_cnt); t.flags = reinterpret_cast<uint32_t *>(a + o_flags);
@@ -754,6 +765,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Part &p : h->parts) p.release_all();
     cvr::free_plan_scratch(h->plan_ws);
+    if (h->seg_arena) (void)hipFree(h->seg_arena);
     if (h->d_small) (void)hipFree(h->d_small);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->z_free) (void)hipEventDestroy(h->z_free);

@@ -325,6 +325,16 @@ __device__ __forceinline__ SegStage seg_stage(uint8_t *smem, const int64_t *rp, 
     return st;
 }
 
+// col / pw without the integer division (a dozen instructions per element of a kernel that is all such small steps): the float
+// quotient, corrected by at most one either way (col < 2^31, pw >= 16: the float error stays below one unit of the quotient)
+__device__ __forceinline__ uint32_t phase_of(uint32_t col, uint32_t pw, float inv_pw)
+{
+    uint32_t q = (uint32_t)((float)col * inv_pw);
+    if ((uint64_t)q * pw > col) q--;
+    else if ((uint64_t)(q + 1) * pw <= col) q++;
+    return q;
+}
+
 // first position in cols[a, z) whose column is >= bound (columns ascending)
 __device__ __forceinline__ uint32_t lower_col(const int32_t *cols, uint32_t a, uint32_t z, uint64_t bound)
 {
@@ -344,12 +354,14 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
                                                           const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
                                                           uint4 *__restrict__ desc, uint2 *__restrict__ desc2, uint32_t nchunks,
                                                           uint32_t pw, uint32_t phases, uint32_t cap, uint32_t *__restrict__ cnt, int64_t *__restrict__ seg_begin,
-                                                          uint32_t *__restrict__ seg_len, uint16_t *__restrict__ seg_row, uint32_t *__restrict__ flags, uint32_t lds_cols, uint32_t pmax)
+                                                          uint32_t *__restrict__ seg_len, uint16_t *__restrict__ seg_row, uint32_t *__restrict__ flags, uint32_t lds_cols, uint32_t psh)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t pc[64], poff[64], sbad, stotal;
     const uint32_t k = blockIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     if (k >= nchunks) return;
+    const float    inv_pw = 1.0f / (float)pw;
+    const uint32_t pmask = (1u << psh) - 1u;       // pieces of at most 2^psh elements (psh = 31: whole segments; a chunk has fewer than 2^31 elements)
     const int64_t  b = nzb[k], e = nzb[k + 1];
     const uint32_t row_first = desc[k].x, nri = desc2[k].y, sbase = k * cap;
     if (threadIdx.x < 64) pc[threadIdx.x] = 0;
@@ -369,24 +381,24 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
         __syncthreads();
         for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
             const int32_t  col = st.cols[j];
-            const uint32_t ph = (uint32_t)col / pw;
+            const uint32_t ph = phase_of((uint32_t)col, pw, inv_pw);
             if (rstart[j]) { atomicAdd(&pc[ph], 1u); continue; }
             const int32_t prev_col = st.cols[j - 1];      // (j > 0 here: element 0 starts a row piece or belongs to no row of the chunk)
             if (col < prev_col) bad = 1;
-            if (ph != (uint32_t)prev_col / pw || j % pmax == 0) atomicAdd(&pc[ph], 1u);      // (pieces are cut at the multiples of pmax from the chunk's first element)
+            if (ph != phase_of((uint32_t)prev_col, pw, inv_pw) || (j & pmask) == 0) atomicAdd(&pc[ph], 1u);      // (pieces are cut at the multiples of 2^psh from the chunk's first element)
         }
     } else {
         for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
             const uint32_t a = st.pa[i], z = st.pz[i];
             if (z <= a) { atomicAdd(&pc[0], 1u); continue; }
             int32_t  prev_col = st.cols[a];
-            uint32_t prev = (uint32_t)prev_col / pw;
+            uint32_t prev = phase_of((uint32_t)prev_col, pw, inv_pw);
             atomicAdd(&pc[prev], 1u);
             for (uint32_t j = a + 1; j < z; j++) {
                 const int32_t  col = st.cols[j];
-                const uint32_t ph = (uint32_t)col / pw;
+                const uint32_t ph = phase_of((uint32_t)col, pw, inv_pw);
                 if (col < prev_col) bad = 1;
-                if (ph != prev || j % pmax == 0) atomicAdd(&pc[ph], 1u);
+                if (ph != prev || (j & pmask) == 0) atomicAdd(&pc[ph], 1u);
                 prev = ph; prev_col = col;
             }
         }
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
                 if (z <= a) { pad = p == 0; np = pad ? 1u : 0u; }
                 else {
                     lo = lower_col(st.cols, a, z, c0); hi = lower_col(st.cols, lo, z, c1);
-                    if (hi > lo) np = (hi - 1) / pmax - lo / pmax + 1;
+                    if (hi > lo) np = ((hi - 1) >> psh) - (lo >> psh) + 1;
                 }
             }
             uint32_t incl = np;                                   // inclusive scan over the wavefront
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
             if (pad) { seg_begin[idx] = -1; seg_len[idx] = 1; seg_row[idx] = (uint16_t)i; }
             else
                 for (uint32_t u = lo; u < hi;) {
-                    const uint32_t nxt = (u / pmax + 1) * pmax, v = nxt < hi ? nxt : hi;
+                    const uint32_t nxt = ((u >> psh) + 1) << psh, v = nxt < hi ? nxt : hi;
                     seg_begin[idx] = b + u; seg_len[idx] = v - u; seg_row[idx] = (uint16_t)i;
                     idx++; u = v;
                 }
@@ -707,7 +719,7 @@ hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTab
 {
     if (img.nchunks == 0) return hipSuccess;
     hipLaunchKernelGGL(seg_build_kernel, dim3(img.nchunks), dim3(kLanes * kSegWaves), seg_lds_bytes(img), s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
-                       img.desc2, img.nchunks, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, st.begin, st.len, st.row, st.flags, seg_lds_cols(img), img.piece_max ? img.piece_max : 0xffffffffu);
+                       img.desc2, img.nchunks, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, st.begin, st.len, st.row, st.flags, seg_lds_cols(img), img.piece_max ? (uint32_t)__builtin_ctz(img.piece_max) : 31u);      // (piece_max is a power of two: cvr_layout)
     hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.nchunks);
     return hipGetLastError();
 }

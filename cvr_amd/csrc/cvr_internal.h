@@ -160,6 +160,8 @@ struct cvr_handle {
     std::vector<unsigned long long> dict_tab;
     uint32_t                        dict_flags[2] = {0, 0};
 
+    void  *seg_arena = nullptr;          // column phases: the conversion-time segment table, allocated by cvr_create (with the other buffers), released by cvr_preprocess
+    size_t seg_arena_bytes = 0;
     IOpt opt_used;                       // the options the handle was created with (the image cache keys on them: cvr_image_io.hip)
 
     bool paneled() const { return parts.size() > 1; }
@@ -212,12 +214,13 @@ constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24
 constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer
 int        pick_steps(int64_t nslots_est, int64_t max_row = 0, double cus = 256.0);
 hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr = nullptr);
-hipStream_t side_stream(int device);
+hipStream_t side_stream(int device, int which = 0);      // two streams per device beside the handles' own (analysis passes side by side)
 hipError_t acquire_stream(int device, hipStream_t *out);
 void       release_stream(int device, hipStream_t s);
 hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64_t nz1, bool f32, bool first, unsigned long long *tab_host, uint32_t *flags_host, bool last,
                              hipStream_t st);
-int        auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt);
+int        auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt,
+                       const std::function<int(const IOpt &)> *meanwhile = nullptr);
 int        choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt, PartPlan &pp,
                        bool allow_reorder);
 int        build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,

@@ -138,14 +138,15 @@ hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const
 // depend on each other (layout probe | dictionary scan, conversion | window choice): each of them is too small to fill the
 // GPU and bound by latency, so side by side they take the time of one.  Created on first use (creating a stream costs
 // milliseconds), never destroyed.
-hipStream_t side_stream(int device)
+hipStream_t side_stream(int device, int which)
 {
     static std::mutex  mu;
-    static hipStream_t streams[64] = {};
-    if (device < 0 || device >= 64) return nullptr;
+    static hipStream_t streams[64][2] = {};
+    if (device < 0 || device >= 64 || which < 0 || which > 1) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); streams[device] = nullptr; }
-    return streams[device];
+    hipStream_t &st = streams[device][which];
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+    return st;
 }
 
 // The handle's own stream comes from a small per-device pool: creating a stream takes 2-3 ms and destroying one about as long,
@@ -200,7 +201,7 @@ hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64
 // diagonal, and feed their rows column phase by column phase when x is larger than what an L2 keeps beside the matrix
 // stream (profiles/r02_wg_window_sweep.log, r02_column_phases_sweep.log: 32.5 -> 23.4 us on the web-Google shape).
 // Decided from a device-side pass over the uploaded CSR (sortedness of the rows, near-diagonal share).
-int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt)
+int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt, const std::function<int(const IOpt &)> *meanwhile)
 {
     const int64_t nnz = nz1 - nz0;
     opt.layout_auto_resident = 0;
@@ -237,25 +238,40 @@ int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f3
     uint32_t           *flagv = pin ? reinterpret_cast<uint32_t *>(h->plan_ws.pinned + kPinnedDictFlags) : reinterpret_cast<uint32_t *>(pageable.data() + 2 * cvr::kProbeBlocks + 1024);
     HIP_TRY(hipStreamSynchronize(h->stream));          // the upload
     const double tp0 = now_s();
-    hipError_t e = cvr::launch_probe(part.d_rp, part.d_ci, nrows, ncols, (uint32_t)(win / 4), d_out, h->stream, h->small_clean);
-    if (e == hipSuccess) e = hipMemcpyAsync(outv, d_out, sizeof(unsigned long long) * 2 * cvr::kProbeBlocks, hipMemcpyDeviceToHost, h->stream);
-    // the dictionary scan of the values rides along: it depends on nothing decided here, and a second submission with its own
-    // synchronisation costs more than the scan
+    // The probe, the dictionary scan of the values (which depends on nothing decided here) and -- `meanwhile` -- the chunk plan of
+    // the layout the probe most often confirms run side by side: each is a handful of kernels too small to fill the GPU, and every
+    // submission with a synchronisation of its own costs more than its kernels (the upload is complete: nothing to order between
+    // the streams).  The caller keeps the speculative plan when the decision below is the layout it was made for.
+    const double xbytes = (double)ncols * vs;
+    const int32_t phases_rule = (int32_t)std::min(32.0, std::max(2.0, std::floor(xbytes / 450e3 + 0.5)));
+    hipStream_t pstream = meanwhile ? side_stream(h->device, 1) : h->stream;
+    if (!pstream) pstream = h->stream;
+    hipError_t e = cvr::launch_probe(part.d_rp, part.d_ci, nrows, ncols, (uint32_t)(win / 4), d_out, pstream, h->small_clean);
+    if (e == hipSuccess) e = hipMemcpyAsync(outv, d_out, sizeof(unsigned long long) * 2 * cvr::kProbeBlocks, hipMemcpyDeviceToHost, pstream);
     const bool with_dict = opt.value_dict != 0 && nnz > 0;
-    hipStream_t side = with_dict ? side_stream(h->device) : nullptr;       // (the upload is complete: nothing to order between the two streams)
+    hipStream_t side = with_dict ? side_stream(h->device, 0) : nullptr;
     if (!side) side = h->stream;
     if (e == hipSuccess && with_dict) e = enqueue_dict_scan(h, part.d_va, nz0, nz1, f32, true, tabv, flagv, true, side);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    double meanwhile_s = 0;
+    if (e == hipSuccess && meanwhile && pstream != h->stream && side != h->stream && xbytes > 2.5e6) {
+        IOpt spec = opt;
+        spec.layout_auto_resident = 1; spec.waves_per_block = best_w; spec.steps_per_chunk = best_S; spec.x_window = (int32_t)win; spec.col_phases = phases_rule;
+        const double tm0 = now_s();
+        const int    rcm = (*meanwhile)(spec);
+        meanwhile_s = now_s() - tm0;
+        if (rcm) { (void)hipStreamSynchronize(pstream); (void)hipStreamSynchronize(side); return rcm; }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(pstream);
+    if (e == hipSuccess && pstream != h->stream) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess && side != h->stream) e = hipStreamSynchronize(side);
     unsigned long long out[2] = {0, 0};
     for (uint32_t b = 0; b < cvr::kProbeBlocks; b++) { out[0] |= outv[2 * b]; out[1] += outv[2 * b + 1]; }
     h->small_clean = false;
     if (e == hipSuccess && with_dict) { h->dict_tab.assign(tabv, tabv + 1024); h->dict_flags[0] = flagv[0]; h->dict_flags[1] = flagv[1]; h->dict_scanned = true; }
-    h->info.probe_s = now_s() - tp0;
+    h->info.probe_s = std::max(0.0, now_s() - tp0 - meanwhile_s);      // (the speculative plan beside it is counted as planning)
     if (e != hipSuccess) return fail(CVR_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
     const bool   sorted = out[0] == 0;
     const double near = (double)out[1] / std::max<double>((double)nnz, 1.0);
-    const double xbytes = (double)ncols * vs;
     // (a matrix with nearly everything near the diagonal is a band: consecutive rows share their lines of x in L1 already)
     const bool   want_win = near >= 0.15 && near < 0.9, want_phases = sorted && xbytes > 2.5e6 && near < 0.9;
     h->info.near_diagonal_share = near;
@@ -264,7 +280,7 @@ int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f3
     opt.waves_per_block = best_w;
     opt.steps_per_chunk = best_S;
     opt.x_window = want_win ? (int32_t)win : 0;
-    opt.col_phases = want_phases ? (int32_t)std::min(32.0, std::max(2.0, std::floor(xbytes / 450e3 + 0.5))) : 1;
+    opt.col_phases = want_phases ? phases_rule : 1;
     return CVR_OK;
 }
 
@@ -325,16 +341,39 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
     PartPlan    local;
     IOpt        popt = opt;
     if (!planned) {
-        int rc = auto_layout(h, part, nrows, ncols, f32, nz0, nz1, popt);      // (waits for the upload; its own pass is timed into info.probe_s)
+        // (the planner's records come back behind the first kPinnedSmall bytes of the pinned buffer: those belong to the probe and the
+        // dictionary scan, which now run at the same time)
+        cvr::PlanScratch plan_view = h->plan_ws;
+        const bool       shifted = plan_view.pinned && plan_view.pinned_bytes > kPinnedSmall;
+        if (shifted) { plan_view.pinned += kPinnedSmall; plan_view.pinned_bytes -= kPinnedSmall; }
+        else { plan_view.pinned = nullptr; plan_view.pinned_bytes = 0; }
+        struct SyncBack { cvr::PlanScratch &view, &home; ~SyncBack() { home.dev = view.dev; home.dev_bytes = view.dev_bytes; } } sync_back{plan_view, h->plan_ws};      // (the planner may grow its device scratch; also on the error paths)
+        DevRows        here{part.d_rp, nz0, nz1, h->stream, &plan_view};
+        const bool     on_dev = rp && nrows > 0 && nrows >= device_plan_rows() && !getenv("CVR_HOST_PLAN");      // (the upload of row_ptr is in front of the planner's kernels on the stream)
+        const int64_t *prp = on_dev ? nullptr : rp;
+        const DevRows *pdr = on_dev ? &here : dr;
+        // the plan of the layout the probe is expected to confirm, made while the probe runs (device planner only: it works on the handle's stream)
+        PartPlan spec_plan;
+        IOpt     spec_opt;
+        bool     spec_done = false;
+        double   spec_s = 0;
+        const std::function<int(const IOpt &)> speculate = [&](const IOpt &so) -> int {
+            const double ts = now_s();
+            HIP_TRY(plan_part(spec_plan, nrows, ncols, f32, prp, so, pdr));
+            spec_opt = so; spec_done = true; spec_s = now_s() - ts;
+            return CVR_OK;
+        };
+        int rc = auto_layout(h, part, nrows, ncols, f32, nz0, nz1, popt, on_dev && !getenv("CVR_NO_SPECULATIVE_PLAN") ? &speculate : nullptr);      // (waits for the upload; its own pass is timed into info.probe_s)
         if (rc) return rc;
         rc = choose_hubs(h, part, part.d_ci, nrows, ncols, f32, nz0, nz1, popt, local, true);
         if (rc) return rc;
         const double   t0 = now_s();
-        DevRows        here{part.d_rp, nz0, nz1, h->stream, &h->plan_ws};
-        const bool     on_dev = rp && nrows > 0 && nrows >= device_plan_rows() && !getenv("CVR_HOST_PLAN");      // (the upload of row_ptr is in front of the planner's kernels on the stream)
-        const int64_t *prp = on_dev ? nullptr : rp;
-        const DevRows *pdr = on_dev ? &here : dr;
-        HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));
+        if (plan_s) *plan_s += spec_s;
+        if (spec_done && popt.layout_auto_resident && popt.waves_per_block == spec_opt.waves_per_block && popt.steps_per_chunk == spec_opt.steps_per_chunk &&
+            popt.x_window == spec_opt.x_window && popt.col_phases == spec_opt.col_phases && local.hub_n == 0)
+            local = std::move(spec_plan);
+        else
+            HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));
         // the resident layout wants every workgroup on a CU of its own at once: one more step per chunk until they fit
         while (popt.layout_auto_resident && !local.too_large && (int64_t)local.plan.chunks.size() > (int64_t)local.wpb * popt.cus && popt.steps_per_chunk < 4096) {
             popt.steps_per_chunk += 4;
@@ -376,7 +415,8 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
             HIP_TRY(hipMemsetAsync(img.pace, 0, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases), h->stream));
             img.pace_epoch = new uint32_t(0);
         }
-        img.piece_max = opt.piece_max > 0 ? (uint32_t)opt.piece_max : opt.piece_max < 0 && S / pp.phases >= 8 && !opt.panel_on_one_xcd ? 8u : 0u;
+        // (a power of two, rounded down: the segment-table kernel cuts with shifts)
+        img.piece_max = opt.piece_max > 0 ? 1u << (31 - __builtin_clz((uint32_t)opt.piece_max)) : opt.piece_max < 0 && S / pp.phases >= 8 && !opt.panel_on_one_xcd ? 8u : 0u;
         img.col_mask = pp.tag16 ? cvr::kColMask : (1u << pp.col_bits) - 1u;
     }
     if (popt.col_phases > 1 && pp.lds_short && !popt.layout_auto_resident) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);

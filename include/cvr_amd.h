@@ -101,7 +101,8 @@ typedef struct {
                                   the 2-D form for matrices too large for one resident pass.  1 = off, <0 = auto (default)   */
     int32_t piece_max;         /* column phases: (row, phase) segments are cut into pieces of at most this many elements (at the
                                   multiples of it from the chunk's first element), so that no lane sits on one long row's
-                                  segment while the others move on to the next column ranges.  0 = whole segments,
+                                  segment while the others move on to the next column ranges.  A power of two (others are rounded
+                                  down).  0 = whole segments,
                                   <0 = auto (default): 8 when the chunks are long enough for a lane to fall a phase behind     */
     int32_t reserved[5];       /* 0 */
 } cvr_options;

@@ -69,7 +69,7 @@ def test_fuzz_parity(ncases=None, seed=None):
         hub = int(rng.choice([0, 0, 7, 300])) if ph == 1 else 0
         reo = int(rng.integers(0, 2)) if hub else 0
         tags = int(rng.choice([-1, 0, 1])) if ph > 1 else -1        # wide row tags, bounded pieces (column phases only)
-        pmax = int(rng.choice([-1, 0, 3, 8])) if ph > 1 else -1
+        pmax = int(rng.choice([-1, 0, 2, 8])) if ph > 1 else -1
         ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32, wpb=wpb, phases=ph, sorted=srt, hub=hub, tags=tags, pmax=pmax)
         from_dev = torch is not None and len(ci) > 0 and rng.integers(0, 4) == 0     # CSR arrays already on the device
         if from_dev:

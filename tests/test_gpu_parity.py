@@ -62,7 +62,7 @@ def test_converter_image_bit_exact_and_y_parity(name, S):
 @pytest.mark.parametrize("name", sorted(CASES))
 @pytest.mark.parametrize("S,wpb,win,P,tags", [(8, 1, 0, 3, 0), (4, 8, 64, 2, 0), (32, 4, 1024, 5, 0), (16, 16, 0, 1, 0), (8, 2, 256, 1, 0),
                                               (8, 1, 0, 3, 1), (32, 4, 1024, 5, 1), (64, 14, 512, 7, 1)])
-@pytest.mark.parametrize("pmax", [0, 3])
+@pytest.mark.parametrize("pmax", [0, 4])
 def test_workgroup_window_and_column_phases(name, S, wpb, win, P, tags, pmax):
     """Several chunks per workgroup sharing an LDS window of x, and column phases (a chunk feeds its rows' pieces column
     range by column range; their sums are added up in LDS): the image against the CPU mirror bit for bit, y against the CSR
