@@ -53,8 +53,8 @@ def pmc_traffic(info, kernel, workload):
                     c["image_bytes"] == info.image_bytes and c["waves_per_block"] == info.waves_per_block and
                     c["col_phases"] == info.col_phases and c["x_window"] == info.x_window and c["workload"] == workload)
             if same and c.get("col_panels", info.col_panels) == info.col_panels:
-                # the summary averages over launches of the SpMV kernel; a panelled matrix launches it once per panel
-                return float(d["hbm_bytes_per_launch_corrected"]) * info.col_panels
+                # the summary averages over launches of the SpMV kernel; a panelled matrix launches it once per panel, or once per round of eight
+                return float(d["hbm_bytes_per_launch_corrected"]) * max(int(info.spmv_launches), 1)
         except Exception:
             continue
     return None
@@ -600,7 +600,7 @@ def main():
         per = wall / args.steps
         emu = bool(args.emulate_rank)
         job_nnz = lnnz if emu else nnz            # (an emulated rank: the flops of its shard)
-        kname = "cvr::spmv_kernel<float>" if f32 else "cvr::spmv_kernel<double>"
+        kname = ("cvr::spmv_seg_kernel" if info.col_phases > 1 else "cvr::spmv_kernel") + ("<float>" if f32 else "<double>")      # (column phases: the kernel without hand-out state)
         workload_text = f"{source}: {nrows}x{ncols}, nnz {nnz}, {'fp32' if f32 else 'fp64'}, y = A x with A (CVR64 image), x, y resident in HBM"
         out = {
             "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64" if args.workload == "webgoogle" else f"SpMV GFLOP/s (2*nnz/t), {args.workload} {'fp32' if f32 else 'fp64'}"

@@ -651,6 +651,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             if (hipMalloc(&h->seg_arena, bytes) == hipSuccess) h->seg_arena_bytes = bytes; else { (void)hipGetLastError(); h->seg_arena = nullptr; }
         }
     }
+    in.spmv_launches = h->d_multi ? (int32_t)h->multi_chunks.size() : (int32_t)h->parts.size();
     CREATE_TRY(hipMalloc(&h->d_err, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&h->d_x, vsz * (size_t)in.x_elems));
     CREATE_TRY(hipMalloc(&h->d_y, vsz * (size_t)in.yext_elems));
