@@ -126,6 +126,7 @@ hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const
         const int64_t total = (int64_t)cvr::kLdsBytes / vs;
         const int64_t fixed = (int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + 4 + ((pp.hub_n + 3) & ~(int64_t)3);     // dictionary room is reserved before it is known
         int64_t stage = std::min<int64_t>(std::max<int64_t>((pp.max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
+        if (const char *cap = getenv("CVR_YSTAGE_CAP")) stage = std::min<int64_t>(stage, std::max<int64_t>(64, atoll(cap) & ~(int64_t)63));      // (experiments: occupancy against staged write-out)
         if (fixed + pp.wpb * stage + pp.win > total) stage = std::max<int64_t>(std::min<int64_t>(stage, 512), ((total - fixed - pp.win) / pp.wpb) & ~(int64_t)63);
         if (stage < 64) stage = 64;
         if (fixed + pp.wpb * stage + pp.win > total) pp.win = std::max<int64_t>(0, total - fixed - pp.wpb * stage) & ~(int64_t)3;

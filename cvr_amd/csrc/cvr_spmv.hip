@@ -192,7 +192,6 @@ template <typename T> __device__ __forceinline__ void store_y(T *p, T v) { *p = 
 template <typename T> struct ChunkState {
     T        acc;       // running sum of the lane's current segment
     uint32_t cur;       // ordinal of that segment in the chunk
-    uint32_t currow;    // column phases: the chunk's row the segment belongs to
     uint32_t fed;       // segments handed out so far (wave-uniform)
     uint32_t feeding;   // 0: the lane is (or has become) a stealer
     uint32_t own;       // the lane parked a row sum in its LDS slot
@@ -204,13 +203,12 @@ template <typename T> __device__ __forceinline__ void lds_add(T *p, T v)
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);      // ds_add_f64 / ds_add_f32
 }
 
-// four steps of all 64 lanes: FMA, then the write-back of the lanes whose segment ends at the step.  SEGT (column phases):
-// the segment's sum is added to its row's accumulator in LDS (ystage[row of the chunk]); the rows of the segments come
-// in the segment's last column word, above the column index (bits [col_bits, 31)).
-template <typename T, int WIN, bool DICT, bool SEGT>
+// four steps of all 64 lanes: FMA, then the write-back of the lanes whose segment ends at the step.  (Images with column phases
+// run through spmv_seg_kernel below, which needs none of this hand-out state.)
+template <typename T, int WIN, bool DICT>
 __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT> &Q, const X4<T> &xq, T *__restrict__ yext,
                                           T *slot_lane, uint32_t row_first, uint32_t nseg, uint32_t head_dest,
-                                          uint32_t last_dest, const T *dict, T *ystage, bool staged, uint32_t col_bits)
+                                          uint32_t last_dest, const T *dict, T *ystage, bool staged)
 {
     // the four values first: with a dictionary they are LDS reads, which would otherwise be issued (and waited for) one by
     // one between the steps' LDS writes
@@ -226,9 +224,7 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
         if (m) {
             if (!s.tail) {
                 if (fl) {
-                    if constexpr (SEGT) {
-                        lds_add(ystage + ((cw & kColMask) >> col_bits), s.acc);
-                    } else if (staged) {
+                    if (staged) {
                         ystage[s.cur] = s.acc;           // written out coalesced at the end of the chunk
                     } else {
                         const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
@@ -241,7 +237,6 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
                 s.fed = __builtin_amdgcn_readfirstlane(s.fed + (uint32_t)__popcll(m));
                 if (s.fed >= nseg) { s.fed = nseg; s.tail = 1; }
             } else if (fl && s.feeding) {
-                if constexpr (SEGT) s.currow = (cw & kColMask) >> col_bits;
                 *slot_lane = s.acc;
                 s.acc = 0;
                 s.feeding = 0;
@@ -256,12 +251,12 @@ __device__ __forceinline__ void sum_group(ChunkState<T> &s, const Group<T, DICT>
 // multi != null (column panels, one panel per XCD at a time): workgroup b works on panel b & 7 of the eight the launch covers --
 // the workgroups with equal b & 7 share an XCD under round-robin dealing, so that XCD's L2 only ever holds that panel's slice
 // of x -- and takes the panel's chunk b >> 3; what differs between the panels comes from multi[b & 7].
-template <typename T, int QA, int XPOL, int DEPTH, int WIN, bool DICT, bool MW, bool SEGT, bool C16>
+template <typename T, int QA, int XPOL, int DEPTH, int WIN, bool DICT, bool MW, bool C16>
 __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv_kernel(
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint8_t *__restrict__ target_a,
     const T *__restrict__ x, T *__restrict__ yext_a, int G, uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz,
     uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict,
-    uint32_t ystage_a, const uint2 *__restrict__ desc2, uint32_t col_bits, const T *__restrict__ hub_x, uint32_t hub_n, uint32_t kstride,
+    uint32_t ystage_a, const T *__restrict__ hub_x, uint32_t hub_n, uint32_t kstride,
     const uint32_t *__restrict__ cbase, uint32_t pad_col, const PanelArgs *__restrict__ multi)
 {
     const uint8_t *__restrict__ stream = stream_a, *__restrict__ target = target_a;
@@ -275,7 +270,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     }
     constexpr int  GB = DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     constexpr bool kSync = WIN != 0 || (DICT && MW);      // LDS filled by other waves of the workgroup
-    // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums (SEGT: row accumulators), the value dictionary (DICT),
+    // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums, the value dictionary (DICT),
     // the x window and its zero slot (WIN; wn + 4 values)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t nw = MW ? blockDim.x >> 6 : 1u;
@@ -303,7 +298,6 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     X4<T>          xs[DEPTH];
     __amdgpu_buffer_rsrc_t rs;
     uint4          d;
-    uint32_t       nri = 0;                            // SEGT: rows with a segment in this chunk
     uint32_t       cb = 0;                             // C16: the chunk's smallest column
     // the first loads of chunk k: its stream (a wave past the last chunk streams nothing), its descriptor
     auto begin_chunk = [&]() {
@@ -312,12 +306,6 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
         for (int i = 0; i < QN; i++) Q[i] = load_group<T, SPOL, DICT, C16>(rs, voff, (uint32_t)i * GB);
         d = live ? desc[k] : uint4{0, 0, 0, 0};
         if constexpr (C16) cb = live ? cbase[k] : 0u;
-        if constexpr (SEGT) {
-            if (live) {
-                nri = desc2[k].y;
-                for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);                 // the row accumulators (+ the dump entry)
-            }
-        }
     };
     begin_chunk();
 
@@ -355,7 +343,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     }
     if constexpr (kSync) {
         __syncthreads();
-    } else if constexpr (DICT || SEGT) {
+    } else if constexpr (DICT) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // one wavefront per workgroup: its own LDS writes, in order
     }
 
@@ -369,7 +357,6 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
         ChunkState<T> s;
         s.acc = 0;
         s.cur = lane;
-        s.currow = 0;
         s.fed = nseg < kLanes ? nseg : kLanes;
         s.feeding = lane < s.fed;
         s.own = 0;
@@ -377,7 +364,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
         // Row sums go to LDS and leave as coalesced stores at the end of the chunk (its rows are consecutive): the scattered
         // 8-byte stores they replace cost 12 % of the kernel (profiles/r01_y_staging.log).  A chunk of more than ystage_n
         // segments (very short rows) stores directly.
-        const bool staged = SEGT || nseg <= ystage_n;
+        const bool staged = nseg <= ystage_n;
         if constexpr (C16) {
 #pragma unroll
             for (int i = 0; i < DEPTH; i++) Q[i].c = widen_cols(Q[i].c, cb, pad_col);
@@ -391,7 +378,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
             const Group<T, DICT> Qn = load_group<T, SPOL, DICT, C16>(rs, voff, (uint32_t)(g + QN) * GB);
             if constexpr (C16) Q[DEPTH].c = widen_cols(Q[DEPTH].c, cb, pad_col);       // (arrived an iteration ago: the gather below needs it anyway)
             const X4<T>    xn = gather<T, XPOL, WIN>(rx, win, Q[DEPTH].c, cmask, wbase, wn, (hub_n + 3u) & ~3u, wn);
-            sum_group<T, WIN, DICT, SEGT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged, col_bits);
+            sum_group<T, WIN, DICT>(s, Q[0], xs[0], yext, slot_lane, row_first, nseg, head_dest, last_dest, dict, ystage, staged);
 #pragma unroll
             for (int i = 0; i + 1 < QN; i++) Q[i] = Q[i + 1];
             Q[QN - 1] = Qn;
@@ -405,9 +392,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
         if (tg != lane) __hip_atomic_fetch_add(&slots[wv * kLanes + tg], s.acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (s.own) {
-            if constexpr (SEGT) {
-                lds_add(ystage + s.currow, *slot_lane);
-            } else if (staged) {
+            if (staged) {
                 ystage[s.cur] = *slot_lane;
             } else {
                 const uint32_t dst = s.cur == 0 ? head_dest : s.cur == nseg - 1 ? last_dest : row_first + s.cur;
@@ -416,7 +401,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
         }
         if (staged) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            const uint32_t nout = SEGT ? nri : nseg;      // SEGT: one entry per row of the chunk; else one per segment
+            const uint32_t nout = nseg;
             for (uint32_t i = lane; i < nout; i += kLanes) {
                 const uint32_t dst = i == 0 ? head_dest : i == nout - 1 ? last_dest : row_first + i;
                 store_y(yext + dst, ystage[i]);
@@ -831,23 +816,22 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     if (img.order_n) x_ext = img.hub_x;            // the kernel gathers from the re-ordered copy of x
     const size_t lds = spmv_lds_bytes(img);
     if (lds > kLdsBytes) return hipErrorInvalidValue;      // build_part sizes the stage and the window to fit; never reached
-    // template parameters: <value type, stream run-ahead beyond the gather, gather cache policy, gather run-ahead, LDS window, dictionary, multi-wave, column phases>
-#define CVR_LAUNCH(T, SP, D, W, DI, MW, SG)                                                                       \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, SG, false>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
+    // template parameters: <value type, stream run-ahead beyond the gather, gather cache policy, gather run-ahead, LDS table, dictionary, multi-wave, narrow chunks>
+#define CVR_LAUNCH(T, SP, D, W, DI, MW)                                                                           \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, false>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
                        multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
-                       static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(img.hub_x), img.hub_n, kstride, img.cbase, img.pad_col, multi)
-#define CVR_PICK_SG(T, SP, D, W, DI, MW) CVR_LAUNCH(T, SP, D, W, DI, MW, false)
-#define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_PICK_SG(T, SP, D, W, DI, true); else CVR_PICK_SG(T, SP, D, W, DI, false); } while (0)
+                       static_cast<const T *>(img.dict), img.ndict, img.ystage, static_cast<const T *>(img.hub_x), img.hub_n, kstride, img.cbase, img.pad_col, multi)
+#define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_LAUNCH(T, SP, D, W, DI, true); else CVR_LAUNCH(T, SP, D, W, DI, false); } while (0)
 #define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_PICK_MW(T, SP, D, W, true); else CVR_PICK_MW(T, SP, D, W, false); } while (0)
 #define CVR_PICK_W(T, SP, D)     do { if (use_win && img.hub_n) CVR_PICK_DI(T, SP, D, 2); else if (use_win) CVR_PICK_DI(T, SP, D, 1); else CVR_PICK_DI(T, SP, D, 0); } while (0)
 #define CVR_PICK_D(T, SP)        do { if (img.depth == 2) CVR_PICK_W(T, SP, 2); else CVR_PICK_W(T, SP, 1); } while (0)
 #define CVR_PICK_SP(T)           do { if (img.stream_ahead >= 2) CVR_PICK_D(T, 3); else CVR_PICK_D(T, 1); } while (0)
 #define CVR_LAUNCH_C16(T, SP, D)                                                                                  \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, 0, false, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
+    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, 0, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
                        static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, 0u,          \
-                       static_cast<const T *>(nullptr), 0u, img.ystage, img.desc2, img.col_bits, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col, (const PanelArgs *)nullptr)
+                       static_cast<const T *>(nullptr), 0u, img.ystage, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col, (const PanelArgs *)nullptr)
 #define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
                              else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
 #define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
@@ -889,7 +873,6 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #undef CVR_PICK_W
 #undef CVR_PICK_DI
 #undef CVR_PICK_MW
-#undef CVR_PICK_SG
 #undef CVR_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || img.nshared == 0 || !with_fixup) return e;
