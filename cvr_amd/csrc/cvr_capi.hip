@@ -39,9 +39,10 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
     if (h->d_multi) {          // eight panels per launch, panel b & 7 on the XCD of the workgroups b
         cvr::DeviceImage shared = h->parts[0].img;
         shared.ystage = h->multi_ystage;
-        for (size_t r = 0; r < h->multi_chunks.size(); r++) {
-            if (h->multi_chunks[r] == 0) continue;
-            const hipError_t e = cvr::launch_spmv(shared, x, nullptr, st, false, h->d_multi + 8 * r, h->multi_chunks[r]);
+        uint32_t most = 0;
+        for (uint32_t c : h->multi_chunks) most = std::max(most, c);
+        if (most) {      // all rounds in one grid
+            const hipError_t e = cvr::launch_spmv(shared, x, nullptr, st, false, h->d_multi, most, (uint32_t)h->multi_chunks.size());
             if (e != hipSuccess) return e;
         }
     } else
@@ -651,7 +652,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             if (hipMalloc(&h->seg_arena, bytes) == hipSuccess) h->seg_arena_bytes = bytes; else { (void)hipGetLastError(); h->seg_arena = nullptr; }
         }
     }
-    in.spmv_launches = h->d_multi ? (int32_t)h->multi_chunks.size() : (int32_t)h->parts.size();
+    in.spmv_launches = h->d_multi ? 1 : (int32_t)h->parts.size();
     CREATE_TRY(hipMalloc(&h->d_err, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&h->d_x, vsz * (size_t)in.x_elems));
     CREATE_TRY(hipMalloc(&h->d_y, vsz * (size_t)in.yext_elems));

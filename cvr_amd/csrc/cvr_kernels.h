@@ -156,8 +156,10 @@ hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream
 struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *target; void *yext; uint32_t nchunks, ystage; const uint2 *desc2; };
 // y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0 and with_fixup)
 // multi != null: eight panels in one launch (plain layout, one chunk per workgroup, no LDS tables): workgroup b takes chunk b >> 3 of
-// panel b & 7; multi_chunks = the most chunks any of them has; img = any of them (for what they share); y_ext and with_fixup unused
-hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup = true, const PanelArgs *multi = nullptr, uint32_t multi_chunks = 0);
+// panel b & 7 of its round; multi[rounds][8]; multi_chunks = the most chunks any panel has (the rounds follow each other in ONE grid:
+// no launch boundary between them); img = any of the panels (for what they share); y_ext and with_fixup unused
+hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup = true, const PanelArgs *multi = nullptr, uint32_t multi_chunks = 0,
+                       uint32_t multi_rounds = 1);
 size_t     spmv_lds_bytes(const DeviceImage &img);      // dynamic LDS of that launch
 inline size_t pace_words(uint32_t phases) { return (size_t)8 * phases * 512; }      // pacing buffer of an image with column phases
 

@@ -263,10 +263,11 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     const uint4 *__restrict__   desc = desc_a;
     T *__restrict__             yext = yext_a;
     uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = blockIdx.x;
-    if (multi) {
-        const PanelArgs pa = multi[blockIdx.x & 7u];
+    if (multi) {          // (nblocks_per_xcd: here the workgroups of one round of eight panels; the rounds follow each other in the grid)
+        const uint32_t  round = blockIdx.x / nblocks_per_xcd, b = blockIdx.x - round * nblocks_per_xcd;
+        const PanelArgs pa = multi[round * 8u + (b & 7u)];
         stream = pa.stream; desc = pa.desc; target = pa.target; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
-        bidx = blockIdx.x >> 3;
+        bidx = b >> 3;
     }
     constexpr int  GB = DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32;
     constexpr bool kSync = WIN != 0 || (DICT && MW);      // LDS filled by other waves of the workgroup
@@ -488,10 +489,11 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     const uint2 *__restrict__   desc2 = desc2_a;
     T *__restrict__             yext = yext_a;
     uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = blockIdx.x;
-    if (multi) {          // column panels, one per XCD at a time: panel blockIdx & 7, its chunk group blockIdx >> 3 (spmv_kernel)
-        const PanelArgs pa = multi[blockIdx.x & 7u];
+    if (multi) {          // column panels, one per XCD at a time, the rounds of eight one after the other in the grid (spmv_kernel)
+        const uint32_t  round = blockIdx.x / nblocks_per_xcd, b = blockIdx.x - round * nblocks_per_xcd;
+        const PanelArgs pa = multi[round * 8u + (b & 7u)];
         stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
-        bidx = blockIdx.x >> 3;
+        bidx = b >> 3;
     }
     constexpr int GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
     // LDS: [waves][ystage_n] row accumulators, the value dictionary (DICT), the x window and its zero slot (WIN; wn + 4 values)
@@ -784,7 +786,7 @@ size_t spmv_lds_bytes(const DeviceImage &img)
     return (size_t)(wpb * (slots + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? ((img.hub_n + 3u) & ~3u) + img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8);
 }
 
-hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup, const PanelArgs *multi, uint32_t multi_chunks)
+hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup, const PanelArgs *multi, uint32_t multi_chunks, uint32_t multi_rounds)
 {
     if (img.nchunks == 0 && !multi) return hipSuccess;
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;                     // consecutive chunks (wavefronts) per workgroup
@@ -806,7 +808,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
         }
     }
     const uint32_t per_xcd = (nblocks + 7) / 8;
-    const uint32_t grid = multi ? multi_chunks * 8 : img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;      // (multi: `img` is one of the eight panels: what they share comes from it)
+    const uint32_t grid = multi ? multi_rounds * multi_chunks * 8 : img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;      // (multi: `img` is one of the eight panels: what they share comes from it)
     const dim3     block(kLanes * wpb);
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
     if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
@@ -819,7 +821,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     // template parameters: <value type, stream run-ahead beyond the gather, gather cache policy, gather run-ahead, LDS table, dictionary, multi-wave, narrow chunks>
 #define CVR_LAUNCH(T, SP, D, W, DI, MW)                                                                           \
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, false>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
-                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
+                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
                        multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
                        static_cast<const T *>(img.dict), img.ndict, img.ystage, static_cast<const T *>(img.hub_x), img.hub_n, kstride, img.cbase, img.pad_col, multi)
 #define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_LAUNCH(T, SP, D, W, DI, true); else CVR_LAUNCH(T, SP, D, W, DI, false); } while (0)
@@ -829,12 +831,12 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_PICK_SP(T)           do { if (img.stream_ahead >= 2) CVR_PICK_D(T, 3); else CVR_PICK_D(T, 1); } while (0)
 #define CVR_LAUNCH_C16(T, SP, D)                                                                                  \
     hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, 0, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
-                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
+                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
                        img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, 0u,          \
                        static_cast<const T *>(nullptr), 0u, img.ystage, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col, (const PanelArgs *)nullptr)
 #define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
                              else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
-#define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
+#define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
                         img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi
 #define CVR_SEG(T, SP, D, W, DI, LD)                                                                               \
     do {                                                                                                           \

@@ -157,8 +157,9 @@ typedef struct {
     double  preprocess_wall_s;     /* host wall time of cvr_preprocess: convert_s (device events) + its temporary allocations and the final sync */
     int32_t row_bands;             /* 1, or the number of row bands (resident launches per SpMV)                                           */
     int32_t piece_max;             /* column phases: longest piece of a lane stream (0 = whole (row, phase) segments)                     */
-    int32_t spmv_launches;         /* launches of the SpMV kernel one SpMV is made of: 1; with column panels one per panel, or one per round of
-                                      eight panels (one panel per XCD at a time); combine / fix-up / hub kernels not counted              */
+    int32_t spmv_launches;         /* launches of the SpMV kernel one SpMV is made of: 1 (also with column panels that run one per XCD at a
+                                      time: all rounds of eight share one grid), or one per panel when each panel runs over the whole chip;
+                                      combine / fix-up / hub kernels not counted                                                            */
     int32_t reserved7;
 } cvr_info;
 
