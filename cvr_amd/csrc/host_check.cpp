@@ -1,5 +1,5 @@
 // host_check.cpp -- sanitizer driver for the host-side sources (make asan-check): both loader modes, the binary image
-// round trip, the planner at several chunk lengths and thresholds, the CSR loop, on every file given.
+// round trip, the keyed cache (miss / hit / stale), the planner at several chunk lengths and thresholds, the CSR loop, on every file given.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -8,6 +8,20 @@
 
 #include "../../include/cvr_amd.h"
 #include "cvr_plan.h"
+
+// copy src to dst, with `tail` (may be NULL) appended; 0 on success
+static int copy_file(const char *src, const char *dst, const char *tail)
+{
+    FILE *i = fopen(src, "rb"), *o = i ? fopen(dst, "wb") : nullptr;
+    if (!i || !o) { if (i) fclose(i); return 1; }
+    char   buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, i)) > 0) fwrite(buf, 1, n, o);
+    if (tail) fputs(tail, o);
+    fclose(i);
+    fclose(o);
+    return 0;
+}
 
 int main(int argc, char **argv)
 {
@@ -38,6 +52,27 @@ int main(int argc, char **argv)
                 cvr_mm_free(&b);
             }
             remove(bin.c_str());
+            // keyed cache beside a copy of the file: miss, hit, stale after the source grows by a comment line
+            const std::string cp = std::string("/tmp/host_check_") + std::to_string(a) + "_" + std::to_string(mode) + ".mtx";
+            if (copy_file(argv[a], cp.c_str(), nullptr) == 0) {
+                cvr_mm_matrix c1, c2, c3;
+                int           hit = -1;
+                if (cvr_mm_read_cached(cp.c_str(), mode, &c1, &hit) || hit != 0) { printf("%s: first cached read (hit %d)\n", argv[a], hit); failures++; }
+                else {
+                    if (cvr_mm_read_cached(cp.c_str(), mode, &c2, &hit) || hit != 1) { printf("%s: second cached read (hit %d)\n", argv[a], hit); failures++; }
+                    else {
+                        if (c2.nnz != m.nnz || memcmp(c2.col_idx, m.col_idx, sizeof(*m.col_idx) * (size_t)m.nnz)) { printf("%s: cached image differs\n", argv[a]); failures++; }
+                        cvr_mm_free(&c2);
+                    }
+                    copy_file(argv[a], cp.c_str(), "%% a comment line more\n");
+                    if (cvr_mm_read_cached(cp.c_str(), mode, &c3, &hit) || hit != 0) { printf("%s: stale cache served (hit %d)\n", argv[a], hit); failures++; }
+                    else cvr_mm_free(&c3);
+                    cvr_mm_free(&c1);
+                }
+                remove(cp.c_str());
+                remove((cp + ".ref.csrbin").c_str());
+                remove((cp + ".strict.csrbin").c_str());
+            }
             cvr_mm_free(&m);
         }
     }
