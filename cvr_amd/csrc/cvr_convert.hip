@@ -15,6 +15,7 @@
 #include "cvr_kernels.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace cvr {
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
     const uint2 *__restrict__ desc2, const int64_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
     const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags, const int32_t *__restrict__ hub_index, const uint32_t *__restrict__ hub_bitmap,
-    const uint32_t *__restrict__ cbase, uint32_t hub_n, uint32_t stage_bytes)
+    const uint32_t *__restrict__ cbase, uint32_t hub_n, uint32_t stage_bytes, uint32_t seg_packed)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t csm[];      // STAGE: stage_bytes per wavefront
     if constexpr (SEGT) { if (seg_flags[0] & 1u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
@@ -102,6 +103,22 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     if constexpr (STAGE) {
         constexpr uint32_t kBatch = 8;              // loads in flight per lane: the copy is a few round trips, not one per 64 entries
         if constexpr (SEGT) {
+            if (seg_packed) {       // 8-byte records {begin | length << 16, row}: one load per segment
+                const uint2 *pk = reinterpret_cast<const uint2 *>(seg_begin) + sbase;
+                for (uint32_t q0 = 0; q0 < nseg; q0 += kLanes * kBatch) {
+                    uint2 r[kBatch];
+#pragma unroll
+                    for (uint32_t u = 0; u < kBatch; u++) {
+                        const uint32_t q = q0 + u * kLanes + lane;
+                        r[u] = q < nseg ? pk[q] : uint2{0u, 0u};
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kBatch; u++) {
+                        const uint32_t q = q0 + u * kLanes + lane;
+                        if (q < nseg) { SBEG(q) = (uint16_t)r[u].x; SLEN(q) = (uint16_t)(r[u].x >> 16); SRW(q) = (uint16_t)r[u].y; }
+                    }
+                }
+            } else
             for (uint32_t q0 = 0; q0 < nseg; q0 += kLanes * kBatch) {
                 int64_t  sb[kBatch];
                 uint32_t sl[kBatch];
@@ -158,9 +175,16 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
                         cnt = SLEN(q);
                         rowtag = TAG ? (uint32_t)SRW(q) : (uint32_t)SRW(q) << col_bits;
                     } else if constexpr (SEGT) {
-                        pos = seg_begin[sbase + q];
-                        cnt = seg_len[sbase + q];
-                        rowtag = TAG ? (uint32_t)seg_row[sbase + q] : (uint32_t)seg_row[sbase + q] << col_bits;
+                        if (seg_packed) {
+                            const uint2 r = reinterpret_cast<const uint2 *>(seg_begin)[sbase + q];
+                            pos = (r.x & 0xffffu) == 0xffffu ? -1 : b + (int64_t)(r.x & 0xffffu);
+                            cnt = r.x >> 16;
+                            rowtag = TAG ? r.y : r.y << col_bits;
+                        } else {
+                            pos = seg_begin[sbase + q];
+                            cnt = seg_len[sbase + q];
+                            rowtag = TAG ? (uint32_t)seg_row[sbase + q] : (uint32_t)seg_row[sbase + q] << col_bits;
+                        }
                     } else if constexpr (STAGE) {
                         if (q < nrow_seg) {
                             const uint32_t a = SROW(q), z = SROW(q + 1);
@@ -453,6 +477,213 @@ __global__ __launch_bounds__(kLanes * kSegWaves) void seg_build_kernel(const int
     }
 }
 
+// The same table as a stable counting sort of the chunk's pieces by phase, for chunks whose elements fit the LDS with their bookkeeping
+// (seg_scan_lds_bytes).  The search-based kernel above and a first version of this one (windows of 64 elements, one ballot per phase
+// for the ranks) were bound by instruction issue: 500 wavefront instructions per 64 elements = 42 M for the web-Google shape, 73 us
+// on 1 024 SIMDs that issue one wave64 instruction per four clocks.  Here every thread owns a run of L consecutive elements:
+//   rows     pieces [pa, pz) of the chunk's rows; E = empty rows in front of a row (an empty row owns a pad slot, fed in phase 0)
+//   walk 1   an element starts a piece if it starts its row (marks scattered by the rows), lies in another phase than its predecessor
+//            or sits at a multiple of the piece length; the thread counts its starts per phase in a column of its own of hist[phase][thread]
+//   scans    hist in (phase, thread) order -> where a thread's pieces of a phase go; the last row start and the first piece start
+//            of the runs in front of / behind a run (running maximum / minimum over the threads)
+//   walk 2   a piece's place = hist[phase][thread]++ (+ the empty rows in front of its row in phase 0, all of them in the later
+//            phases: the table is in (phase, row, position) order); its length = distance to the next start
+constexpr uint32_t kSegThreads = 256, kSegRunMax = 32;
+
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int o = 1; o < kLanes; o <<= 1) { const uint32_t t = __shfl_up(v, o); if ((int)lane >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int o = 1; o < kLanes; o <<= 1) { const uint32_t t = __shfl_up(v, o); if ((int)lane >= o) v = v > t ? v : t; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_min_down(uint32_t v, uint32_t lane)      // minimum over this lane and the lanes behind it
+{
+#pragma unroll
+    for (int o = 1; o < kLanes; o <<= 1) { const uint32_t t = __shfl_down(v, o); if ((int)lane + o < kLanes) v = v < t ? v : t; }
+    return v;
+}
+
+__global__ __launch_bounds__(kSegThreads) void seg_scan_kernel(const int64_t *__restrict__ rp, const int32_t *__restrict__ cidx,
+                                                         const int64_t *__restrict__ nzb, const uint32_t *__restrict__ pad_cnt,
+                                                         uint4 *__restrict__ desc, uint2 *__restrict__ desc2, uint32_t nchunks, const uint32_t *__restrict__ nchunks_dev,
+                                                         uint32_t pw, uint32_t phases, uint32_t cap, uint32_t *__restrict__ cnt, uint2 *__restrict__ packed,
+                                                         uint32_t *__restrict__ flags, uint32_t psh, unsigned long long *__restrict__ dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t kWaves = kSegThreads / kLanes;
+    __shared__ uint32_t sbad, etotal, wsum[kWaves], wmax[kWaves], wmin[kWaves];
+#define SEG_CLOCK(i) do { if (dbg && threadIdx.x == 0 && (blockIdx.x & 255u) == 0) dbg[(blockIdx.x >> 8) * 16 + (i)] = wall_clock64(); } while (0)
+    SEG_CLOCK(0);
+    const uint32_t k = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (k >= (nchunks_dev ? *nchunks_dev : nchunks)) return;
+    const float    inv_pw = 1.0f / (float)pw;
+    const uint32_t pmask = (1u << psh) - 1u;
+    const int64_t  b = nzb[k], e = nzb[k + 1];
+    const uint32_t row_first = desc[k].x, nri = desc2[k].y, sbase = k * cap, n = (uint32_t)(e - b);
+    const uint32_t RW = nri / 64 + 1, L = (n + kSegThreads - 1) / kSegThreads;        // row windows; elements per thread
+    // LDS: pa, pz | epre | cols | hist | E | mark | phb | z0
+    uint32_t *pa = reinterpret_cast<uint32_t *>(smem), *pz = pa + nri;
+    uint32_t *epre = pz + nri;                                             // [RW] empty rows in front of a window of 64 rows
+    int32_t  *cols = reinterpret_cast<int32_t *>(epre + RW);               // [n]
+    uint16_t *hist = reinterpret_cast<uint16_t *>(cols + n);               // [phases][kSegThreads]
+    uint16_t *E = hist + (size_t)phases * kSegThreads;                     // [nri] empty rows in front of the row inside its window
+    uint16_t *mark = E + nri;                                              // [n] row + 1 at the first element of a row, else 0
+    uint8_t  *phb = reinterpret_cast<uint8_t *>(mark + n);                 // [n] phase
+    uint8_t  *z0 = phb + n;                                                // [n] phase-0 starts of the run in front of the element
+    if (tid == 0) sbad = 0;
+    // All loads of a batch are issued before the first is used: one round trip per eight windows of rows / 2 048 columns
+    constexpr uint32_t kBatch = 8;
+    int32_t c0[kBatch];
+#pragma unroll
+    for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = tid + t * kSegThreads; c0[t] = j < n ? cidx[b + j] : 0; }
+    for (uint32_t u0 = wv; u0 < RW; u0 += kWaves * kBatch) {
+        int64_t ra[kBatch], rz[kBatch];
+#pragma unroll
+        for (uint32_t t = 0; t < kBatch; t++) {
+            const uint32_t i = (u0 + t * kWaves) * 64 + lane;
+            ra[t] = i < nri ? rp[row_first + i] : 0;
+            rz[t] = i < nri ? rp[row_first + i + 1] : 0;
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < kBatch; t++) {
+            const uint32_t u = u0 + t * kWaves, i = u * 64 + lane;
+            if (u >= RW) break;
+            bool empty = false;
+            if (i < nri) {
+                int64_t a = ra[t] > b ? ra[t] : b, z = rz[t] < e ? rz[t] : e;
+                if (z < a) z = a;
+                pa[i] = (uint32_t)(a - b); pz[i] = (uint32_t)(z - b);
+                empty = z <= a;
+            }
+            const unsigned long long m = __ballot(empty);
+            if (i < nri) E[i] = (uint16_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) epre[u] = (uint32_t)__popcll(m);
+        }
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = tid + t * kSegThreads; if (j < n) { cols[j] = c0[t]; mark[j] = 0; } }
+    for (uint32_t j0 = tid + kSegThreads * kBatch; j0 < n; j0 += kSegThreads * kBatch) {
+        int32_t c[kBatch];
+#pragma unroll
+        for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = j0 + t * kSegThreads; c[t] = j < n ? cidx[b + j] : 0; }
+#pragma unroll
+        for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = j0 + t * kSegThreads; if (j < n) { cols[j] = c[t]; mark[j] = 0; } }
+    }
+    for (uint32_t p = 0; p < phases; p++) hist[p * kSegThreads + tid] = 0;
+    __syncthreads();
+    SEG_CLOCK(1);
+    if (wv == 0) {          // empty rows in front of every row window
+        uint32_t carry = 0;
+        for (uint32_t u0 = 0; u0 < RW; u0 += 64) {
+            const uint32_t u = u0 + lane, c = u < RW ? epre[u] : 0u, incl = wave_incl_sum(c, lane);
+            if (u < RW) epre[u] = carry + incl - c;
+            carry += __shfl(incl, 63);
+        }
+        if (lane == 0) etotal = carry;
+    }
+    for (uint32_t i = tid; i < nri; i += kSegThreads) if (pz[i] > pa[i]) mark[pa[i]] = (uint16_t)(i + 1);
+    __syncthreads();
+    SEG_CLOCK(2);
+    // walk 1
+    const uint32_t j0 = tid * L, j1 = min(n, j0 + L);
+    uint32_t       smask = 0, last_mark = 0, bad = 0, z = 0, pph = 0;
+    int32_t        pcol = 0;
+    if (j0 < j1 && j0 > 0) { pcol = cols[j0 - 1]; pph = phase_of((uint32_t)pcol, pw, inv_pw); }
+    for (uint32_t j = j0; j < j1; j++) {
+        const int32_t  col = cols[j];
+        const uint32_t ph = phase_of((uint32_t)col, pw, inv_pw), m = mark[j];
+        bool           start = m != 0;
+        if (!start) {                                         // (j > 0 here: element 0 starts a row piece)
+            if (col < pcol) bad = 1;
+            start = ph != pph || (j & pmask) == 0;
+        }
+        phb[j] = (uint8_t)ph;
+        z0[j] = (uint8_t)z;
+        if (start) {
+            smask |= 1u << (j - j0);
+            hist[ph * kSegThreads + tid] += 1;
+            if (ph == 0) z++;
+        }
+        if (m) last_mark = m;
+        pcol = col; pph = ph;
+    }
+    if (bad) sbad = 1;
+    // the last row start in front of the run, the first piece start behind it
+    const uint32_t first_start = smask ? j0 + (uint32_t)__builtin_ctz(smask) : n;
+    const uint32_t imax = wave_incl_max(last_mark, lane), imin = wave_incl_min_down(first_start, lane);
+    if (lane == 63) wmax[wv] = imax;
+    if (lane == 0) wmin[wv] = imin;
+    __syncthreads();
+    SEG_CLOCK(3);
+    uint32_t rbefore = __shfl_up(imax, 1), nafter = __shfl_down(imin, 1);
+    if (lane == 0) rbefore = 0;
+    if (lane == 63) nafter = n;
+    for (uint32_t w = 0; w < kWaves; w++) {
+        if (w < wv) rbefore = max(rbefore, wmax[w]);
+        if (w > wv) nafter = min(nafter, wmin[w]);
+    }
+    // hist in (phase, thread) order: a thread sums `phases` consecutive entries, the sums are scanned over the workgroup
+    uint32_t mine = 0;
+    for (uint32_t q = 0; q < phases; q++) mine += hist[tid * phases + q];
+    const uint32_t isum = wave_incl_sum(mine, lane);
+    if (lane == 63) wsum[wv] = isum;
+    __syncthreads();
+    uint32_t run = isum - mine;
+    for (uint32_t w = 0; w < wv; w++) run += wsum[w];
+    for (uint32_t q = 0; q < phases; q++) { const uint32_t c = hist[tid * phases + q]; hist[tid * phases + q] = (uint16_t)run; run += c; }
+    const uint32_t padc = pad_cnt[k];
+    uint32_t       stotal = 0;
+    for (uint32_t w = 0; w < kWaves; w++) stotal += wsum[w];
+    stotal += etotal + (padc > 0 ? 1u : 0u);
+    if (tid == 0) {
+        cnt[k] = stotal;
+        desc[k].y = stotal;
+        desc2[k].x = sbase;
+        if (sbad) atomicOr(&flags[0], 1u);
+    }
+    __syncthreads();
+    SEG_CLOCK(4);
+    if (sbad) return;                            // unsorted rows: the table is meaningless (cvr_preprocess reports it)
+    // walk 2
+    const uint32_t et = etotal;
+    uint32_t       rcur = rbefore;
+    for (uint32_t j = j0; j < j1; j++) {
+        const uint32_t m = mark[j], i = j - j0;
+        if (m) rcur = m;
+        if ((smask >> i) & 1u) {
+            const uint32_t ph = phb[j], r = rcur - 1u;
+            const uint32_t slot = hist[ph * kSegThreads + tid];
+            hist[ph * kSegThreads + tid] = (uint16_t)(slot + 1);
+            const uint32_t rest = i < 31 ? smask >> (i + 1) : 0u;
+            const uint32_t nxt = rest ? j + 1 + (uint32_t)__builtin_ctz(rest) : nafter;
+            const uint32_t idx = sbase + slot + (ph == 0 ? epre[r >> 6] + E[r] : et);
+            packed[idx] = uint2{j | ((nxt - j) << 16), r};
+        }
+    }
+    __syncthreads();
+    SEG_CLOCK(5);
+    // empty rows: behind the phase-0 pieces in front of their position and the empty rows in front of them
+    for (uint32_t i = tid; i < nri; i += kSegThreads) {
+        const uint32_t a = pa[i];
+        if (pz[i] > a) continue;
+        // (hist has moved on to the END of every thread's pieces of a phase: the pieces of phase 0 in front of position a are those
+        // of the threads in front of its run -- the start of that thread's range = the end of its predecessor's -- and z0)
+        uint32_t before;
+        if (a >= n) before = hist[(size_t)kSegThreads - 1];
+        else { const uint32_t t = a / L; before = (t ? hist[t - 1] : 0u) + z0[a]; }
+        packed[sbase + before + epre[i >> 6] + E[i]] = uint2{0xffffu | (1u << 16), i};
+    }
+    if (padc > 0 && tid == 0) packed[sbase + stotal - 1] = uint2{0xffffu | (padc << 16), nri};
+    SEG_CLOCK(6);
+#undef SEG_CLOCK
+}
+
 // sum of the chunks' segment counts (cvr_info.nsegments), one workgroup
 __global__ __launch_bounds__(1024) void seg_total_kernel(uint32_t *__restrict__ cnt, uint32_t nchunks)
 {
@@ -715,9 +946,44 @@ static uint32_t seg_lds_cols(const DeviceImage &img)
 }
 static size_t seg_lds_bytes(const DeviceImage &img) { return 8 * (size_t)img.ystage + 5 * (size_t)seg_lds_cols(img) + 16; }
 
+// LDS of seg_scan_kernel for a chunk of `cap` elements and at most ystage - 1 rows (0: such chunks do not fit, seg_build_kernel takes them)
+static size_t seg_scan_lds_bytes(const DeviceImage &img)
+{
+    const size_t cap = (size_t)kLanes * img.S, ys = img.ystage;
+    if (cap > (size_t)kSegRunMax * kSegThreads || img.phases > 64) return 0;
+    const size_t bytes = 8 * ys + 4 * (ys / 64 + 2) + 4 * cap + 2 * (size_t)img.phases * kSegThreads + 2 * ys + 2 * cap + cap + cap + 64;
+    return bytes <= kLdsBytes - 1024 ? bytes : 0;
+}
+
 hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s)
 {
     if (img.nchunks == 0) return hipSuccess;
+    static const bool by_rows = getenv("CVR_SEG_BY_ROWS") != nullptr;      // (diagnostics: the search-based kernel)
+    if (const size_t lds = by_rows ? 0 : seg_scan_lds_bytes(img)) {
+        unsigned long long *dbg = nullptr;
+        if (getenv("CVR_SEG_CLOCKS") && hipMalloc(&dbg, sizeof(unsigned long long) * 16 * 64) != hipSuccess) dbg = nullptr;
+        if (dbg) fprintf(stderr, "[seg_scan] %u chunks, S %d, %u phases, ystage %u, LDS %zu bytes per workgroup\n", img.nchunks, img.S, img.phases, img.ystage, lds);
+        hipLaunchKernelGGL(seg_scan_kernel, dim3(img.nchunks), dim3(kSegThreads), lds, s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc, img.desc2,
+                           img.nchunks, (const uint32_t *)nullptr, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, reinterpret_cast<uint2 *>(st.begin), st.flags,
+                           img.piece_max ? (uint32_t)__builtin_ctz(img.piece_max) : 31u, dbg);
+        st.packed = true;
+        if (dbg) {          // CVR_SEG_CLOCKS: 100-MHz time stamps of every 256th workgroup's stages, on stderr
+            unsigned long long h[16 * 64] = {};
+            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                unsigned long long t0 = ~0ull;
+                for (uint32_t g = 0; g * 256 < img.nchunks && g < 64; g++) t0 = std::min(t0, h[g * 16]);
+                for (uint32_t g = 0; g * 256 < img.nchunks && g < 64; g++) {
+                    fprintf(stderr, "[seg_scan] workgroup %5u: start %7.2f us; stages (us)", g * 256, (double)(h[g * 16] - t0) * 0.01);
+                    for (int i = 1; i <= 6; i++) fprintf(stderr, " %6.2f", (double)(h[g * 16 + i] - h[g * 16 + i - 1]) * 0.01);
+                    fprintf(stderr, "\n");
+                }
+            }
+            (void)hipFree(dbg);
+        }
+        hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.nchunks);
+        return hipGetLastError();
+    }
+    st.packed = false;
     hipLaunchKernelGGL(seg_build_kernel, dim3(img.nchunks), dim3(kLanes * kSegWaves), seg_lds_bytes(img), s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
                        img.desc2, img.nchunks, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, st.begin, st.len, st.row, st.flags, seg_lds_cols(img), img.piece_max ? (uint32_t)__builtin_ctz(img.piece_max) : 31u);      // (piece_max is a power of two: cvr_layout)
     hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.nchunks);
@@ -739,7 +1005,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 #define CVR_CONVERT_ARGS(T)                                                                                            \
     csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
     static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, seg ? seg->row : nullptr, img.col_bits,           \
-    seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase, img.hub_n, (uint32_t)per
+    seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase, img.hub_n, (uint32_t)per, seg && seg->packed ? 1u : 0u
 #define CVR_CONVERT(T, DI, SG, SM)                                                                                     \
     do {                                                                                                               \
         if (SG && img.tag16) hipLaunchKernelGGL((convert_kernel<T, DI, SG, false, SM, SG>), grid, block, lds, st, CVR_CONVERT_ARGS(T)); \
@@ -751,11 +1017,11 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
         if (img.f32) hipLaunchKernelGGL((convert_kernel<float, false, false, true, false>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const float *>(csr.vals),
                                         csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
                                         (const float *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
-                                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u);
+                                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u, 0u);
         else hipLaunchKernelGGL((convert_kernel<double, false, false, true, false>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const double *>(csr.vals),
                                 csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
                                 (const double *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
-                                (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u);
+                                (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u, 0u);
         return hipGetLastError();
     }
     if (img.f32) { if (img.dict) CVR_CONVERT_SG(float, true); else CVR_CONVERT_SG(float, false); }

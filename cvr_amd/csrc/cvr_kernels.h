@@ -78,6 +78,8 @@ struct SegTable {
     uint32_t *len = nullptr;        // same layout: slots of the segment
     uint16_t *row = nullptr;        // same layout: the chunk's row of the segment (rows-in-chunk = the pad segment's dump entry)
     uint32_t *flags = nullptr;      // [2]: [0] bit 0 = a row's columns are not ascending
+    bool      packed = false;       // set by launch_seg_build: the entries are 8-byte records {begin - chunk start | length << 16, row} in `begin`'s
+                                    // memory (begin 0xffff = pad slots; chunks of fewer than 65 535 slots): one store and one load per segment
 };
 // the segment table of every chunk (one workgroup each: counts per phase, then (begin, length, row) in (phase, row) order); writes
 // desc[k].y = segments of chunk k, desc2[k].x = where they start, st.cnt, st.flags
