@@ -52,7 +52,7 @@ class Info(C.Structure):
                 ("plan_s", C.c_double), ("upload_s", C.c_double), ("convert_s", C.c_double),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("waves_per_block", C.c_int32),
                 ("x_window", C.c_int32), ("lds_bytes", C.c_int32), ("nsegments", C.c_int64), ("chunk_row_cap", C.c_int64), ("near_diagonal_share", C.c_double), ("hub_entries", C.c_int32), ("narrow_cols", C.c_int32), ("hub_reorder", C.c_int32), ("row_tags16", C.c_int32), ("hub_share", C.c_double),
-                ("hub_select_s", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("spmv_launches", C.c_int32), ("reserved7", C.c_int32)]
+                ("hub_select_s", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("spmv_launches", C.c_int32), ("preprocess_fused", C.c_int32)]
 
 
 class MmMatrix(C.Structure):

@@ -572,7 +572,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // values are collected on the device from the uploaded CSR (a 40-MB scan takes microseconds there, milliseconds
     // on the host).
     const double t_dict0 = now_s();
-    if (opt.value_dict != 0 && in.nnz > 0) {
+    if (opt.value_dict != 0 && in.nnz > 0 && !h->preconverted) {
         if (!h->dict_scanned) {          // (single images with the automatic layout scanned together with the layout probe)
             h->dict_tab.assign(1024, ~0ull);
             for (size_t i = 0; i < h->parts.size(); i++) {
@@ -602,9 +602,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }
     }
     in.value_dict = (int32_t)h->ndict;
-    in.dict_s = now_s() - t_dict0;
+    if (!h->preconverted) in.dict_s = now_s() - t_dict0;
     clk.lap("value dictionary scan");
-    for (Part &p : h->parts) { rc = finish_part(h, p); if (rc) { cvr_destroy(h); return rc; } }
+    if (!h->preconverted) for (Part &p : h->parts) { rc = finish_part(h, p); if (rc) { cvr_destroy(h); return rc; } }
     for (const Part &p : h->parts) in.hub_entries = std::max<int32_t>(in.hub_entries, (int32_t)p.img.hub_n);
     // column panels whose images are plain (one chunk per workgroup, no LDS tables): eight panels per launch, each on the XCD of
     // its workgroups, so that an L2 holds one slice of x at a time and every line of x is fetched by one XCD only
@@ -646,14 +646,14 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         size_t n1 = 0, nch = 0;
         for (const Part &p : h->parts)
             if (p.img.phases > 1 && p.nchunks > 0) { n1 = std::max(n1, (size_t)p.nchunks * (size_t)cvr::kLanes * (size_t)p.img.S); nch = std::max(nch, (size_t)p.nchunks); }
-        if (n1 > 0 && n1 < ((size_t)1 << 32)) {
+        if (n1 > 0 && n1 < ((size_t)1 << 32) && !h->preconverted) {
             auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
             const size_t bytes = up(sizeof(int64_t) * n1) + up(sizeof(uint32_t) * n1) + up(sizeof(uint16_t) * n1) + up(sizeof(uint32_t) * (nch + 1)) + 256;
             if (hipMalloc(&h->seg_arena, bytes) == hipSuccess) h->seg_arena_bytes = bytes; else { (void)hipGetLastError(); h->seg_arena = nullptr; }
         }
     }
     in.spmv_launches = h->d_multi ? 1 : (int32_t)h->parts.size();
-    CREATE_TRY(hipMalloc(&h->d_err, sizeof(uint32_t)));
+    if (!h->d_err) CREATE_TRY(hipMalloc(&h->d_err, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&h->d_x, vsz * (size_t)in.x_elems));
     CREATE_TRY(hipMalloc(&h->d_y, vsz * (size_t)in.yext_elems));
     CREATE_TRY(hipMemsetAsync(h->d_x, 0, vsz * (size_t)in.x_elems, h->stream));
@@ -678,6 +678,14 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     Range range("cvr_preprocess (CSR -> CVR64)");
     const double t_wall0 = now_s();
     HIP_TRY(hipSetDevice(h->device));
+    if (h->preconverted) {          // cvr_create converted behind the planner, in one submission (cvr_fused.hip): its times are in cvr_info already
+        h->preconverted = false;
+        if (seconds) *seconds = h->info.convert_s;
+        h->info.preprocess_wall_s = now_s() - t_wall0;
+        h->converted = true;
+        if (!keep_csr) for (Part &p : h->parts) p.release_csr();
+        return CVR_OK;
+    }
     if (h->events.size() < 2) {
         h->events.resize(2);
         HIP_TRY(hipEventCreate(&h->events[0]));
@@ -744,6 +752,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     h->info.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);      // column phases: the segment-row copy is sized by now
     if (seconds) *seconds = ms * 1e-3;
     if (seg_flags[0] & 1u) return fail(CVR_ERR_INVALID, "col_phases needs the column indices of every row in ascending order");
+    if (seg_flags[0] & 2u) return fail(CVR_ERR_INTERNAL, "segment table: a chunk of the plan exceeds the launch's chunk length");
     if (err) return fail(CVR_ERR_INTERNAL, "device converter self-check failed (flags 0x%x)", err);
     h->info.nsegments = 0;
     for (uint32_t v : seg_totals) h->info.nsegments += v;

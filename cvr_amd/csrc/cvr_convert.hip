@@ -59,10 +59,11 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     uint32_t nchunks, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
     const uint2 *__restrict__ desc2, const int64_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
     const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags, const int32_t *__restrict__ hub_index, const uint32_t *__restrict__ hub_bitmap,
-    const uint32_t *__restrict__ cbase, uint32_t hub_n, uint32_t stage_bytes, uint32_t seg_packed)
+    const uint32_t *__restrict__ cbase, uint32_t hub_n, uint32_t stage_bytes, uint32_t seg_packed, const uint32_t *__restrict__ nchunks_dev)
 {
+    if (nchunks_dev) nchunks = *nchunks_dev;
     extern __shared__ __attribute__((aligned(16))) uint8_t csm[];      // STAGE: stage_bytes per wavefront
-    if constexpr (SEGT) { if (seg_flags[0] & 1u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
+    if constexpr (SEGT) { if (seg_flags[0] & 3u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
     constexpr int GB = (DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
     constexpr int CB = (C16 ? kCols16Bytes : kColsBytes) + (TAG ? kTagBytes : 0);      // bytes of the group in front of the values: column words (+ wide row tags)
     typedef typename Bits<T>::type bits_t;
@@ -527,28 +528,40 @@ __global__ __launch_bounds__(kSegThreads) void seg_scan_kernel(const int64_t *__
     const int64_t  b = nzb[k], e = nzb[k + 1];
     const uint32_t row_first = desc[k].x, nri = desc2[k].y, sbase = k * cap, n = (uint32_t)(e - b);
     const uint32_t RW = nri / 64 + 1, L = (n + kSegThreads - 1) / kSegThreads;        // row windows; elements per thread
-    // LDS: pa, pz | epre | cols | hist | E | mark | phb | z0
-    uint32_t *pa = reinterpret_cast<uint32_t *>(smem), *pz = pa + nri;
-    uint32_t *epre = pz + nri;                                             // [RW] empty rows in front of a window of 64 rows
+    if (nri > cap || n > cap) { if (tid == 0) atomicOr(&flags[0], 2u); return; }      // (a plan that does not belong to this launch)
+    // LDS: epre | cols | hist | E | mark | phb | z0  (sized by the chunk's slots: a chunk of 64 S slots has at most 64 S rows and elements)
+    uint32_t *epre = reinterpret_cast<uint32_t *>(smem);                   // [RW] empty rows in front of a window of 64 rows
     int32_t  *cols = reinterpret_cast<int32_t *>(epre + RW);               // [n]
     uint16_t *hist = reinterpret_cast<uint16_t *>(cols + n);               // [phases][kSegThreads]
     uint16_t *E = hist + (size_t)phases * kSegThreads;                     // [nri] empty rows in front of the row inside its window
     uint16_t *mark = E + nri;                                              // [n] row + 1 at the first element of a row, else 0
     uint8_t  *phb = reinterpret_cast<uint8_t *>(mark + n);                 // [n] phase
     uint8_t  *z0 = phb + n;                                                // [n] phase-0 starts of the run in front of the element
-    if (tid == 0) sbad = 0;
+    if (tid == 0) { sbad = 0; etotal = 0; }
     // All loads of a batch are issued before the first is used: one round trip per eight windows of rows / 2 048 columns
     constexpr uint32_t kBatch = 8;
     int32_t c0[kBatch];
+    int64_t ra[kBatch], rz[kBatch];
 #pragma unroll
     for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = tid + t * kSegThreads; c0[t] = j < n ? cidx[b + j] : 0; }
-    for (uint32_t u0 = wv; u0 < RW; u0 += kWaves * kBatch) {
-        int64_t ra[kBatch], rz[kBatch];
 #pragma unroll
-        for (uint32_t t = 0; t < kBatch; t++) {
-            const uint32_t i = (u0 + t * kWaves) * 64 + lane;
-            ra[t] = i < nri ? rp[row_first + i] : 0;
-            rz[t] = i < nri ? rp[row_first + i + 1] : 0;
+    for (uint32_t t = 0; t < kBatch; t++) {
+        const uint32_t i = (wv + t * kWaves) * 64 + lane;
+        ra[t] = i < nri ? rp[row_first + i] : 0;
+        rz[t] = i < nri ? rp[row_first + i + 1] : 0;
+    }
+    for (uint32_t j = tid; j < n; j += kSegThreads) mark[j] = 0;
+    for (uint32_t p = 0; p < phases; p++) hist[p * kSegThreads + tid] = 0;
+    __syncthreads();
+    // rows: the first element of a row is marked with the row; empty rows are counted (inside the window of 64 rows; the windows' sums follow)
+    for (uint32_t u0 = wv; u0 < RW; u0 += kWaves * kBatch) {
+        if (u0 != wv) {
+#pragma unroll
+            for (uint32_t t = 0; t < kBatch; t++) {
+                const uint32_t i = (u0 + t * kWaves) * 64 + lane;
+                ra[t] = i < nri ? rp[row_first + i] : 0;
+                rz[t] = i < nri ? rp[row_first + i + 1] : 0;
+            }
         }
 #pragma unroll
         for (uint32_t t = 0; t < kBatch; t++) {
@@ -556,10 +569,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_scan_kernel(const int64_t *__
             if (u >= RW) break;
             bool empty = false;
             if (i < nri) {
-                int64_t a = ra[t] > b ? ra[t] : b, z = rz[t] < e ? rz[t] : e;
-                if (z < a) z = a;
-                pa[i] = (uint32_t)(a - b); pz[i] = (uint32_t)(z - b);
+                const int64_t a = ra[t] > b ? ra[t] : b, z = rz[t] < e ? rz[t] : e;
                 empty = z <= a;
+                if (!empty) mark[(uint32_t)(a - b)] = (uint16_t)(i + 1);
             }
             const unsigned long long m = __ballot(empty);
             if (i < nri) E[i] = (uint16_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -567,15 +579,14 @@ __global__ __launch_bounds__(kSegThreads) void seg_scan_kernel(const int64_t *__
         }
     }
 #pragma unroll
-    for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = tid + t * kSegThreads; if (j < n) { cols[j] = c0[t]; mark[j] = 0; } }
+    for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = tid + t * kSegThreads; if (j < n) cols[j] = c0[t]; }
     for (uint32_t j0 = tid + kSegThreads * kBatch; j0 < n; j0 += kSegThreads * kBatch) {
         int32_t c[kBatch];
 #pragma unroll
         for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = j0 + t * kSegThreads; c[t] = j < n ? cidx[b + j] : 0; }
 #pragma unroll
-        for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = j0 + t * kSegThreads; if (j < n) { cols[j] = c[t]; mark[j] = 0; } }
+        for (uint32_t t = 0; t < kBatch; t++) { const uint32_t j = j0 + t * kSegThreads; if (j < n) cols[j] = c[t]; }
     }
-    for (uint32_t p = 0; p < phases; p++) hist[p * kSegThreads + tid] = 0;
     __syncthreads();
     SEG_CLOCK(1);
     if (wv == 0) {          // empty rows in front of every row window
@@ -587,8 +598,6 @@ __global__ __launch_bounds__(kSegThreads) void seg_scan_kernel(const int64_t *__
         }
         if (lane == 0) etotal = carry;
     }
-    for (uint32_t i = tid; i < nri; i += kSegThreads) if (pz[i] > pa[i]) mark[pa[i]] = (uint16_t)(i + 1);
-    __syncthreads();
     SEG_CLOCK(2);
     // walk 1
     const uint32_t j0 = tid * L, j1 = min(n, j0 + L);
@@ -669,24 +678,28 @@ __global__ __launch_bounds__(kSegThreads) void seg_scan_kernel(const int64_t *__
     __syncthreads();
     SEG_CLOCK(5);
     // empty rows: behind the phase-0 pieces in front of their position and the empty rows in front of them
-    for (uint32_t i = tid; i < nri; i += kSegThreads) {
-        const uint32_t a = pa[i];
-        if (pz[i] > a) continue;
-        // (hist has moved on to the END of every thread's pieces of a phase: the pieces of phase 0 in front of position a are those
-        // of the threads in front of its run -- the start of that thread's range = the end of its predecessor's -- and z0)
-        uint32_t before;
-        if (a >= n) before = hist[(size_t)kSegThreads - 1];
-        else { const uint32_t t = a / L; before = (t ? hist[t - 1] : 0u) + z0[a]; }
-        packed[sbase + before + epre[i >> 6] + E[i]] = uint2{0xffffu | (1u << 16), i};
-    }
+    // (hist has moved on to the END of every thread's pieces of a phase: the pieces of phase 0 in front of position a are those
+    // of the threads in front of its run -- the start of that thread's range = the end of its predecessor's -- and z0)
+    if (et > 0)
+        for (uint32_t i = tid; i < nri; i += kSegThreads) {
+            int64_t a, z;
+            row_piece(rp, row_first + i, b, e, a, z);
+            if (z > a) continue;
+            const uint32_t at = (uint32_t)(a - b);
+            uint32_t       before;
+            if (at >= n) before = hist[(size_t)kSegThreads - 1];
+            else { const uint32_t t = at / L; before = (t ? hist[t - 1] : 0u) + z0[at]; }
+            packed[sbase + before + epre[i >> 6] + E[i]] = uint2{0xffffu | (1u << 16), i};
+        }
     if (padc > 0 && tid == 0) packed[sbase + stotal - 1] = uint2{0xffffu | (padc << 16), nri};
     SEG_CLOCK(6);
 #undef SEG_CLOCK
 }
 
 // sum of the chunks' segment counts (cvr_info.nsegments), one workgroup
-__global__ __launch_bounds__(1024) void seg_total_kernel(uint32_t *__restrict__ cnt, uint32_t nchunks)
+__global__ __launch_bounds__(1024) void seg_total_kernel(uint32_t *__restrict__ cnt, uint32_t nchunks, const uint32_t *__restrict__ nchunks_dev, uint32_t *__restrict__ total_out)
 {
+    if (nchunks_dev) nchunks = *nchunks_dev;
     __shared__ uint32_t part[16];
     uint32_t s = 0;
     for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) s += cnt[i];
@@ -694,7 +707,7 @@ __global__ __launch_bounds__(1024) void seg_total_kernel(uint32_t *__restrict__ 
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 16; w++) t += part[w]; cnt[nchunks] = t; }
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < 16; w++) t += part[w]; *total_out = t; }
 }
 
 // Window choice for the SpMV kernel's LDS staging of x: one workgroup per SpMV workgroup (wpb
@@ -702,8 +715,10 @@ __global__ __launch_bounds__(1024) void seg_total_kernel(uint32_t *__restrict__ 
 // columns in LDS, then the best run of `nb` consecutive bins; ties go to the lowest column.
 __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__ cidx, const int64_t *__restrict__ nzb,
                                                       uint32_t nchunks, uint32_t ncols1, uint32_t wn, uint32_t binshift,
-                                                      uint32_t nbins, uint32_t nb, uint32_t *__restrict__ win_base, uint32_t wpb)
+                                                      uint32_t nbins, uint32_t nb, uint32_t *__restrict__ win_base, uint32_t wpb, const uint32_t *__restrict__ nchunks_dev)
 {
+    if (nchunks_dev) nchunks = *nchunks_dev;
+    if (blockIdx.x * wpb >= nchunks) return;
     extern __shared__ uint32_t hist[];                       // [nbins + nb] then one u64 for the arg-max
     unsigned long long *best = reinterpret_cast<unsigned long long *>(hist + ((nbins + nb + 1) & ~1u));
     const uint32_t c0 = blockIdx.x * wpb;
@@ -949,13 +964,21 @@ static size_t seg_lds_bytes(const DeviceImage &img) { return 8 * (size_t)img.yst
 // LDS of seg_scan_kernel for a chunk of `cap` elements and at most ystage - 1 rows (0: such chunks do not fit, seg_build_kernel takes them)
 static size_t seg_scan_lds_bytes(const DeviceImage &img)
 {
-    const size_t cap = (size_t)kLanes * img.S, ys = img.ystage;
+    const size_t cap = (size_t)kLanes * img.S;
     if (cap > (size_t)kSegRunMax * kSegThreads || img.phases > 64) return 0;
-    const size_t bytes = 8 * ys + 4 * (ys / 64 + 2) + 4 * cap + 2 * (size_t)img.phases * kSegThreads + 2 * ys + 2 * cap + cap + cap + 64;
+    const size_t bytes = 4 * (cap / 64 + 2) + 4 * cap + 2 * (size_t)img.phases * kSegThreads + 2 * cap + 2 * cap + cap + cap + 64;
     return bytes <= kLdsBytes - 1024 ? bytes : 0;
 }
 
-hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s)
+bool seg_table_packed_ok(const DeviceImage &img) { return seg_scan_lds_bytes(img) != 0 && !getenv("CVR_SEG_BY_ROWS"); }
+
+hipError_t launch_seg_total(const SegTable &st, uint32_t nchunks, const uint32_t *nchunks_dev, uint32_t *total_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, nchunks, nchunks_dev, total_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s, const uint32_t *nchunks_dev, bool with_total)
 {
     if (img.nchunks == 0) return hipSuccess;
     static const bool by_rows = getenv("CVR_SEG_BY_ROWS") != nullptr;      // (diagnostics: the search-based kernel)
@@ -964,7 +987,7 @@ hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTab
         if (getenv("CVR_SEG_CLOCKS") && hipMalloc(&dbg, sizeof(unsigned long long) * 16 * 64) != hipSuccess) dbg = nullptr;
         if (dbg) fprintf(stderr, "[seg_scan] %u chunks, S %d, %u phases, ystage %u, LDS %zu bytes per workgroup\n", img.nchunks, img.S, img.phases, img.ystage, lds);
         hipLaunchKernelGGL(seg_scan_kernel, dim3(img.nchunks), dim3(kSegThreads), lds, s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc, img.desc2,
-                           img.nchunks, (const uint32_t *)nullptr, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, reinterpret_cast<uint2 *>(st.begin), st.flags,
+                           img.nchunks, nchunks_dev, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, reinterpret_cast<uint2 *>(st.begin), st.flags,
                            img.piece_max ? (uint32_t)__builtin_ctz(img.piece_max) : 31u, dbg);
         st.packed = true;
         if (dbg) {          // CVR_SEG_CLOCKS: 100-MHz time stamps of every 256th workgroup's stages, on stderr
@@ -980,17 +1003,17 @@ hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTab
             }
             (void)hipFree(dbg);
         }
-        hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.nchunks);
+        if (with_total) hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.nchunks, nchunks_dev, st.cnt + img.nchunks);
         return hipGetLastError();
     }
     st.packed = false;
     hipLaunchKernelGGL(seg_build_kernel, dim3(img.nchunks), dim3(kLanes * kSegWaves), seg_lds_bytes(img), s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc,
                        img.desc2, img.nchunks, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, st.begin, st.len, st.row, st.flags, seg_lds_cols(img), img.piece_max ? (uint32_t)__builtin_ctz(img.piece_max) : 31u);      // (piece_max is a power of two: cvr_layout)
-    hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.nchunks);
+    if (with_total) hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1024), 0, s, st.cnt, img.nchunks, nchunks_dev, st.cnt + img.nchunks);
     return hipGetLastError();
 }
 
-hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg)
+hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg, const uint32_t *nchunks_dev)
 {
     if (img.nchunks == 0) return hipSuccess;
     const uint32_t blocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -1005,7 +1028,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 #define CVR_CONVERT_ARGS(T)                                                                                            \
     csr.row_ptr, csr.col_idx, static_cast<const T *>(csr.vals), csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col, \
     static_cast<const T *>(img.dict), img.ndict, img.desc2, seg ? seg->begin : nullptr, seg ? seg->len : nullptr, seg ? seg->row : nullptr, img.col_bits,           \
-    seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase, img.hub_n, (uint32_t)per, seg && seg->packed ? 1u : 0u
+    seg ? seg->flags : nullptr, img.hub_n ? img.hub_index : nullptr, img.hub_bitmap, img.cbase, img.hub_n, (uint32_t)per, seg && seg->packed ? 1u : 0u, nchunks_dev
 #define CVR_CONVERT(T, DI, SG, SM)                                                                                     \
     do {                                                                                                               \
         if (SG && img.tag16) hipLaunchKernelGGL((convert_kernel<T, DI, SG, false, SM, SG>), grid, block, lds, st, CVR_CONVERT_ARGS(T)); \
@@ -1017,11 +1040,11 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
         if (img.f32) hipLaunchKernelGGL((convert_kernel<float, false, false, true, false>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const float *>(csr.vals),
                                         csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
                                         (const float *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
-                                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u, 0u);
+                                        (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u, 0u, nchunks_dev);
         else hipLaunchKernelGGL((convert_kernel<double, false, false, true, false>), grid, block, 0, st, csr.row_ptr, csr.col_idx, static_cast<const double *>(csr.vals),
                                 csr.nz_begin, csr.pad_cnt, img.desc, img.stream, img.target, err_flag, img.G, img.nchunks, img.pad_col,
                                 (const double *)nullptr, 0u, img.desc2, (const int64_t *)nullptr, (const uint32_t *)nullptr, (const uint16_t *)nullptr, img.col_bits,
-                                (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u, 0u);
+                                (const uint32_t *)nullptr, (const int32_t *)nullptr, (const uint32_t *)nullptr, img.cbase, 0u, 0u, 0u, nchunks_dev);
         return hipGetLastError();
     }
     if (img.f32) { if (img.dict) CVR_CONVERT_SG(float, true); else CVR_CONVERT_SG(float, false); }
@@ -1037,7 +1060,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 
 namespace cvr {
 
-hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st)
+hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st, const uint32_t *nchunks_dev)
 {
     if (img.nchunks == 0 || img.win_elems == 0) return hipSuccess;
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;
@@ -1051,7 +1074,7 @@ hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream
     if (nb == 0) nb = 1;
     const size_t lds = sizeof(uint32_t) * ((size_t)((nbins + nb + 1) & ~1u)) + 16;
     hipLaunchKernelGGL(window_kernel, dim3(blocks), dim3(256), lds, st, csr.col_idx, csr.nz_begin, img.nchunks, ncols1,
-                       img.win_elems, binshift, nbins, nb, img.win_base, wpb);
+                       img.win_elems, binshift, nbins, nb, img.win_base, wpb, nchunks_dev);
     return hipGetLastError();
 }
 

@@ -162,6 +162,7 @@ struct cvr_handle {
 
     void  *seg_arena = nullptr;          // column phases: the conversion-time segment table, allocated by cvr_create (with the other buffers), released by cvr_preprocess
     size_t seg_arena_bytes = 0;
+    bool   preconverted = false;         // cvr_create converted the image already (cvr_fused.hip): the first cvr_preprocess has nothing left to do
     IOpt opt_used;                       // the options the handle was created with (the image cache keys on them: cvr_image_io.hip)
 
     bool paneled() const { return parts.size() > 1; }
@@ -214,6 +215,12 @@ constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24
 constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer
 int        pick_steps(int64_t nslots_est, int64_t max_row = 0, double cus = 256.0);
 hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr = nullptr);
+int64_t    plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt);
+bool       resident_candidate(double slots, int cus, int *best_w, int *best_S);
+int        setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, int64_t nchunks, int64_t nshared, const IOpt &opt, const IOpt &popt);
+// cvr_fused.hip: analysis, plan and conversion of a single resident-layout image as one submission (no host round trip between planner
+// and converter); *taken = false: the matrix is not of that kind (or the layout was not confirmed) and the staged path takes over
+int        build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, const IOpt &opt, IOpt &popt, bool *taken);
 hipStream_t side_stream(int device, int which = 0);      // two streams per device beside the handles' own (analysis passes side by side)
 hipError_t acquire_stream(int device, hipStream_t *out);
 void       release_stream(int device, hipStream_t s);

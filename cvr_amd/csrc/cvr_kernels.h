@@ -83,11 +83,15 @@ struct SegTable {
 };
 // the segment table of every chunk (one workgroup each: counts per phase, then (begin, length, row) in (phase, row) order); writes
 // desc[k].y = segments of chunk k, desc2[k].x = where they start, st.cnt, st.flags
-hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t st_);
+// (nchunks_dev, here and below: the number of chunks is read on the device -- a plan that has not come back to the host -- and
+// img.nchunks is the room the launch is made for)
+hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t st_, const uint32_t *nchunks_dev = nullptr, bool with_total = true);
+hipError_t launch_seg_total(const SegTable &st, uint32_t nchunks, const uint32_t *nchunks_dev, uint32_t *total_out, hipStream_t s);      // *total_out = sum of st.cnt
+bool       seg_table_packed_ok(const DeviceImage &img);      // launch_seg_build will write packed entries (st.len / st.row are not needed)
 
 // CSR -> CVR64 (one wavefront per chunk).  *err_flag (device u32, zeroed by the caller) gets bit 0 if a
 // lane stream did not drain, bit 1 if stealing found no over-full lane, bit 2 if a value is missing from the dictionary.
-hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg = nullptr);
+hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg = nullptr, const uint32_t *nchunks_dev = nullptr);
 
 // value-dictionary detection over vals[n0, n1) on the device: `table` = 1024 u64 slots preset to all ones, flags[0] bit 0 =
 // more than kDictMax distinct values, bit 1 = the all-ones pattern occurs, flags[1] = entries in the table
@@ -116,6 +120,21 @@ bool       plan_on_device_ok(int32_t S);
 // scratch the caller may keep across calls: device bytes (grown on demand) and a pinned host buffer for the records coming back
 struct PlanScratch { uint8_t *dev = nullptr; size_t dev_bytes = 0; uint8_t *pinned = nullptr; size_t pinned_bytes = 0; };
 void       free_plan_scratch(PlanScratch &ws);
+// the planner's kernels enqueued without a synchronisation (cvr_fused.hip): the records stay on the device
+struct DevicePlan {
+    bool        declined = false;
+    int64_t     bound = 0, thr = 0, max_rows = 0;       // room of the record arrays; the threshold and row cap in effect
+    const void *chunks = nullptr;                       // [bound] cvr::Chunk records
+    const void *shared = nullptr;                       // [bound] cvr::Shared records
+    const unsigned long long *totals = nullptr;         // [4] chunks, cut rows, flags (1: host must plan, 2: tables too small), most rows in a chunk
+    bool        chunks_shared_adjacent = false;
+};
+struct PlanTables {
+    uint4 *desc = nullptr; uint2 *desc2 = nullptr; uint32_t *pad = nullptr; int64_t *nzb = nullptr; uint32_t room = 0; bool phased = false;
+    unsigned long long *totals = nullptr;      // where the four totals go (null: the planner's scratch)
+};
+hipError_t plan_chunks_device_enqueue(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, hipStream_t st, PlanScratch *ws,
+                                      DevicePlan *out, const PlanTables *tables);
 hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, Plan *out, bool *fallback,
                               hipStream_t st, PlanScratch *ws = nullptr);
 hipError_t max_row_device(const int64_t *rp_dev, int64_t nrows, int64_t *out, hipStream_t st);
@@ -152,7 +171,7 @@ hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, 
 
 // picks, per workgroup of img.wpb chunks, the window of img.win_elems consecutive columns that holds most
 // of its non-zeros (LDS histogram over coarse column bins); writes img.win_base
-hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st);
+hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st, const uint32_t *nchunks_dev = nullptr);
 
 // column panels, one panel per XCD at a time: what differs between the eight panels of one launch (device array of 8; nchunks = 0: none)
 struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *target; void *yext; uint32_t nchunks, ystage; const uint2 *desc2; };

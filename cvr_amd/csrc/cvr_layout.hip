@@ -24,19 +24,10 @@ int pick_steps(int64_t nslots_est, int64_t max_row, double cus)
     return S;
 }
 
-hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr)
+// The workgroup shape and LDS budget of an image with chunk length pp.S (set by the caller): wavefronts per workgroup, column phases,
+// x window, row-tag width, row accumulators.  Returns the cap on the rows of a chunk the planner has to keep (0 = none).
+int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
 {
-    const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
-    pp.S = opt.steps_per_chunk;
-    if (pp.S == 0) {
-        int64_t max_row = 0;
-        const double cus = opt.panel_on_one_xcd ? (double)opt.cus / opt.xcds : (double)opt.cus;
-        if ((double)(nz1 - nz0 + nrows / 4) / (64.0 * 32.0) <= cus * 12.0) {    // (only where the rule weighs single launches)
-            if (rp) for (int64_t r = 0; r < nrows; r++) max_row = std::max(max_row, rp[r + 1] - rp[r]);
-            else { const hipError_t e = cvr::max_row_device(dr->rp, nrows, &max_row, dr->st); if (e != hipSuccess) return e; }
-        }
-        pp.S = pick_steps(nz1 - nz0 + nrows / 4, max_row, cus);
-    }
     // Wavefronts (consecutive chunks) per SpMV workgroup: 1 by default; more only pay together with an LDS window of x,
     // which the workgroup's chunks then share (profiles/r02_wg_window_sweep.log).
     pp.wpb = std::min(std::max(opt.waves_per_block, 1), cvr::kMaxWavesPerBlock);
@@ -69,6 +60,23 @@ hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const
         if (pp.stage < 64) { pp.lds_short = true; pp.phases = 1; pp.stage = 64; }
         else max_rows = pp.stage - 1;                 // + the dump entry of the pad segment
     }
+    return max_rows;
+}
+
+hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr)
+{
+    const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
+    pp.S = opt.steps_per_chunk;
+    if (pp.S == 0) {
+        int64_t max_row = 0;
+        const double cus = opt.panel_on_one_xcd ? (double)opt.cus / opt.xcds : (double)opt.cus;
+        if ((double)(nz1 - nz0 + nrows / 4) / (64.0 * 32.0) <= cus * 12.0) {    // (only where the rule weighs single launches)
+            if (rp) for (int64_t r = 0; r < nrows; r++) max_row = std::max(max_row, rp[r + 1] - rp[r]);
+            else { const hipError_t e = cvr::max_row_device(dr->rp, nrows, &max_row, dr->st); if (e != hipSuccess) return e; }
+        }
+        pp.S = pick_steps(nz1 - nz0 + nrows / 4, max_row, cus);
+    }
+    const int64_t max_rows = plan_layout(pp, ncols, f32, opt);
     if (rp) {
         pp.plan = cvr::plan_chunks(nrows, rp, pp.S, opt.split_threshold, max_rows, pp.plan_threads);
     } else {
@@ -123,7 +131,7 @@ hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const
         // most segments, so every chunk writes its y coalesced (chunks of very short rows beyond the stage store directly);
         // the window takes what it asked for, the stage at least 64 rows per wavefront, and whatever does not fit is cut:
         // first the stage down to 512 rows per wavefront, then the window.
-        const int64_t total = (int64_t)cvr::kLdsBytes / vs;
+        const int64_t vs = f32 ? 4 : 8, total = (int64_t)cvr::kLdsBytes / vs;
         const int64_t fixed = (int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + 4 + ((pp.hub_n + 3) & ~(int64_t)3);     // dictionary room is reserved before it is known
         int64_t stage = std::min<int64_t>(std::max<int64_t>((pp.max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
         if (const char *cap = getenv("CVR_YSTAGE_CAP")) stage = std::min<int64_t>(stage, std::max<int64_t>(64, atoll(cap) & ~(int64_t)63));      // (experiments: occupancy against staged write-out)
@@ -196,6 +204,21 @@ hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64
     return e;
 }
 
+// the resident layout's candidates: 8, 7 or 6 chunks per workgroup with the smallest S that keeps the workgroups a few under the CU
+// count; the one that fills the CUs best wins (ties: more waves).  false: tiny shards and matrices beyond one resident pass
+bool resident_candidate(double slots, int cus, int *best_w, int *best_S)
+{
+    *best_w = 0; *best_S = 0;
+    double best_fill = 0;
+    for (int w = 8; w >= 6; w--) {
+        int S = (int)std::ceil(slots / (64.0 * w * (double)(cus - 4)) / 4.0) * 4;
+        if (S < 24 || S > 128) continue;
+        const double wgs = std::ceil(slots / (64.0 * w * S));
+        if (wgs > best_fill) { best_fill = wgs; *best_w = w; *best_S = S; }
+    }
+    return *best_w != 0;
+}
+
 // The automatic layout (every layout option left at its default; one image, no column panels).  Matrices small enough
 // for all their chunks to be resident at once -- 6 to 8 chunks per workgroup, one workgroup per CU -- run in the "resident"
 // layout when it pays: the workgroup's chunks share an LDS window of x if a sizeable share of the non-zeros lies near the
@@ -214,16 +237,8 @@ int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f3
     if (nrows < 4096 || ncols < 4096) return CVR_OK;
     const int64_t vs = f32 ? 4 : 8;
     const double  slots = ((double)nnz + (double)nrows / 4) * 1.006;      // pad slots of empty rows, chunk tails
-    // candidates: 8, 7 or 6 chunks per workgroup with the smallest S that keeps the workgroups a few under the CU count; the one
-    // that fills the CUs best wins (ties: more waves)
     int best_w = 0, best_S = 0;
-    double best_fill = 0;
-    for (int w = 8; w >= 6; w--) {
-        int S = (int)std::ceil(slots / (64.0 * w * (double)(opt.cus - 4)) / 4.0) * 4;
-        if (S < 24 || S > 128) continue;                       // tiny shards and matrices beyond one resident pass keep the plain layout
-        const double wgs = std::ceil(slots / (64.0 * w * S));
-        if (wgs > best_fill) { best_fill = wgs; best_w = w; best_S = S; }
-    }
+    resident_candidate(slots, opt.cus, &best_w, &best_S);
     if (!best_w) return CVR_OK;
     // 96 KiB of x per workgroup: the gathers that stay outside the window are what loads the L2s (one request per gather, an XCD's
     // L2 takes ~16 per clock: profiles/r03_gather_rate_ubench.log), so the window takes what the row accumulators leave
@@ -322,6 +337,45 @@ int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, i
     return CVR_OK;
 }
 
+// the fields of the device image that follow from the layout (not the per-chunk tables): shared by build_part and the fused path
+int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, int64_t nchunks, int64_t nshared, const IOpt &opt, const IOpt &popt)
+{
+    const int S = pp.S;
+    const int G = S / 4;
+    cvr::DeviceImage &img = part.img;
+    img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
+    img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)nshared;
+    img.xcd_swizzle = opt.xcds != 8 ? 0 : opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
+    img.ncus = (uint32_t)opt.cus;
+    img.stream_ahead = opt.stream_ahead >= 2 ? 3 : 1;
+    img.depth = opt.gather_depth == 2 ? 2 : 1;
+    img.wpb = (uint32_t)pp.wpb;
+    img.ystage = (uint32_t)pp.stage;
+    img.phases = (uint32_t)pp.phases;
+    if (pp.phases > 1) {
+        const int64_t pw = ((ncols + pp.phases - 1) / pp.phases + 15) / 16 * 16;
+        img.phase_width = (uint32_t)std::max<int64_t>(pw, 16);
+        img.col_bits = (uint32_t)pp.col_bits;
+        img.tag16 = pp.tag16;
+        // pieces: a lane that sits on a long row's segment falls behind the column ranges the other lanes have moved on to; with
+        // chunks longer than a few steps per phase the segments are cut (auto: 8 elements once a phase takes 8 steps or more)
+        if (S / pp.phases >= 8 && !opt.panel_on_one_xcd && !getenv("CVR_NO_PACE")) {      // long chunks: the SpMV kernel paces its wavefronts through the phases
+            HIP_TRY(hipMalloc(&img.pace, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases)));
+            HIP_TRY(hipMemsetAsync(img.pace, 0, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases), h->stream));
+            img.pace_epoch = new uint32_t(0);
+        }
+        // (a power of two, rounded down: the segment-table kernel cuts with shifts)
+        img.piece_max = opt.piece_max > 0 ? 1u << (31 - __builtin_clz((uint32_t)opt.piece_max)) : opt.piece_max < 0 && S / pp.phases >= 8 && !opt.panel_on_one_xcd ? 8u : 0u;
+        img.col_mask = pp.tag16 ? cvr::kColMask : (1u << pp.col_bits) - 1u;
+    }
+    if (popt.col_phases > 1 && pp.lds_short && !popt.layout_auto_resident) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
+    const int64_t win = pp.win;
+    img.win_elems = (uint32_t)win;
+    if (opt.debug_col_mask) img.col_mask &= (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
+
+    return CVR_OK;
+}
+
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
 // (rp == nullptr: part.d_rp is already in place -- the row pointers of a column panel split on the device -- and `dr` describes it)
 int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
@@ -341,6 +395,11 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
     }
     PartPlan    local;
     IOpt        popt = opt;
+    if (!planned && rp && !dr && nrows > 0) {      // a whole matrix: analysis, plan and conversion as one submission where the resident layout applies
+        bool       taken = false;
+        const int  rc = build_part_fused(h, part, nrows, ncols, f32, nz0, nz1, opt, popt, &taken);
+        if (rc || taken) return rc;
+    }
     if (!planned) {
         // (the planner's records come back behind the first kPinnedSmall bytes of the pinned buffer: those belong to the probe and the
         // dictionary scan, which now run at the same time)
@@ -386,45 +445,17 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
     }
     PartPlan &pp = *planned;
     if (pp.too_large) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
-    const int        S = pp.S;
     const cvr::Plan &plan = pp.plan;
     const int64_t    nchunks = (int64_t)plan.chunks.size(), yext = pp.yext;
     const std::vector<uint32_t> &desc = pp.desc, &pad = pp.pad;
     const std::vector<int64_t>  &nzb = pp.nzb;
 
     part.nrows = nrows; part.nnz = nz1 - nz0; part.nnz_span = nz1; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
-    const int G = S / 4;
-    cvr::DeviceImage &img = part.img;
-    img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
-    img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)plan.shared.size();
-    img.xcd_swizzle = opt.xcds != 8 ? 0 : opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
-    img.ncus = (uint32_t)opt.cus;
-    img.stream_ahead = opt.stream_ahead >= 2 ? 3 : 1;
-    img.depth = opt.gather_depth == 2 ? 2 : 1;
-    img.wpb = (uint32_t)pp.wpb;
-    img.ystage = (uint32_t)pp.stage;
-    img.phases = (uint32_t)pp.phases;
-    if (pp.phases > 1) {
-        const int64_t pw = ((ncols + pp.phases - 1) / pp.phases + 15) / 16 * 16;
-        img.phase_width = (uint32_t)std::max<int64_t>(pw, 16);
-        img.col_bits = (uint32_t)pp.col_bits;
-        img.tag16 = pp.tag16;
-        // pieces: a lane that sits on a long row's segment falls behind the column ranges the other lanes have moved on to; with
-        // chunks longer than a few steps per phase the segments are cut (auto: 8 elements once a phase takes 8 steps or more)
-        if (S / pp.phases >= 8 && !opt.panel_on_one_xcd && !getenv("CVR_NO_PACE")) {      // long chunks: the SpMV kernel paces its wavefronts through the phases
-            HIP_TRY(hipMalloc(&img.pace, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases)));
-            HIP_TRY(hipMemsetAsync(img.pace, 0, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases), h->stream));
-            img.pace_epoch = new uint32_t(0);
-        }
-        // (a power of two, rounded down: the segment-table kernel cuts with shifts)
-        img.piece_max = opt.piece_max > 0 ? 1u << (31 - __builtin_clz((uint32_t)opt.piece_max)) : opt.piece_max < 0 && S / pp.phases >= 8 && !opt.panel_on_one_xcd ? 8u : 0u;
-        img.col_mask = pp.tag16 ? cvr::kColMask : (1u << pp.col_bits) - 1u;
+    {
+        const int rc = setup_image(h, part, pp, nrows, ncols, f32, nchunks, (int64_t)plan.shared.size(), opt, popt);
+        if (rc) return rc;
     }
-    if (popt.col_phases > 1 && pp.lds_short && !popt.layout_auto_resident) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
-    const int64_t win = pp.win;
-    img.win_elems = (uint32_t)win;
-    if (opt.debug_col_mask) img.col_mask &= (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
-
+    cvr::DeviceImage &img = part.img;
     HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nchunks + 1)));
     HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nchunks, 1)));
     HIP_TRY(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));

@@ -49,7 +49,15 @@ struct PlanArgs {
     uint32_t        *counts;                           // [2 * nblocks]: chunks, cut rows per block
     ChunkRec        *chunks;                           // [bound]
     Shared          *shared;                           // [bound]
-    unsigned long long *totals;                        // chunks, cut rows, flags (1: a block holds 2^31 slots or more)
+    unsigned long long *totals;                        // chunks, cut rows, flags (1: a block holds 2^31 slots or more), most rows in a chunk
+    // optional (cvr_fused.hip): the per-chunk tables of the image written straight from the plan (what plan_part derives on the host)
+    uint4           *odesc;                            // [room] {row_first, nseg, head_dest, last_dest}
+    uint2           *odesc2;                           // [room] {0, rows}
+    uint32_t        *opad;                             // [room]
+    long long       *onzb;                             // [room + 1]
+    uint32_t         oroom;                            // chunks the tables have room for (more: totals[2] |= 2)
+    uint32_t         ophased;                          // last_dest = that of the last ROW (column phases) instead of the last segment
+    long long        nz_end;
 };
 
 __device__ inline uint32_t rows_of(const PlanArgs &a, uint32_t b) { return (uint32_t)min((long long)kPlanRowBlock, a.nrows - (long long)b * kPlanRowBlock); }
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(256) void emit_kernel(PlanArgs a)
     const Start    *st = a.starts + room;
     const uint32_t *Q = a.Q + qbase(b);
     const long long r0 = (long long)b * kPlanRowBlock;
+    uint32_t        most = 0;
     for (uint32_t i = threadIdx.x; i < count; i += 256) {
         const Start     s = st[i];
         const Start     n = i + 1 < count ? st[i + 1] : Start{(uint32_t)(r0 + nb), 0u, 0u};
@@ -223,6 +232,21 @@ __global__ __launch_bounds__(256) void emit_kernel(PlanArgs a)
         c.nseg = c.nrows_in + (c.pad_cnt > 0 ? 1 : 0);
         for (int f = 0; f < 6; f++) c.fill[f] = 0;
         a.chunks[(size_t)kb + i] = c;
+        most = max(most, (uint32_t)c.nrows_in);
+        if (a.odesc && kb + i < a.oroom) {
+            const uint32_t kk = kb + i, nr = (uint32_t)a.nrows;
+            // where segment q writes: a row begun earlier -> carry_head(k); a row continued later -> carry_tail(k); the pad segment -> dump
+            auto dest = [&](long long q) -> uint32_t {
+                if (q >= c.nrows_in) return nr;
+                if (q == 0 && c.head_shared) return nr + 1u + 2u * kk;
+                if (q == c.nrows_in - 1 && c.tail_shared) return nr + 1u + 2u * kk + 1u;
+                return (uint32_t)(c.row_first + q);
+            };
+            a.odesc[kk] = uint4{(uint32_t)c.row_first, (uint32_t)c.nseg, dest(0), dest(a.ophased ? c.nrows_in - 1 : c.nseg - 1)};
+            a.odesc2[kk] = uint2{0u, (uint32_t)c.nrows_in};
+            a.opad[kk] = (uint32_t)c.pad_cnt;
+            a.onzb[kk] = c.nz_begin;
+        }
         // a row whose first piece ends this chunk: it ends in the chunk behind those it fills completely
         if (c.tail_shared && !(c.head_shared && last == (long long)s.row)) {
             const uint32_t rem = Q[ln + 1] - Q[ln] - n.off;
@@ -230,7 +254,17 @@ __global__ __launch_bounds__(256) void emit_kernel(PlanArgs a)
             a.shared[(size_t)sb + s.open] = Shared{(int64_t)n.row, (int64_t)kb + i, (int64_t)kb + i + 1 + middle};
         }
     }
-    if (b + 1 == gridDim.x && threadIdx.x == 0) { a.totals[0] = (unsigned long long)kb + count; a.totals[1] = (unsigned long long)sb + a.counts[2 * b + 1]; }
+    if (b + 1 == gridDim.x && threadIdx.x == 0) {
+        a.totals[0] = (unsigned long long)kb + count; a.totals[1] = (unsigned long long)sb + a.counts[2 * b + 1];
+        if (a.odesc) {
+            if (kb + count <= a.oroom) a.onzb[kb + count] = a.nz_end;
+            else atomicOr(a.totals + 2, 2ull);
+        }
+    }
+    if (a.odesc) {          // the most rows any chunk holds (sizes the SpMV kernel's row accumulators)
+        for (int o = 32; o > 0; o >>= 1) most = max(most, (uint32_t)__shfl_down(most, o));
+        if (lane == 0 && most) atomicMax(a.totals + 3, (unsigned long long)most);
+    }
 }
 
 __global__ __launch_bounds__(256) void max_row_kernel(const long long *__restrict__ rp, long long nrows, unsigned long long *__restrict__ out)
@@ -267,36 +301,29 @@ __global__ __launch_bounds__(256) void block_off_kernel(const uint32_t *__restri
 
 bool plan_on_device_ok(int32_t S) { return (int64_t)kLanes * S < (int64_t)kJumpCut; }
 
-// The plan of plan_chunks(nrows, rp, S, thr, max_rows), from a row_ptr in device memory.  *fallback is set (and nothing else
-// done) when a row block holds 2^31 slots or more -- the caller then plans on the host.  One stream synchronisation for the
-// counts, one for the records.
-hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, Plan *out, bool *fallback,
-                              hipStream_t st, PlanScratch *ws)
+// Enqueues the planner's kernels on `st` (no synchronisation, nothing copied back): chunk records, cut rows and totals stay in
+// the scratch `ws` (grown if needed) at the pointers of `out`; `tables` (optional) are written by the last kernel.
+// out->declined: the plan cannot be made on the device (chunk length beyond the jump table); nothing was enqueued.
+hipError_t plan_chunks_device_enqueue(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, hipStream_t st, PlanScratch *ws,
+                                      DevicePlan *out, const PlanTables *tables)
 {
-    *fallback = false;
-    Plan &p = *out;
-    p = Plan();
-    p.S = S;
+    *out = DevicePlan();
     const int64_t cap = (int64_t)kLanes * S;
     if (thr <= 0) thr = cap / 4;
     if (thr > cap / 2) thr = cap / 2;
-    p.thr = thr;
     if (max_rows <= 0) max_rows = INT64_MAX;
-    p.max_rows = max_rows == INT64_MAX ? 0 : max_rows;
-    p.nz_end = nz_end;
+    out->thr = thr;
+    out->max_rows = max_rows == INT64_MAX ? 0 : max_rows;
     if (nrows <= 0) return hipSuccess;
-    if (!plan_on_device_ok(S)) { *fallback = true; return hipSuccess; }
+    if (!plan_on_device_ok(S)) { out->declined = true; return hipSuccess; }
     const int64_t nblocks = (nrows + kPlanRowBlock - 1) / kPlanRowBlock, ntiles = (nrows + kTileRows - 1) / kTileRows;
     // slots <= nnz + nrows; the sum of the blocks' rooms (bound_of)
     const int64_t slots_ub = nz_end + nrows;        // (rp[0] >= 0)
-    const int64_t bound = 2 * (slots_ub / cap) + (p.max_rows ? nrows / p.max_rows : 0) + 3 * nblocks;
+    const int64_t bound = 2 * (slots_ub / cap) + (out->max_rows ? nrows / out->max_rows : 0) + 3 * nblocks;
     auto          up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t  o_tile = 0, o_q = o_tile + up(4 * (size_t)ntiles), o_j = o_q + up(4 * (size_t)(nrows + nblocks)),
                   o_st = o_j + up(2 * (size_t)nrows), o_cnt = o_st + up(sizeof(Start) * (size_t)bound), o_ch = o_cnt + up(8 * (size_t)nblocks),
                   o_sh = o_ch + up(sizeof(ChunkRec) * (size_t)bound), o_tot = o_sh + up(sizeof(Shared) * (size_t)bound), total = o_tot + 256;
-    // device scratch: the caller's (kept across the images of one cvr_create) or one of our own
-    PlanScratch own;
-    if (!ws) ws = &own;
     hipError_t e = hipSuccess;
     if (ws->dev_bytes < total) {
         if (ws->dev) (void)hipFree(ws->dev);
@@ -309,7 +336,7 @@ hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_e
     PlanArgs a;
     a.rp = reinterpret_cast<const long long *>(rp_dev);
     a.nrows = nrows; a.nblocks = (uint32_t)nblocks; a.cap = (uint32_t)cap; a.thr = (uint32_t)thr;
-    a.max_rows = p.max_rows && p.max_rows < 0xffffffffll ? (uint32_t)p.max_rows : 0xffffffffu;
+    a.max_rows = out->max_rows && out->max_rows < 0xffffffffll ? (uint32_t)out->max_rows : 0xffffffffu;
     a.tile_empty = reinterpret_cast<uint32_t *>(arena + o_tile);
     a.Q = reinterpret_cast<uint32_t *>(arena + o_q);
     a.J = reinterpret_cast<uint16_t *>(arena + o_j);
@@ -317,9 +344,12 @@ hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_e
     a.counts = reinterpret_cast<uint32_t *>(arena + o_cnt);
     a.chunks = reinterpret_cast<ChunkRec *>(arena + o_ch);
     a.shared = reinterpret_cast<Shared *>(arena + o_sh);
-    a.totals = reinterpret_cast<unsigned long long *>(arena + o_tot);
-    unsigned long long  totals_pageable[3] = {0, 0, 0};
-    e = hipMemsetAsync(a.totals, 0, 24, st);
+    a.totals = tables && tables->totals ? tables->totals : reinterpret_cast<unsigned long long *>(arena + o_tot);
+    a.odesc = tables ? tables->desc : nullptr; a.odesc2 = tables ? tables->desc2 : nullptr; a.opad = tables ? tables->pad : nullptr;
+    a.onzb = tables ? reinterpret_cast<long long *>(tables->nzb) : nullptr;
+    a.oroom = tables ? tables->room : 0u; a.ophased = tables && tables->phased ? 1u : 0u;
+    a.nz_end = nz_end;
+    if (!(tables && tables->totals)) e = hipMemsetAsync(a.totals, 0, 32, st);      // (a caller's block is zero already)
     if (e == hipSuccess) {
         hipLaunchKernelGGL(tile_kernel, dim3((uint32_t)ntiles), dim3(kTileRows), 0, st, a);
         hipLaunchKernelGGL(q_kernel, dim3((uint32_t)ntiles), dim3(kTileRows), 0, st, a);
@@ -328,6 +358,33 @@ hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_e
         hipLaunchKernelGGL(emit_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, a);
         e = hipGetLastError();
     }
+    out->bound = bound;
+    out->chunks = a.chunks; out->shared = a.shared; out->totals = a.totals;
+    out->chunks_shared_adjacent = o_sh == o_ch + up(sizeof(ChunkRec) * (size_t)bound) && up(sizeof(ChunkRec) * (size_t)bound) == sizeof(ChunkRec) * (size_t)bound;
+    return e;
+}
+
+// The plan of plan_chunks(nrows, rp, S, thr, max_rows), from a row_ptr in device memory.  *fallback is set (and nothing else
+// done) when a row block holds 2^31 slots or more -- the caller then plans on the host.  One stream synchronisation for the
+// counts, one for the records.
+hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, Plan *out, bool *fallback,
+                              hipStream_t st, PlanScratch *ws)
+{
+    *fallback = false;
+    Plan &p = *out;
+    p = Plan();
+    p.S = S;
+    p.nz_end = nz_end;
+    // device scratch: the caller's (kept across the images of one cvr_create) or one of our own
+    PlanScratch own;
+    if (!ws) ws = &own;
+    DevicePlan dp;
+    hipError_t e = plan_chunks_device_enqueue(rp_dev, nrows, nz_end, S, thr, max_rows, st, ws, &dp, nullptr);
+    p.thr = dp.thr; p.max_rows = dp.max_rows;
+    if (e != hipSuccess || nrows <= 0) { if (own.dev) (void)hipFree(own.dev); return e; }
+    if (dp.declined) { *fallback = true; return hipSuccess; }
+    const int64_t bound = dp.bound;
+    unsigned long long  totals_pageable[3] = {0, 0, 0};
     // Small plans come back in one go, through the caller's pinned buffer if there is one (a copy into pageable memory makes
     // the runtime wait for the stream and stage the bytes: ~25 us per call): counts first, records behind them.
     const size_t rec_bytes = (size_t)bound * (sizeof(ChunkRec) + sizeof(Shared));
@@ -343,14 +400,14 @@ hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_e
             hch = reinterpret_cast<uint8_t *>(p.chunks.data()); hsh = reinterpret_cast<uint8_t *>(p.shared.data());
         }
         // (chunk and cut-row records are neighbours in the arena: one copy when the destination is one buffer too)
-        if (pinned && o_sh == o_ch + up(sizeof(ChunkRec) * (size_t)bound) && up(sizeof(ChunkRec) * (size_t)bound) == sizeof(ChunkRec) * (size_t)bound) {
-            e = hipMemcpyAsync(hch, a.chunks, rec_bytes, hipMemcpyDeviceToHost, st);
+        if (pinned && dp.chunks_shared_adjacent) {
+            e = hipMemcpyAsync(hch, dp.chunks, rec_bytes, hipMemcpyDeviceToHost, st);
         } else {
-            e = hipMemcpyAsync(hch, a.chunks, sizeof(ChunkRec) * (size_t)bound, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(hsh, a.shared, sizeof(Shared) * (size_t)bound, hipMemcpyDeviceToHost, st);
+            e = hipMemcpyAsync(hch, dp.chunks, sizeof(ChunkRec) * (size_t)bound, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(hsh, dp.shared, sizeof(Shared) * (size_t)bound, hipMemcpyDeviceToHost, st);
         }
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(totals, a.totals, 24, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(totals, dp.totals, 24, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess && (totals[2] & 1ull)) { *fallback = true; p.chunks.clear(); p.shared.clear(); }
     else if (e == hipSuccess) {
@@ -364,8 +421,8 @@ hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_e
             p.chunks.resize(nc); p.shared.resize(ns);
         }
         if (!one_go) {
-            if (nc) e = hipMemcpyAsync(p.chunks.data(), a.chunks, sizeof(ChunkRec) * nc, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess && ns) e = hipMemcpyAsync(p.shared.data(), a.shared, sizeof(Shared) * ns, hipMemcpyDeviceToHost, st);
+            if (nc) e = hipMemcpyAsync(p.chunks.data(), dp.chunks, sizeof(ChunkRec) * nc, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && ns) e = hipMemcpyAsync(p.shared.data(), dp.shared, sizeof(Shared) * ns, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
         }
     }

@@ -160,7 +160,8 @@ typedef struct {
     int32_t spmv_launches;         /* launches of the SpMV kernel one SpMV is made of: 1 (also with column panels that run one per XCD at a
                                       time: all rounds of eight share one grid), or one per panel when each panel runs over the whole chip;
                                       combine / fix-up / hub kernels not counted                                                            */
-    int32_t reserved7;
+    int32_t preprocess_fused;      /* 1: cvr_create ran analysis, chunk plan, segment table and conversion as one submission (resident
+                                    * layouts, cvr_fused.hip: plan_s covers all of it, the first cvr_preprocess has nothing left to do) */
 } cvr_info;
 
 void        cvr_default_options(cvr_options *opt);

@@ -204,6 +204,7 @@ def test_timed_configuration_full_size_strict(value_dict):
     got = dict(steps_per_chunk=i.steps_per_chunk, waves_per_block=i.waves_per_block, x_window=i.x_window, col_phases=i.col_phases,
                value_dict=i.value_dict)
     assert got == dict(TIMED_LAYOUT, value_dict=13 if value_dict else 0), got
+    assert i.preprocess_fused == 1                     # analysis, plan, segment table and conversion as one submission (cvr_fused.hip)
     mir = O.Cvr64(nrows, ncols, rp, ci, va, i.steps_per_chunk, use_dict=i.value_dict > 0, phases=i.col_phases, max_rows=i.chunk_row_cap,
                   tag16=i.row_tags16, piece_max=i.piece_max)
     img = A.export_image()
@@ -221,6 +222,46 @@ def test_timed_configuration_full_size_strict(value_dict):
         if i.nshared == 0:
             assert np.array_equal(y, mir.spmv(x)), (value_dict, mode)      # same order of additions as the mirror
     A.close()
+
+
+@pytest.mark.parametrize("kind", ["pattern", "values_fp32", "long_rows"])
+def test_fused_preprocessing_same_image(kind, monkeypatch):
+    """cvr_create's one-submission preprocessing (cvr_fused.hip: planner -> per-chunk tables on the device -> segment table ->
+    conversion without the host in between) gives the image, the descriptors and the y bits of the staged path (CVR_NO_FUSED);
+    with rows cut over chunks (their fix-up list comes from the device plan), fp32 values and no dictionary as well."""
+    nrows, ncols, rp, ci, va = synth.web_google_like(1.0 if kind == "values_fp32" else 0.5)      # (x of more than 2.5 MB: column phases)
+    if kind == "values_fp32":
+        va = np.random.default_rng(5).standard_normal(len(ci)).astype(np.float32)
+    if kind == "long_rows":          # three rows far beyond a chunk: cut over several chunks
+        import scipy.sparse as sp
+        rng = np.random.default_rng(11)
+        M = sp.csr_matrix((va, ci, rp), shape=(nrows, ncols))
+        rows = np.repeat(np.array([7, nrows // 2, nrows - 3]), 9000)
+        cols = np.concatenate([rng.choice(ncols, 9000, replace=False) for _ in range(3)])
+        M = (M + sp.csr_matrix((rng.standard_normal(27000), (rows, cols)), shape=(nrows, ncols))).tocsr()
+        M.sort_indices()
+        rp, ci, va = M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data.astype(np.float64)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    monkeypatch.setenv("CVR_NO_FUSED", "1")
+    B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    monkeypatch.delenv("CVR_NO_FUSED")
+    ia, ib = A.info, B.info
+    assert ia.preprocess_fused == 1 and ib.preprocess_fused == 0
+    for f in ("steps_per_chunk", "waves_per_block", "x_window", "col_phases", "value_dict", "nchunks", "nshared", "nsegments", "row_tags16", "piece_max",
+              "chunk_row_cap", "lds_bytes", "image_bytes", "nslots"):
+        assert getattr(ia, f) == getattr(ib, f), f
+    if kind == "long_rows":
+        assert ia.nshared > 0
+    ea, eb = A.export_image(), B.export_image()
+    for key in ("desc", "target", "shared", "image"):
+        assert np.array_equal(ea[key], eb[key]), key
+    x = O.x_vec_fast(ncols, "rand").astype(va.dtype)
+    ya, _ = A.spmv(x)
+    yb, _ = B.spmv(x)
+    assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8))
+    yref, absy = O.csr_spmv64(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    _assert_close(ya.astype(np.float64), yref, absy, TOL64 if va.dtype == np.float64 else TOL32, kind)
+    A.close(); B.close()
 
 
 def test_full_size_properties(web_google):
