@@ -641,7 +641,8 @@ def main():
             "spmv_only_ms_max_over_ranks": kern_max_s * 1e3, "gflops_spmv_only_no_exchange": 2.0 * job_nnz / kern_max_s / 1e9,
             "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
             "preprocess": {"plan_s": info.plan_s, "probe_s": info.probe_s, "upload_s": info.upload_s, "convert_s": info.convert_s,
-                           "preprocess_wall_s": info.preprocess_wall_s, "tune_s": A.tuning_s,
+                           "preprocess_wall_s": info.preprocess_wall_s, "dict_s": info.dict_s, "one_submission": bool(info.preprocess_fused),
+                           "t_pre_s": info.plan_s + info.probe_s + info.hub_select_s + info.dict_s + info.preprocess_wall_s, "tune_s": A.tuning_s,
                            "workload_build_s": build_s, "create_and_preprocess_wall_s": create_s},
             "independent_spmvs_on_two_streams": None if two is None else {"ms_per_spmv": two * 1e3, "gflops": 2.0 * nnz / two / 1e9},
             "verdict_wrong_rows": wrong, "verdict_tolerance": "rows with |y - y_csr| > %g * sum |a x|" % (1e-5 if f32 else 1e-12),

@@ -22,6 +22,7 @@ namespace cvr {
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_dw __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte load from a dword-aligned address
 typedef double   f64x2 __attribute__((ext_vector_type(2)));
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
 
@@ -43,6 +44,10 @@ __device__ __forceinline__ uint32_t dict_code(const typename Bits<T>::type *dict
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (dict[mid] < b) lo = mid + 1; else hi = mid; }
     return lo;
 }
+
+// CVR_CONVERT_CLOCKS: 100-MHz time stamps of every 256th chunk's stages (launch_convert prints them)
+__device__ unsigned long long *g_conv_dbg = nullptr;
+#define CONV_CLOCK(i) do { if (g_conv_dbg && lane == 0 && (k & 255u) == 0) g_conv_dbg[(k >> 8) * 16 + (i)] = wall_clock64(); } while (0)
 
 // SEGT: the chunk's segments come from a table (column phases: one segment per (row, phase) pair, launch_seg_build) instead
 // of being the chunk's rows in order.
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (k >= nchunks) return;
+    CONV_CLOCK(0);
     const int64_t  b = nzb[k], e = nzb[k + 1];
     const uint4    d = desc[k];
     const uint32_t row_first = d.x, nseg = d.y, pc = pad_cnt[k];
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 
+    CONV_CLOCK(1);
     for (int g = 0; g < G; g++) {
         uint32_t cw[4], cj[4], tg4[4];
         T        vv[4];
@@ -241,6 +248,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
             if (pos >= 0) pos++;
             cnt--;
         }
+        if (g == 3) CONV_CLOCK(2);
 #pragma unroll
         for (int j = 0; j < kGroupSteps; j++) {
             cj[j] = pj[j] >= 0 ? (uint32_t)cidx[pj[j]] : pad_col;
@@ -292,7 +300,9 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
             f32x4 vq = {vv[0], vv[1], vv[2], vv[3]};
             *reinterpret_cast<f32x4 *>(o + CB) = vq;
         }
+        if (g == 3) CONV_CLOCK(3);
     }
+    CONV_CLOCK(4);
     if (cnt != 0) bad |= 1u;
     if (bad) atomicOr(err, bad);
     target[(size_t)k * kLanes + lane] = (uint8_t)tgt;
@@ -302,6 +312,222 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
 #undef SROW
 }
 
+
+// ---- conversion from LDS (packed segment tables) ----------------------------------------------------------------------
+// convert_kernel fetches what a lane emits -- column index and value of ITS position in the CSR arrays -- with per-lane loads: 64
+// addresses in up to 64 cache lines per instruction, twice per step.  The chunk's 12 KB of columns stay in L1, but the L1 looks one
+// line up per clock: 10.8 M lane requests on 256 L1s are 18 us at best, 40-50 us as measured (CVR_CONVERT_CLOCKS: 8-13 us per 16
+// steps of a chunk).  Here the wavefront first copies its chunk's columns and values into LDS with coalesced loads -- the values as
+// dictionary codes already, one byte each -- and the per-lane accesses become ds_read.  The feed table passes through a ring of
+// 2 x kRingHalf entries in LDS: the half behind the one in use is fetched into registers while that one is consumed (a table in LDS
+// as a whole would leave four chunks per CU where seven want to run).  Same hand-out, same image.
+constexpr uint32_t kRingHalf = 448, kRingLoads = kRingHalf / kLanes;
+
+template <typename T, bool DICT, bool TAG>
+__global__ __launch_bounds__(kLanes) void convert_lds_kernel(
+    const int32_t *__restrict__ cidx, const T *__restrict__ vals, const int64_t *__restrict__ nzb,
+    const uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, uint8_t *__restrict__ stream, uint8_t *__restrict__ target, uint32_t *__restrict__ err,
+    int G, uint32_t nchunks, const uint32_t *__restrict__ nchunks_dev, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
+    const uint2 *__restrict__ seg_packed, uint32_t col_bits, const uint32_t *__restrict__ seg_flags)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t csm[];      // ring uint2 [2 kRingHalf] | dictionary [ndict -> 4] | columns u32 [64 S] | values T [64 S] or codes u8 [64 S]
+    typedef typename Bits<T>::type bits_t;
+    if (seg_flags[0] & 3u) return;
+    if (nchunks_dev) nchunks = *nchunks_dev;
+    constexpr int GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
+    constexpr int CB = kColsBytes + (TAG ? kTagBytes : 0);
+    const uint32_t lane = threadIdx.x, k = blockIdx.x;
+    if (k >= nchunks) return;
+    CONV_CLOCK(0);
+    const int      S = G * kGroupSteps;
+    const uint32_t cap = (uint32_t)S * kLanes, dpad = DICT ? (ndict + 3u) & ~3u : 0u;
+    uint2    *ring = reinterpret_cast<uint2 *>(csm);
+    bits_t   *dict = reinterpret_cast<bits_t *>(csm + 16u * kRingHalf);
+    uint32_t *lcol = reinterpret_cast<uint32_t *>(csm + 16u * kRingHalf + sizeof(bits_t) * dpad);
+    uint8_t  *lcode = reinterpret_cast<uint8_t *>(lcol + cap);
+    T        *lval = reinterpret_cast<T *>(lcol + cap);
+    if constexpr (DICT) {
+        for (uint32_t i = lane; i < ndict; i += kLanes) dict[i] = __builtin_bit_cast(bits_t, dict_g[i]);
+    }
+    const int64_t  b = nzb[k], e = nzb[k + 1];
+    const uint32_t n = (uint32_t)(e - b), nseg = desc[k].y, sbase = desc2[k].x;
+    const uint2   *pk = seg_packed + sbase;
+    // the ring's two halves and the half behind them (registers), then the chunk's columns and values, eight loads in flight per lane
+    uint2 pend[kRingLoads];
+#pragma unroll
+    for (uint32_t u = 0; u < 2 * kRingLoads; u++) { const uint32_t i = u * kLanes + lane; ring[i] = i < nseg ? pk[i] : uint2{0u, 0u}; }
+#pragma unroll
+    for (uint32_t u = 0; u < kRingLoads; u++) { const uint32_t i = 2 * kRingHalf + u * kLanes + lane; pend[u] = i < nseg ? pk[i] : uint2{0u, 0u}; }
+    uint32_t ring_end = 2 * kRingHalf, bad = 0;        // entries [ring_end - 2 kRingHalf, ring_end) are in the ring, pend holds the kRingHalf behind them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the dictionary, before its use below)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // columns and values, four consecutive elements per lane and load (16 bytes of columns, 16 or 32 of values); kVec such loads of
+    // each are issued before the first is used; the dictionary searches of a batch run side by side
+    constexpr uint32_t kVec = 4;
+    for (uint32_t i0 = lane * 4; i0 < n; i0 += kLanes * 4 * kVec) {
+        u32x4 c[kVec];
+        T     v[kVec][4];
+#pragma unroll
+        for (uint32_t u = 0; u < kVec; u++) {
+            const uint32_t i = i0 + u * kLanes * 4;
+            if (i + 4 <= n) {
+                c[u] = *reinterpret_cast<const u32x4_dw *>(cidx + b + i);
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[u][q] = vals[b + i + q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { c[u][q] = i + q < n ? (uint32_t)cidx[b + i + q] : 0u; v[u][q] = i + q < n ? vals[b + i + q] : (T)0; }
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kVec; u++) {
+            const uint32_t i = i0 + u * kLanes * 4;
+            if (i >= n) break;
+            *reinterpret_cast<u32x4 *>(lcol + i) = c[u];          // (room for 64 S elements: the last vector of a short chunk stays inside)
+        }
+        if constexpr (DICT) {
+            // first entry >= the value's bit pattern, for the batch's 4 kVec values at once (the search is a chain of dependent LDS reads)
+            uint32_t lo[kVec][4], hi[kVec][4];
+#pragma unroll
+            for (uint32_t u = 0; u < kVec; u++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) { lo[u][q] = 0; hi[u][q] = ndict; }
+            for (uint32_t span = ndict; span > 0; span >>= 1) {
+#pragma unroll
+                for (uint32_t u = 0; u < kVec; u++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (lo[u][q] < hi[u][q]) {
+                            const uint32_t mid = (lo[u][q] + hi[u][q]) >> 1;
+                            if (dict[mid] < __builtin_bit_cast(bits_t, v[u][q])) lo[u][q] = mid + 1; else hi[u][q] = mid;
+                        }
+                    }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kVec; u++) {
+                const uint32_t i = i0 + u * kLanes * 4;
+                if (i >= n) break;
+                uint32_t codes = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t cd = lo[u][q];
+                    if (i + q < n && (cd >= ndict || dict[cd] != __builtin_bit_cast(bits_t, v[u][q]))) bad |= 4u;   // value missing from the dictionary
+                    codes |= (cd & 0xffu) << (8 * q);
+                }
+                *reinterpret_cast<uint32_t *>(lcode + i) = codes;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t u = 0; u < kVec; u++) {
+                const uint32_t i = i0 + u * kLanes * 4;
+                if (i >= n) break;
+#pragma unroll
+                for (int q = 0; q < 4; q++) lval[i + q] = v[u][q];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the wavefront's own LDS writes, in order, before its reads below
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    CONV_CLOCK(1);
+
+    uint32_t pos = 0xffffffffu;      // element of the chunk this lane emits next; 0xffffffff = pad slot
+    uint32_t cnt = 0, fed = 0, tgt = lane, rowtag = 0;
+    uint8_t *out = stream + (size_t)k * G * GB + lane * 16;
+    for (int g = 0; g < G; g++) {
+        uint32_t cw[4], tg4[4], pj[4];
+#pragma unroll
+        for (int j = 0; j < kGroupSteps; j++) {
+            const uint64_t em = __ballot(cnt == 0);
+            if (em) {
+                if (fed + kLanes > ring_end && ring_end < nseg) {      // this step may reach past the ring: the half fetched earlier goes in (over entries long handed out), the next is requested
+#pragma unroll
+                    for (uint32_t u = 0; u < kRingLoads; u++) ring[(ring_end + u * kLanes + lane) % (2 * kRingHalf)] = pend[u];
+                    ring_end += kRingHalf;
+#pragma unroll
+                    for (uint32_t u = 0; u < kRingLoads; u++) { const uint32_t i = ring_end + u * kLanes + lane; pend[u] = i < nseg ? pk[i] : uint2{0u, 0u}; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                const uint32_t rank = lane_rank(em);
+                const uint32_t nempty = (uint32_t)__popcll(em);
+                const uint32_t navail = nseg - fed;
+                bool           want = cnt == 0;
+                if (want && rank < navail) {                 // feeding, spmv.cpp:821-868
+                    const uint2 r = ring[(fed + rank) % (2 * kRingHalf)];
+                    pos = (r.x & 0xffffu) == 0xffffu ? 0xffffffffu : (r.x & 0xffffu);
+                    cnt = r.x >> 16;
+                    rowtag = TAG ? r.y : r.y << col_bits;
+                    want = false;
+                }
+                fed += nempty < navail ? nempty : navail;
+                if (nempty > navail) {                       // stealing, spmv.cpp:869-943
+                    const uint32_t ave = (uint32_t)(S - (g * kGroupSteps + j));   // == sum(count)/64, App. A.6
+                    const uint32_t nsteal = nempty - navail;
+                    const uint32_t s = rank - navail;        // steal order = lane order (spmv.cpp:814)
+                    uint32_t       base = 0;
+                    while (base < nsteal) {
+                        const uint64_t of = __ballot(cnt > ave);
+                        if (!of) { bad |= 2u; break; }
+                        const int      v = __ffsll((unsigned long long)of) - 1;     // FIRST over-full lane (spmv.cpp:876-879)
+                        const uint32_t cv = __shfl(cnt, v), pv = __shfl(pos, v), tv = __shfl(rowtag, v);
+                        const uint32_t m = (cv + ave - 1) / ave - 1;  // steals until v is no longer over-full
+                        const uint32_t kk = m < nsteal - base ? m : nsteal - base;
+                        if (want && s >= base && s < base + kk) {     // takes the FIRST ave (spmv.cpp:927-931)
+                            pos = pv == 0xffffffffu ? pv : pv + (s - base) * ave;
+                            cnt = ave;
+                            rowtag = tv;
+                            tgt = (uint32_t)v;
+                            want = false;
+                        }
+                        if (lane == (uint32_t)v) {
+                            if (pos != 0xffffffffu) pos += kk * ave;
+                            cnt -= kk * ave;
+                        }
+                        base += kk;
+                    }
+                }
+            }
+            pj[j] = pos;
+            if constexpr (TAG) { cw[j] = cnt == 1 ? kEndBit : 0u; tg4[j] = cnt == 1 ? rowtag : 0u; }
+            else cw[j] = cnt == 1 ? kEndBit | rowtag : 0u;
+            if (pos != 0xffffffffu) pos++;
+            cnt--;
+        }
+        if (g == 3) CONV_CLOCK(2);
+        uint8_t *o = out + (size_t)g * GB;
+#pragma unroll
+        for (int j = 0; j < kGroupSteps; j++) cw[j] |= pj[j] != 0xffffffffu ? lcol[pj[j]] : pad_col;
+        u32x4 cq = {cw[0], cw[1], cw[2], cw[3]};
+        *reinterpret_cast<u32x4 *>(o) = cq;
+        if constexpr (TAG) {
+            const uint2 tq = {tg4[0] | (tg4[1] << 16), tg4[2] | (tg4[3] << 16)};
+            *reinterpret_cast<uint2 *>(stream + (size_t)k * G * GB + (size_t)g * GB + kColsBytes + lane * 8) = tq;
+        }
+        if constexpr (DICT) {
+            uint32_t codes = 0;             // (a pad slot holds +0.0: the dictionary's first entry)
+#pragma unroll
+            for (int j = 0; j < kGroupSteps; j++) codes |= (pj[j] != 0xffffffffu ? (uint32_t)lcode[pj[j]] : 0u) << (8 * j);
+            *reinterpret_cast<uint32_t *>(stream + (size_t)k * G * GB + (size_t)g * GB + CB + lane * 4) = codes;
+        } else {
+            T vv[4];
+#pragma unroll
+            for (int j = 0; j < kGroupSteps; j++) vv[j] = pj[j] != 0xffffffffu ? lval[pj[j]] : (T)0;
+            if constexpr (sizeof(T) == 8) {
+                f64x2 lo = {vv[0], vv[1]}, hi = {vv[2], vv[3]};
+                *reinterpret_cast<f64x2 *>(o + CB) = lo;
+                *reinterpret_cast<f64x2 *>(o + CB + kLanes * 16) = hi;
+            } else {
+                f32x4 vq = {vv[0], vv[1], vv[2], vv[3]};
+                *reinterpret_cast<f32x4 *>(o + CB) = vq;
+            }
+        }
+        if (g == 3) CONV_CLOCK(3);
+    }
+    CONV_CLOCK(4);
+    if (cnt != 0) bad |= 1u;
+    if (bad) atomicOr(err, bad);
+    target[(size_t)k * kLanes + lane] = (uint8_t)tgt;
+}
 
 // ---- column phases: the segment table -------------------------------------------------------------------------------
 // A chunk with column phases feeds, phase by phase (column range by column range), the pieces of its rows that fall into
@@ -1016,6 +1242,49 @@ hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTab
 hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg, const uint32_t *nchunks_dev)
 {
     if (img.nchunks == 0) return hipSuccess;
+    unsigned long long *dbg = nullptr;
+    if (getenv("CVR_CONVERT_CLOCKS") && hipMalloc(&dbg, sizeof(unsigned long long) * 16 * 64) == hipSuccess) {
+        (void)hipMemset(dbg, 0, sizeof(unsigned long long) * 16 * 64);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_dbg), &dbg, sizeof(dbg));
+    }
+    struct DbgPrint {
+        unsigned long long *dbg; hipStream_t st; uint32_t n;
+        ~DbgPrint()
+        {
+            if (!dbg) return;
+            unsigned long long h[16 * 64] = {}, *none = nullptr;
+            if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                unsigned long long t0 = ~0ull;
+                for (uint32_t g = 0; g * 256 < n && g < 64; g++) if (h[g * 16]) t0 = std::min(t0, h[g * 16]);
+                for (uint32_t g = 0; g * 256 < n && g < 64; g++) {
+                    if (!h[g * 16]) continue;
+                    fprintf(stderr, "[convert] chunk %5u: start %7.2f us; staging, groups 0-3 up to the hand-out of the fourth, its loads / gathers + stores, the other groups (us)", g * 256, (double)(h[g * 16] - t0) * 0.01);
+                    for (int i = 1; i <= 4; i++) fprintf(stderr, " %6.2f", (double)(h[g * 16 + i] - h[g * 16 + i - 1]) * 0.01);
+                    fprintf(stderr, "\n");
+                }
+            }
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_dbg), &none, sizeof(none));
+            (void)hipFree(dbg);
+        }
+    } dbg_print{dbg, st, img.nchunks};
+    // CVR_CONVERT_LDS=1: the LDS-staged kernel (measured, not faster on the web-Google shape: DESIGN.md section 5.7)
+    if (seg && seg->packed && !img.c16 && !img.hub_n && getenv("CVR_CONVERT_LDS")) {
+        const size_t capl = (size_t)kLanes * img.S, vb = img.dict ? 1 : (img.f32 ? 4 : 8), db = img.dict ? (size_t)((img.ndict + 3u) & ~3u) * (img.f32 ? 4 : 8) : 0;
+        const size_t lds = 16 * (size_t)kRingHalf + db + capl * (4 + vb) + 16;
+        if (lds <= (48u << 10)) {           // at least three chunks per CU
+            const uint2 *pk = reinterpret_cast<const uint2 *>(seg->begin);
+#define CVR_CONVERT_LDS(T, DI, TG)                                                                                                                         \
+    hipLaunchKernelGGL((convert_lds_kernel<T, DI, TG>), dim3(img.nchunks), dim3(kLanes), lds, st, csr.col_idx, static_cast<const T *>(csr.vals), csr.nz_begin,  \
+                       img.desc, img.desc2, img.stream, img.target, err_flag, img.G, img.nchunks, nchunks_dev, img.pad_col,                                      \
+                       static_cast<const T *>(img.dict), img.ndict, pk, img.col_bits, seg->flags)
+#define CVR_CONVERT_LDS_TG(T, DI) do { if (img.tag16) CVR_CONVERT_LDS(T, DI, true); else CVR_CONVERT_LDS(T, DI, false); } while (0)
+            if (img.f32) { if (img.dict) CVR_CONVERT_LDS_TG(float, true); else CVR_CONVERT_LDS_TG(float, false); }
+            else         { if (img.dict) CVR_CONVERT_LDS_TG(double, true); else CVR_CONVERT_LDS_TG(double, false); }
+#undef CVR_CONVERT_LDS_TG
+#undef CVR_CONVERT_LDS
+            return hipGetLastError();
+        }
+    }
     const uint32_t blocks = (img.nchunks + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3     grid(blocks), block(kLanes * kWavesPerBlock);
     // the feed table of a chunk in LDS (convert_kernel, STAGE) when eight chunks' tables fit a CU (16-bit positions: 64 S < 65 535)

@@ -47,7 +47,7 @@ def report(n, nc, rp, ci, va, iters=200, name="matrix"):
            "layout": {"steps_per_chunk": i.steps_per_chunk, "waves_per_workgroup": i.waves_per_block, "x_window": i.x_window, "col_phases": i.col_phases,
                       "col_panels": i.col_panels, "value_dict": i.value_dict},
            "preprocess_us": {"plan": i.plan_s * 1e6, "layout_probe": i.probe_s * 1e6, "hub_selection": i.hub_select_s * 1e6, "dict_scan": i.dict_s * 1e6, "convert_device_events": i.convert_s * 1e6,
-                             "preprocess_wall": i.preprocess_wall_s * 1e6, "upload_incl_dict_scan": i.upload_s * 1e6, "total": t_pre * 1e6, "total_with_h2d": t_pre_h2d * 1e6}},
+                             "preprocess_wall": i.preprocess_wall_s * 1e6, "one_submission": bool(i.preprocess_fused), "upload_incl_dict_scan": i.upload_s * 1e6, "total": t_pre * 1e6, "total_with_h2d": t_pre_h2d * 1e6}},
            "baselines": {}}
     A.close()
     h = C.c_void_p()

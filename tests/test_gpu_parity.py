@@ -264,6 +264,24 @@ def test_fused_preprocessing_same_image(kind, monkeypatch):
     A.close(); B.close()
 
 
+@pytest.mark.parametrize("kind", ["pattern", "values_fp32"])
+def test_lds_staged_converter_same_image(kind, monkeypatch):
+    """CVR_CONVERT_LDS=1: the converter that copies a chunk's columns and values (as dictionary codes) into LDS first and passes the feed
+    table through a ring there (convert_lds_kernel; measured and not the default: DESIGN.md section 5.7) writes the default converter's image."""
+    nrows, ncols, rp, ci, va = synth.web_google_like(1.0 if kind == "values_fp32" else 0.5)
+    if kind == "values_fp32":
+        va = np.random.default_rng(5).standard_normal(len(ci)).astype(np.float32)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    monkeypatch.setenv("CVR_CONVERT_LDS", "1")
+    B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    monkeypatch.delenv("CVR_CONVERT_LDS")
+    assert A.info.col_phases > 1 and A.info.nchunks == B.info.nchunks
+    ea, eb = A.export_image(), B.export_image()
+    for key in ("desc", "target", "shared", "image"):
+        assert np.array_equal(ea[key], eb[key]), key
+    A.close(); B.close()
+
+
 def test_full_size_properties(web_google):
     nrows, ncols, rp, ci, va, A = web_google
     x1 = O.x_vec_fast(ncols, "rand")
