@@ -136,7 +136,8 @@ typedef struct {
     int64_t image_bytes;       /* device bytes of the CVR image incl. descriptors                     */
     int64_t yext_elems;        /* y_ext = [y | dump | 2 carry slots per chunk]                        */
     int64_t x_elems;           /* ncols + 1 : x_ext[ncols] must be 0 (pad slot)                       */
-    double  plan_s, upload_s, convert_s;  /* host planner, H2D of CSR, device conversion kernel      */
+    double  plan_s, upload_s, convert_s;  /* planner (+ panel rule; preprocess_fused: the whole chain up to the converter's end), H2D of the CSR,
+                                           * device time of segment table + conversion (preprocess_fused: from the planner's first kernel) */
     int32_t col_panels;        /* 1, or the number of column panels the matrix was cut into                          */
     int32_t value_dict;        /* 0, or the number of dictionary entries (distinct values + the pad slots' 0)         */
     int32_t col_phases;        /* 1, or the number of column phases                                                    */
@@ -172,7 +173,8 @@ int         cvr_device_count(void);                     /* 0 when there is no us
 /* ---- the handle: one matrix (or one row shard of it) on one GPU ------------------------------ */
 /* Validates the CSR, uploads it, looks at it on the device to choose the layout, plans the chunks (on the device from
  * 200 000 rows on, else on the host: the same plan).  (pre_processing's setup half: chunk partition + row search,
- * spmv.cpp:584-694.) */
+ * spmv.cpp:584-694.)  For a single image in the resident layout the tracker loop follows in the same submission of kernels
+ * (cvr_info.preprocess_fused): the handle comes back converted, and cvr_preprocess only releases the CSR and reports the times. */
 int cvr_create(cvr_handle **out, const cvr_csr_view *csr, const cvr_options *opt);
 /* CSR -> CVR64 on the device (the tracker loop, spmv.cpp:711-1000); `seconds` = what the reference
  * prints at spmv.cpp:1009.  Frees the device copy of the CSR unless keep_csr != 0. */
