@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void convert_kernel(
     const uint16_t *__restrict__ seg_row, uint32_t col_bits, const uint32_t *__restrict__ seg_flags, const int32_t *__restrict__ hub_index, const uint32_t *__restrict__ hub_bitmap,
     const uint32_t *__restrict__ cbase, uint32_t hub_n, uint32_t stage_bytes, uint32_t seg_packed, const uint32_t *__restrict__ nchunks_dev)
 {
-    if (nchunks_dev) nchunks = *nchunks_dev;
+    if (nchunks_dev) nchunks = min(nchunks, *nchunks_dev);      // (a plan beyond the launch's room: the host falls back)
     extern __shared__ __attribute__((aligned(16))) uint8_t csm[];      // STAGE: stage_bytes per wavefront
     if constexpr (SEGT) { if (seg_flags[0] & 3u) return; }      // unsorted rows: the segment table is meaningless (cvr_preprocess reports it)
     constexpr int GB = (DICT ? kGroupBytesDict : C16 ? (sizeof(T) == 8 ? kGroupBytes64C16 : kGroupBytes32C16) : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kLanes) void convert_lds_kernel(
     extern __shared__ __attribute__((aligned(16))) uint8_t csm[];      // ring uint2 [2 kRingHalf] | dictionary [ndict -> 4] | columns u32 [64 S] | values T [64 S] or codes u8 [64 S]
     typedef typename Bits<T>::type bits_t;
     if (seg_flags[0] & 3u) return;
-    if (nchunks_dev) nchunks = *nchunks_dev;
+    if (nchunks_dev) nchunks = min(nchunks, *nchunks_dev);      // (a plan beyond the launch's room: the host falls back)
     constexpr int GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
     constexpr int CB = kColsBytes + (TAG ? kTagBytes : 0);
     const uint32_t lane = threadIdx.x, k = blockIdx.x;
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_scan_kernel(const int64_t *__
 #define SEG_CLOCK(i) do { if (dbg && threadIdx.x == 0 && (blockIdx.x & 255u) == 0) dbg[(blockIdx.x >> 8) * 16 + (i)] = wall_clock64(); } while (0)
     SEG_CLOCK(0);
     const uint32_t k = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (k >= (nchunks_dev ? *nchunks_dev : nchunks)) return;
+    if (k >= (nchunks_dev ? min(nchunks, *nchunks_dev) : nchunks)) return;
     const float    inv_pw = 1.0f / (float)pw;
     const uint32_t pmask = (1u << psh) - 1u;
     const int64_t  b = nzb[k], e = nzb[k + 1];
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(kSegThreads) void seg_scan_kernel(const int64_t *__
 // sum of the chunks' segment counts (cvr_info.nsegments), one workgroup
 __global__ __launch_bounds__(1024) void seg_total_kernel(uint32_t *__restrict__ cnt, uint32_t nchunks, const uint32_t *__restrict__ nchunks_dev, uint32_t *__restrict__ total_out)
 {
-    if (nchunks_dev) nchunks = *nchunks_dev;
+    if (nchunks_dev) nchunks = min(nchunks, *nchunks_dev);      // (a plan beyond the launch's room: the host falls back)
     __shared__ uint32_t part[16];
     uint32_t s = 0;
     for (uint32_t i = threadIdx.x; i < nchunks; i += 1024) s += cnt[i];
@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__
                                                       uint32_t nchunks, uint32_t ncols1, uint32_t wn, uint32_t binshift,
                                                       uint32_t nbins, uint32_t nb, uint32_t *__restrict__ win_base, uint32_t wpb, const uint32_t *__restrict__ nchunks_dev)
 {
-    if (nchunks_dev) nchunks = *nchunks_dev;
+    if (nchunks_dev) nchunks = min(nchunks, *nchunks_dev);      // (a plan beyond the launch's room: the host falls back)
     if (blockIdx.x * wpb >= nchunks) return;
     extern __shared__ uint32_t hist[];                       // [nbins + nb] then one u64 for the arg-max
     unsigned long long *best = reinterpret_cast<unsigned long long *>(hist + ((nbins + nb + 1) & ~1u));

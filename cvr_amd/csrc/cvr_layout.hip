@@ -435,10 +435,22 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
         else
             HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));
         // the resident layout wants every workgroup on a CU of its own at once: one more step per chunk until they fit
-        while (popt.layout_auto_resident && !local.too_large && (int64_t)local.plan.chunks.size() > (int64_t)local.wpb * popt.cus && popt.steps_per_chunk < 4096) {
+        // (longer chunks do not help when it is the cap on a chunk's ROWS -- the LDS accumulators -- that ends them, as with many rows of one
+        // or two non-zeros: two steps without fewer chunks and the matrix gets the plain layout instead)
+        int64_t before = (int64_t)local.plan.chunks.size();
+        int     stuck = 0;
+        while (popt.layout_auto_resident && !local.too_large && (int64_t)local.plan.chunks.size() > (int64_t)local.wpb * popt.cus && popt.steps_per_chunk < 4096 && stuck < 2) {
             popt.steps_per_chunk += 4;
             local = PartPlan();
             HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));      // (the resident layout has no hub table: nothing of `local` to keep)
+            stuck = (int64_t)local.plan.chunks.size() >= before ? stuck + 1 : 0;
+            before = (int64_t)local.plan.chunks.size();
+        }
+        if (popt.layout_auto_resident && !local.too_large && (int64_t)local.plan.chunks.size() > (int64_t)local.wpb * popt.cus) {
+            popt = opt;
+            popt.col_phases = 0; popt.layout_auto_resident = 0;
+            local = PartPlan();
+            HIP_TRY(plan_part(local, nrows, ncols, f32, prp, popt, pdr));
         }
         if (plan_s) *plan_s += now_s() - t0;
         planned = &local;

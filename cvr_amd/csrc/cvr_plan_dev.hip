@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void emit_kernel(PlanArgs a)
             a.odesc2[kk] = uint2{0u, (uint32_t)c.nrows_in};
             a.opad[kk] = (uint32_t)c.pad_cnt;
             a.onzb[kk] = c.nz_begin;
-        }
+        } else if (a.odesc && kb + i == a.oroom) a.onzb[a.oroom] = c.nz_begin;      // (a plan beyond the room: the entry that ends the last chunk there is)
+
         // a row whose first piece ends this chunk: it ends in the chunk behind those it fills completely
         if (c.tail_shared && !(c.head_shared && last == (long long)s.row)) {
             const uint32_t rem = Q[ln + 1] - Q[ln] - n.off;

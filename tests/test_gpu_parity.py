@@ -282,6 +282,39 @@ def test_lds_staged_converter_same_image(kind, monkeypatch):
     A.close(); B.close()
 
 
+@pytest.mark.parametrize("kind", ["banded", "unsorted_rows", "tiny_rows"])
+def test_fused_preprocessing_falls_back(kind):
+    """The one-submission path is an attempt: a probe that does not confirm the resident layout (a band: everything near the diagonal;
+    rows with unsorted columns) or a plan with more chunks than workgroup slots (many rows of one non-zero: the cap on a chunk's rows
+    ends the chunks, whatever their length -- such a matrix gets the plain layout, not ever longer chunks) leave the staged path to do
+    the work; y is checked against the CSR oracle either way."""
+    if kind == "banded":
+        nrows, ncols, rp, ci, va = synth.banded_sym(400000, 13)
+    elif kind == "unsorted_rows":
+        nrows, ncols, rp, ci, va = synth.web_google_like(0.5)
+        ci = ci.copy(); va = va.copy()
+        for r in np.flatnonzero(np.diff(rp) >= 2)[::3]:          # every third row of two or more: columns descending
+            a, z = rp[r], rp[r + 1]
+            ci[a:z] = ci[a:z][::-1]; va[a:z] = va[a:z][::-1]
+    else:
+        nrows = ncols = 2_400_000
+        rng = np.random.default_rng(3)
+        rp = np.arange(nrows + 1, dtype=np.int64)
+        near = rng.random(nrows) < 0.5
+        ci = np.where(near, np.clip(np.arange(nrows) + rng.integers(-200, 200, nrows), 0, nrows - 1), rng.integers(0, nrows, nrows)).astype(np.int32)
+        va = rng.standard_normal(nrows)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    i = A.info
+    assert i.preprocess_fused == 0
+    if kind == "tiny_rows":
+        assert i.col_phases == 1 and i.waves_per_block == 1 and i.steps_per_chunk <= 64 and i.image_bytes < 100e6, (i.steps_per_chunk, i.image_bytes)
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    y, _ = A.spmv(x)
+    _assert_close(y, yref, absy, TOL64, kind)
+    A.close()
+
+
 def test_full_size_properties(web_google):
     nrows, ncols, rp, ci, va, A = web_google
     x1 = O.x_vec_fast(ncols, "rand")
