@@ -939,7 +939,7 @@ __global__ __launch_bounds__(1024) void seg_total_kernel(uint32_t *__restrict__ 
 // Window choice for the SpMV kernel's LDS staging of x: one workgroup per SpMV workgroup (wpb
 // consecutive chunks = one contiguous CSR range).  Histogram of the range's columns over bins of 2^binshift
 // columns in LDS, then the best run of `nb` consecutive bins; ties go to the lowest column.
-__global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__ cidx, const int64_t *__restrict__ nzb,
+__global__ __launch_bounds__(1024) void window_kernel(const int32_t *__restrict__ cidx, const int64_t *__restrict__ nzb,
                                                       uint32_t nchunks, uint32_t ncols1, uint32_t wn, uint32_t binshift,
                                                       uint32_t nbins, uint32_t nb, uint32_t *__restrict__ win_base, uint32_t wpb, const uint32_t *__restrict__ nchunks_dev)
 {
@@ -953,7 +953,14 @@ __global__ __launch_bounds__(256) void window_kernel(const int32_t *__restrict__
     if (threadIdx.x == 0) *best = 0;
     __syncthreads();
     const int64_t lo = nzb[c0], hi = nzb[c1];
-    for (int64_t j = lo + threadIdx.x; j < hi; j += blockDim.x) atomicAdd(&hist[(uint32_t)cidx[j] >> binshift], 1u);
+    constexpr int kBatch = 8;                                 // loads in flight per thread: the pass is a few round trips, not one per element
+    for (int64_t j0 = lo + threadIdx.x; j0 < hi; j0 += (int64_t)blockDim.x * kBatch) {
+        uint32_t c[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) { const int64_t j = j0 + (int64_t)u * blockDim.x; c[u] = j < hi ? (uint32_t)cidx[j] : 0xffffffffu; }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) if (c[u] != 0xffffffffu) atomicAdd(&hist[c[u] >> binshift], 1u);
+    }
     __syncthreads();
     unsigned long long mine = 0;
     for (uint32_t s = threadIdx.x; s < nbins; s += blockDim.x) {
@@ -1005,25 +1012,38 @@ __global__ __launch_bounds__(256) void probe_kernel(const int64_t *__restrict__ 
             }
             __syncthreads();
             const int64_t te = z - t0 < (int64_t)kTile ? z : t0 + kTile;
-            for (int64_t jb = t0; jb < te; jb += 256) {       // (the same trips for every lane: ballots inside)
-                const int64_t  j = jb + threadIdx.x;
-                const bool     valid = j < te;
-                const int32_t  c = valid ? ci[j] : 0;
-                const uint32_t q = (uint32_t)(j - t0);
-                if (valid && j > a && !((starts[q >> 5] >> (q & 31)) & 1u) && ci[j - 1] > c) bad = 1;
-                // the histogram: lanes of a wavefront that hit the bin of the first pending lane add up in one LDS atomic (the
-                // non-zeros near the diagonal fall into one or two bins); after two such rounds the rest goes one by one
-                const uint32_t     bin = (uint32_t)c >> bin_shift;
-                unsigned long long todo = __ballot(valid);
-#pragma unroll 1
-                for (int round = 0; round < 2 && todo; round++) {
-                    const int                lead = __ffsll((long long)todo) - 1;
-                    const uint32_t           lb = __shfl(bin, lead);
-                    const unsigned long long m = __ballot(valid && bin == lb) & todo;
-                    if ((int)lane == lead) atomicAdd(&hist[lb], (uint32_t)__popcll(m));
-                    todo &= ~m;
+            constexpr int kBatch = 4;                         // loads of four trips in flight (a group of 256 rows is a handful of trips: each used to be a round trip to memory)
+            for (int64_t jb0 = t0; jb0 < te; jb0 += 256 * kBatch) {       // (the same trips for every lane: ballots inside)
+                int32_t cc[kBatch], cp[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) {
+                    const int64_t j = jb0 + u * 256 + threadIdx.x;
+                    cc[u] = j < te ? ci[j] : 0;
+                    cp[u] = j < te && j > a ? ci[j - 1] : 0;
                 }
-                if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1u);
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) {
+                    const int64_t jb = jb0 + u * 256;
+                    if (jb >= te) break;
+                    const int64_t  j = jb + threadIdx.x;
+                    const bool     valid = j < te;
+                    const int32_t  c = cc[u];
+                    const uint32_t q = (uint32_t)(j - t0);
+                    if (valid && j > a && !((starts[q >> 5] >> (q & 31)) & 1u) && cp[u] > c) bad = 1;
+                    // the histogram: lanes of a wavefront that hit the bin of the first pending lane add up in one LDS atomic (the
+                    // non-zeros near the diagonal fall into one or two bins); after two such rounds the rest goes one by one
+                    const uint32_t     bin = (uint32_t)c >> bin_shift;
+                    unsigned long long todo = __ballot(valid);
+#pragma unroll 1
+                    for (int round = 0; round < 2 && todo; round++) {
+                        const int                lead = __ffsll((long long)todo) - 1;
+                        const uint32_t           lb = __shfl(bin, lead);
+                        const unsigned long long m = __ballot(valid && bin == lb) & todo;
+                        if ((int)lane == lead) atomicAdd(&hist[lb], (uint32_t)__popcll(m));
+                        todo &= ~m;
+                    }
+                    if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1u);
+                }
             }
             __syncthreads();
         }
@@ -1096,24 +1116,32 @@ __global__ __launch_bounds__(256) void dict_scan_kernel(const B *__restrict__ va
     if (threadIdx.x == 0) { cnt = 0; over = flags[0] & 1u; }      // (set: another workgroup already found too many values)
     __syncthreads();
     unsigned long long last = kEmpty;
-    for (long long j = n0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n1; j += (long long)gridDim.x * blockDim.x) {
+    constexpr int      kBatch = 8;          // loads in flight per thread (the pass used to be one round trip to memory per element and thread)
+    const long long    stride = (long long)gridDim.x * blockDim.x;
+    for (long long j0 = n0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; j0 < n1; j0 += stride * kBatch) {
         if (__hip_atomic_load(&over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        const B                  raw = vals[j];
-        const unsigned long long b = sizeof(B) == 4 && raw == (B)~(B)0 ? kEmpty : (unsigned long long)raw;
-        if (b == last) continue;
-        last = b;
-        if (b == kEmpty) { atomicOr(&flags[0], 2u); continue; }
-        uint32_t hsh = (uint32_t)((b * 0x9E3779B97F4A7C15ull) >> 55);
-        for (;;) {
-            // a plain read first: once the table holds the matrix's few values nearly every look-up ends here, and lanes reading
-            // the same slot are served by one broadcast where the same compare-and-swaps would be executed one after the other
-            unsigned long long old = __hip_atomic_load(&tab[hsh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == b) break;
-            if (old == kEmpty) old = atomicCAS(&tab[hsh], kEmpty, b);
-            if (old == b) break;
-            if (old == kEmpty) { if (atomicAdd(&cnt, 1u) + 1 > (uint32_t)kDictMax) over = 1; break; }
-            hsh = (hsh + 1) & 511u;
-            if (over) break;
+        B raw[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) { const long long j = j0 + u * stride; raw[u] = j < n1 ? vals[j] : vals[j0]; }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const unsigned long long b = sizeof(B) == 4 && raw[u] == (B)~(B)0 ? kEmpty : (unsigned long long)raw[u];
+            if (b == last) continue;
+            last = b;
+            if (b == kEmpty) { atomicOr(&flags[0], 2u); continue; }
+            if (__hip_atomic_load(&over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;      // (too many values already: the table may be full)
+            uint32_t hsh = (uint32_t)((b * 0x9E3779B97F4A7C15ull) >> 55);
+            for (uint32_t probes = 0; probes < 512; probes++) {
+                // a plain read first: once the table holds the matrix's few values nearly every look-up ends here, and lanes reading
+                // the same slot are served by one broadcast where the same compare-and-swaps would be executed one after the other
+                unsigned long long old = __hip_atomic_load(&tab[hsh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (old == b) break;
+                if (old == kEmpty) old = atomicCAS(&tab[hsh], kEmpty, b);
+                if (old == b) break;
+                if (old == kEmpty) { if (atomicAdd(&cnt, 1u) + 1 > (uint32_t)kDictMax) __hip_atomic_store(&over, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+                hsh = (hsh + 1) & 511u;
+                if (__hip_atomic_load(&over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            }
         }
     }
     __syncthreads();
@@ -1342,7 +1370,7 @@ hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream
     uint32_t       nb = img.win_elems >> binshift;
     if (nb == 0) nb = 1;
     const size_t lds = sizeof(uint32_t) * ((size_t)((nbins + nb + 1) & ~1u)) + 16;
-    hipLaunchKernelGGL(window_kernel, dim3(blocks), dim3(256), lds, st, csr.col_idx, csr.nz_begin, img.nchunks, ncols1,
+    hipLaunchKernelGGL(window_kernel, dim3(blocks), dim3(1024), lds, st, csr.col_idx, csr.nz_begin, img.nchunks, ncols1,
                        img.win_elems, binshift, nbins, nb, img.win_base, wpb, nchunks_dev);
     return hipGetLastError();
 }

@@ -72,6 +72,8 @@ def test_fuzz_parity(ncases=None, seed=None):
         pmax = int(rng.choice([-1, 0, 2, 8])) if ph > 1 else -1
         ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, thr=thr, P=P, win=win, f32=f32, wpb=wpb, phases=ph, sorted=srt, hub=hub, tags=tags, pmax=pmax)
         from_dev = torch is not None and len(ci) > 0 and rng.integers(0, 4) == 0     # CSR arrays already on the device
+        if os.environ.get("CVR_FUZZ_TRACE"):
+            print(ctx, "from_dev", from_dev, flush=True)
         if from_dev:
             keep = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp.astype(np.int64), ci.astype(np.int32), va)]
             torch.cuda.synchronize()
