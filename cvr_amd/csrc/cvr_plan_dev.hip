@@ -157,14 +157,7 @@ __global__ __launch_bounds__(256) void walk_kernel(PlanArgs a)
         const uint4 *src = reinterpret_cast<const uint4 *>(a.J + r0);
         uint4       *dst = reinterpret_cast<uint4 *>(jl);
         const uint32_t n16 = nb / 8;
-        constexpr int  kBatch = 8;          // loads in flight per thread: 128 KiB per block arrive in four round trips instead of 32
-        for (uint32_t k0 = threadIdx.x; k0 < n16; k0 += 256 * kBatch) {
-            uint4 q[kBatch];
-#pragma unroll
-            for (int u = 0; u < kBatch; u++) { const uint32_t k = k0 + u * 256; if (k < n16) q[u] = src[k]; }
-#pragma unroll
-            for (int u = 0; u < kBatch; u++) { const uint32_t k = k0 + u * 256; if (k < n16) dst[k] = q[u]; }
-        }
+        for (uint32_t k = threadIdx.x; k < n16; k += 256) dst[k] = src[k];
         for (uint32_t k = n16 * 8 + threadIdx.x; k < nb; k += 256) jl[k] = a.J[r0 + k];
     }
     // where this block's start records go: behind the room of the blocks in front of it
