@@ -393,7 +393,7 @@ class CvrMatrix:
 
     @classmethod
     def from_device(cls, nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, is_f32=False, device=0, steps_per_chunk=0,
-                    split_threshold=0, keep_csr=False, col_panels=-1, value_dict=-1, tune_steps=False, hub_table=-1):
+                    split_threshold=0, keep_csr=False, col_panels=-1, value_dict=-1, tune_steps=False, hub_table=-1, hub_reorder=-1):
         """CSR arrays already in the memory of `device` (raw pointers: int64 row_ptr[nrows+1], int32 col_idx, fp64/fp32 vals),
         e.g. the .data_ptr() of torch tensors: cvr_csr_view.arrays_on_device = 1"""
         self = cls.__new__(cls)
@@ -403,7 +403,7 @@ class CvrMatrix:
         self.dtype = np.float32 if self.f32 else np.float64
         view = CsrView(nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, int(self.f32), 1)
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, -1, -1, 0, keep_csr, 0, 0, col_panels, value_dict, tune_steps,
-                    hub_table=hub_table)
+                    hub_table=hub_table, hub_reorder=hub_reorder)
         return self
 
     def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
