@@ -315,6 +315,60 @@ def test_fused_preprocessing_falls_back(kind):
     A.close()
 
 
+@pytest.mark.parametrize("kind", ["device_arrays", "rectangular", "row_shard", "reconvert"])
+def test_fused_preprocessing_other_inputs(kind, monkeypatch):
+    """The one-submission path with CSR arrays that are already on the device, a rectangular matrix (more columns than rows), a row
+    shard whose row_ptr does not start at 0 (the view a caller hands over for one GPU's rows of a larger matrix), and a second
+    cvr_preprocess on a handle that kept its CSR (the staged converter over the tables the fused path left): image and y equal the
+    staged path's / the CSR oracle's."""
+    nrows, ncols, rp, ci, va = synth.web_google_like(0.5)
+    if kind == "rectangular":
+        ncols = ncols + 300000
+        ci = ci.copy()
+        far = np.flatnonzero(np.arange(len(ci)) % 7 == 0)
+        ci[far] = (ci[far].astype(np.int64) * 5 % ncols).astype(np.int32)
+        import scipy.sparse as sp
+        M = sp.csr_matrix((va, ci, rp), shape=(nrows, ncols)); M.sum_duplicates(); M.sort_indices()
+        rp, ci, va = M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data.astype(np.float64)
+    x = O.x_vec_fast(ncols, "rand")
+    if kind == "row_shard":
+        r0 = nrows // 5
+        view_rp = rp[r0:].copy()                                  # starts at rp[r0] > 0: col_idx / vals are indexed from 0
+        lrows = nrows - r0
+        A = cvr_amd.CvrMatrix(lrows, ncols, view_rp, ci, va)
+        monkeypatch.setenv("CVR_NO_FUSED", "1")
+        B = cvr_amd.CvrMatrix(lrows, ncols, view_rp, ci, va)
+        monkeypatch.delenv("CVR_NO_FUSED")
+        yref, absy = O.csr_spmv64(view_rp - view_rp[0], ci[view_rp[0]:], va[view_rp[0]:], x)
+    elif kind == "device_arrays":
+        import torch
+        keep = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp, ci, va)]
+        torch.cuda.synchronize()
+        A = cvr_amd.CvrMatrix.from_device(nrows, ncols, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr())
+        monkeypatch.setenv("CVR_NO_FUSED", "1")
+        B = cvr_amd.CvrMatrix.from_device(nrows, ncols, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr())
+        monkeypatch.delenv("CVR_NO_FUSED")
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+    else:
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, keep_csr=(kind == "reconvert"))
+        monkeypatch.setenv("CVR_NO_FUSED", "1")
+        B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+        monkeypatch.delenv("CVR_NO_FUSED")
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+    assert A.info.preprocess_fused == 1 and B.info.preprocess_fused == 0
+    if kind == "reconvert":
+        sec = capi.C.c_double()
+        assert capi.lib().cvr_preprocess(A._h, 0, capi.C.byref(sec)) == 0 and sec.value > 0
+    ea, eb = A.export_image(), B.export_image()
+    for key in ("desc", "target", "shared", "image"):
+        assert np.array_equal(ea[key], eb[key]), key
+    ya, _ = A.spmv(x)
+    yb, _ = B.spmv(x)
+    assert np.array_equal(ya.view(np.uint64), yb.view(np.uint64))
+    _assert_close(ya, yref, absy, TOL64, kind)
+    A.close(); B.close()
+
+
 def test_full_size_properties(web_google):
     nrows, ncols, rp, ci, va, A = web_google
     x1 = O.x_vec_fast(ncols, "rand")
