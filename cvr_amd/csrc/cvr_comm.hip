@@ -208,7 +208,43 @@ int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int i
     // way.  After the first step of such a handle the estimate |A x| / |x| is read back once; out of that range every further
     // step normalises exactly (two more passes over the vectors per step, |x| = 1 throughout).
     bool exact = false;
+    // One GPU, an image with column phases and no rows cut over chunks (the resident layout of a web-graph-sized matrix): the step's dot
+    // products and the next iterate come out of the SpMV kernel's write-out (cvr_kernels.h: IterEpilogue) -- one launch per iteration,
+    // x alternating between the caller's buffer and one of ours.
+    bool         fused = !c && !h->paneled() && cvr::iter_epilogue_ok(h->parts[0].img) && h->parts[0].img.hub_n == 0 && !getenv("CVR_ITER_UNFUSED");
+    void        *xalt = nullptr;
+    struct AltGuard { void *&p; ~AltGuard() { (void)hipFree(p); } } alt_guard{xalt};
+    const size_t nsets = (size_t)cvr::power_partials() / 3;
+    if (fused) {
+        HIP_TRY(hipMalloc(&xalt, h->vsz * (size_t)h->info.x_elems));
+        HIP_TRY(hipMemsetAsync(xalt, 0, h->vsz * (size_t)h->info.x_elems, st));
+        HIP_TRY(hipMemsetAsync(s.partial, 0, sizeof(double) * 2 * npart, st));      // (the kernel writes one entry per workgroup and set: the rest stays zero)
+    }
+    void *cur = x_dev, *nxt = xalt;
     for (int it = 0; it < iters; it++) {
+        if (fused) {
+            cvr::IterEpilogue epi;
+            epi.xnext = nxt; epi.prev = it > 0 ? s.partial + (size_t)((it - 1) & 1) * npart : nullptr; epi.out = s.partial + (size_t)(it & 1) * npart; epi.nsets = (uint32_t)nsets;
+            HIP_TRY(cvr::launch_spmv(h->parts[0].img, cur, s.y, st, true, nullptr, 0, 1, &epi));
+            std::swap(cur, nxt);
+            if (f32 && it == 0 && iters > 1) {      // the fp32 range check of the unfused loop below
+                double part[3] = {0, 0, 0};
+                HIP_TRY(cvr::launch_power_sums(s.partial, s.cells, st));
+                HIP_TRY(hipMemcpyAsync(part, s.cells, sizeof(part), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                const double est = part[2] > 0 ? sqrt(part[1] / part[2]) : 0.0;
+                if (!(est > 1e-15 && est < 1e15)) {
+                    exact = true; fused = false;
+                    HIP_TRY(cvr::launch_scale(x_dev, s.y, s.cells + 1, n, f32, st));
+                    continue;
+                }
+            }
+            if (it + 1 == iters) {       // the last iterate leaves normalised exactly, in the caller's buffer: x <- y / ||y||
+                HIP_TRY(cvr::launch_power_sums(s.partial + (size_t)(it & 1) * npart, s.cells, st));
+                HIP_TRY(cvr::launch_scale(x_dev, s.y, s.cells + 1, n, f32, st));
+            }
+            continue;
+        }
         if (exact) {
             HIP_TRY(run_spmv(h, x_dev, s.y, st));
             const void *yfull = s.y;

@@ -179,8 +179,14 @@ struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *targ
 // multi != null: eight panels in one launch (plain layout, one chunk per workgroup, no LDS tables): workgroup b takes chunk b >> 3 of
 // panel b & 7 of its round; multi[rounds][8]; multi_chunks = the most chunks any panel has (the rounds follow each other in ONE grid:
 // no launch boundary between them); img = any of the panels (for what they share); y_ext and with_fixup unused
+// The iterative caller's step inside the SpMV kernel's write-out (images with column phases, no rows cut over chunks, square matrix):
+// per workgroup the partial sums of x . y, y . y, x . x over its rows -> out[set * nsets + workgroup], and x_next = y / ||y of the step
+// before|| (prev: that step's partials, null = 1).  cvr_iter.hip's power_step_kernel is the same step as a pass of its own.
+struct IterEpilogue { void *xnext = nullptr; const double *prev = nullptr; double *out = nullptr; uint32_t nsets = 0; };
+bool iter_epilogue_ok(const DeviceImage &img);      // launch_spmv honours `epi` for this image
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup = true, const PanelArgs *multi = nullptr, uint32_t multi_chunks = 0,
-                       uint32_t multi_rounds = 1);
+                       uint32_t multi_rounds = 1,
+                       const IterEpilogue *epi = nullptr);
 size_t     spmv_lds_bytes(const DeviceImage &img);      // dynamic LDS of that launch
 inline size_t pace_words(uint32_t phases) { return (size_t)8 * phases * 512; }      // pacing buffer of an image with column phases
 

@@ -47,7 +47,7 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
         while (((int64_t)1 << pp.col_bits) <= ncols) pp.col_bits++;
         const int64_t row_field = pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
         auto rows_for = [&](int64_t win) {
-            const int64_t left = (int64_t)cvr::kLdsBytes - (cvr::kDictMax + win + 4) * vs;      // (no steal slots: spmv_seg_kernel)
+            const int64_t left = (int64_t)cvr::kLdsBytes - (cvr::kDictMax + win + 8) * vs;      // (no steal slots: spmv_seg_kernel; window + zero slot + the epilogue's arrival counter)
             return std::min<int64_t>((left / pp.wpb / vs) & ~(int64_t)3, cvr::kYStageMax);
         };
         while (pp.win > 0 && rows_for(pp.win) < 512) pp.win = (pp.win - 1024 > 0 ? pp.win - 1024 : 0) & ~(int64_t)3;      // the window gives way

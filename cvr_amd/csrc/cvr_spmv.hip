@@ -482,7 +482,8 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const T *__restrict__ x, T *__restrict__ yext_a, int G, uint32_t nchunks_a,
     uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn,
     const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, const uint2 *__restrict__ desc2_a, uint32_t col_bits, uint32_t nw_arg, int gb,
-    uint32_t *__restrict__ pace, uint32_t pw, uint32_t pad_col, int pace_lag, uint32_t nphases, uint32_t epoch, const PanelArgs *__restrict__ multi)
+    uint32_t *__restrict__ pace, uint32_t pw, uint32_t pad_col, int pace_lag, uint32_t nphases, uint32_t epoch, const PanelArgs *__restrict__ multi,
+    IterEpilogue epi)
 {
     const uint8_t *__restrict__ stream = stream_a;
     const uint4 *__restrict__   desc = desc_a;
@@ -545,7 +546,9 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
         if constexpr (DICT)
             for (uint32_t i = lane; i < (uint32_t)kDictMax; i += kLanes) dict[i] = i < ndict ? dict_g[i] : T(0);
         if (lane < 4) win[wn + lane] = T(0);
+        if (epi.out && wv == 0 && lane == 0) *reinterpret_cast<uint32_t *>(win + wn + 4) = 0u;      // wavefronts that have finished (the iterative epilogue)
     } else {
+        if (epi.out && threadIdx.x == 0) *reinterpret_cast<uint32_t *>(win + (WIN != 0 ? wn + 4 : 0)) = 0u;
         if constexpr (DICT)
             for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += blockDim.x) dict[i] = i < ndict ? dict_g[i] : T(0);
         if constexpr (WIN != 0) {
@@ -588,6 +591,17 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     uint32_t      *pace_g = pace ? pace + (size_t)(blockIdx.x & 7u) * nphases * kPaceSlots : nullptr;
     if (pace && pace_n > kPaceSlots) pace_g = nullptr;
     uint32_t       cur_phase = 0, next_bound = pw;
+    double         epi_acc = 0;
+    if (epi.out && epi.prev) {          // the iterative epilogue's look at the step before: its loads are in flight beside the first groups'
+        constexpr int kBatch = 16;
+        for (uint32_t i0 = lane; i0 < epi.nsets; i0 += kLanes * kBatch) {
+            double v[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) { const uint32_t i = i0 + u * kLanes; v[u] = i < epi.nsets ? epi.prev[(size_t)epi.nsets + i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) epi_acc += v[u];      // (ascending i: the order of a plain strided loop)
+        }
+    }
     T acc = 0;
     if constexpr (LOADER && WIN != 0) {
         if (gb < 0) { asm volatile("s_barrier" ::: "memory"); wn_eff = wn; }      // (meet the loaders in front of the first gather)
@@ -640,9 +654,66 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
         for (uint32_t p = cur_phase; p < nphases; p++) __hip_atomic_store(pace_g + (size_t)p * kPaceSlots + pace_slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (uint32_t i = lane; i < nri; i += kLanes) {
-        const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
-        store_y(yext + dst, ystage[i]);
+    if (!epi.out) {
+        for (uint32_t i = lane; i < nri; i += kLanes) {
+            const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
+            store_y(yext + dst, ystage[i]);
+        }
+        return;
+    }
+    // The iterative caller's step in the write-out (cvr_power_iteration on a square matrix without rows cut over chunks: every
+    // row is written here, once): the partial sums of x . y, y . y and x . x over this workgroup's rows, and the next iterate
+    // x_next = y / ||y of the step before|| (that step's partials are summed by every wavefront itself, in one fixed order: the same
+    // bits everywhere) -- instead of a pass over x and y behind every SpMV.  A wavefront's sums go to its own LDS cells; the one that
+    // finishes last adds the workgroup's up in wavefront order and writes the three results to the workgroup's place.
+    double inv = 1.0;
+    if (epi.prev) {
+        double acc = epi_acc;          // (this lane's share of the y . y partials of the step before: loaded in front of the main loop)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        inv = acc > 0 ? 1.0 / sqrt(acc) : 0.0;
+    }
+    T *const xnext = static_cast<T *>(epi.xnext);
+    double   axy = 0, ayy = 0, axx = 0;
+    constexpr int kRows = 8;            // x of eight rows per lane in flight (one round trip per 512 rows of the chunk)
+    for (uint32_t i0 = lane; i0 < nri; i0 += kLanes * kRows) {
+        T xv[kRows];
+#pragma unroll
+        for (int u = 0; u < kRows; u++) {
+            const uint32_t i = i0 + u * kLanes, dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
+            xv[u] = i < nri ? x[dst] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < kRows; u++) {
+            const uint32_t i = i0 + u * kLanes;
+            if (i >= nri) break;
+            const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
+            const T        yv = ystage[i];
+            const double   xd = (double)xv[u], yd = (double)yv;
+            store_y(yext + dst, yv);
+            axy += xd * yd; ayy += yd * yd; axx += xd * xd;
+            xnext[dst] = (T)(yd * inv);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { axy += __shfl_xor(axy, o); ayy += __shfl_xor(ayy, o); axx += __shfl_xor(axx, o); }
+    // (this wavefront's row accumulators are free now: their first 24 bytes take its sums; the arrival counter sits behind the window)
+    double   *cell = reinterpret_cast<double *>(ystage);
+    uint32_t *arrived = reinterpret_cast<uint32_t *>(win + (WIN != 0 ? wn + 4 : 0));
+    if (lane == 0) { cell[0] = axy; cell[1] = ayy; cell[2] = axx; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t before = 0;
+    if (lane == 0) before = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    before = __builtin_amdgcn_readfirstlane(before);
+    const uint32_t nlive = min(nw, nchunks - blk * nw);        // wavefronts of this workgroup with a chunk
+    if (before + 1 == nlive && lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (uint32_t w = 0; w < nlive; w++) {
+            const double *cw = reinterpret_cast<const double *>(ystage_all + w * ystage_n);
+            s0 += cw[0]; s1 += cw[1]; s2 += cw[2];
+        }
+        epi.out[blk] = s0; epi.out[(size_t)epi.nsets + blk] = s1; epi.out[2 * (size_t)epi.nsets + blk] = s2;
     }
 }
 
@@ -778,17 +849,21 @@ hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st)
     return hipGetLastError();
 }
 
+bool iter_epilogue_ok(const DeviceImage &img) { return img.phases > 1 && img.nshared == 0 && img.nchunks > 0 && (img.nchunks + (img.wpb > 1 ? img.wpb : 1) - 1) / (img.wpb > 1 ? img.wpb : 1) <= 1024u; }
+
 size_t spmv_lds_bytes(const DeviceImage &img)
 {
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;
     const bool     use_win = (img.win_elems > 0 && img.win_base != nullptr) || img.hub_n > 0;
     const uint32_t slots = img.phases > 1 ? 0u : (uint32_t)kLanes;      // (column phases: no steal slots, spmv_seg_kernel)
-    return (size_t)(wpb * (slots + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? ((img.hub_n + 3u) & ~3u) + img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8);
+    return (size_t)(wpb * (slots + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? ((img.hub_n + 3u) & ~3u) + img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8) + (img.phases > 1 ? 16 : 0);      // (column phases: + the arrival counter of the iterative epilogue)
 }
 
-hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup, const PanelArgs *multi, uint32_t multi_chunks, uint32_t multi_rounds)
+hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup, const PanelArgs *multi, uint32_t multi_chunks, uint32_t multi_rounds,
+                       const IterEpilogue *epi)
 {
     if (img.nchunks == 0 && !multi) return hipSuccess;
+    if (epi && (multi || !iter_epilogue_ok(img))) return hipErrorInvalidValue;
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;                     // consecutive chunks (wavefronts) per workgroup
     uint32_t       nblocks = (img.nchunks + wpb - 1) / wpb;
     // a hub table without a per-workgroup window: persistent workgroups (as many as fit the 256 CUs with this much LDS), each
@@ -837,7 +912,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
                              else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
 #define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
-                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi
+                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi, epi ? *epi : IterEpilogue{}
 #define CVR_SEG(T, SP, D, W, DI, LD)                                                                               \
     do {                                                                                                           \
         const dim3 sblock(kLanes * (wpb + (LD ? loaders : 0u)));                                                   \

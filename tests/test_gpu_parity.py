@@ -679,6 +679,39 @@ def test_power_iteration_device_resident():
         B.close()
 
 
+def test_power_iteration_step_in_the_spmv_epilogue(monkeypatch):
+    """On a matrix in the resident layout (column phases, no rows cut over chunks) the step's dot products and the next iterate come
+    out of the SpMV kernel's write-out (IterEpilogue): against the numpy loop, bit for bit again on a second run, against the loop with
+    the step as a pass of its own (CVR_ITER_UNFUSED), and fp32 with an eigenvalue whose square leaves fp32 (exact normalisation)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    from cvr_amd import power
+    nrows, ncols, rp, ci, va = synth.web_google_like()          # (full size: S = 48, no row is cut over chunks)
+    va = np.abs(va) + 0.5
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    assert A.info.col_phases > 1 and A.info.nshared == 0
+    lam, x, sec = power.power_iteration(A, nrows, iters=25)
+    lam_ref, x_ref = _power_iteration_numpy(rp, ci, va, iters=25)
+    assert abs(lam - lam_ref) <= 1e-9 * abs(lam_ref) and sec > 0
+    assert np.allclose(x.cpu().numpy(), x_ref, rtol=0, atol=1e-9)
+    lam2, x2, sec2 = power.power_iteration(A, nrows, iters=25)
+    assert lam2 == lam and torch.equal(x2.view(torch.int64), x.view(torch.int64))
+    monkeypatch.setenv("CVR_ITER_UNFUSED", "1")
+    lam3, x3, sec3 = power.power_iteration(A, nrows, iters=25)
+    monkeypatch.delenv("CVR_ITER_UNFUSED")
+    assert abs(lam3 - lam) <= 1e-12 * abs(lam) and np.allclose(x3.cpu().numpy(), x.cpu().numpy(), rtol=0, atol=1e-12)
+    assert min(sec, sec2) < sec3                     # one launch per iteration against two
+    A.close()
+    for scale_v, tol in ((1.0, 1e-4), (1e19, 1e-4)):
+        A32 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, (va * scale_v).astype(np.float32))
+        assert A32.info.col_phases > 1
+        lam32, x32, _ = power.power_iteration(A32, nrows, iters=25)
+        assert np.isfinite(lam32) and abs(lam32 - lam_ref * scale_v) <= tol * abs(lam_ref) * scale_v
+        assert np.allclose(x32.cpu().numpy().astype(np.float64), x_ref, rtol=0, atol=1e-5)
+        A32.close()
+
+
 @pytest.mark.parametrize("P", [2, 3, 7])
 def test_column_panels_parity(P):
     """column panels (each panel's slice of x L2-resident, partial sums combined in panel order): same tolerance
