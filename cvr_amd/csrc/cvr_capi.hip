@@ -693,7 +693,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     }
     const hipEvent_t e0 = h->events[0], e1 = h->events[1];
     HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
-    struct SegGuard { cvr::SegTable t; void *arena = nullptr; ~SegGuard() { (void)hipFree(arena); } } sg;      // (one allocation: six cost six times the call)
+    struct SegGuard { cvr::SegTable t; void *arena = nullptr; uint8_t *codes = nullptr; ~SegGuard() { (void)hipFree(arena); (void)hipFree(codes); } } sg;      // (one allocation: six cost six times the call)
     Part &p0 = h->parts[0];
     // column phases: the segment table (conversion-time only) gives every chunk room for as many segments as it has slots, so
     // that counting and filling are one kernel per chunk and the conversion follows without the host in between; the images of a
@@ -732,6 +732,12 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
         if (wstream != h->stream) HIP_TRY(cvr::launch_window(p.img, csr, wstream));
         if (p.img.phases > 1 && p.nchunks > 0) {
             cvr::SegTable &t = sg.t;
+            if (h->d_dict && cvr::seg_table_packed_ok(p.img) && !getenv("CVR_NO_DICT_CODES")) {      // the values as dictionary codes first: the converter then reads a byte per value (cvr_convert.hip: convert_lds_kernel)
+                (void)hipFree(sg.codes); sg.codes = nullptr;
+                HIP_TRY(hipMalloc(&sg.codes, std::max<size_t>((size_t)p.nnz_span, 1)));
+                HIP_TRY(cvr::launch_dict_codes(p.d_va, p.nnz_span - p.nnz, p.nnz_span, p.img.f32, h->d_dict, h->ndict, sg.codes, h->d_err, h->stream));
+                csr.codes = sg.codes;
+            }
             HIP_TRY(cvr::launch_seg_build(p.img, csr, t, h->stream));
             HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream, &t));
             HIP_TRY(hipMemcpyAsync(seg_flags, t.flags, sizeof(seg_flags), hipMemcpyDeviceToHost, h->stream));      // (the flags of all images so far)

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kLanes) void convert_lds_kernel(
     const int32_t *__restrict__ cidx, const T *__restrict__ vals, const int64_t *__restrict__ nzb,
     const uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, uint8_t *__restrict__ stream, uint8_t *__restrict__ target, uint32_t *__restrict__ err,
     int G, uint32_t nchunks, const uint32_t *__restrict__ nchunks_dev, uint32_t pad_col, const T *__restrict__ dict_g, uint32_t ndict,
-    const uint2 *__restrict__ seg_packed, uint32_t col_bits, const uint32_t *__restrict__ seg_flags)
+    const uint2 *__restrict__ seg_packed, uint32_t col_bits, const uint32_t *__restrict__ seg_flags, const uint8_t *__restrict__ codes_g)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t csm[];      // ring uint2 [2 kRingHalf] | dictionary [ndict -> 4] | columns u32 [64 S] | values T [64 S] or codes u8 [64 S]
     typedef typename Bits<T>::type bits_t;
@@ -364,6 +364,34 @@ __global__ __launch_bounds__(kLanes) void convert_lds_kernel(
     // columns and values, four consecutive elements per lane and load (16 bytes of columns, 16 or 32 of values); kVec such loads of
     // each are issued before the first is used; the dictionary searches of a batch run side by side
     constexpr uint32_t kVec = 4;
+    if (DICT && codes_g) {
+        // the values come as dictionary codes already (dict_codes_kernel: one coalesced pass over the values beside the planner): a byte
+        // per element instead of eight, and no search here
+        for (uint32_t i0 = lane * 4; i0 < n; i0 += kLanes * 4 * kVec) {
+            u32x4    c[kVec];
+            uint32_t cd[kVec];
+#pragma unroll
+            for (uint32_t u = 0; u < kVec; u++) {
+                const uint32_t i = i0 + u * kLanes * 4;
+                cd[u] = 0;
+                if (i + 4 <= n) {
+                    c[u] = *reinterpret_cast<const u32x4_dw *>(cidx + b + i);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) cd[u] |= (uint32_t)codes_g[b + i + q] << (8 * q);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { c[u][q] = i + q < n ? (uint32_t)cidx[b + i + q] : 0u; cd[u] |= (i + q < n ? (uint32_t)codes_g[b + i + q] : 0u) << (8 * q); }
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kVec; u++) {
+                const uint32_t i = i0 + u * kLanes * 4;
+                if (i >= n) break;
+                *reinterpret_cast<u32x4 *>(lcol + i) = c[u];
+                *reinterpret_cast<uint32_t *>(lcode + i) = cd[u];
+            }
+        }
+    } else
     for (uint32_t i0 = lane * 4; i0 < n; i0 += kLanes * 4 * kVec) {
         u32x4 c[kVec];
         T     v[kVec][4];
@@ -527,6 +555,51 @@ __global__ __launch_bounds__(kLanes) void convert_lds_kernel(
     if (cnt != 0) bad |= 1u;
     if (bad) atomicOr(err, bad);
     target[(size_t)k * kLanes + lane] = (uint8_t)tgt;
+}
+
+// code[j] = the dictionary code of vals[j] (j in [n0, n1)): one coalesced pass, sixteen values per thread and trip, the searches of a
+// trip side by side; a value that is not in the dictionary sets *err bit 2 (the converter's flag)
+template <typename T>
+__global__ __launch_bounds__(256) void dict_codes_kernel(const T *__restrict__ vals, long long n0, long long n1, const T *__restrict__ dict_g, uint32_t ndict,
+                                                         uint8_t *__restrict__ codes, uint32_t *__restrict__ err)
+{
+    typedef typename Bits<T>::type bits_t;
+    __shared__ bits_t dict[kDictMax];
+    for (uint32_t i = threadIdx.x; i < ndict; i += blockDim.x) dict[i] = __builtin_bit_cast(bits_t, dict_g[i]);
+    __syncthreads();
+    // four consecutive values per thread and load (a wavefront reads 2 KiB in a row), four such loads in flight, their sixteen searches side by side
+    constexpr int kVec = 4;
+    uint32_t      bad = 0;
+    const long long tstride = (long long)gridDim.x * blockDim.x * 4;
+    for (long long j0 = n0 + ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; j0 < n1; j0 += tstride * kVec) {
+        bits_t   v[kVec][4];
+        uint32_t lo[kVec][4], hi[kVec][4];
+#pragma unroll
+        for (int u = 0; u < kVec; u++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const long long j = j0 + u * tstride + q;
+                v[u][q] = j < n1 ? __builtin_bit_cast(bits_t, vals[j]) : (bits_t)0; lo[u][q] = 0; hi[u][q] = ndict;
+            }
+        for (uint32_t span = ndict; span > 0; span >>= 1) {
+#pragma unroll
+            for (int u = 0; u < kVec; u++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (lo[u][q] < hi[u][q]) { const uint32_t mid = (lo[u][q] + hi[u][q]) >> 1; if (dict[mid] < v[u][q]) lo[u][q] = mid + 1; else hi[u][q] = mid; }
+        }
+#pragma unroll
+        for (int u = 0; u < kVec; u++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const long long j = j0 + u * tstride + q;
+                if (j < n1) {
+                    if (lo[u][q] >= ndict || dict[lo[u][q]] != v[u][q]) bad = 4u;
+                    codes[j] = (uint8_t)lo[u][q];
+                }
+            }
+    }
+    if (bad) atomicOr(err, bad);
 }
 
 // ---- column phases: the segment table -------------------------------------------------------------------------------
@@ -1267,6 +1340,15 @@ hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTab
     return hipGetLastError();
 }
 
+hipError_t launch_dict_codes(const void *vals, int64_t n0, int64_t n1, bool f32, const void *dict, uint32_t ndict, uint8_t *codes, uint32_t *err_flag, hipStream_t st)
+{
+    if (n1 <= n0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)std::min<int64_t>(4096, (n1 - n0 + 256 * 16 - 1) / (256 * 16));
+    if (f32) hipLaunchKernelGGL(dict_codes_kernel<float>, dim3(blocks), dim3(256), 0, st, static_cast<const float *>(vals), (long long)n0, (long long)n1, static_cast<const float *>(dict), ndict, codes, err_flag);
+    else hipLaunchKernelGGL(dict_codes_kernel<double>, dim3(blocks), dim3(256), 0, st, static_cast<const double *>(vals), (long long)n0, (long long)n1, static_cast<const double *>(dict), ndict, codes, err_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg, const uint32_t *nchunks_dev)
 {
     if (img.nchunks == 0) return hipSuccess;
@@ -1295,8 +1377,9 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
             (void)hipFree(dbg);
         }
     } dbg_print{dbg, st, img.nchunks};
-    // CVR_CONVERT_LDS=1: the LDS-staged kernel (measured, not faster on the web-Google shape: DESIGN.md section 5.7)
-    if (seg && seg->packed && !img.c16 && !img.hub_n && getenv("CVR_CONVERT_LDS")) {
+    // the LDS-staged kernel: when the values come as dictionary codes (csr.codes), or with CVR_CONVERT_LDS=1 (with the values themselves it
+    // is not faster on the web-Google shape: DESIGN.md section 5.11)
+    if (seg && seg->packed && !img.c16 && !img.hub_n && ((csr.codes && img.dict) || getenv("CVR_CONVERT_LDS"))) {
         const size_t capl = (size_t)kLanes * img.S, vb = img.dict ? 1 : (img.f32 ? 4 : 8), db = img.dict ? (size_t)((img.ndict + 3u) & ~3u) * (img.f32 ? 4 : 8) : 0;
         const size_t lds = 16 * (size_t)kRingHalf + db + capl * (4 + vb) + 16;
         if (lds <= (48u << 10)) {           // at least three chunks per CU
@@ -1304,7 +1387,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 #define CVR_CONVERT_LDS(T, DI, TG)                                                                                                                         \
     hipLaunchKernelGGL((convert_lds_kernel<T, DI, TG>), dim3(img.nchunks), dim3(kLanes), lds, st, csr.col_idx, static_cast<const T *>(csr.vals), csr.nz_begin,  \
                        img.desc, img.desc2, img.stream, img.target, err_flag, img.G, img.nchunks, nchunks_dev, img.pad_col,                                      \
-                       static_cast<const T *>(img.dict), img.ndict, pk, img.col_bits, seg->flags)
+                       static_cast<const T *>(img.dict), img.ndict, pk, img.col_bits, seg->flags, img.dict ? csr.codes : nullptr)
 #define CVR_CONVERT_LDS_TG(T, DI) do { if (img.tag16) CVR_CONVERT_LDS(T, DI, true); else CVR_CONVERT_LDS(T, DI, false); } while (0)
             if (img.f32) { if (img.dict) CVR_CONVERT_LDS_TG(float, true); else CVR_CONVERT_LDS_TG(float, false); }
             else         { if (img.dict) CVR_CONVERT_LDS_TG(double, true); else CVR_CONVERT_LDS_TG(double, false); }

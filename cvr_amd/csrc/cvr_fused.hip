@@ -27,11 +27,12 @@ struct Attempt {
     uint32_t *d_pad = nullptr;
     void     *arena = nullptr;
     void     *d_dict = nullptr;
+    uint8_t  *d_codes = nullptr;        // the values as dictionary codes (conversion only)
     bool      keep = false;
     ~Attempt()
     {
         if (keep) return;
-        for (void *p : {(void *)img.stream, (void *)img.desc, (void *)img.desc2, (void *)img.target, (void *)img.win_base, (void *)img.pace, (void *)d_nzb, (void *)d_pad, arena, d_dict})
+        for (void *p : {(void *)img.stream, (void *)img.desc, (void *)img.desc2, (void *)img.target, (void *)img.win_base, (void *)img.pace, (void *)d_nzb, (void *)d_pad, arena, d_dict, (void *)d_codes})
             if (p) (void)hipFree(p);
         delete img.pace_epoch;
     }
@@ -93,6 +94,7 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     HIP_TRY(hipMalloc(&img.stream, (size_t)room * img.G * gb_plain + 8 * gb_plain));      // (room for either form of the values; the staged path's slack behind the last chunk)
     HIP_TRY(hipMalloc(&at.arena, arena_bytes));
     if (with_dict) HIP_TRY(hipMalloc(&at.d_dict, (size_t)vs * cvr::kDictMax));
+    if (with_dict && !getenv("CVR_NO_DICT_CODES")) HIP_TRY(hipMalloc(&at.d_codes, (size_t)nz1));
     cvr::SegTable seg;
     uint8_t      *res_dev = nullptr;
     {
@@ -108,10 +110,10 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     // events: the plan is on the device (the windows wait for it on their stream); the probe's / the dictionary scan's results are on the
     // host; the segment table is written (its total is summed beside the conversion); the side stream's part of the chain is done
     struct Events {
-        hipEvent_t planned = nullptr, probed = nullptr, scanned = nullptr, seg_done = nullptr, side_done = nullptr;
-        ~Events() { for (hipEvent_t e : {planned, probed, scanned, seg_done, side_done}) if (e) (void)hipEventDestroy(e); }
+        hipEvent_t planned = nullptr, probed = nullptr, scanned = nullptr, seg_done = nullptr, side_done = nullptr, coded = nullptr;
+        ~Events() { for (hipEvent_t e : {planned, probed, scanned, seg_done, side_done, coded}) if (e) (void)hipEventDestroy(e); }
     } ev;
-    for (hipEvent_t *e : {&ev.planned, &ev.probed, &ev.scanned, &ev.seg_done, &ev.side_done}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t *e : {&ev.planned, &ev.probed, &ev.scanned, &ev.seg_done, &ev.side_done, &ev.coded}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     const hipEvent_t planned = ev.planned;
 
     // pinned: probe output | dictionary table | flags (the first kPinnedSmall bytes, as in auto_layout) | results of the chain | dictionary values
@@ -125,8 +127,11 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
 
     HIP_TRY(hipStreamSynchronize(h->stream));          // the upload (and the memsets above)
     const double t0 = now_s();
-    // ---- submission
-    // (the critical path first: planner -> segment table; then the two analysis passes the host waits for; then the side work)
+    // ---- submission: the critical path first (planner -> segment table on the handle's stream), then the two analysis passes the host
+    // waits for (probe: side stream 1; dictionary scan: side stream 0), then the side work behind them (windows, sum of the segment counts).
+    // Measured orders (tools/wg_create_once.py, CVR_FUSED_TRACE): this one ends after 189-191 us; the dictionary scan first and the
+    // codes pass as early as its result allows 199-215 (everything then runs beside the segment table, which takes twice as long for it);
+    // the analysis passes in front of the planner 231-240 (the host needs ~4 us per call: the planner starts 25 us late).
     hipError_t e = hipEventRecord(h->events[0], h->stream);
     cvr::DevicePlan dp;
     cvr::PlanTables tables;
@@ -134,8 +139,7 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     tables.totals = reinterpret_cast<unsigned long long *>(res_dev);
     if (e == hipSuccess) e = cvr::plan_chunks_device_enqueue(part.d_rp, nrows, nz1, pp.S, opt.split_threshold, max_rows, h->stream, &h->plan_ws, &dp, &tables);
     if (e == hipSuccess && !dp.declined) e = hipEventRecord(planned, h->stream);
-    // the segment table needs nothing the host decides below (a layout the probe does not confirm wastes it): straight behind the planner;
-    // the windows and the sum of the segment counts run on the side stream, behind the dictionary scan
+    // the segment table needs nothing the host decides below (a layout the probe does not confirm wastes it): straight behind the planner
     const uint32_t *nch_dev = reinterpret_cast<const uint32_t *>(dp.totals);      // (little endian: the low half of totals[0])
     cvr::DeviceCsr  csr;
     csr.row_ptr = part.d_rp; csr.col_idx = part.d_ci; csr.vals = part.d_va; csr.nz_begin = at.d_nzb; csr.pad_cnt = at.d_pad;
@@ -155,7 +159,7 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     if (go && e == hipSuccess) e = cvr::launch_seg_total(seg, (uint32_t)room, nch_dev, reinterpret_cast<uint32_t *>(res_dev + 40), side);
     if (go && e == hipSuccess) e = hipEventRecord(ev.side_done, side);
     const double t_sub1 = now_s();
-    // ---- the host looks at the probe and the dictionary while the planner runs
+    // ---- the host looks at the probe and the dictionary while planner and segment table run
     if (e == hipSuccess) e = hipEventSynchronize(ev.probed);
     if (e == hipSuccess) e = hipEventSynchronize(ev.scanned);
     if (e != hipSuccess || dp.declined) {
@@ -186,13 +190,21 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     }
     const double t_dict = now_s();
     if (!confirmed) {
-        (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(side);
+        (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(side); (void)hipStreamSynchronize(pstream);
         NOT_TAKEN("probe did not confirm window + phases");
     }
-    // ---- the rest of the chain: the conversion, in the variant the dictionary scan decides.  It reads the dictionary from the pinned
-    // host buffer (a few values per workgroup); the copy the SpMV kernel will use goes to the device beside it
+    // ---- the rest of the chain: the conversion, in the variant the dictionary scan decides.  With a dictionary the values are first
+    // rewritten as codes (one coalesced pass on the probe's stream, idle by now, beside the end of the segment table): the converter then
+    // reads a byte per value and searches nothing.  It reads the dictionary itself from the pinned host buffer (a few values per
+    // workgroup); the copy the SpMV kernel will use goes to the device in front of the codes pass.
     if (ndict) e = hipMemcpyAsync(at.d_dict, dict_host, (size_t)vs * ndict, hipMemcpyHostToDevice, pstream);
     img.dict = ndict ? dict_host : nullptr; img.ndict = ndict;
+    if (ndict && at.d_codes) {
+        if (e == hipSuccess) e = cvr::launch_dict_codes(part.d_va, nz0, nz1, f32, at.d_dict, ndict, at.d_codes, reinterpret_cast<uint32_t *>(res_dev + 44), pstream);
+        if (e == hipSuccess) e = hipEventRecord(ev.coded, pstream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->stream, ev.coded, 0);
+        csr.codes = at.d_codes;
+    }
     if (e == hipSuccess) e = cvr::launch_convert(img, csr, reinterpret_cast<uint32_t *>(res_dev + 44), h->stream, &seg, nch_dev);
     img.dict = ndict ? at.d_dict : nullptr;
     if (e == hipSuccess) e = hipEventRecord(h->events[1], h->stream);
@@ -227,6 +239,7 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     h->ndict = ndict;
     h->dict_scanned = true;
     (void)hipFree(at.arena);
+    if (at.d_codes) (void)hipFree(at.d_codes);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, h->events[0], h->events[1]));
     cvr_info &in = h->info;

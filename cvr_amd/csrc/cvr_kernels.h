@@ -69,6 +69,7 @@ struct DeviceCsr {
     const void     *vals = nullptr;
     const int64_t  *nz_begin = nullptr;   // [nchunks+1]
     const uint32_t *pad_cnt = nullptr;    // [nchunks]
+    const uint8_t  *codes = nullptr;      // optional: the dictionary code of every value, same indexing as vals (launch_dict_codes)
 };
 
 // column phases: the segment table of every chunk, built on the device from the CSR and the plan
@@ -92,6 +93,8 @@ bool       seg_table_packed_ok(const DeviceImage &img);      // launch_seg_build
 // CSR -> CVR64 (one wavefront per chunk).  *err_flag (device u32, zeroed by the caller) gets bit 0 if a
 // lane stream did not drain, bit 1 if stealing found no over-full lane, bit 2 if a value is missing from the dictionary.
 hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg = nullptr, const uint32_t *nchunks_dev = nullptr);
+// codes[j] = dictionary code of vals[j], j in [n0, n1) (one coalesced pass; *err_flag bit 2: a value that is not in the dictionary)
+hipError_t launch_dict_codes(const void *vals, int64_t n0, int64_t n1, bool f32, const void *dict, uint32_t ndict, uint8_t *codes, uint32_t *err_flag, hipStream_t st);
 
 // value-dictionary detection over vals[n0, n1) on the device: `table` = 1024 u64 slots preset to all ones, flags[0] bit 0 =
 // more than kDictMax distinct values, bit 1 = the all-ones pattern occurs, flags[1] = entries in the table

@@ -5,23 +5,27 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r03_convert_clocks.log; cd $R
 export CVR_NO_FUSED=1
 {
-echo "# default converter (per-lane global loads), every 256th chunk"
+echo "# converter with per-lane global loads (CVR_NO_DICT_CODES=1: the round-2 kernel), every 256th chunk"
+CVR_NO_DICT_CODES=1 CVR_CONVERT_CLOCKS=1 python3 tools/wg_create_once.py 2>&1 | grep "\[convert\]" | tail -7
+echo "# LDS-staged converter fed with the values (CVR_NO_DICT_CODES=1 CVR_CONVERT_LDS=1)"
+CVR_NO_DICT_CODES=1 CVR_CONVERT_LDS=1 CVR_CONVERT_CLOCKS=1 python3 tools/wg_create_once.py 2>&1 | grep "\[convert\]" | tail -7
+echo "# LDS-staged converter fed with dictionary codes (the default when the matrix has a dictionary)"
 CVR_CONVERT_CLOCKS=1 python3 tools/wg_create_once.py 2>&1 | grep "\[convert\]" | tail -7
-echo "# LDS-staged converter (CVR_CONVERT_LDS=1)"
-CVR_CONVERT_LDS=1 CVR_CONVERT_CLOCKS=1 python3 tools/wg_create_once.py 2>&1 | grep "\[convert\]" | tail -7
 echo "# segment table (seg_scan_kernel), every 256th chunk"
 CVR_SEG_CLOCKS=1 python3 tools/wg_create_once.py 2>&1 | grep "\[seg_scan\]" | tail -8
 } > $OUT
 cd /tmp; export TMPDIR=/tmp
-for v in "" 1; do
-  if [ -n "$v" ]; then export CVR_CONVERT_LDS=1; fi
+for v in codes values_lds values_global; do
+  unset CVR_CONVERT_LDS CVR_NO_DICT_CODES
+  if [ $v = values_lds ]; then export CVR_CONVERT_LDS=1 CVR_NO_DICT_CODES=1; fi
+  if [ $v = values_global ]; then export CVR_NO_DICT_CODES=1; fi
   rm -rf /tmp/cc_trace; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cc_trace -- python3 $R/tools/wg_create_once.py > /dev/null 2>&1
-  echo "# kernel trace, CVR_CONVERT_LDS=${v:-0}: name, calls, average ns" >> $OUT
+  echo "# kernel trace, converter fed with $v: name, calls, average ns" >> $OUT
   python3 - <<PY >> $OUT
 import csv, glob
 for f in glob.glob("/tmp/cc_trace/*/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
-        if any(k in r["Name"] for k in ("convert", "seg_", "window_kernel")): print("%-60s %5s %10.0f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"])))
+        if any(k in r["Name"] for k in ("convert", "seg_", "window_kernel", "dict_codes")): print("%-60s %5s %10.0f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"])))
 PY
 done
 cat $OUT
