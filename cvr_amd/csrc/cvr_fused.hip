@@ -85,16 +85,20 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t n1 = (size_t)room * (size_t)cap;
     const size_t o_begin = 0, o_cnt = o_begin + up(sizeof(int64_t) * n1), o_flags = o_cnt + up(sizeof(uint32_t) * ((size_t)room + 1)), arena_bytes = o_flags + 256;
-    HIP_TRY(hipMalloc(&at.d_nzb, sizeof(int64_t) * ((size_t)room + 1)));
-    HIP_TRY(hipMalloc(&at.d_pad, sizeof(uint32_t) * (size_t)room));
-    HIP_TRY(hipMalloc(&img.desc, 16 * (size_t)room));
-    HIP_TRY(hipMalloc(&img.desc2, 8 * (size_t)room));
-    HIP_TRY(hipMalloc(&img.target, 64 * (size_t)room));
-    HIP_TRY(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)room / img.wpb + 1)));
-    HIP_TRY(hipMalloc(&img.stream, (size_t)room * img.G * gb_plain + 8 * gb_plain));      // (room for either form of the values; the staged path's slack behind the last chunk)
-    HIP_TRY(hipMalloc(&at.arena, arena_bytes));
-    if (with_dict) HIP_TRY(hipMalloc(&at.d_dict, (size_t)vs * cvr::kDictMax));
-    if (with_dict && !getenv("CVR_NO_DICT_CODES")) HIP_TRY(hipMalloc(&at.d_codes, (size_t)nz1));
+    // (buffers for as many chunks as the layout allows; if the device has no room for them the staged path, which allocates what the plan needs, takes over)
+    bool ok = true;
+    auto alloc = [&ok](auto **p, size_t bytes) { if (ok && hipMalloc(reinterpret_cast<void **>(p), bytes) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; ok = false; } };
+    alloc(&at.d_nzb, sizeof(int64_t) * ((size_t)room + 1));
+    alloc(&at.d_pad, sizeof(uint32_t) * (size_t)room);
+    alloc(&img.desc, 16 * (size_t)room);
+    alloc(&img.desc2, 8 * (size_t)room);
+    alloc(&img.target, 64 * (size_t)room);
+    alloc(&img.win_base, sizeof(uint32_t) * ((size_t)room / img.wpb + 1));
+    alloc(&img.stream, (size_t)room * img.G * gb_plain + 8 * gb_plain);      // (room for either form of the values; the staged path's slack behind the last chunk)
+    alloc(&at.arena, arena_bytes);
+    if (with_dict) alloc(&at.d_dict, (size_t)vs * cvr::kDictMax);
+    if (with_dict && !getenv("CVR_NO_DICT_CODES")) alloc(&at.d_codes, (size_t)nz1);
+    if (!ok) NOT_TAKEN("no device memory for the attempt's buffers");
     cvr::SegTable seg;
     uint8_t      *res_dev = nullptr;
     {
