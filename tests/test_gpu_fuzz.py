@@ -106,3 +106,53 @@ def test_fuzz_parity(ncases=None, seed=None):
         y2, _ = A.spmv(x)
         assert np.array_equal(y.view(np.uint8), y2.view(np.uint8)), ctx
         A.close()
+
+
+def test_fuzz_one_submission_preprocessing():
+    """Matrices of the size the automatic layout makes resident (350 000 - 600 000 rows; local and far columns mixed, empty rows, a few
+    rows far beyond a chunk, square and rectangular, fp64 / fp32, few or many distinct values): cvr_create's one-submission path
+    against the staged one -- same layout, same image and descriptors bit for bit, same y bits -- and y against the CSR oracle."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(int(os.environ.get("CVR_FUZZ_SEED", "20261004")))
+    taken = 0
+    for case in range(int(os.environ.get("CVR_FUZZ_BIG_CASES", "5"))):
+        f32 = bool(rng.integers(0, 3) == 0)
+        nrows = int(rng.integers(700_000, 900_000)) if f32 else int(rng.integers(350_000, 600_000))      # (x beyond 2.5 MB: column phases)
+        ncols = nrows if rng.integers(0, 3) else nrows + int(rng.integers(1, 200_000))
+        deg = rng.zipf(2.2, nrows).clip(0, 400)
+        deg[rng.random(nrows) < rng.choice([0.0, 0.05, 0.3])] = 0                 # empty rows
+        for r in rng.integers(0, nrows, int(rng.integers(0, 4))):
+            deg[r] = int(rng.integers(3_000, 12_000))                             # rows cut over several chunks
+        deg = (deg * (2_600_000 / max(deg.sum(), 1))).astype(np.int64).clip(0, ncols // 2) if deg.sum() < 2_600_000 else deg
+        rows = np.repeat(np.arange(nrows), deg)
+        local = rng.random(len(rows)) < rng.choice([0.3, 0.5, 0.7])
+        cols = np.where(local, np.clip(rows + rng.normal(0, 1500, len(rows)).astype(np.int64), 0, ncols - 1), rng.integers(0, ncols, len(rows)))
+        few = bool(rng.integers(0, 2))
+        vals = rng.choice(np.array([1.0, 2.0, -1.0, 0.5, 3.0, 1e-3, -7.25]), size=len(rows)) if few else rng.standard_normal(len(rows))
+        M = sp.csr_matrix((vals, (rows, cols)), shape=(nrows, ncols))
+        M.sum_duplicates(); M.sort_indices()
+        rp, ci = M.indptr.astype(np.int64), M.indices.astype(np.int32)
+        va = M.data.astype(np.float32 if f32 else np.float64)
+        ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), f32=f32, few=few)
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+        os.environ["CVR_NO_FUSED"] = "1"
+        try:
+            B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+        finally:
+            del os.environ["CVR_NO_FUSED"]
+        ia, ib = A.info, B.info
+        taken += ia.preprocess_fused
+        for f in ("steps_per_chunk", "waves_per_block", "x_window", "col_phases", "value_dict", "nchunks", "nshared", "nsegments", "row_tags16", "piece_max", "chunk_row_cap"):
+            assert getattr(ia, f) == getattr(ib, f), (f, ctx)
+        ea, eb = A.export_image(), B.export_image()
+        for key in ("desc", "target", "shared", "image"):
+            assert np.array_equal(ea[key], eb[key]), (key, ctx)
+        x = O.x_vec_fast(ncols, "rand").astype(va.dtype)
+        ya, _ = A.spmv(x)
+        yb, _ = B.spmv(x)
+        assert np.array_equal(ya.view(np.uint8), yb.view(np.uint8)), ctx
+        yref, absy = O.csr_spmv64(rp, ci, va.astype(np.float64), x.astype(np.float64))
+        tol = 1e-5 if f32 else 1e-12
+        assert np.all(np.abs(ya.astype(np.float64) - yref) <= tol * absy + 1e-300), ctx
+        A.close(); B.close()
+    assert taken >= 3                      # (most of the cases are of the resident kind: otherwise the test tests nothing)
