@@ -322,6 +322,7 @@ def test_header_is_plain_c99_and_links_against_the_library(tmp_path):
     src = tmp_path / "abi.c"
     src.write_text(r'''
 #include <stdio.h>
+#include <stddef.h>
 #include "cvr_amd.h"
 int main(void)
 {
@@ -336,7 +337,8 @@ int main(void)
     int P = cvr_auto_panels(&v, &miss);
     cvr_handle *h = 0;
     int rc = cvr_device_count() > 0 ? 0 : cvr_create(&h, &v, &o);
-    printf("%s|%d|%d|%d|%d|%d|%d\n", cvr_version(), P, rc, (int)sizeof(cvr_csr_view), (int)sizeof(cvr_options), (int)sizeof(cvr_info), (int)sizeof(cvr_timing));
+    printf("%s|%d|%d|%d|%d|%d|%d|%d|%d|%d|%d\n", cvr_version(), P, rc, (int)sizeof(cvr_csr_view), (int)sizeof(cvr_options), (int)sizeof(cvr_info), (int)sizeof(cvr_timing),
+           (int)offsetof(cvr_info, preprocess_fused), (int)offsetof(cvr_info, nsegments), (int)offsetof(cvr_options, piece_max), (int)offsetof(cvr_timing, gather_mean_s));
     return 0;
 }
 ''')
@@ -348,6 +350,8 @@ int main(void)
     assert int(out[2]) in (0, capi.ERR_NO_DEVICE)
     assert int(out[3]) == C.sizeof(capi.CsrView) and int(out[4]) == C.sizeof(capi.Options)
     assert int(out[5]) == C.sizeof(capi.Info) and int(out[6]) == C.sizeof(capi.Timing)
+    assert int(out[7]) == capi.Info.preprocess_fused.offset and int(out[8]) == capi.Info.nsegments.offset          # (the fields a round added last)
+    assert int(out[9]) == capi.Options.piece_max.offset and int(out[10]) == capi.Timing.gather_mean_s.offset
 
 
 def test_loader_fuzz_against_the_pinned_oracle_loader(tmp_path):
