@@ -488,7 +488,9 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
         HIP_TRY(hipMemcpyAsync(img.shared, plan.shared.data(), sizeof(cvr::Shared) * plan.shared.size(), hipMemcpyHostToDevice, h->stream));
     // narrow chunks (plain layout only): if every chunk spans fewer than 32 767 columns -- banded matrices -- the image stores
     // 16-bit column offsets from the chunk's smallest column: 10 instead of 12 bytes per fp64 slot of a stream-bound SpMV
-    if (popt.narrow_cols != 0 && nchunks > 0 && img.wpb == 1 && img.win_elems == 0 && img.phases <= 1 && img.hub_n == 0 && !opt.debug_col_mask) {
+    // (not for a column panel that will run on one XCD beside seven others: those launches take 32-bit columns, and a panel is wide)
+    if (popt.narrow_cols != 0 && nchunks > 0 && img.wpb == 1 && img.win_elems == 0 && img.phases <= 1 && img.hub_n == 0 && !opt.debug_col_mask &&
+        !(opt.panel_on_one_xcd && popt.narrow_cols < 0)) {
         uint32_t *d_wide = nullptr, wide = 1;
         HIP_TRY(hipMalloc(&img.cbase, sizeof(uint32_t) * (size_t)nchunks));
         HIP_TRY(hipMalloc(&d_wide, sizeof(uint32_t)));
