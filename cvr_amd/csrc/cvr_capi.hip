@@ -466,7 +466,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             // per panel: its row pointers made panel-local (a slice of the split's, minus the panel's first position), a hub
             // table of the most popular columns of its own range, and the chunk plan -- all from device arrays
             const double tp = now_s(), hub0 = in.hub_select_s;
-            for (int p = 0; p < P; p++) {
+            bool         batched = false;
+            rc = plan_panels_batched(h, dsg.d, nsubs, ncols, f32, popts, pps, drs, &batched);      // (panels without hub tables: all plans as one submission)
+            if (rc) { cvr_destroy(h); return rc; }
+            for (int p = 0; p < P && !batched; p++) {
                 Part         &part = h->parts[(size_t)p];
                 const int64_t ns = nsubs[(size_t)p], nzp = dsg.d.off[p + 1] - dsg.d.off[p];
                 CREATE_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)ns + 1)));

@@ -220,7 +220,7 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     const double t_end = now_s();
     if (getenv("CVR_FUSED_TRACE")) fprintf(stderr, "[cvr fused] host: first submission %.0f us, probe + scan waited for until %.0f, dictionary %.0f, second submission %.0f, end %.0f\n", (t_sub1 - t0) * 1e6, (t_probe - t0) * 1e6, (t_dict - t0) * 1e6, (t_sub2 - t0) * 1e6, (t_end - t0) * 1e6);
     if (e != hipSuccess) { (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(side); (void)hipStreamSynchronize(pstream); return fail(CVR_ERR_HIP, "fused preprocessing: %s", hipGetErrorString(e)); }
-    const int64_t nchunks = (int64_t)res_totals[0], nshared = (int64_t)res_totals[1], most = (int64_t)res_totals[3];
+    const int64_t nchunks = (int64_t)res_totals[0], nshared = (int64_t)res_totals[1], most = (int64_t)(res_totals[3] >> 1);
     if ((res_totals[2] & 3ull) || nchunks > room || nshared > dp.bound) NOT_TAKEN("more chunks than workgroup slots (or a row block beyond 32-bit slots)");      // the staged path lengthens the chunks
     if (res_small[0] & 2u) NOT_TAKEN("a chunk beyond the launch's length");                                                     // (a chunk the launch has no room for: cannot happen, the plan keeps to S)
     if (res_small[0] & 1u) return fail(CVR_ERR_INVALID, "col_phases needs the column indices of every row in ascending order");

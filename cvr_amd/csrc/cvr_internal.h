@@ -202,6 +202,9 @@ struct PartPlan {
     bool     lds_short = false;    // column phases do not fit beside the window
     int      plan_threads = 0;     // 0: the planner's own small team; 1: the caller plans several images side by side
     int64_t  hub_n = 0;            // hub table entries staged in LDS in front of the window (decided before planning)
+    // the plan stayed on the device (plan_panels_batched): nzb / pad / desc / cut rows are in the part's buffers already, only the counts came back
+    bool     tables_on_device = false;
+    int64_t  dev_nchunks = 0, dev_nshared = 0;
 };
 
 // rows in device memory (rp == nullptr): row_ptr at dr->rp, first and last entry dr->nz0, dr->nz1; planned on the device
@@ -216,6 +219,7 @@ constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags =
 int        pick_steps(int64_t nslots_est, int64_t max_row = 0, double cus = 256.0);
 hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr = nullptr);
 int64_t    plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt);
+void       plan_stage(PartPlan &pp, bool f32);
 bool       resident_candidate(double slots, int cus, int *best_w, int *best_S);
 int        setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, int64_t nchunks, int64_t nshared, const IOpt &opt, const IOpt &popt);
 // cvr_fused.hip: analysis, plan and conversion of a single resident-layout image as one submission (no host round trip between planner
@@ -230,6 +234,8 @@ int        auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
                        const std::function<int(const IOpt &)> *meanwhile = nullptr);
 int        choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt, PartPlan &pp,
                        bool allow_reorder);
+int        plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vector<int64_t> &nsubs, int64_t ncols, bool f32, const std::vector<IOpt> &popts,
+                               std::vector<PartPlan> &pps, std::vector<DevRows> &drs, bool *done);
 int        build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
                       hipMemcpyKind civa_kind, bool f32, const IOpt &opt, double *plan_s, PartPlan *planned = nullptr, const DevRows *dr = nullptr);
 int        finish_part(cvr_handle *h, Part &part);

@@ -129,13 +129,15 @@ struct DevicePlan {
     int64_t     bound = 0, thr = 0, max_rows = 0;       // room of the record arrays; the threshold and row cap in effect
     const void *chunks = nullptr;                       // [bound] cvr::Chunk records
     const void *shared = nullptr;                       // [bound] cvr::Shared records
-    const unsigned long long *totals = nullptr;         // [4] chunks, cut rows, flags (1: host must plan, 2: tables too small), most rows in a chunk
+    const unsigned long long *totals = nullptr;         // [4] chunks, cut rows, flags (1: host must plan, 2: tables too small), 2 * (most rows in a chunk) + (such a chunk has a pad segment)
     bool        chunks_shared_adjacent = false;
 };
 struct PlanTables {
     uint4 *desc = nullptr; uint2 *desc2 = nullptr; uint32_t *pad = nullptr; int64_t *nzb = nullptr; uint32_t room = 0; bool phased = false;
     unsigned long long *totals = nullptr;      // where the four totals go (null: the planner's scratch)
 };
+int64_t    plan_bound_device(int64_t nrows, int64_t nz_end, int32_t S, int64_t max_rows);       // room of the planner's record arrays / of the tables
+size_t     plan_scratch_bytes(int64_t nrows, int64_t nz_end, int32_t S, int64_t max_rows);      // device scratch of one plan
 hipError_t plan_chunks_device_enqueue(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, hipStream_t st, PlanScratch *ws,
                                       DevicePlan *out, const PlanTables *tables);
 hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, Plan *out, bool *fallback,

@@ -63,6 +63,24 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
     return max_rows;
 }
 
+// LDS budget without phases, once the plan's fullest chunk is known (pp.max_nseg): steal slots and dictionary are fixed; the row-sum
+// stage is sized for the chunk with the most segments, so every chunk writes its y coalesced (chunks of very short rows beyond the
+// stage store directly); the window takes what it asked for, the stage at least 64 rows per wavefront, and whatever does not fit is
+// cut: first the stage down to 512 rows per wavefront, then the window.
+void plan_stage(PartPlan &pp, bool f32)
+{
+    if (pp.phases == 1) {
+        const int64_t vs = f32 ? 4 : 8, total = (int64_t)cvr::kLdsBytes / vs;
+        const int64_t fixed = (int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + 4 + ((pp.hub_n + 3) & ~(int64_t)3);     // dictionary room is reserved before it is known
+        int64_t stage = std::min<int64_t>(std::max<int64_t>((pp.max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
+        if (const char *cap = getenv("CVR_YSTAGE_CAP")) stage = std::min<int64_t>(stage, std::max<int64_t>(64, atoll(cap) & ~(int64_t)63));      // (experiments: occupancy against staged write-out)
+        if (fixed + pp.wpb * stage + pp.win > total) stage = std::max<int64_t>(std::min<int64_t>(stage, 512), ((total - fixed - pp.win) / pp.wpb) & ~(int64_t)63);
+        if (stage < 64) stage = 64;
+        if (fixed + pp.wpb * stage + pp.win > total) pp.win = std::max<int64_t>(0, total - fixed - pp.wpb * stage) & ~(int64_t)3;
+        pp.stage = stage;
+    }
+}
+
 hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr)
 {
     const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
@@ -126,20 +144,7 @@ hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const
         for (const cvr::Chunk &c : plan.chunks) most = std::max(most, c.nrows_in);
         pp.stage = std::min<int64_t>(pp.stage, std::max<int64_t>(64, (most + 1 + 3) & ~(int64_t)3));
     }
-    if (pp.phases == 1) {
-        // LDS budget without phases: steal slots and dictionary are fixed; the row-sum stage is sized for the chunk with the
-        // most segments, so every chunk writes its y coalesced (chunks of very short rows beyond the stage store directly);
-        // the window takes what it asked for, the stage at least 64 rows per wavefront, and whatever does not fit is cut:
-        // first the stage down to 512 rows per wavefront, then the window.
-        const int64_t vs = f32 ? 4 : 8, total = (int64_t)cvr::kLdsBytes / vs;
-        const int64_t fixed = (int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + 4 + ((pp.hub_n + 3) & ~(int64_t)3);     // dictionary room is reserved before it is known
-        int64_t stage = std::min<int64_t>(std::max<int64_t>((pp.max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
-        if (const char *cap = getenv("CVR_YSTAGE_CAP")) stage = std::min<int64_t>(stage, std::max<int64_t>(64, atoll(cap) & ~(int64_t)63));      // (experiments: occupancy against staged write-out)
-        if (fixed + pp.wpb * stage + pp.win > total) stage = std::max<int64_t>(std::min<int64_t>(stage, 512), ((total - fixed - pp.win) / pp.wpb) & ~(int64_t)63);
-        if (stage < 64) stage = 64;
-        if (fixed + pp.wpb * stage + pp.win > total) pp.win = std::max<int64_t>(0, total - fixed - pp.wpb * stage) & ~(int64_t)3;
-        pp.stage = stage;
-    }
+    plan_stage(pp, f32);
     return hipSuccess;
 }
 
@@ -376,6 +381,103 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
     return CVR_OK;
 }
 
+// The chunk plans of a device split's column panels as one submission: every panel's planner is enqueued (three streams take turns,
+// each with scratch of its own), its last kernel writes nzb / pad / desc of the panel's image on the device, the cut rows are copied
+// beside them, and only the counts come back -- one synchronisation for all panels instead of two per panel with the plan's records in
+// between (sixteen panels of the LiveJournal shape: 5.0 -> ~1 ms).  For panels without hub tables and phases whose chunk length does
+// not depend on a look at the rows; *done = false: the caller plans panel by panel (nothing is left allocated).
+int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vector<int64_t> &nsubs, int64_t ncols, bool f32, const std::vector<IOpt> &popts,
+                        std::vector<PartPlan> &pps, std::vector<DevRows> &drs, bool *done)
+{
+    *done = false;
+    const int P = (int)h->parts.size();
+    if (P < 2 || getenv("CVR_SERIAL_PANEL_PLANS") || getenv("CVR_HOST_PLAN")) return CVR_OK;
+    std::vector<int64_t> bound((size_t)P), maxr((size_t)P);
+    size_t               scratch = 0;
+    for (int p = 0; p < P; p++) {
+        const IOpt   &o = popts[(size_t)p];
+        const int64_t ns = nsubs[(size_t)p], nzp = d.off[p + 1] - d.off[p];
+        PartPlan     &pp = pps[(size_t)p];
+        if (ns <= 0 || nzp <= 0 || o.hub_table != 0) return CVR_OK;
+        pp.S = o.steps_per_chunk;
+        if (pp.S == 0) {
+            const double cus = o.panel_on_one_xcd ? (double)o.cus / o.xcds : (double)o.cus;
+            if ((double)(nzp + ns / 4) / (64.0 * 32.0) <= cus * 12.0) return CVR_OK;          // (the chunk length would depend on the longest row: plan_part)
+            pp.S = pick_steps(nzp + ns / 4, 0, cus);
+        }
+        if (!cvr::plan_on_device_ok(pp.S)) return CVR_OK;
+        maxr[(size_t)p] = plan_layout(pp, ncols, f32, o);
+        if (pp.phases > 1 || pp.hub_n > 0) return CVR_OK;
+        bound[(size_t)p] = cvr::plan_bound_device(ns, nzp, pp.S, maxr[(size_t)p]);
+        if (ns + 1 + 2 * bound[(size_t)p] >= (int64_t)0xffffffffu || bound[(size_t)p] >= (int64_t)0x7fffffff) return CVR_OK;
+        scratch = std::max(scratch, cvr::plan_scratch_bytes(ns, nzp, pp.S, maxr[(size_t)p]));
+    }
+    hipStream_t sts[3] = {h->stream, side_stream(h->device, 0), side_stream(h->device, 1)};
+    int         nst = 1;
+    if (sts[1] && sts[2]) nst = 3;
+    struct Own {
+        cvr::PlanScratch ws[3];
+        unsigned long long *d_tot = nullptr;
+        ~Own() { for (int i = 1; i < 3; i++) if (ws[i].dev) (void)hipFree(ws[i].dev); (void)hipFree(d_tot); }
+    } own;
+    if (h->plan_ws.dev_bytes < scratch) {
+        if (h->plan_ws.dev) (void)hipFree(h->plan_ws.dev);
+        h->plan_ws.dev = nullptr; h->plan_ws.dev_bytes = 0;
+        HIP_TRY(hipMalloc(&h->plan_ws.dev, scratch));
+        h->plan_ws.dev_bytes = scratch;
+    }
+    own.ws[0].dev = h->plan_ws.dev; own.ws[0].dev_bytes = h->plan_ws.dev_bytes;
+    for (int i = 1; i < nst; i++) { HIP_TRY(hipMalloc(&own.ws[i].dev, scratch)); own.ws[i].dev_bytes = scratch; }
+    HIP_TRY(hipMalloc(&own.d_tot, sizeof(unsigned long long) * 4 * (size_t)P));
+    HIP_TRY(hipMemset(own.d_tot, 0, sizeof(unsigned long long) * 4 * (size_t)P));
+    auto abandon = [&]() {          // (nothing of the attempt stays: the caller allocates again)
+        for (int i = 0; i < nst; i++) (void)hipStreamSynchronize(sts[i]);
+        for (Part &part : h->parts) {
+            for (void *q : {(void *)part.d_rp, (void *)part.d_nzb, (void *)part.d_pad, (void *)part.img.desc, (void *)part.img.shared}) if (q) (void)hipFree(q);
+            part.d_rp = nullptr; part.d_nzb = nullptr; part.d_pad = nullptr; part.img.desc = nullptr; part.img.shared = nullptr;
+        }
+        return CVR_OK;
+    };
+    for (int p = 0; p < P; p++) {
+        Part           &part = h->parts[(size_t)p];
+        const int64_t   ns = nsubs[(size_t)p], nzp = d.off[p + 1] - d.off[p], nb = bound[(size_t)p];
+        const hipStream_t st = sts[p % nst];
+        HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)ns + 1)));
+        HIP_TRY(cvr::launch_shift_rows(d.rp + d.sub0[p], ns + 1, d.off[p], part.d_rp, st));
+        HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nb + 1)));
+        HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nb, 1)));
+        HIP_TRY(hipMalloc(&part.img.desc, 16 * std::max<size_t>((size_t)nb, 1)));
+        HIP_TRY(hipMalloc(&part.img.shared, 24 * std::max<size_t>((size_t)nb, 1)));
+        cvr::PlanTables tables;
+        tables.desc = part.img.desc; tables.pad = part.d_pad; tables.nzb = part.d_nzb; tables.room = (uint32_t)nb; tables.phased = false;
+        tables.totals = own.d_tot + 4 * (size_t)p;
+        cvr::DevicePlan dp;
+        HIP_TRY(cvr::plan_chunks_device_enqueue(part.d_rp, ns, nzp, pps[(size_t)p].S, popts[(size_t)p].split_threshold, maxr[(size_t)p], st, &own.ws[p % nst], &dp, &tables));
+        if (dp.declined || dp.bound != nb) return abandon();
+        if (nb > 0) HIP_TRY(hipMemcpyAsync(part.img.shared, dp.shared, 24 * (size_t)nb, hipMemcpyDeviceToDevice, st));      // (the scratch goes to the stream's next panel)
+    }
+    for (int i = 0; i < nst; i++) HIP_TRY(hipStreamSynchronize(sts[i]));
+    std::vector<unsigned long long> tot(4 * (size_t)P);
+    HIP_TRY(hipMemcpy(tot.data(), own.d_tot, sizeof(unsigned long long) * tot.size(), hipMemcpyDeviceToHost));
+    for (int p = 0; p < P; p++)
+        if ((tot[4 * (size_t)p + 2] & 3ull) || (int64_t)tot[4 * (size_t)p] > bound[(size_t)p] || (int64_t)tot[4 * (size_t)p + 1] > bound[(size_t)p]) return abandon();
+    for (int p = 0; p < P; p++) {
+        PartPlan     &pp = pps[(size_t)p];
+        Part         &part = h->parts[(size_t)p];
+        const int64_t ns = nsubs[(size_t)p], nzp = d.off[p + 1] - d.off[p];
+        pp.tables_on_device = true;
+        pp.dev_nchunks = (int64_t)tot[4 * (size_t)p]; pp.dev_nshared = (int64_t)tot[4 * (size_t)p + 1];
+        pp.max_nseg = (int64_t)(tot[4 * (size_t)p + 3] >> 1) + (int64_t)(tot[4 * (size_t)p + 3] & 1ull);
+        pp.yext = ns + 1 + 2 * pp.dev_nchunks;
+        pp.plan.S = pp.S; pp.plan.nz_end = nzp;
+        plan_stage(pp, f32);
+        drs[(size_t)p] = DevRows{part.d_rp, 0, nzp, h->stream, &h->plan_ws};
+    }
+    if (getenv("CVR_FUSED_TRACE")) fprintf(stderr, "[cvr panels] %d chunk plans as one submission\n", P);
+    *done = true;
+    return CVR_OK;
+}
+
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
 // (rp == nullptr: part.d_rp is already in place -- the row pointers of a column panel split on the device -- and `dr` describes it)
 int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
@@ -458,33 +560,36 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
     PartPlan &pp = *planned;
     if (pp.too_large) return fail(CVR_ERR_INVALID, "matrix too large for 32-bit row ordinals on one GPU");
     const cvr::Plan &plan = pp.plan;
-    const int64_t    nchunks = (int64_t)plan.chunks.size(), yext = pp.yext;
+    const int64_t    nchunks = pp.tables_on_device ? pp.dev_nchunks : (int64_t)plan.chunks.size(), yext = pp.yext;
+    const int64_t    nshared_total = pp.tables_on_device ? pp.dev_nshared : (int64_t)plan.shared.size();
     const std::vector<uint32_t> &desc = pp.desc, &pad = pp.pad;
     const std::vector<int64_t>  &nzb = pp.nzb;
 
-    part.nrows = nrows; part.nnz = nz1 - nz0; part.nnz_span = nz1; part.nchunks = nchunks; part.nshared = (int64_t)plan.shared.size(); part.yext = yext;
+    part.nrows = nrows; part.nnz = nz1 - nz0; part.nnz_span = nz1; part.nchunks = nchunks; part.nshared = nshared_total; part.yext = yext;
     {
-        const int rc = setup_image(h, part, pp, nrows, ncols, f32, nchunks, (int64_t)plan.shared.size(), opt, popt);
+        const int rc = setup_image(h, part, pp, nrows, ncols, f32, nchunks, nshared_total, opt, popt);
         if (rc) return rc;
     }
     cvr::DeviceImage &img = part.img;
-    HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nchunks + 1)));
-    HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nchunks, 1)));
-    HIP_TRY(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
+    if (!pp.tables_on_device) {          // (else: nzb, pad, desc and the cut rows were written by the planner on the device: plan_panels_batched)
+        HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nchunks + 1)));
+        HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nchunks, 1)));
+        HIP_TRY(hipMalloc(&img.desc, 16 * std::max<size_t>((size_t)nchunks, 1)));
+        HIP_TRY(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
+    }
     HIP_TRY(hipMalloc(&img.target, 64 * std::max<size_t>((size_t)nchunks, 1)));
-    HIP_TRY(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
     if (pp.phases > 1) {
         HIP_TRY(hipMalloc(&img.desc2, 8 * std::max<size_t>((size_t)nchunks, 1)));
         if (nchunks) HIP_TRY(hipMemcpyAsync(img.desc2, pp.desc2.data(), sizeof(uint32_t) * pp.desc2.size(), hipMemcpyHostToDevice, h->stream));
     }
     HIP_TRY(hipMalloc(&img.win_base, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1)));
     HIP_TRY(hipMemsetAsync(img.win_base, 0, sizeof(uint32_t) * ((size_t)nchunks / img.wpb + 1), h->stream));
-    if (nchunks) {
+    if (nchunks && !pp.tables_on_device) {
         HIP_TRY(hipMemcpyAsync(part.d_nzb, nzb.data(), sizeof(int64_t) * nzb.size(), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(part.d_pad, pad.data(), sizeof(uint32_t) * pad.size(), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(img.desc, desc.data(), sizeof(uint32_t) * desc.size(), hipMemcpyHostToDevice, h->stream));
     }
-    if (!plan.shared.empty())
+    if (!plan.shared.empty() && !pp.tables_on_device)
         HIP_TRY(hipMemcpyAsync(img.shared, plan.shared.data(), sizeof(cvr::Shared) * plan.shared.size(), hipMemcpyHostToDevice, h->stream));
     // narrow chunks (plain layout only): if every chunk spans fewer than 32 767 columns -- banded matrices -- the image stores
     // 16-bit column offsets from the chunk's smallest column: 10 instead of 12 bytes per fp64 slot of a stream-bound SpMV

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void emit_kernel(PlanArgs a)
         c.nseg = c.nrows_in + (c.pad_cnt > 0 ? 1 : 0);
         for (int f = 0; f < 6; f++) c.fill[f] = 0;
         a.chunks[(size_t)kb + i] = c;
-        most = max(most, (uint32_t)c.nrows_in);
+        most = max(most, 2u * (uint32_t)c.nrows_in + (c.pad_cnt > 0 ? 1u : 0u));      // (the most rows of a chunk, and whether such a chunk has a pad segment: 2 rows + flag)
         if (a.odesc && kb + i < a.oroom) {
             const uint32_t kk = kb + i, nr = (uint32_t)a.nrows;
             // where segment q writes: a row begun earlier -> carry_head(k); a row continued later -> carry_tail(k); the pad segment -> dump
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void emit_kernel(PlanArgs a)
                 return (uint32_t)(c.row_first + q);
             };
             a.odesc[kk] = uint4{(uint32_t)c.row_first, (uint32_t)c.nseg, dest(0), dest(a.ophased ? c.nrows_in - 1 : c.nseg - 1)};
-            a.odesc2[kk] = uint2{0u, (uint32_t)c.nrows_in};
+            if (a.odesc2) a.odesc2[kk] = uint2{0u, (uint32_t)c.nrows_in};
             a.opad[kk] = (uint32_t)c.pad_cnt;
             a.onzb[kk] = c.nz_begin;
         } else if (a.odesc && kb + i == a.oroom) a.onzb[a.oroom] = c.nz_begin;      // (a plan beyond the room: the entry that ends the last chunk there is)
@@ -301,6 +301,20 @@ __global__ __launch_bounds__(256) void block_off_kernel(const uint32_t *__restri
 }  // namespace
 
 bool plan_on_device_ok(int32_t S) { return (int64_t)kLanes * S < (int64_t)kJumpCut; }
+
+// room of the record arrays (an upper bound of the chunks) and bytes of device scratch a plan of these rows needs
+int64_t plan_bound_device(int64_t nrows, int64_t nz_end, int32_t S, int64_t max_rows)
+{
+    const int64_t cap = (int64_t)kLanes * S, nblocks = (nrows + kPlanRowBlock - 1) / kPlanRowBlock;
+    return 2 * ((nz_end + nrows) / cap) + (max_rows > 0 ? nrows / max_rows : 0) + 3 * nblocks;
+}
+size_t plan_scratch_bytes(int64_t nrows, int64_t nz_end, int32_t S, int64_t max_rows)
+{
+    const int64_t nblocks = (nrows + kPlanRowBlock - 1) / kPlanRowBlock, ntiles = (nrows + kTileRows - 1) / kTileRows, bound = plan_bound_device(nrows, nz_end, S, max_rows);
+    auto          up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return up(4 * (size_t)ntiles) + up(4 * (size_t)(nrows + nblocks)) + up(2 * (size_t)nrows) + up(sizeof(Start) * (size_t)bound) + up(8 * (size_t)nblocks) +
+           up(sizeof(ChunkRec) * (size_t)bound) + up(sizeof(Shared) * (size_t)bound) + 256;
+}
 
 // Enqueues the planner's kernels on `st` (no synchronisation, nothing copied back): chunk records, cut rows and totals stay in
 // the scratch `ws` (grown if needed) at the pointers of `out`; `tables` (optional) are written by the last kernel.

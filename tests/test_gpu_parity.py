@@ -751,6 +751,32 @@ def test_column_panels_livejournal_shape():
     A.close()
 
 
+def test_panel_plans_as_one_submission_same_result(monkeypatch, capfd):
+    """Column panels split on the device, without hub tables: all panels' chunk plans are enqueued together and write nzb / pad / desc /
+    cut rows on the device (plan_panels_batched); against the panel-by-panel path (CVR_SERIAL_PANEL_PLANS): same counts, same y bits; y
+    against the CSR oracle.  (hub_table = 0 takes the matrix down that path whatever its columns' popularity.)"""
+    nrows, ncols, rp, ci, va = synth.livejournal_like(scale=0.25)
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    got = []
+    monkeypatch.setenv("CVR_FUSED_TRACE", "1")
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("CVR_SERIAL_PANEL_PLANS", "1")
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=8, hub_table=0)
+        if serial:
+            monkeypatch.delenv("CVR_SERIAL_PANEL_PLANS")
+        i = A.info
+        y, _ = A.spmv(x)
+        got.append(((i.col_panels, i.nchunks, i.nshared, i.steps_per_chunk, i.lds_bytes, i.spmv_launches), y))
+        A.close()
+    assert capfd.readouterr().err.count("chunk plans as one submission") == 1        # (the first handle took the path, the second did not)
+    assert got[0][0] == got[1][0], (got[0][0], got[1][0])
+    assert got[0][0][2] > 0                                           # rows cut over chunks: their list came from the device plan
+    assert np.array_equal(got[0][1].view(np.uint64), got[1][1].view(np.uint64))
+    _assert_close(got[0][1], yref, absy, TOL64, "batched panel plans")
+
+
 def test_value_dictionary():
     """matrices with at most 256 distinct values (pattern matrices: the reference assigns index % 13, spmv.cpp:417)
     store one code byte per slot: image == mirror bit for bit, y bitwise identical to the plain layout (same values,
