@@ -74,26 +74,29 @@ hipError_t select_hubs(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols,
     if (n1 <= n0 || ncols <= 0 || hmax == 0) return hipSuccess;
     uint32_t *cnt = nullptr, *cnt_s = nullptr;
     int32_t  *col = nullptr, *col_s = nullptr;
-    void     *tmp = nullptr;
+    void     *tmp = nullptr, *arena = nullptr;
     unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
     size_t    tmp_bytes = 0;
     hipError_t e = hipSuccess;
-    auto done = [&](hipError_t err) {
-        (void)hipFree(cnt); (void)hipFree(cnt_s); (void)hipFree(col); (void)hipFree(col_s); (void)hipFree(tmp); (void)hipFree(d_out);
-        return err;
-    };
+    auto done = [&](hipError_t err) { (void)hipFree(arena); return err; };      // (one allocation for the pass's six buffers: every hipFree waits for the device)
 #define HUB_TRY(x) do { e = (x); if (e != hipSuccess) return done(e); } while (0)
     const size_t nc = (size_t)ncols;
-    HUB_TRY(hipMalloc(&cnt, 4 * nc)); HUB_TRY(hipMalloc(&cnt_s, 4 * nc)); HUB_TRY(hipMalloc(&col, 4 * nc)); HUB_TRY(hipMalloc(&col_s, 4 * nc));
-    HUB_TRY(hipMalloc(&d_out, sizeof(h_out)));
+    HUB_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, cnt, cnt_s, col, col_s, (int)nc, 0, 32, st));      // (size query: no work)
+    {
+        auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t o_cnt = 0, o_cnts = o_cnt + up(4 * nc), o_col = o_cnts + up(4 * nc), o_cols = o_col + up(4 * nc), o_out = o_cols + up(4 * nc), o_tmp = o_out + 256;
+        HUB_TRY(hipMalloc(&arena, o_tmp + up(tmp_bytes ? tmp_bytes : 16)));
+        uint8_t *a = static_cast<uint8_t *>(arena);
+        cnt = reinterpret_cast<uint32_t *>(a + o_cnt); cnt_s = reinterpret_cast<uint32_t *>(a + o_cnts);
+        col = reinterpret_cast<int32_t *>(a + o_col); col_s = reinterpret_cast<int32_t *>(a + o_cols);
+        d_out = reinterpret_cast<unsigned long long *>(a + o_out); tmp = a + o_tmp;
+    }
     HUB_TRY(hipMemsetAsync(cnt, 0, 4 * nc, st));
     const int64_t stride = hub_sample_stride(n1 - n0), nsamp = (n1 - n0 + stride - 1) / stride;
     const uint32_t blocks = (uint32_t)std::min<int64_t>(8192, (nsamp + 256 * 8 - 1) / (256 * 8));
     hipLaunchKernelGGL(hub_count_kernel, dim3(blocks), dim3(256), 0, st, ci, (long long)n0, (long long)nsamp, (long long)stride, cnt);
     hipLaunchKernelGGL(hub_iota_kernel, dim3((uint32_t)std::min<size_t>(4096, (nc + 255) / 256)), dim3(256), 0, st, col, (uint32_t)nc);
     HUB_TRY(hipGetLastError());
-    HUB_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, cnt, cnt_s, col, col_s, (int)nc, 0, 32, st));
-    HUB_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
     HUB_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tmp_bytes, cnt, cnt_s, col, col_s, (int)nc, 0, 32, st));       // stable: ties by column
     hipLaunchKernelGGL(hub_cut_kernel, dim3(1), dim3(1024), 0, st, cnt_s, (uint32_t)nc, hmax, d_out);
     HUB_TRY(hipGetLastError());
