@@ -74,6 +74,125 @@ __global__ __launch_bounds__(256) void split_emit_kernel(const uint32_t *__restr
     if (blockIdx.x == 0 && threadIdx.x == 0) rp_s[nsub] = n;
 }
 
+// ---- the split as a stable partition (no sort, no search per non-zero) -------------------------------------------------
+// The radix sort of (panel, position) pairs and the gather behind it read the CSR arrays P times over (a panel's elements are 1 / P of
+// every cache line) and search row_ptr once per non-zero.  A partition by panel is a counting sort with P buckets: tiles of 2 048
+// consecutive non-zeros count their elements per panel (part_count_kernel), one scan over the counts in (panel, tile) order gives
+// every tile its place in every panel, and the tiles then move their elements there themselves (part_scatter_kernel): every thread
+// owns eight consecutive non-zeros, counts them per panel in a column of its own in LDS, a scan in (panel, thread) order ranks them --
+// the order inside a panel stays the CSR's, as the stable sort left it -- and the row of a thread's first element is one search, the
+// others follow from row_ptr.  The CSR is read once (the column indices twice).
+constexpr int kPartTile = 2048, kPartThreads = 256, kPartPer = kPartTile / kPartThreads;
+
+__global__ __launch_bounds__(kPartThreads) void part_count_kernel(const int32_t *__restrict__ ci, long long nz0, long long n, uint32_t width, int P, uint32_t ntiles,
+                                                                   uint32_t *__restrict__ cnt)
+{
+    __shared__ uint32_t h[kMaxSplitPanels];
+    const uint32_t tile = blockIdx.x;
+    if (threadIdx.x < kMaxSplitPanels) h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long t0 = (long long)tile * kPartTile;
+#pragma unroll
+    for (int q = 0; q < kPartPer; q++) {
+        const long long t = t0 + q * kPartThreads + threadIdx.x;
+        if (t < n) atomicAdd(&h[(uint32_t)ci[nz0 + t] / width], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < P) cnt[(size_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kPartThreads) void part_scatter_kernel(const long long *__restrict__ rp, long long nrows, const int32_t *__restrict__ ci, const T *__restrict__ va,
+                                                                     long long nz0, long long n, uint32_t width, int P, uint32_t ntiles, const uint32_t *__restrict__ base,
+                                                                     int32_t *__restrict__ ci_s, T *__restrict__ va_s, uint32_t *__restrict__ row_s)
+{
+    extern __shared__ uint16_t hist[];                  // [P][kPartThreads], then pstart[P] (u32)
+    uint32_t *pstart = reinterpret_cast<uint32_t *>(hist + (size_t)P * kPartThreads);
+    __shared__ uint32_t wsum[kPartThreads / 64];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const long long t0 = (long long)tile * kPartTile + (long long)tid * kPartPer;
+    for (int p = 0; p < P; p++) hist[p * kPartThreads + tid] = 0;
+    int32_t c[kPartPer];
+    T       v[kPartPer];
+    uint8_t pan[kPartPer];
+#pragma unroll
+    for (int q = 0; q < kPartPer; q++) {
+        const long long t = t0 + q;
+        c[q] = t < n ? ci[nz0 + t] : 0;
+        v[q] = t < n ? va[nz0 + t] : T(0);
+    }
+#pragma unroll
+    for (int q = 0; q < kPartPer; q++) {
+        pan[q] = (uint8_t)((uint32_t)c[q] / width);
+        if (t0 + q < n) hist[pan[q] * kPartThreads + tid] += 1;
+    }
+    // the row of the thread's first element: the last r with rp[r] <= j (its later elements follow from row_ptr)
+    long long r = 0;
+    if (t0 < n) {
+        const long long j = nz0 + t0;
+        long long lo = 0, hi = nrows;
+        while (lo < hi) { const long long mid = (lo + hi + 1) >> 1; if (rp[mid] <= j) lo = mid; else hi = mid - 1; }
+        r = lo;
+    }
+    __syncthreads();
+    // ranks: hist in (panel, thread) order -- a thread sums P consecutive entries, the sums are scanned over the workgroup
+    uint32_t mine = 0;
+    for (int q = 0; q < P; q++) mine += hist[tid * P + q];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if ((int)lane >= o) incl += u; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t run = incl - mine;
+    for (uint32_t w = 0; w < wv; w++) run += wsum[w];
+    for (int q = 0; q < P; q++) { const uint32_t k = hist[tid * P + q]; hist[tid * P + q] = (uint16_t)run; run += k; }
+    __syncthreads();
+    if ((int)tid < P) pstart[tid] = hist[tid * kPartThreads];          // elements of the tile in the panels in front of panel tid
+    __syncthreads();
+    long long rnext = r < nrows ? rp[r + 1] : 0x7fffffffffffffffll;
+#pragma unroll
+    for (int q = 0; q < kPartPer; q++) {
+        const long long t = t0 + q;
+        if (t >= n) break;
+        const long long j = nz0 + t;
+        while (j >= rnext) { r++; rnext = rp[r + 1]; }                  // (empty rows are stepped over)
+        const uint32_t p = pan[q];
+        const uint32_t slot = hist[p * kPartThreads + tid];
+        hist[p * kPartThreads + tid] = (uint16_t)(slot + 1);
+        const size_t pos = (size_t)base[(size_t)p * ntiles + tile] + (slot - pstart[p]);
+        ci_s[pos] = c[q]; va_s[pos] = v[q]; row_s[pos] = (uint32_t)r;
+    }
+}
+
+// sub-row heads from the partitioned arrays themselves: a new row, or a new panel
+__global__ __launch_bounds__(256) void part_head_kernel(const int32_t *__restrict__ ci_s, const uint32_t *__restrict__ row_s, long long n, uint32_t width,
+                                                        uint32_t *__restrict__ head)
+{
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256)
+        head[t] = (t == 0 || (uint32_t)ci_s[t] / width != (uint32_t)ci_s[t - 1] / width || row_s[t] != row_s[t - 1]) ? 1u : 0u;
+}
+
+// off[p] = where panel p starts among the partitioned non-zeros (the scan's entry of tile 0), off[P] = n
+__global__ void part_bounds_kernel(const uint32_t *__restrict__ base, uint32_t ntiles, long long n, int P, long long *__restrict__ off)
+{
+    const int p = threadIdx.x;
+    if (p < P) off[p] = base[(size_t)p * ntiles];
+    if (p == P) off[p] = n;
+}
+
+// what the host needs of the split, in one block: small[0] = sub-rows in front of the last element, [1] = the last element starts one,
+// [2 + p] = off[p] (p = 0 .. P), [3 + P + p] = sub-rows in front of panel p's first element (one copy instead of P + 3)
+__global__ void split_collect_kernel(const uint32_t *__restrict__ sidx, const uint32_t *__restrict__ head, const long long *__restrict__ off, long long n, int P,
+                                     long long *__restrict__ small)
+{
+    const int p = threadIdx.x;
+    if (p == 0) { small[0] = sidx[n - 1]; small[1] = head[n - 1]; }
+    if (p <= P) {
+        small[2 + p] = off[p];
+        small[3 + P + p] = off[p] < n ? (long long)sidx[off[p]] : -1;
+    }
+}
+
 // ---- the panel rule's L2 model on the device (the host form: l2_miss_estimate in cvr_capi.hip) ----
 constexpr uint32_t kEstBins = 4096;        // line counts 1 .. 4094 have a bin each; larger ones are summed exactly on the side
 
@@ -193,11 +312,14 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
     size_t sort_bytes = 0, scan_bytes = 0;
     SPLIT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, key_in, key, idx_in, idx, (unsigned int)std::max<long long>(n, 1), 0, bits, st));
     SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, head, sidx, (unsigned int)std::max<long long>(n, 1), st));
+    const size_t part_tiles = (size_t)((std::max<long long>(n, 1) + kPartTile - 1) / kPartTile), part_n = (size_t)P * part_tiles;
+    size_t       part_scan_bytes = 0;
+    SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, part_scan_bytes, head, sidx, (unsigned int)part_n, st));
     auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t nn = (size_t)std::max<long long>(n, 4);
     const size_t o_key_in = 0, o_key = o_key_in + up(nn), o_idx_in = o_key + up(nn), o_idx = o_idx_in + up(4 * nn), o_row = o_idx + up(4 * nn),
-                 o_head = o_row + up(4 * nn), o_sidx = o_head + up(4 * nn), o_off = o_sidx + up(4 * nn), o_work = o_off + up(sizeof(long long) * (kMaxSplitPanels + 2)),
-                 total = o_work + up(std::max(sort_bytes, scan_bytes));
+                 o_head = o_row + up(4 * nn), o_sidx = o_head + up(4 * nn), o_off = o_sidx + up(4 * nn), o_part = o_off + up(sizeof(long long) * 3 * (kMaxSplitPanels + 2) + 64), o_work = o_part + up(8 * part_n),
+                 total = o_work + up(std::max(std::max(sort_bytes, scan_bytes), part_scan_bytes));
     SPLIT_TRY(tmp.alloc(&arena, total));
     key_in = arena + o_key_in; key = arena + o_key;
     idx_in = reinterpret_cast<uint32_t *>(arena + o_idx_in); idx = reinterpret_cast<uint32_t *>(arena + o_idx); row_s = reinterpret_cast<uint32_t *>(arena + o_row);
@@ -211,32 +333,43 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
         SPLIT_TRY(hipMemsetAsync(out->rp, 0, 16, st));
         return hipStreamSynchronize(st);
     }
+    static const bool by_sort = getenv("CVR_SPLIT_SORT") != nullptr;      // (diagnostics: the sort-and-gather form)
+    if (!by_sort && width < (1ll << 31) && n > 0) {
+        const uint32_t ntiles = (uint32_t)((n + kPartTile - 1) / kPartTile);
+        uint32_t      *cnt = reinterpret_cast<uint32_t *>(arena + o_part), *base = cnt + (size_t)P * ntiles;
+        hipLaunchKernelGGL(part_count_kernel, dim3(ntiles), dim3(kPartThreads), 0, st, ci_dev, (long long)nz0, n, (uint32_t)width, P, ntiles, cnt);
+        SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(work, part_scan_bytes, cnt, base, (unsigned int)((size_t)P * ntiles), st));
+        const size_t lds = sizeof(uint16_t) * (size_t)P * kPartThreads + sizeof(uint32_t) * (size_t)P;
+        if (f32) hipLaunchKernelGGL(part_scatter_kernel<float>, dim3(ntiles), dim3(kPartThreads), lds, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const float *>(va_dev),
+                                    (long long)nz0, n, (uint32_t)width, P, ntiles, base, out->ci, static_cast<float *>(out->va), row_s);
+        else hipLaunchKernelGGL(part_scatter_kernel<double>, dim3(ntiles), dim3(kPartThreads), lds, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const double *>(va_dev),
+                                (long long)nz0, n, (uint32_t)width, P, ntiles, base, out->ci, static_cast<double *>(out->va), row_s);
+        hipLaunchKernelGGL(part_bounds_kernel, dim3(1), dim3(kMaxSplitPanels + 1), 0, st, base, ntiles, n, P, off_dev);
+        hipLaunchKernelGGL(part_head_kernel, dim3(grid_for(n)), dim3(256), 0, st, out->ci, row_s, n, (uint32_t)width, head);
+    } else {
     hipLaunchKernelGGL(split_key_kernel, dim3(grid_for(n)), dim3(256), 0, st, ci_dev, (long long)nz0, n, (long long)width, key_in, idx_in);
     SPLIT_TRY(hipcub::DeviceRadixSort::SortPairs(work, sort_bytes, key_in, key, idx_in, idx, (unsigned int)n, 0, bits, st));   // stable
     hipLaunchKernelGGL(split_bounds_kernel, dim3(1), dim3(kMaxSplitPanels + 1), 0, st, key, n, P, off_dev);
     if (f32) hipLaunchKernelGGL(split_gather_kernel<float>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const float *>(va_dev), (long long)nz0, n, idx, out->ci, static_cast<float *>(out->va), row_s);
     else hipLaunchKernelGGL(split_gather_kernel<double>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const double *>(va_dev), (long long)nz0, n, idx, out->ci, static_cast<double *>(out->va), row_s);
     hipLaunchKernelGGL(split_head_kernel, dim3(grid_for(n)), dim3(256), 0, st, key, row_s, n, head);
+    }
     SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(work, scan_bytes, head, sidx, (unsigned int)n, st));
-    uint32_t  last[2] = {0, 0};
-    long long off_host[kMaxSplitPanels + 2];
-    SPLIT_TRY(hipMemcpyAsync(&last[0], sidx + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SPLIT_TRY(hipMemcpyAsync(&last[1], head + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SPLIT_TRY(hipMemcpyAsync(off_host, off_dev, sizeof(long long) * (size_t)(P + 1), hipMemcpyDeviceToHost, st));
+    long long small_host[2 * (kMaxSplitPanels + 2) + 2];
+    long long *small_dev = off_dev + (kMaxSplitPanels + 2);
+    hipLaunchKernelGGL(split_collect_kernel, dim3(1), dim3(kMaxSplitPanels + 1), 0, st, sidx, head, off_dev, n, P, small_dev);
+    SPLIT_TRY(hipMemcpyAsync(small_host, small_dev, sizeof(long long) * (size_t)(2 * (P + 1) + 2), hipMemcpyDeviceToHost, st));
     SPLIT_TRY(hipStreamSynchronize(st));
-    const long long nsub = (long long)last[0] + last[1];
+    const long long nsub = small_host[0] + small_host[1];
     out->nsub = nsub;
     SPLIT_TRY(hipMalloc(&out->rows, std::max<size_t>(4 * (size_t)nsub, 16)));
     SPLIT_TRY(hipMalloc(&out->rp, sizeof(long long) * ((size_t)nsub + 1)));
     hipLaunchKernelGGL(split_emit_kernel, dim3(grid_for(n)), dim3(256), 0, st, head, sidx, row_s, n, out->rows, (long long *)out->rp, nsub);
     // first sub-row of every panel = the number of sub-row heads before its first element
-    for (int p = 0; p <= P; p++) out->off[p] = off_host[p];
-    std::vector<uint32_t> s0((size_t)P + 1, 0);
-    for (int p = 0; p < P; p++)
-        if (out->off[p] < n) SPLIT_TRY(hipMemcpyAsync(&s0[(size_t)p], sidx + out->off[p], 4, hipMemcpyDeviceToHost, st));
-    SPLIT_TRY(hipStreamSynchronize(st));
-    for (int p = 0; p < P; p++) out->sub0[p] = out->off[p] < n ? (int64_t)s0[(size_t)p] : nsub;
+    for (int p = 0; p <= P; p++) out->off[p] = small_host[2 + p];
+    for (int p = 0; p < P; p++) out->sub0[p] = out->off[p] < n ? (int64_t)small_host[3 + P + p] : nsub;
     out->sub0[P] = nsub;
+    SPLIT_TRY(hipStreamSynchronize(st));          // (the temporaries go with this call)
     SPLIT_TRY(hipGetLastError());
     return hipSuccess;
 }
