@@ -158,6 +158,25 @@ int check_csr(const cvr_csr_view *c, bool columns_on_host)
 }
 
 // the column range check for col_idx in device memory
+// row_ptr in device memory: non-negative start, no decrease -- checked where it lies (a copy of 8 bytes per row to the host and back costs
+// more than the whole analysis of a large matrix); *rp0 / *rpn = its first / last entry
+int check_rows_device(const int64_t *rp_dev, int64_t nrows, int64_t *rp0, int64_t *rpn)
+{
+    *rp0 = 0; *rpn = 0;
+    if (nrows <= 0) return CVR_OK;
+    long long *d = nullptr, host[3] = {0, 0, -1};
+    HIP_TRY(hipMalloc(&d, sizeof(host)));
+    (void)hipGetLastError();
+    hipError_t e = cvr::launch_rows_check(rp_dev, nrows, d, nullptr);
+    const char *where = "launch";
+    if (e == hipSuccess) { e = hipMemcpy(host, d, sizeof(host), hipMemcpyDeviceToHost); where = "copy"; }
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(CVR_ERR_HIP, "row_ptr check (%s): %s", where, hipGetErrorString(e));
+    if (host[0] < 0) return fail(CVR_ERR_INVALID, "row_ptr[0] < 0");
+    if (host[2] >= 0) return fail(CVR_ERR_INVALID, "row_ptr decreases at row %lld", host[2]);
+    *rp0 = host[0]; *rpn = host[1];
+    return CVR_OK;
+}
 int check_columns_device(const int32_t *ci_dev, int64_t j0, int64_t j1, int64_t ncols)
 {
     if (j1 <= j0) return CVR_OK;
@@ -260,7 +279,11 @@ namespace {
 struct PhaseClock {
     bool   on = getenv("CVR_CREATE_TIMING") && atoi(getenv("CVR_CREATE_TIMING"));
     double t = now_s();
-    void   lap(const char *what) { if (on) { const double n = now_s(); fprintf(stderr, "[cvr_create] %-28s %8.2f ms\n", what, (n - t) * 1e3); t = n; } }
+    void   lap(const char *what)
+    {
+        if (getenv("CVR_DEBUG_STICKY")) { const hipError_t pe = hipPeekAtLastError(); if (pe != hipSuccess) fprintf(stderr, "[cvr_create] sticky error at \"%s\": %s\n", what, hipGetErrorString(pe)); }
+        if (on) { const double n = now_s(); fprintf(stderr, "[cvr_create] %-28s %8.2f ms\n", what, (n - t) * 1e3); t = n; }
+    }
 };
 }  // namespace
 
@@ -284,22 +307,40 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     if (opt.steps_per_chunk != 0 && (opt.steps_per_chunk < 4 || opt.steps_per_chunk % 4 || opt.steps_per_chunk > 4096))
         return fail(CVR_ERR_INVALID, "steps_per_chunk must be a multiple of 4 in [4, 4096]");
 
-    // CSR arrays already in device memory (of opt.device): row_ptr comes back once for the argument checks (8 B per row);
+    // CSR arrays already in device memory (of opt.device): the row_ptr of a small matrix comes back once for the argument checks (8 B per
+    // row), that of a large one is checked by a kernel and stays (R-MAT-24: 33 ms of copies -> 0.5 ms);
     // col_idx and vals stay where they are and are copied device to device; the chunk plan (from 200 000 rows on), the panel
     // rule and the panel split run on the device arrays (cvr_plan_dev.hip, cvr_split.hip).
     cvr_csr_view          hostv = *csr_in;
     const cvr_csr_view   *csr = &hostv;
     std::vector<int64_t>  rp_host;
+    bool                  rows_on_device = false;        // device arrays of a large matrix: row_ptr never comes to the host
+    int64_t               dev_j0 = 0, dev_j1 = 0;        // (then: its first and last entry)
     hipMemcpyKind         civa_kind = hipMemcpyHostToDevice;
     if (on_device) {
         if (hostv.nrows < 0 || hostv.ncols < 0 || (hostv.nrows > 0 && !hostv.row_ptr)) return fail(CVR_ERR_INVALID, "null or negative-size CSR view");
         HIP_TRY(hipSetDevice(opt.device));
-        rp_host.resize((size_t)hostv.nrows + 1, 0);
-        if (hostv.nrows > 0) HIP_TRY(hipMemcpy(rp_host.data(), hostv.row_ptr, sizeof(int64_t) * rp_host.size(), hipMemcpyDeviceToHost));
-        hostv.row_ptr = rp_host.data();
-        rc = check_csr(&hostv, false);
-        if (rc) return rc;
-        const int64_t j0 = rp_host.front(), j1 = rp_host.back();
+        int64_t j0 = 0, j1 = 0;
+        if (hostv.nrows >= device_plan_rows() && hostv.nrows > 0 && !getenv("CVR_DEVICE_ROWS_TO_HOST")) {
+            // a matrix the device plans anyway: its row pointers are checked and used where they are (rows_on_device)
+            cvr_csr_view shape = hostv;
+            shape.nrows = 0; shape.row_ptr = nullptr;                 // (the checks of check_csr that need no rows: sizes, ncols, x within 4 GiB)
+            rc = check_csr(&shape, false);
+            if (rc) return rc;
+            rc = check_rows_device(hostv.row_ptr, hostv.nrows, &j0, &j1);
+            if (rc) return rc;
+            if (j1 > j0 && (!hostv.col_idx || !hostv.vals)) return fail(CVR_ERR_INVALID, "col_idx / vals is null");
+            rows_on_device = true;
+            hostv.row_ptr = nullptr;                                   // (nothing below may read rows on the host)
+        } else {
+            rp_host.resize((size_t)hostv.nrows + 1, 0);
+            if (hostv.nrows > 0) HIP_TRY(hipMemcpy(rp_host.data(), hostv.row_ptr, sizeof(int64_t) * rp_host.size(), hipMemcpyDeviceToHost));
+            hostv.row_ptr = rp_host.data();
+            rc = check_csr(&hostv, false);
+            if (rc) return rc;
+            j0 = rp_host.front(); j1 = rp_host.back();
+        }
+        dev_j0 = j0; dev_j1 = j1;
         rc = check_columns_device(hostv.col_idx, j0, j1, hostv.ncols);
         if (rc) return rc;
         const double xb = (double)hostv.ncols * (hostv.is_f32 ? 4.0 : 8.0);
@@ -328,7 +369,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     h->opt_used = make_iopt(opt_in);
     h->opt_used.cus = opt.cus; h->opt_used.xcds = opt.xcds;
     cvr_info &in = h->info;
-    in.nrows = nrows; in.ncols = ncols; in.nnz = nrows ? csr->row_ptr[nrows] - csr->row_ptr[0] : 0; in.is_f32 = f32 ? 1 : 0;
+    in.nrows = nrows; in.ncols = ncols; in.nnz = rows_on_device ? dev_j1 - dev_j0 : nrows ? csr->row_ptr[nrows] - csr->row_ptr[0] : 0; in.is_f32 = f32 ? 1 : 0;
     in.x_elems = ncols + 1;
 #define CREATE_TRY(expr)                                                                                    \
     do {                                                                                                    \
@@ -349,7 +390,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipMemsetAsync(h->d_small + kSmallDictTab, 0xff, sizeof(unsigned long long) * 1024, h->stream));
     h->small_clean = true;
     if (nrows >= device_plan_rows()) {     // the device planner's scratch, sized for chunks of 16 steps or more (it grows if the plan needs more)
-        const int64_t nnz0 = nrows ? csr->row_ptr[nrows] : 0, nb = nrows / cvr::kPlanRowBlock + 1;
+        const int64_t nnz0 = rows_on_device ? dev_j1 : nrows ? csr->row_ptr[nrows] : 0, nb = nrows / cvr::kPlanRowBlock + 1;
         const size_t  want = (size_t)nrows * 6 + (size_t)nb * 16 + (size_t)nrows / 256 + (size_t)(2 * ((nnz0 + nrows) / 1024) + 3 * nb) * 96 + 8192;
         if (hipMalloc(&h->plan_ws.dev, want) == hipSuccess) h->plan_ws.dev_bytes = want; else (void)hipGetLastError();
     }
@@ -368,7 +409,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         void  release() { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); rp = ci = va = nullptr; }
         ~Staged() { release(); }
     } staged;
-    const int64_t  sj0 = nrows ? csr->row_ptr[0] : 0, sj1 = nrows ? csr->row_ptr[nrows] : 0;
+    const int64_t  sj0 = rows_on_device ? dev_j0 : nrows ? csr->row_ptr[0] : 0, sj1 = rows_on_device ? dev_j1 : nrows ? csr->row_ptr[nrows] : 0;
     const int64_t *rp_d = csr_in->row_ptr;
     const int32_t *ci_d = csr_in->col_idx;
     const void    *va_d = csr_in->vals;
@@ -415,7 +456,14 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             part.d_rp = static_cast<int64_t *>(staged.rp); part.d_ci = static_cast<int32_t *>(staged.ci); part.d_va = staged.va;
             staged.rp = staged.ci = staged.va = nullptr;
         }
-        rc = build_part(h, h->parts[0], nrows, ncols, csr->row_ptr, csr->col_idx, csr->vals, civa_kind, f32, opt, &in.plan_s);
+        if (rows_on_device) {       // the part's row pointers: a device copy of the caller's; planned (and, where the layout allows, converted) from there
+            Part &part = h->parts[0];
+            CREATE_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
+            CREATE_TRY(hipMemcpyAsync(part.d_rp, csr_in->row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyDeviceToDevice, h->stream));
+            const DevRows dr{part.d_rp, sj0, sj1, h->stream, &h->plan_ws};
+            rc = build_part(h, part, nrows, ncols, nullptr, csr->col_idx, csr->vals, civa_kind, f32, opt, &in.plan_s, nullptr, &dr);
+        } else
+            rc = build_part(h, h->parts[0], nrows, ncols, csr->row_ptr, csr->col_idx, csr->vals, civa_kind, f32, opt, &in.plan_s);
         if (rc) { cvr_destroy(h); return rc; }
         in.yext_elems = h->parts[0].yext;
     } else {

@@ -1262,6 +1262,25 @@ hipError_t launch_chunk_span(const DeviceImage &img, const DeviceCsr &csr, uint3
     return hipGetLastError();
 }
 
+// out[0] = rp[0], out[1] = rp[nrows], out[2] = the first row whose successor's pointer is smaller (-1: none); out is written whole
+__global__ __launch_bounds__(256) void rows_check_kernel(const long long *__restrict__ rp, long long nrows, long long *__restrict__ out)
+{
+    long long bad = 0x7fffffffffffffffll;
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < nrows; r += (long long)gridDim.x * 256)
+        if (rp[r + 1] < rp[r]) { bad = r; break; }
+    if (bad != 0x7fffffffffffffffll) atomicMin(reinterpret_cast<unsigned long long *>(out + 2), (unsigned long long)bad);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = rp[0]; out[1] = rp[nrows]; }
+}
+
+hipError_t launch_rows_check(const int64_t *rp, int64_t nrows, long long *out3, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(out3, 0xff, sizeof(long long) * 3, st);      // (all ones: "no bad row" for the unsigned minimum, read back as -1)
+    if (e != hipSuccess) return e;
+    const uint32_t blocks = (uint32_t)std::min<int64_t>(4096, (nrows + 255) / 256);
+    hipLaunchKernelGGL(rows_check_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const long long *>(rp), (long long)nrows, out3);
+    return hipGetLastError();
+}
+
 hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st)
 {
     if (n1 <= n0) return hipSuccess;

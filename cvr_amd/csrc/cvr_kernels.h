@@ -171,6 +171,7 @@ hipError_t launch_probe(const int64_t *rp, const int32_t *ci, int64_t nrows, int
 // per chunk: its smallest column into cbase[k]; *wide (device u32, zeroed by the caller) gets 1 if any chunk spans 32 767 columns or more
 hipError_t launch_chunk_span(const DeviceImage &img, const DeviceCsr &csr, uint32_t *cbase, uint32_t *wide, hipStream_t st);
 // min / max of col_idx[n0 .. n1) into minmax[0..1] (device; initialised by the caller to INT_MAX / INT_MIN)
+hipError_t launch_rows_check(const int64_t *rp, int64_t nrows, long long *out3, hipStream_t st);      // {rp[0], rp[nrows], first decreasing row or -1}
 hipError_t launch_col_range(const int32_t *ci, int64_t n0, int64_t n1, int32_t *minmax, hipStream_t st);
 hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, unsigned long long *table, uint32_t *flags, hipStream_t st);
 

@@ -497,7 +497,7 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
     }
     PartPlan    local;
     IOpt        popt = opt;
-    if (!planned && rp && !dr && nrows > 0) {      // a whole matrix: analysis, plan and conversion as one submission where the resident layout applies
+    if (!planned && nrows > 0) {      // a whole matrix (host rows, or a device copy described by `dr`): analysis, plan and conversion as one submission where the resident layout applies
         bool       taken = false;
         const int  rc = build_part_fused(h, part, nrows, ncols, f32, nz0, nz1, opt, popt, &taken);
         if (rc || taken) return rc;
@@ -512,8 +512,9 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
         struct SyncBack { cvr::PlanScratch &view, &home; ~SyncBack() { home.dev = view.dev; home.dev_bytes = view.dev_bytes; } } sync_back{plan_view, h->plan_ws};      // (the planner may grow its device scratch; also on the error paths)
         DevRows        here{part.d_rp, nz0, nz1, h->stream, &plan_view};
         const bool     on_dev = rp && nrows > 0 && nrows >= device_plan_rows() && !getenv("CVR_HOST_PLAN");      // (the upload of row_ptr is in front of the planner's kernels on the stream)
+        const DevRows  via{dr ? dr->rp : nullptr, nz0, nz1, dr ? dr->st : nullptr, &plan_view};      // the caller's device rows, planned through this call's view of the scratch (it may grow: SyncBack)
         const int64_t *prp = on_dev ? nullptr : rp;
-        const DevRows *pdr = on_dev ? &here : dr;
+        const DevRows *pdr = on_dev ? &here : dr ? &via : nullptr;
         // the plan of the layout the probe is expected to confirm, made while the probe runs (device planner only: it works on the handle's stream)
         PartPlan spec_plan;
         IOpt     spec_opt;

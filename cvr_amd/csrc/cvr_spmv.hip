@@ -21,6 +21,8 @@
 //     fixup_kernel (bitwise reproducible); column panels add their partial sums in panel order (combine_kernel).
 #include "cvr_kernels.h"
 
+#include <cstdio>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -952,6 +954,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #undef CVR_PICK_MW
 #undef CVR_LAUNCH
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess && getenv("CVR_DEBUG_STICKY")) fprintf(stderr, "[launch_spmv] %s: grid %u block %u lds %zu S %d G %d nchunks %u wpb %u c16 %d phases %u win %u hub %u swz %d dict %p stream %p desc %p target %p cbase %p\n", hipGetErrorString(e), grid, kLanes * wpb, lds, img.S, img.G, img.nchunks, wpb, (int)img.c16, img.phases, img.win_elems, img.hub_n, img.xcd_swizzle, img.dict, (void *)img.stream, (void *)img.desc, (void *)img.target, (void *)img.cbase);
     if (e != hipSuccess || img.nshared == 0 || !with_fixup) return e;
     const uint32_t fb = (img.nshared + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3     fblock(kLanes * kWavesPerBlock);

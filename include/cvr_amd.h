@@ -56,8 +56,9 @@ typedef struct {
     const void    *vals;      /* double[] or float[] by is_f32                                 */
     int32_t        is_f32;    /* 0: fp64 values, x, y    1: fp32 values, x, y (fp32 accumulate) */
     int32_t        arrays_on_device;   /* 0: the three arrays are host memory; 1: device memory of cvr_options.device (a GPU-
-                                 * resident caller): row_ptr comes back for the planner (8 B per row), col_idx and vals
-                                 * are copied device to device; the struct's size is unchanged (former padding)          */
+                                 * resident caller): all three are checked and copied device to device; from 200 000 rows on
+                                 * row_ptr never comes to the host (checked by a kernel, planned where it is), below that it
+                                 * comes back once (8 B per row); the struct's size is unchanged (former padding)          */
 } cvr_csr_view;
 
 typedef struct {

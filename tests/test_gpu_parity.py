@@ -946,6 +946,47 @@ def test_csr_arrays_already_on_the_device(name):
         assert e.value.code == capi.ERR_INVALID
 
 
+def test_large_device_arrays_are_checked_and_planned_where_they_are():
+    """row_ptr of a large matrix in device memory never comes to the host (the checks are a kernel, the planner reads the device copy):
+    same image and y as from host arrays; a row pointer that decreases, a negative first entry and a column out of range are rejected
+    with the codes of the host checks."""
+    import torch
+    nrows, ncols, rp, ci, va = synth.web_google_like(0.3)
+    assert nrows >= 200000                                     # (cvr_create's threshold for the device planner)
+    dev = torch.device("cuda", 0)
+    trp, tci, tva = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (rp.astype(np.int64), ci.astype(np.int32), va.astype(np.float64)))
+    torch.cuda.synchronize()
+    for kw in (dict(), dict(steps_per_chunk=4), dict(col_panels=3)):
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, **kw)
+        B = cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), tci.data_ptr(), tva.data_ptr(), **kw)
+        assert (A.info.nchunks, A.info.nshared, A.info.steps_per_chunk, A.info.col_panels) == (B.info.nchunks, B.info.nshared, B.info.steps_per_chunk, B.info.col_panels)
+        if not kw.get("col_panels"):
+            ia, ib = A.export_image(), B.export_image()
+            for k in ("image", "desc", "target", "shared"):
+                assert np.array_equal(ia[k], ib[k]), (kw, k)
+        x = O.x_vec_fast(ncols, "rand")
+        ya, _ = A.spmv(x)
+        yb, _ = B.spmv(x)
+        assert np.array_equal(ya.view(np.uint64), yb.view(np.uint64)), kw
+        A.close(); B.close()
+    bad = trp.clone()
+    bad[nrows // 2] = bad[nrows // 2 - 1] - 1                     # decreases
+    with pytest.raises(cvr_amd.CvrError) as e:
+        cvr_amd.CvrMatrix.from_device(nrows, ncols, bad.data_ptr(), tci.data_ptr(), tva.data_ptr())
+    assert e.value.code == capi.ERR_INVALID and "decreases" in str(e.value)
+    bad = trp.clone()
+    bad[0] = -1
+    with pytest.raises(cvr_amd.CvrError) as e:
+        cvr_amd.CvrMatrix.from_device(nrows, ncols, bad.data_ptr(), tci.data_ptr(), tva.data_ptr())
+    assert e.value.code == capi.ERR_INVALID
+    badc = tci.clone()
+    badc[len(ci) // 3] = ncols
+    torch.cuda.synchronize()
+    with pytest.raises(cvr_amd.CvrError) as e:
+        cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), badc.data_ptr(), tva.data_ptr())
+    assert e.value.code == capi.ERR_INVALID
+
+
 def test_device_arrays_with_column_panels_are_split_on_the_device():
     """the column-panel split runs on the device (cvr_split.hip: one stable radix-sort pass by panel), for device-resident
     arrays and for host arrays (staged once); bit for bit the same y as the host split (CVR_HOST_SPLIT=1, the fallback) of
