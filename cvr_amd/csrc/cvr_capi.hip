@@ -667,9 +667,29 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             const size_t rounds = (h->parts.size() + per_round - 1) / per_round;
             std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr});
             h->multi_chunks.assign(rounds, 0u);
+            // which panel runs where: the heaviest first, each to the XCD with the least work so far that still has a round free (the XCDs
+            // go through their panels independently: what counts is every XCD's sum, not the rounds'); equal-width panels of a real graph
+            // differ in non-zeros
+            std::vector<size_t> slot_of(h->parts.size());
+            if (per_round == 8) {
+                std::vector<size_t> order(h->parts.size());
+                for (size_t j = 0; j < order.size(); j++) order[j] = j;
+                std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return h->parts[a].img.nchunks > h->parts[b].img.nchunks; });
+                uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                size_t   used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t j : order) {
+                    int best = -1;
+                    for (int x = 0; x < 8; x++)
+                        if (used[x] < rounds && (best < 0 || load[x] < load[best])) best = x;
+                    slot_of[j] = used[best] * 8 + (size_t)best;
+                    used[best]++;
+                    load[best] += h->parts[j].img.nchunks;
+                }
+            } else
+                for (size_t j = 0; j < slot_of.size(); j++) slot_of[j] = (j / per_round) * 8 + j % per_round;
             for (size_t j = 0; j < h->parts.size(); j++) {
                 const Part &p = h->parts[j];
-                const size_t i = (j / per_round) * 8 + j % per_round;
+                const size_t i = slot_of[j];
                 pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2};
                 h->multi_chunks[i / 8] = std::max(h->multi_chunks[i / 8], p.img.nchunks);
                 h->multi_ystage = std::max(h->multi_ystage, p.img.ystage);
