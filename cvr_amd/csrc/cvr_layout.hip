@@ -209,17 +209,32 @@ hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64
     return e;
 }
 
-// the resident layout's candidates: 8, 7 or 6 chunks per workgroup with the smallest S that keeps the workgroups a few under the CU
-// count; the one that fills the CUs best wins (ties: more waves).  false: tiny shards and matrices beyond one resident pass
+// The resident layout's candidates: 8 .. 4 chunks per workgroup, each with the smallest S that keeps the workgroups a few under the CU
+// count.  The one whose chunks are closest to 46 steps wins (ties: the longer chunks, then more waves): measured layouts of the
+// web-Google shape, of smaller ones and of its row shards -- whole matrix 7 x 48, half 4 x 44, a third 4 x 32 -- against the 7 x 24 or the
+// plain layout that a rule of "most workgroups, at least 6 chunks each, S >= 24" gave them (profiles/r03_resident_rule.log: half the
+// matrix 14.4 -> 12.8 us, a third 11.1 -> 8.9, one of two row shards 18.2 -> 14.7).
+// false: tiny matrices and matrices beyond one resident pass.  CVR_RESIDENT_RULE=old keeps the former rule (diagnostics).
 bool resident_candidate(double slots, int cus, int *best_w, int *best_S)
 {
     *best_w = 0; *best_S = 0;
-    double best_fill = 0;
-    for (int w = 8; w >= 6; w--) {
-        int S = (int)std::ceil(slots / (64.0 * w * (double)(cus - 4)) / 4.0) * 4;
-        if (S < 24 || S > 128) continue;
-        const double wgs = std::ceil(slots / (64.0 * w * S));
-        if (wgs > best_fill) { best_fill = wgs; *best_w = w; *best_S = S; }
+    static const bool old_rule = getenv("CVR_RESIDENT_RULE") && !strcmp(getenv("CVR_RESIDENT_RULE"), "old");
+    if (old_rule) {
+        double best_fill = 0;
+        for (int w = 8; w >= 6; w--) {
+            int S = (int)std::ceil(slots / (64.0 * w * (double)(cus - 4)) / 4.0) * 4;
+            if (S < 24 || S > 128) continue;
+            const double wgs = std::ceil(slots / (64.0 * w * S));
+            if (wgs > best_fill) { best_fill = wgs; *best_w = w; *best_S = S; }
+        }
+        return *best_w != 0;
+    }
+    int best_d = 1 << 30;
+    for (int w = 8; w >= 4; w--) {
+        const int S = (int)std::ceil(slots / (64.0 * w * (double)(cus - 4)) / 4.0) * 4;
+        if (S < 28 || S > 128) continue;              // (shorter resident chunks lose to the plain layout: 24 x 4 against S = 32 on a quarter of the matrix, 11.5 against 9.9 us)
+        const int d = std::abs(S - 46);
+        if (d < best_d || (d == best_d && S > *best_S)) { best_d = d; *best_w = w; *best_S = S; }
     }
     return *best_w != 0;
 }
