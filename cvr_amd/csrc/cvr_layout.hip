@@ -240,7 +240,7 @@ bool resident_candidate(double slots, int cus, int *best_w, int *best_S)
 }
 
 // The automatic layout (every layout option left at its default; one image, no column panels).  Matrices small enough
-// for all their chunks to be resident at once -- 6 to 8 chunks per workgroup, one workgroup per CU -- run in the "resident"
+// for all their chunks to be resident at once -- 4 to 8 chunks per workgroup, one workgroup per CU -- run in the "resident"
 // layout when it pays: the workgroup's chunks share an LDS window of x if a sizeable share of the non-zeros lies near the
 // diagonal, and feed their rows column phase by column phase when x is larger than what an L2 keeps beside the matrix
 // stream (profiles/r02_wg_window_sweep.log, r02_column_phases_sweep.log: 32.5 -> 23.4 us on the web-Google shape).
