@@ -345,7 +345,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (rc) return rc;
         const double xb = (double)hostv.ncols * (hostv.is_f32 ? 4.0 : 8.0);
         civa_kind = hipMemcpyDeviceToDevice;
-        if (opt.col_panels < 0 && !(xb >= 24e6 && j1 > 0)) opt.col_panels = 1;      // (else: the panel rule runs on the device arrays below)
+        if (opt.col_panels < 0 && !(j1 > 0 && (xb >= 24e6 || (xb >= kMidPanelBytes && resident_out_of_reach(hostv.nrows, j1 - j0, hostv.ncols, hostv.is_f32 != 0, opt)))))
+            opt.col_panels = 1;      // (else: the panel rule runs on the device arrays below)
         // (column panels of device arrays are split on the device: cvr_split.hip)
     }
 
@@ -399,7 +400,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     CREATE_TRY(hipEventCreate(&h->events[1]));
     clk.lap("handle, stream");
     const double t_up0 = now_s();
-    // Host arrays of a matrix that may get column panels (x of 24 MB or more, or panels asked for) are uploaded once, as they
+    // Host arrays of a matrix that may get column panels (x of 24 MB or more -- 12 MB beyond the resident layout --, or panels asked for) are uploaded once, as they
     // are: the panel rule and the split run on that copy (building split arrays on the host means allocating, touching and
     // freeing another copy of the matrix there, which costs more than the PCIe transfer: LiveJournal shape 60 ms to split +
     // 130 ms to free against 20 ms to upload), and a matrix that stays whole adopts it as its device CSR.  The host split
@@ -416,7 +417,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     bool           dev_split = on_device;
     int            P = opt.col_panels;
     const double   xbytes = (double)ncols * (double)vsz;
-    if (!on_device && (P > 1 || (P < 0 && xbytes >= 24e6)) && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !getenv("CVR_HOST_SPLIT")) {
+    // (x of 12 .. 24 MB: the rule also runs for matrices too large for the resident layout -- web-Google shapes of 12-16 M non-zeros run
+    // 21-28 % faster as eight panels, one per XCD, than as one plain image: profiles/r03_mid_size_panels.log)
+    const bool     mid_range = P < 0 && xbytes >= kMidPanelBytes && xbytes < 24e6 && sj1 > sj0 && resident_out_of_reach(nrows, sj1 - sj0, ncols, f32, opt);
+    if (!on_device && (P > 1 || (P < 0 && (xbytes >= 24e6 || mid_range))) && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !getenv("CVR_HOST_SPLIT")) {
         if (hipMalloc(&staged.rp, sizeof(int64_t) * ((size_t)nrows + 1)) == hipSuccess && hipMalloc(&staged.ci, sizeof(int32_t) * (size_t)sj1) == hipSuccess &&
             hipMalloc(&staged.va, vsz * (size_t)sj1) == hipSuccess &&
             hipMemcpy(staged.rp, csr->row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice) == hipSuccess &&
@@ -433,7 +437,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // the panel rule (col_panels < 0): on the device copy when there is one (same windows, same integers as the host form)
     const double t_rule0 = now_s();
     if (P < 0) {
-        if (xbytes < 24e6 || sj1 <= sj0) P = 1;
+        if (!(xbytes >= 24e6 || mid_range) || sj1 <= sj0) P = 1;
         else if (dev_split) {
             double miss = 0;
             CREATE_TRY(l2_miss_estimate_dev(rp_d, ci_d, nrows, ncols, f32, h->stream, &miss));
@@ -446,6 +450,28 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     const char *xp_env = getenv("CVR_XCD_PANELS");
     const bool  xcd_panels = !(xp_env && atoi(xp_env) == 0) && opt.xcds == 8;
     if (P > 1 && panels_auto && xcd_panels && dev_split) P = xcd_panel_count(P, xbytes);      // (the host rule, auto_panels, has counted them that way already)
+    // Power-law matrices whose popular columns will sit in hub tables need fewer, wider panels: the table takes the hot
+    // half of the gathers off the L2s, and what remains runs best with ~16 MB of x per panel instead of ~4 (R-MAT-26 fp32
+    // on one GPU: 59 panels 6.4 ms, 16 panels 5.4 ms; R-MAT-24: 8 and 4 panels alike; profiles/r02_hub_table_rmat.log)
+    if (P > 1 && dev_split && panels_auto && opt.hub_table < 0 && opt.waves_per_block == 0 && opt.x_window <= 0 && !getenv("CVR_NO_AUTO_LAYOUT")) {      // (the predicate of choose_hubs: only panels that will get tables are widened)
+        const int64_t room = ((int64_t)cvr::kLdsBytes / (int64_t)vsz - 8 * (cvr::kLanes + 512) - cvr::kDictMax - 8) & ~(int64_t)1023;
+        cvr::HubSelection sel;
+        const double      th0 = now_s();
+        const hipError_t  e = cvr::select_hubs(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &sel, h->stream);
+        in.hub_select_s += now_s() - th0;
+        const double share = sel.share;
+        cvr::free_hubs(sel);
+        if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
+        if (share >= 0.25) {       // (of the whole matrix: the panels' own tables, ranked inside their ranges, hold more)
+            const int Pw = std::max(2, (int)std::ceil((double)ncols * (double)vsz / 16e6));
+            if (mid_range) P = 1;      // (an x of one such panel: the single image with its hub table, as before -- R-MAT-22 fp32)
+            else if (Pw < P) P = Pw;
+        }
+        // popularity too flat for any panel's table to reach the half it needs (a panel's own top columns hold a few times
+        // the whole matrix's share at most: LiveJournal shape 0.06): the panels skip their own counting passes
+        if (share < 0.08) opt.hub_table = 0;
+    }
+    clk.lap("panel count with hub tables");
     if (P < 1) P = 1;
     if (P > 64) P = 64;
     in.col_panels = P;
@@ -470,27 +496,6 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         PanelSplit   sp;
         struct SplitGuard { cvr::DeviceSplit d; ~SplitGuard() { cvr::free_device_split(d); } } dsg;
         const double t0 = now_s();
-        // Power-law matrices whose popular columns will sit in hub tables need fewer, wider panels: the table takes the hot
-        // half of the gathers off the L2s, and what remains runs best with ~16 MB of x per panel instead of ~4 (R-MAT-26 fp32
-        // on one GPU: 59 panels 6.4 ms, 16 panels 5.4 ms; R-MAT-24: 8 and 4 panels alike; profiles/r02_hub_table_rmat.log)
-        if (dev_split && panels_auto && opt.hub_table < 0 && opt.waves_per_block == 0 && opt.x_window <= 0 && !getenv("CVR_NO_AUTO_LAYOUT")) {      // (the predicate of choose_hubs: only panels that will get tables are widened)
-            const int64_t room = ((int64_t)cvr::kLdsBytes / (int64_t)vsz - 8 * (cvr::kLanes + 512) - cvr::kDictMax - 8) & ~(int64_t)1023;
-            cvr::HubSelection sel;
-            const double      th0 = now_s();
-            const hipError_t  e = cvr::select_hubs(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &sel, h->stream);
-            in.hub_select_s += now_s() - th0;
-            const double share = sel.share;
-            cvr::free_hubs(sel);
-            if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
-            if (share >= 0.25) {       // (of the whole matrix: the panels' own tables, ranked inside their ranges, hold more)
-                const int Pw = std::max(2, (int)std::ceil((double)ncols * (double)vsz / 16e6));
-                if (Pw < P) { P = Pw; h->parts.resize((size_t)P); in.col_panels = P; }
-            }
-            // popularity too flat for any panel's table to reach the half it needs (a panel's own top columns hold a few times
-            // the whole matrix's share at most: LiveJournal shape 0.06): the panels skip their own counting passes
-            if (share < 0.08) opt.hub_table = 0;
-        }
-        clk.lap("  panel count with hub tables");
         std::vector<int64_t> nsubs((size_t)P, 0);
         if (dev_split) {        // nothing but a few counts comes to the host: the sub-rows are planned where they are (cvr_plan_dev.hip)
             const int64_t  width = (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1;

@@ -239,6 +239,29 @@ bool resident_candidate(double slots, int cus, int *best_w, int *best_S)
     return *best_w != 0;
 }
 
+// A matrix with every layout option left to the rules that is too large for the resident layout: more slots than 8 chunks of 128 steps per
+// workgroup hold, or more rows than the chunks' LDS accumulators (plan_layout's row cap) take in one pass -- web-Google shapes from ~11 M
+// non-zeros on (2.2 M rows / 987 per chunk > 2 048 chunks), which the planner would find out after planning (build_part: stuck -> plain
+// layout).  cvr_create asks before it decides about column panels.
+bool resident_out_of_reach(int64_t nrows, int64_t nnz, int64_t ncols, bool f32, const IOpt &opt)
+{
+    if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT")) return false;
+    if (nrows < 4096 || ncols < 4096 || opt.cus <= 4) return false;
+    const int64_t vs = f32 ? 4 : 8;
+    const double  slots = ((double)nnz + (double)nrows / 4) * 1.006;
+    int           w = 0, S = 0;
+    if (!resident_candidate(slots, opt.cus, &w, &S)) return slots > 64.0 * 8 * 128 * (double)(opt.cus - 4);      // (else: too small for it)
+    PartPlan pp;
+    IOpt     spec = opt;
+    spec.waves_per_block = w; spec.steps_per_chunk = S; spec.x_window = (int32_t)((96 * 1024) / vs);
+    spec.col_phases = (int32_t)std::min(32.0, std::max(2.0, std::floor((double)ncols * vs / 450e3 + 0.5)));
+    pp.S = S;
+    const int64_t max_rows = plan_layout(pp, ncols, f32, spec);
+    // (chunks close at the row cap or at their slots, whichever comes first: the web-Google shape fits up to 0.975 of the chunks by rows alone,
+    // not at 0.9975 -- profiles/r03_mid_size_panels.log)
+    return max_rows > 0 && (double)((nrows + max_rows - 1) / max_rows) > 0.985 * (double)w * opt.cus;
+}
+
 // The automatic layout (every layout option left at its default; one image, no column panels).  Matrices small enough
 // for all their chunks to be resident at once -- 4 to 8 chunks per workgroup, one workgroup per CU -- run in the "resident"
 // layout when it pays: the workgroup's chunks share an LDS window of x if a sizeable share of the non-zeros lies near the

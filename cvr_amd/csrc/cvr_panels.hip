@@ -165,6 +165,7 @@ int xcd_panel_count(int P, double xbytes)
     const char *e = getenv("CVR_XCD_PANELS");
     if (P <= 1 || (e && atoi(e) == 0)) return P;
     if (e && atoi(e) > 1) return std::min(64, atoi(e));
+    if (xbytes <= 27e6) return 8;       // (the first round of eight stretches further: web-Google shapes of 23.5 / 26.4 MB 98.0 / 110.1 us as 8, 102.0 / 111.6 as 16 panels)
     return std::min(64, 8 * std::max(1, (int)std::ceil(xbytes / (8.0 * 2.6e6))));
 }
 
@@ -173,7 +174,9 @@ int auto_panels(const cvr_csr_view &v, double *miss_out)
     const double xb = (double)v.ncols * (v.is_f32 ? 4.0 : 8.0);
     int          P = 1;
     double       miss = 0;
-    if (xb >= 24e6) {
+    const int64_t nnz = v.nrows > 0 ? v.row_ptr[v.nrows] - v.row_ptr[0] : 0;
+    // (x of 12 .. 24 MB: only matrices beyond the resident layout of a whole MI355X; cvr_create also looks at the hub share there)
+    if (xb >= 24e6 || (xb >= kMidPanelBytes && nnz > 0 && resident_out_of_reach(v.nrows, nnz, v.ncols, v.is_f32 != 0, make_iopt(nullptr)))) {
         miss = l2_miss_estimate(v);
         P = panels_from_miss(xb, miss);
     }

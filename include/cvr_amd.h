@@ -199,8 +199,10 @@ int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream)
 /* the same, `n` launches back to back (the Ntimes loop of spmv.cpp:1024 without a host round trip per launch) */
 int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *stream, int n);
 /* The column-panel count cvr_create chooses for col_panels = -1 (host only, no device needed): 1 unless x is >= 24 MB
+ * -- or >= 12 MB and the matrix is too large for the resident layout (more slots or rows than its workgroups hold in one pass) --
  * and the estimated share of x gathers missing a 4-MiB L2 (*l2_miss_estimate, sampled over eight windows of 65 536
- * rows) exceeds 0.17; then one panel per 1.8 MB of missing x.  Returns the count (>= 1) or a negative error. */
+ * rows) exceeds 0.17; then one panel per 1.8 MB of missing x, counted in rounds of eight (one panel per XCD at a time: eight up
+ * to 27 MB of x, then 8 * ceil(x / 20.8 MB)).  Returns the count (>= 1) or a negative error. */
 int cvr_auto_panels(const cvr_csr_view *csr, double *l2_miss_estimate);
 
 /* Optional tuning of steps_per_chunk by measurement: builds the matrix with S = 8, 12, ... 64 on the device, times the

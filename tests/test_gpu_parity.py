@@ -315,6 +315,31 @@ def test_fused_preprocessing_falls_back(kind):
     A.close()
 
 
+@pytest.mark.parametrize("arrays", ["host", "device"])
+def test_matrices_beyond_the_resident_layout_get_panels_from_12_mb_of_x(arrays):
+    """x of 12 .. 24 MB: a matrix with more rows than the resident layout's chunks accumulate in one pass (web-Google shape x 2.4: 2.2 M rows,
+    x = 17.6 MB) runs as eight column panels, one per XCD (76 against 97 us as one plain image: profiles/r03_mid_size_panels.log); one that
+    the resident layout holds (x 1.7: x = 12.5 MB) stays a single image with column phases.  From host arrays and from device arrays;
+    y against the CSR oracle."""
+    import torch
+    for scale, panels in ((2.4, 8), (1.7, 1)):
+        nrows, ncols, rp, ci, va = synth.web_google_like(scale)
+        assert 12e6 <= ncols * 8 < 24e6
+        if arrays == "device":
+            trp, tci, tva = (torch.from_numpy(a).cuda() for a in (rp, ci, va))
+            A = cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), tci.data_ptr(), tva.data_ptr(), is_f32=False)
+        else:
+            A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+        i = A.info
+        assert i.col_panels == panels, (scale, i.col_panels)
+        assert (i.col_phases > 1 and i.waves_per_block >= 4) if panels == 1 else i.col_phases == 1
+        x = O.x_vec_fast(ncols, "rand")
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL64, f"scale {scale}")
+        A.close()
+
+
 @pytest.mark.parametrize("kind", ["device_arrays", "rectangular", "row_shard", "reconvert"])
 def test_fused_preprocessing_other_inputs(kind, monkeypatch):
     """The one-submission path with CSR arrays that are already on the device, a rectangular matrix (more columns than rows), a row

@@ -284,6 +284,14 @@ def test_auto_panel_rule_on_the_host():
     m = 1_000_000                                                          # x = 8 MB: never panelled
     P, miss = capi.auto_panels(m, m, rp[:m + 1], scattered[:2 * m] % m)
     assert P == 1 and miss == 0.0
+    # x of 12 .. 24 MB: the rule runs only for matrices beyond the resident layout (here: more rows than 4 chunks per workgroup
+    # accumulate in LDS in one pass); one that the resident layout holds stays whole
+    m = 2_400_000                                                          # x = 19.2 MB, 2.4 M rows
+    P, miss = capi.auto_panels(m, m, rp[:m + 1], scattered[:2 * m] % m)
+    assert P == 8 and miss > 0.6
+    m = 1_600_000                                                          # x = 12.8 MB, 1.6 M rows: resident (5 x 48)
+    P, miss = capi.auto_panels(m, m, rp[:m + 1], scattered[:2 * m] % m)
+    assert P == 1 and miss == 0.0
     assert capi.lib().cvr_auto_panels(None, None) == capi.ERR_INVALID
 
 
