@@ -382,6 +382,21 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }                                                                                                   \
     } while (0)
     CREATE_TRY(hipSetDevice(h->device));
+    // The first cvr_create of a process: the runtime loads a file's code object when one of its kernels is first asked for (milliseconds, on the
+    // calling thread).  A thread of its own asks now, beside the allocations and the upload below; joined before this call returns.
+    struct Warm {
+        std::thread t;
+        ~Warm() { if (t.joinable()) t.join(); }
+    } warm;
+    {
+        static std::atomic<bool> warmed{false};
+        if (!warmed.exchange(true) && !getenv("CVR_NO_WARM_THREAD"))
+            warm.t = std::thread([dev = h->device] {
+                if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
+                cvr::touch_plan_kernels(); cvr::touch_convert_kernels(); cvr::touch_spmv_kernels();
+                (void)side_stream(dev, 0); (void)side_stream(dev, 1);      // (created on first use otherwise: milliseconds each)
+            });
+    }
     CREATE_TRY(acquire_stream(h->device, &h->stream));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->plan_ws.pinned), h->plan_ws.pinned_bytes = nrows >= device_plan_rows() ? (size_t)704 << 10 : kPinnedSmall, hipHostMallocDefault));
     CREATE_TRY(hipMalloc(&h->d_small, kSmallBytes));

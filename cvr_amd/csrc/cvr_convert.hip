@@ -1477,4 +1477,15 @@ hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream
     return hipGetLastError();
 }
 
+// (cvr_create's warm-up thread: asking for a kernel's attributes makes the runtime load this file's code object, which the first launch would
+// otherwise wait for)
+void touch_convert_kernels()
+{
+    hipFuncAttributes a;
+    for (const void *k : {reinterpret_cast<const void *>(&seg_scan_kernel), reinterpret_cast<const void *>(&seg_total_kernel), reinterpret_cast<const void *>(&window_kernel),
+                          reinterpret_cast<const void *>(&probe_kernel)})
+        (void)hipFuncGetAttributes(&a, k);
+    (void)hipGetLastError();
+}
+
 }  // namespace cvr

@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <atomic>
 #include <thread>
 #include <vector>
 

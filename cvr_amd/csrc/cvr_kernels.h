@@ -209,4 +209,8 @@ hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const ui
 // 16-B-per-lane streaming copy (roofline calibration)
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st);
 
+void touch_convert_kernels();
+void touch_plan_kernels();
+void touch_spmv_kernels();
+
 }  // namespace cvr

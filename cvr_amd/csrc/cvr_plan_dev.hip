@@ -485,4 +485,15 @@ hipError_t launch_block_off(const uint32_t *rows, uint32_t n, uint32_t nblocks, 
     return hipGetLastError();
 }
 
+// (cvr_create's warm-up thread: asking for a kernel's attributes makes the runtime load this file's code object, which the first launch would
+// otherwise wait for)
+void touch_plan_kernels()
+{
+    hipFuncAttributes a;
+    for (const void *k : {reinterpret_cast<const void *>(&tile_kernel), reinterpret_cast<const void *>(&q_kernel), reinterpret_cast<const void *>(&jump_kernel),
+                          reinterpret_cast<const void *>(&walk_kernel), reinterpret_cast<const void *>(&emit_kernel)})
+        (void)hipFuncGetAttributes(&a, k);
+    (void)hipGetLastError();
+}
+
 }  // namespace cvr

@@ -965,4 +965,13 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     return hipGetLastError();
 }
 
+// (cvr_create's warm-up thread: asking for a kernel's attributes makes the runtime load this file's code object, which the first launch would
+// otherwise wait for)
+void touch_spmv_kernels()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&copy_kernel));
+    (void)hipGetLastError();
+}
+
 }  // namespace cvr
