@@ -565,9 +565,13 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         int64_t zoff = 0, nsub = 0;
         for (int p = 0; p < P; p++) {
             Part &part = h->parts[(size_t)p];
-            if (dev_split)
-                rc = build_part(h, part, nsubs[(size_t)p], ncols, nullptr, dsg.d.ci + dsg.d.off[p],
-                                static_cast<const uint8_t *>(dsg.d.va) + (size_t)dsg.d.off[p] * vsz, hipMemcpyDeviceToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p], &drs[(size_t)p]);
+            if (dev_split) {       // the panel's column indices and values stay where the split put them (the handle owns the split's arrays from here on)
+                if (p == 0) { h->split_ci = dsg.d.ci; h->split_va = dsg.d.va; dsg.d.ci = nullptr; dsg.d.va = nullptr; }
+                part.d_ci = h->split_ci + dsg.d.off[p];
+                part.d_va = static_cast<uint8_t *>(h->split_va) + (size_t)dsg.d.off[p] * vsz;
+                part.csr_borrowed = true;
+                rc = build_part(h, part, nsubs[(size_t)p], ncols, nullptr, part.d_ci, part.d_va, hipMemcpyDeviceToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p], &drs[(size_t)p]);
+            }
             else
                 rc = build_part(h, part, nsubs[(size_t)p], ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
                                 sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p]);
@@ -774,7 +778,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
         if (seconds) *seconds = h->info.convert_s;
         h->info.preprocess_wall_s = now_s() - t_wall0;
         h->converted = true;
-        if (!keep_csr) for (Part &p : h->parts) p.release_csr();
+        if (!keep_csr) { for (Part &p : h->parts) p.release_csr(); h->release_split(); }
         return CVR_OK;
     }
     if (h->events.size() < 2) {
@@ -855,7 +859,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     for (uint32_t v : seg_totals) h->info.nsegments += v;
     h->info.preprocess_wall_s = now_s() - t_wall0;
     h->converted = true;
-    if (!keep_csr) for (Part &p : h->parts) p.release_csr();
+    if (!keep_csr) { for (Part &p : h->parts) p.release_csr(); h->release_split(); }
     return CVR_OK;
 }
 
@@ -872,6 +876,7 @@ int cvr_destroy(cvr_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Part &p : h->parts) p.release_all();
+    h->release_split();
     cvr::free_plan_scratch(h->plan_ws);
     if (h->seg_arena) (void)hipFree(h->seg_arena);
     if (h->d_small) (void)hipFree(h->d_small);

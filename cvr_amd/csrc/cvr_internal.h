@@ -98,11 +98,12 @@ struct Part {
     int64_t   nrows = 0, nnz = 0, nnz_span = 0, nchunks = 0, nshared = 0, yext = 0;
     int64_t   zoff = 0;        // panels: where this part's y_ext starts in the partial-sum buffer z
 
+    bool      csr_borrowed = false;      // d_ci / d_va point into the handle's split arena (column panels split on the device): not this part's to free
     void release_csr()
     {
         if (d_rp) (void)hipFree(d_rp);
-        if (d_ci) (void)hipFree(d_ci);
-        if (d_va) (void)hipFree(d_va);
+        if (d_ci && !csr_borrowed) (void)hipFree(d_ci);
+        if (d_va && !csr_borrowed) (void)hipFree(d_va);
         if (d_nzb) (void)hipFree(d_nzb);
         if (d_pad) (void)hipFree(d_pad);
         d_rp = nullptr; d_ci = nullptr; d_va = nullptr; d_nzb = nullptr; d_pad = nullptr;
@@ -137,6 +138,9 @@ struct cvr_handle {
     // where each block of kCombineRows rows starts in every panel (combine_kernel)
     void     *d_z = nullptr;
     uint32_t *d_rows = nullptr, *d_block_off = nullptr;
+    int32_t  *split_ci = nullptr;          // the device split's column indices and values, panel after panel: the parts' CSR arrays are slices of these
+    void     *split_va = nullptr;          // (freed with the parts' CSR: after the conversion, or with the handle when it keeps its CSR)
+    void      release_split() { if (split_ci) (void)hipFree(split_ci); if (split_va) (void)hipFree(split_va); split_ci = nullptr; split_va = nullptr; }
     cvr::CombinePanel *d_cpanels = nullptr;
     void     *d_dict = nullptr;           // value dictionary (sorted by bit pattern) shared by all parts, or null
     uint32_t  ndict = 0;

@@ -524,7 +524,7 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
     const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
     const size_t  vsz = f32 ? 4 : 8, nnz_span = (size_t)nz1;   // arrays are indexed literally from 0
     // the CSR goes to the device first (asynchronously): the automatic layout choice below looks at it there
-    const bool adopted = rp && part.d_rp && part.d_ci && part.d_va;      // cvr_create's staging copy of the whole CSR, handed over
+    const bool adopted = part.d_ci && part.d_va && (rp ? part.d_rp != nullptr : part.csr_borrowed);      // cvr_create's staging copy of the whole CSR, handed over; or a panel's slices of the device split
     if (rp && !adopted) HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)nrows + 1)));
     if (!adopted) HIP_TRY(hipMalloc(&part.d_ci, sizeof(int32_t) * std::max<size_t>(nnz_span, 1)));
     if (!adopted) HIP_TRY(hipMalloc(&part.d_va, vsz * std::max<size_t>(nnz_span, 1)));

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void split_emit_kernel(const uint32_t *__restr
 // owns eight consecutive non-zeros, counts them per panel in a column of its own in LDS, a scan in (panel, thread) order ranks them --
 // the order inside a panel stays the CSR's, as the stable sort left it -- and the row of a thread's first element is one search, the
 // others follow from row_ptr.  The CSR is read once (the column indices twice).
-constexpr int kPartTile = 2048, kPartThreads = 256, kPartPer = kPartTile / kPartThreads;
+constexpr int kPartTile = 2048, kPartThreads = 256, kPartPer = kPartTile / kPartThreads, kPartRows = 3072;
 
 __global__ __launch_bounds__(kPartThreads) void part_count_kernel(const int32_t *__restrict__ ci, long long nz0, long long n, uint32_t width, int P, uint32_t ntiles,
                                                                    uint32_t *__restrict__ cnt)
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kPartThreads) void part_scatter_kernel(const long l
                                                                      long long nz0, long long n, uint32_t width, int P, uint32_t ntiles, const uint32_t *__restrict__ base,
                                                                      int32_t *__restrict__ ci_s, T *__restrict__ va_s, uint32_t *__restrict__ row_s)
 {
-    extern __shared__ uint16_t hist[];                  // [P][kPartThreads], then pstart[P] (u32)
+    extern __shared__ __attribute__((aligned(16))) uint16_t hist[];                  // [P][kPartThreads], then pstart[P] (u32), then the staged tile
     uint32_t *pstart = reinterpret_cast<uint32_t *>(hist + (size_t)P * kPartThreads);
     __shared__ uint32_t wsum[kPartThreads / 64];
     const uint32_t tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -126,15 +126,52 @@ __global__ __launch_bounds__(kPartThreads) void part_scatter_kernel(const long l
         pan[q] = (uint8_t)((uint32_t)c[q] / width);
         if (t0 + q < n) hist[pan[q] * kPartThreads + tid] += 1;
     }
-    // the row of the thread's first element: the last r with rp[r] <= j (its later elements follow from row_ptr)
-    long long r = 0;
-    if (t0 < n) {
-        const long long j = nz0 + t0;
-        long long lo = 0, hi = nrows;
-        while (lo < hi) { const long long mid = (lo + hi + 1) >> 1; if (rp[mid] <= j) lo = mid; else hi = mid - 1; }
-        r = lo;
+    // Rows.  The row of an element j is the last r with rp[r] <= j.  The workgroup finds the rows of the tile's first and of its last element
+    // together (one half each, 128 probes per step: 4 dependent loads where a binary search per thread takes 23), brings the row pointers
+    // between them into LDS (relative to the tile's first element), and every thread then looks its first row up there; its later elements
+    // follow from the same copy.  A tile that spans more rows than the copy holds (long runs of empty rows) searches row_ptr itself.
+    __shared__ long long s_lo[2], s_hi[2];
+    __shared__ unsigned long long s_best[2];
+    __shared__ int32_t   srp[kPartRows];
+    const long long tile0 = (long long)tile * kPartTile, tile_n = n - tile0 < kPartTile ? n - tile0 : (long long)kPartTile;
+    {
+        const uint32_t  g = tid >> 7, m = tid & 127u;
+        const long long j = nz0 + tile0 + (g ? tile_n - 1 : 0);
+        if (m == 0) { s_lo[g] = 0; s_hi[g] = nrows; }
+        __syncthreads();
+        while (s_hi[0] > s_lo[0] || s_hi[1] > s_lo[1]) {                 // (uniform: both halves take part in every barrier)
+            const long long lo = s_lo[g], hi = s_hi[g], step = (hi - lo) / 128 + 1, rm = lo + (long long)m * step;
+            if (m == 0) s_best[g] = (unsigned long long)lo;
+            __syncthreads();
+            if (m > 0 && rm <= hi && rp[rm] <= j) atomicMax(&s_best[g], (unsigned long long)rm);
+            __syncthreads();
+            if (m == 0) { const long long b = (long long)s_best[g]; s_lo[g] = b; s_hi[g] = b + step - 1 < hi ? b + step - 1 : hi; }
+            __syncthreads();
+        }
     }
+    const long long r_first = s_lo[0], nr = s_lo[1] - r_first + 2;      // rp[r_first .. r_last + 1]
+    const bool      rows_in_lds = nr <= (long long)kPartRows;
+    if (rows_in_lds)
+        for (long long i = tid; i < nr; i += kPartThreads) {
+            const long long d = rp[r_first + i] - (nz0 + tile0);
+            srp[i] = d < -1 ? -1 : d > (1 << 30) ? (1 << 30) : (int32_t)d;
+        }
     __syncthreads();
+    long long r = 0;
+    int32_t   li = 0;                                                    // r - r_first
+    if (t0 < n) {
+        if (rows_in_lds) {
+            const int32_t jl = (int32_t)(tid * kPartPer);
+            int32_t       lo = 0, hi = (int32_t)nr - 2;
+            while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (srp[mid] <= jl) lo = mid; else hi = mid - 1; }
+            li = lo; r = r_first + lo;
+        } else {
+            const long long j = nz0 + t0;
+            long long lo = 0, hi = nrows;
+            while (lo < hi) { const long long mid = (lo + hi + 1) >> 1; if (rp[mid] <= j) lo = mid; else hi = mid - 1; }
+            r = lo;
+        }
+    }
     // ranks: hist in (panel, thread) order -- a thread sums P consecutive entries, the sums are scanned over the workgroup
     uint32_t mine = 0;
     for (int q = 0; q < P; q++) mine += hist[tid * P + q];
@@ -149,18 +186,35 @@ __global__ __launch_bounds__(kPartThreads) void part_scatter_kernel(const long l
     __syncthreads();
     if ((int)tid < P) pstart[tid] = hist[tid * kPartThreads];          // elements of the tile in the panels in front of panel tid
     __syncthreads();
-    long long rnext = r < nrows ? rp[r + 1] : 0x7fffffffffffffffll;
+    // the elements go through LDS in their order inside the tile's share of every panel (slot = the rank the scan gave), so that the stores
+    // below run along each panel's array instead of hopping between the panels element by element (soc-LiveJournal1 shape, 16 panels: 1.17 -> 0.xx ms)
+    T        *sv = reinterpret_cast<T *>(reinterpret_cast<uint8_t *>(hist) + (((size_t)P * kPartThreads * sizeof(uint16_t) + (size_t)P * sizeof(uint32_t) + 7) & ~(size_t)7));
+    int32_t  *sc = reinterpret_cast<int32_t *>(sv + kPartTile);
+    uint32_t *sr = reinterpret_cast<uint32_t *>(sc + kPartTile);
+    long long rnext = rows_in_lds ? (long long)srp[li + 1] + nz0 + tile0 : r < nrows ? rp[r + 1] : 0x7fffffffffffffffll;
 #pragma unroll
     for (int q = 0; q < kPartPer; q++) {
         const long long t = t0 + q;
         if (t >= n) break;
         const long long j = nz0 + t;
-        while (j >= rnext) { r++; rnext = rp[r + 1]; }                  // (empty rows are stepped over)
+        if (rows_in_lds) while (j >= rnext) { r++; li++; rnext = (long long)srp[li + 1] + nz0 + tile0; }      // (empty rows are stepped over)
+        else while (j >= rnext) { r++; rnext = rp[r + 1]; }
         const uint32_t p = pan[q];
         const uint32_t slot = hist[p * kPartThreads + tid];
         hist[p * kPartThreads + tid] = (uint16_t)(slot + 1);
-        const size_t pos = (size_t)base[(size_t)p * ntiles + tile] + (slot - pstart[p]);
-        ci_s[pos] = c[q]; va_s[pos] = v[q]; row_s[pos] = (uint32_t)r;
+        sc[slot] = c[q]; sv[slot] = v[q]; sr[slot] = (uint32_t)r;
+    }
+    __syncthreads();
+    const long long left = n - (long long)tile * kPartTile;
+    const uint32_t  cnt = left < kPartTile ? (uint32_t)left : (uint32_t)kPartTile;
+#pragma unroll
+    for (int q = 0; q < kPartPer; q++) {
+        const uint32_t i = (uint32_t)q * kPartThreads + tid;
+        if (i >= cnt) break;
+        int lo = 0, hi = P - 1;                                        // the panel of slot i: the last p with pstart[p] <= i
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pstart[mid] <= i) lo = mid; else hi = mid - 1; }
+        const size_t pos = (size_t)base[(size_t)lo * ntiles + tile] + (i - pstart[lo]);
+        ci_s[pos] = sc[i]; va_s[pos] = sv[i]; row_s[pos] = sr[i];
     }
 }
 
@@ -339,7 +393,11 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
         uint32_t      *cnt = reinterpret_cast<uint32_t *>(arena + o_part), *base = cnt + (size_t)P * ntiles;
         hipLaunchKernelGGL(part_count_kernel, dim3(ntiles), dim3(kPartThreads), 0, st, ci_dev, (long long)nz0, n, (uint32_t)width, P, ntiles, cnt);
         SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(work, part_scan_bytes, cnt, base, (unsigned int)((size_t)P * ntiles), st));
-        const size_t lds = sizeof(uint16_t) * (size_t)P * kPartThreads + sizeof(uint32_t) * (size_t)P;
+        const size_t lds = sizeof(uint16_t) * (size_t)P * kPartThreads + sizeof(uint32_t) * (size_t)P + (size_t)kPartTile * (8 + vsz) + 8;      // hist, pstart, the staged tile
+        if (lds > (size_t)48 * 1024) {        // (many panels: more dynamic LDS than a kernel gets without asking)
+            (void)hipFuncSetAttribute(f32 ? reinterpret_cast<const void *>(&part_scatter_kernel<float>) : reinterpret_cast<const void *>(&part_scatter_kernel<double>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        }
         if (f32) hipLaunchKernelGGL(part_scatter_kernel<float>, dim3(ntiles), dim3(kPartThreads), lds, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const float *>(va_dev),
                                     (long long)nz0, n, (uint32_t)width, P, ntiles, base, out->ci, static_cast<float *>(out->va), row_s);
         else hipLaunchKernelGGL(part_scatter_kernel<double>, dim3(ntiles), dim3(kPartThreads), lds, st, (const long long *)rp_dev, (long long)nrows, ci_dev, static_cast<const double *>(va_dev),
