@@ -1027,6 +1027,13 @@ def test_device_arrays_with_column_panels_are_split_on_the_device():
         rng.shuffle(seg)
     todo.append(("unsorted rows", (nrows, ncols, rp, ci_shuffled, va), 5))
     todo.append(("fp32", CASES32["power_law_3000"], 4))
+    # several tiles of the split (2 048 non-zeros each); one of them spans more rows than the workgroup's copy of the row pointers holds (a run
+    # of 9 000 empty rows: that tile searches row_ptr itself), the others look their rows up in LDS; single-element rows and a 3 000-element row
+    deg = np.concatenate([rng.integers(1, 40, 300), np.zeros(9000, dtype=np.int64), np.ones(2500, dtype=np.int64), [3000], rng.integers(0, 6, 4000)])
+    n2 = len(deg)
+    rp2 = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    ci2 = np.concatenate([np.sort(rng.choice(n2, int(k), replace=False)) for k in deg]).astype(np.int32)
+    todo.append(("long run of empty rows", (n2, n2, rp2, ci2, rng.standard_normal(len(ci2))), 5))
     for name, (nrows, ncols, rp, ci, va), P in todo:
         trp = torch.from_numpy(np.ascontiguousarray(rp, dtype=np.int64)).to(dev)
         tci = torch.from_numpy(np.ascontiguousarray(ci, dtype=np.int32)).to(dev)
