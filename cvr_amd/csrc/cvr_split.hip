@@ -370,8 +370,11 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
     size_t       part_scan_bytes = 0;
     SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, part_scan_bytes, head, sidx, (unsigned int)part_n, st));
     auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t nn = (size_t)std::max<long long>(n, 4);
-    const size_t o_key_in = 0, o_key = o_key_in + up(nn), o_idx_in = o_key + up(nn), o_idx = o_idx_in + up(4 * nn), o_row = o_idx + up(4 * nn),
+    static const bool by_sort = getenv("CVR_SPLIT_SORT") != nullptr;      // (diagnostics: the sort-and-gather form)
+    const bool   partition = !by_sort && width < (1ll << 31);
+    if (partition) sort_bytes = 0;                                        // (keys, positions and the sort's work space -- 10 B per non-zero and more -- are the sort form's only)
+    const size_t nn = (size_t)std::max<long long>(n, 4), ns = partition ? 4 : nn;
+    const size_t o_key_in = 0, o_key = o_key_in + up(ns), o_idx_in = o_key + up(ns), o_idx = o_idx_in + up(4 * ns), o_row = o_idx + up(4 * ns),
                  o_head = o_row + up(4 * nn), o_sidx = o_head + up(4 * nn), o_off = o_sidx + up(4 * nn), o_part = o_off + up(sizeof(long long) * 3 * (kMaxSplitPanels + 2) + 64), o_work = o_part + up(8 * part_n),
                  total = o_work + up(std::max(std::max(sort_bytes, scan_bytes), part_scan_bytes));
     SPLIT_TRY(tmp.alloc(&arena, total));
@@ -387,8 +390,7 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
         SPLIT_TRY(hipMemsetAsync(out->rp, 0, 16, st));
         return hipStreamSynchronize(st);
     }
-    static const bool by_sort = getenv("CVR_SPLIT_SORT") != nullptr;      // (diagnostics: the sort-and-gather form)
-    if (!by_sort && width < (1ll << 31) && n > 0) {
+    if (partition && n > 0) {
         const uint32_t ntiles = (uint32_t)((n + kPartTile - 1) / kPartTile);
         uint32_t      *cnt = reinterpret_cast<uint32_t *>(arena + o_part), *base = cnt + (size_t)P * ntiles;
         hipLaunchKernelGGL(part_count_kernel, dim3(ntiles), dim3(kPartThreads), 0, st, ci_dev, (long long)nz0, n, (uint32_t)width, P, ntiles, cnt);
