@@ -1059,6 +1059,33 @@ def test_device_arrays_with_column_panels_are_split_on_the_device():
         B.close()
 
 
+def test_panels_keep_their_slices_of_the_split_until_the_csr_is_released():
+    """Column panels split on the device: the panels' column indices and values are slices of the split's arrays, owned by the handle.  A handle
+    that keeps its CSR converts a second time from them (same y bit for bit), releases them with the third conversion, and a further cvr_preprocess
+    is refused with a code because the CSR is gone; device memory returns to its level after cvr_destroy."""
+    import torch
+    nrows, ncols, rp, ci, va = synth.web_google_like(0.25)
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=4, keep_csr=True).close()      # (what a process allocates once: code objects, streams, the runtime's pools)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=4, keep_csr=True)
+    assert A.info.col_panels == 4
+    y1 = A.spmv(x)[0].copy()
+    _assert_close(y1, yref, absy, TOL64, "first conversion")
+    sec = capi.C.c_double()
+    assert capi.lib().cvr_preprocess(A._h, 1, capi.C.byref(sec)) == 0          # again, still keeping the CSR
+    assert np.array_equal(A.spmv(x)[0].view(np.uint8), y1.view(np.uint8))
+    assert capi.lib().cvr_preprocess(A._h, 0, capi.C.byref(sec)) == 0          # and once more, releasing it
+    assert np.array_equal(A.spmv(x)[0].view(np.uint8), y1.view(np.uint8))
+    assert capi.lib().cvr_preprocess(A._h, 0, capi.C.byref(sec)) != 0          # nothing left to convert from
+    assert np.array_equal(A.spmv(x)[0].view(np.uint8), y1.view(np.uint8))
+    A.close()
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < (8 << 20)
+
+
 def test_spmv_launches_can_be_captured_in_a_hip_graph():
     """cvr_spmv_device makes no synchronising call: a caller can capture it (here with torch.cuda.graph) and replay"""
     import torch
