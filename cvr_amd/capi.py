@@ -35,7 +35,7 @@ class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
                 ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("waves_per_block", C.c_int32),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("hub_table", C.c_int32), ("narrow_cols", C.c_int32),
-                ("hub_reorder", C.c_int32), ("row_tags16", C.c_int32), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("hub_reorder", C.c_int32), ("row_tags16", C.c_int32), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("interleave", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Timing(C.Structure):
@@ -52,7 +52,7 @@ class Info(C.Structure):
                 ("plan_s", C.c_double), ("upload_s", C.c_double), ("convert_s", C.c_double),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("waves_per_block", C.c_int32),
                 ("x_window", C.c_int32), ("lds_bytes", C.c_int32), ("nsegments", C.c_int64), ("chunk_row_cap", C.c_int64), ("near_diagonal_share", C.c_double), ("hub_entries", C.c_int32), ("narrow_cols", C.c_int32), ("hub_reorder", C.c_int32), ("row_tags16", C.c_int32), ("hub_share", C.c_double),
-                ("hub_select_s", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("spmv_launches", C.c_int32), ("preprocess_fused", C.c_int32)]
+                ("hub_select_s", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("spmv_launches", C.c_int32), ("preprocess_fused", C.c_int32), ("interleave", C.c_int32), ("reserved_info", C.c_int32)]
 
 
 class MmMatrix(C.Structure):
@@ -134,6 +134,9 @@ def lib():
         L.cvr_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.cvr_spmv_gather_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                              C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.cvr_multi_handle.argtypes = [C.c_void_p, C.c_int32]
+        L.cvr_multi_handle.restype = C.c_void_p
+        L.cvr_multi_from_handles.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_int32]
         L.cvr_source_key_of.argtypes = [C.c_char_p, C.c_int, C.POINTER(SourceKey)]
         L.cvr_mm_write_bin_keyed.argtypes = [C.c_char_p, C.POINTER(MmMatrix), C.POINTER(SourceKey)]
         L.cvr_mm_read_bin_keyed.argtypes = [C.c_char_p, C.POINTER(SourceKey), C.POINTER(MmMatrix)]
@@ -337,7 +340,7 @@ class CvrMatrix:
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
                  xcd_swizzle=-1, x_window=-1, stream_ahead=0, keep_csr=False, debug_col_mask=0, depth=0,
                  col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1,
-                 row_tags16=-1, row_bands=-1, piece_max=-1):
+                 row_tags16=-1, row_bands=-1, piece_max=-1, interleave=-1):
         """tune_steps: choose steps_per_chunk by measurement first (cvr_tune_steps; its cost is self.tuning_s).
         stream_ahead / depth / debug_col_mask are profiling knobs (tools/sweep.py): they travel through the environment
         (CVR_DEBUG_*), not through cvr_options."""
@@ -357,7 +360,7 @@ class CvrMatrix:
         view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
                     debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block, col_phases, hub_table, narrow_cols, hub_reorder,
-                    row_tags16, row_bands, piece_max)
+                    row_tags16, row_bands, piece_max, interleave)
 
     def save_image(self, path, key=None):
         """cvr_save_image: the converted image on disk, keyed by `key` (capi.source_key of the .mtx file; None = no source key),
@@ -393,7 +396,7 @@ class CvrMatrix:
 
     @classmethod
     def from_device(cls, nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, is_f32=False, device=0, steps_per_chunk=0,
-                    split_threshold=0, keep_csr=False, col_panels=-1, value_dict=-1, tune_steps=False, hub_table=-1, hub_reorder=-1):
+                    split_threshold=0, keep_csr=False, col_panels=-1, value_dict=-1, tune_steps=False, hub_table=-1, hub_reorder=-1, interleave=-1):
         """CSR arrays already in the memory of `device` (raw pointers: int64 row_ptr[nrows+1], int32 col_idx, fp64/fp32 vals),
         e.g. the .data_ptr() of torch tensors: cvr_csr_view.arrays_on_device = 1"""
         self = cls.__new__(cls)
@@ -403,24 +406,36 @@ class CvrMatrix:
         self.dtype = np.float32 if self.f32 else np.float64
         view = CsrView(nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, int(self.f32), 1)
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, -1, -1, 0, keep_csr, 0, 0, col_panels, value_dict, tune_steps,
-                    hub_table=hub_table, hub_reorder=hub_reorder)
+                    hub_table=hub_table, hub_reorder=hub_reorder, interleave=interleave)
         return self
 
     def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
                debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1,
-               row_tags16=-1, row_bands=-1, piece_max=-1):
+               row_tags16=-1, row_bands=-1, piece_max=-1, interleave=-1):
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
         opt.xcd_swizzle, opt.x_window, opt.col_panels, opt.value_dict = xcd_swizzle, x_window, col_panels, value_dict
         opt.waves_per_block, opt.col_phases, opt.hub_table, opt.narrow_cols = waves_per_block, col_phases, hub_table, narrow_cols
         opt.hub_reorder, opt.row_tags16, opt.row_bands, opt.piece_max = hub_reorder, row_tags16, row_bands, piece_max
-        # profiling knobs (tools/sweep.py): read from the environment by cvr_create / cvr_tune
+        opt.interleave = interleave
+        # profiling knobs (tools/sweep.py): cvr_create / cvr_tune read them from the environment.  Only a knob the caller passed is
+        # touched, and what the environment held before comes back once the handle exists (a value the user exported stays theirs).
+        saved = {}
         for name, val in (("CVR_DEBUG_STREAM_AHEAD", stream_ahead), ("CVR_DEBUG_GATHER_DEPTH", depth), ("CVR_DEBUG_COL_MASK", debug_col_mask)):
             if val:
+                saved[name] = os.environ.get(name)
                 os.environ[name] = str(int(val))
-            else:
-                os.environ.pop(name, None)
+        try:
+            self._create(view, nrows, ncols, opt, tune_steps, steps_per_chunk, keep_csr)
+        finally:
+            for name, old in saved.items():
+                if old is None:
+                    os.environ.pop(name, None)
+                else:
+                    os.environ[name] = old
+
+    def _create(self, view, nrows, ncols, opt, tune_steps, steps_per_chunk, keep_csr):
         if tune_steps and steps_per_chunk == 0:          # the layout by measurement (cvr_tune): S, chunks per workgroup, x window, column phases
             best, best_t, tun = Options(), C.c_double(), C.c_double()
             rc = lib().cvr_tune(C.byref(view), C.byref(opt), C.byref(best), C.byref(best_t), C.byref(tun))

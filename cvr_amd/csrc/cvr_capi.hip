@@ -113,6 +113,7 @@ void cvr_default_options(cvr_options *o)
     o->row_tags16 = -1;
     o->row_bands = -1;
     o->piece_max = -1;
+    o->interleave = -1;
 }
 
 }  // extern "C"
@@ -304,6 +305,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     if (opt.device < 0 || opt.device >= ndev) return fail(CVR_ERR_NO_DEVICE, "device %d out of range [0, %d)", opt.device, ndev);
     { const Chip chip = chip_of(opt.device); opt.cus = chip.cus; opt.xcds = chip.xcds; }
     if (opt.xcds != 8 && opt.xcd_swizzle != 0) opt.xcd_swizzle = 0;      // (the chunk-range-per-XCD mapping is written for the whole chip's eight)
+    if (opt.row_bands > 1) return fail(CVR_ERR_INVALID, "row_bands is reserved: leave it at its default");
     if (opt.steps_per_chunk != 0 && (opt.steps_per_chunk < 4 || opt.steps_per_chunk % 4 || opt.steps_per_chunk > 4096))
         return fail(CVR_ERR_INVALID, "steps_per_chunk must be a multiple of 4 in [4, 4096]");
 
@@ -491,6 +493,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     if (P > 64) P = 64;
     in.col_panels = P;
     h->parts.resize((size_t)P);
+    if (P == 1 && opt.interleave < 0) opt.interleave = 0;      // (a single image is interleaved only when asked to)
     if (P == 1) {
         if (staged.rp) {          // the staging copy becomes the part's device CSR
             Part &part = h->parts[0];
@@ -528,6 +531,18 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         IOpt                  panel_opt = opt;
         panel_opt.col_phases = getenv("CVR_PANEL_PHASES") ? atoi(getenv("CVR_PANEL_PHASES")) : 1;          // column phases are for the single image whose chunks are all resident at once
         panel_opt.panel_on_one_xcd = xcd_panels ? 1 : 0;
+        // interleaved chunks (automatic): panels that run one per XCD (their slice of x stays in that L2: what is left to save is the
+        // number of requests) and get no hub tables -- scattered columns without a popular head, the soc-LiveJournal1 shape
+        if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && !getenv("CVR_NO_AUTO_LAYOUT") ? 1 : 0;
+        if (panel_opt.interleave > 0) {
+            panel_opt.hub_table = 0; panel_opt.col_phases = 1;
+            if (panel_opt.steps_per_chunk == 0) {       // one chunk length for all panels (they share a launch): from the mean sub-row and the mean panel
+                int64_t nsub_all = 0;
+                for (int64_t v : nsubs) nsub_all += v;
+                IOpt one = panel_opt;
+                panel_opt.steps_per_chunk = interleave_steps((sj1 - sj0) / P, std::max<int64_t>(nsub_all / P, 1), f32, one);
+            }
+        }
         std::vector<IOpt>        popts((size_t)P, panel_opt);
         std::vector<DevRows>     drs((size_t)P);
         if (dev_split) {
@@ -685,7 +700,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // its workgroups, so that an L2 holds one slice of x at a time and every line of x is fetched by one XCD only
     if (h->paneled() && xcd_panels) {
         bool plain = true;
-        for (const Part &p : h->parts) plain = plain && p.img.wpb <= 1 && p.img.hub_n == 0 && p.img.win_elems == 0 && p.img.phases == h->parts[0].img.phases && p.img.tag16 == h->parts[0].img.tag16 && !p.img.c16 && p.img.S == h->parts[0].img.S;
+        for (const Part &p : h->parts) plain = plain && (p.img.ilv ? p.img.wpb == h->parts[0].img.wpb : p.img.wpb <= 1) && p.img.ilv == h->parts[0].img.ilv && p.img.hub_n == 0 && p.img.win_elems == 0 && p.img.phases == h->parts[0].img.phases && p.img.tag16 == h->parts[0].img.tag16 && !p.img.c16 && p.img.S == h->parts[0].img.S;
         if (plain) {
             const size_t per_round = getenv("CVR_XCD_PANELS_DEBUG") ? (size_t)atoi(getenv("CVR_XCD_PANELS_DEBUG")) : 8;      // (diagnostics: fewer panels side by side)
             const size_t rounds = (h->parts.size() + per_round - 1) / per_round;
@@ -714,6 +729,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             for (size_t j = 0; j < h->parts.size(); j++) {
                 const Part &p = h->parts[j];
                 const size_t i = slot_of[j];
+                h->parts[j].multi_slot = (int32_t)i;
                 pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2};
                 h->multi_chunks[i / 8] = std::max(h->multi_chunks[i / 8], p.img.nchunks);
                 h->multi_ystage = std::max(h->multi_ystage, p.img.ystage);
@@ -732,6 +748,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     in.row_tags16 = h->parts[0].img.tag16 ? 1 : 0;
     in.row_bands = 1;
     in.piece_max = (int32_t)h->parts[0].img.piece_max;
+    in.interleave = h->parts[0].img.ilv ? 1 : 0;
     in.chunk_row_cap = h->parts[0].img.phases > 1 ? (int64_t)h->parts[0].img.ystage - 1 : 0;
     for (const Part &p : h->parts) {
         in.nchunks += p.nchunks; in.nshared += p.nshared; in.nslots += p.nchunks * 64 * p.img.S;
@@ -740,7 +757,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     {   // room for the conversion-time segment table of images with column phases (cvr_preprocess takes it over and releases it)
         size_t n1 = 0, nch = 0;
         for (const Part &p : h->parts)
-            if (p.img.phases > 1 && p.nchunks > 0) { n1 = std::max(n1, (size_t)p.nchunks * (size_t)cvr::kLanes * (size_t)p.img.S); nch = std::max(nch, (size_t)p.nchunks); }
+            if (p.img.phases > 1 && !p.img.ilv && p.nchunks > 0) { n1 = std::max(n1, (size_t)p.nchunks * (size_t)cvr::kLanes * (size_t)p.img.S); nch = std::max(nch, (size_t)p.nchunks); }
         if (n1 > 0 && n1 < ((size_t)1 << 32) && !h->preconverted) {
             auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
             const size_t bytes = up(sizeof(int64_t) * n1) + up(sizeof(uint32_t) * n1) + up(sizeof(uint16_t) * n1) + up(sizeof(uint32_t) * (nch + 1)) + 256;
@@ -794,11 +811,15 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     // that counting and filling are one kernel per chunk and the conversion follows without the host in between; the images of a
     // handle (column panels) are converted one after the other and share the table, sized for the largest
     size_t seg_n1 = 0, seg_chunks = 0;
+    size_t ilv_scratch = 0;          // interleaved images: the segmented sort's buffers, sized for the largest part and shared
     for (const Part &p : h->parts)
-        if (p.img.phases > 1 && p.nchunks > 0) {
+        if (p.img.ilv) ilv_scratch = std::max(ilv_scratch, cvr::convert_interleaved_scratch(p.nnz, (uint32_t)p.nchunks));
+        else if (p.img.phases > 1 && p.nchunks > 0) {
             seg_n1 = std::max(seg_n1, (size_t)p.nchunks * (size_t)cvr::kLanes * (size_t)p.img.S);
             seg_chunks = std::max(seg_chunks, (size_t)p.nchunks);
         }
+    struct IlvGuard { void *p = nullptr; ~IlvGuard() { (void)hipFree(p); } } ilv;
+    if (ilv_scratch) HIP_TRY(hipMalloc(&ilv.p, ilv_scratch));
     const bool phased = seg_n1 > 0;
     if (phased) {
         cvr::SegTable &t = sg.t;
@@ -825,7 +846,9 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
         cvr::DeviceCsr csr;
         csr.row_ptr = p.d_rp; csr.col_idx = p.d_ci; csr.vals = p.d_va; csr.nz_begin = p.d_nzb; csr.pad_cnt = p.d_pad;
         if (wstream != h->stream) HIP_TRY(cvr::launch_window(p.img, csr, wstream));
-        if (p.img.phases > 1 && p.nchunks > 0) {
+        if (p.img.ilv) {
+            HIP_TRY(cvr::launch_convert_interleaved(p.img, csr, p.nnz_span - p.nnz, p.nnz_span, h->d_err, ilv.p, ilv_scratch, h->stream));
+        } else if (p.img.phases > 1 && p.nchunks > 0) {
             cvr::SegTable &t = sg.t;
             if (h->d_dict && cvr::seg_table_packed_ok(p.img) && !getenv("CVR_NO_DICT_CODES")) {      // the values as dictionary codes first: the converter then reads a byte per value (cvr_convert.hip: convert_lds_kernel)
                 (void)hipFree(sg.codes); sg.codes = nullptr;

@@ -46,6 +46,7 @@ struct Attempt {
 int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, const IOpt &opt, IOpt &popt, bool *taken)
 {
     *taken = false;
+    if (opt.interleave > 0) NOT_TAKEN("interleaved chunks");
     const int64_t nnz = nz1 - nz0, vs = f32 ? 4 : 8;
     // the matrices of auto_layout's resident form, planned on the device, with the probe's usual answer assumed
     if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask) NOT_TAKEN("layout options given");

@@ -11,7 +11,7 @@ using namespace cvrh;
 namespace {
 
 constexpr uint64_t kImgMagic = 0x3130474d49525643ull;      // "CVRIMG01"
-constexpr uint32_t kImgVersion = 5;                        // bump when DeviceImage / the handle's tables change
+constexpr uint32_t kImgVersion = 6;                        // bump when DeviceImage / the handle's tables change
 
 struct ImgKey {
     uint64_t       magic;
@@ -45,12 +45,15 @@ struct Reader {
     void  raw(void *p, size_t n) { if (ok && n) ok = fread(p, 1, n, f) == n; }
     template <typename T> void pod(T &v) { raw(&v, sizeof(T)); }
     // a device array of `bytes` (exactly what the writer stored): allocated here, filled through the pinned staging buffer
-    template <typename P> hipError_t dev(P *&d, uint8_t *pinned, size_t pinned_bytes, hipStream_t st, size_t min_alloc = 1)
+    // `want`: the byte count the image's scalars imply -- a file that stores another one is damaged (or crafted) and is refused before
+    // anything is allocated; `optional`: the array may be absent (0 bytes stored)
+    template <typename P> hipError_t dev(P *&d, uint8_t *pinned, size_t pinned_bytes, hipStream_t st, uint64_t want, bool optional = false, size_t min_alloc = 1)
     {
         uint64_t n = 0;
         pod(n);
         d = nullptr;
         if (!ok) return hipErrorUnknown;
+        if (!(n == want || (optional && n == 0))) { ok = false; return hipErrorUnknown; }
         if (!n) return hipSuccess;
         hipError_t e = hipMalloc(&d, std::max<size_t>((size_t)n, min_alloc));
         for (uint64_t off = 0; e == hipSuccess && off < n; off += pinned_bytes) {
@@ -71,7 +74,7 @@ void make_key(ImgKey &k, const cvr_source_key *src, const IOpt &o, size_t vsz)
     k.magic = kImgMagic; k.version = kImgVersion; k.vsz = (uint32_t)vsz;
     if (src) k.source = *src;
     const int64_t ov[] = {0 /* device: not part of the identity */, o.steps_per_chunk, o.split_threshold, o.xcd_swizzle, o.x_window, o.waves_per_block, o.col_panels, o.value_dict,
-                          o.col_phases, o.hub_table, o.narrow_cols, o.hub_reorder, o.row_tags16, o.row_bands, o.piece_max, o.debug_col_mask};
+                          o.col_phases, o.hub_table, o.narrow_cols, o.hub_reorder, o.row_tags16, o.piece_max, o.debug_col_mask, o.interleave};
     static_assert(sizeof(ov) <= sizeof(k.opt), "options fit the key");
     memcpy(k.opt, ov, sizeof(ov));
     k.cus = o.cus; k.xcds = o.xcds; k.stream_ahead = o.stream_ahead; k.gather_depth = o.gather_depth;
@@ -84,6 +87,7 @@ struct ImgScalars {
     uint32_t nchunks, nrows, pad_col, nshared, ystage, ndict, persist_waves, wpb, win_elems, col_mask, phases, phase_width, col_bits, piece_max, hub_n, order_n, ncus, has_pace;
     int64_t  part_nrows, part_nnz, part_nnz_span, part_nchunks, part_nshared, part_yext, part_zoff;
     uint64_t stream_bytes;
+    int32_t  multi_slot, ilv;      // where the panel stands in the rounds of eight (-1: none)
 };
 
 }  // namespace
@@ -122,6 +126,7 @@ int cvr_save_image(cvr_handle *h, const char *path, const cvr_source_key *key)
         s.piece_max = g.piece_max; s.hub_n = g.hub_n; s.order_n = g.order_n; s.ncus = g.ncus; s.has_pace = g.pace ? 1u : 0u;
         s.part_nrows = p.nrows; s.part_nnz = p.nnz; s.part_nnz_span = p.nnz_span; s.part_nchunks = p.nchunks; s.part_nshared = p.nshared; s.part_yext = p.yext; s.part_zoff = p.zoff;
         s.stream_bytes = p.stream_bytes;
+        s.multi_slot = p.multi_slot; s.ilv = g.ilv ? 1 : 0;
         w.pod(s);
         const size_t nc = (size_t)g.nchunks;
         const size_t slack = 8 * (size_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16);
@@ -194,10 +199,12 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
     r.pod(h->info);
     uint32_t nparts = 0, nrounds = 0, has_multi = 0;
     r.pod(nparts); r.pod(h->ndict); r.pod(h->max_nshared); r.pod(h->multi_ystage); r.pod(nrounds); r.pod(has_multi);
-    if (!r.ok || nparts == 0 || nparts > 64 || nrounds > 8) { r.ok = false; LOAD_TRY(hipSuccess); }
+    if (!r.ok || nparts == 0 || nparts > 64 || nrounds > 8 || (has_multi && nrounds != (nparts + 7) / 8) || (int64_t)nparts != (int64_t)std::max(h->info.col_panels, 1)) { r.ok = false; LOAD_TRY(hipSuccess); }
     h->multi_chunks.resize(nrounds);
     for (uint32_t i = 0; i < nrounds; i++) r.pod(h->multi_chunks[i]);
-    LOAD_TRY(r.dev(h->d_dict, pinned, pinned_bytes, h->stream));
+    if (h->ndict > (uint32_t)cvr::kDictMax) { r.ok = false; LOAD_TRY(hipSuccess); }
+    LOAD_TRY(r.dev(h->d_dict, pinned, pinned_bytes, h->stream, have.vsz * (uint64_t)cvr::kDictMax, true));
+    if ((h->d_dict != nullptr) != (h->ndict != 0)) { r.ok = false; LOAD_TRY(hipSuccess); }
     h->parts.resize(nparts);
     const size_t vsz = h->vsz;
     int64_t      ztotal = 0;
@@ -212,18 +219,35 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         g.piece_max = s.piece_max; g.hub_n = s.hub_n; g.order_n = s.order_n; g.ncus = s.ncus;
         p.nrows = s.part_nrows; p.nnz = s.part_nnz; p.nnz_span = s.part_nnz_span; p.nchunks = s.part_nchunks; p.nshared = s.part_nshared; p.yext = s.part_yext; p.zoff = s.part_zoff;
         p.stream_bytes = (size_t)s.stream_bytes;
+        p.multi_slot = s.multi_slot; g.ilv = s.ilv != 0;
         g.dict = h->d_dict;
+        // the scalars must describe one consistent image: every array below is then required to have exactly the size they imply, and the
+        // kernels' LDS and index arithmetic stays inside what cvr_create could have produced
+        {
+            const uint64_t nc = g.nchunks;
+            const bool sane = s.S >= 4 && s.S <= 4096 && s.S % 4 == 0 && s.G == s.S / 4 && nc == (uint64_t)s.part_nchunks && g.nshared == (uint64_t)s.part_nshared && s.part_nrows >= 0 &&
+                              (uint64_t)s.part_nrows == g.nrows && s.part_yext == s.part_nrows + 1 + 2 * (int64_t)nc && s.part_zoff >= 0 && g.wpb >= 1 && g.wpb <= (uint32_t)cvr::kMaxWavesPerBlock &&
+                              g.phases >= 1 && g.phases <= 64 && g.ystage >= 1 && g.ystage <= 65532 && g.col_bits <= 31 && g.ndict == h->ndict && (g.f32 ? 4u : 8u) == have.vsz &&
+                              g.pad_col == (uint64_t)h->info.ncols && (!g.c16 || (!g.tag16 && g.phases == 1)) && (g.order_n == 0 || g.order_n == g.pad_col) &&
+                              s.stream_bytes == nc * (uint64_t)s.G * (uint64_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16) &&
+                              (s.multi_slot < 0 || (has_multi && (uint32_t)s.multi_slot < nrounds * 8)) && cvr::spmv_lds_bytes(g) <= cvr::kLdsBytes;
+            if (!sane) { r.ok = false; LOAD_TRY(hipSuccess); }
+        }
         // (the stream allocation is padded for the kernel's run-ahead past the last chunk, as finish_part pads it)
         const size_t slack = 8 * (size_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16);
-        LOAD_TRY(r.dev(g.stream, pinned, pinned_bytes, h->stream, p.stream_bytes + slack));
+        const uint64_t nc64 = g.nchunks;
+        LOAD_TRY(r.dev(g.stream, pinned, pinned_bytes, h->stream, p.stream_bytes, false, p.stream_bytes + slack));
         if (!g.stream) LOAD_TRY(hipMalloc(&g.stream, std::max<size_t>(slack, 1)));
-        LOAD_TRY(r.dev(g.desc, pinned, pinned_bytes, h->stream, 16));
-        LOAD_TRY(r.dev(g.target, pinned, pinned_bytes, h->stream, 64));
-        LOAD_TRY(r.dev(g.shared, pinned, pinned_bytes, h->stream, 24));
-        LOAD_TRY(r.dev(g.win_base, pinned, pinned_bytes, h->stream));
-        LOAD_TRY(r.dev(g.desc2, pinned, pinned_bytes, h->stream));
-        LOAD_TRY(r.dev(g.cbase, pinned, pinned_bytes, h->stream));
-        LOAD_TRY(r.dev(g.hub_cols, pinned, pinned_bytes, h->stream));
+        LOAD_TRY(r.dev(g.desc, pinned, pinned_bytes, h->stream, 16 * nc64, false, 16));
+        LOAD_TRY(r.dev(g.target, pinned, pinned_bytes, h->stream, 64 * nc64, false, 64));
+        LOAD_TRY(r.dev(g.shared, pinned, pinned_bytes, h->stream, 24 * (uint64_t)g.nshared, false, 24));
+        LOAD_TRY(r.dev(g.win_base, pinned, pinned_bytes, h->stream, sizeof(uint32_t) * (nc64 / g.wpb + 1)));
+        LOAD_TRY(r.dev(g.desc2, pinned, pinned_bytes, h->stream, 8 * nc64, g.phases <= 1));
+        if (g.phases > 1 && nc64 && !g.desc2) { r.ok = false; LOAD_TRY(hipSuccess); }
+        LOAD_TRY(r.dev(g.cbase, pinned, pinned_bytes, h->stream, sizeof(uint32_t) * nc64, !g.c16));
+        if (g.c16 && nc64 && !g.cbase) { r.ok = false; LOAD_TRY(hipSuccess); }
+        LOAD_TRY(r.dev(g.hub_cols, pinned, pinned_bytes, h->stream, sizeof(int32_t) * (uint64_t)(g.order_n ? g.order_n : g.hub_n), g.hub_n == 0));
+        if (g.hub_n && !g.hub_cols) { r.ok = false; LOAD_TRY(hipSuccess); }
         if (g.hub_n) LOAD_TRY(hipMalloc(&g.hub_x, vsz * (g.order_n ? ((size_t)g.order_n + 8) : ((g.hub_n + 3u) & ~3u))));
         if (s.has_pace) {
             LOAD_TRY(hipMalloc(&g.pace, sizeof(uint32_t) * cvr::pace_words(g.phases)));
@@ -234,8 +258,10 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
     }
     if (h->paneled()) {
         const uint32_t nblocks = (uint32_t)((h->info.nrows + cvr::kCombineRows - 1) / cvr::kCombineRows);
-        LOAD_TRY(r.dev(h->d_rows, pinned, pinned_bytes, h->stream));
-        LOAD_TRY(r.dev(h->d_block_off, pinned, pinned_bytes, h->stream));
+        int64_t nsub_all = 0;
+        for (const Part &p : h->parts) nsub_all += p.nrows;
+        LOAD_TRY(r.dev(h->d_rows, pinned, pinned_bytes, h->stream, sizeof(uint32_t) * (uint64_t)std::max<int64_t>(nsub_all, 1)));
+        LOAD_TRY(r.dev(h->d_block_off, pinned, pinned_bytes, h->stream, sizeof(uint32_t) * (uint64_t)nparts * (nblocks + 1)));
         LOAD_TRY(hipMalloc(&h->d_z, vsz * (size_t)std::max<int64_t>(ztotal, 1)));
         LOAD_TRY(hipMemsetAsync(h->d_z, 0, vsz * (size_t)std::max<int64_t>(ztotal, 1), h->stream));
         std::vector<cvr::CombinePanel> cps(nparts);
@@ -256,9 +282,9 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         if (has_multi) {
             const size_t per_round = 8;
             std::vector<cvr::PanelArgs> pa((size_t)nrounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr});
-            for (uint32_t j = 0; j < nparts; j++) {
+            for (uint32_t j = 0; j < nparts; j++) {       // every panel where cvr_create placed it (the heaviest first, each on the XCD with the least work)
                 const Part &p = h->parts[j];
-                pa[(j / per_round) * 8 + j % per_round] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2};
+                pa[p.multi_slot >= 0 ? (size_t)p.multi_slot : (j / per_round) * 8 + j % per_round] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2};
             }
             LOAD_TRY(hipMalloc(&h->d_multi, sizeof(cvr::PanelArgs) * pa.size()));
             LOAD_TRY(hipMemcpy(h->d_multi, pa.data(), sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyHostToDevice));

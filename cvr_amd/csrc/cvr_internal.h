@@ -97,6 +97,7 @@ struct Part {
     size_t    stream_bytes = 0;
     int64_t   nrows = 0, nnz = 0, nnz_span = 0, nchunks = 0, nshared = 0, yext = 0;
     int64_t   zoff = 0;        // panels: where this part's y_ext starts in the partial-sum buffer z
+    int32_t   multi_slot = -1; // panels that run one per XCD: round * 8 + XCD slot of this panel in cvr_handle::d_multi
 
     bool      csr_borrowed = false;      // d_ci / d_va point into the handle's split arena (column panels split on the device): not this part's to free
     void release_csr()
@@ -205,6 +206,7 @@ struct PartPlan {
     int      col_bits = 31;        // column phases: bits of a column index (the row field of a segment's last column word starts there)
     bool     tag16 = false;        // column phases: the rows of the pieces in 16-bit tags of their own
     bool     lds_short = false;    // column phases do not fit beside the window
+    bool     ilv = false;          // interleaved chunks (cvr_options.interleave): planned like an image with column phases (row cap, accumulators in LDS)
     int      plan_threads = 0;     // 0: the planner's own small team; 1: the caller plans several images side by side
     int64_t  hub_n = 0;            // hub table entries staged in LDS in front of the window (decided before planning)
     // the plan stayed on the device (plan_panels_batched): nzb / pad / desc / cut rows are in the part's buffers already, only the counts came back
@@ -222,6 +224,7 @@ inline int64_t device_plan_rows() { const char *e = getenv("CVR_DEVICE_PLAN_ROWS
 constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24 << 10, kSmallBytes = 32 << 10;
 constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer
 int        pick_steps(int64_t nslots_est, int64_t max_row = 0, double cus = 256.0);
+int        interleave_steps(int64_t nnz, int64_t nrows, bool f32, const IOpt &opt);
 hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr = nullptr);
 int64_t    plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt);
 void       plan_stage(PartPlan &pp, bool f32);

@@ -40,6 +40,7 @@ struct DeviceImage {
     bool      tag16 = false;        // column phases: the rows of the pieces stand in 16-bit tags of their own (col_bits = 31)
     uint32_t *pace = nullptr;       // column phases with long chunks: [8][phases][512] words of the SpMV kernel's pacing (spmv_seg_kernel; zeroed once), or null
     uint32_t *pace_epoch = nullptr; // host: launches so far (the value a launch marks with)
+    bool      ilv = false;          // interleaved chunks (cvr_ilv.hip): the image is written in the column-phase format with every slot a piece of its own; conversion only
     uint32_t  piece_max = 0;        // column phases: (row, phase) segments are cut into pieces at the multiples of this many elements from the chunk's first (0 = whole segments)
     uint32_t  col_bits = 31;        // column phases: the LAST column word of a segment carries the chunk's row of the segment
                                     // above the column index: bits [col_bits, 31); bit 31 stays the end flag
@@ -93,6 +94,10 @@ bool       seg_table_packed_ok(const DeviceImage &img);      // launch_seg_build
 // CSR -> CVR64 (one wavefront per chunk).  *err_flag (device u32, zeroed by the caller) gets bit 0 if a
 // lane stream did not drain, bit 1 if stealing found no over-full lane, bit 2 if a value is missing from the dictionary.
 hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg = nullptr, const uint32_t *nchunks_dev = nullptr);
+// interleaved chunks (cvr_ilv.hip): the chunks' non-zeros [n0, n1) sorted by column inside every chunk and dealt to the lanes in that order;
+// `scratch`: convert_interleaved_scratch(n1 - n0, img.nchunks) bytes of device memory; *err_flag bit 2: a value that is not in the dictionary
+size_t     convert_interleaved_scratch(int64_t nnz, uint32_t nchunks);
+hipError_t launch_convert_interleaved(const DeviceImage &img, const DeviceCsr &csr, int64_t n0, int64_t n1, uint32_t *err_flag, void *scratch, size_t scratch_bytes, hipStream_t st);
 // codes[j] = dictionary code of vals[j], j in [n0, n1) (one coalesced pass; *err_flag bit 2: a value that is not in the dictionary)
 hipError_t launch_dict_codes(const void *vals, int64_t n0, int64_t n1, bool f32, const void *dict, uint32_t ndict, uint8_t *codes, uint32_t *err_flag, hipStream_t st);
 

@@ -34,9 +34,14 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
     pp.phases = std::min(std::max(opt.col_phases, 1), 64);
     if (ncols < 64 * pp.phases) pp.phases = 1;
     if (pp.hub_n > 0) pp.phases = 1;               // (the hub flag and the row field of a phased image share bits of the column word)
+    // interleaved chunks: planned and run like an image with column phases (every slot carries its row, the rows' sums live in LDS);
+    // four chunks per workgroup unless the caller says otherwise, no window
+    pp.ilv = opt.interleave > 0 && pp.hub_n == 0;
+    if (pp.ilv) { pp.phases = 2; if (opt.waves_per_block <= 0) pp.wpb = 4; }
     // LDS window of x per workgroup (off by default): `win` consecutive values of x staged with coalesced loads; gathers
     // inside it are served by ds_read instead of a 128-byte L1 fill each.
     pp.win = std::min<int64_t>(opt.x_window < 0 ? 0 : opt.x_window, ncols + 1) & ~(int64_t)3;      // whole 16-byte loads, inside x_ext
+    if (pp.ilv) pp.win = 0;
     const int64_t vs = f32 ? 4 : 8;
     int64_t       max_rows = 0;
     if (pp.phases > 1) {
@@ -54,7 +59,7 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
         // a chunk of S steps holds at most 64 S rows: no need for more accumulators than that (keeps the LDS small)
         const int64_t want = std::min<int64_t>(rows_for(pp.win), ((int64_t)cvr::kLanes * pp.S + 1 + 3) & ~(int64_t)3);
         // wide row tags (16 bits of their own per slot) when the column word has no room for the rows such a chunk may hold
-        pp.tag16 = opt.row_tags16 > 0 || (opt.row_tags16 < 0 && row_field + 1 < want);
+        pp.tag16 = opt.row_tags16 > 0 || (opt.row_tags16 < 0 && row_field + 1 < want) || (pp.ilv && row_field + 1 < 64);      // (an interleaved image always has its accumulators: tags when the column word has no room at all)
         if (pp.tag16) pp.col_bits = 31;
         pp.stage = std::min<int64_t>(want, pp.tag16 ? (int64_t)65532 : (row_field + 1) & ~(int64_t)3);
         if (pp.stage < 64) { pp.lds_short = true; pp.phases = 1; pp.stage = 64; }
@@ -81,10 +86,26 @@ void plan_stage(PartPlan &pp, bool f32)
     }
 }
 
+// Chunk length of an interleaved image: as long as the row accumulators of a wavefront allow (the more non-zeros are sorted together,
+// the more lanes share lines of x: profiles/r04_request_model.log) -- the rows a quarter of the LDS holds times the mean row, at least
+// 16 steps, below the device planner's limit; a small matrix still gets a chunk for every wavefront of the chip.  (The panels of one
+// matrix share the length: they run side by side in one launch.)
+int interleave_steps(int64_t nnz, int64_t nrows, bool f32, const IOpt &opt)
+{
+    const int64_t vs = f32 ? 4 : 8, wpb = opt.waves_per_block > 0 ? opt.waves_per_block : 4;
+    const int64_t rows = std::min<int64_t>(((int64_t)cvr::kLdsBytes / vs - cvr::kDictMax - 8) / wpb, cvr::kYStageMax) - 1;
+    const double  mean = (double)nnz / (double)std::max<int64_t>(nrows, 1);
+    const double  cus = opt.panel_on_one_xcd ? (double)opt.cus / opt.xcds : (double)opt.cus;
+    int64_t       S = (int64_t)(mean * (double)rows / 64.0) + 1;
+    S = std::min<int64_t>(S, (int64_t)((double)nnz / (64.0 * cus * (double)wpb)) + 1);
+    return (int)std::min<int64_t>(508, std::max<int64_t>(16, (S + 3) / 4 * 4));
+}
+
 hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr)
 {
     const int64_t nz0 = rp ? (nrows ? rp[0] : 0) : dr->nz0, nz1 = rp ? (nrows ? rp[nrows] : 0) : dr->nz1;
     pp.S = opt.steps_per_chunk;
+    if (pp.S == 0 && opt.interleave > 0 && nrows > 0) pp.S = interleave_steps(nz1 - nz0, nrows, f32, opt);
     if (pp.S == 0) {
         int64_t max_row = 0;
         const double cus = opt.panel_on_one_xcd ? (double)opt.cus / opt.xcds : (double)opt.cus;
@@ -272,7 +293,7 @@ int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f3
 {
     const int64_t nnz = nz1 - nz0;
     opt.layout_auto_resident = 0;
-    if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT")) {
+    if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || opt.interleave > 0 || getenv("CVR_NO_AUTO_LAYOUT")) {
         if (opt.col_phases < 0) opt.col_phases = 0;
         return CVR_OK;
     }
@@ -350,7 +371,7 @@ int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f3
 int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt, PartPlan &pp,
                        bool allow_reorder)
 {
-    if (opt.hub_table == 0 || opt.layout_auto_resident || opt.col_phases > 1 || nrows <= 0 || ncols >= (int64_t)cvr::kHubBit) return CVR_OK;
+    if (opt.hub_table == 0 || opt.layout_auto_resident || opt.col_phases > 1 || opt.interleave > 0 || nrows <= 0 || ncols >= (int64_t)cvr::kHubBit) return CVR_OK;
     const int64_t vs = f32 ? 4 : 8, nnz = nz1 - nz0;
     const bool    automatic = opt.hub_table < 0;
     if (automatic && (opt.waves_per_block != 0 || opt.x_window > 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT") || (double)ncols * vs < 6e6 || nnz < (8 << 20))) return CVR_OK;
@@ -402,7 +423,8 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
         img.tag16 = pp.tag16;
         // pieces: a lane that sits on a long row's segment falls behind the column ranges the other lanes have moved on to; with
         // chunks longer than a few steps per phase the segments are cut (auto: 8 elements once a phase takes 8 steps or more)
-        if (S / pp.phases >= 8 && !opt.panel_on_one_xcd && !getenv("CVR_NO_PACE")) {      // long chunks: the SpMV kernel paces its wavefronts through the phases
+        img.ilv = pp.ilv;
+        if (S / pp.phases >= 8 && !opt.panel_on_one_xcd && !pp.ilv && !getenv("CVR_NO_PACE")) {      // long chunks: the SpMV kernel paces its wavefronts through the phases
             HIP_TRY(hipMalloc(&img.pace, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases)));
             HIP_TRY(hipMemsetAsync(img.pace, 0, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases), h->stream));
             img.pace_epoch = new uint32_t(0);
@@ -410,6 +432,7 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
         // (a power of two, rounded down: the segment-table kernel cuts with shifts)
         img.piece_max = opt.piece_max > 0 ? 1u << (31 - __builtin_clz((uint32_t)opt.piece_max)) : opt.piece_max < 0 && S / pp.phases >= 8 && !opt.panel_on_one_xcd ? 8u : 0u;
         img.col_mask = pp.tag16 ? cvr::kColMask : (1u << pp.col_bits) - 1u;
+        if (pp.ilv) { img.piece_max = 1; if (!opt.gather_depth) img.depth = 2; if (!opt.stream_ahead) img.stream_ahead = 3; }      // (every slot is a piece; two groups of gathers in flight, the stream three groups ahead of them)
     }
     if (popt.col_phases > 1 && pp.lds_short && !popt.layout_auto_resident) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
     const int64_t win = pp.win;

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace cvr {
 namespace {
@@ -485,8 +486,9 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn,
     const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, const uint2 *__restrict__ desc2_a, uint32_t col_bits, uint32_t nw_arg, int gb,
     uint32_t *__restrict__ pace, uint32_t pw, uint32_t pad_col, int pace_lag, uint32_t nphases, uint32_t epoch, const PanelArgs *__restrict__ multi,
-    IterEpilogue epi)
+    IterEpilogue epi, uint32_t groups_in_desc2)
 {
+    const int G_alloc = G;                            // groups every chunk has room for: the stride of the stream
     const uint8_t *__restrict__ stream = stream_a;
     const uint4 *__restrict__   desc = desc_a;
     const uint2 *__restrict__   desc2 = desc2_a;
@@ -537,7 +539,9 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     constexpr int  QN = DEPTH + QA;
     SegGroup<T, DICT, TAG> Q[QN];
     X4<T>          xs[DEPTH];
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G * GB), live ? (uint32_t)G * GB : 0u);
+    // interleaved images (groups_in_desc2): desc2[k].x = the groups that hold the chunk's non-zeros; the padding behind them is neither streamed nor walked
+    if (groups_in_desc2 && live) G = min(G, (int)desc2[k].x);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G_alloc * GB), live ? (uint32_t)G * GB : 0u);
 #pragma unroll
     for (int i = 0; i < QN; i++) Q[i] = load_seg_group<T, DICT, TAG>(rs, voff, (uint32_t)i * GB);
     const uint4    d = live ? desc[k] : uint4{0, 0, 0, 0};
@@ -719,6 +723,177 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     }
 }
 
+// ---- interleaved images: spmv_ilv_kernel, a HAND-PIPELINED loop --------------------------------------------------------------------
+// An interleaved image (cvr_ilv.hip) is the column-phase format with every slot a piece of its own, so spmv_seg_kernel runs it as it
+// is; this kernel is the same arithmetic -- product rounded once, added to the row's accumulator in LDS, steps in order, lanes in order:
+// the same y bit for bit -- around a loop that keeps four groups of gathers in flight per wavefront.  hipcc does not keep a ring of
+// in-flight loads in fixed registers (it copies the ring's registers at the loop's back-edge behind s_waitcnt vmcnt(0): the loop of
+// spmv_seg_kernel waits out a full gather round trip in every group), and with four wavefronts per CU (their accumulators fill the
+// LDS) nothing else hides that latency.  So the ring lives in registers the compiler does not allocate: the kernel is held to
+// v0..v95 (amdgpu_num_vgpr), stream and gather loads are issued by asm statements into v96.. and waited for with counted s_waitcnt
+// vmcnt, and what a step consumes is copied out with v_mov.  Every vector-memory instruction between the run-in and the end of the loop
+// is issued by these statements (one issued by the compiler there would not be counted by them).
+//   x ring: D slots (the four gathered values of a group); Q ring: 2 D slots (column words, tags, values / codes of a group).
+//   Step g: wait until the gathers of group g and the stream of group g + D have landed (the loads of the D - 1 steps in between stay
+//   in flight), copy group g out, gather group g + D, stream group g + 2 D into the freed slots, then the arithmetic of group g.
+// (The same ring around the headline kernel's loop made that kernel slower -- seven wavefronts per CU already fill the L2s' queues:
+// profiles/r04_seg_ring_kernel.log.)
+constexpr int kRingCap = 96;          // the compiler's registers: v0 .. v95
+constexpr int kRingThreads = 512;     // at most 8 wavefronts per workgroup: 256 registers each
+
+template <int R> __device__ __forceinline__ void ring_ld128(uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff)
+{
+    asm volatile("buffer_load_dwordx4 v[%0:%1], %2, %3, %4 offen" ::"n"(R), "n"(R + 3), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int R> __device__ __forceinline__ void ring_ld64(uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff)
+{
+    asm volatile("buffer_load_dwordx2 v[%0:%1], %2, %3, %4 offen" ::"n"(R), "n"(R + 1), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int R> __device__ __forceinline__ void ring_ld32(uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff)
+{
+    asm volatile("buffer_load_dword v[%0], %1, %2, %3 offen" ::"n"(R), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int R> __device__ __forceinline__ uint32_t ring_get()
+{
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, v[%1]" : "=v"(v) : "n"(R) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void ring_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+template <typename T, bool DICT, bool TAG> struct RingLayout {
+    static constexpr int D = 4;                                                                     // groups of gathers in flight
+    static constexpr int XSZ = sizeof(T) == 8 ? 8 : 4;                                              // registers of an x slot
+    static constexpr int TOFF = 4, VOFF = 4 + (TAG ? 2 : 0);                                        // tags / values inside a Q slot
+    static constexpr int QSZ = (VOFF + (DICT ? 1 : sizeof(T) == 8 ? 8 : 4) + 1) & ~1;               // registers of a Q slot (even: 64-bit pairs stay aligned)
+    static constexpr int NS = 1 + (TAG ? 1 : 0) + (DICT ? 1 : sizeof(T) == 8 ? 2 : 1);              // stream loads per group
+    static constexpr int XB = kRingCap, QB = XB + D * XSZ, TOP = QB + 2 * D * QSZ;
+    static_assert(TOP <= 256, "the ring does not fit 256 registers");
+};
+
+template <typename T, bool DICT, bool TAG>
+__global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingCap))) void spmv_ilv_kernel(
+    const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint2 *__restrict__ desc2_a, const T *__restrict__ x, T *__restrict__ yext_a, int G_alloc,
+    uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes, const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, uint32_t col_bits,
+    const PanelArgs *__restrict__ multi)
+{
+    using L = RingLayout<T, DICT, TAG>;
+    constexpr int D = L::D, QN = 2 * D, XB = L::XB, QB = L::QB, K = (D - 1) * (4 + L::NS);
+    asm volatile("" ::: "v255");                   // (the kernel's register count: the ring is invisible to the compiler)
+    const uint8_t *__restrict__ stream = stream_a;
+    const uint4 *__restrict__   desc = desc_a;
+    const uint2 *__restrict__   desc2 = desc2_a;
+    T *__restrict__             yext = yext_a;
+    uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = blockIdx.x;
+    if (multi) {          // column panels, one per XCD at a time (spmv_kernel)
+        const uint32_t  round = blockIdx.x / nblocks_per_xcd, b = blockIdx.x - round * nblocks_per_xcd;
+        const PanelArgs pa = multi[round * 8u + (b & 7u)];
+        stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
+        bidx = b >> 3;
+    }
+    constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
+    constexpr uint32_t VB = kColsBytes + (TAG ? kTagBytes : 0);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t nw = blockDim.x >> 6;
+    T *const ystage_all = reinterpret_cast<T *>(smem);
+    T *const dict = ystage_all + nw * ystage_n;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t blk = remap_block(bidx, nblocks_per_xcd, swz);
+    const uint32_t k = __builtin_amdgcn_readfirstlane(blk * nw + wv);
+    const bool     live = k < nchunks;
+    T *const       ystage = ystage_all + wv * ystage_n;
+    const uint4    d = live ? desc[k] : uint4{0, 0, 0, 0};
+    const uint2    d2 = live ? desc2[k] : uint2{0, 0};
+    const uint32_t nri = d2.y;                                        // rows of this chunk
+    const uint32_t G = __builtin_amdgcn_readfirstlane(min((uint32_t)G_alloc, d2.x));      // the groups that hold its non-zeros
+    if (live) for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);
+    if constexpr (DICT) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += blockDim.x) dict[i] = i < ndict ? dict_g[i] : T(0);
+        __syncthreads();
+    } else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (!live) return;
+    // (the descriptors must live in scalar registers: the asm statements below take them as such)
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes);
+    const uint64_t sbase = reinterpret_cast<uint64_t>(stream + (size_t)k * ((size_t)G_alloc * GB));
+    const uint64_t sbase_u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sbase) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32)) << 32);      // (the builtin returns int: no sign extension)
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const void *>(sbase_u), __builtin_amdgcn_readfirstlane(G * GB));
+    const uint32_t vo_c = lane * 16u, vo_t = lane * 8u + (uint32_t)kColsBytes, vo_code = lane * 4u + VB, vo_v0 = lane * 16u + VB, vo_v1 = vo_v0 + (uint32_t)kLanes * 16u;
+    (void)vo_t; (void)vo_code; (void)vo_v1;
+    // the stream of group `grp` into Q slot `qs` (a group past the chunk's last is out of range: zeros, no traffic)
+    auto load_q = [&](auto qsc, uint32_t grp) {
+        constexpr int  R = QB + decltype(qsc)::value * L::QSZ;
+        // (the group's offset goes into the VECTOR offset: the buffer's range check covers that one only, not the scalar offset -- a
+        // load past the chunk's last group must not reach memory, the ring runs up to 4 D - 1 groups ahead)
+        const uint32_t so = grp * GB;
+        ring_ld128<R>(vo_c + so, rs, 0u);
+        if constexpr (TAG) ring_ld64<R + L::TOFF>(vo_t + so, rs, 0u);
+        if constexpr (DICT) ring_ld32<R + L::VOFF>(vo_code + so, rs, 0u);
+        else if constexpr (sizeof(T) == 8) { ring_ld128<R + L::VOFF>(vo_v0 + so, rs, 0u); ring_ld128<R + L::VOFF + 4>(vo_v1 + so, rs, 0u); }
+        else ring_ld128<R + L::VOFF>(vo_v0 + so, rs, 0u);
+    };
+    // the x of the group in Q slot `qs` into x slot `xs`
+    auto gather_x = [&](auto qsc, auto xsc) {
+        constexpr int R = QB + decltype(qsc)::value * L::QSZ, X = XB + decltype(xsc)::value * L::XSZ;
+        const uint32_t o0 = (ring_get<R>() & cmask) * (uint32_t)sizeof(T), o1 = (ring_get<R + 1>() & cmask) * (uint32_t)sizeof(T), o2 = (ring_get<R + 2>() & cmask) * (uint32_t)sizeof(T),
+                       o3 = (ring_get<R + 3>() & cmask) * (uint32_t)sizeof(T);
+        if constexpr (sizeof(T) == 8) { ring_ld64<X>(o0, rx, 0u); ring_ld64<X + 2>(o1, rx, 0u); ring_ld64<X + 4>(o2, rx, 0u); ring_ld64<X + 6>(o3, rx, 0u); }
+        else { ring_ld32<X>(o0, rx, 0u); ring_ld32<X + 1>(o1, rx, 0u); ring_ld32<X + 2>(o2, rx, 0u); ring_ld32<X + 3>(o3, rx, 0u); }
+    };
+    // run-in: the first D groups' stream, then what the steps -D .. -1 of the loop would have issued
+    static_for<0, D>([&](auto ic) { load_q(ic, (uint32_t)decltype(ic)::value); });
+    ring_wait<0>();
+    static_for<0, D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        gather_x(ic, ic);
+        load_q(std::integral_constant<int, i + D>{}, (uint32_t)(i + D));
+    });
+    for (uint32_t gb = 0; gb < G; gb += QN) {
+        static_for<0, QN>([&](auto ic) {
+            constexpr int  i = decltype(ic)::value, R = QB + i * L::QSZ, X = XB + (i % D) * L::XSZ;
+            const uint32_t g = gb + (uint32_t)i;
+            ring_wait<K>();
+            const uint32_t cw[4] = {ring_get<R>(), ring_get<R + 1>(), ring_get<R + 2>(), ring_get<R + 3>()};
+            uint32_t       tg[2] = {0, 0}, vv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (TAG) { tg[0] = ring_get<R + L::TOFF>(); tg[1] = ring_get<R + L::TOFF + 1>(); }
+            if constexpr (DICT) vv[0] = ring_get<R + L::VOFF>();
+            else static_for<0, (sizeof(T) == 8 ? 8 : 4)>([&](auto jc) { vv[decltype(jc)::value] = ring_get<R + L::VOFF + decltype(jc)::value>(); });
+            static_for<0, L::XSZ>([&](auto jc) { xx[decltype(jc)::value] = ring_get<X + decltype(jc)::value>(); });
+            gather_x(std::integral_constant<int, (i + D) % QN>{}, std::integral_constant<int, i % D>{});
+            load_q(ic, g + (uint32_t)QN);
+            if (g >= G) return;                      // (the ring runs up to 2 D - 1 groups past the chunk's last: nothing to add)
+            T av[kGroupSteps];
+#pragma unroll
+            for (int j = 0; j < kGroupSteps; j++) {
+                if constexpr (DICT) av[j] = dict[(vv[0] >> (8 * j)) & 0xffu];
+                else if constexpr (sizeof(T) == 8) av[j] = __builtin_bit_cast(double, (uint64_t)vv[2 * j] | ((uint64_t)vv[2 * j + 1] << 32));
+                else av[j] = __builtin_bit_cast(float, vv[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < kGroupSteps; j++) {
+                T xv;
+                if constexpr (sizeof(T) == 8) xv = __builtin_bit_cast(double, (uint64_t)xx[2 * j] | ((uint64_t)xx[2 * j + 1] << 32));
+                else xv = __builtin_bit_cast(float, xx[j]);
+                uint32_t row;
+                if constexpr (TAG) row = (tg[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                else row = (cw[j] & kColMask) >> col_bits;
+                lds_add(ystage + row, fma_t(av[j], xv, T(0)));          // (= the rounded product: what spmv_seg_kernel adds for a piece of one element)
+            }
+        });
+    }
+    ring_wait<0>();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t i = lane; i < nri; i += kLanes) {          // the rows leave coalesced (head / last row of a chunk that shares it: its carry slot)
+        const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
+        store_y(yext + dst, ystage[i]);
+    }
+}
+
 // rows cut over chunks c0..c1: y[row] = carry_tail(c0) + sum_{c0 < c <= c1} carry_head(c), one wavefront per
 // row, fixed summation tree (replaces the atomics of spmv.cpp:1280-1282, 1640-1649)
 template <typename T>
@@ -885,6 +1060,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
         }
     }
     const uint32_t per_xcd = (nblocks + 7) / 8;
+    if (multi) multi_chunks = (multi_chunks + wpb - 1) / wpb;          // (from here on: the workgroups of wpb chunks the fullest panel needs)
     const uint32_t grid = multi ? multi_rounds * multi_chunks * 8 : img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;      // (multi: `img` is one of the eight panels: what they share comes from it)
     const dim3     block(kLanes * wpb);
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
@@ -914,7 +1090,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
                              else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
 #define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
-                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi, epi ? *epi : IterEpilogue{}
+                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi, epi ? *epi : IterEpilogue{}, img.ilv ? 1u : 0u
 #define CVR_SEG(T, SP, D, W, DI, LD)                                                                               \
     do {                                                                                                           \
         const dim3 sblock(kLanes * (wpb + (LD ? loaders : 0u)));                                                   \
@@ -936,7 +1112,16 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     const int pace_lag = env_pace >= 0 ? env_pace : 2;
     uint32_t *pace = img.phases > 1 && img.pace && pace_lag > 0 && !multi ? img.pace : nullptr;
     const uint32_t epoch = pace ? ++*img.pace_epoch : 0u;        // (a launch marks with its own number: nothing to zero in between)
-    if (img.phases > 1) { if (img.f32) CVR_SEG_SP(float); else CVR_SEG_SP(double); }
+    // interleaved images: the hand-pipelined kernel (spmv_ilv_kernel) whenever the workgroup fits it
+    static const int env_ilv = [] { const char *e = getenv("CVR_DEBUG_ILV_KERNEL"); return e ? atoi(e) : 1; }();      // 0: through spmv_seg_kernel (the same y)
+    if (img.ilv && env_ilv && kLanes * wpb <= (uint32_t)kRingThreads && !epi) {
+#define CVR_ILV(T, DI, TG) hipLaunchKernelGGL((spmv_ilv_kernel<T, DI, TG>), dim3(grid), block, lds, st, img.stream, img.desc, img.desc2, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, \
+                                              multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.col_bits, multi)
+        if (img.f32) { if (use_dict) { if (img.tag16) CVR_ILV(float, true, true); else CVR_ILV(float, true, false); } else { if (img.tag16) CVR_ILV(float, false, true); else CVR_ILV(float, false, false); } }
+        else { if (use_dict) { if (img.tag16) CVR_ILV(double, true, true); else CVR_ILV(double, true, false); } else { if (img.tag16) CVR_ILV(double, false, true); else CVR_ILV(double, false, false); } }
+#undef CVR_ILV
+    }
+    else if (img.phases > 1) { if (img.f32) CVR_SEG_SP(float); else CVR_SEG_SP(double); }
     else if (img.c16 && !use_win && !use_dict && wpb == 1 && img.phases <= 1 && !multi) { if (img.f32) CVR_PICK_C16(float); else CVR_PICK_C16(double); }
     else if (img.f32) CVR_PICK_SP(float); else CVR_PICK_SP(double);
 #undef CVR_SEG_SP

@@ -97,15 +97,20 @@ typedef struct {
                                   instead of above the column index in the piece's last column word: lifts the limit of
                                   2^(31 - bits of ncols) rows per chunk.  0 = off, 1 = on, <0 = auto (default): when the
                                   chunks the layout wants hold more rows than the column word has room for                  */
-    int32_t row_bands;         /* row bands: the rows are cut into this many consecutive bands, each a resident launch of its own
-                                  (every workgroup on a CU of its own, its rows' sums in LDS, column phases over the whole of x):
-                                  the 2-D form for matrices too large for one resident pass.  1 = off, <0 = auto (default)   */
+    int32_t row_bands;         /* reserved (the 2-D form of round 3 -- row bands, each a resident launch -- was measured and not adopted:
+                                  DESIGN.md 5.9).  Leave at the default (<0) or 1; values > 1 are refused with CVR_ERR_INVALID             */
     int32_t piece_max;         /* column phases: (row, phase) segments are cut into pieces of at most this many elements (at the
                                   multiples of it from the chunk's first element), so that no lane sits on one long row's
                                   segment while the others move on to the next column ranges.  A power of two (others are rounded
                                   down).  0 = whole segments,
                                   <0 = auto (default): 8 when the chunks are long enough for a lane to fall a phase behind     */
-    int32_t reserved[5];       /* 0 */
+    int32_t interleave;        /* interleaved chunks: a chunk's non-zeros are dealt to the 64 lanes in COLUMN order (element e of the chunk's
+                                  column-sorted list at step e / 64, lane e % 64) instead of one row per lane, so that a gather instruction
+                                  reads 64 column-sorted neighbours and lanes share 128-byte lines of x; every slot carries its row, the
+                                  rows' sums are accumulated in LDS (four chunks of up to 4 095 rows per workgroup).  For matrices whose x
+                                  is far larger than an L2 and whose columns are scattered.  0 = off, 1 = on,
+                                  <0 = auto (default): for column panels that run one per XCD and get no hub tables                       */
+    int32_t reserved[4];       /* 0 */
 } cvr_options;
 /* Automatic layout: with steps_per_chunk = 0, waves_per_block = 0, x_window < 0 and col_phases < 0 (the defaults) cvr_create
  * looks at the uploaded CSR on the device (are the rows sorted by column? which share of the non-zeros lies near the
@@ -164,6 +169,8 @@ typedef struct {
                                       combine / fix-up / hub kernels not counted                                                            */
     int32_t preprocess_fused;      /* 1: cvr_create ran analysis, chunk plan, segment table and conversion as one submission (resident
                                     * layouts, cvr_fused.hip: plan_s covers all of it, the first cvr_preprocess has nothing left to do) */
+    int32_t interleave;            /* 1: the image's chunks are interleaved (cvr_options.interleave)                                      */
+    int32_t reserved_info;         /* 0 */
 } cvr_info;
 
 void        cvr_default_options(cvr_options *opt);

@@ -342,6 +342,111 @@ int orc_cvr64_build_tag(int64_t nrows, int64_t ncols, const int64_t *rp, const i
     return rc;
 }
 
+/* Interleaved chunks (cvr_options.interleave; cvr_amd/csrc/cvr_ilv.hip): the chunk plan of an image with column phases (rows capped
+ * at max_rows, their sums accumulated in LDS), but the chunk's non-zeros are dealt to the lanes in COLUMN order -- element e of the
+ * chunk's list sorted by (column, position) stands at step e / 64, lane e % 64 -- and every slot is a piece of its own: end flag and
+ * row in every column word (or 16-bit tag).  Slots behind the chunk's non-zeros (the tail padding and the pad slots the planner counts
+ * for empty rows) hold the pad column, value 0 and the dump entry.  Written from that definition; orc_cvr64_spmv interprets the image
+ * as it does any image with column phases (c->phases = 2 marks it). */
+typedef struct { int32_t col; int64_t pos; } ilvkey_t;
+static int cmp_ilv(const void *a, const void *b)
+{
+    const ilvkey_t *x = (const ilvkey_t *)a, *y = (const ilvkey_t *)b;
+    if (x->col != y->col) return x->col < y->col ? -1 : 1;
+    return x->pos < y->pos ? -1 : x->pos > y->pos;
+}
+
+int orc_cvr64_build_ilv(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
+                        int S, int64_t thr, int use_dict, int64_t max_rows, int tag16, orc_cvr64 *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->tag16 = tag16 != 0;
+    c->phases = 2;
+    int col_bits = 1;
+    while (((int64_t)1 << col_bits) <= ncols) col_bits++;
+    if (c->tag16) col_bits = 31;
+    c->col_bits = col_bits;
+    if (!c->tag16 && (col_bits >= 31 || max_rows > (((int64_t)1 << (31 - col_bits)) - 1) || max_rows <= 0)) return -7;
+    if (c->tag16 && (max_rows <= 0 || max_rows > 65534)) return -7;
+    if (S < 4 || S % 4) return -1;
+    const int64_t cap = (int64_t)W * S;
+    if (thr <= 0) thr = cap / 4;
+    if (thr > cap / 2) thr = cap / 2;
+    c->nrows = nrows; c->ncols = ncols; c->nnz = nrows ? rp[nrows] - rp[0] : 0; c->S = S; c->is_f32 = is_f32;
+    chunk_t *ch;
+    c->nchunks = plan(nrows, rp, cap, thr, max_rows, &ch, &c->shared, &c->nshared);
+    const int64_t NC = c->nchunks;
+    const int G = S / 4;
+    if (use_dict) {
+        c->ndict = build_dict(vals, is_f32, nrows ? rp[0] : 0, nrows ? rp[nrows] : 0, c->dict);
+        if (c->ndict < 0) { free(ch); return -5; }
+    }
+    const size_t gb = (c->ndict ? 1280 : is_f32 ? 2048 : 3072) + (c->tag16 ? 512 : 0);
+    const size_t cbytes = 1024 + (c->tag16 ? 512 : 0);
+    c->image_bytes = (int64_t)((size_t)NC * G * gb);
+    c->image = (uint8_t *)calloc((size_t)c->image_bytes + 16, 1);
+    c->desc = (uint32_t *)calloc((size_t)NC * 4 + 4, sizeof(uint32_t));
+    c->target = (uint8_t *)calloc((size_t)NC * W + 1, 1);
+    c->nz_begin = (int64_t *)calloc((size_t)NC + 1, sizeof(int64_t));
+    c->pad_cnt = (int64_t *)calloc((size_t)NC + 1, sizeof(int64_t));
+    c->seg_off = (uint32_t *)calloc((size_t)NC + 1, sizeof(uint32_t));
+    c->nrows_in = (uint32_t *)calloc((size_t)NC + 1, sizeof(uint32_t));
+    c->seg_row = (uint16_t *)calloc(1, sizeof(uint16_t));
+    ilvkey_t *key = (ilvkey_t *)malloc(sizeof(ilvkey_t) * (size_t)(cap + 1));
+    int code0 = 0;                          /* the dictionary code of +0.0 */
+    while (code0 < c->ndict && c->dict[code0] != 0) code0++;
+    int rc = 0;
+    for (int64_t k = 0; k < NC && !rc; k++) {
+        const chunk_t *q = &ch[k];
+        const int64_t b = q->nzb, e = k + 1 < NC ? ch[k + 1].nzb : (nrows ? rp[nrows] : 0), n = e - b;
+        c->nz_begin[k] = b; c->pad_cnt[k] = q->pad;
+        c->nrows_in[k] = (uint32_t)q->nrows_in;
+        c->desc[4 * k + 0] = (uint32_t)q->row_first;
+        c->desc[4 * k + 1] = (uint32_t)q->nseg;
+        for (int w = 0; w < 2; w++) {      /* destination of the first and of the last ROW */
+            const int64_t s = w ? q->nrows_in - 1 : 0;
+            uint32_t d;
+            if (s == 0 && q->head) d = (uint32_t)(nrows + 1 + 2 * k);
+            else if (s == q->nrows_in - 1 && q->tail) d = (uint32_t)(nrows + 1 + 2 * k + 1);
+            else d = (uint32_t)(q->row_first + s);
+            c->desc[4 * k + 2 + w] = d;
+        }
+        if (n > cap) { rc = -2; break; }
+        for (int64_t i = 0; i < n; i++) { key[i].col = cols[b + i]; key[i].pos = b + i; }
+        qsort(key, (size_t)n, sizeof(ilvkey_t), cmp_ilv);
+        for (int64_t s = 0; s < cap; s++) {
+            const int i = (int)(s / W), l = (int)(s % W), g = i / 4, j = i % 4;
+            uint8_t *grp = c->image + ((size_t)k * G + g) * gb;
+            uint32_t col = (uint32_t)ncols, row = (uint32_t)q->nrows_in;
+            double v = 0;
+            if (s < n) {
+                const int64_t p = key[s].pos;
+                int64_t r = q->row_first;            /* the chunk's row of position p: the last of its rows that starts at or before p */
+                while (r + 1 < q->row_first + q->nrows_in && rp[r + 1] <= p) r++;
+                col = (uint32_t)key[s].col; row = (uint32_t)(r - q->row_first);
+                v = is_f32 ? (double)((const float *)vals)[p] : ((const double *)vals)[p];
+            }
+            ((uint32_t *)grp)[l * 4 + j] = col | 0x80000000u | (c->tag16 ? 0u : row << col_bits);
+            if (c->tag16) ((uint16_t *)(grp + 1024))[l * 4 + j] = (uint16_t)row;
+            if (c->ndict) {
+                int code = code0;
+                if (s < n) {
+                    uint64_t bits;
+                    if (is_f32) { float f = (float)v; uint32_t u; memcpy(&u, &f, 4); bits = u; } else memcpy(&bits, &v, 8);
+                    code = 0;
+                    while (code < c->ndict && c->dict[code] != bits) code++;
+                }
+                (grp + cbytes)[l * 4 + j] = (uint8_t)code;
+            }
+            else if (is_f32) ((float *)(grp + cbytes))[l * 4 + j] = (float)v;
+            else ((double *)(grp + cbytes + (j / 2) * 1024))[l * 2 + j % 2] = v;
+        }
+    }
+    if (NC) c->nz_begin[NC] = nrows ? rp[nrows] : 0;
+    free(key); free(ch);
+    return rc;
+}
+
 void orc_cvr64_free(orc_cvr64 *c)
 {
     free(c->image); free(c->desc); free(c->target); free(c->shared); free(c->nz_begin); free(c->pad_cnt);

@@ -124,6 +124,9 @@ int  orc_cvr64_build_full(int64_t nrows, int64_t ncols, const int64_t *rowptr, c
  * (row, phase) segments cut into pieces of at most piece_max elements (piece_max > 0) */
 int  orc_cvr64_build_tag(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
                          int S, int64_t split_threshold, int use_dict, int phases, int64_t max_rows, int64_t hub_max, int reorder, int narrow, int tag16, int64_t piece_max, orc_cvr64 *out);
+/* interleaved chunks (cvr_options.interleave): the chunk's non-zeros dealt to the lanes in column order, every slot a piece of its own */
+int  orc_cvr64_build_ilv(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
+                         int S, int64_t split_threshold, int use_dict, int64_t max_rows, int tag16, orc_cvr64 *out);
 void orc_cvr64_free(orc_cvr64 *c);
 /* interpret the image exactly as the HIP kernel does (same per-lane order of operations) */
 void orc_cvr64_spmv(const orc_cvr64 *c, const void *x, void *y);

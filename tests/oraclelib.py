@@ -60,6 +60,8 @@ def lib():
                                               C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(OrcCvr64)]
         _lib.orc_cvr64_build_tag.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(OrcCvr64)]
+        _lib.orc_cvr64_build_ilv.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.POINTER(OrcCvr64)]
         _lib.orc_write_mtx_pattern.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     return _lib
 
@@ -178,14 +180,18 @@ class Cvr8:
 class Cvr64:
     """CPU mirror of the device format (arrays copied to numpy)"""
 
-    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0, use_dict=False, phases=1, max_rows=0, hub_max=0, narrow=False, reorder=False, tag16=False, piece_max=0):
+    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0, use_dict=False, phases=1, max_rows=0, hub_max=0, narrow=False, reorder=False, tag16=False, piece_max=0, interleave=False):
         self.rp = np.ascontiguousarray(rowptr, dtype=np.int64)
         self.cl = np.ascontiguousarray(cols, dtype=np.int32)
         self.f32 = vals.dtype == np.float32
         self.vl = np.ascontiguousarray(vals, dtype=np.float32 if self.f32 else np.float64)
         self.c = OrcCvr64()
-        self.rc = lib().orc_cvr64_build_tag(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data,
-                                            int(self.f32), S, thr, int(use_dict), phases, max_rows, hub_max, int(bool(reorder)), int(bool(narrow)), int(bool(tag16)), int(piece_max), C.byref(self.c))
+        if interleave:
+            self.rc = lib().orc_cvr64_build_ilv(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data, int(self.f32), S, thr, int(use_dict),
+                                                max_rows, int(bool(tag16)), C.byref(self.c))
+        else:
+            self.rc = lib().orc_cvr64_build_tag(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data,
+                                                int(self.f32), S, thr, int(use_dict), phases, max_rows, hub_max, int(bool(reorder)), int(bool(narrow)), int(bool(tag16)), int(piece_max), C.byref(self.c))
         if self.rc:
             raise RuntimeError(f"orc_cvr64_build = {self.rc}")
         c = self.c

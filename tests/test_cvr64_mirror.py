@@ -201,3 +201,48 @@ def test_mirror_column_phases_match_csr_oracle(name, S, P, tags, pmax):
         assert np.array_equal(m.desc, m0.desc) and np.array_equal(m.target, m0.target)
         x = O.x_vec_fast(ncols, "rand")
         assert np.array_equal(m.spmv(x), m0.spmv(x))
+
+
+# ---- interleaved chunks (cvr_options.interleave; oracle: orc_cvr64_build_ilv) ----
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("S,tags,use_dict", [(4, 1, 0), (16, 1, 1), (32, 0, 0)])
+def test_interleaved_mirror_matches_csr_oracle(name, S, tags, use_dict):
+    """the interleaved image (a chunk's non-zeros dealt to the lanes in column order, every slot with its row) gives the CSR loop's y,
+    and is a permutation of the CSR non-zeros plus pad slots that point at the dump entry"""
+    nrows, ncols, rp, ci, va = CASES[name]
+    if use_dict and len(np.unique(va)) > 255:
+        pytest.skip("more than 255 distinct values")
+    max_rows = min(64 * S, 2000)
+    if not tags:
+        bits = max(1, int(ncols).bit_length())
+        max_rows = min(max_rows, (1 << (31 - bits)) - 1)
+    m = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=bool(use_dict), max_rows=max_rows, tag16=tags, interleave=True)
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(ncols, mode)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        bad, worst = O.tol_check(m.spmv(x), yref, absy, tol=1e-12)
+        assert len(bad) == 0, (mode, worst, bad[:5])
+    gb = (1280 if use_dict else 3072) + (512 if tags else 0)
+    img = m.image.reshape(-1, gb)
+    cw = img[:, :1024].copy().view(np.uint32).reshape(m.nchunks, -1, 64, 4)          # [chunk][group][lane][step in group]
+    assert np.all(cw >> 31 == 1)                                                      # every slot ends a piece
+    cmask = 0x7FFFFFFF if tags else (1 << m.c.col_bits) - 1
+    col = (cw & cmask).transpose(0, 1, 3, 2).reshape(m.nchunks, -1)                   # [chunk][slot in (step, lane) order]
+    real = col != ncols
+    assert real.sum() == len(ci)
+    for k in range(m.nchunks):
+        n = int(m.nz_begin[k + 1] - m.nz_begin[k])
+        assert np.all(real[k, :n]) and not real[k, n:].any()                          # the chunk's non-zeros first, then padding
+        assert np.all(np.diff(col[k, :n].astype(np.int64)) >= 0)                      # in column order
+        assert np.array_equal(np.sort(col[k, :n]), np.sort(ci[m.nz_begin[k]:m.nz_begin[k + 1]]).astype(np.uint32))
+
+
+def test_interleaved_mirror_fp32_and_limits():
+    nrows, ncols, rp, ci, va = CASES32["power_law_3000"]
+    m = O.Cvr64(nrows, ncols, rp, ci, va, 16, max_rows=500, tag16=1, interleave=True)
+    x = O.x_vec_fast(ncols, "rand").astype(np.float32)
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    bad, worst = O.tol_check(m.spmv(x), yref, absy, tol=1e-5)
+    assert len(bad) == 0, worst
+    with pytest.raises(RuntimeError):          # the row field of the column word cannot hold that many rows
+        O.Cvr64(nrows, ncols, rp, ci, va, 16, max_rows=1 << 20, tag16=0, interleave=True)

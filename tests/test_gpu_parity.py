@@ -91,6 +91,60 @@ def test_workgroup_window_and_column_phases(name, S, wpb, win, P, tags, pmax):
     A.close()
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("S,wpb,tags", [(4, 1, 1), (16, 4, 1), (32, 2, 0), (64, 4, -1)])
+def test_interleaved_chunks_image_bit_exact_and_y_parity(name, S, wpb, tags):
+    """cvr_options.interleave: a chunk's non-zeros dealt to the lanes in column order, every slot with its row, the rows' sums in LDS
+    (cvr_ilv.hip).  The image against the CPU mirror (orc_cvr64_build_ilv) bit for bit, y against the CSR oracle, y bitwise equal to
+    the mirror's interpretation of the image when no row is cut over chunks, and bitwise equal from run to run."""
+    nrows, ncols, rp, ci, va = CASES[name]
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, waves_per_block=wpb, row_tags16=tags, interleave=1, col_panels=1)
+    i = A.info
+    assert (i.interleave, i.waves_per_block, i.col_panels, i.piece_max) == (1, wpb, 1, 1)
+    if tags >= 0:
+        assert i.row_tags16 == tags
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=i.value_dict > 0, max_rows=i.chunk_row_cap, tag16=i.row_tags16, interleave=True)
+    img = A.export_image()
+    assert (i.nchunks, i.nshared, i.value_dict) == (mir.nchunks, mir.nshared, mir.ndict)
+    for key in ("desc", "shared", "image"):
+        assert np.array_equal(img[key], getattr(mir, key)), key
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(ncols, mode)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL64, (name, S, wpb, tags, mode))
+        if i.nshared == 0:
+            assert np.array_equal(y, mir.spmv(x)), (name, S, wpb, tags, mode)
+        y2, _ = A.spmv(x)
+        assert np.array_equal(y, y2)
+    A.close()
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_interleaved_column_panels_one_per_xcd(f32):
+    """the configuration the automatic rule picks for the soc-LiveJournal1 shape, scaled down: column panels that run one per XCD, every
+    panel's chunks interleaved, four chunks per workgroup; unsorted rows are fine (the converter sorts)"""
+    n, nc, rp, ci, va = synth.livejournal_like(scale=0.03)
+    rng = np.random.default_rng(11)
+    if f32:
+        va = (rng.random(len(ci)) - 0.5).astype(np.float32)
+    for r in rng.integers(0, n, 200):              # a few rows with their entries out of order
+        a, b = int(rp[r]), int(rp[r + 1])
+        p = rng.permutation(b - a)
+        ci[a:b], va[a:b] = ci[a:b][p], va[a:b][p]
+    A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, col_panels=16, interleave=1)
+    i = A.info
+    assert (i.interleave, i.col_panels, i.waves_per_block, i.spmv_launches) == (1, 16, 4, 1), (i.interleave, i.col_panels, i.waves_per_block, i.spmv_launches)
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(nc, mode).astype(va.dtype)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL32 if f32 else TOL64, ("interleaved panels", f32, mode))
+        y2, _ = A.spmv(x)
+        assert np.array_equal(y, y2)
+    A.close()
+
+
 def test_column_phases_need_sorted_rows_and_fit_the_row_field():
     rng = np.random.default_rng(5)
     nrows, ncols, rp, ci, va = K.csr_from_lengths([7] * 300, 5000, rng, sort=False)
