@@ -533,7 +533,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         panel_opt.panel_on_one_xcd = xcd_panels ? 1 : 0;
         // interleaved chunks (automatic): panels that run one per XCD (their slice of x stays in that L2: what is left to save is the
         // number of requests) and get no hub tables -- scattered columns without a popular head, the soc-LiveJournal1 shape
-        if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && !getenv("CVR_NO_AUTO_LAYOUT") ? 1 : 0;
+        // (from 8 M non-zeros on: below, the few long chunks per XCD cost what the sorting saves -- wiki-Talk shape 5 M: 48.6 -> 50.4 us, a
+        // 2.4-M-row matrix of single-entry rows 36.7 -> 38.7; web-Google shape x 3, 15 M: 94.9 -> 86.9; com-Orkut shape 1 307 -> 778:
+        // profiles/r04_ilv_auto_probe.log)
+        if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && sj1 - sj0 >= (int64_t)8 << 20 && !getenv("CVR_NO_AUTO_LAYOUT") ? 1 : 0;
         if (panel_opt.interleave > 0) {
             panel_opt.hub_table = 0; panel_opt.col_phases = 1;
             if (panel_opt.steps_per_chunk == 0) {       // one chunk length for all panels (they share a launch): from the mean sub-row and the mean panel
@@ -543,6 +546,11 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 panel_opt.steps_per_chunk = interleave_steps((sj1 - sj0) / P, std::max<int64_t>(nsub_all / P, 1), f32, one);
             }
         }
+        // interleaved panels keep their columns relative to the panel's first (the row field of the column word then has room for the
+        // chunk's rows without 16-bit tags): such a part is planned and built as a matrix of the panel's width
+        const int64_t pwidth = (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1;          // (the split's width)
+        auto part_base = [&](int p) { return panel_opt.interleave > 0 ? std::min<int64_t>((int64_t)p * pwidth, std::max<int64_t>(ncols - 1, 0)) : (int64_t)0; };
+        auto part_cols = [&](int p) { return panel_opt.interleave > 0 ? std::max<int64_t>(1, std::min<int64_t>(pwidth, ncols - (int64_t)p * pwidth)) : ncols; };
         std::vector<IOpt>        popts((size_t)P, panel_opt);
         std::vector<DevRows>     drs((size_t)P);
         if (dev_split) {
@@ -560,7 +568,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 drs[(size_t)p] = DevRows{part.d_rp, 0, nzp, h->stream, &h->plan_ws};
                 rc = choose_hubs(h, part, dsg.d.ci + dsg.d.off[p], ns, ncols, f32, 0, nzp, popts[(size_t)p], pps[(size_t)p], false);
                 if (rc) { cvr_destroy(h); return rc; }
-                CREATE_TRY(plan_part(pps[(size_t)p], ns, ncols, f32, nullptr, popts[(size_t)p], &drs[(size_t)p]));
+                CREATE_TRY(plan_part(pps[(size_t)p], ns, part_cols(p), f32, nullptr, popts[(size_t)p], &drs[(size_t)p]));
             }
             in.plan_s += now_s() - tp - (in.hub_select_s - hub0);      // (hub selection is reported on its own)
             clk.lap("  hub tables, plans (device)");
@@ -569,7 +577,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             const double tp = now_s();
             int T = (int)std::thread::hardware_concurrency();
             T = std::max(1, std::min(T, P));
-            auto work = [&](int t) { for (int p = t; p < P; p += T) { pps[(size_t)p].plan_threads = 1; (void)plan_part(pps[(size_t)p], nsubs[(size_t)p], ncols, f32, sp.rp[(size_t)p].data(), popts[(size_t)p]); } };
+            auto work = [&](int t) { for (int p = t; p < P; p += T) { pps[(size_t)p].plan_threads = 1; (void)plan_part(pps[(size_t)p], nsubs[(size_t)p], part_cols(p), f32, sp.rp[(size_t)p].data(), popts[(size_t)p]); } };
             std::vector<std::thread> th;
             for (int t = 1; t < T; t++) th.emplace_back(work, t);
             work(0);
@@ -585,12 +593,13 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 part.d_ci = h->split_ci + dsg.d.off[p];
                 part.d_va = static_cast<uint8_t *>(h->split_va) + (size_t)dsg.d.off[p] * vsz;
                 part.csr_borrowed = true;
-                rc = build_part(h, part, nsubs[(size_t)p], ncols, nullptr, part.d_ci, part.d_va, hipMemcpyDeviceToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p], &drs[(size_t)p]);
+                rc = build_part(h, part, nsubs[(size_t)p], part_cols(p), nullptr, part.d_ci, part.d_va, hipMemcpyDeviceToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p], &drs[(size_t)p]);
             }
             else
-                rc = build_part(h, part, nsubs[(size_t)p], ncols, sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
+                rc = build_part(h, part, nsubs[(size_t)p], part_cols(p), sp.rp[(size_t)p].data(), sp.ci[(size_t)p].data(),
                                 sp.va[(size_t)p].data(), hipMemcpyHostToDevice, f32, popts[(size_t)p], &in.plan_s, &pps[(size_t)p]);
             if (rc) { cvr_destroy(h); return rc; }
+            part.img.col_base = (uint32_t)part_base(p);
             part.zoff = zoff;
             zoff += part.yext;
             nsub += part.nrows;
@@ -704,7 +713,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (plain) {
             const size_t per_round = getenv("CVR_XCD_PANELS_DEBUG") ? (size_t)atoi(getenv("CVR_XCD_PANELS_DEBUG")) : 8;      // (diagnostics: fewer panels side by side)
             const size_t rounds = (h->parts.size() + per_round - 1) / per_round;
-            std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr});
+            std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u});
             h->multi_chunks.assign(rounds, 0u);
             // which panel runs where: the heaviest first, each to the XCD with the least work so far that still has a round free (the XCDs
             // go through their panels independently: what counts is every XCD's sum, not the rounds'); equal-width panels of a real graph
@@ -730,7 +739,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 const Part &p = h->parts[j];
                 const size_t i = slot_of[j];
                 h->parts[j].multi_slot = (int32_t)i;
-                pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2};
+                pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col};
                 h->multi_chunks[i / 8] = std::max(h->multi_chunks[i / 8], p.img.nchunks);
                 h->multi_ystage = std::max(h->multi_ystage, p.img.ystage);
                 if (getenv("CVR_XCD_PANELS_TRACE")) fprintf(stderr, "[xcd panels] part %zu slot %zu nchunks %u ystage %u S %d G %d zoff %lld yext %lld nshared %u stream %p\n", j, i, p.img.nchunks, p.img.ystage, p.img.S, p.img.G, (long long)p.zoff, (long long)p.yext, p.img.nshared, (void *)p.img.stream);

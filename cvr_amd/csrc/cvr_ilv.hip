@@ -38,7 +38,7 @@ template <typename T, bool DICT, bool TAG>
 __global__ __launch_bounds__(256) void ilv_emit_kernel(uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, const int64_t *__restrict__ nzb,
                                                        const int64_t *__restrict__ rp, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sidx, const T *__restrict__ vals,
                                                        const uint8_t *__restrict__ codes, const T *__restrict__ dict, uint32_t ndict, int G, int64_t n0, uint32_t pad_col, uint32_t col_bits,
-                                                       uint32_t *__restrict__ err)
+                                                       uint32_t col_base, uint32_t *__restrict__ err)
 {
     constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
     constexpr uint32_t VB = kColsBytes + (TAG ? kTagBytes : 0);
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void ilv_emit_kernel(uint8_t *__restrict__ str
     uint32_t code = 0;
     if (e < n) {
         const int64_t p = n0 + (int64_t)sidx[b - n0 + e];         // position in the part's CSR arrays
-        col = skey[b - n0 + e];
+        col = skey[b - n0 + e] - col_base;                         // (a column panel keeps its columns relative to its first)
         // the chunk's row of position p: the last of its rows that starts at or before p (a row cut over chunks begins before the chunk)
         uint32_t lo = 0, hi = nri;                                // answer in [0, nri)
         while (hi - lo > 1) {
@@ -123,7 +123,7 @@ hipError_t launch_convert_interleaved(const DeviceImage &img, const DeviceCsr &c
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (nnz > 0) {
         int bits = 1;
-        while (bits < 32 && (1ull << bits) <= (unsigned long long)img.pad_col) bits++;
+        while (bits < 32 && (1ull << bits) <= (unsigned long long)img.col_base + img.pad_col) bits++;
         e = hipcub::DeviceSegmentedRadixSort::SortPairs(d_tmp, tmp, reinterpret_cast<const uint32_t *>(csr.col_idx + n0), skey, idx, sidx, (int)nnz, (int)img.nchunks, off32, off32 + 1, 0, bits, st);
         if (e != hipSuccess) return e;
     }
@@ -131,7 +131,7 @@ hipError_t launch_convert_interleaved(const DeviceImage &img, const DeviceCsr &c
     const bool dict = img.dict != nullptr;
 #define CVR_ILV(T, DI, TG)                                                                                                                           \
     hipLaunchKernelGGL((ilv_emit_kernel<T, DI, TG>), grid, block, 0, st, img.stream, img.desc, img.desc2, csr.nz_begin, csr.row_ptr, skey, sidx, static_cast<const T *>(csr.vals), \
-                       csr.codes, static_cast<const T *>(img.dict), img.ndict, img.G, (long long)n0, img.pad_col, img.col_bits, err_flag)
+                       csr.codes, static_cast<const T *>(img.dict), img.ndict, img.G, (long long)n0, img.pad_col, img.col_bits, img.col_base, err_flag)
     if (img.f32) { if (dict) { if (img.tag16) CVR_ILV(float, true, true); else CVR_ILV(float, true, false); } else { if (img.tag16) CVR_ILV(float, false, true); else CVR_ILV(float, false, false); } }
     else { if (dict) { if (img.tag16) CVR_ILV(double, true, true); else CVR_ILV(double, true, false); } else { if (img.tag16) CVR_ILV(double, false, true); else CVR_ILV(double, false, false); } }
 #undef CVR_ILV

@@ -11,7 +11,7 @@ using namespace cvrh;
 namespace {
 
 constexpr uint64_t kImgMagic = 0x3130474d49525643ull;      // "CVRIMG01"
-constexpr uint32_t kImgVersion = 6;                        // bump when DeviceImage / the handle's tables change
+constexpr uint32_t kImgVersion = 7;                        // bump when DeviceImage / the handle's tables change
 
 struct ImgKey {
     uint64_t       magic;
@@ -88,6 +88,7 @@ struct ImgScalars {
     int64_t  part_nrows, part_nnz, part_nnz_span, part_nchunks, part_nshared, part_yext, part_zoff;
     uint64_t stream_bytes;
     int32_t  multi_slot, ilv;      // where the panel stands in the rounds of eight (-1: none)
+    uint32_t col_base, reserved;
 };
 
 }  // namespace
@@ -126,7 +127,7 @@ int cvr_save_image(cvr_handle *h, const char *path, const cvr_source_key *key)
         s.piece_max = g.piece_max; s.hub_n = g.hub_n; s.order_n = g.order_n; s.ncus = g.ncus; s.has_pace = g.pace ? 1u : 0u;
         s.part_nrows = p.nrows; s.part_nnz = p.nnz; s.part_nnz_span = p.nnz_span; s.part_nchunks = p.nchunks; s.part_nshared = p.nshared; s.part_yext = p.yext; s.part_zoff = p.zoff;
         s.stream_bytes = p.stream_bytes;
-        s.multi_slot = p.multi_slot; s.ilv = g.ilv ? 1 : 0;
+        s.multi_slot = p.multi_slot; s.ilv = g.ilv ? 1 : 0; s.col_base = g.col_base;
         w.pod(s);
         const size_t nc = (size_t)g.nchunks;
         const size_t slack = 8 * (size_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16);
@@ -219,7 +220,7 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         g.piece_max = s.piece_max; g.hub_n = s.hub_n; g.order_n = s.order_n; g.ncus = s.ncus;
         p.nrows = s.part_nrows; p.nnz = s.part_nnz; p.nnz_span = s.part_nnz_span; p.nchunks = s.part_nchunks; p.nshared = s.part_nshared; p.yext = s.part_yext; p.zoff = s.part_zoff;
         p.stream_bytes = (size_t)s.stream_bytes;
-        p.multi_slot = s.multi_slot; g.ilv = s.ilv != 0;
+        p.multi_slot = s.multi_slot; g.ilv = s.ilv != 0; g.col_base = s.col_base;
         g.dict = h->d_dict;
         // the scalars must describe one consistent image: every array below is then required to have exactly the size they imply, and the
         // kernels' LDS and index arithmetic stays inside what cvr_create could have produced
@@ -228,7 +229,7 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
             const bool sane = s.S >= 4 && s.S <= 4096 && s.S % 4 == 0 && s.G == s.S / 4 && nc == (uint64_t)s.part_nchunks && g.nshared == (uint64_t)s.part_nshared && s.part_nrows >= 0 &&
                               (uint64_t)s.part_nrows == g.nrows && s.part_yext == s.part_nrows + 1 + 2 * (int64_t)nc && s.part_zoff >= 0 && g.wpb >= 1 && g.wpb <= (uint32_t)cvr::kMaxWavesPerBlock &&
                               g.phases >= 1 && g.phases <= 64 && g.ystage >= 1 && g.ystage <= 65532 && g.col_bits <= 31 && g.ndict == h->ndict && (g.f32 ? 4u : 8u) == have.vsz &&
-                              g.pad_col == (uint64_t)h->info.ncols && (!g.c16 || (!g.tag16 && g.phases == 1)) && (g.order_n == 0 || g.order_n == g.pad_col) &&
+                              (uint64_t)g.col_base + g.pad_col <= (uint64_t)h->info.ncols && (g.col_base == 0 ? g.pad_col == (uint64_t)h->info.ncols : g.ilv) && (!g.c16 || (!g.tag16 && g.phases == 1)) && (g.order_n == 0 || g.order_n == g.pad_col) &&
                               s.stream_bytes == nc * (uint64_t)s.G * (uint64_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16) &&
                               (s.multi_slot < 0 || (has_multi && (uint32_t)s.multi_slot < nrounds * 8)) && cvr::spmv_lds_bytes(g) <= cvr::kLdsBytes;
             if (!sane) { r.ok = false; LOAD_TRY(hipSuccess); }
@@ -281,10 +282,10 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         LOAD_TRY(hipMemcpy(h->d_fixparts, fp.data(), sizeof(cvr::FixPart) * nparts, hipMemcpyHostToDevice));
         if (has_multi) {
             const size_t per_round = 8;
-            std::vector<cvr::PanelArgs> pa((size_t)nrounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr});
+            std::vector<cvr::PanelArgs> pa((size_t)nrounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u});
             for (uint32_t j = 0; j < nparts; j++) {       // every panel where cvr_create placed it (the heaviest first, each on the XCD with the least work)
                 const Part &p = h->parts[j];
-                pa[p.multi_slot >= 0 ? (size_t)p.multi_slot : (j / per_round) * 8 + j % per_round] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2};
+                pa[p.multi_slot >= 0 ? (size_t)p.multi_slot : (j / per_round) * 8 + j % per_round] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col};
             }
             LOAD_TRY(hipMalloc(&h->d_multi, sizeof(cvr::PanelArgs) * pa.size()));
             LOAD_TRY(hipMemcpy(h->d_multi, pa.data(), sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyHostToDevice));

@@ -40,6 +40,7 @@ struct DeviceImage {
     bool      tag16 = false;        // column phases: the rows of the pieces stand in 16-bit tags of their own (col_bits = 31)
     uint32_t *pace = nullptr;       // column phases with long chunks: [8][phases][512] words of the SpMV kernel's pacing (spmv_seg_kernel; zeroed once), or null
     uint32_t *pace_epoch = nullptr; // host: launches so far (the value a launch marks with)
+    uint32_t  col_base = 0;         // interleaved column panels: the image's column indices are relative to this column (pad_col = the panel's width)
     bool      ilv = false;          // interleaved chunks (cvr_ilv.hip): the image is written in the column-phase format with every slot a piece of its own; conversion only
     uint32_t  piece_max = 0;        // column phases: (row, phase) segments are cut into pieces at the multiples of this many elements from the chunk's first (0 = whole segments)
     uint32_t  col_bits = 31;        // column phases: the LAST column word of a segment carries the chunk's row of the segment
@@ -185,7 +186,7 @@ hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, 
 hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st, const uint32_t *nchunks_dev = nullptr);
 
 // column panels, one panel per XCD at a time: what differs between the eight panels of one launch (device array of 8; nchunks = 0: none)
-struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *target; void *yext; uint32_t nchunks, ystage; const uint2 *desc2; };
+struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *target; void *yext; uint32_t nchunks, ystage; const uint2 *desc2; uint32_t col_base, pad_col; };      // (col_base, pad_col: interleaved panels keep panel-local columns)
 // y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0 and with_fixup)
 // multi != null: eight panels in one launch (plain layout, one chunk per workgroup, no LDS tables): workgroup b takes chunk b >> 3 of
 // panel b & 7 of its round; multi[rounds][8]; multi_chunks = the most chunks any panel has (the rounds follow each other in ONE grid:

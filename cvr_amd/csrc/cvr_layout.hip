@@ -37,7 +37,7 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
     // interleaved chunks: planned and run like an image with column phases (every slot carries its row, the rows' sums live in LDS);
     // four chunks per workgroup unless the caller says otherwise, no window
     pp.ilv = opt.interleave > 0 && pp.hub_n == 0;
-    if (pp.ilv) { pp.phases = 2; if (opt.waves_per_block <= 0) pp.wpb = 4; }
+    if (pp.ilv) { pp.phases = 2; pp.wpb = opt.waves_per_block <= 0 ? 4 : std::min(pp.wpb, 8); }      // (spmv_ilv_kernel: at most eight wavefronts)
     // LDS window of x per workgroup (off by default): `win` consecutive values of x staged with coalesced loads; gathers
     // inside it are served by ds_read instead of a 128-byte L1 fill each.
     pp.win = std::min<int64_t>(opt.x_window < 0 ? 0 : opt.x_window, ncols + 1) & ~(int64_t)3;      // whole 16-byte loads, inside x_ext
@@ -96,7 +96,7 @@ int interleave_steps(int64_t nnz, int64_t nrows, bool f32, const IOpt &opt)
     const int64_t rows = std::min<int64_t>(((int64_t)cvr::kLdsBytes / vs - cvr::kDictMax - 8) / wpb, cvr::kYStageMax) - 1;
     const double  mean = (double)nnz / (double)std::max<int64_t>(nrows, 1);
     const double  cus = opt.panel_on_one_xcd ? (double)opt.cus / opt.xcds : (double)opt.cus;
-    int64_t       S = (int64_t)(mean * (double)rows / 64.0) + 1;
+    int64_t       S = (int64_t)(0.85 * mean * (double)rows / 64.0) + 1;      // (a little under what the row cap fills: most chunks then end at their slots, not at their rows -- 384 / 320 steps: 343 / 332 us on the soc-LiveJournal1 shape)
     S = std::min<int64_t>(S, (int64_t)((double)nnz / (64.0 * cus * (double)wpb)) + 1);
     return (int)std::min<int64_t>(508, std::max<int64_t>(16, (S + 3) / 4 * 4));
 }

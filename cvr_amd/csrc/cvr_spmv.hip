@@ -486,9 +486,8 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn,
     const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, const uint2 *__restrict__ desc2_a, uint32_t col_bits, uint32_t nw_arg, int gb,
     uint32_t *__restrict__ pace, uint32_t pw, uint32_t pad_col, int pace_lag, uint32_t nphases, uint32_t epoch, const PanelArgs *__restrict__ multi,
-    IterEpilogue epi, uint32_t groups_in_desc2)
+    IterEpilogue epi)
 {
-    const int G_alloc = G;                            // groups every chunk has room for: the stride of the stream
     const uint8_t *__restrict__ stream = stream_a;
     const uint4 *__restrict__   desc = desc_a;
     const uint2 *__restrict__   desc2 = desc2_a;
@@ -539,9 +538,7 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     constexpr int  QN = DEPTH + QA;
     SegGroup<T, DICT, TAG> Q[QN];
     X4<T>          xs[DEPTH];
-    // interleaved images (groups_in_desc2): desc2[k].x = the groups that hold the chunk's non-zeros; the padding behind them is neither streamed nor walked
-    if (groups_in_desc2 && live) G = min(G, (int)desc2[k].x);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G_alloc * GB), live ? (uint32_t)G * GB : 0u);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G * GB), live ? (uint32_t)G * GB : 0u);
 #pragma unroll
     for (int i = 0; i < QN; i++) Q[i] = load_seg_group<T, DICT, TAG>(rs, voff, (uint32_t)i * GB);
     const uint4    d = live ? desc[k] : uint4{0, 0, 0, 0};
@@ -778,8 +775,8 @@ template <typename T, bool DICT, bool TAG> struct RingLayout {
 template <typename T, bool DICT, bool TAG>
 __global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingCap))) void spmv_ilv_kernel(
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint2 *__restrict__ desc2_a, const T *__restrict__ x, T *__restrict__ yext_a, int G_alloc,
-    uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes, const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, uint32_t col_bits,
-    const PanelArgs *__restrict__ multi)
+    uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes_a, const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, uint32_t col_bits,
+    uint32_t col_base_a, const PanelArgs *__restrict__ multi)
 {
     using L = RingLayout<T, DICT, TAG>;
     constexpr int D = L::D, QN = 2 * D, XB = L::XB, QB = L::QB, K = (D - 1) * (4 + L::NS);
@@ -788,11 +785,12 @@ __global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingC
     const uint4 *__restrict__   desc = desc_a;
     const uint2 *__restrict__   desc2 = desc2_a;
     T *__restrict__             yext = yext_a;
-    uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = blockIdx.x;
-    if (multi) {          // column panels, one per XCD at a time (spmv_kernel)
+    uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = blockIdx.x, col_base = col_base_a, xbytes = xbytes_a;
+    if (multi) {          // column panels, one per XCD at a time (spmv_kernel); the panel's columns are relative to its first
         const uint32_t  round = blockIdx.x / nblocks_per_xcd, b = blockIdx.x - round * nblocks_per_xcd;
         const PanelArgs pa = multi[round * 8u + (b & 7u)];
         stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
+        col_base = pa.col_base; xbytes = (pa.pad_col + 1u) * (uint32_t)sizeof(T);
         bidx = b >> 3;
     }
     constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
@@ -818,7 +816,7 @@ __global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingC
     } else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (!live) return;
     // (the descriptors must live in scalar registers: the asm statements below take them as such)
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, xbytes);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + col_base, xbytes);
     const uint64_t sbase = reinterpret_cast<uint64_t>(stream + (size_t)k * ((size_t)G_alloc * GB));
     const uint64_t sbase_u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sbase) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32)) << 32);      // (the builtin returns int: no sign extension)
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const void *>(sbase_u), __builtin_amdgcn_readfirstlane(G * GB));
@@ -1026,7 +1024,7 @@ hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st)
     return hipGetLastError();
 }
 
-bool iter_epilogue_ok(const DeviceImage &img) { return img.phases > 1 && img.nshared == 0 && img.nchunks > 0 && (img.nchunks + (img.wpb > 1 ? img.wpb : 1) - 1) / (img.wpb > 1 ? img.wpb : 1) <= 1024u; }
+bool iter_epilogue_ok(const DeviceImage &img) { return img.phases > 1 && !img.ilv && img.nshared == 0 && img.nchunks > 0 && (img.nchunks + (img.wpb > 1 ? img.wpb : 1) - 1) / (img.wpb > 1 ? img.wpb : 1) <= 1024u; }
 
 size_t spmv_lds_bytes(const DeviceImage &img)
 {
@@ -1090,7 +1088,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
 #define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
                              else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
 #define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
-                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi, epi ? *epi : IterEpilogue{}, img.ilv ? 1u : 0u
+                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi, epi ? *epi : IterEpilogue{}
 #define CVR_SEG(T, SP, D, W, DI, LD)                                                                               \
     do {                                                                                                           \
         const dim3 sblock(kLanes * (wpb + (LD ? loaders : 0u)));                                                   \
@@ -1113,10 +1111,10 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     uint32_t *pace = img.phases > 1 && img.pace && pace_lag > 0 && !multi ? img.pace : nullptr;
     const uint32_t epoch = pace ? ++*img.pace_epoch : 0u;        // (a launch marks with its own number: nothing to zero in between)
     // interleaved images: the hand-pipelined kernel (spmv_ilv_kernel) whenever the workgroup fits it
-    static const int env_ilv = [] { const char *e = getenv("CVR_DEBUG_ILV_KERNEL"); return e ? atoi(e) : 1; }();      // 0: through spmv_seg_kernel (the same y)
-    if (img.ilv && env_ilv && kLanes * wpb <= (uint32_t)kRingThreads && !epi) {
+    if (img.ilv) {
+        if (epi || kLanes * wpb > (uint32_t)kRingThreads) return hipErrorInvalidValue;      // (plan_layout keeps interleaved workgroups within the ring kernel's eight wavefronts)
 #define CVR_ILV(T, DI, TG) hipLaunchKernelGGL((spmv_ilv_kernel<T, DI, TG>), dim3(grid), block, lds, st, img.stream, img.desc, img.desc2, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, \
-                                              multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.col_bits, multi)
+                                              multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.col_bits, img.col_base, multi)
         if (img.f32) { if (use_dict) { if (img.tag16) CVR_ILV(float, true, true); else CVR_ILV(float, true, false); } else { if (img.tag16) CVR_ILV(float, false, true); else CVR_ILV(float, false, false); } }
         else { if (use_dict) { if (img.tag16) CVR_ILV(double, true, true); else CVR_ILV(double, true, false); } else { if (img.tag16) CVR_ILV(double, false, true); else CVR_ILV(double, false, false); } }
 #undef CVR_ILV

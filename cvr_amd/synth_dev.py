@@ -143,3 +143,72 @@ def csr_spmv_reference(rp, ci, va, x):
         y[r0:r1] = torch.segment_reduce(prod, "sum", lengths=lengths, unsafe=True)
         ay[r0:r1] = torch.segment_reduce(prod.abs(), "sum", lengths=lengths, unsafe=True)
     return y, ay
+
+
+# ---- two more SuiteSparse-shaped power-law stand-ins (round 4): defined like R-MAT above -- by torch generator streams, so per device type --
+# and built on the device in seconds.  Pattern matrices: value = (position in row-major order) % 13, what the reference's loader gives a
+# `pattern` file (spmv.cpp:417), so the value dictionary applies as it does to the SNAP graphs themselves.
+ORKUT = dict(n=3_072_441, edges=117_185_083, seed=20261004)          # com-Orkut: undirected friendship graph, mean degree 76, max 33 313
+WIKITALK = dict(n=2_394_385, nnz=5_021_410, seed=20261005)           # wiki-Talk: 94 % of the users never write, a few write to 100 000 others
+
+
+def _csr_from_keys(key, n, device):
+    """sorted unique keys row * n + col -> (row_ptr int64, col_idx int32)"""
+    r = torch.div(key, n, rounding_mode="floor")
+    c = (key - r * n).to(torch.int32)
+    rp = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rp[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+    return rp, c
+
+
+def _pattern_values(nnz, device, dtype=torch.float64):
+    return (torch.arange(nnz, dtype=torch.int64, device=device) % 13).to(dtype)
+
+
+def orkut_like(scale=1.0, device="cpu", dtype=torch.float64):
+    """com-Orkut's shape: symmetric, ~3.07 M x 3.07 M, ~234 M non-zeros (mean 76 per row), degrees with a power-law tail, half of a user's
+    friends inside the user's own community (ids nearby), half drawn by popularity.  Returns (n, row_ptr, col_idx, vals) on `device`."""
+    n = max(1024, int(ORKUT["n"] * scale))
+    m = max(4096, int(ORKUT["edges"] * scale))
+    g = _gen(device, ORKUT["seed"])
+    perm = torch.randperm(n, generator=g, device=device)
+    keys = []
+    step = 1 << 25
+    for lo in range(0, m, step):                       # in pieces: the temporaries of 117 M edges at once are several GB
+        k = min(step, m - lo)
+        u = perm[(n * torch.rand(k, generator=g, device=device, dtype=torch.float64) ** 1.65).to(torch.int64).clamp_(0, n - 1)]
+        pop = perm[(n * torch.rand(k, generator=g, device=device, dtype=torch.float64) ** 1.65).to(torch.int64).clamp_(0, n - 1)]
+        e = torch.rand(k, generator=g, device=device, dtype=torch.float64)
+        lap = (20000.0 * torch.sign(e - 0.5) * torch.log1p(-2.0 * (e - 0.5).abs().clamp_(max=0.4999999))).round().to(torch.int64)      # Laplace(0, 20 000)
+        v = torch.where(torch.rand(k, generator=g, device=device) < 0.5, (u - lap).clamp_(0, n - 1), pop)
+        keep = u != v
+        a, b = torch.minimum(u, v)[keep], torch.maximum(u, v)[keep]
+        keys.append(torch.unique(a * n + b))
+        del u, pop, e, lap, v, keep, a, b
+    und = torch.unique(torch.cat(keys))
+    del keys
+    a, b = torch.div(und, n, rounding_mode="floor"), und % n
+    del und
+    key = torch.sort(torch.cat([a * n + b, b * n + a])).values
+    del a, b
+    rp, ci = _csr_from_keys(key, n, device)
+    return n, rp, ci, _pattern_values(len(ci), device, dtype)
+
+
+def wikitalk_like(scale=1.0, device="cpu", dtype=torch.float64):
+    """wiki-Talk's shape: 2.39 M x 2.39 M, ~5.0 M non-zeros; 94 % of the rows are empty, the others' lengths follow a power law up to
+    100 000 (a handful of rows hold a third of the matrix), columns nearly uniform (everybody gets written to once or twice)"""
+    n = max(1024, int(WIKITALK["n"] * scale))
+    nnz = max(4096, int(WIKITALK["nnz"] * scale))
+    g = _gen(device, WIKITALK["seed"])
+    writers = torch.nonzero(torch.rand(n, generator=g, device=device) < 0.06).flatten()
+    k = len(writers)
+    max_deg = max(16, min(int(100_022 * min(1.0, scale * 4)), n // 2))
+    deg = torch.floor((1.0 - torch.rand(k, generator=g, device=device, dtype=torch.float64)) ** (-1.0 / 0.6)).clamp_(1, max_deg)
+    deg = (deg * (nnz * 1.02 / float(deg.sum()))).round().clamp_(1, max_deg).to(torch.int64)
+    rows = torch.repeat_interleave(writers, deg)
+    perm = torch.randperm(n, generator=g, device=device)
+    cols = perm[(n * torch.rand(len(rows), generator=g, device=device, dtype=torch.float64) ** 1.3).to(torch.int64).clamp_(0, n - 1)]
+    key = torch.unique(rows * n + cols)
+    rp, ci = _csr_from_keys(key, n, device)
+    return n, rp, ci, _pattern_values(len(ci), device, dtype)

@@ -396,3 +396,24 @@ def test_loader_fuzz_against_the_pinned_oracle_loader(tmp_path):
         assert np.array_equal(a["row_ptr"], b["rowptr"].astype(np.int64)), ctx
         assert np.array_equal(a["col_idx"], b["cols"]), ctx
         assert np.array_equal(a["vals"].view(np.uint64), b["val"].view(np.uint64)), ctx
+
+
+def test_power_law_stand_ins_have_their_shapes():
+    """the two further SuiteSparse-shaped stand-ins (cvr_amd/synth_dev.py), scaled down, on the CPU: com-Orkut's shape is symmetric
+    without self-loops, wiki-Talk's has ~94 % empty rows and a few rows that hold a large share; rows sorted, no duplicates"""
+    torch = pytest.importorskip("torch")
+    from cvr_amd import synth_dev as D
+    n, rp, ci, va = D.orkut_like(0.004)
+    r = torch.repeat_interleave(torch.arange(n), rp[1:] - rp[:-1])
+    assert torch.equal(torch.sort(r * n + ci).values, torch.sort(ci.to(torch.int64) * n + r).values)      # A == A^T
+    assert not bool((r == ci).any()) and int(rp[-1]) == len(ci) == len(va)
+    key = r * n + ci
+    assert bool((key[1:] > key[:-1]).all())
+    assert 20 < len(ci) / n < 90
+    n, rp, ci, va = D.wikitalk_like(0.05)
+    d = rp[1:] - rp[:-1]
+    assert 0.92 < float((d == 0).float().mean()) < 0.96
+    assert float(torch.sort(d, descending=True).values[:20].sum()) / len(ci) > 0.1
+    key = torch.repeat_interleave(torch.arange(n), d) * n + ci
+    assert bool((key[1:] > key[:-1]).all())
+    assert set(va.unique().tolist()) <= set(float(v) for v in range(13))

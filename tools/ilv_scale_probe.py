@@ -9,7 +9,7 @@ A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, col_panels=P, interleave=1, waves_per_b
 i = A.info
 print("scale", sc, "P", i.col_panels, "S", i.steps_per_chunk, "chunks", i.nchunks, "launches", i.spmv_launches, "tags", i.row_tags16, "wpb", i.waves_per_block, "lds", i.lds_bytes, flush=True)
 x = synth.x_rand(nc)
-y, t = A.spmv(x, iters=5)
+y, t = A.spmv(x, iters=30)
 yref, absy = O.csr_spmv64(rp, ci, va, x)
 bad, worst = O.tol_check(y, yref, absy, tol=1e-12)
 print("bad", len(bad), "worst", worst, "us", t.mean_s * 1e6, flush=True)
