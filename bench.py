@@ -82,6 +82,11 @@ def pmc_fields(info, kernel, workload, nnz):
     return out
 
 
+def capi_row_cost():
+    from cvr_amd import capi
+    return capi.ROW_COST_MILLI_DEFAULT
+
+
 OTHER_WORKLOADS = ("livejournal", "rmat22", "orkut", "wikitalk")      # the power-law shapes beside the headline (north_star: "three SuiteSparse power-law matrices")
 
 
@@ -404,6 +409,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--col-panels", type=int, default=-1, help="column panels (-1 = the library's rule)")
     ap.add_argument("--interleave", type=int, default=-1, help="interleaved chunks (cvr_options.interleave; -1 = the library's rule)")
+    ap.add_argument("--partition", default="cost", choices=["cost", "nnz"], help="row shards balanced by predicted time (non-zeros + 1.25 per row: cvr_row_partition_cost) "
+                    "or by non-zeros alone (the reference's rule)")
     ap.add_argument("--other-workloads", default="auto", help="comma-separated shapes measured beside the headline in the same JSON line (N = 1, headline workload only); "
                     "auto = " + ",".join(OTHER_WORKLOADS) + " within a time box; none = skip")
     ap.add_argument("--two-streams", action="store_true", help="also report the throughput of independent SpMVs alternating on two streams "
@@ -450,6 +457,7 @@ def main():
     device_built = args.workload.startswith("rmat") or args.workload.startswith("banded")
     tune = world > 1 and args.steps_per_chunk == 0 and not os.environ.get("CVR_BENCH_NO_TUNE")
     rp = ci = va = None
+    row_cost = 0 if args.partition == "nnz" else capi_row_cost()
     pworld, prank = world, rank           # the partition the shard belongs to (--emulate-rank: one rank of N on this one GPU)
     if args.emulate_rank:
         if world != 1 or not device_built:
@@ -463,7 +471,7 @@ def main():
             scale = int(args.workload[4:] or 22)
             nrows = ncols = 1 << scale
             deg = D.rmat_row_degrees(scale, device=dev)
-            bounds, grp = D.partition_from_degrees(deg, pworld)
+            bounds, grp = D.partition_from_degrees(deg, pworld, row_cost)
             nnz = int(grp[-1])
             nnz_per = [int(grp[bounds[p + 1]] - grp[bounds[p]]) for p in range(pworld)]
             del deg, grp
@@ -472,7 +480,7 @@ def main():
             f32 = True
         else:
             nrows = ncols = int(float(args.workload[6:] or 3.5e6))
-            bounds, nnz = D.banded_partition(nrows, 13, pworld)
+            bounds, nnz = D.banded_partition(nrows, 13, pworld, row_cost)
             lrp_t, lci_t, lva_t = D.banded_rows(nrows, int(bounds[prank]), int(bounds[prank + 1]), device=dev)
             r = np.arange(nrows, dtype=np.int64)
             pre = np.concatenate([[0], np.cumsum(np.minimum(r, 13) + 1 + np.minimum(nrows - 1 - r, 13))])
@@ -489,7 +497,7 @@ def main():
     else:
         nrows, ncols, rp, ci, va, source = load_host_workload(args.workload)
         nnz = len(ci)
-        bounds = shard.row_partition(rp, world)
+        bounds = shard.row_partition(rp, world, row_cost)
         nnz_per = [int(rp[bounds[p + 1]] - rp[bounds[p]]) for p in range(world)]
         lrows, lrp, lci, lva = shard.local_csr(rp, ci, va, bounds, rank)
         lnnz = int(lrp[-1])

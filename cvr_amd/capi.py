@@ -68,7 +68,7 @@ SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_c
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
            "cvr_tune_steps", "cvr_tune", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat",
            "cvr_source_key_of", "cvr_mm_write_bin_keyed", "cvr_mm_read_bin_keyed", "cvr_mm_read_cached", "cvr_save_image", "cvr_load_image",
-           "cvr_row_partition", "cvr_create_multi", "cvr_preprocess_multi", "cvr_spmv_multi", "cvr_multi_shards", "cvr_multi_info", "cvr_multi_uses_rccl", "cvr_destroy_multi", "cvr_multi_from_handles", "cvr_multi_handle"]
+           "cvr_row_partition", "cvr_row_partition_cost", "cvr_create_multi", "cvr_preprocess_multi", "cvr_spmv_multi", "cvr_multi_shards", "cvr_multi_info", "cvr_multi_uses_rccl", "cvr_destroy_multi", "cvr_multi_from_handles", "cvr_multi_handle"]
 
 
 def lib_path():
@@ -145,6 +145,8 @@ def lib():
         L.cvr_load_image.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.POINTER(SourceKey), C.POINTER(Options), C.POINTER(C.c_double)]
         L.cvr_row_partition.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
         L.cvr_row_partition.restype = C.c_int64
+        L.cvr_row_partition_cost.argtypes = [C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.cvr_row_partition_cost.restype = C.c_int64
         L.cvr_create_multi.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CsrView), C.POINTER(Options), C.c_void_p, C.c_int32]
         L.cvr_preprocess_multi.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.cvr_spmv_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Timing)]
@@ -156,13 +158,17 @@ def lib():
     return _lib
 
 
-def row_partition(row_ptr, nparts):
-    """cvr_row_partition: bounds[nparts + 1] of contiguous row blocks with balanced non-zeros, cut at row boundaries (host only)"""
+ROW_COST_MILLI_DEFAULT = 1250      # include/cvr_amd.h: CVR_ROW_COST_MILLI_DEFAULT
+
+
+def row_partition(row_ptr, nparts, row_cost_milli=0):
+    """cvr_row_partition_cost: bounds[nparts + 1] of contiguous row blocks cut at row boundaries with balanced cost = non-zeros +
+    row_cost_milli / 1000 per row (0: balanced non-zeros, the reference's rule = cvr_row_partition).  Host only."""
     rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
     bounds = np.zeros(nparts + 1, dtype=np.int64)
-    rc = lib().cvr_row_partition(len(rp) - 1, rp.ctypes.data, nparts, bounds.ctypes.data)
+    rc = lib().cvr_row_partition_cost(len(rp) - 1, rp.ctypes.data, nparts, int(row_cost_milli), bounds.ctypes.data)
     if rc < 0:
-        raise CvrError(int(rc), "cvr_row_partition")
+        raise CvrError(int(rc), "cvr_row_partition_cost")
     return bounds
 
 
@@ -338,12 +344,11 @@ class CvrMatrix:
     """One matrix (or row shard) resident on one GPU: cvr_create + cvr_preprocess, then spmv()."""
 
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
-                 xcd_swizzle=-1, x_window=-1, stream_ahead=0, keep_csr=False, debug_col_mask=0, depth=0,
+                 xcd_swizzle=-1, x_window=-1, keep_csr=False, debug_col_mask=0,
                  col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1,
                  row_tags16=-1, row_bands=-1, piece_max=-1, interleave=-1):
         """tune_steps: choose steps_per_chunk by measurement first (cvr_tune_steps; its cost is self.tuning_s).
-        stream_ahead / depth / debug_col_mask are profiling knobs (tools/sweep.py): they travel through the environment
-        (CVR_DEBUG_*), not through cvr_options."""
+        debug_col_mask is a profiling knob (tools/sweep.py): it travels through the environment (CVR_DEBUG_COL_MASK), not through cvr_options."""
         self._h = C.c_void_p()
         self.tuning_s = 0.0
         rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
@@ -358,8 +363,8 @@ class CvrMatrix:
         if nrows > 0 and (len(ci) < rp[-1] or len(va) < rp[-1]):      # the library reads row_ptr[nrows] entries of both
             raise ValueError(f"col_idx / vals hold {len(ci)} / {len(va)} entries, row_ptr[nrows] = {int(rp[-1])}")
         view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
-        self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
-                    debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block, col_phases, hub_table, narrow_cols, hub_reorder,
+        self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, keep_csr,
+                    debug_col_mask, col_panels, value_dict, tune_steps, waves_per_block, col_phases, hub_table, narrow_cols, hub_reorder,
                     row_tags16, row_bands, piece_max, interleave)
 
     def save_image(self, path, key=None):
@@ -405,12 +410,12 @@ class CvrMatrix:
         self.f32 = bool(is_f32)
         self.dtype = np.float32 if self.f32 else np.float64
         view = CsrView(nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, int(self.f32), 1)
-        self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, -1, -1, 0, keep_csr, 0, 0, col_panels, value_dict, tune_steps,
+        self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, -1, -1, keep_csr, 0, col_panels, value_dict, tune_steps,
                     hub_table=hub_table, hub_reorder=hub_reorder, interleave=interleave)
         return self
 
-    def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, stream_ahead, keep_csr,
-               debug_col_mask, depth, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1,
+    def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, keep_csr,
+               debug_col_mask, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1,
                row_tags16=-1, row_bands=-1, piece_max=-1, interleave=-1):
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
@@ -422,7 +427,7 @@ class CvrMatrix:
         # profiling knobs (tools/sweep.py): cvr_create / cvr_tune read them from the environment.  Only a knob the caller passed is
         # touched, and what the environment held before comes back once the handle exists (a value the user exported stays theirs).
         saved = {}
-        for name, val in (("CVR_DEBUG_STREAM_AHEAD", stream_ahead), ("CVR_DEBUG_GATHER_DEPTH", depth), ("CVR_DEBUG_COL_MASK", debug_col_mask)):
+        for name, val in (("CVR_DEBUG_COL_MASK", debug_col_mask),):
             if val:
                 saved[name] = os.environ.get(name)
                 os.environ[name] = str(int(val))

@@ -63,8 +63,6 @@ IOpt make_iopt(const cvr_options *in)
     IOpt o;
     if (in) static_cast<cvr_options &>(o) = *in; else cvr_default_options(&o);
     auto env = [](const char *name) { const char *e = getenv(name); return e ? (int32_t)strtol(e, nullptr, 0) : 0; };
-    o.stream_ahead = env("CVR_DEBUG_STREAM_AHEAD");
-    o.gather_depth = env("CVR_DEBUG_GATHER_DEPTH");
     o.debug_col_mask = env("CVR_DEBUG_COL_MASK");
     return o;
 }
@@ -558,7 +556,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             // table of the most popular columns of its own range, and the chunk plan -- all from device arrays
             const double tp = now_s(), hub0 = in.hub_select_s;
             bool         batched = false;
-            rc = plan_panels_batched(h, dsg.d, nsubs, ncols, f32, popts, pps, drs, &batched);      // (panels without hub tables: all plans as one submission)
+            std::vector<int64_t> pcols((size_t)P);
+            for (int p = 0; p < P; p++) pcols[(size_t)p] = part_cols(p);
+            rc = plan_panels_batched(h, dsg.d, nsubs, pcols, f32, popts, pps, drs, &batched);      // (panels without hub tables: all plans as one submission)
             if (rc) { cvr_destroy(h); return rc; }
             for (int p = 0; p < P && !batched; p++) {
                 Part         &part = h->parts[(size_t)p];
@@ -750,7 +750,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     }
     if (!h->z_free && in.hub_entries) CREATE_TRY(hipEventCreateWithFlags(&h->z_free, hipEventDisableTiming));
     in.steps_per_chunk = h->parts[0].img.S;
-    in.col_phases = (int32_t)h->parts[0].img.phases; in.waves_per_block = (int32_t)h->parts[0].img.wpb; in.x_window = (int32_t)h->parts[0].img.win_elems;
+    in.col_phases = h->parts[0].img.ilv ? 1 : (int32_t)h->parts[0].img.phases;      // (an interleaved image is planned like one with phases, but has none)
+    in.waves_per_block = (int32_t)h->parts[0].img.wpb; in.x_window = (int32_t)h->parts[0].img.win_elems;
     in.lds_bytes = (int32_t)cvr::spmv_lds_bytes(h->parts[0].img);
     in.narrow_cols = h->parts[0].img.c16 ? 1 : 0;
     in.hub_reorder = h->parts[0].img.order_n ? 1 : 0;
@@ -820,15 +821,20 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     // that counting and filling are one kernel per chunk and the conversion follows without the host in between; the images of a
     // handle (column panels) are converted one after the other and share the table, sized for the largest
     size_t seg_n1 = 0, seg_chunks = 0;
-    size_t ilv_scratch = 0;          // interleaved images: the segmented sort's buffers, sized for the largest part and shared
+    int64_t ilv_nnz = 0;             // interleaved images: converted together behind the loop (one sort over all their non-zeros)
+    bool    any_ilv = false;
     for (const Part &p : h->parts)
-        if (p.img.ilv) ilv_scratch = std::max(ilv_scratch, cvr::convert_interleaved_scratch(p.nnz, (uint32_t)p.nchunks));
+        if (p.img.ilv) { ilv_nnz += p.nnz; any_ilv = true; }
         else if (p.img.phases > 1 && p.nchunks > 0) {
             seg_n1 = std::max(seg_n1, (size_t)p.nchunks * (size_t)cvr::kLanes * (size_t)p.img.S);
             seg_chunks = std::max(seg_chunks, (size_t)p.nchunks);
         }
     struct IlvGuard { void *p = nullptr; ~IlvGuard() { (void)hipFree(p); } } ilv;
+    const size_t ilv_scratch = any_ilv ? cvr::convert_interleaved_scratch(ilv_nnz, 0) : 0;
     if (ilv_scratch) HIP_TRY(hipMalloc(&ilv.p, ilv_scratch));
+    std::vector<const cvr::DeviceImage *> ilv_imgs;
+    std::vector<cvr::DeviceCsr>           ilv_csrs;
+    std::vector<int64_t>                  ilv_n0, ilv_n1;
     const bool phased = seg_n1 > 0;
     if (phased) {
         cvr::SegTable &t = sg.t;
@@ -856,7 +862,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
         csr.row_ptr = p.d_rp; csr.col_idx = p.d_ci; csr.vals = p.d_va; csr.nz_begin = p.d_nzb; csr.pad_cnt = p.d_pad;
         if (wstream != h->stream) HIP_TRY(cvr::launch_window(p.img, csr, wstream));
         if (p.img.ilv) {
-            HIP_TRY(cvr::launch_convert_interleaved(p.img, csr, p.nnz_span - p.nnz, p.nnz_span, h->d_err, ilv.p, ilv_scratch, h->stream));
+            if (p.nchunks > 0) { ilv_imgs.push_back(&p.img); ilv_csrs.push_back(csr); ilv_n0.push_back(p.nnz_span - p.nnz); ilv_n1.push_back(p.nnz_span); }
         } else if (p.img.phases > 1 && p.nchunks > 0) {
             cvr::SegTable &t = sg.t;
             if (h->d_dict && cvr::seg_table_packed_ok(p.img) && !getenv("CVR_NO_DICT_CODES")) {      // the values as dictionary codes first: the converter then reads a byte per value (cvr_convert.hip: convert_lds_kernel)
@@ -873,6 +879,15 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
             HIP_TRY(cvr::launch_convert(p.img, csr, h->d_err, h->stream));
         }
         if (wstream == h->stream) HIP_TRY(cvr::launch_window(p.img, csr, h->stream));
+    }
+    if (!ilv_imgs.empty()) {
+        // groups of up to 64 images with equal layout parameters (the panels of one matrix: one group)
+        for (size_t i0 = 0; i0 < ilv_imgs.size();) {
+            size_t i1 = i0 + 1;
+            while (i1 < ilv_imgs.size() && i1 - i0 < 64 && ilv_imgs[i1]->G == ilv_imgs[i0]->G && ilv_imgs[i1]->tag16 == ilv_imgs[i0]->tag16 && ilv_imgs[i1]->col_bits == ilv_imgs[i0]->col_bits) i1++;
+            HIP_TRY(cvr::launch_convert_interleaved(ilv_imgs.data() + i0, ilv_csrs.data() + i0, ilv_n0.data() + i0, ilv_n1.data() + i0, (int)(i1 - i0), h->d_err, ilv.p, ilv_scratch, h->stream));
+            i0 = i1;
+        }
     }
     HIP_TRY(hipEventRecord(e1, h->stream));
     uint32_t err = 0;

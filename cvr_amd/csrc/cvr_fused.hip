@@ -32,9 +32,8 @@ struct Attempt {
     ~Attempt()
     {
         if (keep) return;
-        for (void *p : {(void *)img.stream, (void *)img.desc, (void *)img.desc2, (void *)img.target, (void *)img.win_base, (void *)img.pace, (void *)d_nzb, (void *)d_pad, arena, d_dict, (void *)d_codes})
+        for (void *p : {(void *)img.stream, (void *)img.desc, (void *)img.desc2, (void *)img.target, (void *)img.win_base, (void *)d_nzb, (void *)d_pad, arena, d_dict, (void *)d_codes})
             if (p) (void)hipFree(p);
-        delete img.pace_epoch;
     }
 };
 

@@ -24,118 +24,186 @@
 namespace cvr {
 namespace {
 
-__global__ __launch_bounds__(256) void ilv_prepare_kernel(const int64_t *__restrict__ nzb, uint32_t nchunks, uint32_t *__restrict__ off32, int64_t n0, int64_t n1,
-                                                          uint32_t *__restrict__ idx, uint2 *__restrict__ desc2)
+constexpr int kIlvMaxParts = 64;
+// what the kernels need of one image; the images of a handle (column panels) are converted together: one sort, one pass that writes
+struct IlvPartDev {
+    uint8_t       *stream;
+    const uint4   *desc;
+    uint2         *desc2;
+    const int64_t *nzb, *rp;
+    const int32_t *ci;
+    const void    *vals;
+    int64_t        n0;          // the part's first position in its CSR arrays
+    int64_t        e0;          // where its elements start in the concatenated key array
+    uint32_t       nchunks, chunk0;      // its chunks are numbered chunk0 .. chunk0 + nchunks - 1 over all parts
+    uint32_t       pad_col, col_base;
+};
+struct IlvTable { IlvPartDev part[kIlvMaxParts]; int64_t e_end[kIlvMaxParts]; uint32_t chunk_end[kIlvMaxParts]; uint32_t nparts; };
+
+__device__ __forceinline__ uint32_t part_of_chunk(const IlvTable *__restrict__ t, uint32_t kk)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = t; i <= (int64_t)nchunks; i += nt) off32[i] = (uint32_t)(nzb[i] - n0);
-    for (int64_t i = t; i < (int64_t)nchunks; i += nt) desc2[i].x = (uint32_t)((nzb[i + 1] - nzb[i] + 255) / 256);      // the groups that hold non-zeros (the SpMV kernel stops there)
-    for (int64_t j = n0 + t; j < n1; j += nt) idx[j - n0] = (uint32_t)(j - n0);
+    uint32_t p = 0;
+    while (p + 1 < t->nparts && t->chunk_end[p] <= kk) p++;
+    return p;
 }
 
-// one workgroup per group of 256 slots: thread t writes the slot of lane t & 63 at step t >> 6 of the group
-template <typename T, bool DICT, bool TAG>
-__global__ __launch_bounds__(256) void ilv_emit_kernel(uint8_t *__restrict__ stream, const uint4 *__restrict__ desc, const uint2 *__restrict__ desc2, const int64_t *__restrict__ nzb,
-                                                       const int64_t *__restrict__ rp, const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sidx, const T *__restrict__ vals,
-                                                       const uint8_t *__restrict__ codes, const T *__restrict__ dict, uint32_t ndict, int G, int64_t n0, uint32_t pad_col, uint32_t col_bits,
-                                                       uint32_t col_base, uint32_t *__restrict__ err)
+// key = chunk (numbered over all parts) << cbits | column inside the image (relative to col_base), value = position in the concatenation:
+// one stable radix sort over these keys sorts every chunk's non-zeros by column (ties: by position, i.e. by row), the chunks staying in
+// place.  One workgroup per chunk (its part and number are the workgroup's: no search per element).  Also desc2[k].x = the groups of
+// chunk k that hold non-zeros (the SpMV kernel stops there).
+template <typename K>
+__global__ __launch_bounds__(256) void ilv_keys_kernel(const IlvTable *__restrict__ t, uint32_t cbits, K *__restrict__ key, uint32_t *__restrict__ idx)
+{
+    const uint32_t    kk = blockIdx.x;
+    const IlvPartDev &q = t->part[part_of_chunk(t, kk)];
+    const uint32_t    k = kk - q.chunk0;
+    const int64_t     b = q.nzb[k], n = q.nzb[k + 1] - b, E0 = q.e0 + (b - q.n0);
+    if (threadIdx.x == 0) q.desc2[k].x = (uint32_t)((n + 255) / 256);
+    const K hi = (K)kk << cbits;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        key[E0 + i] = hi | (K)((uint32_t)q.ci[b + i] - q.col_base);
+        idx[E0 + i] = (uint32_t)(E0 + i);
+    }
+}
+
+// One workgroup per chunk: the starts of the chunk's rows (relative to its first position, clipped to the chunk) go to LDS once, then the
+// threads walk the chunk's slots -- thread t of a group of 256 slots writes lane t & 63 at step t >> 6 -- and find the row of an element
+// by a search in LDS.
+constexpr int kEmitThreads = 1024;
+template <typename T, bool DICT, bool TAG, typename K>
+__global__ __launch_bounds__(kEmitThreads) void ilv_emit_kernel(const IlvTable *__restrict__ t, const K *__restrict__ skey, const uint32_t *__restrict__ sidx, const T *__restrict__ dict,
+                                                                uint32_t ndict, int G, uint32_t col_bits, uint32_t cbits, uint32_t *__restrict__ err)
 {
     constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
     constexpr uint32_t VB = kColsBytes + (TAG ? kTagBytes : 0);
-    const uint32_t k = blockIdx.x / (uint32_t)G, g = blockIdx.x - k * (uint32_t)G;
-    const uint32_t lane = threadIdx.x & 63u, j = threadIdx.x >> 6;
-    const int64_t  b = nzb[k], n = nzb[k + 1] - b;
-    const int64_t  e = (int64_t)g * 256 + (int64_t)j * 64 + lane;
-    const uint32_t row_first = desc[k].x, nri = desc2[k].y;
-    uint32_t col = pad_col, row = nri;
-    T        v = T(0);
-    uint32_t code = 0;
-    if (e < n) {
-        const int64_t p = n0 + (int64_t)sidx[b - n0 + e];         // position in the part's CSR arrays
-        col = skey[b - n0 + e] - col_base;                         // (a column panel keeps its columns relative to its first)
-        // the chunk's row of position p: the last of its rows that starts at or before p (a row cut over chunks begins before the chunk)
-        uint32_t lo = 0, hi = nri;                                // answer in [0, nri)
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (rp[row_first + mid] <= p) lo = mid; else hi = mid;
-        }
-        row = lo;
-        if constexpr (DICT) {
-            if (codes) code = codes[p];
-            else {
-                const T   val = vals[p];
-                uint32_t  a = 0, z = ndict;                        // the dictionary is sorted by bit pattern
+    extern __shared__ uint32_t rstart[];                         // [nri]: where row i of the chunk starts among the chunk's elements
+    const uint32_t    kk = blockIdx.x;
+    const IlvPartDev &q = t->part[part_of_chunk(t, kk)];
+    const uint32_t    k = kk - q.chunk0;
+    const int64_t     b = q.nzb[k], n = q.nzb[k + 1] - b;
+    const uint32_t    row_first = q.desc[k].x, nri = q.desc2[k].y;
+    const int64_t     E0 = q.e0 + (b - q.n0);                    // the chunk's first element in the sorted arrays
+    for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
+        const int64_t r = q.rp[row_first + i] - b;               // (a row cut over chunks begins before the chunk)
+        rstart[i] = (uint32_t)(r < 0 ? 0 : r > n ? n : r);
+    }
+    __syncthreads();
+    uint32_t code0 = 0;                                           // the code of +0.0 (cvr_create puts it into every dictionary)
+    if constexpr (DICT) {
+        typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type U;
+        while (code0 < ndict && __builtin_bit_cast(U, dict[code0]) != (U)0) code0++;
+        if (code0 >= ndict) { if (threadIdx.x == 0) atomicOr(err, 4u); code0 = 0; }
+    }
+    const int64_t nslots = (int64_t)G * 256;
+    for (int64_t e = threadIdx.x; e < nslots; e += blockDim.x) {
+        const uint32_t g = (uint32_t)(e >> 8), j = (uint32_t)(e >> 6) & 3u, lane = (uint32_t)e & 63u;
+        uint32_t col = q.pad_col, row = nri, code = code0;
+        T        v = T(0);
+        if (e < n) {
+            const uint32_t pe = (uint32_t)((int64_t)sidx[E0 + e] - E0);      // the element's place among the chunk's, in CSR order
+            col = (uint32_t)(skey[E0 + e] & (((K)1 << cbits) - 1));          // (relative to the image's first column)
+            uint32_t lo = 0, hi = nri;                                        // its row: the last one that starts at or before it
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rstart[mid] <= pe) lo = mid; else hi = mid; }
+            row = lo;
+            const T val = static_cast<const T *>(q.vals)[b + pe];
+            if constexpr (DICT) {
+                uint32_t a = 0, z = ndict;                                    // the dictionary is sorted by bit pattern
                 typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type U;
-                const U   bits = __builtin_bit_cast(U, val);
+                const U  bits = __builtin_bit_cast(U, val);
                 while (a < z) { const uint32_t m = (a + z) >> 1; if (__builtin_bit_cast(U, dict[m]) < bits) a = m + 1; else z = m; }
                 if (a >= ndict || __builtin_bit_cast(U, dict[a]) != bits) { atomicOr(err, 4u); a = 0; }
                 code = a;
-            }
-        } else v = vals[p];
-    } else if constexpr (DICT) {
-        // the code of +0.0 (cvr_create puts it into every dictionary)
-        uint32_t a = 0;
-        typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type U;
-        while (a < ndict && __builtin_bit_cast(U, dict[a]) != (U)0) a++;
-        if (a >= ndict) { atomicOr(err, 4u); a = 0; }
-        code = a;
+            } else v = val;
+        }
+        uint8_t *grp = q.stream + ((size_t)k * G + g) * GB;
+        uint32_t cw = col | kEndBit;
+        if constexpr (!TAG) cw |= row << col_bits;
+        reinterpret_cast<uint32_t *>(grp)[lane * 4 + j] = cw;
+        if constexpr (TAG) reinterpret_cast<uint16_t *>(grp + kColsBytes)[lane * 4 + j] = (uint16_t)row;
+        if constexpr (DICT) (grp + VB)[lane * 4 + j] = (uint8_t)code;
+        else if constexpr (sizeof(T) == 8) reinterpret_cast<double *>(grp + VB + (j >> 1) * (kLanes * 16))[lane * 2 + (j & 1)] = v;
+        else reinterpret_cast<float *>(grp + VB)[lane * 4 + j] = v;
     }
-    uint8_t *grp = stream + ((size_t)k * G + g) * GB;
-    uint32_t cw = col | kEndBit;
-    if constexpr (!TAG) cw |= row << col_bits;
-    reinterpret_cast<uint32_t *>(grp)[lane * 4 + j] = cw;
-    if constexpr (TAG) reinterpret_cast<uint16_t *>(grp + kColsBytes)[lane * 4 + j] = (uint16_t)row;
-    if constexpr (DICT) (grp + VB)[lane * 4 + j] = (uint8_t)code;
-    else if constexpr (sizeof(T) == 8) reinterpret_cast<double *>(grp + VB + (j >> 1) * (kLanes * 16))[lane * 2 + (j & 1)] = v;
-    else reinterpret_cast<float *>(grp + VB)[lane * 4 + j] = v;
 }
 
-}  // namespace
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline uint32_t bits_of(uint64_t v) { uint32_t b = 1; while (b < 63 && ((uint64_t)1 << b) <= v) b++; return b; }      // bits that hold 0 .. v
 
-size_t convert_interleaved_scratch(int64_t nnz, uint32_t nchunks)
+template <typename K> size_t sort_bytes(int64_t nnz)
 {
     size_t tmp = 0;
-    (void)hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                                      (int)std::max<int64_t>(nnz, 1), (int)std::max<uint32_t>(nchunks, 1), (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 32, nullptr);
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    return up(tmp) + 3 * up(sizeof(uint32_t) * (size_t)std::max<int64_t>(nnz, 1)) + up(sizeof(uint32_t) * ((size_t)nchunks + 1)) + 256;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const K *)nullptr, (K *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (unsigned int)std::max<int64_t>(nnz, 1), 0, (int)sizeof(K) * 8, nullptr);
+    return tmp;
 }
 
-// scratch: convert_interleaved_scratch(nnz of the part, nchunks) bytes of device memory
-hipError_t launch_convert_interleaved(const DeviceImage &img, const DeviceCsr &csr, int64_t n0, int64_t n1, uint32_t *err_flag, void *scratch, size_t scratch_bytes, hipStream_t st)
+template <typename K>
+hipError_t convert_t(const IlvTable &tab, int64_t ntot, uint32_t nchunks_tot, const DeviceImage &common, uint32_t ystage_max, uint32_t cbits, uint32_t kbits, uint32_t *err_flag, uint8_t *a, size_t scratch_bytes, hipStream_t st)
 {
-    if (img.nchunks == 0) return hipSuccess;
-    const int64_t nnz = n1 - n0;
-    if (nnz >= (int64_t)0x7fffffff) return hipErrorInvalidValue;
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t tmp = 0;
-    hipError_t e = hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                                               (int)std::max<int64_t>(nnz, 1), (int)img.nchunks, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0, 32, st);
-    if (e != hipSuccess) return e;
-    const size_t nn = up(sizeof(uint32_t) * (size_t)std::max<int64_t>(nnz, 1));
-    if (up(tmp) + 3 * nn + up(sizeof(uint32_t) * ((size_t)img.nchunks + 1)) > scratch_bytes) return hipErrorInvalidValue;
-    uint8_t  *a = static_cast<uint8_t *>(scratch);
+    const size_t nk = up256(sizeof(K) * (size_t)std::max<int64_t>(ntot, 1)), nv = up256(sizeof(uint32_t) * (size_t)std::max<int64_t>(ntot, 1));
+    size_t       tmp = sort_bytes<K>(ntot);
+    if (up256(sizeof(IlvTable)) + up256(tmp) + 2 * nk + 2 * nv > scratch_bytes) return hipErrorInvalidValue;
+    IlvTable *d_tab = reinterpret_cast<IlvTable *>(a);
+    a += up256(sizeof(IlvTable));
     void     *d_tmp = a;
-    uint32_t *idx = reinterpret_cast<uint32_t *>(a + up(tmp)), *skey = reinterpret_cast<uint32_t *>(a + up(tmp) + nn), *sidx = reinterpret_cast<uint32_t *>(a + up(tmp) + 2 * nn),
-             *off32 = reinterpret_cast<uint32_t *>(a + up(tmp) + 3 * nn);
-    const uint32_t pb = (uint32_t)std::min<int64_t>(4096, (std::max<int64_t>(nnz, (int64_t)img.nchunks + 1) + 255) / 256);
-    hipLaunchKernelGGL(ilv_prepare_kernel, dim3(std::max(pb, 1u)), dim3(256), 0, st, csr.nz_begin, img.nchunks, off32, (long long)n0, (long long)n1, idx, img.desc2);
+    K        *key = reinterpret_cast<K *>(a + up256(tmp)), *skey = reinterpret_cast<K *>(a + up256(tmp) + nk);
+    uint32_t *idx = reinterpret_cast<uint32_t *>(a + up256(tmp) + 2 * nk), *sidx = reinterpret_cast<uint32_t *>(a + up256(tmp) + 2 * nk + nv);
+    hipError_t e = hipMemcpyAsync(d_tab, &tab, sizeof(IlvTable), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ilv_keys_kernel<K>, dim3(nchunks_tot), dim3(256), 0, st, d_tab, cbits, key, idx);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (nnz > 0) {
-        int bits = 1;
-        while (bits < 32 && (1ull << bits) <= (unsigned long long)img.col_base + img.pad_col) bits++;
-        e = hipcub::DeviceSegmentedRadixSort::SortPairs(d_tmp, tmp, reinterpret_cast<const uint32_t *>(csr.col_idx + n0), skey, idx, sidx, (int)nnz, (int)img.nchunks, off32, off32 + 1, 0, bits, st);
+    if (ntot > 0) {
+        e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp, key, skey, idx, sidx, (unsigned int)ntot, 0, (int)(cbits + kbits), st);      // stable: ties keep their positions' order
         if (e != hipSuccess) return e;
     }
-    const dim3 grid(img.nchunks * (uint32_t)img.G), block(256);
-    const bool dict = img.dict != nullptr;
+    const dim3   grid(nchunks_tot), block(kEmitThreads);
+    const size_t lds = sizeof(uint32_t) * (size_t)std::max<uint32_t>(ystage_max, 1u);      // (the rows of a chunk fit its accumulators: ystage - 1 at most)
+    const bool   dict = common.dict != nullptr;
 #define CVR_ILV(T, DI, TG)                                                                                                                           \
-    hipLaunchKernelGGL((ilv_emit_kernel<T, DI, TG>), grid, block, 0, st, img.stream, img.desc, img.desc2, csr.nz_begin, csr.row_ptr, skey, sidx, static_cast<const T *>(csr.vals), \
-                       csr.codes, static_cast<const T *>(img.dict), img.ndict, img.G, (long long)n0, img.pad_col, img.col_bits, img.col_base, err_flag)
-    if (img.f32) { if (dict) { if (img.tag16) CVR_ILV(float, true, true); else CVR_ILV(float, true, false); } else { if (img.tag16) CVR_ILV(float, false, true); else CVR_ILV(float, false, false); } }
-    else { if (dict) { if (img.tag16) CVR_ILV(double, true, true); else CVR_ILV(double, true, false); } else { if (img.tag16) CVR_ILV(double, false, true); else CVR_ILV(double, false, false); } }
+    hipLaunchKernelGGL((ilv_emit_kernel<T, DI, TG, K>), grid, block, lds, st, d_tab, skey, sidx, static_cast<const T *>(common.dict), common.ndict, common.G, common.col_bits, cbits, err_flag)
+    if (common.f32) { if (dict) { if (common.tag16) CVR_ILV(float, true, true); else CVR_ILV(float, true, false); } else { if (common.tag16) CVR_ILV(float, false, true); else CVR_ILV(float, false, false); } }
+    else { if (dict) { if (common.tag16) CVR_ILV(double, true, true); else CVR_ILV(double, true, false); } else { if (common.tag16) CVR_ILV(double, false, true); else CVR_ILV(double, false, false); } }
 #undef CVR_ILV
     return hipGetLastError();
+}
+}  // namespace
+
+// device scratch of a conversion of `nnz` non-zeros in all (room for either key width: which one is decided at conversion time)
+size_t convert_interleaved_scratch(int64_t nnz, uint32_t nchunks)
+{
+    (void)nchunks;
+    const size_t n = (size_t)std::max<int64_t>(nnz, 1);
+    return up256(sizeof(IlvTable)) + up256(std::max(sort_bytes<uint32_t>(nnz), sort_bytes<uint64_t>(nnz))) + 2 * up256(sizeof(uint64_t) * n) + 2 * up256(sizeof(uint32_t) * n) + 256;
+}
+
+// The interleaved images imgs[0 .. n) (all of one handle: same chunk length, value type, dictionary, tag width and row field) converted
+// together -- one sort over all their non-zeros, one pass that writes all their groups; csrs[i], [n0[i], n1[i]) = image i's CSR arrays and
+// positions.  scratch: convert_interleaved_scratch(sum of the non-zeros, ..) bytes.  *err_flag bit 2: a value that is not in the dictionary.
+hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const DeviceCsr *csrs, const int64_t *n0, const int64_t *n1, int n, uint32_t *err_flag, void *scratch,
+                                      size_t scratch_bytes, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    if (n > kIlvMaxParts) return hipErrorInvalidValue;
+    IlvTable tab;
+    memset(&tab, 0, sizeof(tab));
+    int64_t  e = 0;
+    uint32_t c = 0, pad_max = 0, ystage_max = 0;
+    for (int i = 0; i < n; i++) {
+        const DeviceImage &g = *imgs[i];
+        if (g.G != imgs[0]->G || g.f32 != imgs[0]->f32 || g.dict != imgs[0]->dict || g.tag16 != imgs[0]->tag16 || g.col_bits != imgs[0]->col_bits) return hipErrorInvalidValue;
+        IlvPartDev &q = tab.part[i];
+        q.stream = g.stream; q.desc = g.desc; q.desc2 = g.desc2; q.nzb = csrs[i].nz_begin; q.rp = csrs[i].row_ptr; q.ci = csrs[i].col_idx; q.vals = csrs[i].vals;
+        q.n0 = n0[i]; q.e0 = e; q.nchunks = g.nchunks; q.chunk0 = c; q.pad_col = g.pad_col; q.col_base = g.col_base;
+        e += n1[i] - n0[i]; c += g.nchunks;
+        tab.e_end[i] = e; tab.chunk_end[i] = c;
+        pad_max = std::max(pad_max, g.pad_col);
+        ystage_max = std::max(ystage_max, g.ystage);
+    }
+    tab.nparts = (uint32_t)n;
+    if (c == 0) return hipSuccess;
+    if (e >= (int64_t)0xffffffffll) return hipErrorInvalidValue;        // positions in the concatenation are 32-bit
+    const uint32_t cbits = bits_of(pad_max), kbits = bits_of(c - 1);
+    if (cbits + kbits <= 32) return convert_t<uint32_t>(tab, e, c, *imgs[0], ystage_max, cbits, kbits, err_flag, static_cast<uint8_t *>(scratch), scratch_bytes, st);
+    return convert_t<uint64_t>(tab, e, c, *imgs[0], ystage_max, cbits, kbits, err_flag, static_cast<uint8_t *>(scratch), scratch_bytes, st);
 }
 
 }  // namespace cvr

@@ -11,14 +11,14 @@ using namespace cvrh;
 namespace {
 
 constexpr uint64_t kImgMagic = 0x3130474d49525643ull;      // "CVRIMG01"
-constexpr uint32_t kImgVersion = 7;                        // bump when DeviceImage / the handle's tables change
+constexpr uint32_t kImgVersion = 8;                        // bump when DeviceImage / the handle's tables change
 
 struct ImgKey {
     uint64_t       magic;
     uint32_t       version, vsz;
     cvr_source_key source;
     int64_t        opt[20];          // the options, field by field (no padding bytes in the key)
-    int32_t        cus, xcds, stream_ahead, gather_depth;
+    int32_t        cus, xcds, reserved[2];
     char           lib[48];
 };
 
@@ -77,14 +77,14 @@ void make_key(ImgKey &k, const cvr_source_key *src, const IOpt &o, size_t vsz)
                           o.col_phases, o.hub_table, o.narrow_cols, o.hub_reorder, o.row_tags16, o.piece_max, o.debug_col_mask, o.interleave};
     static_assert(sizeof(ov) <= sizeof(k.opt), "options fit the key");
     memcpy(k.opt, ov, sizeof(ov));
-    k.cus = o.cus; k.xcds = o.xcds; k.stream_ahead = o.stream_ahead; k.gather_depth = o.gather_depth;
+    k.cus = o.cus; k.xcds = o.xcds;
     snprintf(k.lib, sizeof(k.lib), "%s", cvr_version());
 }
 
 // the scalar part of a DeviceImage (everything but its pointers), field by field so that the file does not depend on the struct's layout
 struct ImgScalars {
-    int32_t  S, G, f32, xcd_swizzle, stream_ahead, depth, c16, tag16;
-    uint32_t nchunks, nrows, pad_col, nshared, ystage, ndict, persist_waves, wpb, win_elems, col_mask, phases, phase_width, col_bits, piece_max, hub_n, order_n, ncus, has_pace;
+    int32_t  S, G, f32, xcd_swizzle, c16, tag16;
+    uint32_t nchunks, nrows, pad_col, nshared, ystage, ndict, wpb, win_elems, col_mask, phases, phase_width, col_bits, piece_max, hub_n, order_n, ncus;
     int64_t  part_nrows, part_nnz, part_nnz_span, part_nchunks, part_nshared, part_yext, part_zoff;
     uint64_t stream_bytes;
     int32_t  multi_slot, ilv;      // where the panel stands in the rounds of eight (-1: none)
@@ -121,10 +121,10 @@ int cvr_save_image(cvr_handle *h, const char *path, const cvr_source_key *key)
         const cvr::DeviceImage &g = p.img;
         ImgScalars s;
         memset(&s, 0, sizeof(s));
-        s.S = g.S; s.G = g.G; s.f32 = g.f32; s.xcd_swizzle = g.xcd_swizzle; s.stream_ahead = g.stream_ahead; s.depth = g.depth; s.c16 = g.c16; s.tag16 = g.tag16;
-        s.nchunks = g.nchunks; s.nrows = g.nrows; s.pad_col = g.pad_col; s.nshared = g.nshared; s.ystage = g.ystage; s.ndict = g.ndict; s.persist_waves = g.persist_waves;
+        s.S = g.S; s.G = g.G; s.f32 = g.f32; s.xcd_swizzle = g.xcd_swizzle; s.c16 = g.c16; s.tag16 = g.tag16;
+        s.nchunks = g.nchunks; s.nrows = g.nrows; s.pad_col = g.pad_col; s.nshared = g.nshared; s.ystage = g.ystage; s.ndict = g.ndict;
         s.wpb = g.wpb; s.win_elems = g.win_elems; s.col_mask = g.col_mask; s.phases = g.phases; s.phase_width = g.phase_width; s.col_bits = g.col_bits;
-        s.piece_max = g.piece_max; s.hub_n = g.hub_n; s.order_n = g.order_n; s.ncus = g.ncus; s.has_pace = g.pace ? 1u : 0u;
+        s.piece_max = g.piece_max; s.hub_n = g.hub_n; s.order_n = g.order_n; s.ncus = g.ncus;
         s.part_nrows = p.nrows; s.part_nnz = p.nnz; s.part_nnz_span = p.nnz_span; s.part_nchunks = p.nchunks; s.part_nshared = p.nshared; s.part_yext = p.yext; s.part_zoff = p.zoff;
         s.stream_bytes = p.stream_bytes;
         s.multi_slot = p.multi_slot; s.ilv = g.ilv ? 1 : 0; s.col_base = g.col_base;
@@ -214,8 +214,8 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         r.pod(s);
         LOAD_TRY(hipSuccess);
         cvr::DeviceImage &g = p.img;
-        g.S = s.S; g.G = s.G; g.f32 = s.f32 != 0; g.xcd_swizzle = s.xcd_swizzle; g.stream_ahead = s.stream_ahead; g.depth = s.depth; g.c16 = s.c16 != 0; g.tag16 = s.tag16 != 0;
-        g.nchunks = s.nchunks; g.nrows = s.nrows; g.pad_col = s.pad_col; g.nshared = s.nshared; g.ystage = s.ystage; g.ndict = s.ndict; g.persist_waves = s.persist_waves;
+        g.S = s.S; g.G = s.G; g.f32 = s.f32 != 0; g.xcd_swizzle = s.xcd_swizzle; g.c16 = s.c16 != 0; g.tag16 = s.tag16 != 0;
+        g.nchunks = s.nchunks; g.nrows = s.nrows; g.pad_col = s.pad_col; g.nshared = s.nshared; g.ystage = s.ystage; g.ndict = s.ndict;
         g.wpb = s.wpb; g.win_elems = s.win_elems; g.col_mask = s.col_mask; g.phases = s.phases; g.phase_width = s.phase_width; g.col_bits = s.col_bits;
         g.piece_max = s.piece_max; g.hub_n = s.hub_n; g.order_n = s.order_n; g.ncus = s.ncus;
         p.nrows = s.part_nrows; p.nnz = s.part_nnz; p.nnz_span = s.part_nnz_span; p.nchunks = s.part_nchunks; p.nshared = s.part_nshared; p.yext = s.part_yext; p.zoff = s.part_zoff;
@@ -250,11 +250,6 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         LOAD_TRY(r.dev(g.hub_cols, pinned, pinned_bytes, h->stream, sizeof(int32_t) * (uint64_t)(g.order_n ? g.order_n : g.hub_n), g.hub_n == 0));
         if (g.hub_n && !g.hub_cols) { r.ok = false; LOAD_TRY(hipSuccess); }
         if (g.hub_n) LOAD_TRY(hipMalloc(&g.hub_x, vsz * (g.order_n ? ((size_t)g.order_n + 8) : ((g.hub_n + 3u) & ~3u))));
-        if (s.has_pace) {
-            LOAD_TRY(hipMalloc(&g.pace, sizeof(uint32_t) * cvr::pace_words(g.phases)));
-            LOAD_TRY(hipMemsetAsync(g.pace, 0, sizeof(uint32_t) * cvr::pace_words(g.phases), h->stream));
-            g.pace_epoch = new uint32_t(0);
-        }
         ztotal = std::max<int64_t>(ztotal, p.zoff + p.yext);
     }
     if (h->paneled()) {

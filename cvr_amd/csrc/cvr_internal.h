@@ -77,8 +77,6 @@ inline double now_s()
 // cvr_options plus what cvr_create decides on the way and the profiling knobs it reads from the environment
 struct IOpt : cvr_options {
     int32_t layout_auto_resident = 0;      // the automatic layout chose the "resident" form: every workgroup on a CU of its own at once
-    int32_t stream_ahead = 0;              // CVR_DEBUG_STREAM_AHEAD: groups the matrix stream runs ahead of the x gather: 0 / 1 = one, >= 2 = three
-    int32_t gather_depth = 0;              // CVR_DEBUG_GATHER_DEPTH: groups the x gather runs ahead of the FMAs: 1 or 2
     int32_t debug_col_mask = 0;            // CVR_DEBUG_COL_MASK: folds the gather onto a 2^k-entry table (timing only: wrong y)
     int32_t panel_on_one_xcd = 0;          // this image is a column panel that will run on the workgroups of one XCD (run_spmv, d_multi)
     int32_t cus = 256, xcds = 8;           // the device's geometry (chip_of)
@@ -118,8 +116,6 @@ struct Part {
         if (img.shared) (void)hipFree(img.shared);
         if (img.win_base) (void)hipFree(img.win_base);
         if (img.desc2) (void)hipFree(img.desc2);
-        if (img.pace) (void)hipFree(img.pace);
-        delete img.pace_epoch;
         if (img.cbase) (void)hipFree(img.cbase);
         if (img.hub_cols) (void)hipFree(img.hub_cols);
         if (img.hub_index) (void)hipFree(img.hub_index);
@@ -244,7 +240,7 @@ int        auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, 
                        const std::function<int(const IOpt &)> *meanwhile = nullptr);
 int        choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, IOpt &opt, PartPlan &pp,
                        bool allow_reorder);
-int        plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vector<int64_t> &nsubs, int64_t ncols, bool f32, const std::vector<IOpt> &popts,
+int        plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vector<int64_t> &nsubs, const std::vector<int64_t> &pcols, bool f32, const std::vector<IOpt> &popts,
                                std::vector<PartPlan> &pps, std::vector<DevRows> &drs, bool *done);
 int        build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *ci, const void *va,
                       hipMemcpyKind civa_kind, bool f32, const IOpt &opt, double *plan_s, PartPlan *planned = nullptr, const DevRows *dr = nullptr);

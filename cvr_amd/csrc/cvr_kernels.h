@@ -21,12 +21,9 @@ struct DeviceImage {
     uint32_t nshared = 0;
     uint32_t ncus = 256;            // CUs of the device (hipDeviceProp_t::multiProcessorCount)
     int      xcd_swizzle = 1;       // 0 off, 1 contiguous chunk range per XCD, 2 additionally consecutive chunks per CU (experiment)
-    int      stream_ahead = 1;      // groups the matrix stream runs ahead of the x gather: 1, or 3 (>= 2)
     uint32_t ystage = 1024;         // row sums a wavefront stages in LDS (multiple of 64, <= kYStageMax)
-    int      depth = 1;             // groups the x gather runs ahead of the FMAs (1 or 2)
     const void *dict = nullptr;     // value dictionary: ndict values of T sorted by bit pattern (device), or null
     uint32_t  ndict = 0;
-    uint32_t persist_waves = 0;     // > 0: persistent workgroups, this many wavefronts per CU, each looping over chunk groups (0 = one launch per chunk group)
     uint32_t wpb = 1;               // wavefronts (= consecutive chunks) per SpMV workgroup, 1..kMaxWavesPerBlock
     uint32_t *win_base = nullptr;   // [ceil(nchunks / wpb)] first column of each workgroup's LDS window of x
     uint32_t win_elems = 0;         // window length in values (0 = no window)
@@ -38,8 +35,6 @@ struct DeviceImage {
     uint32_t  phase_width = 0;      // columns per phase (multiple of 16)
     uint2    *desc2 = nullptr;      // [nchunks] {first entry of the chunk in the conversion-time segment table, rows with a segment in the chunk}
     bool      tag16 = false;        // column phases: the rows of the pieces stand in 16-bit tags of their own (col_bits = 31)
-    uint32_t *pace = nullptr;       // column phases with long chunks: [8][phases][512] words of the SpMV kernel's pacing (spmv_seg_kernel; zeroed once), or null
-    uint32_t *pace_epoch = nullptr; // host: launches so far (the value a launch marks with)
     uint32_t  col_base = 0;         // interleaved column panels: the image's column indices are relative to this column (pad_col = the panel's width)
     bool      ilv = false;          // interleaved chunks (cvr_ilv.hip): the image is written in the column-phase format with every slot a piece of its own; conversion only
     uint32_t  piece_max = 0;        // column phases: (row, phase) segments are cut into pieces at the multiples of this many elements from the chunk's first (0 = whole segments)
@@ -95,10 +90,12 @@ bool       seg_table_packed_ok(const DeviceImage &img);      // launch_seg_build
 // CSR -> CVR64 (one wavefront per chunk).  *err_flag (device u32, zeroed by the caller) gets bit 0 if a
 // lane stream did not drain, bit 1 if stealing found no over-full lane, bit 2 if a value is missing from the dictionary.
 hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t *err_flag, hipStream_t st, const SegTable *seg = nullptr, const uint32_t *nchunks_dev = nullptr);
-// interleaved chunks (cvr_ilv.hip): the chunks' non-zeros [n0, n1) sorted by column inside every chunk and dealt to the lanes in that order;
-// `scratch`: convert_interleaved_scratch(n1 - n0, img.nchunks) bytes of device memory; *err_flag bit 2: a value that is not in the dictionary
+// interleaved chunks (cvr_ilv.hip): the images' non-zeros sorted by column inside every chunk and dealt to the lanes in that order; the
+// images of one handle (same chunk length, value type, dictionary, tag width) go together: one sort, one writing pass.
+// `scratch`: convert_interleaved_scratch(sum of the non-zeros, ..) bytes of device memory; *err_flag bit 2: a value that is not in the dictionary
 size_t     convert_interleaved_scratch(int64_t nnz, uint32_t nchunks);
-hipError_t launch_convert_interleaved(const DeviceImage &img, const DeviceCsr &csr, int64_t n0, int64_t n1, uint32_t *err_flag, void *scratch, size_t scratch_bytes, hipStream_t st);
+hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const DeviceCsr *csrs, const int64_t *n0, const int64_t *n1, int n, uint32_t *err_flag, void *scratch,
+                                      size_t scratch_bytes, hipStream_t st);
 // codes[j] = dictionary code of vals[j], j in [n0, n1) (one coalesced pass; *err_flag bit 2: a value that is not in the dictionary)
 hipError_t launch_dict_codes(const void *vals, int64_t n0, int64_t n1, bool f32, const void *dict, uint32_t ndict, uint8_t *codes, uint32_t *err_flag, hipStream_t st);
 
@@ -200,7 +197,6 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                        uint32_t multi_rounds = 1,
                        const IterEpilogue *epi = nullptr);
 size_t     spmv_lds_bytes(const DeviceImage &img);      // dynamic LDS of that launch
-inline size_t pace_words(uint32_t phases) { return (size_t)8 * phases * 512; }      // pacing buffer of an image with column phases
 
 // column panels: one fix-up launch for all panels (each with its own y_ext inside the partial-sum buffer)
 struct FixPart { const int64_t *shared; void *yext; uint32_t nshared, nrows; };

@@ -404,6 +404,7 @@ int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, i
 // the fields of the device image that follow from the layout (not the per-chunk tables): shared by build_part and the fused path
 int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, int64_t nchunks, int64_t nshared, const IOpt &opt, const IOpt &popt)
 {
+    (void)h;
     const int S = pp.S;
     const int G = S / 4;
     cvr::DeviceImage &img = part.img;
@@ -411,8 +412,6 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
     img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)nshared;
     img.xcd_swizzle = opt.xcds != 8 ? 0 : opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
     img.ncus = (uint32_t)opt.cus;
-    img.stream_ahead = opt.stream_ahead >= 2 ? 3 : 1;
-    img.depth = opt.gather_depth == 2 ? 2 : 1;
     img.wpb = (uint32_t)pp.wpb;
     img.ystage = (uint32_t)pp.stage;
     img.phases = (uint32_t)pp.phases;
@@ -424,15 +423,10 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
         // pieces: a lane that sits on a long row's segment falls behind the column ranges the other lanes have moved on to; with
         // chunks longer than a few steps per phase the segments are cut (auto: 8 elements once a phase takes 8 steps or more)
         img.ilv = pp.ilv;
-        if (S / pp.phases >= 8 && !opt.panel_on_one_xcd && !pp.ilv && !getenv("CVR_NO_PACE")) {      // long chunks: the SpMV kernel paces its wavefronts through the phases
-            HIP_TRY(hipMalloc(&img.pace, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases)));
-            HIP_TRY(hipMemsetAsync(img.pace, 0, sizeof(uint32_t) * cvr::pace_words((uint32_t)pp.phases), h->stream));
-            img.pace_epoch = new uint32_t(0);
-        }
         // (a power of two, rounded down: the segment-table kernel cuts with shifts)
         img.piece_max = opt.piece_max > 0 ? 1u << (31 - __builtin_clz((uint32_t)opt.piece_max)) : opt.piece_max < 0 && S / pp.phases >= 8 && !opt.panel_on_one_xcd ? 8u : 0u;
         img.col_mask = pp.tag16 ? cvr::kColMask : (1u << pp.col_bits) - 1u;
-        if (pp.ilv) { img.piece_max = 1; if (!opt.gather_depth) img.depth = 2; if (!opt.stream_ahead) img.stream_ahead = 3; }      // (every slot is a piece; two groups of gathers in flight, the stream three groups ahead of them)
+        if (pp.ilv) img.piece_max = 1;      // (every slot is a piece of its own)
     }
     if (popt.col_phases > 1 && pp.lds_short && !popt.layout_auto_resident) return fail(CVR_ERR_INVALID, "col_phases: no room for at least 63 row accumulators per chunk (LDS beside %d waves per workgroup and the x window, or %d-bit column indices)", pp.wpb, pp.col_bits);
     const int64_t win = pp.win;
@@ -447,7 +441,7 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
 // beside them, and only the counts come back -- one synchronisation for all panels instead of two per panel with the plan's records in
 // between (sixteen panels of the LiveJournal shape: 5.0 -> ~1 ms).  For panels without hub tables and phases whose chunk length does
 // not depend on a look at the rows; *done = false: the caller plans panel by panel (nothing is left allocated).
-int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vector<int64_t> &nsubs, int64_t ncols, bool f32, const std::vector<IOpt> &popts,
+int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vector<int64_t> &nsubs, const std::vector<int64_t> &pcols, bool f32, const std::vector<IOpt> &popts,
                         std::vector<PartPlan> &pps, std::vector<DevRows> &drs, bool *done)
 {
     *done = false;
@@ -467,8 +461,8 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
             pp.S = pick_steps(nzp + ns / 4, 0, cus);
         }
         if (!cvr::plan_on_device_ok(pp.S)) return CVR_OK;
-        maxr[(size_t)p] = plan_layout(pp, ncols, f32, o);
-        if (pp.phases > 1 || pp.hub_n > 0) return CVR_OK;
+        maxr[(size_t)p] = plan_layout(pp, pcols[(size_t)p], f32, o);
+        if ((pp.phases > 1 && !pp.ilv) || pp.hub_n > 0) return CVR_OK;      // (interleaved panels: planned like phased images, their tables written on the device too)
         bound[(size_t)p] = cvr::plan_bound_device(ns, nzp, pp.S, maxr[(size_t)p]);
         if (ns + 1 + 2 * bound[(size_t)p] >= (int64_t)0xffffffffu || bound[(size_t)p] >= (int64_t)0x7fffffff) return CVR_OK;
         scratch = std::max(scratch, cvr::plan_scratch_bytes(ns, nzp, pp.S, maxr[(size_t)p]));
@@ -494,8 +488,8 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
     auto abandon = [&]() {          // (nothing of the attempt stays: the caller allocates again)
         for (int i = 0; i < nst; i++) (void)hipStreamSynchronize(sts[i]);
         for (Part &part : h->parts) {
-            for (void *q : {(void *)part.d_rp, (void *)part.d_nzb, (void *)part.d_pad, (void *)part.img.desc, (void *)part.img.shared}) if (q) (void)hipFree(q);
-            part.d_rp = nullptr; part.d_nzb = nullptr; part.d_pad = nullptr; part.img.desc = nullptr; part.img.shared = nullptr;
+            for (void *q : {(void *)part.d_rp, (void *)part.d_nzb, (void *)part.d_pad, (void *)part.img.desc, (void *)part.img.desc2, (void *)part.img.shared}) if (q) (void)hipFree(q);
+            part.d_rp = nullptr; part.d_nzb = nullptr; part.d_pad = nullptr; part.img.desc = nullptr; part.img.desc2 = nullptr; part.img.shared = nullptr;
         }
         return CVR_OK;
     };
@@ -509,8 +503,10 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
         HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nb, 1)));
         HIP_TRY(hipMalloc(&part.img.desc, 16 * std::max<size_t>((size_t)nb, 1)));
         HIP_TRY(hipMalloc(&part.img.shared, 24 * std::max<size_t>((size_t)nb, 1)));
+        const bool phased = pps[(size_t)p].phases > 1;
+        if (phased) HIP_TRY(hipMalloc(&part.img.desc2, 8 * std::max<size_t>((size_t)nb, 1)));
         cvr::PlanTables tables;
-        tables.desc = part.img.desc; tables.pad = part.d_pad; tables.nzb = part.d_nzb; tables.room = (uint32_t)nb; tables.phased = false;
+        tables.desc = part.img.desc; tables.desc2 = part.img.desc2; tables.pad = part.d_pad; tables.nzb = part.d_nzb; tables.room = (uint32_t)nb; tables.phased = phased;
         tables.totals = own.d_tot + 4 * (size_t)p;
         cvr::DevicePlan dp;
         HIP_TRY(cvr::plan_chunks_device_enqueue(part.d_rp, ns, nzp, pps[(size_t)p].S, popts[(size_t)p].split_threshold, maxr[(size_t)p], st, &own.ws[p % nst], &dp, &tables));
@@ -531,6 +527,10 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
         pp.max_nseg = (int64_t)(tot[4 * (size_t)p + 3] >> 1) + (int64_t)(tot[4 * (size_t)p + 3] & 1ull);
         pp.yext = ns + 1 + 2 * pp.dev_nchunks;
         pp.plan.S = pp.S; pp.plan.nz_end = nzp;
+        if (pp.phases > 1) {          // no more accumulators than the fullest chunk has rows (+ the dump entry), as plan_part sizes them
+            const int64_t most = (int64_t)(tot[4 * (size_t)p + 3] >> 1);
+            pp.stage = std::min<int64_t>(pp.stage, std::max<int64_t>(64, (most + 1 + 3) & ~(int64_t)3));
+        }
         plan_stage(pp, f32);
         drs[(size_t)p] = DevRows{part.d_rp, 0, nzp, h->stream, &h->plan_ws};
     }
@@ -640,7 +640,7 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
         HIP_TRY(hipMalloc(&img.shared, 24 * std::max<size_t>(plan.shared.size(), 1)));
     }
     HIP_TRY(hipMalloc(&img.target, 64 * std::max<size_t>((size_t)nchunks, 1)));
-    if (pp.phases > 1) {
+    if (pp.phases > 1 && !pp.tables_on_device) {
         HIP_TRY(hipMalloc(&img.desc2, 8 * std::max<size_t>((size_t)nchunks, 1)));
         if (nchunks) HIP_TRY(hipMemcpyAsync(img.desc2, pp.desc2.data(), sizeof(uint32_t) * pp.desc2.size(), hipMemcpyHostToDevice, h->stream));
     }

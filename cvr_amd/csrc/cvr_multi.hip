@@ -132,18 +132,24 @@ int multi_device_side(cvr_multi *m)
 
 extern "C" {
 
-int64_t cvr_row_partition(int64_t nrows, const int64_t *row_ptr, int32_t nparts, int64_t *bounds)
+int64_t cvr_row_partition(int64_t nrows, const int64_t *row_ptr, int32_t nparts, int64_t *bounds) { return cvr_row_partition_cost(nrows, row_ptr, nparts, 0, bounds); }
+
+int64_t cvr_row_partition_cost(int64_t nrows, const int64_t *row_ptr, int32_t nparts, int32_t row_cost_milli, int64_t *bounds)
 {
-    if (nrows < 0 || nparts < 1 || !bounds || (nrows > 0 && !row_ptr)) return fail(CVR_ERR_INVALID, "bad partition arguments");
-    const int64_t nz0 = nrows ? row_ptr[0] : 0, nnz = nrows ? row_ptr[nrows] - nz0 : 0;
+    if (nrows < 0 || nparts < 1 || row_cost_milli < 0 || !bounds || (nrows > 0 && !row_ptr)) return fail(CVR_ERR_INVALID, "bad partition arguments");
+    const int64_t nz0 = nrows ? row_ptr[0] : 0;
+    // cost of the rows before r, in thousandths of a non-zero: monotone in r, so the cut is a binary search (spmv.cpp:631-667 searches
+    // row_ptr the same way, per thread, for non-zeros alone)
+    auto cost = [&](int64_t r) { return (__int128)(row_ptr[r] - nz0) * 1000 + (__int128)r * row_cost_milli; };
+    const int64_t nnz = nrows ? row_ptr[nrows] - nz0 : 0;
     bounds[0] = 0;
     bounds[nparts] = nrows;
     for (int32_t p = 1; p < nparts; p++) {
-        // the first row whose start reaches p / nparts of the non-zeros (spmv.cpp:631-667 searches the same way, per thread)
-        const int64_t target = nz0 + (int64_t)((__int128)nnz * p / nparts);
-        int64_t       b = nrows ? std::lower_bound(row_ptr, row_ptr + nrows + 1, target) - row_ptr : 0;
-        b = std::min<int64_t>(std::max(b, bounds[p - 1]), nrows);
-        bounds[p] = b;
+        // p / nparts of the non-zeros (rounded down, as the nnz-only rule always did) and of the rows' own cost
+        const __int128 target = ((__int128)nnz * p / nparts) * 1000 + (__int128)nrows * row_cost_milli * p / nparts;
+        int64_t        lo = 0, hi = nrows;            // the first row r in [0, nrows] with cost(r) >= target
+        while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (cost(mid) >= target) hi = mid; else lo = mid + 1; }
+        bounds[p] = std::min<int64_t>(std::max(lo, bounds[p - 1]), nrows);
     }
     int64_t most = 0;
     for (int32_t p = 0; p < nparts; p++) most = std::max(most, bounds[p + 1] - bounds[p]);
@@ -185,7 +191,8 @@ int cvr_create_multi(cvr_multi **out, const cvr_csr_view *csr, const cvr_options
     m->G = G; m->f32 = csr->is_f32 != 0; m->vsz = m->f32 ? 4 : 8; m->nrows = csr->nrows; m->ncols = csr->ncols;
     m->dev.assign(devices, devices + G);
     m->bounds.assign((size_t)G + 1, 0);
-    m->max_rows = cvr_row_partition(csr->nrows, csr->row_ptr, G, m->bounds.data());
+    const char *pm = getenv("CVR_PARTITION");          // "nnz": balanced non-zeros, the reference's rule (spmv.cpp:584-627)
+    m->max_rows = cvr_row_partition_cost(csr->nrows, csr->row_ptr, G, pm && !strcmp(pm, "nnz") ? 0 : CVR_ROW_COST_MILLI_DEFAULT, m->bounds.data());
     m->H.assign((size_t)G, nullptr); m->dx.assign((size_t)G, nullptr); m->dy.assign((size_t)G, nullptr); m->dall.assign((size_t)G, nullptr);
     m->st.assign((size_t)G, nullptr); m->comm.assign((size_t)G, nullptr); m->ev.resize((size_t)G);
 #define MULTI_TRY(expr) do { const int rc_ = (expr); if (rc_) { cvr_destroy_multi(m); return rc_; } } while (0)

@@ -428,7 +428,6 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
 // (what spmv.cpp:1197-1224 and 1579-1651 do with records and t_rets): ~20 vector instructions per step where the general
 // kernel above issues ~70, which is what bounds a loop of 12 groups per wavefront with two wavefronts per SIMD.
 // TAG (wide row tags): the rows stand in 16-bit tags of their own, four per lane and group, instead of above the column index
-constexpr uint32_t kPaceSlots = 512;      // pacing buffer: [8 groups][phases][kPaceSlots] words, one per wavefront of a group (cvr_kernels.h: pace_words)
 template <typename T, bool DICT, bool TAG> struct SegGroup : Group<T, DICT> { uint32_t t01, t23; };
 
 template <typename T, bool DICT, bool TAG>
@@ -473,6 +472,8 @@ __device__ __forceinline__ void sum_group_seg(T &acc, const SegGroup<T, DICT, TA
     }
 }
 
+// (Round 3's pacing of long chunks through the phases -- wavefronts of an XCD waiting for each other -- was measured with the row bands,
+// lost everywhere and is gone: DESIGN.md 5.9.)
 // LOADER: the workgroup has extra wavefronts (behind its `nw` computing ones) that do nothing but bring the window of x into
 // LDS with LDS-direct loads (global_load_lds_dwordx4: 1 KiB per wave instruction, no registers) and leave.  The computing
 // wavefronts start their loop at once, gathering everything from global memory, and meet the loaders at one s_barrier in
@@ -485,8 +486,7 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const T *__restrict__ x, T *__restrict__ yext_a, int G, uint32_t nchunks_a,
     uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn,
     const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, const uint2 *__restrict__ desc2_a, uint32_t col_bits, uint32_t nw_arg, int gb,
-    uint32_t *__restrict__ pace, uint32_t pw, uint32_t pad_col, int pace_lag, uint32_t nphases, uint32_t epoch, const PanelArgs *__restrict__ multi,
-    IterEpilogue epi)
+    const PanelArgs *__restrict__ multi, IterEpilogue epi)
 {
     const uint8_t *__restrict__ stream = stream_a;
     const uint4 *__restrict__   desc = desc_a;
@@ -573,9 +573,6 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
         __syncthreads();
     }
     uint32_t wn_eff = LOADER ? 0u : wn;             // LOADER: the window is not there yet: everything through the buffer descriptor
-    if (!live && pace && lane == 0 && ((gridDim.x - (blockIdx.x & 7u) + 7u) >> 3) * nw <= kPaceSlots)       // (a wavefront without a chunk is out of every phase at once)
-        for (uint32_t p = 0; p < nphases; p++)
-            __hip_atomic_store(pace + ((size_t)(blockIdx.x & 7u) * nphases + p) * kPaceSlots + (blockIdx.x >> 3) * nw + wv, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if constexpr (LOADER && WIN != 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // this wavefront's own dictionary / zero-slot writes before its reads
         if (!live) { __builtin_amdgcn_s_barrier(); return; }
@@ -583,17 +580,6 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
         if (!live) return;
     }
 
-    // Pacing (long chunks: `pace` != null).  Column phases keep an XCD's L2 on one slice of x only while its wavefronts walk
-    // through the phases together; over hundreds of steps they drift apart.  The wavefronts of the workgroups with equal
-    // blockIdx & 7 (one XCD under round-robin dealing: for speed only) therefore form a group: a wavefront marks every phase
-    // it has left (one word per wavefront and phase, plain write-through stores of the launch's epoch: no atomics, nothing to
-    // zero between launches; the phase is read off lane 0's column) and, before it gathers from phase q, looks whether the
-    // whole group has left phase q - pace_lag, sleeping a little while it has not.  A hint, never a dependency: the wait is
-    // bounded and y does not depend on it.
-    const uint32_t pace_slot = (blockIdx.x >> 3) * nw + wv, pace_n = ((gridDim.x - (blockIdx.x & 7u) + 7u) >> 3) * nw;
-    uint32_t      *pace_g = pace ? pace + (size_t)(blockIdx.x & 7u) * nphases * kPaceSlots : nullptr;
-    if (pace && pace_n > kPaceSlots) pace_g = nullptr;
-    uint32_t       cur_phase = 0, next_bound = pw;
     double         epi_acc = 0;
     if (epi.out && epi.prev) {          // the iterative epilogue's look at the step before: its loads are in flight beside the first groups'
         constexpr int kBatch = 16;
@@ -612,30 +598,6 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
 #pragma unroll
     for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, kPolDefault, WIN>(rx, win, Q[i].c, cmask, wbase, wn_eff, 0u, wn);
     for (int g = 0; g < G; g++) {
-        if (pace_g) {
-            const uint32_t c0 = __builtin_amdgcn_readfirstlane(Q[DEPTH].c.x & cmask);
-            if (c0 != pad_col && c0 >= next_bound) {                  // lane 0 has moved on to a later phase
-                uint32_t q = cur_phase;
-                while (c0 >= next_bound) { q++; next_bound += pw; }
-                if (lane == 0)
-                    for (uint32_t p = cur_phase; p < q; p++) __hip_atomic_store(pace_g + (size_t)p * kPaceSlots + pace_slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cur_phase = q;
-                if ((int)q >= pace_lag) {
-                    const uint32_t *row = pace_g + (size_t)(q - (uint32_t)pace_lag) * kPaceSlots;
-                    for (int spin = 0; spin < 64; spin++) {
-                        bool behind = false;
-#pragma unroll
-                        for (uint32_t u = 0; u < kPaceSlots / kLanes; u++) {
-                            const uint32_t i = u * kLanes + lane;
-                            const uint32_t v = __hip_atomic_load(row + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            behind |= i < pace_n && v != epoch;
-                        }
-                        if (!__ballot(behind)) break;
-                        __builtin_amdgcn_s_sleep(16);
-                    }
-                }
-            }
-        }
         if constexpr (LOADER && WIN != 0) {
             if (g == gb) {                          // the window has arrived (the loaders waited for their loads in front of this barrier)
                 asm volatile("s_barrier" ::: "memory");
@@ -653,8 +615,6 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
         xs[DEPTH - 1] = xn;
     }
     if constexpr (LOADER && WIN != 0) { if (gb >= G) asm volatile("s_barrier" ::: "memory"); }      // (every wavefront meets the loaders exactly once)
-    if (pace_g && lane == 0)        // out of every phase
-        for (uint32_t p = cur_phase; p < nphases; p++) __hip_atomic_store(pace_g + (size_t)p * kPaceSlots + pace_slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!epi.out) {
@@ -1034,117 +994,79 @@ size_t spmv_lds_bytes(const DeviceImage &img)
     return (size_t)(wpb * (slots + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? ((img.hub_n + 3u) & ~3u) + img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8) + (img.phases > 1 ? 16 : 0);      // (column phases: + the arrival counter of the iterative epilogue)
 }
 
+// run-time flags -> template arguments, without macro towers: with_flag(v, f) calls f(std::true_type / false_type)
+template <typename F> inline void with_flag(bool v, F &&f) { if (v) f(std::true_type{}); else f(std::false_type{}); }
+template <typename F> inline void with_real(bool f32, F &&f) { if (f32) f(float{}); else f(double{}); }
+
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup, const PanelArgs *multi, uint32_t multi_chunks, uint32_t multi_rounds,
                        const IterEpilogue *epi)
 {
     if (img.nchunks == 0 && !multi) return hipSuccess;
     if (epi && (multi || !iter_epilogue_ok(img))) return hipErrorInvalidValue;
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;                     // consecutive chunks (wavefronts) per workgroup
-    uint32_t       nblocks = (img.nchunks + wpb - 1) / wpb;
-    // a hub table without a per-workgroup window: persistent workgroups (as many as fit the 256 CUs with this much LDS), each
-    // staging the table once and taking chunk groups blk, blk + grid, ...
-    uint32_t       kstride = 0;
-    if (img.win_elems == 0 && img.xcd_swizzle != 2 && img.phases <= 1 && !multi) {
-        // persistent workgroups: as many as are resident at once, each taking chunk groups blk, blk + grid, ...  With a hub
-        // table they stage it once.  Without one they were measured on the banded shape (CVR_PERSIST_WAVES = 8 .. 32
-        // wavefronts per CU: 204-230 us against 204-208 us for one launch per chunk, profiles/r02_persistent_plain_layout.log)
-        // and stay off: the dispatcher is not what limits the plain layout.
-        const uint32_t per_cu_lds = (uint32_t)std::max<size_t>(1, kLdsBytes / std::max<size_t>(spmv_lds_bytes(img), 1));
-        static const int env_waves = [] { const char *e = getenv("CVR_PERSIST_WAVES"); return e ? atoi(e) : -1; }();
-        const uint32_t waves = img.hub_n ? 16u : env_waves >= 0 ? (uint32_t)env_waves : img.persist_waves;       // wavefronts per CU
-        if (waves > 0) {
-            const uint32_t resident = img.ncus * std::min<uint32_t>(per_cu_lds, std::max<uint32_t>(1u, waves / wpb));
-            if (nblocks > resident) { nblocks = resident; kstride = resident * wpb; }
-        }
+    uint32_t       nblocks = (img.nchunks + wpb - 1) / wpb, kstride = 0;
+    const size_t   lds = spmv_lds_bytes(img);
+    if (lds > kLdsBytes) return hipErrorInvalidValue;                   // build_part sizes the stage and the window to fit; never reached
+    // a hub table without a per-workgroup window: persistent workgroups (as many as are resident at once: 16 wavefronts per CU, or what
+    // the LDS allows), each staging the table once and taking chunk groups blk, blk + grid, ...  (Without a table persistent
+    // wavefronts change nothing: profiles/r02_persistent_plain_layout.log.)
+    if (img.hub_n && img.win_elems == 0 && img.phases <= 1 && !multi) {
+        const uint32_t resident = img.ncus * std::min<uint32_t>((uint32_t)std::max<size_t>(1, kLdsBytes / std::max<size_t>(lds, 1)), std::max<uint32_t>(1u, 16u / wpb));
+        if (nblocks > resident) { nblocks = resident; kstride = resident * wpb; }
     }
     const uint32_t per_xcd = (nblocks + 7) / 8;
     if (multi) multi_chunks = (multi_chunks + wpb - 1) / wpb;          // (from here on: the workgroups of wpb chunks the fullest panel needs)
-    const uint32_t grid = multi ? multi_rounds * multi_chunks * 8 : img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;      // (multi: `img` is one of the eight panels: what they share comes from it)
-    const dim3     block(kLanes * wpb);
+    const uint32_t grid = multi ? multi_rounds * multi_chunks * 8 : img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;      // (multi: `img` is one of the panels: what they share comes from it)
+    const uint32_t per = multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd;      // the kernels' block -> chunk mapping (remap_block; multi: workgroups of one round)
+    const int      swz = multi ? 0 : img.xcd_swizzle;
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
-    if (xb > 0xffffffffull) return hipErrorInvalidValue;   // x is addressed through a 32-bit buffer descriptor
-    const bool   use_win = (img.win_elems > 0 && img.win_base != nullptr) || img.hub_n > 0;
-    const bool   use_dict = img.dict != nullptr;
+    if (xb > 0xffffffffull) return hipErrorInvalidValue;               // x is addressed through a 32-bit buffer descriptor
+    const bool use_win = (img.win_elems > 0 && img.win_base != nullptr) || img.hub_n > 0, use_dict = img.dict != nullptr;
     if (img.hub_n) { const hipError_t eh = launch_hub_gather(img, x_ext, st); if (eh != hipSuccess) return eh; }
-    if (img.order_n) x_ext = img.hub_x;            // the kernel gathers from the re-ordered copy of x
-    const size_t lds = spmv_lds_bytes(img);
-    if (lds > kLdsBytes) return hipErrorInvalidValue;      // build_part sizes the stage and the window to fit; never reached
-    // template parameters: <value type, stream run-ahead beyond the gather, gather cache policy, gather run-ahead, LDS table, dictionary, multi-wave, narrow chunks>
-#define CVR_LAUNCH(T, SP, D, W, DI, MW)                                                                           \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, W, DI, MW, false>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
-                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
-                       multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems,          \
-                       static_cast<const T *>(img.dict), img.ndict, img.ystage, static_cast<const T *>(img.hub_x), img.hub_n, kstride, img.cbase, img.pad_col, multi)
-#define CVR_PICK_MW(T, SP, D, W, DI) do { if (wpb > 1) CVR_LAUNCH(T, SP, D, W, DI, true); else CVR_LAUNCH(T, SP, D, W, DI, false); } while (0)
-#define CVR_PICK_DI(T, SP, D, W) do { if (use_dict) CVR_PICK_MW(T, SP, D, W, true); else CVR_PICK_MW(T, SP, D, W, false); } while (0)
-#define CVR_PICK_W(T, SP, D)     do { if (use_win && img.hub_n) CVR_PICK_DI(T, SP, D, 2); else if (use_win) CVR_PICK_DI(T, SP, D, 1); else CVR_PICK_DI(T, SP, D, 0); } while (0)
-#define CVR_PICK_D(T, SP)        do { if (img.depth == 2) CVR_PICK_W(T, SP, 2); else CVR_PICK_W(T, SP, 1); } while (0)
-#define CVR_PICK_SP(T)           do { if (img.stream_ahead >= 2) CVR_PICK_D(T, 3); else CVR_PICK_D(T, 1); } while (0)
-#define CVR_LAUNCH_C16(T, SP, D)                                                                                  \
-    hipLaunchKernelGGL((spmv_kernel<T, SP, kPolDefault, D, 0, false, false, true>), dim3(grid), block, lds, st, img.stream, img.desc, img.target, \
-                       static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd,       \
-                       img.xcd_swizzle, img.col_mask, (uint32_t)xb, img.win_base, 0u,          \
-                       static_cast<const T *>(nullptr), 0u, img.ystage, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col, (const PanelArgs *)nullptr)
-#define CVR_PICK_C16(T) do { if (img.stream_ahead >= 2) { if (img.depth == 2) CVR_LAUNCH_C16(T, 3, 2); else CVR_LAUNCH_C16(T, 3, 1); } \
-                             else { if (img.depth == 2) CVR_LAUNCH_C16(T, 1, 2); else CVR_LAUNCH_C16(T, 1, 1); } } while (0)
-#define CVR_SEG_ARGS(T) img.stream, img.desc, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, \
-                        img.win_base, img.win_elems, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.desc2, img.col_bits, wpb, win_group, pace, img.phase_width, img.pad_col, pace_lag, img.phases, epoch, multi, epi ? *epi : IterEpilogue{}
-#define CVR_SEG(T, SP, D, W, DI, LD)                                                                               \
-    do {                                                                                                           \
-        const dim3 sblock(kLanes * (wpb + (LD ? loaders : 0u)));                                                   \
-        if (img.tag16) hipLaunchKernelGGL((spmv_seg_kernel<T, SP, D, W, DI, LD, true>), dim3(grid), sblock, lds, st, CVR_SEG_ARGS(T)); \
-        else hipLaunchKernelGGL((spmv_seg_kernel<T, SP, D, W, DI, LD, false>), dim3(grid), sblock, lds, st, CVR_SEG_ARGS(T)); \
-    } while (0)
-#define CVR_SEG_DI(T, SP, D, W, LD) do { if (use_dict) CVR_SEG(T, SP, D, W, true, LD); else CVR_SEG(T, SP, D, W, false, LD); } while (0)
-#define CVR_SEG_W(T, SP, D)     do { if (use_win && loaders) CVR_SEG_DI(T, SP, D, 1, true); else if (use_win) CVR_SEG_DI(T, SP, D, 1, false); else CVR_SEG_DI(T, SP, D, 0, false); } while (0)
-#define CVR_SEG_D(T, SP)        do { if (img.depth == 2) CVR_SEG_W(T, SP, 2); else CVR_SEG_W(T, SP, 1); } while (0)
-#define CVR_SEG_SP(T)           do { if (img.stream_ahead >= 2) CVR_SEG_D(T, 3); else CVR_SEG_D(T, 1); } while (0)
-    // column phases with a window: `loaders` extra wavefronts per workgroup bring the window in while the others start (spmv_seg_kernel)
-    static const int env_loaders = [] { const char *e = getenv("CVR_WIN_LOADERS"); return e ? atoi(e) : -1; }();
-    static const int env_group = [] { const char *e = getenv("CVR_WIN_GROUP"); return e ? atoi(e) : -2; }();
-    uint32_t  loaders = img.phases > 1 && use_win ? (env_loaders >= 0 ? (uint32_t)env_loaders : 4u) : 0u;
-    if (wpb + loaders > (uint32_t)kMaxWavesPerBlock) loaders = wpb < (uint32_t)kMaxWavesPerBlock ? (uint32_t)kMaxWavesPerBlock - wpb : 0u;
-    const int win_group = env_group >= -1 ? env_group : 0;      // group in front of which the computing wavefronts meet the loaders (-1: in front of the first gather)
-    // pacing of long chunks (spmv_seg_kernel): the counters are zeroed in front of every launch
-    static const int env_pace = [] { const char *e = getenv("CVR_PACE_LAG"); return e ? atoi(e) : -1; }();
-    const int pace_lag = env_pace >= 0 ? env_pace : 2;
-    uint32_t *pace = img.phases > 1 && img.pace && pace_lag > 0 && !multi ? img.pace : nullptr;
-    const uint32_t epoch = pace ? ++*img.pace_epoch : 0u;        // (a launch marks with its own number: nothing to zero in between)
-    // interleaved images: the hand-pipelined kernel (spmv_ilv_kernel) whenever the workgroup fits it
-    if (img.ilv) {
-        if (epi || kLanes * wpb > (uint32_t)kRingThreads) return hipErrorInvalidValue;      // (plan_layout keeps interleaved workgroups within the ring kernel's eight wavefronts)
-#define CVR_ILV(T, DI, TG) hipLaunchKernelGGL((spmv_ilv_kernel<T, DI, TG>), dim3(grid), block, lds, st, img.stream, img.desc, img.desc2, static_cast<const T *>(x_ext), static_cast<T *>(y_ext), img.G, img.nchunks, \
-                                              multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd, multi ? 0 : img.xcd_swizzle, img.col_mask, (uint32_t)xb, static_cast<const T *>(img.dict), img.ndict, img.ystage, img.col_bits, img.col_base, multi)
-        if (img.f32) { if (use_dict) { if (img.tag16) CVR_ILV(float, true, true); else CVR_ILV(float, true, false); } else { if (img.tag16) CVR_ILV(float, false, true); else CVR_ILV(float, false, false); } }
-        else { if (use_dict) { if (img.tag16) CVR_ILV(double, true, true); else CVR_ILV(double, true, false); } else { if (img.tag16) CVR_ILV(double, false, true); else CVR_ILV(double, false, false); } }
-#undef CVR_ILV
-    }
-    else if (img.phases > 1) { if (img.f32) CVR_SEG_SP(float); else CVR_SEG_SP(double); }
-    else if (img.c16 && !use_win && !use_dict && wpb == 1 && img.phases <= 1 && !multi) { if (img.f32) CVR_PICK_C16(float); else CVR_PICK_C16(double); }
-    else if (img.f32) CVR_PICK_SP(float); else CVR_PICK_SP(double);
-#undef CVR_SEG_SP
-#undef CVR_SEG_D
-#undef CVR_SEG_W
-#undef CVR_SEG_DI
-#undef CVR_SEG
-#undef CVR_SEG_ARGS
-#undef CVR_PICK_C16
-#undef CVR_LAUNCH_C16
-#undef CVR_PICK_SP
-#undef CVR_PICK_D
-#undef CVR_PICK_W
-#undef CVR_PICK_DI
-#undef CVR_PICK_MW
-#undef CVR_LAUNCH
+    if (img.order_n) x_ext = img.hub_x;                                 // the kernel gathers from the re-ordered copy of x
+    if (img.ilv && (epi || kLanes * wpb > (uint32_t)kRingThreads)) return hipErrorInvalidValue;      // (plan_layout keeps interleaved workgroups within the ring kernel's eight wavefronts)
+    // column phases with a window: four extra wavefronts per workgroup bring the window in while the others start (spmv_seg_kernel)
+    const uint32_t loaders = img.phases > 1 && !img.ilv && use_win ? std::min<uint32_t>(4u, (uint32_t)kMaxWavesPerBlock - std::min<uint32_t>(wpb, kMaxWavesPerBlock)) : 0u;
+    with_real(img.f32, [&](auto real) {
+        using T = decltype(real);
+        const T *x = static_cast<const T *>(x_ext), *dict = static_cast<const T *>(img.dict);
+        T       *y = static_cast<T *>(y_ext);
+        with_flag(use_dict, [&](auto DI) {
+            constexpr bool kDict = decltype(DI)::value;
+            if (img.ilv) {                  // interleaved chunks: the hand-pipelined kernel
+                with_flag(img.tag16, [&](auto TG) {
+                    hipLaunchKernelGGL((spmv_ilv_kernel<T, kDict, decltype(TG)::value>), dim3(grid), dim3(kLanes * wpb), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
+                                       img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi);
+                });
+            } else if (img.phases > 1) {    // column phases: every piece carries its row
+                with_flag(img.tag16, [&](auto TG) { with_flag(use_win, [&](auto WI) { with_flag(loaders > 0, [&](auto LD) {
+                    constexpr int kWin = decltype(WI)::value ? 1 : 0;
+                    if constexpr (decltype(LD)::value && !decltype(WI)::value) return;          // (loaders only come with a window)
+                    else hipLaunchKernelGGL((spmv_seg_kernel<T, 1, 1, kWin, kDict, decltype(LD)::value, decltype(TG)::value>), dim3(grid), dim3(kLanes * (wpb + loaders)), lds, st, img.stream, img.desc, x, y,
+                                            img.G, img.nchunks, per, swz, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems, dict, img.ndict, img.ystage, img.desc2, img.col_bits, wpb, 0, multi,
+                                            epi ? *epi : IterEpilogue{});
+                }); }); });
+            } else if (img.c16 && !use_win && !kDict && wpb == 1 && !multi) {          // narrow chunks (banded matrices)
+                if constexpr (!kDict)
+                    hipLaunchKernelGGL((spmv_kernel<T, 1, kPolDefault, 1, 0, false, false, true>), dim3(grid), dim3(kLanes), lds, st, img.stream, img.desc, img.target, x, y, img.G, img.nchunks, per, swz,
+                                       img.col_mask, (uint32_t)xb, img.win_base, 0u, static_cast<const T *>(nullptr), 0u, img.ystage, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col,
+                                       static_cast<const PanelArgs *>(nullptr));
+            } else {                        // the general kernel: rows handed out by ballot / rank; LDS table: none, a window of x, or a hub table
+                with_flag(wpb > 1, [&](auto MW) {
+                    auto go = [&](auto W) {
+                        hipLaunchKernelGGL((spmv_kernel<T, 1, kPolDefault, 1, decltype(W)::value, kDict, decltype(MW)::value, false>), dim3(grid), dim3(kLanes * wpb), lds, st, img.stream, img.desc, img.target,
+                                           x, y, img.G, img.nchunks, per, swz, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems, dict, img.ndict, img.ystage, static_cast<const T *>(img.hub_x),
+                                           img.hub_n, kstride, img.cbase, img.pad_col, multi);
+                    };
+                    if (use_win && img.hub_n) go(std::integral_constant<int, 2>{}); else if (use_win) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 0>{});
+                });
+            }
+        });
+    });
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess && getenv("CVR_DEBUG_STICKY")) fprintf(stderr, "[launch_spmv] %s: grid %u block %u lds %zu S %d G %d nchunks %u wpb %u c16 %d phases %u win %u hub %u swz %d dict %p stream %p desc %p target %p cbase %p\n", hipGetErrorString(e), grid, kLanes * wpb, lds, img.S, img.G, img.nchunks, wpb, (int)img.c16, img.phases, img.win_elems, img.hub_n, img.xcd_swizzle, img.dict, (void *)img.stream, (void *)img.desc, (void *)img.target, (void *)img.cbase);
     if (e != hipSuccess || img.nshared == 0 || !with_fixup) return e;
     const uint32_t fb = (img.nshared + kWavesPerBlock - 1) / kWavesPerBlock;
-    const dim3     fblock(kLanes * kWavesPerBlock);
-    if (img.f32)
-        hipLaunchKernelGGL(fixup_kernel<float>, dim3(fb), fblock, 0, st, img.shared, img.nshared, static_cast<float *>(y_ext), img.nrows);
-    else
-        hipLaunchKernelGGL(fixup_kernel<double>, dim3(fb), fblock, 0, st, img.shared, img.nshared, static_cast<double *>(y_ext), img.nrows);
+    with_real(img.f32, [&](auto real) { using T = decltype(real); hipLaunchKernelGGL(fixup_kernel<T>, dim3(fb), dim3(kLanes * kWavesPerBlock), 0, st, img.shared, img.nshared, static_cast<T *>(y_ext), img.nrows); });
     return hipGetLastError();
 }
 

@@ -4,11 +4,11 @@ repairs with atomics); x replicated; y slices all-gathered (RCCL over xGMI on GP
 import numpy as np
 
 
-def row_partition(row_ptr, nparts):
-    """bounds[nparts+1]: part p owns rows bounds[p] .. bounds[p+1]-1; nnz per part as equal as row
-    boundaries allow"""
+def row_partition(row_ptr, nparts, row_cost_milli=0):
+    """bounds[nparts+1]: part p owns rows bounds[p] .. bounds[p+1]-1; cost per part (non-zeros + row_cost_milli / 1000 per row) as
+    equal as row boundaries allow; row_cost_milli = 0: non-zeros alone, the reference's rule (spmv.cpp:584-627)"""
     from . import capi
-    return capi.row_partition(row_ptr, nparts)      # the library's one partition rule (cvr_row_partition, cvr_multi.hip)
+    return capi.row_partition(row_ptr, nparts, row_cost_milli)      # the library's one partition rule (cvr_row_partition_cost, cvr_multi.hip)
 
 
 def local_csr(row_ptr, col_idx, vals, bounds, p):

@@ -45,13 +45,15 @@ def rmat_row_degrees(scale, edge_factor=16, a=0.57, b=0.19, c=0.19, seed=1, devi
     return deg
 
 
-def partition_from_degrees(deg, nparts):
-    """bounds[nparts + 1] with nnz per part as equal as row boundaries allow (cvr_amd.shard.row_partition on the prefix sums)"""
+def partition_from_degrees(deg, nparts, row_cost_milli=0):
+    """bounds[nparts + 1] with cost per part (non-zeros + row_cost_milli / 1000 per row) as equal as row boundaries allow
+    (cvr_row_partition_cost on the prefix sums, restated on device tensors)"""
     rp = torch.zeros(len(deg) + 1, dtype=torch.int64, device=deg.device)
     rp[1:] = torch.cumsum(deg, 0)
-    nnz = int(rp[-1])
-    targets = (torch.arange(1, nparts, dtype=torch.int64, device=deg.device) * nnz) // nparts
-    cuts = torch.searchsorted(rp, targets, right=False)
+    cost = rp * 1000 + torch.arange(len(deg) + 1, dtype=torch.int64, device=deg.device) * int(row_cost_milli)
+    k = torch.arange(1, nparts, dtype=torch.int64, device=deg.device)
+    targets = ((k * int(rp[-1])) // nparts) * 1000 + (k * (len(deg) * int(row_cost_milli))) // nparts
+    cuts = torch.searchsorted(cost, targets, right=False)
     bounds = torch.cat([torch.zeros(1, dtype=torch.int64, device=deg.device), cuts.clamp(0, len(deg)),
                         torch.tensor([len(deg)], dtype=torch.int64, device=deg.device)])
     return torch.cummax(bounds, 0).values.cpu().numpy(), rp
@@ -91,13 +93,13 @@ def _splitmix_unit(z):
     return shr(z, 11).to(torch.float64) * (2.0 / 9007199254740992.0) - 1.0
 
 
-def banded_partition(n, half_band, nparts):
+def banded_partition(n, half_band, nparts, row_cost_milli=0):
     """nnz-balanced row bounds of the banded matrix, from the closed-form row lengths"""
     r = np.arange(n, dtype=np.int64)
     deg = np.minimum(r, half_band) + 1 + np.minimum(n - 1 - r, half_band)
     rp = np.concatenate([[0], np.cumsum(deg)])
     from . import shard
-    return shard.row_partition(rp, nparts), int(rp[-1])
+    return shard.row_partition(rp, nparts, row_cost_milli), int(rp[-1])
 
 
 def banded_rows(n, row_lo, row_hi, half_band=13, device="cpu", dtype=torch.float64):

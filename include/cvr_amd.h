@@ -117,9 +117,8 @@ typedef struct {
  * diagonal?) and, for matrices whose chunks can all be resident at once, picks 6-8 chunks per workgroup sharing a 64-KiB LDS
  * window of x and/or column phases; everything else keeps one chunk per workgroup.  CVR_NO_AUTO_LAYOUT=1 in the environment
  * or any explicit value of those four options switches it off.
- * Profiling knobs are not part of this struct: CVR_DEBUG_STREAM_AHEAD (groups the matrix stream runs ahead of the gather: 1 or
- * 3), CVR_DEBUG_GATHER_DEPTH (1 or 2 gather batches in flight) and CVR_DEBUG_COL_MASK (folds the gather onto a 2^k-entry
- * table: wrong results, timing only) are read from the environment by cvr_create. */
+ * The one profiling knob is not part of this struct: CVR_DEBUG_COL_MASK in the environment (folds the gather onto a 2^k-entry table:
+ * wrong results, timing only) is read by cvr_create. */
 
 typedef struct {
     int32_t iters;
@@ -227,7 +226,7 @@ int cvr_tune(const cvr_csr_view *csr, const cvr_options *opt, cvr_options *best,
 /* ---- one call = all GPUs of the process ------------------------------------------------------------------
  * In the reference ONE call drives all threads (pre_processing spmv.cpp:1857 -> omp parallel num_threads at :577;
  * spmv_compute_kernel :1882 -> :1034).  The multi-device handle is that for GPUs: it cuts the rows into one contiguous block
- * per device with balanced non-zeros (cvr_row_partition: binary search on row_ptr, the reference's per-thread trick of
+ * per device with balanced predicted time (cvr_row_partition_cost: non-zeros plus a cost per row; binary search on row_ptr, the reference's per-thread trick of
  * spmv.cpp:631-667, but at row boundaries, so no row spans devices and nothing is reduced across them), builds one shard
  * handle per device (x replicated), owns the device vectors, the communicators (ncclCommInitAll) and the all-gather of y.
  * A device may be listed several times (CVR_DEVICES=0,0,0 on a one-GPU box): sharding, handles and gather layout stay,
@@ -236,6 +235,14 @@ typedef struct cvr_multi cvr_multi;
 /* bounds[nparts + 1]: rows [bounds[p], bounds[p+1]) go to part p; returns the largest part's row count (>= 0) or < 0 on error.
  * Host only, no device needed.  The one partition rule of this library (the host program, bench.py and cvr_amd/shard.py use it). */
 int64_t cvr_row_partition(int64_t nrows, const int64_t *row_ptr, int32_t nparts, int64_t *bounds);
+/* The same cut on predicted TIME instead of non-zeros: a row costs its non-zeros plus row_cost_milli / 1000 of a non-zero (its hand-out,
+ * its accumulator, its store: a fit over the eight row shards of R-MAT-26, whose kernels ran 851 .. 1 074 us at equal non-zeros --
+ * t = 6.33 ns per 1 000 non-zeros + 7.7 ns per 1 000 rows, i.e. 1.22 non-zeros per row; profiles/r03_rank_emulation_rmat26.json).
+ * bounds[p] = the first row r with 1000 * nnz(rows before r) + row_cost_milli * r >= 1000 * floor(nnz * p / nparts) + floor(nrows * row_cost_milli * p / nparts).  row_cost_milli = 0 is cvr_row_partition (the
+ * reference balances non-zeros only, spmv.cpp:584-627); CVR_ROW_COST_MILLI_DEFAULT is what cvr_create_multi, spmv.cvr and bench.py use
+ * (spmv.cvr: CVR_PARTITION=nnz in the environment keeps the reference's rule). */
+#define CVR_ROW_COST_MILLI_DEFAULT 1250
+int64_t cvr_row_partition_cost(int64_t nrows, const int64_t *row_ptr, int32_t nparts, int32_t row_cost_milli, int64_t *bounds);
 /* csr: host arrays of the whole matrix; opt: as for cvr_create (opt->device is ignored); devices[ndevices]: HIP ordinals */
 int cvr_create_multi(cvr_multi **out, const cvr_csr_view *csr, const cvr_options *opt, const int32_t *devices, int32_t ndevices);
 int cvr_preprocess_multi(cvr_multi *m, int keep_csr, double *seconds);      /* seconds: the slowest shard's conversion + planning */

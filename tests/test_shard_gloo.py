@@ -40,6 +40,19 @@ def test_row_partition_properties():
             nnz = int(rp[-1] - rp[0])
             want = np.concatenate([[0], np.clip(np.searchsorted(rp, rp[0] + (np.arange(1, nparts) * nnz) // nparts, side="left"), 0, n), [n]])
             assert np.array_equal(shard.row_partition(rp, nparts), np.maximum.accumulate(want)), (trial, nparts)
+            # the cut on predicted time (cvr_row_partition_cost): a row costs its non-zeros + w / 1000; the first row whose cost prefix
+            # reaches p / nparts of the total -- w = 0 is the rule above
+            for w in (0, 1250, 40000):
+                cost = (rp - rp[0]) * 1000 + np.arange(n + 1) * w
+                want_c = np.concatenate([[0], np.clip(np.searchsorted(cost, ((np.arange(1, nparts) * nnz) // nparts) * 1000 + (np.arange(1, nparts) * n * w) // nparts, side="left"), 0, n), [n]])
+                assert np.array_equal(shard.row_partition(rp, nparts, w), np.maximum.accumulate(want_c)), (trial, nparts, w)
+    # many short rows behind a few long ones (R-MAT's shape along the rows): equal non-zeros give the last part most of the rows; with the
+    # row cost the parts' predicted times (non-zeros + 1.25 per row) are level and the row counts closer
+    deg = np.concatenate([np.full(100, 5000), np.full(100000, 5)])
+    rp2 = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    b0, b1 = shard.row_partition(rp2, 4), shard.row_partition(rp2, 4, 1250)
+    t = lambda b: np.array([(rp2[b[p + 1]] - rp2[b[p]]) + 1.25 * (b[p + 1] - b[p]) for p in range(4)])
+    assert t(b1).max() / t(b1).mean() < 1.02 < t(b0).max() / t(b0).mean()
     # balance on a matrix with many rows: within one max row of the ideal
     nrows, ncols, rp, ci, va = K.cases()["uniform_2000"]
     b = shard.row_partition(rp, 8)

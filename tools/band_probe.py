@@ -62,7 +62,7 @@ def main():
                     lrp = rp[r0:r1 + 1]
                     try:
                         A = cvr_amd.CvrMatrix(r1 - r0, nc, lrp, ci, va, steps_per_chunk=S, waves_per_block=wpb, x_window=0, col_phases=P, col_panels=1,
-                                              split_threshold=32 * S, depth=dp, hub_table=0, piece_max=pm)
+                                              split_threshold=32 * S, hub_table=0, piece_max=pm)
                     except Exception as e:
                         print(f"  band {b} wpb {wpb} S {S} P {P}: {e}")
                         continue

@@ -67,8 +67,8 @@ def main():
                                                    for dp in a.depth.split(",") for w in a.win.split(",") for pn in a.panels.split(",")
                                                    for vd in a.dict.split(",") for php in a.phases.split(",") for hb in a.hub.split(",") for na in a.narrow.split(",")]:
                     try:
-                        A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz, stream_ahead=nt,
-                                              debug_col_mask=cm, depth=dp, x_window=win, col_panels=pan, waves_per_block=wpb, value_dict=vd, col_phases=php, hub_table=hub, narrow_cols=nar)
+                        A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, steps_per_chunk=S, split_threshold=thr, xcd_swizzle=swz,
+                                              debug_col_mask=cm, x_window=win, col_panels=pan, waves_per_block=wpb, value_dict=vd, col_phases=php, hub_table=hub, narrow_cols=nar)
                     except Exception as e:
                         print(f"  {S:4d} wpb {wpb} win {win}: {e}", flush=True)
                         continue
