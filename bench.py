@@ -394,7 +394,7 @@ def self_launch(args):
 
 
 def _pre_times(info):
-    """the preprocessing times of a handle (cvr_info): T_pre = analysis + conversion without the upload, as tests/compare_csr.py counts it"""
+    """the preprocessing times of a handle (cvr_info): T_pre = analysis + conversion without the upload, as tools/compare_csr.py counts it"""
     return {"plan_s": info.plan_s, "probe_s": info.probe_s, "upload_s": info.upload_s, "convert_s": info.convert_s,
             "preprocess_wall_s": info.preprocess_wall_s, "dict_s": info.dict_s, "one_submission": bool(info.preprocess_fused),
             "t_pre_s": info.plan_s + info.probe_s + info.hub_select_s + info.dict_s + info.preprocess_wall_s}
@@ -509,7 +509,7 @@ def main():
     create_s = time.perf_counter() - t_build0 - build_s
     info = A.info
     # The first cvr_create of a process also loads the code object and creates the library's streams (milliseconds); the preprocessing
-    # times DESIGN section 5.7 / 5.11 and tests/compare_csr.py quote are those of a process that has done so.  Host workloads that build in
+    # times DESIGN section 5.7 / 5.11 and tools/compare_csr.py quote are those of a process that has done so.  Host workloads that build in
     # a moment are therefore built a second time, untimed by the bench, and the JSON line carries both.
     warm_info = None
     if not (device_built or tune) and create_s < 2.0:

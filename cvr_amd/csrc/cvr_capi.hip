@@ -276,11 +276,11 @@ extern "C" {
 namespace {
 // CVR_CREATE_TIMING=1: wall time of the phases of cvr_create on stderr (diagnostics only)
 struct PhaseClock {
-    bool   on = getenv("CVR_CREATE_TIMING") && atoi(getenv("CVR_CREATE_TIMING"));
+    bool   on = cvr::debug_env("create_timing") && atoi(cvr::debug_env("create_timing"));
     double t = now_s();
     void   lap(const char *what)
     {
-        if (getenv("CVR_DEBUG_STICKY")) { const hipError_t pe = hipPeekAtLastError(); if (pe != hipSuccess) fprintf(stderr, "[cvr_create] sticky error at \"%s\": %s\n", what, hipGetErrorString(pe)); }
+        if (cvr::debug_env("sticky")) { const hipError_t pe = hipPeekAtLastError(); if (pe != hipSuccess) fprintf(stderr, "[cvr_create] sticky error at \"%s\": %s\n", what, hipGetErrorString(pe)); }
         if (on) { const double n = now_s(); fprintf(stderr, "[cvr_create] %-28s %8.2f ms\n", what, (n - t) * 1e3); t = n; }
     }
 };
@@ -289,6 +289,7 @@ struct PhaseClock {
 int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *opt_in)
 {
     PhaseClock clk;
+    cvr::debug_refresh();
     if (!out) return fail(CVR_ERR_INVALID, "out is null");
     *out = nullptr;
     Range range("cvr_create (validate, plan, upload)");
@@ -321,7 +322,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (hostv.nrows < 0 || hostv.ncols < 0 || (hostv.nrows > 0 && !hostv.row_ptr)) return fail(CVR_ERR_INVALID, "null or negative-size CSR view");
         HIP_TRY(hipSetDevice(opt.device));
         int64_t j0 = 0, j1 = 0;
-        if (hostv.nrows >= device_plan_rows() && hostv.nrows > 0 && !getenv("CVR_DEVICE_ROWS_TO_HOST")) {
+        if (hostv.nrows >= device_plan_rows() && hostv.nrows > 0 && !cvr::debug_env("device_rows_to_host")) {
             // a matrix the device plans anyway: its row pointers are checked and used where they are (rows_on_device)
             cvr_csr_view shape = hostv;
             shape.nrows = 0; shape.row_ptr = nullptr;                 // (the checks of check_csr that need no rows: sizes, ncols, x within 4 GiB)
@@ -390,7 +391,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     } warm;
     {
         static std::atomic<bool> warmed{false};
-        if (!warmed.exchange(true) && !getenv("CVR_NO_WARM_THREAD"))
+        if (!warmed.exchange(true) && !cvr::debug_env("no_warm_thread"))
             warm.t = std::thread([dev = h->device] {
                 if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); return; }
                 cvr::touch_plan_kernels(); cvr::touch_convert_kernels(); cvr::touch_spmv_kernels();
@@ -435,7 +436,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // (x of 12 .. 24 MB: the rule also runs for matrices too large for the resident layout -- web-Google shapes of 12-16 M non-zeros run
     // 21-28 % faster as eight panels, one per XCD, than as one plain image: profiles/r03_mid_size_panels.log)
     const bool     mid_range = P < 0 && xbytes >= kMidPanelBytes && xbytes < 24e6 && sj1 > sj0 && resident_out_of_reach(nrows, sj1 - sj0, ncols, f32, opt);
-    if (!on_device && (P > 1 || (P < 0 && (xbytes >= 24e6 || mid_range))) && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !getenv("CVR_HOST_SPLIT")) {
+    if (!on_device && (P > 1 || (P < 0 && (xbytes >= 24e6 || mid_range))) && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !cvr::debug_env("host_split")) {
         if (hipMalloc(&staged.rp, sizeof(int64_t) * ((size_t)nrows + 1)) == hipSuccess && hipMalloc(&staged.ci, sizeof(int32_t) * (size_t)sj1) == hipSuccess &&
             hipMalloc(&staged.va, vsz * (size_t)sj1) == hipSuccess &&
             hipMemcpy(staged.rp, csr->row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice) == hipSuccess &&
@@ -462,13 +463,13 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     const double panel_rule_s = now_s() - t_rule0;          // part of the analysis: added to plan_s below
     clk.lap("panel rule");
     // panels in rounds of eight, each on one XCD (run_spmv, d_multi; cvr_panels.hip: xcd_panel_count)
-    const char *xp_env = getenv("CVR_XCD_PANELS");
+    const char *xp_env = cvr::debug_env("xcd_panels");
     const bool  xcd_panels = !(xp_env && atoi(xp_env) == 0) && opt.xcds == 8;
     if (P > 1 && panels_auto && xcd_panels && dev_split) P = xcd_panel_count(P, xbytes);      // (the host rule, auto_panels, has counted them that way already)
     // Power-law matrices whose popular columns will sit in hub tables need fewer, wider panels: the table takes the hot
     // half of the gathers off the L2s, and what remains runs best with ~16 MB of x per panel instead of ~4 (R-MAT-26 fp32
     // on one GPU: 59 panels 6.4 ms, 16 panels 5.4 ms; R-MAT-24: 8 and 4 panels alike; profiles/r02_hub_table_rmat.log)
-    if (P > 1 && dev_split && panels_auto && opt.hub_table < 0 && opt.waves_per_block == 0 && opt.x_window <= 0 && !getenv("CVR_NO_AUTO_LAYOUT")) {      // (the predicate of choose_hubs: only panels that will get tables are widened)
+    if (P > 1 && dev_split && panels_auto && opt.hub_table < 0 && opt.waves_per_block == 0 && opt.x_window <= 0 && !cvr::debug_env("no_auto_layout")) {      // (the predicate of choose_hubs: only panels that will get tables are widened)
         const int64_t room = ((int64_t)cvr::kLdsBytes / (int64_t)vsz - 8 * (cvr::kLanes + 512) - cvr::kDictMax - 8) & ~(int64_t)1023;
         cvr::HubSelection sel;
         const double      th0 = now_s();
@@ -527,14 +528,14 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         clk.lap("panel split");
         std::vector<PartPlan> pps((size_t)P);
         IOpt                  panel_opt = opt;
-        panel_opt.col_phases = getenv("CVR_PANEL_PHASES") ? atoi(getenv("CVR_PANEL_PHASES")) : 1;          // column phases are for the single image whose chunks are all resident at once
+        panel_opt.col_phases = cvr::debug_env("panel_phases") ? atoi(cvr::debug_env("panel_phases")) : 1;          // column phases are for the single image whose chunks are all resident at once
         panel_opt.panel_on_one_xcd = xcd_panels ? 1 : 0;
         // interleaved chunks (automatic): panels that run one per XCD (their slice of x stays in that L2: what is left to save is the
         // number of requests) and get no hub tables -- scattered columns without a popular head, the soc-LiveJournal1 shape
         // (from 8 M non-zeros on: below, the few long chunks per XCD cost what the sorting saves -- wiki-Talk shape 5 M: 48.6 -> 50.4 us, a
         // 2.4-M-row matrix of single-entry rows 36.7 -> 38.7; web-Google shape x 3, 15 M: 94.9 -> 86.9; com-Orkut shape 1 307 -> 778:
         // profiles/r04_ilv_auto_probe.log)
-        if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && sj1 - sj0 >= (int64_t)8 << 20 && !getenv("CVR_NO_AUTO_LAYOUT") ? 1 : 0;
+        if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && sj1 - sj0 >= (int64_t)8 << 20 && !cvr::debug_env("no_auto_layout") ? 1 : 0;
         if (panel_opt.interleave > 0) {
             panel_opt.hub_table = 0; panel_opt.col_phases = 1;
             if (panel_opt.steps_per_chunk == 0) {       // one chunk length for all panels (they share a launch): from the mean sub-row and the mean panel
@@ -711,7 +712,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         bool plain = true;
         for (const Part &p : h->parts) plain = plain && (p.img.ilv ? p.img.wpb == h->parts[0].img.wpb : p.img.wpb <= 1) && p.img.ilv == h->parts[0].img.ilv && p.img.hub_n == 0 && p.img.win_elems == 0 && p.img.phases == h->parts[0].img.phases && p.img.tag16 == h->parts[0].img.tag16 && !p.img.c16 && p.img.S == h->parts[0].img.S;
         if (plain) {
-            const size_t per_round = getenv("CVR_XCD_PANELS_DEBUG") ? (size_t)atoi(getenv("CVR_XCD_PANELS_DEBUG")) : 8;      // (diagnostics: fewer panels side by side)
+            const size_t per_round = cvr::debug_env("xcd_panels_debug") ? (size_t)atoi(cvr::debug_env("xcd_panels_debug")) : 8;      // (diagnostics: fewer panels side by side)
             const size_t rounds = (h->parts.size() + per_round - 1) / per_round;
             std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u});
             h->multi_chunks.assign(rounds, 0u);
@@ -742,7 +743,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col};
                 h->multi_chunks[i / 8] = std::max(h->multi_chunks[i / 8], p.img.nchunks);
                 h->multi_ystage = std::max(h->multi_ystage, p.img.ystage);
-                if (getenv("CVR_XCD_PANELS_TRACE")) fprintf(stderr, "[xcd panels] part %zu slot %zu nchunks %u ystage %u S %d G %d zoff %lld yext %lld nshared %u stream %p\n", j, i, p.img.nchunks, p.img.ystage, p.img.S, p.img.G, (long long)p.zoff, (long long)p.yext, p.img.nshared, (void *)p.img.stream);
+                if (cvr::debug_env("xcd_panels_trace")) fprintf(stderr, "[xcd panels] part %zu slot %zu nchunks %u ystage %u S %d G %d zoff %lld yext %lld nshared %u stream %p\n", j, i, p.img.nchunks, p.img.ystage, p.img.S, p.img.G, (long long)p.zoff, (long long)p.yext, p.img.nshared, (void *)p.img.stream);
             }
             CREATE_TRY(hipMalloc(&h->d_multi, sizeof(cvr::PanelArgs) * pa.size()));
             CREATE_TRY(hipMemcpy(h->d_multi, pa.data(), sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyHostToDevice));
@@ -795,6 +796,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
 
 int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
 {
+    cvr::debug_refresh();
     if (!h) return fail(CVR_ERR_INVALID, "handle is null");
     if (h->parts.empty() || !h->parts[0].d_rp) return fail(CVR_ERR_STATE, "the device CSR was already released: cvr_preprocess runs once unless keep_csr was set");
     Range range("cvr_preprocess (CSR -> CVR64)");
@@ -865,7 +867,7 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
             if (p.nchunks > 0) { ilv_imgs.push_back(&p.img); ilv_csrs.push_back(csr); ilv_n0.push_back(p.nnz_span - p.nnz); ilv_n1.push_back(p.nnz_span); }
         } else if (p.img.phases > 1 && p.nchunks > 0) {
             cvr::SegTable &t = sg.t;
-            if (h->d_dict && cvr::seg_table_packed_ok(p.img) && !getenv("CVR_NO_DICT_CODES")) {      // the values as dictionary codes first: the converter then reads a byte per value (cvr_convert.hip: convert_lds_kernel)
+            if (h->d_dict && cvr::seg_table_packed_ok(p.img) && !cvr::debug_env("no_dict_codes")) {      // the values as dictionary codes first: the converter then reads a byte per value (cvr_convert.hip: convert_lds_kernel)
                 (void)hipFree(sg.codes); sg.codes = nullptr;
                 HIP_TRY(hipMalloc(&sg.codes, std::max<size_t>((size_t)p.nnz_span, 1)));
                 HIP_TRY(cvr::launch_dict_codes(p.d_va, p.nnz_span - p.nnz, p.nnz_span, p.img.f32, h->d_dict, h->ndict, sg.codes, h->d_err, h->stream));

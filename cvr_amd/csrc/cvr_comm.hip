@@ -152,6 +152,7 @@ int cvr_spmv_gather_repeat(cvr_handle *h, cvr_comm *c, const void *x_dev, void *
 int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int iters, void *x_dev, double *lambda,
                         double *seconds_per_iter, void *stream)
 {
+    cvr::debug_refresh();
     if (!h || !x_dev || iters < 0) return fail(CVR_ERR_INVALID, "null argument");
     if (!h->converted) return fail(CVR_ERR_STATE, "cvr_power_iteration before cvr_preprocess");
     const int     nparts = c ? c->nranks : 1;
@@ -211,7 +212,7 @@ int cvr_power_iteration(cvr_handle *h, cvr_comm *c, const int64_t *bounds, int i
     // One GPU, an image with column phases and no rows cut over chunks (the resident layout of a web-graph-sized matrix): the step's dot
     // products and the next iterate come out of the SpMV kernel's write-out (cvr_kernels.h: IterEpilogue) -- one launch per iteration,
     // x alternating between the caller's buffer and one of ours.
-    bool         fused = !c && !h->paneled() && cvr::iter_epilogue_ok(h->parts[0].img) && h->parts[0].img.hub_n == 0 && !getenv("CVR_ITER_UNFUSED");
+    bool         fused = !c && !h->paneled() && cvr::iter_epilogue_ok(h->parts[0].img) && h->parts[0].img.hub_n == 0 && !cvr::debug_env("iter_unfused");
     void        *xalt = nullptr;
     struct AltGuard { void *&p; ~AltGuard() { (void)hipFree(p); } } alt_guard{xalt};
     const size_t nsets = (size_t)cvr::power_partials() / 3;

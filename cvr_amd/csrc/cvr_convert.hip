@@ -1316,7 +1316,7 @@ static size_t seg_scan_lds_bytes(const DeviceImage &img)
     return bytes <= kLdsBytes - 1024 ? bytes : 0;
 }
 
-bool seg_table_packed_ok(const DeviceImage &img) { return seg_scan_lds_bytes(img) != 0 && !getenv("CVR_SEG_BY_ROWS"); }
+bool seg_table_packed_ok(const DeviceImage &img) { return seg_scan_lds_bytes(img) != 0 && !cvr::debug_env("seg_by_rows"); }
 
 hipError_t launch_seg_total(const SegTable &st, uint32_t nchunks, const uint32_t *nchunks_dev, uint32_t *total_out, hipStream_t s)
 {
@@ -1327,10 +1327,10 @@ hipError_t launch_seg_total(const SegTable &st, uint32_t nchunks, const uint32_t
 hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s, const uint32_t *nchunks_dev, bool with_total)
 {
     if (img.nchunks == 0) return hipSuccess;
-    static const bool by_rows = getenv("CVR_SEG_BY_ROWS") != nullptr;      // (diagnostics: the search-based kernel)
+    static const bool by_rows = cvr::debug_env("seg_by_rows") != nullptr;      // (diagnostics: the search-based kernel)
     if (const size_t lds = by_rows ? 0 : seg_scan_lds_bytes(img)) {
         unsigned long long *dbg = nullptr;
-        if (getenv("CVR_SEG_CLOCKS") && hipMalloc(&dbg, sizeof(unsigned long long) * 16 * 64) != hipSuccess) dbg = nullptr;
+        if (cvr::debug_env("seg_clocks") && hipMalloc(&dbg, sizeof(unsigned long long) * 16 * 64) != hipSuccess) dbg = nullptr;
         if (dbg) fprintf(stderr, "[seg_scan] %u chunks, S %d, %u phases, ystage %u, LDS %zu bytes per workgroup\n", img.nchunks, img.S, img.phases, img.ystage, lds);
         hipLaunchKernelGGL(seg_scan_kernel, dim3(img.nchunks), dim3(kSegThreads), lds, s, csr.row_ptr, csr.col_idx, csr.nz_begin, csr.pad_cnt, img.desc, img.desc2,
                            img.nchunks, nchunks_dev, img.phase_width, img.phases, (uint32_t)(kLanes * img.S), st.cnt, reinterpret_cast<uint2 *>(st.begin), st.flags,
@@ -1372,7 +1372,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 {
     if (img.nchunks == 0) return hipSuccess;
     unsigned long long *dbg = nullptr;
-    if (getenv("CVR_CONVERT_CLOCKS") && hipMalloc(&dbg, sizeof(unsigned long long) * 16 * 64) == hipSuccess) {
+    if (cvr::debug_env("convert_clocks") && hipMalloc(&dbg, sizeof(unsigned long long) * 16 * 64) == hipSuccess) {
         (void)hipMemset(dbg, 0, sizeof(unsigned long long) * 16 * 64);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_dbg), &dbg, sizeof(dbg));
     }
@@ -1398,7 +1398,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     } dbg_print{dbg, st, img.nchunks};
     // the LDS-staged kernel: when the values come as dictionary codes (csr.codes), or with CVR_CONVERT_LDS=1 (with the values themselves it
     // is not faster on the web-Google shape: DESIGN.md section 5.11)
-    if (seg && seg->packed && !img.c16 && !img.hub_n && ((csr.codes && img.dict) || getenv("CVR_CONVERT_LDS"))) {
+    if (seg && seg->packed && !img.c16 && !img.hub_n && ((csr.codes && img.dict) || cvr::debug_env("convert_lds"))) {
         const size_t capl = (size_t)kLanes * img.S, vb = img.dict ? 1 : (img.f32 ? 4 : 8), db = img.dict ? (size_t)((img.ndict + 3u) & ~3u) * (img.f32 ? 4 : 8) : 0;
         const size_t lds = 16 * (size_t)kRingHalf + db + capl * (4 + vb) + 16;
         if (lds <= (48u << 10)) {           // at least three chunks per CU
@@ -1421,7 +1421,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     const size_t cap = (size_t)kLanes * img.S;
     size_t       per = seg ? 6 * cap : 4 * (cap + 2);
     per = (per + 15) & ~(size_t)15;
-    static const bool direct = getenv("CVR_CONVERT_DIRECT") != nullptr;       // (diagnostics: the unstaged kernel)
+    static const bool direct = cvr::debug_env("convert_direct") != nullptr;       // (diagnostics: the unstaged kernel)
     const bool   stage = !img.c16 && cap < 65535 && per * kWavesPerBlock <= (20u << 10) && !direct;
     const size_t lds = stage ? per * kWavesPerBlock : 0;
 #define CVR_CONVERT_ARGS(T)                                                                                            \

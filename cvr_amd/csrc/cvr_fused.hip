@@ -40,7 +40,7 @@ struct Attempt {
 }  // namespace
 
 // CVR_FUSED_TRACE=1: why the one-submission path was not taken, on stderr
-#define NOT_TAKEN(why) do { if (getenv("CVR_FUSED_TRACE")) fprintf(stderr, "[cvr fused] not taken: %s\n", why); return CVR_OK; } while (0)
+#define NOT_TAKEN(why) do { if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr fused] not taken: %s\n", why); return CVR_OK; } while (0)
 
 int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f32, int64_t nz0, int64_t nz1, const IOpt &opt, IOpt &popt, bool *taken)
 {
@@ -49,7 +49,7 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     const int64_t nnz = nz1 - nz0, vs = f32 ? 4 : 8;
     // the matrices of auto_layout's resident form, planned on the device, with the probe's usual answer assumed
     if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask) NOT_TAKEN("layout options given");
-    if (getenv("CVR_NO_AUTO_LAYOUT") || getenv("CVR_NO_FUSED") || getenv("CVR_NO_SPECULATIVE_PLAN") || getenv("CVR_HOST_PLAN") || getenv("CVR_SEG_BY_ROWS")) NOT_TAKEN("switched off by the environment");
+    if (cvr::debug_env("no_auto_layout") || cvr::debug_env("no_fused") || cvr::debug_env("no_speculative_plan") || cvr::debug_env("host_plan") || cvr::debug_env("seg_by_rows")) NOT_TAKEN("switched off by the environment");
     if (nrows < 4096 || ncols < 4096 || nrows < device_plan_rows() || nnz <= 0 || nz1 >= (int64_t)0x7fffffff00ll) NOT_TAKEN("too small for the device planner");
     const double xbytes = (double)ncols * vs;
     if (xbytes <= 2.5e6) NOT_TAKEN("x fits the L2s: no column phases");
@@ -97,7 +97,7 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     alloc(&img.stream, (size_t)room * img.G * gb_plain + 8 * gb_plain);      // (room for either form of the values; the staged path's slack behind the last chunk)
     alloc(&at.arena, arena_bytes);
     if (with_dict) alloc(&at.d_dict, (size_t)vs * cvr::kDictMax);
-    if (with_dict && !getenv("CVR_NO_DICT_CODES")) alloc(&at.d_codes, (size_t)nz1);
+    if (with_dict && !cvr::debug_env("no_dict_codes")) alloc(&at.d_codes, (size_t)nz1);
     if (!ok) NOT_TAKEN("no device memory for the attempt's buffers");
     cvr::SegTable seg;
     uint8_t      *res_dev = nullptr;
@@ -218,7 +218,7 @@ int build_part_fused(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bo
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(pstream);
     const double t_end = now_s();
-    if (getenv("CVR_FUSED_TRACE")) fprintf(stderr, "[cvr fused] host: first submission %.0f us, probe + scan waited for until %.0f, dictionary %.0f, second submission %.0f, end %.0f\n", (t_sub1 - t0) * 1e6, (t_probe - t0) * 1e6, (t_dict - t0) * 1e6, (t_sub2 - t0) * 1e6, (t_end - t0) * 1e6);
+    if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr fused] host: first submission %.0f us, probe + scan waited for until %.0f, dictionary %.0f, second submission %.0f, end %.0f\n", (t_sub1 - t0) * 1e6, (t_probe - t0) * 1e6, (t_dict - t0) * 1e6, (t_sub2 - t0) * 1e6, (t_end - t0) * 1e6);
     if (e != hipSuccess) { (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(side); (void)hipStreamSynchronize(pstream); return fail(CVR_ERR_HIP, "fused preprocessing: %s", hipGetErrorString(e)); }
     const int64_t nchunks = (int64_t)res_totals[0], nshared = (int64_t)res_totals[1], most = (int64_t)(res_totals[3] >> 1);
     if ((res_totals[2] & 3ull) || nchunks > room || nshared > dp.bound) NOT_TAKEN("more chunks than workgroup slots (or a row block beyond 32-bit slots)");      // the staged path lengthens the chunks

@@ -156,6 +156,7 @@ int cvr_save_image(cvr_handle *h, const char *path, const cvr_source_key *key)
 
 int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *expect, const cvr_options *opt_in, double *seconds)
 {
+    cvr::debug_refresh();
     if (!out) return fail(CVR_ERR_INVALID, "out is null");
     *out = nullptr;
     if (!path) return fail(CVR_ERR_INVALID, "null argument");

@@ -215,7 +215,7 @@ struct DevRows { const int64_t *rp = nullptr; int64_t nz0 = 0, nz1 = 0; hipStrea
 // matrices of at least this many rows whose row_ptr is on the device anyway are planned there (cvr_plan_dev.hip)
 constexpr int64_t kDevicePlanRows = 200000;
 // (CVR_DEVICE_PLAN_ROWS overrides it: the fuzz tests send their small matrices through the device planner with 0)
-inline int64_t device_plan_rows() { const char *e = getenv("CVR_DEVICE_PLAN_ROWS"); return e ? atoll(e) : kDevicePlanRows; }
+inline int64_t device_plan_rows() { const char *e = cvr::debug_env("device_plan_rows"); return e ? atoll(e) : kDevicePlanRows; }
 
 constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24 << 10, kSmallBytes = 32 << 10;
 constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer

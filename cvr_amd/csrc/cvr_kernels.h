@@ -8,6 +8,11 @@
 
 namespace cvr {
 
+// diagnostics (cvr_debug.cpp): CVR_DEBUG="name[=value],..." in the environment, parsed by debug_refresh() where a call of the C ABI begins;
+// debug_env(name) = the value ("1" without one) or nullptr
+void        debug_refresh();
+const char *debug_env(const char *name);
+
 struct DeviceImage {
     int32_t  S = 0, G = 0;
     bool     f32 = false;

@@ -78,7 +78,7 @@ void plan_stage(PartPlan &pp, bool f32)
         const int64_t vs = f32 ? 4 : 8, total = (int64_t)cvr::kLdsBytes / vs;
         const int64_t fixed = (int64_t)pp.wpb * cvr::kLanes + cvr::kDictMax + 4 + ((pp.hub_n + 3) & ~(int64_t)3);     // dictionary room is reserved before it is known
         int64_t stage = std::min<int64_t>(std::max<int64_t>((pp.max_nseg + 63) / 64 * 64, 64), cvr::kYStageMax);
-        if (const char *cap = getenv("CVR_YSTAGE_CAP")) stage = std::min<int64_t>(stage, std::max<int64_t>(64, atoll(cap) & ~(int64_t)63));      // (experiments: occupancy against staged write-out)
+        if (const char *cap = cvr::debug_env("ystage_cap")) stage = std::min<int64_t>(stage, std::max<int64_t>(64, atoll(cap) & ~(int64_t)63));      // (experiments: occupancy against staged write-out)
         if (fixed + pp.wpb * stage + pp.win > total) stage = std::max<int64_t>(std::min<int64_t>(stage, 512), ((total - fixed - pp.win) / pp.wpb) & ~(int64_t)63);
         if (stage < 64) stage = 64;
         if (fixed + pp.wpb * stage + pp.win > total) pp.win = std::max<int64_t>(0, total - fixed - pp.wpb * stage) & ~(int64_t)3;
@@ -239,7 +239,7 @@ hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64
 bool resident_candidate(double slots, int cus, int *best_w, int *best_S)
 {
     *best_w = 0; *best_S = 0;
-    static const bool old_rule = getenv("CVR_RESIDENT_RULE") && !strcmp(getenv("CVR_RESIDENT_RULE"), "old");
+    static const bool old_rule = cvr::debug_env("resident_rule") && !strcmp(cvr::debug_env("resident_rule"), "old");
     if (old_rule) {
         double best_fill = 0;
         for (int w = 8; w >= 6; w--) {
@@ -266,7 +266,7 @@ bool resident_candidate(double slots, int cus, int *best_w, int *best_S)
 // layout).  cvr_create asks before it decides about column panels.
 bool resident_out_of_reach(int64_t nrows, int64_t nnz, int64_t ncols, bool f32, const IOpt &opt)
 {
-    if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT")) return false;
+    if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || cvr::debug_env("no_auto_layout")) return false;
     if (nrows < 4096 || ncols < 4096 || opt.cus <= 4) return false;
     const int64_t vs = f32 ? 4 : 8;
     const double  slots = ((double)nnz + (double)nrows / 4) * 1.006;
@@ -293,7 +293,7 @@ int auto_layout(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, bool f3
 {
     const int64_t nnz = nz1 - nz0;
     opt.layout_auto_resident = 0;
-    if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || opt.interleave > 0 || getenv("CVR_NO_AUTO_LAYOUT")) {
+    if (opt.steps_per_chunk != 0 || opt.waves_per_block != 0 || opt.x_window >= 0 || opt.col_phases >= 0 || opt.debug_col_mask || opt.interleave > 0 || cvr::debug_env("no_auto_layout")) {
         if (opt.col_phases < 0) opt.col_phases = 0;
         return CVR_OK;
     }
@@ -374,7 +374,7 @@ int choose_hubs(cvr_handle *h, Part &part, const int32_t *d_ci, int64_t nrows, i
     if (opt.hub_table == 0 || opt.layout_auto_resident || opt.col_phases > 1 || opt.interleave > 0 || nrows <= 0 || ncols >= (int64_t)cvr::kHubBit) return CVR_OK;
     const int64_t vs = f32 ? 4 : 8, nnz = nz1 - nz0;
     const bool    automatic = opt.hub_table < 0;
-    if (automatic && (opt.waves_per_block != 0 || opt.x_window > 0 || opt.debug_col_mask || getenv("CVR_NO_AUTO_LAYOUT") || (double)ncols * vs < 6e6 || nnz < (8 << 20))) return CVR_OK;
+    if (automatic && (opt.waves_per_block != 0 || opt.x_window > 0 || opt.debug_col_mask || cvr::debug_env("no_auto_layout") || (double)ncols * vs < 6e6 || nnz < (8 << 20))) return CVR_OK;
     const int     wpb = opt.waves_per_block > 0 ? std::min(opt.waves_per_block, cvr::kMaxWavesPerBlock) : 8;
     const int64_t win = std::max(opt.x_window, 0);
     int64_t       room = ((int64_t)cvr::kLdsBytes / vs - (int64_t)wpb * (cvr::kLanes + 512) - cvr::kDictMax - win - 8) & ~(int64_t)1023;      // 512 staged row sums per chunk
@@ -446,7 +446,7 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
 {
     *done = false;
     const int P = (int)h->parts.size();
-    if (P < 2 || getenv("CVR_SERIAL_PANEL_PLANS") || getenv("CVR_HOST_PLAN")) return CVR_OK;
+    if (P < 2 || cvr::debug_env("serial_panel_plans") || cvr::debug_env("host_plan")) return CVR_OK;
     std::vector<int64_t> bound((size_t)P), maxr((size_t)P);
     size_t               scratch = 0;
     for (int p = 0; p < P; p++) {
@@ -534,7 +534,7 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
         plan_stage(pp, f32);
         drs[(size_t)p] = DevRows{part.d_rp, 0, nzp, h->stream, &h->plan_ws};
     }
-    if (getenv("CVR_FUSED_TRACE")) fprintf(stderr, "[cvr panels] %d chunk plans as one submission\n", P);
+    if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr panels] %d chunk plans as one submission\n", P);
     *done = true;
     return CVR_OK;
 }
@@ -572,7 +572,7 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
         else { plan_view.pinned = nullptr; plan_view.pinned_bytes = 0; }
         struct SyncBack { cvr::PlanScratch &view, &home; ~SyncBack() { home.dev = view.dev; home.dev_bytes = view.dev_bytes; } } sync_back{plan_view, h->plan_ws};      // (the planner may grow its device scratch; also on the error paths)
         DevRows        here{part.d_rp, nz0, nz1, h->stream, &plan_view};
-        const bool     on_dev = rp && nrows > 0 && nrows >= device_plan_rows() && !getenv("CVR_HOST_PLAN");      // (the upload of row_ptr is in front of the planner's kernels on the stream)
+        const bool     on_dev = rp && nrows > 0 && nrows >= device_plan_rows() && !cvr::debug_env("host_plan");      // (the upload of row_ptr is in front of the planner's kernels on the stream)
         const DevRows  via{dr ? dr->rp : nullptr, nz0, nz1, dr ? dr->st : nullptr, &plan_view};      // the caller's device rows, planned through this call's view of the scratch (it may grow: SyncBack)
         const int64_t *prp = on_dev ? nullptr : rp;
         const DevRows *pdr = on_dev ? &here : dr ? &via : nullptr;
@@ -587,7 +587,7 @@ int build_part(cvr_handle *h, Part &part, int64_t nrows, int64_t ncols, const in
             spec_opt = so; spec_done = true; spec_s = now_s() - ts;
             return CVR_OK;
         };
-        int rc = auto_layout(h, part, nrows, ncols, f32, nz0, nz1, popt, on_dev && !getenv("CVR_NO_SPECULATIVE_PLAN") ? &speculate : nullptr);      // (waits for the upload; its own pass is timed into info.probe_s)
+        int rc = auto_layout(h, part, nrows, ncols, f32, nz0, nz1, popt, on_dev && !cvr::debug_env("no_speculative_plan") ? &speculate : nullptr);      // (waits for the upload; its own pass is timed into info.probe_s)
         if (rc) return rc;
         rc = choose_hubs(h, part, part.d_ci, nrows, ncols, f32, nz0, nz1, popt, local, true);
         if (rc) return rc;
@@ -687,7 +687,7 @@ int finish_part(cvr_handle *h, Part &part)
     // descriptor's range check returns zeros for them); the allocation is padded by that much so that the last chunk's
     // run-ahead stays inside it whatever the hardware does with an offset beyond num_records
     const size_t slack = 8 * (size_t)cvr::group_bytes(img.f32, h->d_dict != nullptr, img.c16, img.tag16);
-    if (getenv("CVR_STREAM_UNCACHED"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
+    if (cvr::debug_env("stream_uncached"))   // experiment: matrix image in uncached (MTYPE UC) memory, so that it cannot displace x in L2
         HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, part.stream_bytes + slack, hipDeviceMallocUncached));
     else
         HIP_TRY(hipMalloc(&img.stream, part.stream_bytes + slack));

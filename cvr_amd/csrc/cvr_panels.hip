@@ -162,7 +162,7 @@ int panels_from_miss(double xb, double miss) { return miss > 0.17 ? std::min(64,
 // rule's count (each panel over the whole chip), CVR_XCD_PANELS=<n > 1> sets the count itself (experiments).
 int xcd_panel_count(int P, double xbytes)
 {
-    const char *e = getenv("CVR_XCD_PANELS");
+    const char *e = cvr::debug_env("xcd_panels");
     if (P <= 1 || (e && atoi(e) == 0)) return P;
     if (e && atoi(e) > 1) return std::min(64, atoi(e));
     if (xbytes <= 27e6) return 8;       // (the first round of eight stretches further: web-Google shapes of 23.5 / 26.4 MB 98.0 / 110.1 us as 8, 102.0 / 111.6 as 16 panels)
@@ -195,6 +195,7 @@ extern "C" {
 
 int cvr_auto_panels(const cvr_csr_view *csr, double *l2_miss_estimate_out)
 {
+    cvr::debug_refresh();
     if (!csr) return fail(CVR_ERR_INVALID, "null argument");
     if (csr->arrays_on_device) return fail(CVR_ERR_INVALID, "cvr_auto_panels reads host arrays");
     if (csr->nrows > 0 && (!csr->row_ptr || (csr->row_ptr[csr->nrows] > 0 && !csr->col_idx))) return fail(CVR_ERR_INVALID, "null argument");

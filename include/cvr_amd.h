@@ -115,7 +115,7 @@ typedef struct {
 /* Automatic layout: with steps_per_chunk = 0, waves_per_block = 0, x_window < 0 and col_phases < 0 (the defaults) cvr_create
  * looks at the uploaded CSR on the device (are the rows sorted by column? which share of the non-zeros lies near the
  * diagonal?) and, for matrices whose chunks can all be resident at once, picks 6-8 chunks per workgroup sharing a 64-KiB LDS
- * window of x and/or column phases; everything else keeps one chunk per workgroup.  CVR_NO_AUTO_LAYOUT=1 in the environment
+ * window of x and/or column phases; everything else keeps one chunk per workgroup.  CVR_DEBUG=no_auto_layout in the environment
  * or any explicit value of those four options switches it off.
  * The one profiling knob is not part of this struct: CVR_DEBUG_COL_MASK in the environment (folds the gather onto a 2^k-entry table:
  * wrong results, timing only) is read by cvr_create. */

@@ -43,11 +43,11 @@ def _random_case(rng):
 def test_fuzz_parity_through_the_device_planner():
     """the same cases with every matrix planned on the device (cvr_plan_dev.hip; cvr_create uses it from 200 000 rows on):
     the image is still the mirror's bit for bit"""
-    os.environ["CVR_DEVICE_PLAN_ROWS"] = "0"
+    os.environ["CVR_DEBUG"] = "device_plan_rows=0"
     try:
         test_fuzz_parity(int(os.environ.get("CVR_FUZZ_CASES", "96")), 20261003)
     finally:
-        del os.environ["CVR_DEVICE_PLAN_ROWS"]
+        del os.environ["CVR_DEBUG"]
 
 
 def test_fuzz_parity(ncases=None, seed=None):
@@ -135,11 +135,11 @@ def test_fuzz_one_submission_preprocessing():
         va = M.data.astype(np.float32 if f32 else np.float64)
         ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), f32=f32, few=few)
         A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
-        os.environ["CVR_NO_FUSED"] = "1"
+        os.environ["CVR_DEBUG"] = "no_fused"
         try:
             B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
         finally:
-            del os.environ["CVR_NO_FUSED"]
+            del os.environ["CVR_DEBUG"]
         ia, ib = A.info, B.info
         taken += ia.preprocess_fused
         for f in ("steps_per_chunk", "waves_per_block", "x_window", "col_phases", "value_dict", "nchunks", "nshared", "nsegments", "row_tags16", "piece_max", "chunk_row_cap"):

@@ -281,7 +281,7 @@ def test_timed_configuration_full_size_strict(value_dict):
 @pytest.mark.parametrize("kind", ["pattern", "values_fp32", "long_rows"])
 def test_fused_preprocessing_same_image(kind, monkeypatch):
     """cvr_create's one-submission preprocessing (cvr_fused.hip: planner -> per-chunk tables on the device -> segment table ->
-    conversion without the host in between) gives the image, the descriptors and the y bits of the staged path (CVR_NO_FUSED);
+    conversion without the host in between) gives the image, the descriptors and the y bits of the staged path (CVR_DEBUG=no_fused);
     with rows cut over chunks (their fix-up list comes from the device plan), fp32 values and no dictionary as well."""
     nrows, ncols, rp, ci, va = synth.web_google_like(1.0 if kind == "values_fp32" else 0.5)      # (x of more than 2.5 MB: column phases)
     if kind == "values_fp32":
@@ -296,9 +296,9 @@ def test_fused_preprocessing_same_image(kind, monkeypatch):
         M.sort_indices()
         rp, ci, va = M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data.astype(np.float64)
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
-    monkeypatch.setenv("CVR_NO_FUSED", "1")
+    monkeypatch.setenv("CVR_DEBUG", "no_fused")
     B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
-    monkeypatch.delenv("CVR_NO_FUSED")
+    monkeypatch.delenv("CVR_DEBUG")
     ia, ib = A.info, B.info
     assert ia.preprocess_fused == 1 and ib.preprocess_fused == 0
     for f in ("steps_per_chunk", "waves_per_block", "x_window", "col_phases", "value_dict", "nchunks", "nshared", "nsegments", "row_tags16", "piece_max",
@@ -320,15 +320,15 @@ def test_fused_preprocessing_same_image(kind, monkeypatch):
 
 @pytest.mark.parametrize("kind", ["pattern", "values_fp32"])
 def test_lds_staged_converter_same_image(kind, monkeypatch):
-    """CVR_CONVERT_LDS=1: the converter that copies a chunk's columns and values (as dictionary codes) into LDS first and passes the feed
+    """CVR_DEBUG=convert_lds: the converter that copies a chunk's columns and values (as dictionary codes) into LDS first and passes the feed
     table through a ring there (convert_lds_kernel; measured and not the default: DESIGN.md section 5.7) writes the default converter's image."""
     nrows, ncols, rp, ci, va = synth.web_google_like(1.0 if kind == "values_fp32" else 0.5)
     if kind == "values_fp32":
         va = np.random.default_rng(5).standard_normal(len(ci)).astype(np.float32)
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
-    monkeypatch.setenv("CVR_CONVERT_LDS", "1")
+    monkeypatch.setenv("CVR_DEBUG", "convert_lds")
     B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
-    monkeypatch.delenv("CVR_CONVERT_LDS")
+    monkeypatch.delenv("CVR_DEBUG")
     assert A.info.col_phases > 1 and A.info.nchunks == B.info.nchunks
     ea, eb = A.export_image(), B.export_image()
     for key in ("desc", "target", "shared", "image"):
@@ -415,24 +415,24 @@ def test_fused_preprocessing_other_inputs(kind, monkeypatch):
         view_rp = rp[r0:].copy()                                  # starts at rp[r0] > 0: col_idx / vals are indexed from 0
         lrows = nrows - r0
         A = cvr_amd.CvrMatrix(lrows, ncols, view_rp, ci, va)
-        monkeypatch.setenv("CVR_NO_FUSED", "1")
+        monkeypatch.setenv("CVR_DEBUG", "no_fused")
         B = cvr_amd.CvrMatrix(lrows, ncols, view_rp, ci, va)
-        monkeypatch.delenv("CVR_NO_FUSED")
+        monkeypatch.delenv("CVR_DEBUG")
         yref, absy = O.csr_spmv64(view_rp - view_rp[0], ci[view_rp[0]:], va[view_rp[0]:], x)
     elif kind == "device_arrays":
         import torch
         keep = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp, ci, va)]
         torch.cuda.synchronize()
         A = cvr_amd.CvrMatrix.from_device(nrows, ncols, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr())
-        monkeypatch.setenv("CVR_NO_FUSED", "1")
+        monkeypatch.setenv("CVR_DEBUG", "no_fused")
         B = cvr_amd.CvrMatrix.from_device(nrows, ncols, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr())
-        monkeypatch.delenv("CVR_NO_FUSED")
+        monkeypatch.delenv("CVR_DEBUG")
         yref, absy = O.csr_spmv64(rp, ci, va, x)
     else:
         A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, keep_csr=(kind == "reconvert"))
-        monkeypatch.setenv("CVR_NO_FUSED", "1")
+        monkeypatch.setenv("CVR_DEBUG", "no_fused")
         B = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
-        monkeypatch.delenv("CVR_NO_FUSED")
+        monkeypatch.delenv("CVR_DEBUG")
         yref, absy = O.csr_spmv64(rp, ci, va, x)
     assert A.info.preprocess_fused == 1 and B.info.preprocess_fused == 0
     if kind == "reconvert":
@@ -782,7 +782,7 @@ def test_power_iteration_device_resident():
 def test_power_iteration_step_in_the_spmv_epilogue(monkeypatch):
     """On a matrix in the resident layout (column phases, no rows cut over chunks) the step's dot products and the next iterate come
     out of the SpMV kernel's write-out (IterEpilogue): against the numpy loop, bit for bit again on a second run, against the loop with
-    the step as a pass of its own (CVR_ITER_UNFUSED), and fp32 with an eigenvalue whose square leaves fp32 (exact normalisation)."""
+    the step as a pass of its own (CVR_DEBUG=iter_unfused), and fp32 with an eigenvalue whose square leaves fp32 (exact normalisation)."""
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
@@ -797,9 +797,9 @@ def test_power_iteration_step_in_the_spmv_epilogue(monkeypatch):
     assert np.allclose(x.cpu().numpy(), x_ref, rtol=0, atol=1e-9)
     lam2, x2, sec2 = power.power_iteration(A, nrows, iters=25)
     assert lam2 == lam and torch.equal(x2.view(torch.int64), x.view(torch.int64))
-    monkeypatch.setenv("CVR_ITER_UNFUSED", "1")
+    monkeypatch.setenv("CVR_DEBUG", "iter_unfused")
     lam3, x3, sec3 = power.power_iteration(A, nrows, iters=25)
-    monkeypatch.delenv("CVR_ITER_UNFUSED")
+    monkeypatch.delenv("CVR_DEBUG")
     assert abs(lam3 - lam) <= 1e-12 * abs(lam) and np.allclose(x3.cpu().numpy(), x.cpu().numpy(), rtol=0, atol=1e-12)
     assert min(sec, sec2) < sec3                     # one launch per iteration against two
     A.close()
@@ -853,19 +853,19 @@ def test_column_panels_livejournal_shape():
 
 def test_panel_plans_as_one_submission_same_result(monkeypatch, capfd):
     """Column panels split on the device, without hub tables: all panels' chunk plans are enqueued together and write nzb / pad / desc /
-    cut rows on the device (plan_panels_batched); against the panel-by-panel path (CVR_SERIAL_PANEL_PLANS): same counts, same y bits; y
+    cut rows on the device (plan_panels_batched); against the panel-by-panel path (CVR_DEBUG=serial_panel_plans): same counts, same y bits; y
     against the CSR oracle.  (hub_table = 0 takes the matrix down that path whatever its columns' popularity.)"""
     nrows, ncols, rp, ci, va = synth.livejournal_like(scale=0.25)
     x = O.x_vec_fast(ncols, "rand")
     yref, absy = O.csr_spmv64(rp, ci, va, x)
     got = []
-    monkeypatch.setenv("CVR_FUSED_TRACE", "1")
+    monkeypatch.setenv("CVR_DEBUG", "fused_trace")
     for serial in (False, True):
         if serial:
-            monkeypatch.setenv("CVR_SERIAL_PANEL_PLANS", "1")
+            monkeypatch.setenv("CVR_DEBUG", "fused_trace,serial_panel_plans")
         A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=8, hub_table=0)
         if serial:
-            monkeypatch.delenv("CVR_SERIAL_PANEL_PLANS")
+            monkeypatch.setenv("CVR_DEBUG", "fused_trace")
         i = A.info
         y, _ = A.spmv(x)
         got.append(((i.col_panels, i.nchunks, i.nshared, i.steps_per_chunk, i.lds_bytes, i.spmv_launches), y))
@@ -1089,7 +1089,7 @@ def test_large_device_arrays_are_checked_and_planned_where_they_are():
 
 def test_device_arrays_with_column_panels_are_split_on_the_device():
     """the column-panel split runs on the device (cvr_split.hip: one stable radix-sort pass by panel), for device-resident
-    arrays and for host arrays (staged once); bit for bit the same y as the host split (CVR_HOST_SPLIT=1, the fallback) of
+    arrays and for host arrays (staged once); bit for bit the same y as the host split (CVR_DEBUG=host_split, the fallback) of
     the same matrix -- sorted and unsorted rows, empty rows, fp32, 2..64 panels"""
     import torch
     dev = torch.device("cuda", 0)
@@ -1115,11 +1115,11 @@ def test_device_arrays_with_column_panels_are_split_on_the_device():
         tva = torch.from_numpy(np.ascontiguousarray(va)).to(dev)
         torch.cuda.synchronize()
         f32 = va.dtype == np.float32
-        os.environ["CVR_HOST_SPLIT"] = "1"                       # the threaded counting sort on the host (the fallback path)
+        os.environ["CVR_DEBUG"] = "host_split"                       # the threaded counting sort on the host (the fallback path)
         try:
             A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=P)
         finally:
-            del os.environ["CVR_HOST_SPLIT"]
+            del os.environ["CVR_DEBUG"]
         B = cvr_amd.CvrMatrix.from_device(nrows, ncols, trp.data_ptr(), tci.data_ptr(), tva.data_ptr(), is_f32=f32, col_panels=P)
         C2 = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=P)      # host arrays, staged to the device and split there
         assert A.info.col_panels == P and B.info.col_panels == P and C2.info.col_panels == P
@@ -1381,6 +1381,8 @@ def test_full_size_shapes_every_row(name):
 def test_amortisation_report_small():
     """paper Eq. 1 / Table 4 (reference: run_comparison.sh:20-45): CVR64 against the CSR comparators on the same GPU, every
     result checked against the oracle; I_pre with T_pre = planner + probe + dictionary scan + conversion, and with H2D"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import compare_csr as R
     nrows, ncols, rp, ci, va = synth.web_google_like(scale=0.1)
     out = R.report(nrows, ncols, rp, ci, va, iters=50, name="webgoogle/10")

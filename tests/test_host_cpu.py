@@ -264,7 +264,7 @@ def test_size_limits_are_rejected_with_a_message():
 
 def test_auto_panel_rule_on_the_host():
     """cvr_auto_panels: x small -> 1; x large and banded (lines re-used) -> 1; x large and scattered -> panels: in rounds of
-    eight with ~2.6 MB of x each (one panel per XCD at a time), or, with CVR_XCD_PANELS=0 (every panel over the whole chip), one
+    eight with ~2.6 MB of x each (one panel per XCD at a time), or, with CVR_DEBUG=xcd_panels=0 (every panel over the whole chip), one
     per 1.8 MB of missing x; comm / tuning entry points fail with codes (no device here)"""
     rng = np.random.default_rng(5)
     n = 4_000_000                                                          # x = 32 MB of fp64
@@ -272,11 +272,11 @@ def test_auto_panel_rule_on_the_host():
     scattered = rng.integers(0, n, 2 * n).astype(np.int32)
     P, miss = capi.auto_panels(n, n, rp, scattered)
     assert miss > 0.6 and P == 8 * int(np.ceil(n * 8 / (8 * 2.6e6)))
-    os.environ["CVR_XCD_PANELS"] = "0"
+    os.environ["CVR_DEBUG"] = "xcd_panels=0"
     try:
         P0, miss0 = capi.auto_panels(n, n, rp, scattered)
     finally:
-        del os.environ["CVR_XCD_PANELS"]
+        del os.environ["CVR_DEBUG"]
     assert miss0 == miss and P0 == int(n * 8 * miss / 1.8e6 + 0.5)
     band = (np.repeat(np.arange(n, dtype=np.int64), 2) + np.tile([0, 3], n)).clip(0, n - 1).astype(np.int32)
     P, miss = capi.auto_panels(n, n, rp, band)

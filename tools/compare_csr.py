@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""tests/compare_csr.py [matrix] -- preprocessing-amortisation report (paper Eq. 1; Tables 1 and 4):
+"""tools/compare_csr.py [matrix] -- preprocessing-amortisation report (paper Eq. 1; Tables 1 and 4):
     I_pre = T_pre(CVR) / (T_spmv(baseline) - T_spmv(CVR))
 with GPU-resident CSR baselines on the same device: a plain CSR-vector kernel and rocSPARSE (adaptive, rowsplit,
 LRB).  The paper's baseline is MKL's CSR on KNL (I_pre = 8.4 iterations on web-Google, Table 4).
-Comparators live in cvr_amd/libcvr_cmp.so; they are sanity comparators, not oracles."""
+Comparators live in cvr_amd/libcvr_cmp.so; they are sanity comparators, not oracles.  Results are checked against the library's host CSR
+loop (cvr_csr_spmv_host: the reference's self-check loop, spmv.cpp:1843-1850, pinned on the golden fixtures by tests/test_oracle_pin.py);
+the parity tests proper -- against the oracle -- live under tests/."""
 import ctypes as C
 import json
 import os
@@ -13,9 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cvr_amd
-import oraclelib as O
 from cvr_amd import synth
 
 L = C.CDLL(os.path.join(ROOT, "cvr_amd", "libcvr_cmp.so"))
@@ -28,24 +28,35 @@ L.cmp_csr_destroy.argtypes = [C.c_void_p]
 KINDS = {0: "csr_vector (own)", 1: "rocsparse adaptive", 2: "rocsparse rowsplit"}
 
 
+def _csr_check(rp, ci, va, x):
+    """y and sum |a x| per row by the library's host loop (all cores)"""
+    nt = len(os.sched_getaffinity(0))
+    return (cvr_amd.csr_spmv_host(rp, ci, va.astype(np.float64), x.astype(np.float64), nthreads=nt),
+            cvr_amd.csr_spmv_host(rp, ci, np.abs(va).astype(np.float64), np.abs(x).astype(np.float64), nthreads=nt))
+
+
+def _rows_off(y, yref, absy, tol=1e-12):
+    return int(np.count_nonzero(np.abs(np.asarray(y, dtype=np.float64) - yref) > tol * absy + 1e-300))
+
+
 def report(n, nc, rp, ci, va, iters=200, name="matrix"):
     """the amortisation report of one matrix: CVR64 and the CSR comparators on the same GPU, every result checked against
     the CSR oracle; I_pre with T_pre = planner + layout probe + dictionary scan + conversion (device-resident CSR), and with
     the host-to-device upload of the CSR on top"""
     nnz = len(ci)
     x = synth.x_rand(nc)
-    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    yref, absy = _csr_check(rp, ci, va, x)
     cvr_amd.CvrMatrix(n, nc, rp, ci, va).close()      # the first handle of a process pays for code loading and the planner's thread pool: not preprocessing
     A = cvr_amd.CvrMatrix(n, nc, rp, ci, va)
     y, _ = A.spmv(x)
-    cvr_ok = len(O.tol_check(y, yref, absy)[0]) == 0
+    cvr_ok = _rows_off(y, yref, absy) == 0
     t_cvr = A.bench(20, iters)
     i = A.info
     t_pre = i.plan_s + i.probe_s + i.hub_select_s + i.dict_s + i.preprocess_wall_s
     t_pre_h2d = i.plan_s + i.probe_s + i.hub_select_s + i.upload_s + i.preprocess_wall_s          # upload_s holds the H2D copies and the dictionary scan
     out = {"matrix": name, "rows": n, "nnz": nnz, "cvr": {"spmv_us": t_cvr * 1e6, "gflops": 2 * nnz / t_cvr / 1e9, "result_ok": cvr_ok,
            "layout": {"steps_per_chunk": i.steps_per_chunk, "waves_per_workgroup": i.waves_per_block, "x_window": i.x_window, "col_phases": i.col_phases,
-                      "col_panels": i.col_panels, "value_dict": i.value_dict},
+                      "col_panels": i.col_panels, "value_dict": i.value_dict, "interleave": i.interleave},
            "preprocess_us": {"plan": i.plan_s * 1e6, "layout_probe": i.probe_s * 1e6, "hub_selection": i.hub_select_s * 1e6, "dict_scan": i.dict_s * 1e6, "convert_device_events": i.convert_s * 1e6,
                              "preprocess_wall": i.preprocess_wall_s * 1e6, "one_submission": bool(i.preprocess_fused), "upload_incl_dict_scan": i.upload_s * 1e6, "total": t_pre * 1e6, "total_with_h2d": t_pre_h2d * 1e6}},
            "baselines": {}}
@@ -62,7 +73,7 @@ def report(n, nc, rp, ci, va, iters=200, name="matrix"):
             continue
         yb = np.zeros(n)
         L.cmp_csr_get_y(h, yb.ctypes.data)
-        ok = len(O.tol_check(yb, yref, absy, tol=1e-11)[0]) == 0
+        ok = _rows_off(yb, yref, absy, tol=1e-11) == 0
         gain = s.value - t_cvr
         out["baselines"][label] = {"spmv_us": s.value * 1e6, "gflops": 2 * nnz / s.value / 1e9, "own_preprocess_us": p.value * 1e6,
                                    "result_ok": ok, "cvr_speedup": s.value / t_cvr,
@@ -86,6 +97,11 @@ def main():
         n, nc, rp, ci, va = synth.banded_sym(int(float(name[4:])))
     elif name.startswith("rmat"):
         n, nc, rp, ci, va = synth.rmat(int(name[4:]), dtype=np.float64)
+    elif name in ("orkut", "wikitalk"):          # the stand-ins that are built on the device (cvr_amd/synth_dev.py)
+        from cvr_amd import synth_dev as D
+        n, rp_t, ci_t, va_t = (D.orkut_like if name == "orkut" else D.wikitalk_like)(device="cuda")
+        nc, rp, ci, va = n, rp_t.cpu().numpy(), ci_t.cpu().numpy(), va_t.cpu().numpy()
+        del rp_t, ci_t, va_t
     else:
         raise SystemExit("unknown matrix")
     print(json.dumps(report(n, nc, rp, ci, va, iters, name), indent=1))

@@ -9,9 +9,9 @@
 MAT=${1:-webgoogle}; IT=${2:-20}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/locality_$MAT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 i=0
-for grp in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_LEVEL_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
+for grp in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_LEVEL_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum"; do
   i=$((i+1))
-  ( cd $R && timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 tests/compare_csr.py $MAT $IT > $OUT/p$i.json 2> $OUT/p$i.err )
+  ( cd $R && timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 tools/compare_csr.py $MAT $IT > $OUT/p$i.json 2> $OUT/p$i.err )
 done
 python3 - <<PY > $R/gpurun_out/locality_$MAT.txt
 import csv, glob, collections, json
@@ -20,7 +20,7 @@ def group(k):
     if "rocsparse" in k:
         return "rocSPARSE " + ("adaptive" if "adaptive" in k or "csrmvn_adaptive" in k else "row-split / general" if "csrmvn" in k else "other")
     if "csr_vector_kernel" in k: return "CSR-vector (own comparator)"
-    for s in ("spmv_seg_kernel", "spmv_kernel", "combine_kernel", "fixup", "hub_gather"):
+    for s in ("spmv_ilv_kernel", "spmv_seg_kernel", "spmv_kernel", "combine_kernel", "fixup", "hub_gather"):
         if s in k: return "CVR64 (all kernels of an SpMV)"
     return None
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -46,12 +46,16 @@ except Exception as e:
 # SpMVs executed per group: compare_csr runs 1 warm-up + 1 timed (cvr_spmv) + 20 + iters (bench) for CVR64, 20 + iters per comparator kernel
 nsp = {"CVR64 (all kernels of an SpMV)": 22 + it}
 print("# per SpMV (sums over all launches / number of SpMVs)")
-print(f"{'kernels':34s} {'us (profiled)':>13s} {'L1->L2 reads':>13s} {'lat (clk)':>10s} {'L2 hit %':>9s} {'fabric reads':>13s} {'to DRAM':>12s} {'fabric lat (clk)':>16s}")
+nnz = rep["nnz"] if "rep" in dir() else 0
+print("# requests / nnz: L1->L2 read requests of all kernels of an SpMV (x gathers, matrix stream, tables) per non-zero; L1 lines: the vector L1s' cache-line accesses (tag look-ups)")
+print(f"{'kernels':34s} {'us (profiled)':>13s} {'L1->L2 reads':>13s} {'req / nnz':>10s} {'L1 lines':>12s} {'L1 hit %':>9s} {'lat (clk)':>10s} {'L2 hit %':>9s} {'fabric reads':>13s} {'to DRAM':>12s} {'fabric lat (clk)':>16s}")
 for g, c in sorted(agg.items()):
     n = nsp.get(g, 20 + it)
     hit = 100.0 * c.get("TCC_HIT_sum", 0) / max(c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0), 1)
     lat = c.get("TCP_TCC_READ_REQ_LATENCY_sum", 0) / max(c.get("TCP_TCC_READ_REQ_sum", 1), 1)
     flat = c.get("TCC_EA0_RDREQ_LEVEL_sum", 0) / max(c.get("TCC_EA0_RDREQ_sum", 1), 1)
-    print(f"{g:34s} {dur[g] / n:13.1f} {c.get('TCP_TCC_READ_REQ_sum', 0) / n:13.0f} {lat:10.0f} {hit:9.1f} {c.get('TCC_EA0_RDREQ_sum', 0) / n:13.0f} {c.get('TCC_EA0_RDREQ_DRAM_sum', 0) / n:12.0f} {flat:16.0f}")
+    l1 = c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0) / n
+    l1hit = 100.0 * (1.0 - (c.get("TCP_TCC_READ_REQ_sum", 0) / n) / l1) if l1 > 0 else float("nan")
+    print(f"{g:34s} {dur[g] / n:13.1f} {c.get('TCP_TCC_READ_REQ_sum', 0) / n:13.0f} {c.get('TCP_TCC_READ_REQ_sum', 0) / n / max(nnz, 1):10.3f} {l1:12.0f} {l1hit:9.1f} {lat:10.0f} {hit:9.1f} {c.get('TCC_EA0_RDREQ_sum', 0) / n:13.0f} {c.get('TCC_EA0_RDREQ_DRAM_sum', 0) / n:12.0f} {flat:16.0f}")
 PY
 cat $R/gpurun_out/locality_$MAT.txt
