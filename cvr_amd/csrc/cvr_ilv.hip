@@ -12,11 +12,12 @@
 //   slots e <  n (the chunk's non-zeros)     : column | end flag [| row << col_bits], value / code, [tag = row]
 //   slots e >= n (padding up to 64 S; the pad slots the planner counts for empty rows among them): pad column (x_ext[ncols] = 0),
 //                                              value 0, row = the dump entry behind the chunk's rows
-// Preprocessing: a stable segmented radix sort of (column, position) over the chunks' element ranges (hipCUB), then one pass that writes
+// Preprocessing: one workgroup per chunk sorts the chunk's (column, position) pairs in LDS (hipCUB block radix sort, stable) and writes
 // the groups.
 #include "cvr_kernels.h"
 
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/block/block_radix_sort.hpp>
 
 #include <algorithm>
 #include <type_traits>
@@ -47,132 +48,125 @@ __device__ __forceinline__ uint32_t part_of_chunk(const IlvTable *__restrict__ t
     return p;
 }
 
-// key = chunk (numbered over all parts) << cbits | column inside the image (relative to col_base), value = position in the concatenation:
-// one stable radix sort over these keys sorts every chunk's non-zeros by column (ties: by position, i.e. by row), the chunks staying in
-// place.  One workgroup per chunk (its part and number are the workgroup's: no search per element).  Also desc2[k].x = the groups of
-// chunk k that hold non-zeros (the SpMV kernel stops there).
-template <typename K>
-__global__ __launch_bounds__(256) void ilv_keys_kernel(const IlvTable *__restrict__ t, uint32_t cbits, K *__restrict__ key, uint32_t *__restrict__ idx)
-{
-    const uint32_t    kk = blockIdx.x;
-    const IlvPartDev &q = t->part[part_of_chunk(t, kk)];
-    const uint32_t    k = kk - q.chunk0;
-    const int64_t     b = q.nzb[k], n = q.nzb[k + 1] - b, E0 = q.e0 + (b - q.n0);
-    if (threadIdx.x == 0) q.desc2[k].x = (uint32_t)((n + 255) / 256);
-    const K hi = (K)kk << cbits;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        key[E0 + i] = hi | (K)((uint32_t)q.ci[b + i] - q.col_base);
-        idx[E0 + i] = (uint32_t)(E0 + i);
-    }
-}
+// One workgroup per chunk (its part and number are the workgroup's: no search per element) does the whole conversion on chip:
+//   1. the starts of the chunk's rows (relative to its first position, clipped to the chunk) go to LDS; thread t takes the positions
+//      [t IPT, (t + 1) IPT) of the chunk's CSR range and finds their rows (one search, then a walk);
+//   2. a stable block radix sort (hipCUB, LDS only) of (column inside the image, position | row << 15) by the column's bits: ties keep
+//      their positions' order, i.e. ascend by row; positions behind the chunk's non-zeros carry the pad column and stay behind;
+//   3. element e of the sorted list = thread e % NT, item e / NT (striped), written to step e / 64, lane e % 64 of the chunk.
+// (Round 4 began with one device-wide radix sort of chunk << bits | column over all panels: 4 passes of 8 bytes per non-zero through
+// HBM, 2.0 of the 8.0 ms of the soc-LiveJournal1 shape's preprocessing, and 24 bytes of scratch per non-zero.)
+// Also desc2[k].x = the groups of chunk k that hold non-zeros (the SpMV kernel stops there).
+constexpr uint32_t kIlvF32 = 1u, kIlvDict = 2u, kIlvTag = 4u;
+template <int NT, int IPT, int RB> struct ChunkSort { typedef rocprim::block_radix_sort<uint32_t, NT, IPT, uint32_t, 1, 1, RB> type; };
 
-// One workgroup per chunk: the starts of the chunk's rows (relative to its first position, clipped to the chunk) go to LDS once, then the
-// threads walk the chunk's slots -- thread t of a group of 256 slots writes lane t & 63 at step t >> 6 -- and find the row of an element
-// by a search in LDS.
-constexpr int kEmitThreads = 1024;
-template <typename T, bool DICT, bool TAG, typename K>
-__global__ __launch_bounds__(kEmitThreads) void ilv_emit_kernel(const IlvTable *__restrict__ t, const K *__restrict__ skey, const uint32_t *__restrict__ sidx, const T *__restrict__ dict,
-                                                                uint32_t ndict, int G, uint32_t col_bits, uint32_t cbits, uint32_t *__restrict__ err)
+template <int NT, int IPT, int RB>
+__global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restrict__ t, const void *__restrict__ dict_v, uint32_t ndict, int G, uint32_t col_bits, uint32_t cbits,
+                                                                  uint32_t flags, uint32_t *__restrict__ err)
 {
-    constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
-    constexpr uint32_t VB = kColsBytes + (TAG ? kTagBytes : 0);
-    extern __shared__ uint32_t rstart[];                         // [nri]: where row i of the chunk starts among the chunk's elements
+    typedef typename ChunkSort<NT, IPT, RB>::type Sort;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *const   rstart = reinterpret_cast<uint32_t *>(smem);       // [nri]; the sort's storage takes its place afterwards
+    const bool        f32 = flags & kIlvF32, use_dict = flags & kIlvDict, tag = flags & kIlvTag;
     const uint32_t    kk = blockIdx.x;
     const IlvPartDev &q = t->part[part_of_chunk(t, kk)];
     const uint32_t    k = kk - q.chunk0;
-    const int64_t     b = q.nzb[k], n = q.nzb[k + 1] - b;
+    const int64_t     b = q.nzb[k];
+    const uint32_t    n = (uint32_t)(q.nzb[k + 1] - b);
     const uint32_t    row_first = q.desc[k].x, nri = q.desc2[k].y;
-    const int64_t     E0 = q.e0 + (b - q.n0);                    // the chunk's first element in the sorted arrays
+    if (threadIdx.x == 0) q.desc2[k].x = (n + 255u) / 256u;
     for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
-        const int64_t r = q.rp[row_first + i] - b;               // (a row cut over chunks begins before the chunk)
-        rstart[i] = (uint32_t)(r < 0 ? 0 : r > n ? n : r);
+        const int64_t r = q.rp[row_first + i] - b;                       // (a row cut over chunks begins before the chunk)
+        rstart[i] = (uint32_t)(r < 0 ? 0 : r > (int64_t)n ? (int64_t)n : r);
     }
     __syncthreads();
-    uint32_t code0 = 0;                                           // the code of +0.0 (cvr_create puts it into every dictionary)
-    if constexpr (DICT) {
-        typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type U;
-        while (code0 < ndict && __builtin_bit_cast(U, dict[code0]) != (U)0) code0++;
+    uint32_t       key[IPT], val[IPT];
+    const uint32_t p0 = threadIdx.x * IPT;
+    uint32_t       row = 0;
+    if (p0 < n && nri > 1) {                                              // the last row that starts at or before p0
+        uint32_t lo = 0, hi = nri;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rstart[mid] <= p0) lo = mid; else hi = mid; }
+        row = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const uint32_t p = p0 + i;
+        if (p < n) {
+            while (row + 1 < nri && rstart[row + 1] <= p) row++;
+            key[i] = (uint32_t)q.ci[b + p] - q.col_base;
+            val[i] = p | (row << 15);
+        } else { key[i] = q.pad_col; val[i] = 0xffffffffu; }
+    }
+    __syncthreads();
+    if (!(flags & 8u)) Sort().sort_to_striped(key, val, *reinterpret_cast<typename Sort::storage_type *>(smem), 0u, cbits);
+    if (flags & 16u) return;
+
+    uint32_t code0 = 0;                                                   // the code of +0.0 (cvr_create puts it into every dictionary)
+    const uint64_t *const d64 = static_cast<const uint64_t *>(dict_v);
+    const uint32_t *const d32 = static_cast<const uint32_t *>(dict_v);
+    if (use_dict) {
+        while (code0 < ndict && (f32 ? (uint64_t)d32[code0] : d64[code0]) != 0) code0++;
         if (code0 >= ndict) { if (threadIdx.x == 0) atomicOr(err, 4u); code0 = 0; }
     }
-    const int64_t nslots = (int64_t)G * 256;
-    for (int64_t e = threadIdx.x; e < nslots; e += blockDim.x) {
-        const uint32_t g = (uint32_t)(e >> 8), j = (uint32_t)(e >> 6) & 3u, lane = (uint32_t)e & 63u;
-        uint32_t col = q.pad_col, row = nri, code = code0;
-        T        v = T(0);
+    const uint32_t GB = (use_dict ? kGroupBytesDict : f32 ? kGroupBytes32 : kGroupBytes64) + (tag ? kTagBytes : 0);
+    const uint32_t VB = kColsBytes + (tag ? kTagBytes : 0);
+    const uint32_t nslots = (uint32_t)G * 256u;
+    uint8_t *const base = q.stream + (size_t)k * G * GB;
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const uint32_t e = (uint32_t)i * NT + threadIdx.x;
+        if (e >= nslots) break;
+        const uint32_t g = e >> 8, j = (e >> 6) & 3u, lane = e & 63u;
+        uint32_t col = q.pad_col, r = nri, code = code0;
+        uint64_t bits = 0;
         if (e < n) {
-            const uint32_t pe = (uint32_t)((int64_t)sidx[E0 + e] - E0);      // the element's place among the chunk's, in CSR order
-            col = (uint32_t)(skey[E0 + e] & (((K)1 << cbits) - 1));          // (relative to the image's first column)
-            uint32_t lo = 0, hi = nri;                                        // its row: the last one that starts at or before it
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rstart[mid] <= pe) lo = mid; else hi = mid; }
-            row = lo;
-            const T val = static_cast<const T *>(q.vals)[b + pe];
-            if constexpr (DICT) {
-                uint32_t a = 0, z = ndict;                                    // the dictionary is sorted by bit pattern
-                typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type U;
-                const U  bits = __builtin_bit_cast(U, val);
-                while (a < z) { const uint32_t m = (a + z) >> 1; if (__builtin_bit_cast(U, dict[m]) < bits) a = m + 1; else z = m; }
-                if (a >= ndict || __builtin_bit_cast(U, dict[a]) != bits) { atomicOr(err, 4u); a = 0; }
+            const uint32_t pe = val[i] & 0x7fffu;                         // the element's place among the chunk's, in CSR order
+            col = key[i];
+            r = val[i] >> 15;
+            bits = f32 ? (uint64_t)static_cast<const uint32_t *>(q.vals)[b + pe] : static_cast<const uint64_t *>(q.vals)[b + pe];
+            if (use_dict) {
+                uint32_t a = 0, z = ndict;                                // the dictionary is sorted by bit pattern
+                while (a < z) { const uint32_t m = (a + z) >> 1; if ((f32 ? (uint64_t)d32[m] : d64[m]) < bits) a = m + 1; else z = m; }
+                if (a >= ndict || (f32 ? (uint64_t)d32[a] : d64[a]) != bits) { atomicOr(err, 4u); a = 0; }
                 code = a;
-            } else v = val;
+            }
         }
-        uint8_t *grp = q.stream + ((size_t)k * G + g) * GB;
+        uint8_t *grp = base + (size_t)g * GB;
         uint32_t cw = col | kEndBit;
-        if constexpr (!TAG) cw |= row << col_bits;
+        if (!tag) cw |= r << col_bits;
         reinterpret_cast<uint32_t *>(grp)[lane * 4 + j] = cw;
-        if constexpr (TAG) reinterpret_cast<uint16_t *>(grp + kColsBytes)[lane * 4 + j] = (uint16_t)row;
-        if constexpr (DICT) (grp + VB)[lane * 4 + j] = (uint8_t)code;
-        else if constexpr (sizeof(T) == 8) reinterpret_cast<double *>(grp + VB + (j >> 1) * (kLanes * 16))[lane * 2 + (j & 1)] = v;
-        else reinterpret_cast<float *>(grp + VB)[lane * 4 + j] = v;
+        if (tag) reinterpret_cast<uint16_t *>(grp + kColsBytes)[lane * 4 + j] = (uint16_t)r;
+        if (use_dict) (grp + VB)[lane * 4 + j] = (uint8_t)code;
+        else if (!f32) reinterpret_cast<uint64_t *>(grp + VB + (j >> 1) * (kLanes * 16))[lane * 2 + (j & 1)] = bits;
+        else reinterpret_cast<uint32_t *>(grp + VB)[lane * 4 + j] = (uint32_t)bits;
     }
 }
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline uint32_t bits_of(uint64_t v) { uint32_t b = 1; while (b < 63 && ((uint64_t)1 << b) <= v) b++; return b; }      // bits that hold 0 .. v
 
-template <typename K> size_t sort_bytes(int64_t nnz)
+template <int NT, int IPT, int RB = 0>
+hipError_t launch_chunks(const IlvTable *d_tab, uint32_t nchunks_tot, const DeviceImage &c, uint32_t ystage_max, uint32_t cbits, uint32_t *err_flag, hipStream_t st)
 {
-    size_t tmp = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const K *)nullptr, (K *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (unsigned int)std::max<int64_t>(nnz, 1), 0, (int)sizeof(K) * 8, nullptr);
-    return tmp;
-}
-
-template <typename K>
-hipError_t convert_t(const IlvTable &tab, int64_t ntot, uint32_t nchunks_tot, const DeviceImage &common, uint32_t ystage_max, uint32_t cbits, uint32_t kbits, uint32_t *err_flag, uint8_t *a, size_t scratch_bytes, hipStream_t st)
-{
-    const size_t nk = up256(sizeof(K) * (size_t)std::max<int64_t>(ntot, 1)), nv = up256(sizeof(uint32_t) * (size_t)std::max<int64_t>(ntot, 1));
-    size_t       tmp = sort_bytes<K>(ntot);
-    if (up256(sizeof(IlvTable)) + up256(tmp) + 2 * nk + 2 * nv > scratch_bytes) return hipErrorInvalidValue;
-    IlvTable *d_tab = reinterpret_cast<IlvTable *>(a);
-    a += up256(sizeof(IlvTable));
-    void     *d_tmp = a;
-    K        *key = reinterpret_cast<K *>(a + up256(tmp)), *skey = reinterpret_cast<K *>(a + up256(tmp) + nk);
-    uint32_t *idx = reinterpret_cast<uint32_t *>(a + up256(tmp) + 2 * nk), *sidx = reinterpret_cast<uint32_t *>(a + up256(tmp) + 2 * nk + nv);
-    hipError_t e = hipMemcpyAsync(d_tab, &tab, sizeof(IlvTable), hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(ilv_keys_kernel<K>, dim3(nchunks_tot), dim3(256), 0, st, d_tab, cbits, key, idx);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (ntot > 0) {
-        e = hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp, key, skey, idx, sidx, (unsigned int)ntot, 0, (int)(cbits + kbits), st);      // stable: ties keep their positions' order
+    const size_t   lds = std::max(sizeof(typename ChunkSort<NT, IPT, RB>::type::storage_type), sizeof(uint32_t) * (size_t)std::max<uint32_t>(ystage_max, 1u));
+    const uint32_t flags = (c.f32 ? kIlvF32 : 0u) | (c.dict ? kIlvDict : 0u) | (c.tag16 ? kIlvTag : 0u) | (debug_env("ilv_nosort") ? 8u : 0u) | (debug_env("ilv_nowrite") ? 16u : 0u);
+    static bool    attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ilv_chunk_kernel<NT, IPT, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
         if (e != hipSuccess) return e;
+        attr = true;
     }
-    const dim3   grid(nchunks_tot), block(kEmitThreads);
-    const size_t lds = sizeof(uint32_t) * (size_t)std::max<uint32_t>(ystage_max, 1u);      // (the rows of a chunk fit its accumulators: ystage - 1 at most)
-    const bool   dict = common.dict != nullptr;
-#define CVR_ILV(T, DI, TG)                                                                                                                           \
-    hipLaunchKernelGGL((ilv_emit_kernel<T, DI, TG, K>), grid, block, lds, st, d_tab, skey, sidx, static_cast<const T *>(common.dict), common.ndict, common.G, common.col_bits, cbits, err_flag)
-    if (common.f32) { if (dict) { if (common.tag16) CVR_ILV(float, true, true); else CVR_ILV(float, true, false); } else { if (common.tag16) CVR_ILV(float, false, true); else CVR_ILV(float, false, false); } }
-    else { if (dict) { if (common.tag16) CVR_ILV(double, true, true); else CVR_ILV(double, true, false); } else { if (common.tag16) CVR_ILV(double, false, true); else CVR_ILV(double, false, false); } }
-#undef CVR_ILV
+    if (lds > kLdsBytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((ilv_chunk_kernel<NT, IPT, RB>), dim3(nchunks_tot), dim3(NT), lds, st, d_tab, c.dict, c.ndict, c.G, c.col_bits, cbits, flags, err_flag);
     return hipGetLastError();
 }
 }  // namespace
 
-// device scratch of a conversion of `nnz` non-zeros in all (room for either key width: which one is decided at conversion time)
+// device scratch of a conversion (the table of the images; the sort itself happens in LDS)
 size_t convert_interleaved_scratch(int64_t nnz, uint32_t nchunks)
 {
-    (void)nchunks;
-    const size_t n = (size_t)std::max<int64_t>(nnz, 1);
-    return up256(sizeof(IlvTable)) + up256(std::max(sort_bytes<uint32_t>(nnz), sort_bytes<uint64_t>(nnz))) + 2 * up256(sizeof(uint64_t) * n) + 2 * up256(sizeof(uint32_t) * n) + 256;
+    (void)nnz; (void)nchunks;
+    return up256(sizeof(IlvTable)) + 256;
 }
 
 // The interleaved images imgs[0 .. n) (all of one handle: same chunk length, value type, dictionary, tag width and row field) converted
@@ -200,10 +194,26 @@ hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const Devi
     }
     tab.nparts = (uint32_t)n;
     if (c == 0) return hipSuccess;
-    if (e >= (int64_t)0xffffffffll) return hipErrorInvalidValue;        // positions in the concatenation are 32-bit
-    const uint32_t cbits = bits_of(pad_max), kbits = bits_of(c - 1);
-    if (cbits + kbits <= 32) return convert_t<uint32_t>(tab, e, c, *imgs[0], ystage_max, cbits, kbits, err_flag, static_cast<uint8_t *>(scratch), scratch_bytes, st);
-    return convert_t<uint64_t>(tab, e, c, *imgs[0], ystage_max, cbits, kbits, err_flag, static_cast<uint8_t *>(scratch), scratch_bytes, st);
+    const DeviceImage &c0 = *imgs[0];
+    const uint32_t     cbits = bits_of(pad_max);
+    const int          ipt = (c0.S + 15) / 16;                             // 64 S slots over 1024 threads
+    if (up256(sizeof(IlvTable)) > scratch_bytes || ipt > 32 || ystage_max > 65536u) return hipErrorInvalidValue;      // (position 15 bits, row 16 bits in the sort's payload)
+    IlvTable *d_tab = static_cast<IlvTable *>(scratch);
+    hipError_t rc = hipMemcpyAsync(d_tab, &tab, sizeof(IlvTable), hipMemcpyHostToDevice, st);
+    if (rc != hipSuccess) return rc;
+    // (1 024 threads leave 128 registers each: 16 (column, position) pairs per thread sort without spills; the long chunks take 512 threads)
+    if (ipt <= 4) return launch_chunks<1024, 4>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    if (ipt <= 8) return launch_chunks<1024, 8>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    if (ipt <= 12) return launch_chunks<1024, 12>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    if (ipt <= 16) return launch_chunks<1024, 16>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    if (debug_env("ilv_nt512")) {
+        if (ipt <= 24) return launch_chunks<512, 48>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+        return launch_chunks<512, 64>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    }
+    if (ipt <= 24 && debug_env("ilv_rb10")) return launch_chunks<1024, 24, 10>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    if (ipt <= 24 && debug_env("ilv_rb7")) return launch_chunks<1024, 24, 7>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    if (ipt <= 24) return launch_chunks<1024, 24>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    return launch_chunks<1024, 32>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
 }
 
 }  // namespace cvr

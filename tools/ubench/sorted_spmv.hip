@@ -207,7 +207,7 @@ __global__ __launch_bounds__(1024) void sorted_spmv_kernel(const uint8_t *__rest
 #define XR(s, j, n) "v[96+8*" S(s) "+" S(n) "*" S(j) ":96+8*" S(s) "+" S(n) "*" S(j) "+" S(n) "-1]"
 #define XR1(s, o) "v[96+8*" S(s) "+" S(o) "]"
 
-template <typename T, bool DICT, bool TAG, bool SHARED>
+template <typename T, bool DICT, bool TAG, bool SHARED, bool BAR = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sorted_spmv_ring_kernel(const uint8_t *__restrict__ stream, const ChunkDesc *__restrict__ desc, const uint32_t *__restrict__ wg_first,
                                                            const uint32_t *__restrict__ wg_count, const T *__restrict__ x, T *__restrict__ z, uint32_t col_bits,
                                                            uint32_t R, const T *__restrict__ dict_g, uint32_t ndict)
@@ -305,6 +305,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
             else row = col_bits >= 32 ? 0u : cw_[j] >> col_bits;                                                                        \
             lds_add<T, SHARED>(acc + row, av * xv);                                                                                     \
         }                                                                                                                               \
+        if constexpr (BAR) __builtin_amdgcn_s_barrier();      /* mode 2: every wavefront has added its group of the round */         \
     } while (0)
 
     // run-in: the stream of the first QN groups, then virtual steps -D .. -1 issue what steps of the loop would have issued
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
         GATHER(2, 2); LOADQ(6, gb + 6u * gs);
         GATHER(3, 3); LOADQ(7, gb + 7u * gs);
     }
-    for (uint32_t gb = g0; gb < d.G; gb += gs * QN) {
+    for (uint32_t gb = g0, rb = 0; BAR ? rb < d.G : gb < d.G; gb += gs * QN, rb += gs * QN) {      // (BAR: the same trip count in every wavefront)
         STEP(0, 4, 0); STEP(1, 5, 1); STEP(2, 6, 2); STEP(3, 7, 3);
         STEP(4, 0, 0); STEP(5, 1, 1); STEP(6, 2, 2); STEP(7, 3, 3);
     }
@@ -364,7 +365,7 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     uint32_t pw = (uint32_t)((A.ncols + P - 1) / P);
     pw = (pw + per_line - 1) / per_line * per_line;
     P = (uint32_t)((A.ncols + pw - 1) / pw);
-    const uint32_t Reff = mode == 1 ? R * W : R;
+    const uint32_t Reff = mode >= 1 ? R * W : R;
     // ---- split into panels: per panel the sub-rows (row, begin) and the elements, in row order
     struct Panel { std::vector<int64_t> sp; std::vector<int32_t> srow; std::vector<int32_t> col; std::vector<double> val; };
     std::vector<Panel> pan(P);
@@ -493,7 +494,7 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
         }
     } else for (auto &q : xq[0]) { wg_first.push_back(q.first); wg_count.push_back(q.second); }
     const uint32_t nwg = (uint32_t)wg_first.size();
-    const size_t lds = (size_t)(use_dict ? 256 : 0) * sizeof(T) + (size_t)(mode == 1 ? 1 : W) * (Reff + 1) * sizeof(T);
+    const size_t lds = (size_t)(use_dict ? 256 : 0) * sizeof(T) + (size_t)(mode >= 1 ? 1 : W) * (Reff + 1) * sizeof(T);
     int64_t slots = 0; for (auto &d : desc) slots += (int64_t)d.G * 256;
     printf("# %s nrows %ld nnz %ld | P %u (%u cols, %.2f MB) pairs %.2fM chunks %zu wgs %u slots/nnz %.3f | R %u W %u Smax %u mode %d depth %d tag %d dict %d(%zu) bits %u+%u GB %u stream %.1f MB lds %zu | build %.1fs\n",
            sizeof(T) == 8 ? "f64" : "f32", (long)A.nrows, (long)A.nnz, P, pw, pw * sizeof(T) / 1e6, npairs / 1e6, nch, nwg, (double)slots / A.nnz, R, W, Smax, mode, depth, (int)tag, (int)use_dict,
@@ -518,8 +519,9 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     auto launch = [&]() {
 #define L(DI, TG, DP, SH, NA) hipLaunchKernelGGL((sorted_spmv_kernel<T, DI, TG, DP, SH, NA>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size())
 #define L_NA(DI, TG, DP, SH) do { if (noadd) L(DI, TG, DP, SH, 1); else L(DI, TG, DP, SH, 0); } while (0)
-#define L_SH(DI, TG, DP) do { if (mode == 1) L_NA(DI, TG, DP, true); else L_NA(DI, TG, DP, false); } while (0)
-#define L_RING(DI, TG) do { if (mode == 1) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
+#define L_SH(DI, TG, DP) do { if (mode >= 1) L_NA(DI, TG, DP, true); else L_NA(DI, TG, DP, false); } while (0)
+#define L_RING(DI, TG) do { if (mode == 2) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
+        else if (mode == 1) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
         else hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, false>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); } while (0)
 #define L_DP(DI, TG) do { if (depth == 9) L_RING(DI, TG); else if (depth >= 8) L_SH(DI, TG, 8); else if (depth >= 4) L_SH(DI, TG, 4); else if (depth >= 2) L_SH(DI, TG, 2); else L_SH(DI, TG, 1); } while (0)
 #define L_TG(DI) do { if (tag) L_DP(DI, true); else L_DP(DI, false); } while (0)
