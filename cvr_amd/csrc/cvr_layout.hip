@@ -410,7 +410,7 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
     cvr::DeviceImage &img = part.img;
     img.S = S; img.G = G; img.f32 = f32; img.nchunks = (uint32_t)nchunks; img.nrows = (uint32_t)nrows;
     img.pad_col = (uint32_t)ncols; img.nshared = (uint32_t)nshared;
-    img.xcd_swizzle = opt.xcds != 8 ? 0 : opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 2 ? 1 : opt.xcd_swizzle;
+    img.xcd_swizzle = opt.xcds != 8 ? 0 : opt.xcd_swizzle < 0 ? 1 : opt.xcd_swizzle > 6 ? 1 : opt.xcd_swizzle;
     img.ncus = (uint32_t)opt.cus;
     img.wpb = (uint32_t)pp.wpb;
     img.ystage = (uint32_t)pp.stage;

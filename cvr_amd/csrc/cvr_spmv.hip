@@ -179,6 +179,12 @@ __device__ __forceinline__ uint32_t remap_block(uint32_t b, uint32_t nblocks_per
         const uint32_t cnt = q + (xcd < r ? 1u : 0u), base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
         return j < cnt ? base + j : 0x00ffffffu;
     }
+    if (swz >= 3) {
+        // swz = 3, 4, 5, 6: an XCD takes RUNS of 2, 4, 8, 16 consecutive blocks, the runs dealt round-robin over the XCDs -- neighbouring rows still
+        // meet in one L2, and stretches of the matrix that gather more than others are spread over all eight (here the argument is the total n)
+        const uint32_t lg = (uint32_t)swz - 2u, blk = ((((j >> lg) << 3) + xcd) << lg) + (j & ((1u << lg) - 1u));
+        return blk < nblocks_per_xcd ? blk : 0x00ffffffu;
+    }
     // swz = 2 (experiment): within the XCD, blocks j, j+32, j+64, .. (one CU under round-robin placement) take
     // consecutive chunks, so that the waves resident on a CU work on neighbouring rows and share x lines in its L1
     const uint32_t per_cu = (nblocks_per_xcd + 31) / 32;
@@ -1016,8 +1022,9 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     }
     const uint32_t per_xcd = (nblocks + 7) / 8;
     if (multi) multi_chunks = (multi_chunks + wpb - 1) / wpb;          // (from here on: the workgroups of wpb chunks the fullest panel needs)
-    const uint32_t grid = multi ? multi_rounds * multi_chunks * 8 : img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;      // (multi: `img` is one of the panels: what they share comes from it)
-    const uint32_t per = multi ? multi_chunks * 8 : img.xcd_swizzle == 1 ? nblocks : per_xcd;      // the kernels' block -> chunk mapping (remap_block; multi: workgroups of one round)
+    const uint32_t run8 = img.xcd_swizzle >= 3 ? 8u << (img.xcd_swizzle - 2) : 0u;       // (runs of blocks dealt over the XCDs: whole rounds of eight runs)
+    const uint32_t grid = multi ? multi_rounds * multi_chunks * 8 : run8 ? (nblocks + run8 - 1) / run8 * run8 : img.xcd_swizzle == 2 ? ((per_xcd + 31) / 32) * 32 * 8 : img.xcd_swizzle ? per_xcd * 8 : nblocks;      // (multi: `img` is one of the panels: what they share comes from it)
+    const uint32_t per = multi ? multi_chunks * 8 : img.xcd_swizzle == 1 || run8 ? nblocks : per_xcd;      // the kernels' block -> chunk mapping (remap_block; multi: workgroups of one round)
     const int      swz = multi ? 0 : img.xcd_swizzle;
     const uint64_t xb = (uint64_t)(img.pad_col + 1ull) * (img.f32 ? 4 : 8);
     if (xb > 0xffffffffull) return hipErrorInvalidValue;               // x is addressed through a 32-bit buffer descriptor

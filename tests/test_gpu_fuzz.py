@@ -89,7 +89,8 @@ def test_fuzz_parity(ncases=None, seed=None):
             if ph > 1:
                 hub = 0
             A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, split_threshold=thr, col_panels=P, x_window=win,
-                                  waves_per_block=wpb, col_phases=ph, hub_table=hub, hub_reorder=reo if P == 1 else 0, row_tags16=tags, piece_max=pmax)
+                                  waves_per_block=wpb, col_phases=ph, hub_table=hub, hub_reorder=reo if P == 1 else 0, row_tags16=tags, piece_max=pmax,
+                                  xcd_swizzle=int(rng.choice([-1, -1, 0, 3, 4, 5, 6])))
             ph = A.info.col_phases
         ctx["from_dev"] = bool(from_dev)
         if P == 1:

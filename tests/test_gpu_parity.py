@@ -178,7 +178,7 @@ def test_fp32_path(name):
 
 
 @pytest.mark.parametrize("thr", [1, 16, 100000])
-@pytest.mark.parametrize("swz", [0, 1])
+@pytest.mark.parametrize("swz", [0, 1, 3, 4, 6])
 def test_split_threshold_and_launch_options(thr, swz):
     for name, S in (("power_law_3000", 8), ("two_giants", 16), ("dense_row_plus_singletons", 4)):
         nrows, ncols, rp, ci, va = CASES[name]

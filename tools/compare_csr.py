@@ -98,10 +98,18 @@ def main():
     elif name.startswith("rmat"):
         n, nc, rp, ci, va = synth.rmat(int(name[4:]), dtype=np.float64)
     elif name in ("orkut", "wikitalk"):          # the stand-ins that are built on the device (cvr_amd/synth_dev.py)
-        from cvr_amd import synth_dev as D
-        n, rp_t, ci_t, va_t = (D.orkut_like if name == "orkut" else D.wikitalk_like)(device="cuda")
-        nc, rp, ci, va = n, rp_t.cpu().numpy(), ci_t.cpu().numpy(), va_t.cpu().numpy()
-        del rp_t, ci_t, va_t
+        # built by a child process without the profiler's preloads (rocprofv3's counter collection aborts on the generator's torch
+        # kernels), handed over through a file
+        import subprocess, tempfile
+        fn = os.path.join(tempfile.gettempdir(), f"cvr_standin_{name}.npz")
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); from cvr_amd import synth_dev as D; "
+                "n, rp, ci, va = (D.orkut_like if %r == 'orkut' else D.wikitalk_like)(device='cuda'); "
+                "np.savez(%r, n=n, rp=rp.cpu().numpy(), ci=ci.cpu().numpy(), va=va.cpu().numpy())") % (ROOT, name, fn)
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTRACER"))}
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+        z = np.load(fn)
+        n = nc = int(z["n"]); rp, ci, va = z["rp"], z["ci"], z["va"]
+        os.unlink(fn)
     else:
         raise SystemExit("unknown matrix")
     print(json.dumps(report(n, nc, rp, ci, va, iters, name), indent=1))

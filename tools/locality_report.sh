@@ -11,7 +11,7 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/locality_$MAT; mkdir -p $OUT; cd /tmp; exp
 i=0
 for grp in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_LEVEL_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum"; do
   i=$((i+1))
-  ( cd $R && timeout 900 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 tools/compare_csr.py $MAT $IT > $OUT/p$i.json 2> $OUT/p$i.err )
+  ( cd $R && timeout 420 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 tools/compare_csr.py $MAT $IT > $OUT/p$i.json 2> $OUT/p$i.err )
 done
 python3 - <<PY > $R/gpurun_out/locality_$MAT.txt
 import csv, glob, collections, json
