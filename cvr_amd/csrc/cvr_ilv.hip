@@ -101,44 +101,57 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
     if (!(flags & 8u)) Sort().sort_to_striped(key, val, *reinterpret_cast<typename Sort::storage_type *>(smem), 0u, cbits);
     if (flags & 16u) return;
 
-    uint32_t code0 = 0;                                                   // the code of +0.0 (cvr_create puts it into every dictionary)
-    const uint64_t *const d64 = static_cast<const uint64_t *>(dict_v);
-    const uint32_t *const d32 = static_cast<const uint32_t *>(dict_v);
+    // the dictionary (sorted by bit pattern, at most 256 entries) goes to LDS in the sort's place: a search per element is eight LDS reads
+    uint64_t *const dl = reinterpret_cast<uint64_t *>(smem);
+    uint32_t        code0 = 0;                                            // the code of +0.0 (cvr_create puts it into every dictionary)
     if (use_dict) {
-        while (code0 < ndict && (f32 ? (uint64_t)d32[code0] : d64[code0]) != 0) code0++;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 256u; i += NT)
+            dl[i] = i < ndict ? (f32 ? (uint64_t)static_cast<const uint32_t *>(dict_v)[i] : static_cast<const uint64_t *>(dict_v)[i]) : ~(uint64_t)0;
+        __syncthreads();
+        while (code0 < ndict && dl[code0] != 0) code0++;
         if (code0 >= ndict) { if (threadIdx.x == 0) atomicOr(err, 4u); code0 = 0; }
     }
     const uint32_t GB = (use_dict ? kGroupBytesDict : f32 ? kGroupBytes32 : kGroupBytes64) + (tag ? kTagBytes : 0);
     const uint32_t VB = kColsBytes + (tag ? kTagBytes : 0);
     const uint32_t nslots = (uint32_t)G * 256u;
     uint8_t *const base = q.stream + (size_t)k * G * GB;
+    const void *const vals = q.vals;
+    const uint32_t pad_col = q.pad_col;
+    constexpr int  kB = IPT % 8 == 0 ? 8 : 4;                             // the values' bit patterns: the loads of kB elements in flight together
 #pragma unroll
-    for (int i = 0; i < IPT; i++) {
-        const uint32_t e = (uint32_t)i * NT + threadIdx.x;
-        if (e >= nslots) break;
-        const uint32_t g = e >> 8, j = (e >> 6) & 3u, lane = e & 63u;
-        uint32_t col = q.pad_col, r = nri, code = code0;
-        uint64_t bits = 0;
-        if (e < n) {
-            const uint32_t pe = val[i] & 0x7fffu;                         // the element's place among the chunk's, in CSR order
-            col = key[i];
-            r = val[i] >> 15;
-            bits = f32 ? (uint64_t)static_cast<const uint32_t *>(q.vals)[b + pe] : static_cast<const uint64_t *>(q.vals)[b + pe];
-            if (use_dict) {
-                uint32_t a = 0, z = ndict;                                // the dictionary is sorted by bit pattern
-                while (a < z) { const uint32_t m = (a + z) >> 1; if ((f32 ? (uint64_t)d32[m] : d64[m]) < bits) a = m + 1; else z = m; }
-                if (a >= ndict || (f32 ? (uint64_t)d32[a] : d64[a]) != bits) { atomicOr(err, 4u); a = 0; }
-                code = a;
+    for (int i0 = 0; i0 < IPT; i0 += kB) {
+        uint64_t bits[kB];
+#pragma unroll
+        for (int u = 0; u < kB; u++) {
+            const uint32_t e = (uint32_t)(i0 + u) * NT + threadIdx.x, pe = val[i0 + u] & 0x7fffu;      // pe: the element's place among the chunk's, in CSR order
+            bits[u] = e >= n ? 0 : f32 ? (uint64_t)static_cast<const uint32_t *>(vals)[b + pe] : static_cast<const uint64_t *>(vals)[b + pe];
+        }
+#pragma unroll
+        for (int u = 0; u < kB; u++) {
+            const int      i = i0 + u;
+            const uint32_t e = (uint32_t)i * NT + threadIdx.x;
+            if (e < nslots) {
+                const uint32_t g = e >> 8, j = (e >> 6) & 3u, lane = e & 63u;
+                const uint32_t col = e < n ? key[i] : pad_col, r = e < n ? val[i] >> 15 : nri;
+                uint32_t       code = code0;
+                if (use_dict && e < n) {
+                    uint32_t a = 0;                                       // entries below bits[u] (branch-free: the entries behind ndict are all ones)
+#pragma unroll
+                    for (uint32_t st = 128; st > 0; st >>= 1) a += dl[a + st - 1] < bits[u] ? st : 0u;
+                    if (a >= ndict || dl[a] != bits[u]) { atomicOr(err, 4u); a = 0; }
+                    code = a;
+                }
+                uint8_t *grp = base + (size_t)g * GB;
+                uint32_t cw = col | kEndBit;
+                if (!tag) cw |= r << col_bits;
+                reinterpret_cast<uint32_t *>(grp)[lane * 4 + j] = cw;
+                if (tag) reinterpret_cast<uint16_t *>(grp + kColsBytes)[lane * 4 + j] = (uint16_t)r;
+                if (use_dict) (grp + VB)[lane * 4 + j] = (uint8_t)code;
+                else if (!f32) reinterpret_cast<uint64_t *>(grp + VB + (j >> 1) * (kLanes * 16))[lane * 2 + (j & 1)] = bits[u];
+                else reinterpret_cast<uint32_t *>(grp + VB)[lane * 4 + j] = (uint32_t)bits[u];
             }
         }
-        uint8_t *grp = base + (size_t)g * GB;
-        uint32_t cw = col | kEndBit;
-        if (!tag) cw |= r << col_bits;
-        reinterpret_cast<uint32_t *>(grp)[lane * 4 + j] = cw;
-        if (tag) reinterpret_cast<uint16_t *>(grp + kColsBytes)[lane * 4 + j] = (uint16_t)r;
-        if (use_dict) (grp + VB)[lane * 4 + j] = (uint8_t)code;
-        else if (!f32) reinterpret_cast<uint64_t *>(grp + VB + (j >> 1) * (kLanes * 16))[lane * 2 + (j & 1)] = bits;
-        else reinterpret_cast<uint32_t *>(grp + VB)[lane * 4 + j] = (uint32_t)bits;
     }
 }
 
@@ -148,7 +161,7 @@ inline uint32_t bits_of(uint64_t v) { uint32_t b = 1; while (b < 63 && ((uint64_
 template <int NT, int IPT, int RB = 0>
 hipError_t launch_chunks(const IlvTable *d_tab, uint32_t nchunks_tot, const DeviceImage &c, uint32_t ystage_max, uint32_t cbits, uint32_t *err_flag, hipStream_t st)
 {
-    const size_t   lds = std::max(sizeof(typename ChunkSort<NT, IPT, RB>::type::storage_type), sizeof(uint32_t) * (size_t)std::max<uint32_t>(ystage_max, 1u));
+    const size_t   lds = std::max(sizeof(typename ChunkSort<NT, IPT, RB>::type::storage_type), std::max<size_t>(2048, sizeof(uint32_t) * (size_t)std::max<uint32_t>(ystage_max, 1u)));
     const uint32_t flags = (c.f32 ? kIlvF32 : 0u) | (c.dict ? kIlvDict : 0u) | (c.tag16 ? kIlvTag : 0u) | (debug_env("ilv_nosort") ? 8u : 0u) | (debug_env("ilv_nowrite") ? 16u : 0u);
     static bool    attr = false;
     if (!attr) {
@@ -210,8 +223,6 @@ hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const Devi
         if (ipt <= 24) return launch_chunks<512, 48>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
         return launch_chunks<512, 64>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     }
-    if (ipt <= 24 && debug_env("ilv_rb10")) return launch_chunks<1024, 24, 10>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
-    if (ipt <= 24 && debug_env("ilv_rb7")) return launch_chunks<1024, 24, 7>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 24) return launch_chunks<1024, 24>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     return launch_chunks<1024, 32>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
 }

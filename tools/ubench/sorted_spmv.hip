@@ -557,12 +557,47 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
 
 int main(int argc, char **argv)
 {
-    if (argc < 10) { fprintf(stderr, "usage: %s csr.bin f32|f64 R W Smax P mode depth iters [dict] [noadd]\n", argv[0]); return 1; }
+    if (argc < 10) { fprintf(stderr, "usage: %s csr.bin f32|f64 R W Smax P mode depth iters [dict] [noadd] [rank] [maxdeg] [mindeg]\n", argv[0]); return 1; }
     const bool f32 = !strcmp(argv[2], "f32");
     const Csr  A = read_csr(argv[1], f32);
     const uint32_t R = atoi(argv[3]), W = atoi(argv[4]), Smax = atoi(argv[5]), P = atoi(argv[6]);
     const int mode = atoi(argv[7]), depth = atoi(argv[8]), iters = atoi(argv[9]);
     const bool dict = argc > 10 && atoi(argv[10]) != 0;
     const int  noadd = argc > 11 ? atoi(argv[11]) : 0;
+    const int  rank = argc > 12 ? atoi(argv[12]) : 0;          // 1: columns renumbered by popularity (most popular first), rows re-sorted
+    const long maxdeg = argc > 13 ? atol(argv[13]) : 0;        // > 0: rows of that many non-zeros or more are emptied (what a long-row kernel would take)
+    const long mindeg = argc > 14 ? atol(argv[14]) : 0;        // > 0: rows of fewer non-zeros are emptied
+    if (rank || maxdeg || mindeg) {
+        Csr &M = const_cast<Csr &>(A);
+        if (rank) {
+            std::vector<int64_t> cnt(M.ncols, 0);
+            for (int64_t i = 0; i < M.nnz; i++) cnt[M.ci[i]]++;
+            std::vector<int32_t> order(M.ncols), rk(M.ncols);
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt[a] > cnt[b]; });
+            for (int64_t i = 0; i < M.ncols; i++) rk[order[i]] = (int32_t)i;
+#pragma omp parallel for schedule(dynamic, 1024)
+            for (int64_t r = 0; r < M.nrows; r++) {
+                const int64_t b = M.rp[r], e = M.rp[r + 1];
+                std::vector<std::pair<int32_t, double>> t((size_t)(e - b));
+                for (int64_t j = b; j < e; j++) t[(size_t)(j - b)] = {rk[M.ci[j]], M.va[j]};
+                std::stable_sort(t.begin(), t.end(), [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &c) { return a.first < c.first; });
+                for (int64_t j = b; j < e; j++) { M.ci[j] = t[(size_t)(j - b)].first; M.va[j] = t[(size_t)(j - b)].second; }
+            }
+        }
+        if (maxdeg || mindeg) {
+            std::vector<int64_t> rp(M.nrows + 1, 0);
+            int64_t w = 0;
+            for (int64_t r = 0; r < M.nrows; r++) {
+                const int64_t b = M.rp[r], e = M.rp[r + 1];
+                rp[r] = w;
+                if ((maxdeg && e - b >= maxdeg) || (mindeg && e - b < mindeg)) continue;
+                for (int64_t j = b; j < e; j++) { M.ci[w] = M.ci[j]; M.va[w] = M.va[j]; w++; }
+            }
+            rp[M.nrows] = w;
+            M.rp = rp; M.nnz = w; M.ci.resize(w); M.va.resize(w);
+        }
+        printf("# columns %s, rows kept: degree in [%ld, %ld): nnz %ld\n", rank ? "ranked by popularity" : "natural", mindeg, maxdeg ? maxdeg : -1, (long)M.nnz);
+    }
     return f32 ? run<float>(A, R, W, Smax, P, mode, depth, iters, dict, noadd) : run<double>(A, R, W, Smax, P, mode, depth, iters, dict, noadd);
 }
