@@ -550,6 +550,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         const int64_t pwidth = (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1;          // (the split's width)
         auto part_base = [&](int p) { return panel_opt.interleave > 0 ? std::min<int64_t>((int64_t)p * pwidth, std::max<int64_t>(ncols - 1, 0)) : (int64_t)0; };
         auto part_cols = [&](int p) { return panel_opt.interleave > 0 ? std::max<int64_t>(1, std::min<int64_t>(pwidth, ncols - (int64_t)p * pwidth)) : ncols; };
+        if (panel_opt.interleave > 0) panel_opt.col_span = pwidth;          // (the last panel may be narrower: its column words keep the others' fields)
         std::vector<IOpt>        popts((size_t)P, panel_opt);
         std::vector<DevRows>     drs((size_t)P);
         if (dev_split) {

@@ -230,7 +230,7 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
             const bool sane = s.S >= 4 && s.S <= 4096 && s.S % 4 == 0 && s.G == s.S / 4 && nc == (uint64_t)s.part_nchunks && g.nshared == (uint64_t)s.part_nshared && s.part_nrows >= 0 &&
                               (uint64_t)s.part_nrows == g.nrows && s.part_yext == s.part_nrows + 1 + 2 * (int64_t)nc && s.part_zoff >= 0 && g.wpb >= 1 && g.wpb <= (uint32_t)cvr::kMaxWavesPerBlock &&
                               g.phases >= 1 && g.phases <= 64 && g.ystage >= 1 && g.ystage <= 65532 && g.col_bits <= 31 && g.ndict == h->ndict && (g.f32 ? 4u : 8u) == have.vsz &&
-                              (uint64_t)g.col_base + g.pad_col <= (uint64_t)h->info.ncols && (g.col_base == 0 ? g.pad_col == (uint64_t)h->info.ncols : g.ilv) && (!g.c16 || (!g.tag16 && g.phases == 1)) && (g.order_n == 0 || g.order_n == g.pad_col) &&
+                              (uint64_t)g.col_base + g.pad_col <= (uint64_t)h->info.ncols && (g.ilv ? h->info.col_panels > 1 || (g.col_base == 0 && g.pad_col == (uint64_t)h->info.ncols) : g.col_base == 0 && g.pad_col == (uint64_t)h->info.ncols) && (!g.c16 || (!g.tag16 && g.phases == 1)) && (g.order_n == 0 || g.order_n == g.pad_col) &&
                               s.stream_bytes == nc * (uint64_t)s.G * (uint64_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16) &&
                               (s.multi_slot < 0 || (has_multi && (uint32_t)s.multi_slot < nrounds * 8)) && cvr::spmv_lds_bytes(g) <= cvr::kLdsBytes;
             if (!sane) { r.ok = false; LOAD_TRY(hipSuccess); }

@@ -80,6 +80,7 @@ struct IOpt : cvr_options {
     int32_t debug_col_mask = 0;            // CVR_DEBUG_COL_MASK: folds the gather onto a 2^k-entry table (timing only: wrong y)
     int32_t panel_on_one_xcd = 0;          // this image is a column panel that will run on the workgroups of one XCD (run_spmv, d_multi)
     int32_t cus = 256, xcds = 8;           // the device's geometry (chip_of)
+    int64_t col_span = 0;                  // > 0: the widest of the column panels that share a launch with this image: column and row fields are sized for it
 };
 
 // One CVR64 image on the device: the whole matrix, or one column panel of it (rows compacted to those that

@@ -49,7 +49,7 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
         // the 160 KiB beside steal slots, dictionary and window -- and at what the row field of a segment's last column
         // word can hold (the bits between the column index and the end flag)
         pp.col_bits = 1;
-        while (((int64_t)1 << pp.col_bits) <= ncols) pp.col_bits++;
+        while (((int64_t)1 << pp.col_bits) <= std::max<int64_t>(ncols, opt.col_span)) pp.col_bits++;      // (column panels of one launch: one width for all)
         const int64_t row_field = pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
         auto rows_for = [&](int64_t win) {
             const int64_t left = (int64_t)cvr::kLdsBytes - (cvr::kDictMax + win + 8) * vs;      // (no steal slots: spmv_seg_kernel; window + zero slot + the epilogue's arrival counter)

@@ -109,6 +109,51 @@ def test_fuzz_parity(ncases=None, seed=None):
         A.close()
 
 
+def test_fuzz_interleaved_chunks():
+    """cvr_options.interleave over the same random shapes (sorted or unsorted rows, host or device planner): one image -> the CPU mirror's
+    bits (orc_cvr64_build_ilv) and y of the mirror; column panels -> y against the CSR oracle; reruns bit for bit"""
+    ncases = int(os.environ.get("CVR_FUZZ_CASES", "120"))
+    rng = np.random.default_rng(int(os.environ.get("CVR_FUZZ_SEED", "20261006")))
+    for case in range(ncases):
+        nrows, ncols, rp, ci, va, srt = _random_case(rng)
+        f32 = bool(rng.integers(0, 4) == 0)
+        if rng.integers(0, 2) == 0:
+            va = rng.choice(np.array([0.0, 1.0, -1.0, 0.5, 3.0, 1e-3, -7.25]), size=len(va))
+        va = va.astype(np.float32 if f32 else np.float64)
+        S = int(rng.choice([4, 8, 16, 32, 64, 128, 256, 508]))
+        P = int(rng.choice([1, 1, 1, 2, 3, 8]))
+        wpb = int(rng.choice([0, 1, 2, 4, 8]))
+        tags = int(rng.choice([-1, -1, 0, 1]))
+        dev_plan = bool(rng.integers(0, 3) == 0)
+        ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, P=P, wpb=wpb, tags=tags, f32=f32, srt=srt, dev_plan=dev_plan)
+        if dev_plan:
+            os.environ["CVR_DEBUG"] = "device_plan_rows=0"
+        try:
+            try:
+                A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, col_panels=P, waves_per_block=wpb, row_tags16=tags, interleave=1)
+            except cvr_amd.CvrError as e:          # (tags forced off where column and row do not fit one word: a refusal with a code, not a wrong image)
+                assert tags == 0, (ctx, str(e))
+                continue
+        finally:
+            os.environ.pop("CVR_DEBUG", None)
+        i = A.info
+        assert i.interleave == 1, ctx
+        x = O.x_vec_fast(ncols, "rand").astype(va.dtype)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        bad, worst = O.tol_check(y, yref, absy + 1e-30, tol=1e-5 if f32 else 1e-12)
+        assert len(bad) == 0, (ctx, bad[:5], worst)
+        if i.col_panels == 1:
+            mir = O.Cvr64(nrows, ncols, rp, ci, va, i.steps_per_chunk, use_dict=i.value_dict > 0, max_rows=i.chunk_row_cap, tag16=i.row_tags16, interleave=True)
+            img = A.export_image()
+            assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc) and np.array_equal(img["shared"], mir.shared), ctx
+            if i.nshared == 0:
+                assert np.array_equal(y.view(np.uint8), mir.spmv(x).view(np.uint8)), ctx
+        y2, _ = A.spmv(x)
+        assert np.array_equal(y.view(np.uint8), y2.view(np.uint8)), ctx
+        A.close()
+
+
 def test_fuzz_one_submission_preprocessing():
     """Matrices of the size the automatic layout makes resident (350 000 - 600 000 rows; local and far columns mixed, empty rows, a few
     rows far beyond a chunk, square and rectangular, fp64 / fp32, few or many distinct values): cvr_create's one-submission path

@@ -145,6 +145,22 @@ def test_interleaved_column_panels_one_per_xcd(f32):
     A.close()
 
 
+@pytest.mark.parametrize("ncols", [129, 262, 1000, 4097])
+def test_interleaved_panels_of_unequal_width(ncols):
+    """the last column panel is narrower than the others (its column index needs fewer bits): the panels share a launch, so they share
+    the width of the column and row fields (a fuzz case found them decoded with the first panel's width)"""
+    rng = np.random.default_rng(5)
+    nrows, nc, rp, ci, va = K.csr_from_lengths(np.full(3841, 46, dtype=np.int64), ncols, rng, sort=False)
+    for P in (8, 5, 16):
+        A = cvr_amd.CvrMatrix(nrows, nc, rp, ci, va, steps_per_chunk=128, col_panels=P, interleave=1)
+        assert (A.info.interleave, A.info.col_panels) == (1, P)
+        x = O.x_vec_fast(nc, "rand")
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL64, ("panels of unequal width", ncols, P))
+        A.close()
+
+
 def test_column_phases_need_sorted_rows_and_fit_the_row_field():
     rng = np.random.default_rng(5)
     nrows, ncols, rp, ci, va = K.csr_from_lengths([7] * 300, 5000, rng, sort=False)
@@ -581,7 +597,7 @@ def test_multi_device_handle_one_call_all_gpus():
     A.close()
 
 
-@pytest.mark.parametrize("kind", ["resident_phases", "plain", "panels", "hub"])
+@pytest.mark.parametrize("kind", ["resident_phases", "plain", "panels", "hub", "interleaved", "interleaved_panels"])
 def test_image_cache_roundtrip_and_staleness(tmp_path, kind):
     """cvr_save_image / cvr_load_image: the converted image from disk gives the same y bit for bit without analysis, planner or
     converter; a file written for another source file, other options or a damaged file is refused with a code"""
@@ -591,7 +607,8 @@ def test_image_cache_roundtrip_and_staleness(tmp_path, kind):
     else:
         nrows, ncols, rp, ci, va = synth.web_google_like(scale=0.05)
         opts = dict(resident_phases=dict(steps_per_chunk=12, waves_per_block=8, x_window=2048, col_phases=6), plain=dict(steps_per_chunk=16),
-                    panels=dict(col_panels=3, steps_per_chunk=16))[kind]
+                    panels=dict(col_panels=3, steps_per_chunk=16), interleaved=dict(col_panels=1, interleave=1, steps_per_chunk=32, waves_per_block=4),
+                    interleaved_panels=dict(col_panels=8, interleave=1))[kind]
     x = O.x_vec_fast(ncols, "rand").astype(va.dtype)
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, **opts)
     y, _ = A.spmv(x)
@@ -599,12 +616,13 @@ def test_image_cache_roundtrip_and_staleness(tmp_path, kind):
     key = capi.SourceKey(size=123, mtime_ns=456, hash=789, mode=0)
     A.save_image(path, key)
     B = cvr_amd.CvrMatrix.from_image(path, key, **opts)
-    assert (B.info.nchunks, B.info.nshared, B.info.col_panels, B.info.col_phases, B.info.value_dict, B.info.hub_entries) == \
-           (A.info.nchunks, A.info.nshared, A.info.col_panels, A.info.col_phases, A.info.value_dict, A.info.hub_entries)
+    assert (B.info.nchunks, B.info.nshared, B.info.col_panels, B.info.col_phases, B.info.value_dict, B.info.hub_entries, B.info.interleave, B.info.spmv_launches) == \
+           (A.info.nchunks, A.info.nshared, A.info.col_panels, A.info.col_phases, A.info.value_dict, A.info.hub_entries, A.info.interleave, A.info.spmv_launches)
+    assert A.info.interleave == (1 if kind.startswith("interleaved") else 0)
     assert B.info.plan_s == 0 and B.info.convert_s == 0
     y2, _ = B.spmv(x)
     assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))
-    if kind in ("resident_phases", "plain"):
+    if kind in ("resident_phases", "plain", "interleaved"):
         ia, ib = A.export_image(), B.export_image()
         for k in ("image", "desc", "target", "shared"):
             assert np.array_equal(ia[k], ib[k]), k
