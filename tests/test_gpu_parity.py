@@ -228,6 +228,35 @@ def test_golden_reference_fixtures(name):
         A.close()
 
 
+def test_full_size_mtx_file_end_to_end(tmp_path):
+    """run_sample.sh:5-10 at the size BASELINE.json quotes: the web-Google-shaped matrix as a `pattern` Matrix-Market file -> the product's
+    REFCOMPAT loader == the pinned oracle loader bit for bit (values idx % 13 in file order, padded 1-based arrays) -> HIP SpMV == the
+    oracle's CSR loop on those arrays -> ./spmv.cvr on the same file prints the reference's lines with 0 wrong rows"""
+    import json
+    import subprocess
+    n, nc, rp, ci, _ = synth.web_google_like()
+    mtx = str(tmp_path / "web-Google-shaped.mtx")
+    O.write_mtx_pattern(mtx, n, nc, rp, ci)
+    ref = O.read_matrix(mtx)
+    m = cvr_amd.load_mm(mtx, capi.MM_REFCOMPAT)
+    assert (m["ref_nItems"], m["ref_nItemsRaw"], m["ref_numRows"]) == (ref["nItems"], ref["nItemsRaw"], ref["numRows"]) and ref["nItemsRaw"] == len(ci)
+    assert np.array_equal(m["row_ptr"], ref["rowptr"].astype(np.int64)) and np.array_equal(m["col_idx"], ref["cols"])
+    assert np.array_equal(m["vals"].view(np.uint64), ref["val"].view(np.uint64))
+    A = cvr_amd.CvrMatrix(m["nrows"], m["ncols"], m["row_ptr"], m["col_idx"], m["vals"])
+    assert A.info.value_dict == 13 and A.info.col_phases > 1          # (the loader's 13 values; the resident layout)
+    x = O.x_vec_fast(m["ncols"], "rand")
+    yref, absy = O.csr_spmv64(m["row_ptr"], m["col_idx"], m["vals"], x)
+    y, _ = A.spmv(x)
+    _assert_close(y, yref, absy, TOL64, "full-size .mtx")
+    A.close()
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spmv.cvr")
+    r = subprocess.run([exe, mtx, "68", "100"], capture_output=True, text=True, timeout=600, env=dict(os.environ, CVR_X="rand"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Very Good! Your result is correct" in r.stdout
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"backend"')][0])
+    assert line["wrong"] == 0 and line["nnz"] >= len(ci), line
+
+
 def test_call_order_errors():
     nrows, ncols, rp, ci, va = CASES["uniform_2000"]
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
