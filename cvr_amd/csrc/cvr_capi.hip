@@ -421,9 +421,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // freeing another copy of the matrix there, which costs more than the PCIe transfer: LiveJournal shape 60 ms to split +
     // 130 ms to free against 20 ms to upload), and a matrix that stays whole adopts it as its device CSR.  The host split
     // stays as the fallback for matrices beyond the device split's 32-bit positions or when the copy does not fit.
-    struct Staged {
+    struct Staged {          // (one allocation: every hipFree of a large buffer takes ~190 us with the GPU idle behind it)
         void *rp = nullptr, *ci = nullptr, *va = nullptr;
-        void  release() { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); rp = ci = va = nullptr; }
+        void  release() { (void)hipFree(rp); rp = ci = va = nullptr; }
         ~Staged() { release(); }
     } staged;
     const int64_t  sj0 = rows_on_device ? dev_j0 : nrows ? csr->row_ptr[0] : 0, sj1 = rows_on_device ? dev_j1 : nrows ? csr->row_ptr[nrows] : 0;
@@ -437,8 +437,13 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // 21-28 % faster as eight panels, one per XCD, than as one plain image: profiles/r03_mid_size_panels.log)
     const bool     mid_range = P < 0 && xbytes >= kMidPanelBytes && xbytes < 24e6 && sj1 > sj0 && resident_out_of_reach(nrows, sj1 - sj0, ncols, f32, opt);
     if (!on_device && (P > 1 || (P < 0 && (xbytes >= 24e6 || mid_range))) && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !cvr::debug_env("host_split")) {
-        if (hipMalloc(&staged.rp, sizeof(int64_t) * ((size_t)nrows + 1)) == hipSuccess && hipMalloc(&staged.ci, sizeof(int32_t) * (size_t)sj1) == hipSuccess &&
-            hipMalloc(&staged.va, vsz * (size_t)sj1) == hipSuccess &&
+        auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t b_rp = up(sizeof(int64_t) * ((size_t)nrows + 1)), b_ci = up(sizeof(int32_t) * (size_t)sj1), b_va = up(vsz * (size_t)sj1);
+        if (hipMalloc(&staged.rp, b_rp + b_ci + b_va) == hipSuccess) {
+            staged.ci = static_cast<uint8_t *>(staged.rp) + b_rp;
+            staged.va = static_cast<uint8_t *>(staged.ci) + b_ci;
+        }
+        if (staged.rp &&
             hipMemcpy(staged.rp, csr->row_ptr, sizeof(int64_t) * ((size_t)nrows + 1), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(staged.ci, csr->col_idx, sizeof(int32_t) * (size_t)sj1, hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(staged.va, csr->vals, vsz * (size_t)sj1, hipMemcpyHostToDevice) == hipSuccess) {
@@ -497,6 +502,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (staged.rp) {          // the staging copy becomes the part's device CSR
             Part &part = h->parts[0];
             part.d_rp = static_cast<int64_t *>(staged.rp); part.d_ci = static_cast<int32_t *>(staged.ci); part.d_va = staged.va;
+            part.csr_borrowed = true;          // (one allocation: d_rp is its base and the part's to free, d_ci / d_va lie inside it)
             staged.rp = staged.ci = staged.va = nullptr;
         }
         if (rows_on_device) {       // the part's row pointers: a device copy of the caller's; planned (and, where the layout allows, converted) from there
