@@ -550,6 +550,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 IOpt one = panel_opt;
                 panel_opt.steps_per_chunk = interleave_steps((sj1 - sj0) / P, std::max<int64_t>(nsub_all / P, 1), f32, one);
             }
+            // rows are cut over chunks only when they are longer than half a chunk: the padding behind an interleaved chunk's non-zeros is
+            // neither stored in a stream that is read nor walked (desc2.x), and a matrix without cut rows needs no fix-up launch
+            if (panel_opt.split_threshold == 0) panel_opt.split_threshold = 32 * (int64_t)panel_opt.steps_per_chunk;
         }
         // interleaved panels keep their columns relative to the panel's first (the row field of the column word then has room for the
         // chunk's rows without 16-bit tags): such a part is planned and built as a matrix of the panel's width

@@ -626,6 +626,23 @@ def test_multi_device_handle_one_call_all_gpus():
     A.close()
 
 
+def test_multi_device_shards_take_interleaved_panels():
+    """row shards of a power-law matrix (soc-LiveJournal1 shape x 0.65, two shards on one device): every shard is large enough for the
+    automatic rule to give it column panels with interleaved chunks; the gathered y against the oracle, bitwise reproducible"""
+    nrows, ncols, rp, ci, va = synth.livejournal_like(scale=0.65)
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    M = cvr_amd.MultiMatrix(nrows, ncols, rp, ci, va, [0, 0])
+    for p in range(M.shards):
+        info, r0, r1, _ = M.shard_info(p)
+        assert info.nnz >= 8 << 20 and info.col_panels >= 8 and info.interleave == 1, (p, info.nnz, info.col_panels, info.interleave)
+    y, _ = M.spmv(x, iters=3)
+    _assert_close(y, yref, absy, TOL64, "interleaved shards")
+    y2, _ = M.spmv(x)
+    assert np.array_equal(y.view(np.uint64), y2.view(np.uint64))
+    M.close()
+
+
 @pytest.mark.parametrize("kind", ["resident_phases", "plain", "panels", "hub", "interleaved", "interleaved_panels"])
 def test_image_cache_roundtrip_and_staleness(tmp_path, kind):
     """cvr_save_image / cvr_load_image: the converted image from disk gives the same y bit for bit without analysis, planner or
