@@ -32,6 +32,7 @@ struct ChunkDesc {
     uint64_t zoff;            // where its sums go
     uint32_t xbase;           // first column of its panel
     uint32_t xcols;           // columns of its panel
+    uint32_t nacc, pad_;      // mode 3: accumulators (rows + 3 per replicated row)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, uint32_t bytes)
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(1024) void sorted_spmv_kernel(const uint8_t *__rest
     T       *acc;
     if constexpr (SHARED) { k = first; live = cnt > 0; acc = acc_all; }
     else { k = first + wv_u; live = wv_u < cnt; acc = acc_all + (size_t)wv_u * (R + 1); }
-    ChunkDesc d = live ? desc[k] : ChunkDesc{0, 0, 0, 0, 0, 0};
+    ChunkDesc d = live ? desc[k] : ChunkDesc{0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (SHARED) { for (uint32_t i = threadIdx.x; i <= d.nrows; i += blockDim.x) acc[i] = T(0); }
     else if (live) for (uint32_t i = lane; i <= d.nrows; i += 64u) acc[i] = T(0);
     if constexpr (SHARED || DICT) __syncthreads();
@@ -207,10 +208,10 @@ __global__ __launch_bounds__(1024) void sorted_spmv_kernel(const uint8_t *__rest
 #define XR(s, j, n) "v[96+8*" S(s) "+" S(n) "*" S(j) ":96+8*" S(s) "+" S(n) "*" S(j) "+" S(n) "-1]"
 #define XR1(s, o) "v[96+8*" S(s) "+" S(o) "]"
 
-template <typename T, bool DICT, bool TAG, bool SHARED, bool BAR = false>
+template <typename T, bool DICT, bool TAG, bool SHARED, bool BAR = false, bool REP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sorted_spmv_ring_kernel(const uint8_t *__restrict__ stream, const ChunkDesc *__restrict__ desc, const uint32_t *__restrict__ wg_first,
                                                            const uint32_t *__restrict__ wg_count, const T *__restrict__ x, T *__restrict__ z, uint32_t col_bits,
-                                                           uint32_t R, const T *__restrict__ dict_g, uint32_t ndict)
+                                                           uint32_t R, const T *__restrict__ dict_g, uint32_t ndict, const uint32_t *__restrict__ rowslot = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t GB = group_bytes<T, DICT, TAG>();
@@ -228,8 +229,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
     T       *acc;
     if constexpr (SHARED) { k = first; live = cnt > 0; acc = acc_all; }
     else { k = first + wv_u; live = wv_u < cnt; acc = acc_all + (size_t)wv_u * (R + 1); }
-    ChunkDesc d = live ? desc[k] : ChunkDesc{0, 0, 0, 0, 0, 0};
-    if constexpr (SHARED) { for (uint32_t i = threadIdx.x; i <= d.nrows; i += blockDim.x) acc[i] = T(0); }
+    ChunkDesc d = live ? desc[k] : ChunkDesc{0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (SHARED) { for (uint32_t i = threadIdx.x; i <= (REP ? d.nacc : d.nrows); i += blockDim.x) acc[i] = T(0); }
     else if (live) for (uint32_t i = lane; i <= d.nrows; i += 64u) acc[i] = T(0);
     if constexpr (SHARED || DICT) __syncthreads();
     if (!live) return;
@@ -327,7 +328,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
 #undef TAKE
 #undef GATHER
 #undef LOADQ
-    if constexpr (SHARED) {
+    if constexpr (SHARED && REP) {          // mode 3: a replicated row has one accumulator per wavefront, added up in wavefront order
+        __syncthreads();
+        constexpr uint32_t kB = 8;                       // (eight table loads in flight per thread: the loop is a chain of round trips otherwise)
+        for (uint32_t i0 = threadIdx.x; i0 < d.nrows; i0 += blockDim.x * kB) {
+            uint32_t rs_[kB];
+#pragma unroll
+            for (uint32_t u = 0; u < kB; u++) { const uint32_t i = i0 + u * blockDim.x; rs_[u] = i < d.nrows ? rowslot[d.zoff + i] : 0u; }
+#pragma unroll
+            for (uint32_t u = 0; u < kB; u++) {
+                const uint32_t i = i0 + u * blockDim.x, sl = rs_[u] & 0x7fffffffu;
+                if (i < d.nrows) z[d.zoff + i] = (rs_[u] >> 31) ? ((acc[sl] + acc[sl + 1]) + acc[sl + 2]) + acc[sl + 3] : acc[sl];
+            }
+        }
+    } else if constexpr (SHARED) {
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < d.nrows; i += blockDim.x) z[d.zoff + i] = acc[i + 1];
     } else {
@@ -365,7 +379,7 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     uint32_t pw = (uint32_t)((A.ncols + P - 1) / P);
     pw = (pw + per_line - 1) / per_line * per_line;
     P = (uint32_t)((A.ncols + pw - 1) / pw);
-    const uint32_t Reff = mode >= 1 ? R * W : R;
+    const uint32_t Reff = mode >= 1 ? R * W : R;          // (mode 3: rows per chunk; its accumulators -- rows + 3 per replicated row -- must fit the LDS)
     // ---- split into panels: per panel the sub-rows (row, begin) and the elements, in row order
     struct Panel { std::vector<int64_t> sp; std::vector<int32_t> srow; std::vector<int32_t> col; std::vector<double> val; };
     std::vector<Panel> pan(P);
@@ -423,7 +437,7 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     // ---- formats
     uint32_t col_bits = 1; while ((1ull << col_bits) < pw) col_bits++;
     uint32_t row_bits = 1; while ((1ull << row_bits) < (uint64_t)Reff + 1) row_bits++;      // tags 0 .. Reff
-    const bool tag = col_bits + row_bits > 32;
+    const bool tag = col_bits + row_bits > 32 || mode == 3;
     if (tag && Reff + 1 > 65536) { fprintf(stderr, "rows per chunk beyond 16-bit tags\n"); return 1; }
     const uint32_t GB = 1024u + (tag ? 512u : 0u) + (use_dict ? 256u : sizeof(T) == 8 ? 2048u : 1024u);
     std::vector<ChunkDesc> desc(nch);
@@ -431,11 +445,14 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     for (size_t k = 0; k < nch; k++) {
         const auto &c = chunks[k];
         const uint32_t G = (uint32_t)((c.e1 - c.e0 + 255) / 256);
-        desc[k] = {soff, G, (uint32_t)(c.sub1 - c.sub0), zoff, (uint32_t)c.panel * pw, (uint32_t)std::min<int64_t>(pw, A.ncols - (int64_t)c.panel * pw)};
+        desc[k] = {soff, G, (uint32_t)(c.sub1 - c.sub0), zoff, (uint32_t)c.panel * pw, (uint32_t)std::min<int64_t>(pw, A.ncols - (int64_t)c.panel * pw), 0u, 0u};
         soff += (uint64_t)G * GB; zoff += (uint64_t)(c.sub1 - c.sub0);
     }
     std::vector<uint8_t> stream(soff + 8 * GB, 0);
     std::vector<int32_t> zrow(zoff);
+    std::vector<uint32_t> rowslot(zoff + 1, 0);
+    const long hotT = getenv("HOT_T") ? atol(getenv("HOT_T")) : 16;
+    int64_t nrep_tot = 0, nconf_tot = 0; uint32_t nacc_max = 0;
     double t0 = omp_get_wtime();
 #pragma omp parallel for schedule(dynamic, 8)
     for (size_t k = 0; k < nch; k++) {
@@ -454,6 +471,29 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
         std::vector<uint32_t> idx(n);
         std::iota(idx.begin(), idx.end(), 0u);
         std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return (key[a] >> 24) < (key[b] >> 24); });
+        std::vector<uint32_t> slot;          // mode 3: accumulator of a row (+ the wavefront for a replicated row)
+        std::vector<uint8_t>  rep;
+        if (mode == 3) {
+            const uint32_t nr = (uint32_t)(c.sub1 - c.sub0);
+            std::vector<uint32_t> deg(nr, 0), orow(nr, 0xffffffffu);
+            std::vector<uint8_t>  owav(nr, 0);
+            rep.assign(nr, 0);
+            for (int64_t e = 0; e < n; e++) deg[key[idx[e]] & 0xffffffu]++;
+            for (uint32_t r = 0; r < nr; r++) rep[r] = deg[r] >= (uint32_t)hotT;
+            int64_t nconf = 0;
+            for (int64_t e = 0; e < n; e++) {                      // a row that two wavefronts touch in one round is replicated as well
+                const uint32_t r = (uint32_t)(key[idx[e]] & 0xffffffu), round = (uint32_t)(e / (256 * W)), wave = (uint32_t)(e / 256) % W;
+                if (rep[r]) continue;
+                if (orow[r] == round && owav[r] != wave && !getenv("NOREP")) { rep[r] = 1; nconf++; }
+                else { orow[r] = round; owav[r] = (uint8_t)wave; }
+            }
+            slot.resize(nr);
+            uint32_t s = 1, nrep = 0;
+            for (uint32_t r = 0; r < nr; r++) { slot[r] = s; s += rep[r] ? W : 1; nrep += rep[r]; rowslot[desc[k].zoff + r] = slot[r] | ((uint32_t)rep[r] << 31); }
+            desc[k].nacc = s;
+#pragma omp critical
+            { nrep_tot += nrep; nconf_tot += nconf; nacc_max = std::max(nacc_max, s); }
+        }
         uint8_t *base = stream.data() + desc[k].stream_off;
         for (int64_t e = 0; e < (int64_t)desc[k].G * 256; e++) {
             const uint32_t g = (uint32_t)(e / 256), j = (uint32_t)(e % 256) / 64, ln = (uint32_t)(e % 64);
@@ -462,6 +502,7 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
             if (e < n) { const uint32_t i = idx[e]; col = (uint32_t)(key[i] >> 24); row = (uint32_t)(key[i] & 0xffffffu); v = pp.val[c.e0 + i]; }
             else { col = n ? (uint32_t)(key[idx[n - 1]] >> 24) : 0u; row = 0xffffffffu; v = 0.0; }      // pad: the last column again, the dump accumulator (tag 0)
             row += 1u;            // tags are biased by one: tag 0 (what a load past the end returns) is the dump accumulator
+            if (mode == 3) row = e < n ? slot[row - 1] + (rep[row - 1] ? (uint32_t)(e / 256) % W : 0u) : 0u;
             uint32_t cw = tag ? col : (col_bits >= 32 ? col : col | (row << col_bits));
             reinterpret_cast<uint32_t *>(gp)[ln * 4 + j] = cw;
             if (tag) reinterpret_cast<uint16_t *>(gp + 1024)[ln * 4 + j] = (uint16_t)row;
@@ -494,7 +535,8 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
         }
     } else for (auto &q : xq[0]) { wg_first.push_back(q.first); wg_count.push_back(q.second); }
     const uint32_t nwg = (uint32_t)wg_first.size();
-    const size_t lds = (size_t)(use_dict ? 256 : 0) * sizeof(T) + (size_t)(mode >= 1 ? 1 : W) * (Reff + 1) * sizeof(T);
+    const size_t lds = (size_t)(use_dict ? 256 : 0) * sizeof(T) + (mode == 3 ? (size_t)(nacc_max + 1) : (size_t)(mode >= 1 ? 1 : W) * (Reff + 1)) * sizeof(T);
+    if (mode == 3) printf("# mode 3: hot rows from %ld non-zeros; replicated rows %ld of %ld (%.1f %%), of them for a conflict %ld; most accumulators in a chunk %u\n", hotT, (long)nrep_tot, (long)npairs, 100.0 * nrep_tot / npairs, (long)nconf_tot, nacc_max);
     int64_t slots = 0; for (auto &d : desc) slots += (int64_t)d.G * 256;
     printf("# %s nrows %ld nnz %ld | P %u (%u cols, %.2f MB) pairs %.2fM chunks %zu wgs %u slots/nnz %.3f | R %u W %u Smax %u mode %d depth %d tag %d dict %d(%zu) bits %u+%u GB %u stream %.1f MB lds %zu | build %.1fs\n",
            sizeof(T) == 8 ? "f64" : "f32", (long)A.nrows, (long)A.nnz, P, pw, pw * sizeof(T) / 1e6, npairs / 1e6, nch, nwg, (double)slots / A.nnz, R, W, Smax, mode, depth, (int)tag, (int)use_dict,
@@ -507,7 +549,8 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
         zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull; zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull; zz ^= zz >> 31;
         x[j] = (T)((double)(zz >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0);
     }
-    uint8_t *d_stream; ChunkDesc *d_desc; uint32_t *d_first, *d_count; T *d_x, *d_z, *d_dict;
+    uint8_t *d_stream; ChunkDesc *d_desc; uint32_t *d_first, *d_count, *d_rowslot; T *d_x, *d_z, *d_dict;
+    CK(hipMalloc(&d_rowslot, rowslot.size() * 4)); CK(hipMemcpy(d_rowslot, rowslot.data(), rowslot.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_stream, stream.size())); CK(hipMemcpy(d_stream, stream.data(), stream.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&d_desc, nch * sizeof(ChunkDesc))); CK(hipMemcpy(d_desc, desc.data(), nch * sizeof(ChunkDesc), hipMemcpyHostToDevice));
     CK(hipMalloc(&d_first, nwg * 4)); CK(hipMemcpy(d_first, wg_first.data(), nwg * 4, hipMemcpyHostToDevice));
@@ -520,7 +563,8 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
 #define L(DI, TG, DP, SH, NA) hipLaunchKernelGGL((sorted_spmv_kernel<T, DI, TG, DP, SH, NA>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size())
 #define L_NA(DI, TG, DP, SH) do { if (noadd) L(DI, TG, DP, SH, 1); else L(DI, TG, DP, SH, 0); } while (0)
 #define L_SH(DI, TG, DP) do { if (mode >= 1) L_NA(DI, TG, DP, true); else L_NA(DI, TG, DP, false); } while (0)
-#define L_RING(DI, TG) do { if (mode == 2) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
+#define L_RING(DI, TG) do { if (mode == 3) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size(), d_rowslot); \
+        else if (mode == 2) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
         else if (mode == 1) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
         else hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, false>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); } while (0)
 #define L_DP(DI, TG) do { if (depth == 9) L_RING(DI, TG); else if (depth >= 8) L_SH(DI, TG, 8); else if (depth >= 4) L_SH(DI, TG, 4); else if (depth >= 2) L_SH(DI, TG, 2); else L_SH(DI, TG, 1); } while (0)
