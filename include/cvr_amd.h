@@ -65,9 +65,11 @@ typedef struct {
     int32_t device;            /* HIP device ordinal                                           */
     int32_t steps_per_chunk;   /* S: lane-stream length of one chunk, multiple of 4; 0 = auto  */
     int64_t split_threshold;   /* rows with more remaining nnz than this may be cut at a chunk */
-                               /* boundary; 0 = default (16*S)                                 */
+                               /* boundary; 0 = default (16*S; interleaved column panels: 32*S) */
     int32_t xcd_swizzle;       /* 1 (default when <0): contiguous chunk ranges per XCD; 0 off; */
-                               /* 2: also consecutive chunks per CU (measured within +-2 %)    */
+                               /* 2: also consecutive chunks per CU (measured within +-2 %);   */
+                               /* 3..6: runs of 2 / 4 / 8 / 16 workgroups dealt over the XCDs  */
+                               /* (measured: no gain over 1)                                   */
     int32_t x_window;          /* values of x each workgroup stages in LDS with coalesced loads */
                                /* and serves its gathers from (cut to what fits the 160 KiB of */
                                /* LDS beside the row-sum stage); 0 = off (<0 = default = off)  */
