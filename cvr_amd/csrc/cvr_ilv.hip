@@ -98,8 +98,7 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
         } else { key[i] = q.pad_col; val[i] = 0xffffffffu; }
     }
     __syncthreads();
-    if (!(flags & 8u)) Sort().sort_to_striped(key, val, *reinterpret_cast<typename Sort::storage_type *>(smem), 0u, cbits);
-    if (flags & 16u) return;
+    Sort().sort_to_striped(key, val, *reinterpret_cast<typename Sort::storage_type *>(smem), 0u, cbits);
 
     // the dictionary (sorted by bit pattern, at most 256 entries) goes to LDS in the sort's place: a search per element is eight LDS reads
     uint64_t *const dl = reinterpret_cast<uint64_t *>(smem);
@@ -162,7 +161,7 @@ template <int NT, int IPT, int RB = 0>
 hipError_t launch_chunks(const IlvTable *d_tab, uint32_t nchunks_tot, const DeviceImage &c, uint32_t ystage_max, uint32_t cbits, uint32_t *err_flag, hipStream_t st)
 {
     const size_t   lds = std::max(sizeof(typename ChunkSort<NT, IPT, RB>::type::storage_type), std::max<size_t>(2048, sizeof(uint32_t) * (size_t)std::max<uint32_t>(ystage_max, 1u)));
-    const uint32_t flags = (c.f32 ? kIlvF32 : 0u) | (c.dict ? kIlvDict : 0u) | (c.tag16 ? kIlvTag : 0u) | (debug_env("ilv_nosort") ? 8u : 0u) | (debug_env("ilv_nowrite") ? 16u : 0u);
+    const uint32_t flags = (c.f32 ? kIlvF32 : 0u) | (c.dict ? kIlvDict : 0u) | (c.tag16 ? kIlvTag : 0u);
     static bool    attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&ilv_chunk_kernel<NT, IPT, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
@@ -214,15 +213,12 @@ hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const Devi
     IlvTable *d_tab = static_cast<IlvTable *>(scratch);
     hipError_t rc = hipMemcpyAsync(d_tab, &tab, sizeof(IlvTable), hipMemcpyHostToDevice, st);
     if (rc != hipSuccess) return rc;
-    // (1 024 threads leave 128 registers each: 16 (column, position) pairs per thread sort without spills; the long chunks take 512 threads)
+    // (1 024 threads leave 128 registers each: 16 (column, position) pairs per thread sort without spills, 24 spill 92 bytes, 32 spill 470;
+    // 512 threads x 48 / 64 pairs spill more and ran slower: 2.8 against 2.2 ms on the soc-LiveJournal1 shape)
     if (ipt <= 4) return launch_chunks<1024, 4>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 8) return launch_chunks<1024, 8>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 12) return launch_chunks<1024, 12>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 16) return launch_chunks<1024, 16>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
-    if (debug_env("ilv_nt512")) {
-        if (ipt <= 24) return launch_chunks<512, 48>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
-        return launch_chunks<512, 64>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
-    }
     if (ipt <= 24) return launch_chunks<1024, 24>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     return launch_chunks<1024, 32>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
 }

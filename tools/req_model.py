@@ -40,6 +40,14 @@ if which == 'lj':
     n, _, rp, ci, va = synth.livejournal_like(scale=sc)
     print('gen', time.time()-t)
     model(rp, ci, n, 8, [1, int(max(1,round(16*sc)))], [1280, 2048, 4096, 8192, 16384], f'lj x{sc}')
+elif which == 'orkut':
+    import torch
+    from cvr_amd import synth_dev as D
+    sc = float(sys.argv[2]) if len(sys.argv) > 2 else 0.25
+    n, rp_t, ci_t, _ = D.orkut_like(scale=sc, device='cpu')
+    rp, ci = rp_t.numpy(), ci_t.numpy()
+    print('gen', time.time()-t)
+    model(rp, ci, n, 8, [int(max(1,round(8*sc)))], [2048, 3400, 4096, 8192, 16384, 32768], f'orkut x{sc}')
 elif which == 'rmat':
     s = int(sys.argv[2])
     n, _, rp, ci, va = synth.rmat(s)
