@@ -549,6 +549,11 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 for (int64_t v : nsubs) nsub_all += v;
                 IOpt one = panel_opt;
                 panel_opt.steps_per_chunk = interleave_steps((sj1 - sj0) / P, std::max<int64_t>(nsub_all / P, 1), f32, one);
+                if (xcd_panels && dev_split && !cvr::debug_env("ilv_plain_steps")) {      // panels one per XCD: the length that fills whole generations of workgroups
+                    std::vector<int64_t> pnz((size_t)P);
+                    for (int p = 0; p < P; p++) pnz[(size_t)p] = dsg.d.off[p + 1] - dsg.d.off[p];
+                    panel_opt.steps_per_chunk = interleave_steps_panels(pnz, nsubs, (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1, (P + 7) / 8, f32, one);
+                }
             }
             // rows are cut over chunks only when they are longer than half a chunk: the padding behind an interleaved chunk's non-zeros is
             // neither stored in a stream that is read nor walked (desc2.x), and a matrix without cut rows needs no fix-up launch

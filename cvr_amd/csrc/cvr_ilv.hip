@@ -9,7 +9,7 @@
 // r04_sorted_prototype_lj.log).  Every slot is a piece of its own: its column word carries the end flag and the row inside the chunk (or
 // the 16-bit tag does), which is the column-phase format in the limit of one column per phase and pieces of one element -- the image
 // runs through spmv_seg_kernel unchanged (per row the products are added in column order, as the CSR loop of spmv.cpp:1843-1850 does).
-//   slots e <  n (the chunk's non-zeros)     : column | end flag [| row << col_bits], value / code, [tag = row]
+//   slots e <  n (the chunk's non-zeros)     : column | row << col_bits (bits [col_bits, 32): no end flag, every slot ends a piece), or column | end flag + tag = row; value / code
 //   slots e >= n (padding up to 64 S; the pad slots the planner counts for empty rows among them): pad column (x_ext[ncols] = 0),
 //                                              value 0, row = the dump entry behind the chunk's rows
 // Preprocessing: one workgroup per chunk sorts the chunk's (column, position) pairs in LDS (hipCUB block radix sort, stable) and writes
@@ -142,8 +142,7 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
                     code = a;
                 }
                 uint8_t *grp = base + (size_t)g * GB;
-                uint32_t cw = col | kEndBit;
-                if (!tag) cw |= r << col_bits;
+                const uint32_t cw = tag ? col | kEndBit : col | (r << col_bits);          // (no end flag without tags: every slot ends a piece, the row takes bits [col_bits, 32))
                 reinterpret_cast<uint32_t *>(grp)[lane * 4 + j] = cw;
                 if (tag) reinterpret_cast<uint16_t *>(grp + kColsBytes)[lane * 4 + j] = (uint16_t)r;
                 if (use_dict) (grp + VB)[lane * 4 + j] = (uint8_t)code;
@@ -220,7 +219,7 @@ hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const Devi
     if (ipt <= 12) return launch_chunks<1024, 12>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 16) return launch_chunks<1024, 16>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 24) return launch_chunks<1024, 24>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
-    return launch_chunks<1024, 32>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    return launch_chunks<1024, 32>(d_tab, c, c0, ystage_max, cbits, err_flag, st);          // (768 threads x 44 pairs -- 170 registers each -- spill 364 bytes and take as long)
 }
 
 }  // namespace cvr

@@ -11,7 +11,7 @@ using namespace cvrh;
 namespace {
 
 constexpr uint64_t kImgMagic = 0x3130474d49525643ull;      // "CVRIMG01"
-constexpr uint32_t kImgVersion = 8;                        // bump when DeviceImage / the handle's tables change
+constexpr uint32_t kImgVersion = 9;                        // bump when DeviceImage / the handle's tables change
 
 struct ImgKey {
     uint64_t       magic;

@@ -50,10 +50,12 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
         // word can hold (the bits between the column index and the end flag)
         pp.col_bits = 1;
         while (((int64_t)1 << pp.col_bits) <= std::max<int64_t>(ncols, opt.col_span)) pp.col_bits++;      // (column panels of one launch: one width for all)
-        const int64_t row_field = pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
+        // (an interleaved column word has no end flag -- every slot ends a piece --, so its row field has one bit more; and its chunks may
+        // take every accumulator the LDS holds: 5 052 fp64 rows for each of four wavefronts)
+        const int64_t row_field = pp.ilv ? (pp.col_bits < 32 ? ((int64_t)1 << (32 - pp.col_bits)) - 1 : 0) : pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
         auto rows_for = [&](int64_t win) {
             const int64_t left = (int64_t)cvr::kLdsBytes - (cvr::kDictMax + win + 8) * vs;      // (no steal slots: spmv_seg_kernel; window + zero slot + the epilogue's arrival counter)
-            return std::min<int64_t>((left / pp.wpb / vs) & ~(int64_t)3, cvr::kYStageMax);
+            return std::min<int64_t>((left / pp.wpb / vs) & ~(int64_t)3, pp.ilv ? 2 * (int64_t)cvr::kYStageMax : cvr::kYStageMax);
         };
         while (pp.win > 0 && rows_for(pp.win) < 512) pp.win = (pp.win - 1024 > 0 ? pp.win - 1024 : 0) & ~(int64_t)3;      // the window gives way
         // a chunk of S steps holds at most 64 S rows: no need for more accumulators than that (keeps the LDS small)
@@ -93,12 +95,55 @@ void plan_stage(PartPlan &pp, bool f32)
 int interleave_steps(int64_t nnz, int64_t nrows, bool f32, const IOpt &opt)
 {
     const int64_t vs = f32 ? 4 : 8, wpb = opt.waves_per_block > 0 ? opt.waves_per_block : 4;
-    const int64_t rows = std::min<int64_t>(((int64_t)cvr::kLdsBytes / vs - cvr::kDictMax - 8) / wpb, cvr::kYStageMax) - 1;
+    const int64_t rows = std::min<int64_t>(((int64_t)cvr::kLdsBytes / vs - cvr::kDictMax - 8) / wpb, 2 * (int64_t)cvr::kYStageMax) - 1;
     const double  mean = (double)nnz / (double)std::max<int64_t>(nrows, 1);
     const double  cus = opt.panel_on_one_xcd ? (double)opt.cus / opt.xcds : (double)opt.cus;
     int64_t       S = (int64_t)(0.85 * mean * (double)rows / 64.0) + 1;      // (a little under what the row cap fills: most chunks then end at their slots, not at their rows -- 384 / 320 steps: 343 / 332 us on the soc-LiveJournal1 shape)
     S = std::min<int64_t>(S, (int64_t)((double)nnz / (64.0 * cus * (double)wpb)) + 1);
     return (int)std::min<int64_t>(508, std::max<int64_t>(16, (S + 3) / 4 * 4));
+}
+
+// Chunk length of interleaved column panels that run one per XCD (`rounds` panels after each other on an XCD's CUs): the launch takes as
+// many GENERATIONS of workgroups as ceil(workgroups of an XCD / its CUs), every workgroup holds the LDS of a CU, so the time is
+// generations x (time of a workgroup ~ S + a constant) -- soc-LiveJournal1 shape, 16 panels: 3 051 chunks (S = 416, 96 workgroups per XCD,
+// three generations) 305 us, 3 074 chunks (S = 412: 97, four generations) 345 us (profiles/r04_layout_probes.log).  The chunks of a panel
+// are estimated from its rows and non-zeros (chunks end at the row cap or at their slots: the cubic mean of the two counts is within 2 %
+// of the planner's), 3 % are added; the result is the smallest S that needs no more generations than S = 508 does.
+int interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<int64_t> &nsub, int64_t col_span, int rounds, bool f32, const IOpt &opt)
+{
+    const int64_t vs = f32 ? 4 : 8, wpb = opt.waves_per_block > 0 ? opt.waves_per_block : 4;
+    int           cb = 1;
+    while (((int64_t)1 << cb) <= col_span) cb++;
+    const int64_t field = cb < 32 ? ((int64_t)1 << (32 - cb)) : 0;
+    const int64_t rows = std::max<int64_t>(63, std::min<int64_t>(std::min<int64_t>((((int64_t)cvr::kLdsBytes / vs - cvr::kDictMax - 8) / wpb) & ~(int64_t)3, 2 * (int64_t)cvr::kYStageMax), field & ~(int64_t)3) - 1);
+    const double  cus = (double)opt.cus / opt.xcds;
+    const size_t  P = nnz.size();
+    auto workgroups = [&](int64_t S) {                 // of the XCD with the most: the panels dealt as cvr_create deals them (the fullest first, each to the XCD with the least)
+        std::vector<double> w(P);
+        for (size_t p = 0; p < P; p++) {
+            const double a = (double)nsub[p] / (double)rows, b = (double)nnz[p] / (64.0 * (double)S);
+            w[p] = std::ceil(std::cbrt(a * a * a + b * b * b) * 1.03 / (double)wpb);
+        }
+        std::sort(w.begin(), w.end(), [](double x, double y) { return x > y; });
+        double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int    cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t p = 0; p < P; p++) {
+            int x = -1;
+            for (int i = 0; i < 8; i++) if (cnt[i] < rounds && (x < 0 || load[i] < load[x])) x = i;
+            if (x < 0) x = 0;
+            load[x] += w[p]; cnt[x]++;
+        }
+        return *std::max_element(load, load + 8);
+    };
+    // the fewest generations the longest chunks allow, then the shortest chunks that still make it (the time of a generation depends
+    // little on S: soc-LiveJournal1 shape three generations 305-311 us at S = 416 .. 508, four generations 323-351 us at S = 284 .. 412)
+    const double  gmin = std::ceil(workgroups(508) / cus);
+    int64_t       best = 508;
+    for (int64_t S = 504; S >= 16; S -= 4) {
+        if (std::ceil(workgroups(S) / cus) > gmin) break;
+        best = S;
+    }
+    return (int)best;
 }
 
 hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr)

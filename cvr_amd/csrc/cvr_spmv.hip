@@ -844,7 +844,7 @@ __global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingC
                 else xv = __builtin_bit_cast(float, xx[j]);
                 uint32_t row;
                 if constexpr (TAG) row = (tg[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                else row = (cw[j] & kColMask) >> col_bits;
+                else row = cw[j] >> col_bits;          // (an interleaved column word has no end flag: bits [col_bits, 32) are the row)
                 lds_add(ystage + row, fma_t(av[j], xv, T(0)));          // (= the rounded product: what spmv_seg_kernel adds for a piece of one element)
             }
         });

@@ -366,7 +366,8 @@ int orc_cvr64_build_ilv(int64_t nrows, int64_t ncols, const int64_t *rp, const i
     while (((int64_t)1 << col_bits) <= ncols) col_bits++;
     if (c->tag16) col_bits = 31;
     c->col_bits = col_bits;
-    if (!c->tag16 && (col_bits >= 31 || max_rows > (((int64_t)1 << (31 - col_bits)) - 1) || max_rows <= 0)) return -7;
+    c->ilv = 1;          /* every slot is a piece of its own: no end flag; without tags the column word's bits [col_bits, 32) hold the row */
+    if (!c->tag16 && (col_bits >= 31 || max_rows > (((int64_t)1 << (32 - col_bits)) - 1) || max_rows <= 0)) return -7;
     if (c->tag16 && (max_rows <= 0 || max_rows > 65534)) return -7;
     if (S < 4 || S % 4) return -1;
     const int64_t cap = (int64_t)W * S;
@@ -426,7 +427,7 @@ int orc_cvr64_build_ilv(int64_t nrows, int64_t ncols, const int64_t *rp, const i
                 col = (uint32_t)key[s].col; row = (uint32_t)(r - q->row_first);
                 v = is_f32 ? (double)((const float *)vals)[p] : ((const double *)vals)[p];
             }
-            ((uint32_t *)grp)[l * 4 + j] = col | 0x80000000u | (c->tag16 ? 0u : row << col_bits);
+            ((uint32_t *)grp)[l * 4 + j] = c->tag16 ? col | 0x80000000u : col | row << col_bits;
             if (c->tag16) ((uint16_t *)(grp + 1024))[l * 4 + j] = (uint16_t)row;
             if (c->ndict) {
                 int code = code0;
@@ -500,8 +501,8 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
                 uint32_t col = cw & cmask;
                 if (c->hub_n && (col & 0x40000000u)) col = (uint32_t)c->hub_cols[col & 0x3fffffffu];     /* hub slot: rank -> column */
                 else if (c->order_n && col < (uint32_t)c->order_n) col = (uint32_t)c->hub_cols[col];      /* re-ordered x: rank -> column (the pad column stays) */
-                flagged[l] = cw >> 31;
-                rowtag[l] = !ph ? 0 : c->tag16 ? ((const uint16_t *)(grp + 1024))[l * 4 + j] : (cw & 0x7fffffffu) >> c->col_bits;
+                flagged[l] = c->ilv ? 1 : cw >> 31;
+                rowtag[l] = !ph ? 0 : c->tag16 ? ((const uint16_t *)(grp + 1024))[l * 4 + j] : c->ilv ? cw >> c->col_bits : (cw & 0x7fffffffu) >> c->col_bits;
                 if (c->is_f32) {
                     float v;
                     if (c->ndict) { const uint32_t u = (uint32_t)c->dict[(grp + cbytes)[l * 4 + j]]; memcpy(&v, &u, 4); }

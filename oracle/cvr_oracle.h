@@ -101,6 +101,7 @@ typedef struct {
     int       narrow;        /* 1: narrow chunks -- groups hold [64][4] u16 column offsets from cbase[k] (512 B) before the values */
     uint32_t *cbase;         /* narrow: [nchunks] smallest column of the chunk                                              */
     int       tag16;         /* phases > 1: the rows of the pieces stand in [64][4] u16 tags (512 B) behind the column words (col_bits = 31) */
+    int       ilv;           /* interleaved chunks (orc_cvr64_build_ilv): every slot ends a piece; without tags its column word holds the row in bits [col_bits, 32) */
 } orc_cvr64;
 
 int  orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,

@@ -30,7 +30,7 @@ class OrcCvr64(C.Structure):
                 ("ndict", C.c_int), ("dict", C.c_uint64 * 256), ("phases", C.c_int),
                 ("seg_off", C.POINTER(C.c_uint32)), ("seg_row", C.POINTER(C.c_uint16)), ("nrows_in", C.POINTER(C.c_uint32)),
                 ("col_bits", C.c_int), ("hub_n", C.c_int), ("hub_cols", C.POINTER(C.c_int32)),
-                ("order_n", C.c_int), ("narrow", C.c_int), ("cbase", C.POINTER(C.c_uint32)), ("tag16", C.c_int)]
+                ("order_n", C.c_int), ("narrow", C.c_int), ("cbase", C.POINTER(C.c_uint32)), ("tag16", C.c_int), ("ilv", C.c_int)]
 
 
 def lib():

@@ -927,7 +927,7 @@ def test_panel_plans_as_one_submission_same_result(monkeypatch, capfd):
     for serial in (False, True):
         if serial:
             monkeypatch.setenv("CVR_DEBUG", "fused_trace,serial_panel_plans")
-        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=8, hub_table=0)
+        A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, col_panels=8, hub_table=0, split_threshold=64)      # (a low threshold: rows are cut over chunks)
         if serial:
             monkeypatch.setenv("CVR_DEBUG", "fused_trace")
         i = A.info

@@ -53,7 +53,7 @@ def main():
         s = A.bench(20, 200)
         i = A.info
         print(f"  {spec or '(default)':50s} {s * 1e6:9.2f} us  {balg / s / 8e12 * 100:5.1f} %  wrong {wrong}  S {i.steps_per_chunk} wpb {i.waves_per_block} panels {i.col_panels} ilv {i.interleave} "
-              f"phases {i.col_phases} win {i.x_window} hub {i.hub_entries} ({i.hub_share:.2f}) reorder {i.hub_reorder} dict {i.value_dict} launches {i.spmv_launches} image_MB {i.image_bytes / 1e6:.0f} create_ms {wall * 1e3:.1f}", flush=True)
+              f"phases {i.col_phases} win {i.x_window} hub {i.hub_entries} ({i.hub_share:.2f}) reorder {i.hub_reorder} dict {i.value_dict} launches {i.spmv_launches} chunks {i.nchunks} rowcap {i.chunk_row_cap} image_MB {i.image_bytes / 1e6:.0f} create_ms {wall * 1e3:.1f}", flush=True)
         A.close()
 
 
