@@ -553,6 +553,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                     std::vector<int64_t> pnz((size_t)P);
                     for (int p = 0; p < P; p++) pnz[(size_t)p] = dsg.d.off[p + 1] - dsg.d.off[p];
                     panel_opt.steps_per_chunk = interleave_steps_panels(pnz, nsubs, (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1, (P + 7) / 8, f32, one);
+                    if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] interleaved panels: %d panels, chunk length %d for whole generations of workgroups\n", P, panel_opt.steps_per_chunk);
                 }
             }
             // rows are cut over chunks only when they are longer than half a chunk: the padding behind an interleaved chunk's non-zeros is
