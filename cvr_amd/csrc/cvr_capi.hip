@@ -542,6 +542,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         // 2.4-M-row matrix of single-entry rows 36.7 -> 38.7; web-Google shape x 3, 15 M: 94.9 -> 86.9; com-Orkut shape 1 307 -> 778:
         // profiles/r04_ilv_auto_probe.log)
         if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && sj1 - sj0 >= (int64_t)8 << 20 && !cvr::debug_env("no_auto_layout") ? 1 : 0;
+        int ilv_generations = 0;          // > 0: the chunk length was chosen for this many generations of workgroups (checked against the plan below)
         if (panel_opt.interleave > 0) {
             panel_opt.hub_table = 0; panel_opt.col_phases = 1;
             if (panel_opt.steps_per_chunk == 0) {       // one chunk length for all panels (they share a launch): from the mean sub-row and the mean panel
@@ -552,7 +553,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 if (xcd_panels && dev_split && !cvr::debug_env("ilv_plain_steps")) {      // panels one per XCD: the length that fills whole generations of workgroups
                     std::vector<int64_t> pnz((size_t)P);
                     for (int p = 0; p < P; p++) pnz[(size_t)p] = dsg.d.off[p + 1] - dsg.d.off[p];
-                    panel_opt.steps_per_chunk = interleave_steps_panels(pnz, nsubs, (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1, (P + 7) / 8, f32, one);
+                    panel_opt.steps_per_chunk = interleave_steps_panels(pnz, nsubs, (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1, (P + 7) / 8, f32, one, &ilv_generations);
                     if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] interleaved panels: %d panels, chunk length %d for whole generations of workgroups\n", P, panel_opt.steps_per_chunk);
                 }
             }
@@ -577,6 +578,25 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             for (int p = 0; p < P; p++) pcols[(size_t)p] = part_cols(p);
             rc = plan_panels_batched(h, dsg.d, nsubs, pcols, f32, popts, pps, drs, &batched);      // (panels without hub tables: all plans as one submission)
             if (rc) { cvr_destroy(h); return rc; }
+            if (batched && ilv_generations > 0 && panel_opt.steps_per_chunk < 508) {
+                // the plan has more chunks than the estimate said and the launch would take a generation more: once more with longer chunks
+                std::vector<int64_t> nch((size_t)P);
+                for (int p = 0; p < P; p++) nch[(size_t)p] = pps[(size_t)p].dev_nchunks;
+                const int wpb_i = panel_opt.waves_per_block > 0 ? panel_opt.waves_per_block : 4, cus_x = std::max(1, opt.cus / std::max(1, opt.xcds));
+                double    fullest = 0;
+                if (panel_generations(nch, (P + 7) / 8, wpb_i, cus_x, &fullest) > ilv_generations) {
+                    const int S2 = (int)std::min<int64_t>(508, ((int64_t)std::ceil(panel_opt.steps_per_chunk * fullest / ((double)ilv_generations * cus_x) * 1.02) + 3) / 4 * 4);
+                    if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] interleaved panels: %.0f workgroups on the fullest XCD, more than %d generations: planned again with chunk length %d\n", fullest, ilv_generations, S2);
+                    release_panel_plans(h);
+                    panel_opt.steps_per_chunk = S2;
+                    if (opt.split_threshold == 0) panel_opt.split_threshold = 32 * (int64_t)S2;
+                    for (IOpt &o : popts) { o.steps_per_chunk = S2; o.split_threshold = panel_opt.split_threshold; }
+                    pps.assign((size_t)P, PartPlan{});
+                    batched = false;
+                    rc = plan_panels_batched(h, dsg.d, nsubs, pcols, f32, popts, pps, drs, &batched);
+                    if (rc) { cvr_destroy(h); return rc; }
+                }
+            }
             for (int p = 0; p < P && !batched; p++) {
                 Part         &part = h->parts[(size_t)p];
                 const int64_t ns = nsubs[(size_t)p], nzp = dsg.d.off[p + 1] - dsg.d.off[p];

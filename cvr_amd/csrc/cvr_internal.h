@@ -222,7 +222,9 @@ constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24
 constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer
 int        pick_steps(int64_t nslots_est, int64_t max_row = 0, double cus = 256.0);
 int        interleave_steps(int64_t nnz, int64_t nrows, bool f32, const IOpt &opt);
-int interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<int64_t> &nsub, int64_t col_span, int rounds, bool f32, const IOpt &opt);
+int        interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<int64_t> &nsub, int64_t col_span, int rounds, bool f32, const IOpt &opt, int *generations = nullptr);
+int        panel_generations(const std::vector<int64_t> &chunks, int rounds, int wpb, int cus_per_xcd, double *fullest = nullptr);
+void       release_panel_plans(cvr_handle *h);
 hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const int64_t *rp, const IOpt &opt, const DevRows *dr = nullptr);
 int64_t    plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt);
 void       plan_stage(PartPlan &pp, bool f32);

@@ -108,8 +108,28 @@ int interleave_steps(int64_t nnz, int64_t nrows, bool f32, const IOpt &opt)
 // generations x (time of a workgroup ~ S + a constant) -- soc-LiveJournal1 shape, 16 panels: 3 051 chunks (S = 416, 96 workgroups per XCD,
 // three generations) 305 us, 3 074 chunks (S = 412: 97, four generations) 345 us (profiles/r04_layout_probes.log).  The chunks of a panel
 // are estimated from its rows and non-zeros (chunks end at the row cap or at their slots: the cubic mean of the two counts is within 2 %
-// of the planner's), 3 % are added; the result is the smallest S that needs no more generations than S = 508 does.
-int interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<int64_t> &nsub, int64_t col_span, int rounds, bool f32, const IOpt &opt)
+// of the planner's); the result is the smallest S that needs no more generations than S = 508 does.  cvr_create checks the plan against
+// it and plans once more with longer chunks when the plan has a generation more (panel_generations).
+// generations of workgroups of the fullest XCD for `chunks[p]` chunks per panel, `rounds` panels per XCD dealt as cvr_create deals them
+int panel_generations(const std::vector<int64_t> &chunks, int rounds, int wpb, int cus_per_xcd, double *fullest)
+{
+    std::vector<double> w(chunks.size());
+    for (size_t p = 0; p < chunks.size(); p++) w[p] = std::ceil((double)chunks[p] / (double)wpb);
+    std::sort(w.begin(), w.end(), [](double x, double y) { return x > y; });
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int    cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t p = 0; p < w.size(); p++) {
+        int x = -1;
+        for (int i = 0; i < 8; i++) if (cnt[i] < rounds && (x < 0 || load[i] < load[x])) x = i;
+        if (x < 0) x = 0;
+        load[x] += w[p]; cnt[x]++;
+    }
+    const double m = *std::max_element(load, load + 8);
+    if (fullest) *fullest = m;
+    return (int)std::ceil(m / (double)cus_per_xcd);
+}
+
+int interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<int64_t> &nsub, int64_t col_span, int rounds, bool f32, const IOpt &opt, int *generations)
 {
     const int64_t vs = f32 ? 4 : 8, wpb = opt.waves_per_block > 0 ? opt.waves_per_block : 4;
     int           cb = 1;
@@ -118,22 +138,16 @@ int interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<i
     const int64_t rows = std::max<int64_t>(63, std::min<int64_t>(std::min<int64_t>((((int64_t)cvr::kLdsBytes / vs - cvr::kDictMax - 8) / wpb) & ~(int64_t)3, 2 * (int64_t)cvr::kYStageMax), field & ~(int64_t)3) - 1);
     const double  cus = (double)opt.cus / opt.xcds;
     const size_t  P = nnz.size();
-    auto workgroups = [&](int64_t S) {                 // of the XCD with the most: the panels dealt as cvr_create deals them (the fullest first, each to the XCD with the least)
-        std::vector<double> w(P);
+    const double margin = cvr::debug_env("ilv_est_percent") ? atof(cvr::debug_env("ilv_est_percent")) / 100.0 : 1.0;      // (a test hook: an estimate that is too low makes cvr_create plan twice)
+    auto workgroups = [&](int64_t S) {                 // of the XCD with the most
+        std::vector<int64_t> c(P);
         for (size_t p = 0; p < P; p++) {
             const double a = (double)nsub[p] / (double)rows, b = (double)nnz[p] / (64.0 * (double)S);
-            w[p] = std::ceil(std::cbrt(a * a * a + b * b * b) * 1.03 / (double)wpb);
+            c[p] = (int64_t)std::ceil(std::cbrt(a * a * a + b * b * b) * margin);
         }
-        std::sort(w.begin(), w.end(), [](double x, double y) { return x > y; });
-        double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int    cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (size_t p = 0; p < P; p++) {
-            int x = -1;
-            for (int i = 0; i < 8; i++) if (cnt[i] < rounds && (x < 0 || load[i] < load[x])) x = i;
-            if (x < 0) x = 0;
-            load[x] += w[p]; cnt[x]++;
-        }
-        return *std::max_element(load, load + 8);
+        double m = 0;
+        (void)panel_generations(c, rounds, (int)wpb, (int)cus, &m);
+        return m;
     };
     // the fewest generations the longest chunks allow, then the shortest chunks that still make it (the time of a generation depends
     // little on S: soc-LiveJournal1 shape three generations 305-311 us at S = 416 .. 508, four generations 323-351 us at S = 284 .. 412)
@@ -143,6 +157,7 @@ int interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<i
         if (std::ceil(workgroups(S) / cus) > gmin) break;
         best = S;
     }
+    if (generations) *generations = (int)gmin;
     return (int)best;
 }
 
@@ -587,6 +602,15 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
     if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr panels] %d chunk plans as one submission\n", P);
     *done = true;
     return CVR_OK;
+}
+
+// what plan_panels_batched left in the parts, released (cvr_create plans the panels again with a longer chunk)
+void release_panel_plans(cvr_handle *h)
+{
+    for (Part &part : h->parts) {
+        for (void *q : {(void *)part.d_rp, (void *)part.d_nzb, (void *)part.d_pad, (void *)part.img.desc, (void *)part.img.desc2, (void *)part.img.shared}) if (q) (void)hipFree(q);
+        part.d_rp = nullptr; part.d_nzb = nullptr; part.d_pad = nullptr; part.img.desc = nullptr; part.img.desc2 = nullptr; part.img.shared = nullptr;
+    }
 }
 
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)

@@ -145,6 +145,28 @@ def test_interleaved_column_panels_one_per_xcd(f32):
     A.close()
 
 
+def test_interleaved_panels_planned_again_when_the_estimate_is_low(monkeypatch, capfd):
+    """the chunk length of one-per-XCD panels is chosen for whole generations of workgroups from an ESTIMATE of the chunk counts; when the
+    plan has a generation more, cvr_create plans once more with longer chunks (here the estimate is scaled down to 70 % to force that)"""
+    n, nc, rp, ci, va = synth.livejournal_like(scale=0.2)
+    x = O.x_vec_fast(nc, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    got = []
+    for pct in ("100", "70"):
+        monkeypatch.setenv("CVR_DEBUG", f"fused_trace,ilv_est_percent={pct}")
+        A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, col_panels=16, interleave=1)
+        err = capfd.readouterr().err
+        i = A.info
+        got.append((i.steps_per_chunk, i.nchunks, "planned again" in err))
+        assert i.interleave == 1 and "whole generations" in err
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL64, ("planned again", pct))
+        A.close()
+    monkeypatch.delenv("CVR_DEBUG")
+    assert got[1][2], got                                   # (the low estimate was corrected by a second plan ...)
+    assert got[1][0] > 16 and got[1][1] > 0, got
+
+
 @pytest.mark.parametrize("ncols", [129, 262, 1000, 4097])
 def test_interleaved_panels_of_unequal_width(ncols):
     """the last column panel is narrower than the others (its column index needs fewer bits): the panels share a launch, so they share
