@@ -108,7 +108,7 @@ int interleave_steps(int64_t nnz, int64_t nrows, bool f32, const IOpt &opt)
 // generations x (time of a workgroup ~ S + a constant) -- soc-LiveJournal1 shape, 16 panels: 3 051 chunks (S = 416, 96 workgroups per XCD,
 // three generations) 305 us, 3 074 chunks (S = 412: 97, four generations) 345 us (profiles/r04_layout_probes.log).  The chunks of a panel
 // are estimated from its rows and non-zeros (chunks end at the row cap or at their slots: the cubic mean of the two counts is within 2 %
-// of the planner's); the result is the smallest S that needs no more generations than S = 508 does.  cvr_create checks the plan against
+// of the planner's; 2 % are added); the result is the smallest S that needs no more generations than S = 508 does.  cvr_create checks the plan against
 // it and plans once more with longer chunks when the plan has a generation more (panel_generations).
 // generations of workgroups of the fullest XCD for `chunks[p]` chunks per panel, `rounds` panels per XCD dealt as cvr_create deals them
 int panel_generations(const std::vector<int64_t> &chunks, int rounds, int wpb, int cus_per_xcd, double *fullest)
@@ -138,7 +138,7 @@ int interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<i
     const int64_t rows = std::max<int64_t>(63, std::min<int64_t>(std::min<int64_t>((((int64_t)cvr::kLdsBytes / vs - cvr::kDictMax - 8) / wpb) & ~(int64_t)3, 2 * (int64_t)cvr::kYStageMax), field & ~(int64_t)3) - 1);
     const double  cus = (double)opt.cus / opt.xcds;
     const size_t  P = nnz.size();
-    const double margin = cvr::debug_env("ilv_est_percent") ? atof(cvr::debug_env("ilv_est_percent")) / 100.0 : 1.0;      // (a test hook: an estimate that is too low makes cvr_create plan twice)
+    const double margin = cvr::debug_env("ilv_est_percent") ? atof(cvr::debug_env("ilv_est_percent")) / 100.0 : 1.02;      // (a test hook: an estimate that is too low makes cvr_create plan twice)
     auto workgroups = [&](int64_t S) {                 // of the XCD with the most
         std::vector<int64_t> c(P);
         for (size_t p = 0; p < P; p++) {
