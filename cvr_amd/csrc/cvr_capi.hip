@@ -607,6 +607,11 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 if (rc) { cvr_destroy(h); return rc; }
                 CREATE_TRY(plan_part(pps[(size_t)p], ns, part_cols(p), f32, nullptr, popts[(size_t)p], &drs[(size_t)p]));
             }
+            if (batched && cvr::debug_env("fused_trace")) {
+                fprintf(stderr, "[cvr] chunks per panel:");
+                for (int p = 0; p < P; p++) fprintf(stderr, " %lld", (long long)pps[(size_t)p].dev_nchunks);
+                fprintf(stderr, "\n");
+            }
             in.plan_s += now_s() - tp - (in.hub_select_s - hub0);      // (hub selection is reported on its own)
             clk.lap("  hub tables, plans (device)");
         } else {
