@@ -488,9 +488,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             if (mid_range) P = 1;      // (an x of one such panel: the single image with its hub table, as before -- R-MAT-22 fp32)
             else if (Pw < P) P = Pw;
         }
-        // popularity too flat for any panel's table to reach the half it needs (a panel's own top columns hold a few times
-        // the whole matrix's share at most: LiveJournal shape 0.06): the panels skip their own counting passes
-        if (share < 0.08) opt.hub_table = 0;
+        // popularity too flat for the panels to be widened for their tables (a panel's own top columns hold a few times the whole
+        // matrix's share at most: LiveJournal shape 0.06): the panels skip their own counting passes and take interleaved chunks instead
+        // (web-Google shape x 2.2, whose share lies between 0.08 and 0.25: 72 us as plain panels that end up without tables, 55 us interleaved)
+        if (share < (cvr::debug_env("flat_share") ? atof(cvr::debug_env("flat_share")) : 0.25)) opt.hub_table = 0;
     }
     clk.lap("panel count with hub tables");
     if (P < 1) P = 1;
@@ -537,11 +538,11 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         panel_opt.col_phases = cvr::debug_env("panel_phases") ? atoi(cvr::debug_env("panel_phases")) : 1;          // column phases are for the single image whose chunks are all resident at once
         panel_opt.panel_on_one_xcd = xcd_panels ? 1 : 0;
         // interleaved chunks (automatic): panels that run one per XCD (their slice of x stays in that L2: what is left to save is the
-        // number of requests) and get no hub tables -- scattered columns without a popular head, the soc-LiveJournal1 shape
-        // (from 8 M non-zeros on: below, the few long chunks per XCD cost what the sorting saves -- wiki-Talk shape 5 M: 48.6 -> 50.4 us, a
-        // 2.4-M-row matrix of single-entry rows 36.7 -> 38.7; web-Google shape x 3, 15 M: 94.9 -> 86.9; com-Orkut shape 1 307 -> 778:
-        // profiles/r04_ilv_auto_probe.log)
-        if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && sj1 - sj0 >= (int64_t)8 << 20 && !cvr::debug_env("no_auto_layout") ? 1 : 0;
+        // number of requests) and get no hub tables -- scattered columns without a popular head, the soc-LiveJournal1 shape.  From 4 M
+        // non-zeros on (with the chunk length that fills whole generations of workgroups: wiki-Talk shape, 5 M, 48.6 -> 43.6 us; a 2.4-M-row
+        // matrix of single-entry rows 36.9 -> 38.6: stays plain; web-Google shape x 2.2 / 2.6 / 3: 72 -> 55, 84 -> 65, 95 -> 86; com-Orkut
+        // shape 1 307 -> 765: profiles/r04_ilv_auto_probe.log)
+        if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && sj1 - sj0 >= (cvr::debug_env("ilv_min_nnz") ? atoll(cvr::debug_env("ilv_min_nnz")) : (int64_t)4 << 20) && !cvr::debug_env("no_auto_layout") ? 1 : 0;
         int ilv_generations = 0;          // > 0: the chunk length was chosen for this many generations of workgroups (checked against the plan below)
         if (panel_opt.interleave > 0) {
             panel_opt.hub_table = 0; panel_opt.col_phases = 1;

@@ -33,19 +33,23 @@ def shapes(which):
     if "webgoogle3" in which:          # a web-Google shape three times the size (x = 22 MB: the mid range that gets eight panels)
         n, nc, rp, ci, va = synth.power_law_graph(int(916_428 * 3), int(5_105_039 * 3), 0.193, 456, 20261002)
         yield "webgoogle x3", n, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev)
+    for f in (2.2, 2.6):
+        if f"webgoogle{f}" in which:
+            n, nc, rp, ci, va = synth.power_law_graph(int(916_428 * f), int(5_105_039 * f), 0.193, 456, 20261002)
+            yield f"webgoogle x{f}", n, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), torch.from_numpy(va).to(dev)
     for s in (24,):
         if f"rmat{s}" in which:
             rp, ci, va = D.rmat_rows(s, 0, 1 << s, device=dev)
             yield f"rmat{s}", 1 << s, rp, ci, va
 
 
-which = sys.argv[1:] or ["orkut", "wikitalk", "tiny_rows", "webgoogle3"]
+which = sys.argv[1:] or ["orkut", "wikitalk", "tiny_rows", "webgoogle3", "webgoogle2.2", "webgoogle2.6"]
 for name, n, rp, ci, va in shapes(which):
     f32 = va.dtype == torch.float32
     tdt = va.dtype
     x_full = D.x_rand(n, device=dev, dtype=tdt)
     yref, absy = D.csr_spmv_reference(rp, ci, va, x_full)
-    for ilv in (0, -1):
+    for ilv in (0, -1, 1):
         A = cvr_amd.CvrMatrix.from_device(n, n, rp.data_ptr(), ci.data_ptr(), va.data_ptr(), is_f32=f32, interleave=ilv)
         i = A.info
         x = torch.zeros(i.x_elems, dtype=tdt, device=dev); x[:n] = x_full
