@@ -109,7 +109,7 @@ typedef struct {
     int32_t interleave;        /* interleaved chunks: a chunk's non-zeros are dealt to the 64 lanes in COLUMN order (element e of the chunk's
                                   column-sorted list at step e / 64, lane e % 64) instead of one row per lane, so that a gather instruction
                                   reads 64 column-sorted neighbours and lanes share 128-byte lines of x; every slot carries its row, the
-                                  rows' sums are accumulated in LDS (four chunks of up to 4 095 rows per workgroup).  For matrices whose x
+                                  rows' sums are accumulated in LDS (four chunks of up to 5 051 rows per workgroup).  For matrices whose x
                                   is far larger than an L2 and whose columns are scattered.  0 = off, 1 = on,
                                   <0 = auto (default): for column panels that run one per XCD and get no hub tables                       */
     int32_t reserved[4];       /* 0 */
