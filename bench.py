@@ -233,12 +233,35 @@ def _numactl_prefix():
     return ([exe, "--interleave=all"], "numactl --interleave=all") if ok else ([], "numactl refused --interleave=all: first-touch placement")
 
 
-def _run_reference(exe, path, T, iters, nnz, nrows, ncols, prefix=()):
+def _cpu_topology():
+    """{package id: [one logical CPU per physical core, ascending]} of the CPUs this process may run on (sysfs); {} if it cannot be read"""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except Exception:
+        return {}
+    pk = {}
+    for c in sorted(allowed):
+        base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+        try:
+            pkg = int(open(base + "physical_package_id").read())
+            sib = open(base + "thread_siblings_list").read().strip()
+            first = int(sib.replace("-", ",").split(",")[0])
+        except Exception:
+            return {}
+        if first == c or first not in allowed:          # the first hardware thread of its core (or the only one this process may use)
+            pk.setdefault(pkg, []).append(c)
+    return pk
+
+
+def _run_reference(exe, path, T, iters, nnz, nrows, ncols, prefix=(), cpus=None):
+    """one run of the reference binary; cpus: the CPUs the child is pinned to before it starts (its loader thread first-touches every
+    page there, its OpenMP threads are placed inside the set: what `numactl --membind` does for the reference, run_sample.sh:10)"""
     import re
     from cvr_amd import synth
     env = _child_env(OMP_NUM_THREADS=str(T), OMP_PROC_BIND="close", OMP_PLACES="cores")
+    pin = (lambda: os.sched_setaffinity(0, cpus)) if cpus else None
     try:
-        r = subprocess.run(list(prefix) + [exe, path, str(T), str(iters)], capture_output=True, text=True, timeout=240, env=env)
+        r = subprocess.run(list(prefix) + [exe, path, str(T), str(iters)], capture_output=True, text=True, timeout=240, env=env, preexec_fn=pin)
     except Exception:
         return None
     out = r.stdout
@@ -248,13 +271,15 @@ def _run_reference(exe, path, T, iters, nnz, nrows, ncols, prefix=()):
         return None
     per = float(m.group(1))
     return {"threads": T, "ms_per_step": per * 1e3, "gflops": 2.0 * nnz / per / 1e9, "reference_convention_gflops": nnz / per / 1e9,
-            "gbs_alg": synth.b_alg(nrows, ncols, nnz) / per / 1e9, "preprocess_s": float(p.group(1)) if p else None}
+            "gbs_alg": synth.b_alg(nrows, ncols, nnz) / per / 1e9, "preprocess_s": float(p.group(1)) if p else None, "pinned_cpus": len(cpus) if cpus else 0}
 
 
 def _cpu_reference(nrows, ncols, rp, ci, logical, physical):
     """the UNMODIFIED reference (spmv.cpp compiled by oracle/Makefile into oracle/_ref/, prebuilt in the build container) on a
-    Matrix-Market file of the bench matrix: kind = "reference".  None if it cannot run here.  Timed with 68 threads
-    (run_sample.sh:10) or all logical cores if fewer, and with one thread per physical core."""
+    Matrix-Market file of the bench matrix: kind = "reference".  None if it cannot run here.  Two configurations, five runs each:
+    (a) ONE SOCKET: min(68, physical cores of a socket) threads, the process pinned to that socket's cores (one hardware thread per
+    core) before it starts -- threads and pages on one socket, as run_sample.sh:10 binds its 68 threads' memory to one node --, and
+    (b) one thread per physical core of the whole host, pinned to exactly those."""
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib as O
@@ -262,36 +287,54 @@ def _cpu_reference(nrows, ncols, rp, ci, logical, physical):
     if not os.path.exists(exe):
         return None
     iters = 300
-    repeats = 3
+    repeats = 5
     runs = []
-    prefix, placement = _numactl_prefix()
+    topo = _cpu_topology()
+    configs = []          # (label, threads, cpus or None)
+    if topo:
+        pkg0 = sorted(topo)[0]
+        one = topo[pkg0][:68]
+        every = sorted(c for cs in topo.values() for c in cs)
+        configs.append((f"one socket: {len(one)} threads on {len(one)} cores of package {pkg0}", len(one), set(one)))
+        if len(every) > len(one):
+            configs.append((f"all {len(every)} physical cores of {len(topo)} packages", len(every), set(every)))
+        placement = "child pinned with sched_setaffinity before it starts (threads and first-touched pages inside the set)"
+        prefix = ()
+    else:
+        prefix, placement = _numactl_prefix()
+        for T in sorted({min(logical, 68), physical}, reverse=True):
+            configs.append((f"{T} threads, unpinned", T, None))
     with tempfile.TemporaryDirectory(dir="/tmp") as d:
         path = os.path.join(d, "bench.mtx")
         O.write_mtx_pattern(path, nrows, ncols, rp, ci)
-        for T in sorted({min(logical, 68), physical}, reverse=True):
+        for label, T, cpus in configs:
             for _ in range(repeats):
-                r = _run_reference(exe, path, T, iters, len(ci), nrows, ncols, prefix)
+                r = _run_reference(exe, path, T, iters, len(ci), nrows, ncols, prefix, cpus)
                 if r:
+                    r["config"] = label
                     runs.append(r)
     if not runs:
         return None
-    # per thread count: min / median / max over the repeats (the reference's time depends on where its threads and pages land);
-    # `value` is the MEDIAN of the better thread count -- a typical run, not the luckiest
-    by_t = {}
+    # per configuration: min / median / max over the repeats and their spread; `value` is the MEDIAN run of the configuration whose
+    # median is better -- a typical run, not the luckiest
+    by_c = {}
     for r in runs:
-        by_t.setdefault(r["threads"], []).append(r)
+        by_c.setdefault(r["config"], []).append(r)
     stats = []
-    for T, rs in by_t.items():
+    for label, rs in by_c.items():
         ms = sorted(x["ms_per_step"] for x in rs)
-        stats.append({"threads": T, "runs": len(rs), "ms_per_step_min": ms[0], "ms_per_step_median": ms[len(ms) // 2], "ms_per_step_max": ms[-1]})
+        med = ms[len(ms) // 2]
+        stats.append({"config": label, "threads": rs[0]["threads"], "runs": len(rs), "ms_per_step_min": ms[0], "ms_per_step_median": med, "ms_per_step_max": ms[-1],
+                      "spread_max_minus_min_over_median": (ms[-1] - ms[0]) / med})
     pick = min(stats, key=lambda x: x["ms_per_step_median"])
-    best = sorted(by_t[pick["threads"]], key=lambda x: x["ms_per_step"])[len(by_t[pick["threads"]]) // 2]
+    chosen = sorted(by_c[pick["config"]], key=lambda x: x["ms_per_step"])
+    best = chosen[len(chosen) // 2]
     return {"value": best["gflops"], "unit": "GFLOP/s", "cores": best["threads"], "kind": "reference",
             "sample": f"unmodified reference source built by oracle/Makefile (g++ -O3 -mavx512f -fopenmp, 4 intrinsic-spelling aliases in oracle/ref_shim.h), "
                       f"{iters} timed SpMV iterations of the full matrix per run, y zeroing outside the timer as the reference does (spmv.cpp:1026-1033); "
-                      f"{repeats} runs each with 68 threads (run_sample.sh:10; all logical cores if fewer) and with one thread per physical core, memory: {placement}; "
-                      "`value` is the median run of the thread count whose median is better",
-            "ms_per_step": best["ms_per_step"], "preprocess_s": best["preprocess_s"], "gbs_alg": best["gbs_alg"],
+                      f"{repeats} runs per configuration ({'; '.join(c[0] for c in configs)}), memory: {placement}; "
+                      "`value` is the median run of the configuration whose median is better",
+            "ms_per_step": best["ms_per_step"], "preprocess_s": best["preprocess_s"], "gbs_alg": best["gbs_alg"], "spread": pick["spread_max_minus_min_over_median"],
             "reference_convention_gflops": best["reference_convention_gflops"], "per_thread_count": stats, "memory_placement": placement, "runs": runs}
 
 
@@ -426,6 +469,8 @@ def main():
     ap.add_argument("--two-streams", action="store_true", help="also report the throughput of independent SpMVs alternating on two streams "
                     "(off by default: concurrent kernels would distort a rocprofv3 kernel-time summary of this command)")
     ap.add_argument("--workload", default="webgoogle", help="webgoogle (the headline, default) | livejournal | orkut | wikitalk | banded[<rows>] | rmat[<scale>] (fp32)")
+    ap.add_argument("--dump-y", default="", help="rank 0 writes the y of the last timed step (N > 1: the all-gathered vector, padding removed) to this .npy file: "
+                    "the tests check it against the oracle (bench.py itself may not use oracle/ outside its cpu_baseline leg)")
     ap.add_argument("--emulate-rank", default="", help="r/N with --gpus 1 and a device-built workload (rmat<scale>, banded<rows>): build and time ONLY rank r's "
                     "row shard of an N-way partition (x replicated, as on N GPUs); no exchange.  The per-rank regime of the 8-GPU configurations on one GPU")
     args = ap.parse_args()
@@ -734,6 +779,9 @@ def main():
             wrong = int(np.count_nonzero(np.abs(yh.astype(np.float64) - yref) > tol * absy + (1e-30 if f32 else 1e-300)))
             wrong_ref = int(cvr_amd.verdict(yh.astype(np.float64), yref, nrows))
 
+    if args.dump_y and rank == 0:
+        ydump = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()
+        np.save(args.dump_y, ydump)
     copy_gbs = None
     if rank == 0:
         try:                      # achievable-HBM yardstick measured live: 1 GiB streaming copy, read + write

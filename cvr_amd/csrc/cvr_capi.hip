@@ -288,8 +288,8 @@ struct PhaseClock {
 
 int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *opt_in)
 {
+    cvr::debug_refresh();          // (first: everything below, the phase clock included, reads this call's CVR_DEBUG)
     PhaseClock clk;
-    cvr::debug_refresh();
     if (!out) return fail(CVR_ERR_INVALID, "out is null");
     *out = nullptr;
     Range range("cvr_create (validate, plan, upload)");

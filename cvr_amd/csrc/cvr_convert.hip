@@ -1327,7 +1327,7 @@ hipError_t launch_seg_total(const SegTable &st, uint32_t nchunks, const uint32_t
 hipError_t launch_seg_build(const DeviceImage &img, const DeviceCsr &csr, SegTable &st, hipStream_t s, const uint32_t *nchunks_dev, bool with_total)
 {
     if (img.nchunks == 0) return hipSuccess;
-    static const bool by_rows = cvr::debug_env("seg_by_rows") != nullptr;      // (diagnostics: the search-based kernel)
+    const bool by_rows = cvr::debug_env("seg_by_rows") != nullptr;      // (diagnostics: the search-based kernel)
     if (const size_t lds = by_rows ? 0 : seg_scan_lds_bytes(img)) {
         unsigned long long *dbg = nullptr;
         if (cvr::debug_env("seg_clocks") && hipMalloc(&dbg, sizeof(unsigned long long) * 16 * 64) != hipSuccess) dbg = nullptr;
@@ -1421,7 +1421,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
     const size_t cap = (size_t)kLanes * img.S;
     size_t       per = seg ? 6 * cap : 4 * (cap + 2);
     per = (per + 15) & ~(size_t)15;
-    static const bool direct = cvr::debug_env("convert_direct") != nullptr;       // (diagnostics: the unstaged kernel)
+    const bool direct = cvr::debug_env("convert_direct") != nullptr;       // (diagnostics: the unstaged kernel)
     const bool   stage = !img.c16 && cap < 65535 && per * kWavesPerBlock <= (20u << 10) && !direct;
     const size_t lds = stage ? per * kWavesPerBlock : 0;
 #define CVR_CONVERT_ARGS(T)                                                                                            \

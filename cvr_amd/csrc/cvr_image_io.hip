@@ -202,6 +202,7 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
     uint32_t nparts = 0, nrounds = 0, has_multi = 0;
     r.pod(nparts); r.pod(h->ndict); r.pod(h->max_nshared); r.pod(h->multi_ystage); r.pod(nrounds); r.pod(has_multi);
     if (!r.ok || nparts == 0 || nparts > 64 || nrounds > 8 || (has_multi && nrounds != (nparts + 7) / 8) || (int64_t)nparts != (int64_t)std::max(h->info.col_panels, 1)) { r.ok = false; LOAD_TRY(hipSuccess); }
+    std::vector<bool> slot_used((size_t)nrounds * 8, false);          // (has_multi: the parts' slots must be distinct)
     h->multi_chunks.resize(nrounds);
     for (uint32_t i = 0; i < nrounds; i++) r.pod(h->multi_chunks[i]);
     if (h->ndict > (uint32_t)cvr::kDictMax) { r.ok = false; LOAD_TRY(hipSuccess); }
@@ -234,6 +235,12 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
                               s.stream_bytes == nc * (uint64_t)s.G * (uint64_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16) &&
                               (s.multi_slot < 0 || (has_multi && (uint32_t)s.multi_slot < nrounds * 8)) && cvr::spmv_lds_bytes(g) <= cvr::kLdsBytes;
             if (!sane) { r.ok = false; LOAD_TRY(hipSuccess); }
+            // panels that run one per XCD: every part has a slot of its own in d_multi (two parts on one slot would leave one of them
+            // unlaunched -- its slice of z stays zero, y silently wrong --; a part without a slot in a file that has the table likewise)
+            if (has_multi) {
+                if (s.multi_slot < 0 || slot_used[(size_t)s.multi_slot]) { r.ok = false; LOAD_TRY(hipSuccess); }
+                slot_used[(size_t)s.multi_slot] = true;
+            }
         }
         // (the stream allocation is padded for the kernel's run-ahead past the last chunk, as finish_part pads it)
         const size_t slack = 8 * (size_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16);

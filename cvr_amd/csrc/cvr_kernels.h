@@ -129,7 +129,8 @@ hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const in
 struct Plan;
 bool       plan_on_device_ok(int32_t S);
 // scratch the caller may keep across calls: device bytes (grown on demand) and a pinned host buffer for the records coming back
-struct PlanScratch { uint8_t *dev = nullptr; size_t dev_bytes = 0; uint8_t *pinned = nullptr; size_t pinned_bytes = 0; };
+struct PlanScratch { uint8_t *dev = nullptr; size_t dev_bytes = 0; uint8_t *pinned = nullptr; size_t pinned_bytes = 0;
+                     bool borrowed = false; };      // borrowed: `dev` points INTO someone else's allocation -- never freed or grown here (a plan that needs more is an error)
 void       free_plan_scratch(PlanScratch &ws);
 // the planner's kernels enqueued without a synchronisation (cvr_fused.hip): the records stay on the device
 struct DevicePlan {

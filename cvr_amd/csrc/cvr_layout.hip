@@ -299,7 +299,8 @@ hipError_t enqueue_dict_scan(cvr_handle *h, const void *d_va, int64_t nz0, int64
 bool resident_candidate(double slots, int cus, int *best_w, int *best_S)
 {
     *best_w = 0; *best_S = 0;
-    static const bool old_rule = cvr::debug_env("resident_rule") && !strcmp(cvr::debug_env("resident_rule"), "old");
+    const char *const rr = cvr::debug_env("resident_rule");          // (read per call: a latched static would keep the first call's environment)
+    const bool old_rule = rr && !strcmp(rr, "old");
     if (old_rule) {
         double best_fill = 0;
         for (int w = 8; w >= 6; w--) {
@@ -546,7 +547,7 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
     {
         const size_t sc = (scratch + 255) & ~(size_t)255, tot_bytes = sizeof(unsigned long long) * 4 * (size_t)P;
         HIP_TRY(hipMalloc(&own.base, sc * (size_t)(nst - 1) + tot_bytes));
-        for (int i = 1; i < nst; i++) { own.ws[i].dev = static_cast<uint8_t *>(own.base) + sc * (size_t)(i - 1); own.ws[i].dev_bytes = scratch; }
+        for (int i = 1; i < nst; i++) { own.ws[i].dev = static_cast<uint8_t *>(own.base) + sc * (size_t)(i - 1); own.ws[i].dev_bytes = scratch; own.ws[i].borrowed = true; }
         own.d_tot = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(own.base) + sc * (size_t)(nst - 1));
         HIP_TRY(hipMemset(own.d_tot, 0, tot_bytes));
     }

@@ -317,7 +317,7 @@ size_t plan_scratch_bytes(int64_t nrows, int64_t nz_end, int32_t S, int64_t max_
 }
 
 // Enqueues the planner's kernels on `st` (no synchronisation, nothing copied back): chunk records, cut rows and totals stay in
-// the scratch `ws` (grown if needed) at the pointers of `out`; `tables` (optional) are written by the last kernel.
+// the scratch `ws` (grown if needed, unless it is borrowed) at the pointers of `out`; `tables` (optional) are written by the last kernel.
 // out->declined: the plan cannot be made on the device (chunk length beyond the jump table); nothing was enqueued.
 hipError_t plan_chunks_device_enqueue(const int64_t *rp_dev, int64_t nrows, int64_t nz_end, int32_t S, int64_t thr, int64_t max_rows, hipStream_t st, PlanScratch *ws,
                                       DevicePlan *out, const PlanTables *tables)
@@ -341,6 +341,7 @@ hipError_t plan_chunks_device_enqueue(const int64_t *rp_dev, int64_t nrows, int6
                   o_sh = o_ch + up(sizeof(ChunkRec) * (size_t)bound), o_tot = o_sh + up(sizeof(Shared) * (size_t)bound), total = o_tot + 256;
     hipError_t e = hipSuccess;
     if (ws->dev_bytes < total) {
+        if (ws->borrowed) return hipErrorInvalidValue;          // (an interior pointer of the caller's arena, sized by plan_scratch_bytes: the same formula as `total`)
         if (ws->dev) (void)hipFree(ws->dev);
         ws->dev = nullptr; ws->dev_bytes = 0;
         e = hipMalloc(&ws->dev, total + total / 4);
@@ -447,7 +448,7 @@ hipError_t plan_chunks_device(const int64_t *rp_dev, int64_t nrows, int64_t nz_e
 
 void free_plan_scratch(PlanScratch &ws)
 {
-    if (ws.dev) (void)hipFree(ws.dev);
+    if (ws.dev && !ws.borrowed) (void)hipFree(ws.dev);
     if (ws.pinned) (void)hipHostFree(ws.pinned);
     ws = PlanScratch();
 }

@@ -370,7 +370,7 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
     size_t       part_scan_bytes = 0;
     SPLIT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, part_scan_bytes, head, sidx, (unsigned int)part_n, st));
     auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    static const bool by_sort = cvr::debug_env("split_sort") != nullptr;      // (diagnostics: the sort-and-gather form)
+    const bool by_sort = cvr::debug_env("split_sort") != nullptr;      // (diagnostics: the sort-and-gather form)
     const bool   partition = !by_sort && width < (1ll << 31);
     if (partition) sort_bytes = 0;                                        // (keys, positions and the sort's work space -- 10 B per non-zero and more -- are the sort form's only)
     const size_t nn = (size_t)std::max<long long>(n, 4), ns = partition ? 4 : nn;

@@ -701,7 +701,10 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
 //   in flight), copy group g out, gather group g + D, stream group g + 2 D into the freed slots, then the arithmetic of group g.
 // (The same ring around the headline kernel's loop made that kernel slower -- seven wavefronts per CU already fill the L2s' queues:
 // profiles/r04_seg_ring_kernel.log.)
-constexpr int kRingCap = 96;          // the compiler's registers: v0 .. v95
+#ifndef CVR_RING_CAP
+#define CVR_RING_CAP 96               // (tools/isa_check.py's self-test compiles with a cap the compiler cannot live in and expects the guard to refuse the result)
+#endif
+constexpr int kRingCap = CVR_RING_CAP;      // the compiler's registers: v0 .. v95
 constexpr int kRingThreads = 512;     // at most 8 wavefronts per workgroup: 256 registers each
 
 template <int R> __device__ __forceinline__ void ring_ld128(uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff)
@@ -809,6 +812,9 @@ __global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingC
         else { ring_ld32<X>(o0, rx, 0u); ring_ld32<X + 1>(o1, rx, 0u); ring_ld32<X + 2>(o2, rx, 0u); ring_ld32<X + 3>(o3, rx, 0u); }
     };
     // run-in: the first D groups' stream, then what the steps -D .. -1 of the loop would have issued
+    // (the two markers bracket the region tools/isa_check.py looks at in the compiler's output -- `make isa-check`: every vector-memory
+    // instruction between them must be one of the asm statements' loads into the ring's registers, and nothing may spill)
+    asm volatile("; CVR_RING_BEGIN cap=%0" ::"n"(kRingCap) : "memory");
     static_for<0, D>([&](auto ic) { load_q(ic, (uint32_t)decltype(ic)::value); });
     ring_wait<0>();
     static_for<0, D>([&](auto ic) {
@@ -850,6 +856,7 @@ __global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingC
         });
     }
     ring_wait<0>();
+    asm volatile("; CVR_RING_END" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (uint32_t i = lane; i < nri; i += kLanes) {          // the rows leave coalesced (head / last row of a chunk that shares it: its carry slot)

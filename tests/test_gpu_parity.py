@@ -1401,6 +1401,52 @@ def test_bench_starts_itself_for_two_ranks_on_one_device():
     assert len(d["config"]["rows_per_gpu"]) == 2 and sum(d["config"]["nnz_per_gpu"]) == 5105039
 
 
+@pytest.mark.parametrize("workload", ["rmat20", "banded1e6"])
+def test_bench_eight_ranks_on_one_device(workload, tmp_path):
+    """The 8-rank path of configs[3] / [4] end to end on ONE device (CVR_BENCH_ONE_DEVICE=1: eight processes on cuda:0, gloo carries the
+    exchange -- RCCL refuses two ranks on one GPU): device-built shards (R-MAT fp32, banded fp64), the cost-balanced cut, x replicated, y
+    all-gathered.  Checks n_gpus, a clean in-run verdict on every rank's slice, the balance of the cut, and the gathered y of the last
+    timed step (--dump-y) row by row against the pinned oracle on the matrix built in one piece.  (No 8-GPU box in this pool: the RCCL
+    form of the same exchange has only ever run with one rank -- DESIGN.md section 6.)"""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from cvr_amd import synth_dev as D
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CVR_BENCH_ONE_DEVICE="1", CVR_BENCH_NO_TUNE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    ypath = str(tmp_path / "y.npy")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "10", "--warmup", "2", "--workload", workload, "--no-cpu-baseline",
+                        "--dump-y", ypath], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["verdict_wrong_rows"] == 0 and d["scaling"] == "strong"
+    cfg = d["config"]
+    assert len(cfg["rows_per_gpu"]) == 8 and len(cfg["nnz_per_gpu"]) == 8
+    if workload == "rmat20":
+        n, f32 = 1 << 20, True
+        rp_t, ci_t, va_t = D.rmat_rows(20, 0, n, device="cuda")
+        assert cfg["nnz_imbalance_max_over_mean"] < 1.35          # (the cut balances non-zeros + 1.25 per row, not non-zeros: R-MAT's last shard holds the short rows)
+    else:
+        n, f32 = 1_000_000, False
+        rp_t, ci_t, va_t = D.banded_rows(n, 0, n, device="cuda")
+        assert cfg["nnz_imbalance_max_over_mean"] < 1.01
+    assert sum(cfg["rows_per_gpu"]) == n and sum(cfg["nnz_per_gpu"]) == int(rp_t[-1])
+    rp, ci, va = rp_t.cpu().numpy(), ci_t.cpu().numpy(), va_t.cpu().numpy()
+    del rp_t, ci_t, va_t
+    torch.cuda.empty_cache()
+    y = np.load(ypath)
+    assert y.shape == (n,) and y.dtype == (np.float32 if f32 else np.float64)
+    x = synth.x_rand(n, np.float32 if f32 else np.float64)
+    yref, absy = O.csr_spmv64(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    bad, worst = O.tol_check(y.astype(np.float64), yref, absy, tol=1e-5 if f32 else 1e-12)
+    assert len(bad) == 0, (len(bad), worst)
+
+
 def test_bench_device_built_workload():
     """bench.py --workload rmat20: the matrix is built shard by shard on the GPU (cvr_amd/synth_dev.py), handed over as
     device-resident CSR, and the timed configuration is checked on the device against a torch fp64 segment sum"""

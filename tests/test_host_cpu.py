@@ -217,6 +217,24 @@ def test_host_sources_under_sanitizers():
     assert "0 failure(s)" in r.stdout
 
 
+def test_ring_kernel_isa_guard():
+    """spmv_ilv_kernel keeps its in-flight loads in registers the compiler does not allocate and waits with counted vmcnt: the build
+    checks the compiler's assembly for spills, for compiler-issued vector-memory instructions inside the ring region and for compiler
+    use of the ring's registers (make isa-check, tools/isa_check.py; also run by __graft_entry__.build()).  The guard must pass on the
+    kernel as it is and must FAIL the build -- not a parity test -- on one compiled with a register cap the compiler cannot keep."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "cvr_amd", "csrc"), "isa-check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "isa_check: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("vgpr spills 0") == 8          # every instantiation was looked at
+    env = dict(os.environ, HIPCC_EXTRA="-DCVR_RING_CAP=24")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "cvr_amd", "csrc"), "isa-check"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "isa_check: FAIL" in r.stdout, r.stdout[-3000:]
+
+
 @pytest.mark.parametrize("kind", ["pattern symmetric", "real general", "real symmetric", "integer general"])
 def test_parallel_loader_equals_pinned_oracle_loader_on_large_files(tmp_path, kind):
     """files large enough to be parsed in several text segments: the product loader (REFCOMPAT) against the oracle's

@@ -158,18 +158,34 @@ def _shard_local_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_shard_local_workloads_equal_slices_of_the_whole():
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_local_workloads_equal_slices_of_the_whole(world):
+    """world 8 = the rank count of BASELINE.json configs[3] / [4] (one process per GPU of a node): partition_from_degrees and the
+    shard-local generators at that size, over gloo"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29000 + os.getpid() % 1000
-    procs = [ctx.Process(target=_shard_local_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_local_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    ok = q.get(timeout=120)
+    ok = q.get(timeout=300)
     for p in procs:
-        p.join(60)
+        p.join(120)
+        assert p.exitcode == 0
     assert ok
+
+
+def test_partition_from_degrees_is_the_library_rule_at_eight_parts():
+    """synth_dev.partition_from_degrees restates cvr_row_partition_cost on device tensors (shards are built where they will live): the same
+    bounds as the C routine for 8 parts, with the row cost of the product (1.25 non-zeros per row) and without"""
+    from cvr_amd import synth_dev as D
+    deg = D.rmat_row_degrees(14)
+    rp = np.concatenate([[0], np.cumsum(deg.numpy())]).astype(np.int64)
+    for cost in (0, 1250):
+        bounds, grp = D.partition_from_degrees(deg, 8, cost)
+        assert np.array_equal(np.asarray(bounds, dtype=np.int64), np.asarray(shard.row_partition(rp, 8, cost), dtype=np.int64))
+        assert int(grp[-1]) == int(rp[-1]) and bounds[0] == 0 and bounds[-1] == len(deg)
 
 
 def test_synth_dev_matches_the_numpy_generators_where_defined():

@@ -552,6 +552,20 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     uint8_t *d_stream; ChunkDesc *d_desc; uint32_t *d_first, *d_count, *d_rowslot; T *d_x, *d_z, *d_dict;
     CK(hipMalloc(&d_rowslot, rowslot.size() * 4)); CK(hipMemcpy(d_rowslot, rowslot.data(), rowslot.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_stream, stream.size())); CK(hipMemcpy(d_stream, stream.data(), stream.size(), hipMemcpyHostToDevice));
+    // SAME_STREAM=M (timing only, wrong sums): every chunk streams the image of one of the first M chunks of its panel (its own x slice and
+    // accumulators), so the matrix stream is L2-resident -- what a perfect prefetch of the stream into the L2s would give; the gathers keep
+    // the pattern of real chunks (round 5: how much of the kernel is the stream's HBM misses holding the L1's miss queue?)
+    if (getenv("SAME_STREAM") && atoi(getenv("SAME_STREAM")) > 0) {
+        const size_t M = (size_t)atoi(getenv("SAME_STREAM"));
+        std::vector<ChunkDesc> d2 = desc;
+        size_t base = 0;
+        for (size_t k = 0; k < nch; k++) {
+            if (k > 0 && chunks[k].panel != chunks[k - 1].panel) base = k;
+            const ChunkDesc &src = desc[base + (k - base) % M < nch && chunks[base + (k - base) % M].panel == chunks[k].panel ? base + (k - base) % M : base];
+            d2[k].stream_off = src.stream_off; d2[k].G = std::min(desc[k].G, src.G);
+        }
+        desc = d2;
+    }
     CK(hipMalloc(&d_desc, nch * sizeof(ChunkDesc))); CK(hipMemcpy(d_desc, desc.data(), nch * sizeof(ChunkDesc), hipMemcpyHostToDevice));
     CK(hipMalloc(&d_first, nwg * 4)); CK(hipMemcpy(d_first, wg_first.data(), nwg * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_count, nwg * 4)); CK(hipMemcpy(d_count, wg_count.data(), nwg * 4, hipMemcpyHostToDevice));
