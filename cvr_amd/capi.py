@@ -64,7 +64,7 @@ class MmMatrix(C.Structure):
 # every symbol include/cvr_amd.h declares (tests check the library exports all of them)
 SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_count", "cvr_create", "cvr_preprocess",
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
-           "cvr_spmv_bench", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_plan_selfcheck", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
+           "cvr_spmv_bench", "cvr_debug_phase_clocks", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_plan_selfcheck", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
            "cvr_tune_steps", "cvr_tune", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat",
            "cvr_source_key_of", "cvr_mm_write_bin_keyed", "cvr_mm_read_bin_keyed", "cvr_mm_read_cached", "cvr_save_image", "cvr_load_image",
@@ -108,6 +108,7 @@ def lib():
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = C.c_void_p
         L.cvr_spmv_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.cvr_debug_phase_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.cvr_export_image.argtypes = [C.c_void_p] * 5
         L.cvr_device_copy_bench.argtypes = [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)]
         L.cvr_plan_selfcheck.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -511,6 +512,18 @@ class CvrMatrix:
         if rc:
             raise CvrError(rc, "cvr_spmv_bench")
         return s.value
+
+    def phase_clocks(self):
+        """diagnostics (CVR_DEBUG=phase_clocks at creation): [workgroups][16 wavefronts][8] uint64 stamps of the last SpMV (cvr_debug_phase_clocks)"""
+        n = C.c_int64()
+        rc = lib().cvr_debug_phase_clocks(self._h, None, 0, C.byref(n))
+        if rc:
+            raise CvrError(rc, "cvr_debug_phase_clocks")
+        out = np.zeros(n.value, dtype=np.uint64)
+        rc = lib().cvr_debug_phase_clocks(self._h, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+        if rc:
+            raise CvrError(rc, "cvr_debug_phase_clocks")
+        return out.reshape(-1, 16, 8)
 
     @property
     def x_device(self):

@@ -39,6 +39,7 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
     if (h->d_multi) {          // eight panels per launch, panel b & 7 on the XCD of the workgroups b
         cvr::DeviceImage shared = h->parts[0].img;
         shared.ystage = h->multi_ystage;
+        shared.flip_now = shared.ilv_flip ? (h->spmv_calls++ & 1u) : 0u;
         uint32_t most = 0;
         for (uint32_t c : h->multi_chunks) most = std::max(most, c);
         if (most) {      // all rounds in one grid
@@ -86,11 +87,47 @@ Chip chip_of(int device)
     return cache[device];
 }
 
+
+// Interleaved images whose stream does not stay in the Infinity Cache from one SpMV to the next (256 MiB: the image, x and the partial sums share it)
+// get helper wavefronts -- two per chunk, both 64-byte halves of every line, up to 24 groups ahead (spmv_ilv_kernel; soc-LiveJournal1 shape
+// 312 -> 277 us, com-Orkut shape 783 -> 704: profiles/r05_helper_wavefronts.log; an image that the cache keeps gains nothing: wiki-Talk
+// shape 43.4 -> 43.7) -- and walk their workgroups backwards every other SpMV, so that what the last one streamed last is the first thing
+// the next one wants (305 against 312 us).  CVR_DEBUG=ilv_helpers / ilv_ahead / ilv_per_line / ilv_flip set them for experiments.
+// (launch parameters, not part of the image: cvr_create and cvr_load_image both end with this)
+void ilv_runtime_settings(cvr_handle *h)
+{
+    size_t stream_all = 0;
+    for (const Part &p : h->parts) if (p.img.ilv) stream_all += p.stream_bytes;
+    const bool big = stream_all > ((size_t)192 << 20);
+    for (Part &p : h->parts) {
+        if (!p.img.ilv) continue;
+        const char *e;
+        p.img.ilv_helpers = (e = cvr::debug_env("ilv_helpers")) ? (uint32_t)std::max(0, atoi(e)) : big ? 2u : 0u;
+        p.img.ilv_per_line = (e = cvr::debug_env("ilv_per_line")) ? (uint32_t)std::max(1, atoi(e)) : 2u;
+        p.img.ilv_ahead = (e = cvr::debug_env("ilv_ahead")) ? (uint32_t)std::max(1, atoi(e)) : 24u;
+        p.img.ilv_flip = (e = cvr::debug_env("ilv_flip")) ? (uint32_t)std::max(0, atoi(e)) : big ? 1u : 0u;
+    }
+}
+
 }  // namespace cvrh
 
 extern "C" {
 
 const char *cvr_last_error(void) { return g_err; }
+
+/* diagnostics: the time stamps of the last SpMV of a handle created under CVR_DEBUG=phase_clocks (spmv_seg_kernel<.., PROF>) */
+int cvr_debug_phase_clocks(cvr_handle *h, unsigned long long *out, int64_t max_words, int64_t *nwords)
+{
+    if (!h || !nwords) return fail(CVR_ERR_INVALID, "null argument");
+    *nwords = 0;
+    if (h->parts.empty() || !h->parts[0].img.prof) return fail(CVR_ERR_STATE, "the handle was not created under CVR_DEBUG=phase_clocks (or its layout has no phase clocks)");
+    const int64_t n = std::min<int64_t>(max_words, h->parts[0].img.prof_words);
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (out && n > 0) HIP_TRY(hipMemcpy(out, h->parts[0].img.prof, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+    *nwords = h->parts[0].img.prof_words;
+    return CVR_OK;
+}
 const char *cvr_version(void) { return "cvr_amd 0.1 (gfx950, CVR64)"; }
 
 void cvr_default_options(cvr_options *o)
@@ -307,6 +344,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     if (opt.row_bands > 1) return fail(CVR_ERR_INVALID, "row_bands is reserved: leave it at its default");
     if (opt.steps_per_chunk != 0 && (opt.steps_per_chunk < 4 || opt.steps_per_chunk % 4 || opt.steps_per_chunk > 4096))
         return fail(CVR_ERR_INVALID, "steps_per_chunk must be a multiple of 4 in [4, 4096]");
+    // (interleaved chunks are sorted by one workgroup in LDS: refused here, before any planning or allocation -- the converter would fail with
+    // hipErrorInvalidValue after all of it)
+    if (opt.interleave > 0 && opt.steps_per_chunk > cvr::kIlvMaxSteps)
+        return fail(CVR_ERR_INVALID, "interleave = 1 takes steps_per_chunk <= %d (a chunk is sorted in one workgroup's LDS)", cvr::kIlvMaxSteps);
 
     // CSR arrays already in device memory (of opt.device): the row_ptr of a small matrix comes back once for the argument checks (8 B per
     // row), that of a large one is checked by a kernel and stays (R-MAT-24: 33 ms of copies -> 0.5 ms);
@@ -457,13 +498,15 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     clk.lap("staging upload");
     // the panel rule (col_panels < 0): on the device copy when there is one (same windows, same integers as the host form)
     const double t_rule0 = now_s();
+    double       rule_miss = -1;          // >= 0: the device rule ran and its count is still to be weighed against the partial sums it costs (below)
     if (P < 0) {
         if (!(xbytes >= 24e6 || mid_range) || sj1 <= sj0) P = 1;
         else if (dev_split) {
             double miss = 0;
             CREATE_TRY(l2_miss_estimate_dev(rp_d, ci_d, nrows, ncols, f32, h->stream, &miss));
             P = panels_from_miss(xbytes, miss);
-        } else P = auto_panels(*csr, nullptr);
+            rule_miss = miss;
+        } else P = auto_panels(*csr, nullptr);          // (the host rule asks both questions itself)
     }
     const double panel_rule_s = now_s() - t_rule0;          // part of the analysis: added to plan_s below
     clk.lap("panel rule");
@@ -492,6 +535,18 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         // matrix's share at most: LiveJournal shape 0.06): the panels skip their own counting passes and take interleaved chunks instead
         // (web-Google shape x 2.2, whose share lies between 0.08 and 0.25: 72 us as plain panels that end up without tables, 55 us interleaved)
         if (share < (cvr::debug_env("flat_share") ? atof(cvr::debug_env("flat_share")) : 0.25)) opt.hub_table = 0;
+    }
+    // the rule's second question, for the count it arrived at: do the panels' partial sums cost less than the misses they save?  (cvr_panels.hip: panels_pay)
+    if (P > 1 && panels_auto && dev_split && rule_miss >= 0 && !cvr::debug_env("no_pairs_rule")) {
+        double ppn = 0;
+        const double tq = now_s();
+        CREATE_TRY(pairs_per_nnz_dev(rp_d, ci_d, nrows, (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1, h->stream, &ppn));
+        if (!panels_pay(rule_miss, ppn)) {
+            if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] %d column panels dropped: L2 miss share %.3f against %.3f (row, panel) pairs per non-zero\n", P, rule_miss, ppn);
+            P = 1;
+            opt.hub_table = opt_in ? opt_in->hub_table : -1;          // (the flat-popularity shortcut above was taken for panels)
+        }
+        in.plan_s += now_s() - tq;
     }
     clk.lap("panel count with hub tables");
     if (P < 1) P = 1;
@@ -579,14 +634,14 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             for (int p = 0; p < P; p++) pcols[(size_t)p] = part_cols(p);
             rc = plan_panels_batched(h, dsg.d, nsubs, pcols, f32, popts, pps, drs, &batched);      // (panels without hub tables: all plans as one submission)
             if (rc) { cvr_destroy(h); return rc; }
-            if (batched && ilv_generations > 0 && panel_opt.steps_per_chunk < 508) {
+            if (batched && ilv_generations > 0 && panel_opt.steps_per_chunk < cvr::kIlvMaxSteps) {
                 // the plan has more chunks than the estimate said and the launch would take a generation more: once more with longer chunks
                 std::vector<int64_t> nch((size_t)P);
                 for (int p = 0; p < P; p++) nch[(size_t)p] = pps[(size_t)p].dev_nchunks;
                 const int wpb_i = panel_opt.waves_per_block > 0 ? panel_opt.waves_per_block : 4, cus_x = std::max(1, opt.cus / std::max(1, opt.xcds));
                 double    fullest = 0;
                 if (panel_generations(nch, (P + 7) / 8, wpb_i, cus_x, &fullest) > ilv_generations) {
-                    const int S2 = (int)std::min<int64_t>(508, ((int64_t)std::ceil(panel_opt.steps_per_chunk * fullest / ((double)ilv_generations * cus_x) * 1.02) + 3) / 4 * 4);
+                    const int S2 = (int)std::min<int64_t>(cvr::kIlvMaxSteps, ((int64_t)std::ceil(panel_opt.steps_per_chunk * fullest / ((double)ilv_generations * cus_x) * 1.02) + 3) / 4 * 4);
                     if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] interleaved panels: %.0f workgroups on the fullest XCD, more than %d generations: planned again with chunk length %d\n", fullest, ilv_generations, S2);
                     release_panel_plans(h);
                     panel_opt.steps_per_chunk = S2;
@@ -817,6 +872,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             if (hipMalloc(&h->seg_arena, bytes) == hipSuccess) h->seg_arena_bytes = bytes; else { (void)hipGetLastError(); h->seg_arena = nullptr; }
         }
     }
+    ilv_runtime_settings(h);
     in.spmv_launches = h->d_multi ? 1 : (int32_t)h->parts.size();
     if (!h->d_err) CREATE_TRY(hipMalloc(&h->d_err, sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(&h->d_x, vsz * (size_t)in.x_elems));

@@ -58,6 +58,7 @@ constexpr int      kWavesPerBlock = 1;   // converter / fix-up launches; the SpM
 constexpr int64_t  kPlanRowBlock = 65536;   // the planner restarts a chunk at every multiple of this many rows (blocks are planned in parallel)
 constexpr int      kMaxWavesPerBlock = 16;   // SpMV workgroups of several consecutive chunks share an LDS window of x (cvr_options.waves_per_block)
 constexpr size_t   kLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
+constexpr int      kIlvMaxSteps = 576;      // longest interleaved chunk: the converter sorts a chunk's 64 S (column, position) pairs in one workgroup's LDS, up to 36 per thread (cvr_ilv.hip)
 
 inline int group_bytes(bool f32, bool dict = false, bool c16 = false, bool tag16 = false) { return (dict ? kGroupBytesDict : c16 ? (f32 ? kGroupBytes32C16 : kGroupBytes64C16) : f32 ? kGroupBytes32 : kGroupBytes64) + (tag16 ? kTagBytes : 0); }
 

@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t part_of_chunk(const IlvTable *__restrict__ t
 // One workgroup per chunk (its part and number are the workgroup's: no search per element) does the whole conversion on chip:
 //   1. the starts of the chunk's rows (relative to its first position, clipped to the chunk) go to LDS; thread t takes the positions
 //      [t IPT, (t + 1) IPT) of the chunk's CSR range and finds their rows (one search, then a walk);
-//   2. a stable block radix sort (hipCUB, LDS only) of (column inside the image, position | row << 15) by the column's bits: ties keep
+//   2. a stable block radix sort (hipCUB, LDS only) of (column inside the image, position | row << 16) by the column's bits: ties keep
 //      their positions' order, i.e. ascend by row; positions behind the chunk's non-zeros carry the pad column and stay behind;
 //   3. element e of the sorted list = thread e % NT, item e / NT (striped), written to step e / 64, lane e % 64 of the chunk.
 // (Round 4 began with one device-wide radix sort of chunk << bits | column over all panels: 4 passes of 8 bytes per non-zero through
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
         if (p < n) {
             while (row + 1 < nri && rstart[row + 1] <= p) row++;
             key[i] = (uint32_t)q.ci[b + p] - q.col_base;
-            val[i] = p | (row << 15);
+            val[i] = p | (row << 16);
         } else { key[i] = q.pad_col; val[i] = 0xffffffffu; }
     }
     __syncthreads();
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
         uint64_t bits[kB];
 #pragma unroll
         for (int u = 0; u < kB; u++) {
-            const uint32_t e = (uint32_t)(i0 + u) * NT + threadIdx.x, pe = val[i0 + u] & 0x7fffu;      // pe: the element's place among the chunk's, in CSR order
+            const uint32_t e = (uint32_t)(i0 + u) * NT + threadIdx.x, pe = val[i0 + u] & 0xffffu;      // pe: the element's place among the chunk's, in CSR order
             bits[u] = e >= n ? 0 : f32 ? (uint64_t)static_cast<const uint32_t *>(vals)[b + pe] : static_cast<const uint64_t *>(vals)[b + pe];
         }
 #pragma unroll
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
             const uint32_t e = (uint32_t)i * NT + threadIdx.x;
             if (e < nslots) {
                 const uint32_t g = e >> 8, j = (e >> 6) & 3u, lane = e & 63u;
-                const uint32_t col = e < n ? key[i] : pad_col, r = e < n ? val[i] >> 15 : nri;
+                const uint32_t col = e < n ? key[i] : pad_col, r = e < n ? val[i] >> 16 : nri;
                 uint32_t       code = code0;
                 if (use_dict && e < n) {
                     uint32_t a = 0;                                       // entries below bits[u] (branch-free: the entries behind ndict are all ones)
@@ -208,7 +208,8 @@ hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const Devi
     const DeviceImage &c0 = *imgs[0];
     const uint32_t     cbits = bits_of(pad_max);
     const int          ipt = (c0.S + 15) / 16;                             // 64 S slots over 1024 threads
-    if (up256(sizeof(IlvTable)) > scratch_bytes || ipt > 32 || ystage_max > 65536u) return hipErrorInvalidValue;      // (position 15 bits, row 16 bits in the sort's payload)
+    static_assert((kIlvMaxSteps + 15) / 16 <= 36, "the longest interleaved chunk needs more than 36 pairs per thread");
+    if (up256(sizeof(IlvTable)) > scratch_bytes || ipt > 36 || ystage_max > 65536u) return hipErrorInvalidValue;      // (position 16 bits, row 16 bits in the sort's payload; 36 pairs per thread: 144 KiB of LDS)
     IlvTable *d_tab = static_cast<IlvTable *>(scratch);
     hipError_t rc = hipMemcpyAsync(d_tab, &tab, sizeof(IlvTable), hipMemcpyHostToDevice, st);
     if (rc != hipSuccess) return rc;
@@ -219,7 +220,8 @@ hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const Devi
     if (ipt <= 12) return launch_chunks<1024, 12>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 16) return launch_chunks<1024, 16>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 24) return launch_chunks<1024, 24>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
-    return launch_chunks<1024, 32>(d_tab, c, c0, ystage_max, cbits, err_flag, st);          // (768 threads x 44 pairs -- 170 registers each -- spill 364 bytes and take as long)
+    if (ipt <= 32) return launch_chunks<1024, 32>(d_tab, c, c0, ystage_max, cbits, err_flag, st);          // (768 threads x 44 pairs -- 170 registers each -- spill 364 bytes and take as long)
+    return launch_chunks<1024, 36>(d_tab, c, c0, ystage_max, cbits, err_flag, st);          // (chunks of up to 576 steps: what lets a launch of 8 200 chunks at S = 508 fit eight generations of workgroups instead of nine)
 }
 
 }  // namespace cvr

@@ -309,6 +309,7 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
     (void)hipHostFree(pinned);
     pinned = nullptr;
 #undef LOAD_TRY
+    ilv_runtime_settings(h);
     h->converted = true;
     // what the first run spent on analysis and conversion does not apply to this handle
     h->info.plan_s = 0; h->info.probe_s = 0; h->info.hub_select_s = 0; h->info.dict_s = 0; h->info.convert_s = 0; h->info.preprocess_wall_s = 0;

@@ -122,6 +122,7 @@ struct Part {
         if (img.hub_index) (void)hipFree(img.hub_index);
         if (img.hub_bitmap) (void)hipFree(img.hub_bitmap);
         if (img.hub_x) (void)hipFree(img.hub_x);
+        if (img.prof) (void)hipFree(img.prof);
         img = cvr::DeviceImage{};
     }
 };
@@ -155,6 +156,7 @@ struct cvr_handle {
     std::vector<hipEvent_t> events;
     hipEvent_t z_free = nullptr;         // column panels: recorded after the combine pass; the next SpMV (on any stream) waits for it
     bool       z_used = false;
+    uint32_t   spmv_calls = 0;           // SpMVs launched so far (interleaved panels with ilv_flip: every other one walks the workgroups backwards)
     cvr::PlanScratch plan_ws;            // cvr_create only: scratch of the device planner (released before cvr_create returns)
     // cvr_create only: 32 KiB of device scratch for the small tables of its analysis passes (layout probe 16 KiB, dictionary
     // table 8 KiB + flags) and the host copies of the dictionary scan when it ran together with the probe
@@ -180,7 +182,8 @@ namespace cvrh {
 // whole chip and switch themselves off otherwise.  Cached per device; {256, 8} if the query fails.
 struct Chip { int cus = 256, xcds = 8; };
 Chip       chip_of(int device);
-hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st);      // y_ext = A x for the whole handle on `st`
+hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st);
+void       ilv_runtime_settings(cvr_handle *h);          // helper wavefronts / sweep direction of interleaved images (launch parameters)      // y_ext = A x for the whole handle on `st`
 IOpt       make_iopt(const cvr_options *in);
 int        check_csr(const cvr_csr_view *c, bool columns_on_host = true);
 int        check_columns_device(const int32_t *ci_dev, int64_t j0, int64_t j1, int64_t ncols);
@@ -274,6 +277,9 @@ void       split_panels(const cvr_csr_view &v, int P, PanelSplit &out);
 double     l2_miss_estimate(const cvr_csr_view &v);
 hipError_t l2_miss_estimate_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t ncols, bool f32, hipStream_t st, double *miss);
 int        panels_from_miss(double xb, double miss);
+double     pairs_per_nnz(const cvr_csr_view &v, int64_t width);
+hipError_t pairs_per_nnz_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t width, hipStream_t st, double *out);
+bool       panels_pay(double miss, double pairs_per_nonzero);
 int        auto_panels(const cvr_csr_view &v, double *miss_out);
 int        xcd_panel_count(int P, double xbytes);
 

@@ -41,7 +41,12 @@ struct DeviceImage {
     uint2    *desc2 = nullptr;      // [nchunks] {first entry of the chunk in the conversion-time segment table, rows with a segment in the chunk}
     bool      tag16 = false;        // column phases: the rows of the pieces stand in 16-bit tags of their own (col_bits = 31)
     uint32_t  col_base = 0;         // interleaved column panels: the image's column indices are relative to this column (pad_col = the panel's width)
-    bool      ilv = false;          // interleaved chunks (cvr_ilv.hip): the image is written in the column-phase format with every slot a piece of its own; conversion only
+    bool      ilv = false;          // interleaved chunks (cvr_ilv.hip): the image is written in the column-phase format with every slot a piece of its own
+    unsigned long long *prof = nullptr;      // CVR_DEBUG=phase_clocks: [workgroups * 16 wavefronts][8] time stamps of spmv_seg_kernel's phases (diagnostics; null otherwise)
+    uint32_t  prof_words = 0;
+    uint32_t  ilv_helpers = 0, ilv_ahead = 16, ilv_per_line = 1;
+    uint32_t  ilv_flip = 0;         // interleaved: 1 = every other SpMV walks the workgroups in reverse order (what the last one streamed last is still in the Infinity Cache); set per launch
+    uint32_t  flip_now = 0;      // interleaved: helper wavefronts per chunk (scalar prefetch of the stream), how many groups ahead, loads per line
     uint32_t  piece_max = 0;        // column phases: (row, phase) segments are cut into pieces at the multiples of this many elements from the chunk's first (0 = whole segments)
     uint32_t  col_bits = 31;        // column phases: the LAST column word of a segment carries the chunk's row of the segment
                                     // above the column index: bits [col_bits, 31); bit 31 stays the end flag
@@ -121,13 +126,15 @@ struct DeviceSplit {
 hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, const void *va_dev, bool f32, int64_t nrows, int64_t nz0,
                                int64_t nz1, int64_t width, int P, DeviceSplit *out, hipStream_t st);
 void       free_device_split(DeviceSplit &s);
+// the panel rule's second question (cvr_split.hip): (row, panel) pairs of the same windows for panels of `width` columns
+hipError_t panel_pairs_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t width, double *pairs, hipStream_t st);
 // the panel rule's L2 model for a device-resident CSR (cvr_split.hip): per window of W rows, gathers and hits among the `resident` most used lines
 hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t ncols, bool f32, size_t resident,
                           double *refs, double *hits, hipStream_t st);
 
 // ---- the chunk planner on the device (cvr_plan_dev.hip): the plan of plan_chunks from a device-resident row_ptr ----
 struct Plan;
-bool       plan_on_device_ok(int32_t S);
+bool       plan_on_device_ok(int32_t S, int64_t max_rows = 0);
 // scratch the caller may keep across calls: device bytes (grown on demand) and a pinned host buffer for the records coming back
 struct PlanScratch { uint8_t *dev = nullptr; size_t dev_bytes = 0; uint8_t *pinned = nullptr; size_t pinned_bytes = 0;
                      bool borrowed = false; };      // borrowed: `dev` points INTO someone else's allocation -- never freed or grown here (a plan that needs more is an error)

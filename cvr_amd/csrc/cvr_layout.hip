@@ -100,7 +100,7 @@ int interleave_steps(int64_t nnz, int64_t nrows, bool f32, const IOpt &opt)
     const double  cus = opt.panel_on_one_xcd ? (double)opt.cus / opt.xcds : (double)opt.cus;
     int64_t       S = (int64_t)(0.85 * mean * (double)rows / 64.0) + 1;      // (a little under what the row cap fills: most chunks then end at their slots, not at their rows -- 384 / 320 steps: 343 / 332 us on the soc-LiveJournal1 shape)
     S = std::min<int64_t>(S, (int64_t)((double)nnz / (64.0 * cus * (double)wpb)) + 1);
-    return (int)std::min<int64_t>(508, std::max<int64_t>(16, (S + 3) / 4 * 4));
+    return (int)std::min<int64_t>(cvr::kIlvMaxSteps, std::max<int64_t>(16, (S + 3) / 4 * 4));
 }
 
 // Chunk length of interleaved column panels that run one per XCD (`rounds` panels after each other on an XCD's CUs): the launch takes as
@@ -151,9 +151,9 @@ int interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<i
     };
     // the fewest generations the longest chunks allow, then the shortest chunks that still make it (the time of a generation depends
     // little on S: soc-LiveJournal1 shape three generations 305-311 us at S = 416 .. 508, four generations 323-351 us at S = 284 .. 412)
-    const double  gmin = std::ceil(workgroups(508) / cus);
-    int64_t       best = 508;
-    for (int64_t S = 504; S >= 16; S -= 4) {
+    const double  gmin = std::ceil(workgroups(cvr::kIlvMaxSteps) / cus);
+    int64_t       best = cvr::kIlvMaxSteps;
+    for (int64_t S = cvr::kIlvMaxSteps - 4; S >= 16; S -= 4) {
         if (std::ceil(workgroups(S) / cus) > gmin) break;
         best = S;
     }
@@ -484,6 +484,11 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
         // pieces: a lane that sits on a long row's segment falls behind the column ranges the other lanes have moved on to; with
         // chunks longer than a few steps per phase the segments are cut (auto: 8 elements once a phase takes 8 steps or more)
         img.ilv = pp.ilv;
+        if (cvr::debug_env("phase_clocks") && !pp.ilv && !f32) {          // room for the time stamps of every wavefront of the launch (spmv_seg_kernel<.., PROF>)
+            const size_t words = ((size_t)nchunks / (size_t)std::max(pp.wpb, 1) + 16) * 16 * 8;
+            if (hipMalloc(&img.prof, words * sizeof(unsigned long long)) == hipSuccess) { img.prof_words = (uint32_t)words; (void)hipMemset(img.prof, 0, words * sizeof(unsigned long long)); }
+            else { (void)hipGetLastError(); img.prof = nullptr; }
+        }
         // (a power of two, rounded down: the segment-table kernel cuts with shifts)
         img.piece_max = opt.piece_max > 0 ? 1u << (31 - __builtin_clz((uint32_t)opt.piece_max)) : opt.piece_max < 0 && S / pp.phases >= 8 && !opt.panel_on_one_xcd ? 8u : 0u;
         img.col_mask = pp.tag16 ? cvr::kColMask : (1u << pp.col_bits) - 1u;
@@ -521,8 +526,8 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
             if ((double)(nzp + ns / 4) / (64.0 * 32.0) <= cus * 12.0) return CVR_OK;          // (the chunk length would depend on the longest row: plan_part)
             pp.S = pick_steps(nzp + ns / 4, 0, cus);
         }
-        if (!cvr::plan_on_device_ok(pp.S)) return CVR_OK;
         maxr[(size_t)p] = plan_layout(pp, pcols[(size_t)p], f32, o);
+        if (!cvr::plan_on_device_ok(pp.S, maxr[(size_t)p])) return CVR_OK;
         if ((pp.phases > 1 && !pp.ilv) || pp.hub_n > 0) return CVR_OK;      // (interleaved panels: planned like phased images, their tables written on the device too)
         bound[(size_t)p] = cvr::plan_bound_device(ns, nzp, pp.S, maxr[(size_t)p]);
         if (ns + 1 + 2 * bound[(size_t)p] >= (int64_t)0xffffffffu || bound[(size_t)p] >= (int64_t)0x7fffffff) return CVR_OK;

@@ -155,6 +155,57 @@ hipError_t l2_miss_estimate_dev(const int64_t *rp_dev, const int32_t *ci_dev, in
     return hipSuccess;
 }
 
+// The panel rule's second question.  Panels trade L2 misses of the gathers for partial sums: every (row, panel) pair with a non-zero is a
+// value the panel kernel writes and the combine pass reads back with its row number.  pairs_per_nnz: those pairs per non-zero in the same
+// eight windows of rows the miss estimate looks at, for panels of `width` columns.  Matrices of short rows whose misses are moderate lose
+// with panels what they gain (round 5 hold-out, profiles/r05_holdout.log: a citation-like matrix of 4.5 non-zeros per row, miss 0.29,
+// 0.59 pairs per non-zero ran 185 us as 16 panels, 139 us whole; a uniform random one, miss 0.65 / 0.44 pairs, 234 against 419; the
+// web-Google shape x 2.2, 0.31 / 0.33, 55 against 72): panels_pay() keeps them from miss >= 0.68 pairs per non-zero on.
+double pairs_per_nnz(const cvr_csr_view &v, int64_t width)
+{
+    const int64_t nrows = v.nrows, W = std::min<int64_t>(65536, nrows);
+    if (W <= 0 || width < 1 || v.arrays_on_device) return 0.0;
+    const int nwin = nrows == W ? 1 : 8;
+    double    pairs = 0, refs = 0;
+    for (int w = 0; w < nwin; w++) {
+        const int64_t r0 = nwin == 1 ? 0 : (nrows - W) * w / (nwin - 1);
+        for (int64_t r = r0; r < r0 + W; r++) {
+            int64_t last = -1;
+            for (int64_t j = v.row_ptr[r]; j < v.row_ptr[r + 1]; j++) {
+                const int64_t p = v.col_idx[j] / width;
+                if (p != last) { pairs += 1; last = p; }
+            }
+        }
+        refs += (double)(v.row_ptr[r0 + W] - v.row_ptr[r0]);
+    }
+    return refs > 0 ? pairs / refs : 0.0;
+}
+
+hipError_t pairs_per_nnz_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t width, hipStream_t st, double *out)
+{
+    *out = 0.0;
+    const int64_t W = std::min<int64_t>(65536, nrows);
+    if (W <= 0 || width < 1) return hipSuccess;
+    const int nwin = nrows == W ? 1 : 8;
+    int64_t   r0[8], edge[16];
+    double    pairs[8];
+    for (int w = 0; w < nwin; w++) r0[w] = nwin == 1 ? 0 : (nrows - W) * w / (nwin - 1);
+    hipError_t e = cvr::panel_pairs_device(rp_dev, ci_dev, r0, nwin, W, width, pairs, st);
+    if (e != hipSuccess) return e;
+    double refs = 0, all = 0;
+    for (int w = 0; w < nwin; w++) {          // (the windows' non-zeros: two row pointers each)
+        e = hipMemcpy(&edge[2 * w], rp_dev + r0[w], sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&edge[2 * w + 1], rp_dev + r0[w] + W, sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        refs += (double)(edge[2 * w + 1] - edge[2 * w]);
+        all += pairs[w];
+    }
+    *out = refs > 0 ? all / refs : 0.0;
+    return hipSuccess;
+}
+
+bool panels_pay(double miss, double pairs_per_nonzero) { return miss >= 0.68 * pairs_per_nonzero; }
+
 int panels_from_miss(double xb, double miss) { return miss > 0.17 ? std::min(64, std::max(2, (int)(xb * miss / 1.8e6 + 0.5))) : 1; }
 
 // Panels that run one per XCD at a time, eight per launch (run_spmv, d_multi): the count the miss rule gave is for slices that share
@@ -181,7 +232,9 @@ int auto_panels(const cvr_csr_view &v, double *miss_out)
         P = panels_from_miss(xb, miss);
     }
     if (miss_out) *miss_out = miss;
-    return xcd_panel_count(P, xb);      // (as cvr_create counts them on a whole MI355X: eight XCDs)
+    P = xcd_panel_count(P, xb);         // (as cvr_create counts them on a whole MI355X: eight XCDs)
+    if (P > 1 && !cvr::debug_env("no_pairs_rule") && !panels_pay(miss, pairs_per_nnz(v, (v.ncols + P - 1) / P > 0 ? (v.ncols + P - 1) / P : 1))) P = 1;
+    return P;
 }
 
 void split_panels(const cvr_csr_view &v, int P, PanelSplit &out)

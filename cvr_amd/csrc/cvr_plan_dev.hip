@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void block_off_kernel(const uint32_t *__restri
 
 }  // namespace
 
-bool plan_on_device_ok(int32_t S) { return (int64_t)kLanes * S < (int64_t)kJumpCut; }
+// (the jump table holds, per row, how many ROWS a chunk starting there spans, in 15 bits: at most min(slots of a chunk, the row cap))
+bool plan_on_device_ok(int32_t S, int64_t max_rows) { return (int64_t)kLanes * S < (int64_t)kJumpCut || (max_rows > 0 && max_rows < (int64_t)kJumpCut); }
 
 // room of the record arrays (an upper bound of the chunks) and bytes of device scratch a plan of these rows needs
 int64_t plan_bound_device(int64_t nrows, int64_t nz_end, int32_t S, int64_t max_rows)
@@ -330,7 +331,7 @@ hipError_t plan_chunks_device_enqueue(const int64_t *rp_dev, int64_t nrows, int6
     out->thr = thr;
     out->max_rows = max_rows == INT64_MAX ? 0 : max_rows;
     if (nrows <= 0) return hipSuccess;
-    if (!plan_on_device_ok(S)) { out->declined = true; return hipSuccess; }
+    if (!plan_on_device_ok(S, out->max_rows)) { out->declined = true; return hipSuccess; }
     const int64_t nblocks = (nrows + kPlanRowBlock - 1) / kPlanRowBlock, ntiles = (nrows + kTileRows - 1) / kTileRows;
     // slots <= nnz + nrows; the sum of the blocks' rooms (bound_of)
     const int64_t slots_ub = nz_end + nrows;        // (rp[0] >= 0)

@@ -339,6 +339,46 @@ hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const in
     return hipSuccess;
 }
 
+// (row, panel) pairs of the windows' rows -- the partial sums column panels of `width` columns would write and the combine pass would read --
+// for rows whose columns ascend (an unsorted row counts more pairs than it has: the estimate then errs against panels).  A pair begins
+// where the panel changes between neighbouring non-zeros, or where a row begins inside a run of one panel.
+__global__ __launch_bounds__(256) void est_pairs_kernel(const long long *__restrict__ rp, const int32_t *__restrict__ ci, const long long *__restrict__ r0, long long W,
+                                                        uint32_t width, unsigned long long *__restrict__ pairs)
+{
+    const uint32_t  w = blockIdx.y;
+    const long long ra = r0[w], j0 = rp[ra], j1 = rp[ra + W];
+    unsigned long long n = 0;
+    for (long long j = j0 + 1 + (long long)blockIdx.x * 256 + threadIdx.x; j < j1; j += (long long)gridDim.x * 256) n += (uint32_t)ci[j] / width != (uint32_t)ci[j - 1] / width;
+    for (long long r = ra + (long long)blockIdx.x * 256 + threadIdx.x; r < ra + W; r += (long long)gridDim.x * 256) {
+        const long long s = rp[r];
+        if (s < rp[r + 1] && (s == j0 || (uint32_t)ci[s] / width == (uint32_t)ci[s - 1] / width)) n++;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&pairs[w], n);
+}
+
+hipError_t panel_pairs_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t width, double *pairs, hipStream_t st)
+{
+    if (nwin < 1 || nwin > 64 || width < 1) return hipErrorInvalidValue;
+    Tmp                 tmp;
+    unsigned long long *small = nullptr;     // [nwin] pairs, then the windows' first rows
+    hipError_t e = tmp.alloc(&small, sizeof(unsigned long long) * 2 * (size_t)nwin);
+    if (e != hipSuccess) return e;
+    long long *d_r0 = reinterpret_cast<long long *>(small + nwin);
+    e = hipMemsetAsync(small, 0, sizeof(unsigned long long) * (size_t)nwin, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_r0, r0_host, sizeof(long long) * (size_t)nwin, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(est_pairs_kernel, dim3(256, (uint32_t)nwin), dim3(256), 0, st, reinterpret_cast<const long long *>(rp_dev), ci_dev, d_r0, (long long)W,
+                       (uint32_t)std::min<int64_t>(width, 0x7fffffff), small);
+    std::vector<unsigned long long> sm((size_t)nwin);
+    e = hipMemcpyAsync(sm.data(), small, sizeof(unsigned long long) * sm.size(), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    for (int w = 0; w < nwin; w++) pairs[w] = (double)sm[(size_t)w];
+    return hipSuccess;
+}
+
 void free_device_split(DeviceSplit &s)
 {
     (void)hipFree(s.ci); (void)hipFree(s.va); (void)hipFree(s.rows); (void)hipFree(s.rp);

@@ -487,19 +487,26 @@ __device__ __forceinline__ void sum_group_seg(T &acc, const SegGroup<T, DICT, TA
 // bandwidth, not latency -- which every wavefront used to wait out in front of its first gather; and a wavefront's own loads
 // complete in order, so it cannot overlap that wait itself.)  Dictionary and zero slot are written by every computing
 // wavefront for itself (the same values to the same addresses), so nothing else needs a barrier.
-template <typename T, int QA, int DEPTH, int WIN, bool DICT, bool LOADER, bool TAG>
+// PROF (CVR_DEBUG=phase_clocks; diagnostics, one extra instantiation): every wavefront stamps the 100-MHz real-time counter (s_memrealtime: one
+// clock for the whole chip) at entry / prologue done / window barrier passed / loop done / rows stored, with its XCC and hardware id:
+// prof[(blockIdx.x * 16 + wave) * 8 + 0..7]; tools/phase_clocks.py turns the dump into the per-XCD histogram of profiles/.
+__device__ __forceinline__ unsigned long long prof_now() { return __builtin_amdgcn_s_memrealtime(); }
+
+template <typename T, int QA, int DEPTH, int WIN, bool DICT, bool LOADER, bool TAG, bool PROF = false>
 __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const T *__restrict__ x, T *__restrict__ yext_a, int G, uint32_t nchunks_a,
     uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn,
     const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, const uint2 *__restrict__ desc2_a, uint32_t col_bits, uint32_t nw_arg, int gb,
-    const PanelArgs *__restrict__ multi, IterEpilogue epi)
+    const PanelArgs *__restrict__ multi, IterEpilogue epi, unsigned long long *__restrict__ prof = nullptr)
 {
+    unsigned long long pc[5] = {0, 0, 0, 0, 0};
+    if constexpr (PROF) pc[0] = prof_now();
     const uint8_t *__restrict__ stream = stream_a;
     const uint4 *__restrict__   desc = desc_a;
     const uint2 *__restrict__   desc2 = desc2_a;
     T *__restrict__             yext = yext_a;
     uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = blockIdx.x;
-    if (multi) {          // column panels, one per XCD at a time, the rounds of eight one after the other in the grid (spmv_kernel)
+    if (multi) {          // column panels, one per XCD at a time, the rounds of eight one after the other in the grid (spmv_seg_kernel)
         const uint32_t  round = blockIdx.x / nblocks_per_xcd, b = blockIdx.x - round * nblocks_per_xcd;
         const PanelArgs pa = multi[round * 8u + (b & 7u)];
         stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
@@ -530,6 +537,15 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
                                                          (__attribute__((address_space(3))) void *)(win + i0), 16, 0, 0);
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (PROF) {          // (a loader: entry, its loads landed, barrier passed)
+                pc[1] = prof_now();
+                __builtin_amdgcn_s_barrier();
+                if (lane == 0 && prof) {
+                    unsigned long long *o = prof + ((size_t)blockIdx.x * 16 + wv) * 8;
+                    o[0] = pc[0]; o[1] = pc[1]; o[2] = prof_now(); o[3] = 0; o[4] = 0; o[5] = __builtin_amdgcn_s_getreg(6164); o[6] = __builtin_amdgcn_s_getreg(63492); o[7] = 2;
+                }
+                return;
+            }
             __builtin_amdgcn_s_barrier();
             return;
         }
@@ -544,16 +560,27 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     constexpr int  QN = DEPTH + QA;
     SegGroup<T, DICT, TAG> Q[QN];
     X4<T>          xs[DEPTH];
+    // Everything the prologue loads is ISSUED before anything is waited for (the phase clocks of round 5 showed 2.9 us between entry and the
+    // first gather: the accumulators were zeroed up to a count that a load brought, then the dictionary was fetched -- two memory round trips
+    // one after the other behind the first stream loads): the dictionary's values into registers, the descriptors, the first groups of the
+    // stream; the accumulators are zeroed up to the layout's cap, which needs no load.
+    T dv[LOADER && WIN != 0 && DICT ? kDictMax / kLanes : 1];
+    if constexpr (LOADER && WIN != 0 && DICT) {
+#pragma unroll
+        for (int u = 0; u < kDictMax / kLanes; u++) dv[u] = (uint32_t)u * kLanes + lane < ndict ? dict_g[(uint32_t)u * kLanes + lane] : T(0);
+    }
+    const uint4    d = live ? desc[k] : uint4{0, 0, 0, 0};
+    const uint32_t nri = live ? desc2[k].y : 0u;                      // rows with a piece in this chunk
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G * GB), live ? (uint32_t)G * GB : 0u);
 #pragma unroll
     for (int i = 0; i < QN; i++) Q[i] = load_seg_group<T, DICT, TAG>(rs, voff, (uint32_t)i * GB);
-    const uint4    d = live ? desc[k] : uint4{0, 0, 0, 0};
-    const uint32_t nri = live ? desc2[k].y : 0u;                      // rows with a piece in this chunk
-    if (live) for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);      // the row accumulators (+ the dump entry of the pad pieces)
+    if (live) for (uint32_t i = lane; i < ystage_n; i += kLanes) ystage[i] = T(0);      // the row accumulators (+ the dump entry of the pad pieces: nri < ystage_n)
 
     if constexpr (LOADER && WIN != 0) {
-        if constexpr (DICT)
-            for (uint32_t i = lane; i < (uint32_t)kDictMax; i += kLanes) dict[i] = i < ndict ? dict_g[i] : T(0);
+        if constexpr (DICT) {
+#pragma unroll
+            for (int u = 0; u < kDictMax / kLanes; u++) dict[(uint32_t)u * kLanes + lane] = dv[u];
+        }
         if (lane < 4) win[wn + lane] = T(0);
         if (epi.out && wv == 0 && lane == 0) *reinterpret_cast<uint32_t *>(win + wn + 4) = 0u;      // wavefronts that have finished (the iterative epilogue)
     } else {
@@ -598,8 +625,9 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
         }
     }
     T acc = 0;
+    if constexpr (PROF) pc[1] = prof_now();
     if constexpr (LOADER && WIN != 0) {
-        if (gb < 0) { asm volatile("s_barrier" ::: "memory"); wn_eff = wn; }      // (meet the loaders in front of the first gather)
+        if (gb < 0) { asm volatile("s_barrier" ::: "memory"); wn_eff = wn; if constexpr (PROF) pc[2] = prof_now(); }      // (meet the loaders in front of the first gather)
     }
 #pragma unroll
     for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, kPolDefault, WIN>(rx, win, Q[i].c, cmask, wbase, wn_eff, 0u, wn);
@@ -608,6 +636,7 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
             if (g == gb) {                          // the window has arrived (the loaders waited for their loads in front of this barrier)
                 asm volatile("s_barrier" ::: "memory");
                 wn_eff = wn;
+                if constexpr (PROF) pc[2] = prof_now();
             }
         }
         const SegGroup<T, DICT, TAG> Qn = load_seg_group<T, DICT, TAG>(rs, voff, (uint32_t)(g + QN) * GB);
@@ -623,10 +652,19 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     if constexpr (LOADER && WIN != 0) { if (gb >= G) asm volatile("s_barrier" ::: "memory"); }      // (every wavefront meets the loaders exactly once)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pc[3] = prof_now(); }
     if (!epi.out) {
         for (uint32_t i = lane; i < nri; i += kLanes) {
             const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
             store_y(yext + dst, ystage[i]);
+        }
+        if constexpr (PROF) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the stores have left the wavefront; the kernel's end also waits for the L2's write-back)
+            pc[4] = prof_now();
+            if (lane == 0 && prof) {
+                unsigned long long *o = prof + ((size_t)blockIdx.x * 16 + wv) * 8;
+                o[0] = pc[0]; o[1] = pc[1]; o[2] = pc[2]; o[3] = pc[3]; o[4] = pc[4]; o[5] = __builtin_amdgcn_s_getreg(6164); o[6] = __builtin_amdgcn_s_getreg(63492); o[7] = 1;
+            }
         }
         return;
     }
@@ -702,10 +740,9 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
 // (The same ring around the headline kernel's loop made that kernel slower -- seven wavefronts per CU already fill the L2s' queues:
 // profiles/r04_seg_ring_kernel.log.)
 #ifndef CVR_RING_CAP
-#define CVR_RING_CAP 96               // (tools/isa_check.py's self-test compiles with a cap the compiler cannot live in and expects the guard to refuse the result)
+#define CVR_RING_CAP 40               // (tools/isa_check.py's self-test compiles with a cap the compiler cannot live in and expects the guard to refuse the result)
 #endif
-constexpr int kRingCap = CVR_RING_CAP;      // the compiler's registers: v0 .. v95
-constexpr int kRingThreads = 512;     // at most 8 wavefronts per workgroup: 256 registers each
+constexpr int kRingCap = CVR_RING_CAP;      // the compiler's registers: v0 .. v39 (it needs no more: no spill in any instantiation, checked by `make isa-check`)
 
 template <int R> __device__ __forceinline__ void ring_ld128(uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff)
 {
@@ -739,24 +776,41 @@ template <typename T, bool DICT, bool TAG> struct RingLayout {
     static constexpr int NS = 1 + (TAG ? 1 : 0) + (DICT ? 1 : sizeof(T) == 8 ? 2 : 1);              // stream loads per group
     static constexpr int XB = kRingCap, QB = XB + D * XSZ, TOP = QB + 2 * D * QSZ;
     static_assert(TOP <= 256, "the ring does not fit 256 registers");
+    // registers of the kernel (ring included) -> wavefronts a SIMD holds -> the largest workgroup: 4 chunks' computing wavefronts + their
+    // helper wavefronts (below)
+    static constexpr int REGS = TOP <= 128 ? 128 : TOP <= 168 ? 168 : 256;
+    static constexpr int THREADS = REGS == 128 ? 1024 : REGS == 168 ? 768 : 512;
 };
+template <int REGS> __device__ __forceinline__ void ring_claim()          // (the kernel's register count: the ring is invisible to the compiler)
+{
+    if constexpr (REGS == 128) asm volatile("" ::: "v127");
+    else if constexpr (REGS == 168) asm volatile("" ::: "v167");
+    else asm volatile("" ::: "v255");
+}
 
+// HELPER WAVEFRONTS (round 5).  A CU's vector L1 returns its loads in order and keeps ~100 line requests in flight; a gather that hits the L2
+// holds its place for ~0.13 us, a line of the matrix stream that comes from HBM for ~1 us -- the stream is a ninth of the requests and half
+// of the queue's time (the prototype with an L2-resident stream: 248 -> 179 us on the soc-LiveJournal1 shape, profiles/r05_same_stream_probe.log).
+// The scalar data cache is a second path from the CU to the L2: `nw_compute` < blockDim / 64 makes the workgroup's other wavefronts HELPERS
+// that touch the lines of their chunk's stream with s_load a few groups ahead of the computing wavefront's buffer loads (paced by a
+// progress word the computing wavefront keeps in LDS), so that those find their lines in the L2.  Helpers read no data and write nothing.
 template <typename T, bool DICT, bool TAG>
-__global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingCap))) void spmv_ilv_kernel(
+__global__ __launch_bounds__((RingLayout<T, DICT, TAG>::THREADS)) __attribute__((amdgpu_num_vgpr(kRingCap))) void spmv_ilv_kernel(
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint2 *__restrict__ desc2_a, const T *__restrict__ x, T *__restrict__ yext_a, int G_alloc,
     uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes_a, const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, uint32_t col_bits,
-    uint32_t col_base_a, const PanelArgs *__restrict__ multi)
+    uint32_t col_base_a, const PanelArgs *__restrict__ multi, uint32_t nw_compute, uint32_t help_ahead, uint32_t help_per_line, uint32_t flip)
 {
     using L = RingLayout<T, DICT, TAG>;
     constexpr int D = L::D, QN = 2 * D, XB = L::XB, QB = L::QB, K = (D - 1) * (4 + L::NS);
-    asm volatile("" ::: "v255");                   // (the kernel's register count: the ring is invisible to the compiler)
+    ring_claim<L::REGS>();
     const uint8_t *__restrict__ stream = stream_a;
     const uint4 *__restrict__   desc = desc_a;
     const uint2 *__restrict__   desc2 = desc2_a;
     T *__restrict__             yext = yext_a;
-    uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = blockIdx.x, col_base = col_base_a, xbytes = xbytes_a;
+    const uint32_t              bx = flip ? gridDim.x - 1u - blockIdx.x : blockIdx.x;          // (flip: the launch walks its workgroups backwards)
+    uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = bx, col_base = col_base_a, xbytes = xbytes_a;
     if (multi) {          // column panels, one per XCD at a time (spmv_kernel); the panel's columns are relative to its first
-        const uint32_t  round = blockIdx.x / nblocks_per_xcd, b = blockIdx.x - round * nblocks_per_xcd;
+        const uint32_t  round = bx / nblocks_per_xcd, b = bx - round * nblocks_per_xcd;
         const PanelArgs pa = multi[round * 8u + (b & 7u)];
         stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
         col_base = pa.col_base; xbytes = (pa.pad_col + 1u) * (uint32_t)sizeof(T);
@@ -765,25 +819,69 @@ __global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingC
     constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
     constexpr uint32_t VB = kColsBytes + (TAG ? kTagBytes : 0);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t nw = blockDim.x >> 6;
+    const uint32_t nw = nw_compute, nwt = blockDim.x >> 6;           // computing wavefronts (= chunks of the workgroup), all wavefronts
     T *const ystage_all = reinterpret_cast<T *>(smem);
     T *const dict = ystage_all + nw * ystage_n;
+    uint32_t *const prog = reinterpret_cast<uint32_t *>(dict + (DICT ? kDictMax : 0));      // [nw] the group each computing wavefront has reached
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t blk = remap_block(bidx, nblocks_per_xcd, swz);
-    const uint32_t k = __builtin_amdgcn_readfirstlane(blk * nw + wv);
+    const bool     helper = wv >= nw;
+    const uint32_t wc = helper ? (wv - nw) % nw : wv;                 // the computing wavefront this one is, or helps
+    const uint32_t k = __builtin_amdgcn_readfirstlane(blk * nw + wc);
     const bool     live = k < nchunks;
-    T *const       ystage = ystage_all + wv * ystage_n;
+    T *const       ystage = ystage_all + wc * ystage_n;
     const uint4    d = live ? desc[k] : uint4{0, 0, 0, 0};
     const uint2    d2 = live ? desc2[k] : uint2{0, 0};
     const uint32_t nri = d2.y;                                        // rows of this chunk
     const uint32_t G = __builtin_amdgcn_readfirstlane(min((uint32_t)G_alloc, d2.x));      // the groups that hold its non-zeros
-    if (live) for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);
+    if (live && !helper) for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);
+    if (nwt > nw && threadIdx.x < nw) prog[threadIdx.x] = 0u;
     if constexpr (DICT) {
         for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += blockDim.x) dict[i] = i < ndict ? dict_g[i] : T(0);
         __syncthreads();
-    } else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    } else {
+        if (nwt > nw) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
     if (!live) return;
+    constexpr uint32_t GBH = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
+    if (helper) {
+        // lines of the chunk's stream, in batches of kHB per helper (what the scalar-memory counter of a wavefront tracks), helper h of H taking
+        // batches h, h + H, ...; a batch is issued once the computing wavefront is within help_ahead groups of it, and skipped when that
+        // wavefront's own loads have passed it
+        constexpr uint32_t kHB = 15, LPG = GBH / 128u;
+        static_assert(GBH % 128u == 0, "a group is whole 128-byte lines");
+        const uint32_t H = (nwt - nw) / nw, h = (wv - nw) / nw;
+        if (h >= H) return;
+        const uint64_t hb = reinterpret_cast<uint64_t>(stream + (size_t)k * ((size_t)G_alloc * GBH));
+        const uint64_t hbase = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)hb) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(hb >> 32)) << 32);
+        const uint32_t nlines = G * LPG, last = nlines ? (nlines - 1u) * 128u : 0u;
+        const uint32_t step = help_per_line > 1 ? 64u : 128u, per = help_per_line > 1 ? kHB / 2u : kHB;      // lines per batch (two loads per line: both 64-byte halves)
+        for (uint32_t line = (uint32_t)(2 * QN) * LPG + h * per; line < nlines; line += H * per) {
+            const uint32_t tg = line / LPG;
+            uint32_t       gc;
+            for (;;) {
+                gc = __hip_atomic_load(prog + wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tg <= gc + help_ahead) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (tg < gc + (uint32_t)QN + 2u) continue;                  // (too late: the computing wavefront issues the loads of group tg at group tg - QN)
+            const uint32_t o0 = line * 128u;
+            // (a scalar load writes its destination when the data comes back: every destination is a register of its own, distinct from the
+            // operands -- early clobber -- and stays claimed until the wait, which names them all)
+            uint32_t       j[kHB];
+#pragma unroll
+            for (uint32_t i = 0; i < kHB; i++) {
+                const uint32_t off = min(o0 + i * step, last);
+                asm volatile("s_load_dword %0, %1, %2" : "=&s"(j[i]) : "s"(hbase), "s"(off) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+s"(j[0]), "+s"(j[1]), "+s"(j[2]), "+s"(j[3]), "+s"(j[4]), "+s"(j[5]), "+s"(j[6]), "+s"(j[7]), "+s"(j[8]), "+s"(j[9]), "+s"(j[10]), "+s"(j[11]), "+s"(j[12]),
+                           "+s"(j[13]), "+s"(j[14])
+                         :: "memory");
+        }
+        return;
+    }
     // (the descriptors must live in scalar registers: the asm statements below take them as such)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + col_base, xbytes);
     const uint64_t sbase = reinterpret_cast<uint64_t>(stream + (size_t)k * ((size_t)G_alloc * GB));
@@ -826,6 +924,7 @@ __global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingC
         static_for<0, QN>([&](auto ic) {
             constexpr int  i = decltype(ic)::value, R = QB + i * L::QSZ, X = XB + (i % D) * L::XSZ;
             const uint32_t g = gb + (uint32_t)i;
+            if (nwt > nw && lane == 0) prog[wv] = g;              // (helpers pace themselves by it)
             ring_wait<K>();
             const uint32_t cw[4] = {ring_get<R>(), ring_get<R + 1>(), ring_get<R + 2>(), ring_get<R + 3>()};
             uint32_t       tg[2] = {0, 0}, vv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -857,6 +956,7 @@ __global__ __launch_bounds__(kRingThreads) __attribute__((amdgpu_num_vgpr(kRingC
     }
     ring_wait<0>();
     asm volatile("; CVR_RING_END" ::: "memory");
+    if (nwt > nw && lane == 0) prog[wv] = 0x7ffffff0u;                // (a helper still waiting for this wavefront goes on and ends)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (uint32_t i = lane; i < nri; i += kLanes) {          // the rows leave coalesced (head / last row of a chunk that shares it: its carry slot)
@@ -887,14 +987,16 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void fixup_kernel(const in
 // partial sums of those rows (a contiguous range of the panel's y_ext: the panel's rows are sorted) together with their
 // row numbers and adds them into LDS accumulators; a row occurs at most once per panel, and a barrier separates the
 // panels, so the additions happen in panel order (bitwise reproducible).  All global accesses are coalesced streams.
-template <typename T>
+template <typename T, int kBatch>
 __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off,
                                                       uint32_t nblocks, T *__restrict__ y, uint32_t nrows)
 {
     // The loads of kBatch panels are issued together (kEach entries per thread and panel in registers), then added panel by panel:
     // one memory round trip per batch instead of one per panel in front of every barrier (16 panels: 54 -> 3x us on the
     // soc-LiveJournal1 shape); what a panel holds beyond 256 * kEach entries for this block is added behind them.
-    constexpr int kBatch = 4, kEach = 4;
+    // (kBatch = 8 for up to eight panels: ONE round trip per block -- a matrix with few non-zeros per row block, the wiki-Talk shape, spends
+    // its combine pass waiting for those round trips, not moving bytes)
+    constexpr int kEach = 4;
     __shared__ T acc[kCombineRows];
     const uint32_t b = blockIdx.x, r0 = b * kCombineRows;
     for (uint32_t i = threadIdx.x; i < (uint32_t)kCombineRows; i += blockDim.x) acc[i] = 0;
@@ -985,8 +1087,13 @@ hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const ui
 {
     if (nrows == 0) return hipSuccess;
     const uint32_t nblocks = (nrows + kCombineRows - 1) / kCombineRows;
-    if (f32) hipLaunchKernelGGL(combine_kernel<float>, dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<float *>(y), nrows);
-    else hipLaunchKernelGGL(combine_kernel<double>, dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<double *>(y), nrows);
+    if (npanels <= 8) {
+        if (f32) hipLaunchKernelGGL((combine_kernel<float, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<float *>(y), nrows);
+        else hipLaunchKernelGGL((combine_kernel<double, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<double *>(y), nrows);
+    } else {
+        if (f32) hipLaunchKernelGGL((combine_kernel<float, 4>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<float *>(y), nrows);
+        else hipLaunchKernelGGL((combine_kernel<double, 4>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<double *>(y), nrows);
+    }
     return hipGetLastError();
 }
 
@@ -1004,7 +1111,7 @@ size_t spmv_lds_bytes(const DeviceImage &img)
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;
     const bool     use_win = (img.win_elems > 0 && img.win_base != nullptr) || img.hub_n > 0;
     const uint32_t slots = img.phases > 1 ? 0u : (uint32_t)kLanes;      // (column phases: no steal slots, spmv_seg_kernel)
-    return (size_t)(wpb * (slots + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? ((img.hub_n + 3u) & ~3u) + img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8) + (img.phases > 1 ? 16 : 0);      // (column phases: + the arrival counter of the iterative epilogue)
+    return (size_t)(wpb * (slots + img.ystage) + (img.dict ? kDictMax : 0) + (use_win ? ((img.hub_n + 3u) & ~3u) + img.win_elems + 4 : 0)) * (img.f32 ? 4 : 8) + (img.phases > 1 ? 16 : 0) + (img.ilv ? 64 : 0);      // (column phases: + the arrival counter of the iterative epilogue; interleaved: + the progress words of the computing wavefronts)
 }
 
 // run-time flags -> template arguments, without macro towers: with_flag(v, f) calls f(std::true_type / false_type)
@@ -1038,7 +1145,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
     const bool use_win = (img.win_elems > 0 && img.win_base != nullptr) || img.hub_n > 0, use_dict = img.dict != nullptr;
     if (img.hub_n) { const hipError_t eh = launch_hub_gather(img, x_ext, st); if (eh != hipSuccess) return eh; }
     if (img.order_n) x_ext = img.hub_x;                                 // the kernel gathers from the re-ordered copy of x
-    if (img.ilv && (epi || kLanes * wpb > (uint32_t)kRingThreads)) return hipErrorInvalidValue;      // (plan_layout keeps interleaved workgroups within the ring kernel's eight wavefronts)
+    if (img.ilv && (epi || wpb > 8u)) return hipErrorInvalidValue;      // (plan_layout keeps interleaved workgroups within eight computing wavefronts)
     // column phases with a window: four extra wavefronts per workgroup bring the window in while the others start (spmv_seg_kernel)
     const uint32_t loaders = img.phases > 1 && !img.ilv && use_win ? std::min<uint32_t>(4u, (uint32_t)kMaxWavesPerBlock - std::min<uint32_t>(wpb, kMaxWavesPerBlock)) : 0u;
     with_real(img.f32, [&](auto real) {
@@ -1049,13 +1156,23 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
             constexpr bool kDict = decltype(DI)::value;
             if (img.ilv) {                  // interleaved chunks: the hand-pipelined kernel
                 with_flag(img.tag16, [&](auto TG) {
-                    hipLaunchKernelGGL((spmv_ilv_kernel<T, kDict, decltype(TG)::value>), dim3(grid), dim3(kLanes * wpb), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
-                                       img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi);
+                    // helper wavefronts (spmv_ilv_kernel): as many per chunk as the kernel's registers leave room for on the CU, at most `ilv_helpers`
+                    using L = RingLayout<T, kDict, decltype(TG)::value>;
+                    const uint32_t room = (uint32_t)L::THREADS / kLanes, hmax = room / wpb > 0 ? room / wpb - 1u : 0u;
+                    const uint32_t H = std::min<uint32_t>(hmax, img.ilv_helpers);
+                    hipLaunchKernelGGL((spmv_ilv_kernel<T, kDict, decltype(TG)::value>), dim3(grid), dim3(kLanes * wpb * (1u + H)), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
+                                       img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi, wpb, img.ilv_ahead, img.ilv_per_line, img.flip_now);
                 });
             } else if (img.phases > 1) {    // column phases: every piece carries its row
                 with_flag(img.tag16, [&](auto TG) { with_flag(use_win, [&](auto WI) { with_flag(loaders > 0, [&](auto LD) {
                     constexpr int kWin = decltype(WI)::value ? 1 : 0;
                     if constexpr (decltype(LD)::value && !decltype(WI)::value) return;          // (loaders only come with a window)
+                    else if (img.prof && !multi && !epi) {          // the same kernel with its phases' time stamps (CVR_DEBUG=phase_clocks)
+                        if constexpr (std::is_same<T, double>::value && kDict && decltype(LD)::value && !decltype(TG)::value)
+                            hipLaunchKernelGGL((spmv_seg_kernel<T, 1, 1, kWin, kDict, true, false, true>), dim3(grid), dim3(kLanes * (wpb + loaders)), lds, st, img.stream, img.desc, x, y,
+                                               img.G, img.nchunks, per, swz, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems, dict, img.ndict, img.ystage, img.desc2, img.col_bits, wpb, 0, multi,
+                                               IterEpilogue{}, img.prof);
+                    }
                     else hipLaunchKernelGGL((spmv_seg_kernel<T, 1, 1, kWin, kDict, decltype(LD)::value, decltype(TG)::value>), dim3(grid), dim3(kLanes * (wpb + loaders)), lds, st, img.stream, img.desc, x, y,
                                             img.G, img.nchunks, per, swz, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems, dict, img.ndict, img.ystage, img.desc2, img.col_bits, wpb, 0, multi,
                                             epi ? *epi : IterEpilogue{});

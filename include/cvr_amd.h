@@ -309,6 +309,13 @@ void *cvr_stream(cvr_handle *h);
 /* `iters` back-to-back launches on the handle's stream and buffers between two HIP events;
  * returns mean seconds per launch.  No host copies.  (bench.py's roofline leg) */
 int cvr_spmv_bench(cvr_handle *h, int warmup, int iters, double *mean_s);
+/* Diagnostics (no counterpart in the reference, which times its phases with microtime(), spmv.cpp:575 / 1009, 1033 / 1656): a handle
+ * created with CVR_DEBUG=phase_clocks in the environment (headline layout: fp64, column phases + window + dictionary) runs the SpMV
+ * kernel in a build that stamps the chip's 100-MHz real-time counter per wavefront at entry / prologue done / window barrier passed /
+ * loop done / rows stored; this copies the stamps of the last SpMV out: [workgroup][16 wavefronts][8] =
+ * {t_entry, t_prologue, t_window, t_loop_end, t_stored, XCC id, hardware id, kind (1 computing, 2 loader, 0 none)}.
+ * *nwords = words available; tools/phase_clocks.py makes the per-XCD histogram. */
+int cvr_debug_phase_clocks(cvr_handle *h, unsigned long long *out, int64_t max_words, int64_t *nwords);
 
 /* Calibration for the roofline: a 16-byte-per-lane copy kernel over `bytes` of device memory (read
  * `bytes`, write `bytes`); returns the mean read+write rate in GB/s over `iters` launches on `device`. */
