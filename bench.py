@@ -760,11 +760,27 @@ def main():
     wrong = wrong_ref = -1
     if device_built:
         from cvr_amd import synth_dev as D
-        yl = (yalls[last[0]][rank * max_rows: rank * max_rows + lrows] if sharded else y[:lrows]).to(torch.float64)
         yref_t, absy_t = D.csr_spmv_reference(lrp_t, lci_t, lva_t, x[:ncols])
-        bad = torch.count_nonzero((yl - yref_t).abs() > (1e-5 if f32 else 1e-12) * absy_t + 1e-300).to(torch.int64).reshape(1)
+        tol_t = 1e-5 if f32 else 1e-12
         if sharded:
-            dist.all_reduce(bad)
+            # every rank checks the WHOLE gathered vector: the owners' references travel the same way as y (padded slices, all-gathered), so a
+            # rank's copy of another rank's slice is compared too -- the exchange is part of what is verified, not only the local SpMV
+            pad = torch.zeros(2 * max_rows, dtype=torch.float64, device=dev)
+            pad[:lrows] = yref_t
+            pad[max_rows: max_rows + lrows] = absy_t
+            allref = torch.zeros(world * 2 * max_rows, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allref, pad)
+            torch.cuda.synchronize()
+            allref = allref.view(world, 2, max_rows)
+            yg = yalls[last[0]].view(world, max_rows).to(torch.float64)
+            bad = torch.zeros(1, dtype=torch.int64, device=dev)
+            for p in range(world):
+                np_ = int(bounds[p + 1] - bounds[p])
+                bad += torch.count_nonzero((yg[p, :np_] - allref[p, 0, :np_]).abs() > tol_t * allref[p, 1, :np_] + 1e-300)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)          # (the worst rank's count of wrong rows over the whole vector)
+        else:
+            yl = y[:lrows].to(torch.float64)
+            bad = torch.count_nonzero((yl - yref_t).abs() > tol_t * absy_t + 1e-300).to(torch.int64).reshape(1)
         wrong = int(bad.item())
     else:
         yh = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()
@@ -779,6 +795,24 @@ def main():
             wrong = int(np.count_nonzero(np.abs(yh.astype(np.float64) - yref) > tol * absy + (1e-30 if f32 else 1e-300)))
             wrong_ref = int(cvr_amd.verdict(yh.astype(np.float64), yref, nrows))
 
+    # the exchange itself: every rank must hold the SAME gathered vector, and rank p's copy of slice p is the one its own check above
+    # covered -- so per slice, every rank's bits against the owner's (a 64-bit wrap-around sum of the slice's bit patterns)
+    gathered_mismatch = None
+    shard_sums = None
+    if sharded and device_built:          # what every rank built (the tests compare it with slices of the matrix built in one piece)
+        mine_s = [int(lrows), int(lnnz), int(lci_t.to(torch.int64).sum().item()), int((lva_t.to(torch.float64) * 1e6).round().to(torch.int64).sum().item())]
+        shard_sums = [None] * world
+        dist.all_gather_object(shard_sums, mine_s)
+    if sharded:
+        sizes = [int(bounds[p + 1] - bounds[p]) for p in range(world)]
+        mine = torch.stack([yalls[last[0]][p * max_rows: p * max_rows + sizes[p]].view(bits).to(torch.int64).sum() for p in range(world)])
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        tab = torch.stack(every).cpu().numpy()          # [rank][slice]
+        gathered_mismatch = int(sum(int(tab[r][p] != tab[p][p]) for r in range(world) for p in range(world)))
+        if gathered_mismatch and rank == 0:
+            print("[bench] gathered y differs between ranks: (rank, slice) pairs off: "
+                  + ", ".join(f"({r},{p})" for r in range(world) for p in range(world) if tab[r][p] != tab[p][p]), file=sys.stderr)
     if args.dump_y and rank == 0:
         ydump = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()
         np.save(args.dump_y, ydump)
@@ -838,6 +872,7 @@ def main():
                            "warm": None if warm_info is None else {**_pre_times(warm_info), "create_and_preprocess_wall_s": warm_create_s,
                                                                     "which": "the same matrix built a second time in this process"}},
             "independent_spmvs_on_two_streams": None if two is None else {"ms_per_spmv": two * 1e3, "gflops": 2.0 * nnz / two / 1e9},
+            "gathered_slices_differing_between_ranks": gathered_mismatch, "shard_checksums": shard_sums,
             "verdict_wrong_rows": wrong, "verdict_tolerance": "rows with |y - y_csr| > %g * sum |a x|" % (1e-5 if f32 else 1e-12),
             "verdict_wrong_rows_reference_criterion_abs_1e-3": wrong_ref if wrong_ref >= 0 else None, "gather_impl": gather_impl, "gather_calibration_ms_per_step": calib,
         }

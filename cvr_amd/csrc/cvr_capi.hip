@@ -53,7 +53,7 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
         }
     hipError_t e = cvr::launch_fixup_multi(h->d_fixparts, (uint32_t)h->parts.size(), h->max_nshared, h->vsz == 4, st);
     if (e != hipSuccess) return e;
-    e = cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st);
+    e = cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st, h->combine_batch, h->combine_mul);
     if (e != hipSuccess) return e;
     h->z_used = true;
     return hipEventRecord(h->z_free, st);
@@ -106,6 +106,17 @@ void ilv_runtime_settings(cvr_handle *h)
         p.img.ilv_per_line = (e = cvr::debug_env("ilv_per_line")) ? (uint32_t)std::max(1, atoi(e)) : 2u;
         p.img.ilv_ahead = (e = cvr::debug_env("ilv_ahead")) ? (uint32_t)std::max(1, atoi(e)) : 24u;
         p.img.ilv_flip = (e = cvr::debug_env("ilv_flip")) ? (uint32_t)std::max(0, atoi(e)) : big ? 1u : 0u;
+    }
+    if (const char *e = cvr::debug_env("combine_batch")) h->combine_batch = atoi(e) == 8 ? 8 : 4;
+    // the combine pass of a matrix whose rows are mostly empty (fewer partial sums over all panels than rows): eight blocks of rows per workgroup,
+    // the loads of eight panels per round trip (combine_kernel)
+    if (h->paneled()) {
+        int64_t pairs = 0;
+        for (const Part &p : h->parts) pairs += p.nrows;
+        const bool sparse = pairs < h->info.nrows;
+        const char *e = cvr::debug_env("combine_mul");
+        h->combine_mul = e ? (atoi(e) == 8 ? 8 : 1) : sparse ? 8 : 1;
+        if (!cvr::debug_env("combine_batch") && sparse && h->parts.size() <= 8) h->combine_batch = 8;
     }
 }
 

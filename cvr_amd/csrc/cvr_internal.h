@@ -156,6 +156,8 @@ struct cvr_handle {
     std::vector<hipEvent_t> events;
     hipEvent_t z_free = nullptr;         // column panels: recorded after the combine pass; the next SpMV (on any stream) waits for it
     bool       z_used = false;
+    int        combine_mul = 1;          // blocks of kCombineRows rows per workgroup of the combine pass: 8 when the panels' partial sums are fewer than the rows (mostly empty rows)
+    int        combine_batch = 4;        // panels whose loads share a round trip in the combine pass (CVR_DEBUG=combine_batch=8: experiment)
     uint32_t   spmv_calls = 0;           // SpMVs launched so far (interleaved panels with ilv_flip: every other one walks the workgroups backwards)
     cvr::PlanScratch plan_ws;            // cvr_create only: scratch of the device planner (released before cvr_create returns)
     // cvr_create only: 32 KiB of device scratch for the small tables of its analysis passes (layout probe 16 KiB, dictionary

@@ -45,6 +45,7 @@ struct DeviceImage {
     unsigned long long *prof = nullptr;      // CVR_DEBUG=phase_clocks: [workgroups * 16 wavefronts][8] time stamps of spmv_seg_kernel's phases (diagnostics; null otherwise)
     uint32_t  prof_words = 0;
     uint32_t  ilv_helpers = 0, ilv_ahead = 16, ilv_per_line = 1;
+    uint32_t  stream_mod = 0;       // profiling only (CVR_DEBUG=stream_mod=M): every chunk streams the image of chunk k % M (L2-resident stream, wrong sums)
     uint32_t  ilv_flip = 0;         // interleaved: 1 = every other SpMV walks the workgroups in reverse order (what the last one streamed last is still in the Infinity Cache); set per launch
     uint32_t  flip_now = 0;      // interleaved: helper wavefronts per chunk (scalar prefetch of the stream), how many groups ahead, loads per line
     uint32_t  piece_max = 0;        // column phases: (row, phase) segments are cut into pieces at the multiples of this many elements from the chunk's first (0 = whole segments)
@@ -219,7 +220,7 @@ hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t ma
 // and belongs to row rows[u] (ascending); block_off[p * (nblocks + 1) + b] = first u of panel p with rows[u] >= b * kCombineRows.
 constexpr int kCombineRows = 1024;
 struct CombinePanel { const void *z; const uint32_t *rows; };
-hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st);
+hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch = 4, int mul = 1);      // batch: panels whose loads share a round trip (4 or 8); mul: blocks of kCombineRows rows per workgroup (1 or 8)
 
 // 16-B-per-lane streaming copy (roofline calibration)
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st);

@@ -498,6 +498,7 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
     const int64_t win = pp.win;
     img.win_elems = (uint32_t)win;
     if (opt.debug_col_mask) img.col_mask &= (uint32_t)opt.debug_col_mask & cvr::kColMask;   // profiling knob (tools/sweep.py --colmask)
+    if (const char *e = cvr::debug_env("stream_mod")) img.stream_mod = (uint32_t)std::max(0, atoi(e));
 
     return CVR_OK;
 }

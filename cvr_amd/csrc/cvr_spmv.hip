@@ -266,7 +266,7 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     const T *__restrict__ x, T *__restrict__ yext_a, int G, uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz,
     uint32_t cmask, uint32_t xbytes, const uint32_t *__restrict__ win_base, uint32_t wn, const T *__restrict__ dict_g, uint32_t ndict,
     uint32_t ystage_a, const T *__restrict__ hub_x, uint32_t hub_n, uint32_t kstride,
-    const uint32_t *__restrict__ cbase, uint32_t pad_col, const PanelArgs *__restrict__ multi)
+    const uint32_t *__restrict__ cbase, uint32_t pad_col, const PanelArgs *__restrict__ multi, uint32_t stream_mod)
 {
     const uint8_t *__restrict__ stream = stream_a, *__restrict__ target = target_a;
     const uint4 *__restrict__   desc = desc_a;
@@ -283,6 +283,8 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     // LDS: [waves][64] steal slots, [waves][ystage_n] staged row sums, the value dictionary (DICT),
     // the x window and its zero slot (WIN; wn + 4 values)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // (Helper wavefronts as in spmv_ilv_kernel -- scalar prefetch of the stream -- were measured on this kernel's persistent hub-table form and
+    // made it slower: R-MAT-22 fp32 286 -> 308-315 us, profiles/r05_rmat_helpers_not_adopted.log: the prefetched lines displace x in the L2s.)
     const uint32_t nw = MW ? blockDim.x >> 6 : 1u;
     T *const slots = reinterpret_cast<T *>(smem);
     T *const ystage_all = slots + nw * kLanes;
@@ -311,7 +313,9 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
     uint32_t       cb = 0;                             // C16: the chunk's smallest column
     // the first loads of chunk k: its stream (a wave past the last chunk streams nothing), its descriptor
     auto begin_chunk = [&]() {
-        rs = make_rsrc(stream + (size_t)(live ? k : 0) * ((size_t)G * GB), live ? (uint32_t)G * GB : 0u);
+        // (stream_mod, CVR_DEBUG=stream_mod=M: timing only, wrong sums -- every chunk streams the image of one of the first M chunks, i.e. an L2-resident
+        // stream: what a perfect prefetch of the stream would give)
+        rs = make_rsrc(stream + (size_t)(live ? (stream_mod ? k % stream_mod : k) : 0) * ((size_t)G * GB), live ? (uint32_t)G * GB : 0u);
 #pragma unroll
         for (int i = 0; i < QN; i++) Q[i] = load_group<T, SPOL, DICT, C16>(rs, voff, (uint32_t)i * GB);
         d = live ? desc[k] : uint4{0, 0, 0, 0};
@@ -488,7 +492,7 @@ __device__ __forceinline__ void sum_group_seg(T &acc, const SegGroup<T, DICT, TA
 // complete in order, so it cannot overlap that wait itself.)  Dictionary and zero slot are written by every computing
 // wavefront for itself (the same values to the same addresses), so nothing else needs a barrier.
 // PROF (CVR_DEBUG=phase_clocks; diagnostics, one extra instantiation): every wavefront stamps the 100-MHz real-time counter (s_memrealtime: one
-// clock for the whole chip) at entry / prologue done / window barrier passed / loop done / rows stored, with its XCC and hardware id:
+// clock for the whole chip) at entry / prologue done / window barrier passed / loop done / rows stored, with its XCC id and the time it arrived at the window barrier:
 // prof[(blockIdx.x * 16 + wave) * 8 + 0..7]; tools/phase_clocks.py turns the dump into the per-XCD histogram of profiles/.
 __device__ __forceinline__ unsigned long long prof_now() { return __builtin_amdgcn_s_memrealtime(); }
 
@@ -626,14 +630,19 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     }
     T acc = 0;
     if constexpr (PROF) pc[1] = prof_now();
+    // (Round 5, measured and not adopted: meeting the loaders only in front of the first group that gathers inside the window, with the column
+    // phases walked from two behind the chunk's diagonal on so that the window's phase comes last -- the window's loads then share the vector
+    // L1's in-order queue with the far gathers and land after 10-14 us instead of 2.5; 21.7 against 21.1 us: profiles/r05_phase_clocks_webgoogle_c_*)
+    unsigned long long pc_arrive = 0;
     if constexpr (LOADER && WIN != 0) {
-        if (gb < 0) { asm volatile("s_barrier" ::: "memory"); wn_eff = wn; if constexpr (PROF) pc[2] = prof_now(); }      // (meet the loaders in front of the first gather)
+        if (gb < 0) { if constexpr (PROF) pc_arrive = prof_now(); asm volatile("s_barrier" ::: "memory"); wn_eff = wn; if constexpr (PROF) pc[2] = prof_now(); }      // (meet the loaders in front of the first gather)
     }
 #pragma unroll
     for (int i = 0; i < DEPTH; i++) xs[i] = gather<T, kPolDefault, WIN>(rx, win, Q[i].c, cmask, wbase, wn_eff, 0u, wn);
     for (int g = 0; g < G; g++) {
         if constexpr (LOADER && WIN != 0) {
             if (g == gb) {                          // the window has arrived (the loaders waited for their loads in front of this barrier)
+                if constexpr (PROF) pc_arrive = prof_now();
                 asm volatile("s_barrier" ::: "memory");
                 wn_eff = wn;
                 if constexpr (PROF) pc[2] = prof_now();
@@ -649,7 +658,7 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
         for (int i = 0; i + 1 < DEPTH; i++) xs[i] = xs[i + 1];
         xs[DEPTH - 1] = xn;
     }
-    if constexpr (LOADER && WIN != 0) { if (gb >= G) asm volatile("s_barrier" ::: "memory"); }      // (every wavefront meets the loaders exactly once)
+    if constexpr (LOADER && WIN != 0) { if (gb >= G) { if constexpr (PROF) pc_arrive = prof_now(); asm volatile("s_barrier" ::: "memory"); if constexpr (PROF) pc[2] = prof_now(); } }      // (every wavefront meets the loaders exactly once)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if constexpr (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pc[3] = prof_now(); }
@@ -663,7 +672,7 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
             pc[4] = prof_now();
             if (lane == 0 && prof) {
                 unsigned long long *o = prof + ((size_t)blockIdx.x * 16 + wv) * 8;
-                o[0] = pc[0]; o[1] = pc[1]; o[2] = pc[2]; o[3] = pc[3]; o[4] = pc[4]; o[5] = __builtin_amdgcn_s_getreg(6164); o[6] = __builtin_amdgcn_s_getreg(63492); o[7] = 1;
+                o[0] = pc[0]; o[1] = pc[1]; o[2] = pc[2]; o[3] = pc[3]; o[4] = pc[4]; o[5] = __builtin_amdgcn_s_getreg(6164); o[6] = pc_arrive; o[7] = 1;
             }
         }
         return;
@@ -831,20 +840,51 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG>::THREADS)) __attribute__(
     const uint32_t k = __builtin_amdgcn_readfirstlane(blk * nw + wc);
     const bool     live = k < nchunks;
     T *const       ystage = ystage_all + wc * ystage_n;
+    constexpr uint32_t GBH = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
+    // PROLOGUE: everything it loads is ISSUED before anything is waited for -- the dictionary's values (into registers), the chunk's
+    // descriptors, the stream of the first D groups -- and the accumulators are zeroed up to the layout's cap, which needs no load.  (It
+    // used to zero up to a count that a load brought, then fetch the dictionary, then start the stream: three memory round trips one after
+    // the other, ~3.4 us in front of every workgroup's first addition -- 13 % of the wiki-Talk shape's kernel.)
+    T dv[4] = {T(0), T(0), T(0), T(0)};
+    if constexpr (DICT) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = threadIdx.x + (uint32_t)u * blockDim.x; if (i < ndict) dv[u] = dict_g[i]; }          // (blockDim >= 64: four rounds cover the 256 entries)
+    }
     const uint4    d = live ? desc[k] : uint4{0, 0, 0, 0};
     const uint2    d2 = live ? desc2[k] : uint2{0, 0};
-    const uint32_t nri = d2.y;                                        // rows of this chunk
-    const uint32_t G = __builtin_amdgcn_readfirstlane(min((uint32_t)G_alloc, d2.x));      // the groups that hold its non-zeros
-    if (live && !helper) for (uint32_t i = lane; i <= nri; i += kLanes) ystage[i] = T(0);
+    // (the descriptors must live in scalar registers: the asm statements below take them as such)
+    const uint64_t sbase = reinterpret_cast<uint64_t>(stream + (size_t)(live ? k : 0) * ((size_t)G_alloc * GBH));
+    const uint64_t sbase_u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sbase) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32)) << 32);      // (the builtin returns int: no sign extension)
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(reinterpret_cast<const void *>(sbase_u), __builtin_amdgcn_readfirstlane((uint32_t)G_alloc * GBH));      // the chunk's whole allocation: the run-in's range
+    const uint32_t vo_c = lane * 16u, vo_t = lane * 8u + (uint32_t)kColsBytes, vo_code = lane * 4u + VB, vo_v0 = lane * 16u + VB, vo_v1 = vo_v0 + (uint32_t)kLanes * 16u;
+    (void)vo_t; (void)vo_code; (void)vo_v1;
+    // the stream of group `grp` into Q slot `qs` (a group past the chunk's last is out of range: zeros, no traffic)
+    auto load_q_from = [&](const __amdgpu_buffer_rsrc_t rs, auto qsc, uint32_t grp) {
+        constexpr int  R = QB + decltype(qsc)::value * L::QSZ;
+        // (the group's offset goes into the VECTOR offset: the buffer's range check covers that one only, not the scalar offset -- a
+        // load past the chunk's last group must not reach memory, the ring runs up to 4 D - 1 groups ahead)
+        const uint32_t so = grp * GB;
+        ring_ld128<R>(vo_c + so, rs, 0u);
+        if constexpr (TAG) ring_ld64<R + L::TOFF>(vo_t + so, rs, 0u);
+        if constexpr (DICT) ring_ld32<R + L::VOFF>(vo_code + so, rs, 0u);
+        else if constexpr (sizeof(T) == 8) { ring_ld128<R + L::VOFF>(vo_v0 + so, rs, 0u); ring_ld128<R + L::VOFF + 4>(vo_v1 + so, rs, 0u); }
+        else ring_ld128<R + L::VOFF>(vo_v0 + so, rs, 0u);
+    };
+    // run-in, first half: the stream of the first D groups (through the allocation's descriptor: the count of groups that hold non-zeros
+    // is one of the loads in flight; groups behind it are padding of the chunk's own allocation)
+    if (live && !helper) static_for<0, D>([&](auto ic) { load_q_from(rs0, ic, (uint32_t)decltype(ic)::value); });
+    if (live && !helper) for (uint32_t i = lane; i < ystage_n; i += kLanes) ystage[i] = T(0);
     if (nwt > nw && threadIdx.x < nw) prog[threadIdx.x] = 0u;
     if constexpr (DICT) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)kDictMax; i += blockDim.x) dict[i] = i < ndict ? dict_g[i] : T(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = threadIdx.x + (uint32_t)u * blockDim.x; if (i < (uint32_t)kDictMax) dict[i] = dv[u]; }
         __syncthreads();
     } else {
         if (nwt > nw) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
     if (!live) return;
-    constexpr uint32_t GBH = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
+    const uint32_t nri = d2.y;                                        // rows of this chunk
+    const uint32_t G = __builtin_amdgcn_readfirstlane(min((uint32_t)G_alloc, d2.x));      // the groups that hold its non-zeros
     if (helper) {
         // lines of the chunk's stream, in batches of kHB per helper (what the scalar-memory counter of a wavefront tracks), helper h of H taking
         // batches h, h + H, ...; a batch is issued once the computing wavefront is within help_ahead groups of it, and skipped when that
@@ -882,25 +922,9 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG>::THREADS)) __attribute__(
         }
         return;
     }
-    // (the descriptors must live in scalar registers: the asm statements below take them as such)
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + col_base, xbytes);
-    const uint64_t sbase = reinterpret_cast<uint64_t>(stream + (size_t)k * ((size_t)G_alloc * GB));
-    const uint64_t sbase_u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sbase) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32)) << 32);      // (the builtin returns int: no sign extension)
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const void *>(sbase_u), __builtin_amdgcn_readfirstlane(G * GB));
-    const uint32_t vo_c = lane * 16u, vo_t = lane * 8u + (uint32_t)kColsBytes, vo_code = lane * 4u + VB, vo_v0 = lane * 16u + VB, vo_v1 = vo_v0 + (uint32_t)kLanes * 16u;
-    (void)vo_t; (void)vo_code; (void)vo_v1;
-    // the stream of group `grp` into Q slot `qs` (a group past the chunk's last is out of range: zeros, no traffic)
-    auto load_q = [&](auto qsc, uint32_t grp) {
-        constexpr int  R = QB + decltype(qsc)::value * L::QSZ;
-        // (the group's offset goes into the VECTOR offset: the buffer's range check covers that one only, not the scalar offset -- a
-        // load past the chunk's last group must not reach memory, the ring runs up to 4 D - 1 groups ahead)
-        const uint32_t so = grp * GB;
-        ring_ld128<R>(vo_c + so, rs, 0u);
-        if constexpr (TAG) ring_ld64<R + L::TOFF>(vo_t + so, rs, 0u);
-        if constexpr (DICT) ring_ld32<R + L::VOFF>(vo_code + so, rs, 0u);
-        else if constexpr (sizeof(T) == 8) { ring_ld128<R + L::VOFF>(vo_v0 + so, rs, 0u); ring_ld128<R + L::VOFF + 4>(vo_v1 + so, rs, 0u); }
-        else ring_ld128<R + L::VOFF>(vo_v0 + so, rs, 0u);
-    };
+    auto load_q = [&](auto qsc, uint32_t grp) { load_q_from(rs, qsc, grp); };
     // the x of the group in Q slot `qs` into x slot `xs`
     auto gather_x = [&](auto qsc, auto xsc) {
         constexpr int R = QB + decltype(qsc)::value * L::QSZ, X = XB + decltype(xsc)::value * L::XSZ;
@@ -913,7 +937,6 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG>::THREADS)) __attribute__(
     // (the two markers bracket the region tools/isa_check.py looks at in the compiler's output -- `make isa-check`: every vector-memory
     // instruction between them must be one of the asm statements' loads into the ring's registers, and nothing may spill)
     asm volatile("; CVR_RING_BEGIN cap=%0" ::"n"(kRingCap) : "memory");
-    static_for<0, D>([&](auto ic) { load_q(ic, (uint32_t)decltype(ic)::value); });
     ring_wait<0>();
     static_for<0, D>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -987,7 +1010,11 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void fixup_kernel(const in
 // partial sums of those rows (a contiguous range of the panel's y_ext: the panel's rows are sorted) together with their
 // row numbers and adds them into LDS accumulators; a row occurs at most once per panel, and a barrier separates the
 // panels, so the additions happen in panel order (bitwise reproducible).  All global accesses are coalesced streams.
-template <typename T, int kBatch>
+// MUL: a workgroup owns MUL of those blocks of rows (block_off keeps its granularity): for matrices whose rows are mostly EMPTY -- the
+// wiki-Talk shape: 6 % of the rows hold all the non-zeros -- a block of 1 024 rows has a few dozen partial sums per panel and the pass is
+// all launch and round-trip latency (2 339 workgroups, 13.7 us); with MUL = 8 a workgroup has eight times the entries per round trip and
+// there are an eighth of the workgroups.
+template <typename T, int kBatch, int MUL>
 __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off,
                                                       uint32_t nblocks, T *__restrict__ y, uint32_t nrows)
 {
@@ -997,9 +1024,10 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
     // (kBatch = 8 for up to eight panels: ONE round trip per block -- a matrix with few non-zeros per row block, the wiki-Talk shape, spends
     // its combine pass waiting for those round trips, not moving bytes)
     constexpr int kEach = 4;
-    __shared__ T acc[kCombineRows];
-    const uint32_t b = blockIdx.x, r0 = b * kCombineRows;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kCombineRows; i += blockDim.x) acc[i] = 0;
+    constexpr uint32_t kRows = (uint32_t)kCombineRows * MUL;
+    __shared__ T acc[kRows];
+    const uint32_t b = blockIdx.x * MUL, b1 = min(b + (uint32_t)MUL, nblocks), r0 = b * kCombineRows;      // the blocks [b, b1) of the tables
+    for (uint32_t i = threadIdx.x; i < kRows; i += blockDim.x) acc[i] = 0;
     __syncthreads();
     for (uint32_t p0 = 0; p0 < npanels; p0 += kBatch) {
         T        v[kBatch][kEach];
@@ -1012,7 +1040,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
             const uint32_t *rows = nullptr;
             if (p < npanels) {
                 const CombinePanel cp = panels[p];
-                lo = block_off[(size_t)p * (nblocks + 1) + b]; hi = block_off[(size_t)p * (nblocks + 1) + b + 1];
+                lo = block_off[(size_t)p * (nblocks + 1) + b]; hi = block_off[(size_t)p * (nblocks + 1) + b1];
                 z = static_cast<const T *>(cp.z); rows = cp.rows;
             }
 #pragma unroll
@@ -1029,14 +1057,14 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
 #pragma unroll
                 for (int e = 0; e < kEach; e++) if (rw[q][e] != 0xffffffffu) acc[rw[q][e] - r0] += v[q][e];
                 const CombinePanel cp = panels[p];
-                const uint32_t     lo = block_off[(size_t)p * (nblocks + 1) + b], hi = block_off[(size_t)p * (nblocks + 1) + b + 1];
+                const uint32_t     lo = block_off[(size_t)p * (nblocks + 1) + b], hi = block_off[(size_t)p * (nblocks + 1) + b1];
                 const T           *z = static_cast<const T *>(cp.z);
                 for (uint32_t u = lo + threadIdx.x + (uint32_t)kEach * 256u; u < hi; u += 256u) acc[cp.rows[u] - r0] += z[u];
             }
             __syncthreads();
         }
     }
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kCombineRows && r0 + i < nrows; i += blockDim.x) y[r0 + i] = acc[i];
+    for (uint32_t i = threadIdx.x; i < kRows && r0 + i < nrows; i += blockDim.x) y[r0 + i] = acc[i];
 }
 
 // plain streaming copy: the achievable-HBM-rate yardstick beside the 8 TB/s nominal peak.  Four independent
@@ -1083,17 +1111,23 @@ hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t ma
     return hipGetLastError();
 }
 
-hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st)
+hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch, int mul)
 {
     if (nrows == 0) return hipSuccess;
     const uint32_t nblocks = (nrows + kCombineRows - 1) / kCombineRows;
-    if (npanels <= 8) {
-        if (f32) hipLaunchKernelGGL((combine_kernel<float, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<float *>(y), nrows);
-        else hipLaunchKernelGGL((combine_kernel<double, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<double *>(y), nrows);
-    } else {
-        if (f32) hipLaunchKernelGGL((combine_kernel<float, 4>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<float *>(y), nrows);
-        else hipLaunchKernelGGL((combine_kernel<double, 4>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, static_cast<double *>(y), nrows);
-    }
+    auto go = [&](auto real) {
+        using T = decltype(real);
+        T *yt = static_cast<T *>(y);
+        if (mul == 8) {
+            const uint32_t grid = (nblocks + 7) / 8;
+            if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else hipLaunchKernelGGL((combine_kernel<T, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+        } else {
+            if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else hipLaunchKernelGGL((combine_kernel<T, 4, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+        }
+    };
+    if (f32) go(float{}); else go(double{});
     return hipGetLastError();
 }
 
@@ -1181,13 +1215,13 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                 if constexpr (!kDict)
                     hipLaunchKernelGGL((spmv_kernel<T, 1, kPolDefault, 1, 0, false, false, true>), dim3(grid), dim3(kLanes), lds, st, img.stream, img.desc, img.target, x, y, img.G, img.nchunks, per, swz,
                                        img.col_mask, (uint32_t)xb, img.win_base, 0u, static_cast<const T *>(nullptr), 0u, img.ystage, static_cast<const T *>(nullptr), 0u, kstride, img.cbase, img.pad_col,
-                                       static_cast<const PanelArgs *>(nullptr));
+                                       static_cast<const PanelArgs *>(nullptr), img.stream_mod);
             } else {                        // the general kernel: rows handed out by ballot / rank; LDS table: none, a window of x, or a hub table
                 with_flag(wpb > 1, [&](auto MW) {
                     auto go = [&](auto W) {
                         hipLaunchKernelGGL((spmv_kernel<T, 1, kPolDefault, 1, decltype(W)::value, kDict, decltype(MW)::value, false>), dim3(grid), dim3(kLanes * wpb), lds, st, img.stream, img.desc, img.target,
                                            x, y, img.G, img.nchunks, per, swz, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems, dict, img.ndict, img.ystage, static_cast<const T *>(img.hub_x),
-                                           img.hub_n, kstride, img.cbase, img.pad_col, multi);
+                                           img.hub_n, kstride, img.cbase, img.pad_col, multi, img.stream_mod);
                     };
                     if (use_win && img.hub_n) go(std::integral_constant<int, 2>{}); else if (use_win) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 0>{});
                 });

@@ -313,7 +313,7 @@ int cvr_spmv_bench(cvr_handle *h, int warmup, int iters, double *mean_s);
  * created with CVR_DEBUG=phase_clocks in the environment (headline layout: fp64, column phases + window + dictionary) runs the SpMV
  * kernel in a build that stamps the chip's 100-MHz real-time counter per wavefront at entry / prologue done / window barrier passed /
  * loop done / rows stored; this copies the stamps of the last SpMV out: [workgroup][16 wavefronts][8] =
- * {t_entry, t_prologue, t_window, t_loop_end, t_stored, XCC id, hardware id, kind (1 computing, 2 loader, 0 none)}.
+ * {t_entry, t_prologue, t_window (barrier passed), t_loop_end, t_stored, XCC id, t_arrived at the window barrier (loaders: hardware id), kind (1 computing, 2 loader, 0 none)}.
  * *nwords = words available; tools/phase_clocks.py makes the per-XCD histogram. */
 int cvr_debug_phase_clocks(cvr_handle *h, unsigned long long *out, int64_t max_words, int64_t *nwords);
 

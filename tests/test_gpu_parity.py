@@ -1460,7 +1460,14 @@ def test_bench_eight_ranks_on_one_device(workload, tmp_path):
         rp_t, ci_t, va_t = D.banded_rows(n, 0, n, device="cuda")
         assert cfg["nnz_imbalance_max_over_mean"] < 1.01
     assert sum(cfg["rows_per_gpu"]) == n and sum(cfg["nnz_per_gpu"]) == int(rp_t[-1])
+    assert d["gathered_slices_differing_between_ranks"] == 0          # every rank holds the same gathered vector (bench.py's own cross-rank check)
     rp, ci, va = rp_t.cpu().numpy(), ci_t.cpu().numpy(), va_t.cpu().numpy()
+    # every rank built the slice of THIS matrix that the cut gives it (rows, non-zeros, column sum, value sum)
+    b = np.concatenate([[0], np.cumsum(cfg["rows_per_gpu"])])
+    for p in range(8):
+        lo, hi = int(rp[b[p]]), int(rp[b[p + 1]])
+        want = [int(b[p + 1] - b[p]), hi - lo, int(ci[lo:hi].astype(np.int64).sum()), int(np.round(va[lo:hi].astype(np.float64) * 1e6).astype(np.int64).sum())]
+        assert d["shard_checksums"][p] == want, (p, d["shard_checksums"][p], want)
     del rp_t, ci_t, va_t
     torch.cuda.empty_cache()
     y = np.load(ypath)
@@ -1468,7 +1475,8 @@ def test_bench_eight_ranks_on_one_device(workload, tmp_path):
     x = synth.x_rand(n, np.float32 if f32 else np.float64)
     yref, absy = O.csr_spmv64(rp, ci, va.astype(np.float64), x.astype(np.float64))
     bad, worst = O.tol_check(y.astype(np.float64), yref, absy, tol=1e-5 if f32 else 1e-12)
-    assert len(bad) == 0, (len(bad), worst)
+    per_slice = [int(np.count_nonzero((bad >= b[p]) & (bad < b[p + 1]))) for p in range(8)]
+    assert len(bad) == 0, (len(bad), worst, "wrong rows per rank's slice", per_slice)
 
 
 @pytest.mark.parametrize("shape", ["webgoogle_seed7", "webgoogle_real", "lj_half", "road", "citation", "rmat21b", "wikitalk_x2", "uniform16"])

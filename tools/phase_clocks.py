@@ -5,8 +5,9 @@ done / window barrier passed / loop done / rows stored), one launch, dumped as a
 
   start    = a wavefront's entry after the launch's first entry (dispatch skew)
   prologue = entry -> first gather (descriptor and stream loads issued, accumulators zeroed, dictionary copied)
-  window   = wait at the barrier for the loader wavefronts' LDS-direct loads of the 96-KiB window
-  loop     = the gather loop
+  loop before the window barrier = what a wavefront does between its prologue and the barrier (nothing in the product: the barrier stands in
+             front of the first group); wait = at that barrier, for the loader wavefronts' LDS-direct loads of the 96-KiB window
+  loop     = the gather loop, the wait taken out
   store    = rows written out (until the stores have left the wavefront)
   end      = a wavefront's last stamp after the launch's first entry; the kernel's duration is the largest + the launch floor's tail
 
@@ -44,8 +45,9 @@ def main():
     print(f"# {name}: {n} rows, {len(ci)} nnz; layout S {i.steps_per_chunk} x {i.waves_per_block} chunks per workgroup, window {i.x_window}, phases {i.col_phases}, dict {i.value_dict}; "
           f"{i.nchunks} chunks; stamped kernel {t * 1e6:.2f} us per SpMV (event-timed, back to back)")
     print(f"# {len(comp)} computing wavefronts, {len(load)} loader wavefronts; 100-MHz counter: 10 ns per tick")
-    rows = [("start (entry - first entry)", comp[:, 0] - t0), ("prologue", comp[:, 1] - comp[:, 0]), ("window wait", comp[:, 2] - comp[:, 1]),
-            ("loop", comp[:, 3] - comp[:, 2]), ("store", comp[:, 4] - comp[:, 3]), ("end (last stamp - first entry)", comp[:, 4] - t0)]
+    rows = [("start (entry - first entry)", comp[:, 0] - t0), ("prologue", comp[:, 1] - comp[:, 0]), ("loop before the window barrier", comp[:, 6] - comp[:, 1]),
+            ("wait at the window barrier", comp[:, 2] - comp[:, 6]), ("loop behind the barrier", comp[:, 3] - comp[:, 2]), ("loop in all (without the wait)", comp[:, 3] - comp[:, 1] - (comp[:, 2] - comp[:, 6])),
+            ("store", comp[:, 4] - comp[:, 3]), ("end (last stamp - first entry)", comp[:, 4] - t0)]
     print(f"{'phase, us':34s} {'min':>7s} {'p10':>7s} {'median':>7s} {'p90':>7s} {'max':>7s} {'mean':>7s}")
     for label, v in rows:
         v = us(v)
@@ -57,10 +59,12 @@ def main():
     xcc = comp[:, 5] & 0xf
     for xid in sorted(set(xcc.tolist())):
         m = xcc == xid
-        lp, en, st = us(comp[m, 3] - comp[m, 2]), us(comp[m, 4] - t0), us(comp[m, 0] - t0)
-        print(f"  XCC {xid}: {int(m.sum()):5d} wavefronts  start median {pct(st, 50):6.2f} max {st.max():6.2f} | loop median {pct(lp, 50):6.2f} max {lp.max():6.2f} | end median {pct(en, 50):6.2f} max {en.max():6.2f}")
+        lp, en, st = us(comp[m, 3] - comp[m, 1] - (comp[m, 2] - comp[m, 6])), us(comp[m, 4] - t0), us(comp[m, 0] - t0)
+        wt, bf = us(comp[m, 2] - comp[m, 6]), us(comp[m, 6] - comp[m, 1])
+        print(f"  XCC {xid}: {int(m.sum()):5d} wavefronts  start median {pct(st, 50):6.2f} | before barrier median {pct(bf, 50):6.2f} | barrier wait median {pct(wt, 50):6.2f} max {wt.max():6.2f} | "
+              f"loop median {pct(lp, 50):6.2f} max {lp.max():6.2f} | end median {pct(en, 50):6.2f} max {en.max():6.2f}")
     end = us(comp[:, 4] - t0)
-    loop_share = float(us(comp[:, 3] - comp[:, 2]).mean() / end.max())
+    loop_share = float(us(comp[:, 3] - comp[:, 1] - (comp[:, 2] - comp[:, 6])).mean() / end.max())
     print(f"# slowest wavefront ends at {end.max():.2f} us, the median one at {pct(end, 50):.2f} us; mean loop / slowest end = {loop_share:.2f}")
     A.close()
 

@@ -58,7 +58,7 @@ int main()
         for (int infl : {4, 8, 15}) {
             for (uint32_t stride : {64u, 128u}) {
                 const int waves = cus * wpc;
-                size_t per_wave = ((size_t)24 << 20) / wpc;          // 24 MiB per CU and run
+                size_t per_wave = ((size_t)8 << 20) / wpc;          // 8 MiB per CU and run (256 CUs: 2 GiB of the 3)
                 per_wave = per_wave / (15 * 128) * (15 * 128);
                 if (cursor + (size_t)waves * per_wave > total) cursor = 0;
                 const dim3 grid(cus), block(64 * wpc);
@@ -77,7 +77,7 @@ int main()
     printf("# vector path, 16 B per lane, 4 loads in flight per lane\n");
     for (int wpc : {4, 8, 16}) {
         const int waves = cus * wpc;
-        size_t per_wave = (((size_t)24 << 20) / wpc) & ~(size_t)4095;
+        size_t per_wave = (((size_t)8 << 20) / wpc) & ~(size_t)4095;
         if (cursor + (size_t)waves * per_wave > total) cursor = 0;
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL(vmem_kernel, dim3(cus), dim3(64 * wpc), 0, 0, buf + cursor, per_wave, sink);
