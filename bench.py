@@ -769,7 +769,7 @@ def main():
             pad[:lrows] = yref_t
             pad[max_rows: max_rows + lrows] = absy_t
             allref = torch.zeros(world * 2 * max_rows, dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(allref, pad)
+            shard.all_gather_tensor(allref, pad)
             torch.cuda.synchronize()
             allref = allref.view(world, 2, max_rows)
             yg = yalls[last[0]].view(world, max_rows).to(torch.float64)
@@ -806,16 +806,25 @@ def main():
     if sharded:
         sizes = [int(bounds[p + 1] - bounds[p]) for p in range(world)]
         mine = torch.stack([yalls[last[0]][p * max_rows: p * max_rows + sizes[p]].view(bits).to(torch.int64).sum() for p in range(world)])
-        every = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every, mine)
-        tab = torch.stack(every).cpu().numpy()          # [rank][slice]
+        if backend == "gloo":          # (device tensors over gloo go through host tensors: cvr_amd/shard.py, all_gather_y)
+            every = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(every, mine.cpu())
+        else:
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+        tab = torch.stack([e.cpu() for e in every]).numpy()          # [rank][slice]
         gathered_mismatch = int(sum(int(tab[r][p] != tab[p][p]) for r in range(world) for p in range(world)))
         if gathered_mismatch and rank == 0:
             print("[bench] gathered y differs between ranks: (rank, slice) pairs off: "
                   + ", ".join(f"({r},{p})" for r in range(world) for p in range(world) if tab[r][p] != tab[p][p]), file=sys.stderr)
     if args.dump_y and rank == 0:
+        torch.cuda.synchronize()
         ydump = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()
         np.save(args.dump_y, ydump)
+        if os.environ.get("CVR_BENCH_DEBUG_DUMP") and sharded:          # (diagnostics: the padded gathered buffer, the index array and the bounds as they are)
+            np.save(args.dump_y + ".raw.npy", yalls[last[0]].cpu().numpy())
+            np.save(args.dump_y + ".pick.npy", np.asarray(pick))
+            np.save(args.dump_y + ".bounds.npy", np.asarray(bounds))
     copy_gbs = None
     if rank == 0:
         try:                      # achievable-HBM yardstick measured live: 1 GiB streaming copy, read + write

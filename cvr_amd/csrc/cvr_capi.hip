@@ -530,12 +530,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     // on one GPU: 59 panels 6.4 ms, 16 panels 5.4 ms; R-MAT-24: 8 and 4 panels alike; profiles/r02_hub_table_rmat.log)
     if (P > 1 && dev_split && panels_auto && opt.hub_table < 0 && opt.waves_per_block == 0 && opt.x_window <= 0 && !cvr::debug_env("no_auto_layout")) {      // (the predicate of choose_hubs: only panels that will get tables are widened)
         const int64_t room = ((int64_t)cvr::kLdsBytes / (int64_t)vsz - 8 * (cvr::kLanes + 512) - cvr::kDictMax - 8) & ~(int64_t)1023;
-        cvr::HubSelection sel;
+        double            share = 0;
         const double      th0 = now_s();
-        const hipError_t  e = cvr::select_hubs(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &sel, h->stream);
+        const hipError_t  e = cvr::hub_share_device(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &share, h->stream);      // (the share alone: no ranking of the columns)
         in.hub_select_s += now_s() - th0;
-        const double share = sel.share;
-        cvr::free_hubs(sel);
         if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
         if (share >= 0.25) {       // (of the whole matrix: the panels' own tables, ranked inside their ranges, hold more)
             const int Pw = std::max(2, (int)std::ceil((double)ncols * (double)vsz / 16e6));

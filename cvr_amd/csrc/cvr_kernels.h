@@ -69,6 +69,8 @@ inline int64_t hub_sample_stride(int64_t nnz) { return nnz > (int64_t)(1 << 23) 
 // the (at most hmax) columns with the most non-zeros among col_idx[n0, n1), at least 2 each; share = their part of the non-zeros; synchronises st
 hipError_t select_hubs(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, HubSelection *out, hipStream_t st, bool full_order = false);
 void       free_hubs(HubSelection &s);
+// select_hubs' share alone (no ranking, no tables): synchronises st
+hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, double *share, hipStream_t st);
 hipError_t launch_hub_gather(const DeviceImage &img, const void *x_ext, hipStream_t st);     // hub_x = x[hub_cols]
 
 struct DeviceCsr {
