@@ -579,10 +579,30 @@ def main():
     bits = torch.int32 if f32 else torch.int64
     x = torch.zeros(info.x_elems, dtype=tdt, device=dev)
     x[:ncols] = torch.from_numpy(synth.x_rand(ncols, np_dtype)).to(dev)
+    xcheck = lambda tag: None
+    if os.environ.get("CVR_BENCH_DEBUG_DUMP"):          # (diagnostics: is x still what was uploaded?)
+        x_host_dbg = synth.x_rand(ncols, np_dtype)
+        def xcheck(tag):
+            if tag in os.environ.get("CVR_BENCH_DEBUG_SKIP", ""):
+                return
+            torch.cuda.synchronize()
+            got = x[:ncols].cpu().numpy()
+            d_ = np.flatnonzero(got != x_host_dbg)
+            if len(d_):
+                print(f"[bench rank {rank}] x differs at \"{tag}\": {len(d_)} of {ncols} elements, first {d_[0]} last {d_[-1]}, got {got[d_[:4]].tolist()} want {x_host_dbg[d_[:4]].tolist()}, "
+                      f"zeros among them {int((got[d_] == 0).sum())}, x ptr {x.data_ptr():#x}", file=sys.stderr, flush=True)
+            else:
+                print(f"[bench rank {rank}] x ok at \"{tag}\"", file=sys.stderr, flush=True)
+    xcheck("uploaded")
     ny = max(info.yext_elems, max_rows)
     ybufs = [torch.zeros(ny, dtype=tdt, device=dev) for _ in range(2 if sharded else 1)]
     yalls = [torch.zeros(world * max_rows, dtype=tdt, device=dev) for _ in range(2)] if sharded else None
     y = ybufs[0]
+    # Everything above (the upload of x, the zero fills) was enqueued on the device's default stream, and the stream below does not wait for
+    # that stream: drain it before the first launch.  (Round 5, eight processes on one device: the first SpMV of the slowest rank ran on the
+    # new stream BEFORE the default stream had copied x out of its staging tensor, whose memory had by then become a y buffer -- x came
+    # out as that buffer's zeros from then on, and the run's own check, made with the same x, passed: profiles/r05_eight_ranks_debug.log.)
+    torch.cuda.synchronize()
     stream = torch.cuda.Stream(device=dev)     # kernels, events and the collective all go on this stream
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
@@ -633,6 +653,7 @@ def main():
                 comm.close()
                 comm = None
 
+    xcheck("buffers, stream")
     overlap = [False]
 
     def step(n=1):
@@ -670,6 +691,7 @@ def main():
 
     step(args.warmup)
     sync()
+    xcheck("warmup")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record(stream)
@@ -694,6 +716,7 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) * 1e-3 / n_t
     kern_s = kernel_time(A, y)
+    xcheck("kernel_time")
     gather_s = None
     if sharded:                         # the exchange step alone, same message, same stream (reported beside the total)
         e4, e5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -758,6 +781,9 @@ def main():
     # spmv.cpp:1843-1850, 1916-1938): the product's host loop for host-built workloads, a torch fp64 loop on the rank's own
     # shard for device-built ones
     wrong = wrong_ref = -1
+    x_damaged = int(torch.count_nonzero(x[:ncols] != torch.from_numpy(synth.x_rand(ncols, np_dtype)).to(dev)).item())     # (the device reference below is made from this x)
+    if x_damaged:
+        print(f"[bench rank {rank}] x on the device differs from what was uploaded in {x_damaged} elements", file=sys.stderr)
     if device_built:
         from cvr_amd import synth_dev as D
         yref_t, absy_t = D.csr_spmv_reference(lrp_t, lci_t, lva_t, x[:ncols])
@@ -777,15 +803,16 @@ def main():
             for p in range(world):
                 np_ = int(bounds[p + 1] - bounds[p])
                 bad += torch.count_nonzero((yg[p, :np_] - allref[p, 0, :np_]).abs() > tol_t * allref[p, 1, :np_] + 1e-300)
+            bad += x_damaged                                       # (a rank whose x is not the uploaded one fails the run whatever its y)
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)          # (the worst rank's count of wrong rows over the whole vector)
         else:
             yl = y[:lrows].to(torch.float64)
-            bad = torch.count_nonzero((yl - yref_t).abs() > tol_t * absy_t + 1e-300).to(torch.int64).reshape(1)
+            bad = torch.count_nonzero((yl - yref_t).abs() > tol_t * absy_t + 1e-300).to(torch.int64).reshape(1) + x_damaged
         wrong = int(bad.item())
     else:
         yh = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()
         if rank == 0:
-            xh = x[:ncols].cpu().numpy().astype(np.float64)
+            xh = synth.x_rand(ncols, np_dtype).astype(np.float64)          # (what was uploaded, not what the device holds now)
             nt = len(os.sched_getaffinity(0))
             yref = cvr_amd.csr_spmv_host(rp, ci, va.astype(np.float64), xh, nthreads=nt)
             # rows off by more than tol * sum |a x| (1e-12 fp64, 1e-5 for the fp32 path, which has no reference
@@ -806,17 +833,22 @@ def main():
     if sharded:
         sizes = [int(bounds[p + 1] - bounds[p]) for p in range(world)]
         mine = torch.stack([yalls[last[0]][p * max_rows: p * max_rows + sizes[p]].view(bits).to(torch.int64).sum() for p in range(world)])
-        if backend == "gloo":          # (device tensors over gloo go through host tensors: cvr_amd/shard.py, all_gather_y)
-            every = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(every, mine.cpu())
-        else:
-            every = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(every, mine)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
         tab = torch.stack([e.cpu() for e in every]).numpy()          # [rank][slice]
         gathered_mismatch = int(sum(int(tab[r][p] != tab[p][p]) for r in range(world) for p in range(world)))
         if gathered_mismatch and rank == 0:
             print("[bench] gathered y differs between ranks: (rank, slice) pairs off: "
                   + ", ".join(f"({r},{p})" for r in range(world) for p in range(world) if tab[r][p] != tab[p][p]), file=sys.stderr)
+    xcheck("verified")
+    if args.dump_y and os.environ.get("CVR_BENCH_DEBUG_DUMP") and sharded and device_built:
+        # (diagnostics, every rank: its shard's arrays hashed, its own y buffers, its reference, its copy of the gathered vector)
+        import hashlib
+        torch.cuda.synchronize()
+        hs = [hashlib.sha1(t.cpu().numpy().tobytes()).hexdigest() for t in (lrp_t, lci_t, lva_t)]
+        np.savez(args.dump_y + f".rank{rank}.npz", hashes=np.asarray(hs), y0=ybufs[0][:lrows].cpu().numpy(), y1=ybufs[1][:lrows].cpu().numpy(),
+                 yref=yref_t.cpu().numpy(), absy=absy_t.cpu().numpy(), yall0=yalls[0].cpu().numpy(), yall1=yalls[1].cpu().numpy(), last=np.asarray([last[0]]),
+                 x=x[:ncols].cpu().numpy())
     if args.dump_y and rank == 0:
         torch.cuda.synchronize()
         ydump = (yalls[last[0]][torch.from_numpy(pick).to(dev)] if sharded else y[:nrows]).cpu().numpy()

@@ -595,7 +595,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             split_panels(*csr, P, sp);
             for (int p = 0; p < P; p++) nsubs[(size_t)p] = (int64_t)sp.rows[(size_t)p].size();
         }
-        in.plan_s += now_s() - t0 - in.hub_select_s;      // (the hub count that sizes the panels is reported on its own)
+        in.plan_s += now_s() - t0;      // (the split; the hub count that sizes the panels ran before t0 and is reported on its own)
         clk.lap("panel split");
         std::vector<PartPlan> pps((size_t)P);
         IOpt                  panel_opt = opt;

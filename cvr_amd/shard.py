@@ -30,18 +30,9 @@ def gather_layout(bounds):
 
 
 def all_gather_tensor(out, src):
-    """dist.all_gather_into_tensor(out, src); device tensors over gloo are staged through host tensors with blocking copies (all_gather_y)"""
-    import torch
+    """dist.all_gather_into_tensor(out, src) (bench.py: the owners' references travel like y)"""
     import torch.distributed as dist
-    if src.is_cuda and dist.get_backend() == "gloo":
-        torch.cuda.current_stream(src.device).synchronize()
-        h = src.cpu()
-        dst = torch.empty(out.numel(), dtype=h.dtype)
-        dist.all_gather_into_tensor(dst, h.reshape(-1))
-        out.reshape(-1).copy_(dst)
-        torch.cuda.current_stream(src.device).synchronize()
-    else:
-        dist.all_gather_into_tensor(out, src)
+    dist.all_gather_into_tensor(out, src)
     return out
 
 
@@ -54,18 +45,6 @@ def all_gather_y(y_local, max_rows, out=None):
     world = dist.get_world_size()
     if out is None:
         out = torch.empty(world * max_rows, dtype=y_local.dtype, device=y_local.device)
-    if y_local.is_cuda and dist.get_backend() == "gloo":
-        # Device tensors over gloo (the one-device emulation of the N > 1 path: CVR_BENCH_ONE_DEVICE, RCCL refuses two ranks on a GPU):
-        # staged through host tensors HERE, with blocking copies.  gloo's own staging of device tensors left parts of the gathered
-        # vector unwritten on this stack (round 5: eight processes on one MI355X, the largest rank's slice mostly zeros on the other
-        # ranks a moment after it had compared equal: profiles/r05_eight_ranks_debug.log); host tensors are what gloo is made for.
-        torch.cuda.current_stream(y_local.device).synchronize()
-        src = y_local[:max_rows].cpu()
-        dst = torch.empty(world * max_rows, dtype=src.dtype)
-        dist.all_gather_into_tensor(dst, src)
-        out.copy_(dst)
-        torch.cuda.current_stream(y_local.device).synchronize()
-        return out
     dist.all_gather_into_tensor(out, y_local[:max_rows])
     return out
 
@@ -76,11 +55,6 @@ def pipelined_steps(spmv, y_bufs, yall_bufs, max_rows, steps):
     step k + 1 and is waited for before its buffers are reused (step k + 2).  Every step's y is fully gathered on
     every rank when this returns.  spmv(y_buf) must enqueue the local SpMV into y_buf on the current stream."""
     import torch.distributed as dist
-    if y_bufs[0].is_cuda and dist.get_backend() == "gloo":          # (device tensors over gloo: in order, staged through the host -- all_gather_y)
-        for k in range(steps):
-            spmv(y_bufs[k & 1])
-            all_gather_y(y_bufs[k & 1], max_rows, out=yall_bufs[k & 1])
-        return (steps - 1) & 1 if steps > 0 else 0
     pending = [None, None]
     for k in range(steps):
         b = k & 1

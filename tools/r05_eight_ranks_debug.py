@@ -35,3 +35,17 @@ import cvr_amd
 A = cvr_amd.CvrMatrix(n, n, rp, ci, va)
 y1, _ = A.spmv(x)
 print("one handle vs oracle wrong:", int((np.abs(y1.astype(np.float64) - yref) > 1e-5 * absy + 1e-300).sum()), "; dump vs one handle wrong:", int((np.abs(y.astype(np.float64) - y1.astype(np.float64)) > 2e-5 * absy + 1e-300).sum()))
+# every rank's own view (CVR_BENCH_DEBUG_DUMP): shard arrays, own y, own reference, own copy of the gathered vector
+import hashlib
+print("x as the test builds it == rank 0's x:", bool(np.array_equal(x, np.load("/tmp/y8.npy.rank0.npz")["x"])))
+for p in range(8):
+    z = np.load(f"/tmp/y8.npy.rank{p}.npz")
+    lo, hi = int(b[p]), int(b[p + 1]); e0, e1 = int(rp[lo]), int(rp[hi])
+    want = [hashlib.sha1(a.tobytes()).hexdigest() for a in ((rp[lo:hi + 1] - rp[lo]).astype(rp.dtype), ci[e0:e1], va[e0:e1])]
+    L = int(z["last"][0])
+    def nbad(v, ref=yref[lo:hi], ab=absy[lo:hi]):
+        return int((np.abs(v.astype(np.float64) - ref) > 1e-5 * ab + 1e-300).sum())
+    own = [z["yall0"], z["yall1"]][L]
+    per = [nbad(own[q * mr: q * mr + int(b[q + 1] - b[q])], yref[int(b[q]):int(b[q + 1])], absy[int(b[q]):int(b[q + 1])]) for q in range(8)]
+    print(f"rank {p}: shard arrays equal the slice {[a == w for a, w in zip(z['hashes'].tolist(), want)]}; own y0 wrong {nbad(z['y0'])}, own y1 wrong {nbad(z['y1'])}; "
+          f"own reference vs oracle wrong {nbad(z['yref'])}; x equal {bool(np.array_equal(z['x'], x))}; last {L}; its gathered copy, wrong rows per slice {per}")
