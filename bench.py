@@ -286,8 +286,21 @@ def _cpu_reference(nrows, ncols, rp, ci, logical, physical):
     exe = os.path.join(ROOT, "oracle", "_ref", "spmv.cvr.ref")
     if not os.path.exists(exe):
         return None
-    iters = 300
+    iters = 1000         # (a second of SpMVs per run: round 5's first pinned runs of 300 iterations differed by a factor of three on a host shared with other jobs)
     repeats = 5
+    def _host_state():          # what else runs on the host while the baseline is timed (the GPU boxes of this pool are containers on a shared host)
+        st = {}
+        try:
+            st["loadavg"] = open("/proc/loadavg").read().split()[:3]
+        except OSError:
+            pass
+        for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu.stat"):
+            try:
+                st[os.path.basename(f)] = " ".join(open(f).read().split())
+            except OSError:
+                pass
+        return st
+    host_before = _host_state()
     runs = []
     topo = _cpu_topology()
     configs = []          # (label, threads, cpus or None)
@@ -335,7 +348,8 @@ def _cpu_reference(nrows, ncols, rp, ci, logical, physical):
                       f"{repeats} runs per configuration ({'; '.join(c[0] for c in configs)}), memory: {placement}; "
                       "`value` is the median run of the configuration whose median is better",
             "ms_per_step": best["ms_per_step"], "preprocess_s": best["preprocess_s"], "gbs_alg": best["gbs_alg"], "spread": pick["spread_max_minus_min_over_median"],
-            "reference_convention_gflops": best["reference_convention_gflops"], "per_thread_count": stats, "memory_placement": placement, "runs": runs}
+            "reference_convention_gflops": best["reference_convention_gflops"], "per_thread_count": stats, "memory_placement": placement, "runs": runs,
+            "host_state": {"before": host_before, "after": _host_state(), "logical_cpus_visible": len(os.sched_getaffinity(0))}}
 
 
 def _cpu_port(nrows, ncols, rp, ci, va, cores, budget_s=8.0, probe=(8, 16, 32, 64, 128)):

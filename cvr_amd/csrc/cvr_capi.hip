@@ -514,7 +514,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (!(xbytes >= 24e6 || mid_range) || sj1 <= sj0) P = 1;
         else if (dev_split) {
             double miss = 0;
-            CREATE_TRY(l2_miss_estimate_dev(rp_d, ci_d, nrows, ncols, f32, h->stream, &miss));
+            CREATE_TRY(l2_miss_estimate_dev(rp_d, ci_d, nrows, ncols, f32, h->stream, &miss, cvr::Scratch{h->plan_ws.dev, h->plan_ws.dev_bytes}));      // (the planner's scratch is idle until the split is done)
             P = panels_from_miss(xbytes, miss);
             rule_miss = miss;
         } else P = auto_panels(*csr, nullptr);          // (the host rule asks both questions itself)
@@ -532,7 +532,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         const int64_t room = ((int64_t)cvr::kLdsBytes / (int64_t)vsz - 8 * (cvr::kLanes + 512) - cvr::kDictMax - 8) & ~(int64_t)1023;
         double            share = 0;
         const double      th0 = now_s();
-        const hipError_t  e = cvr::hub_share_device(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &share, h->stream);      // (the share alone: no ranking of the columns)
+        const hipError_t  e = cvr::hub_share_device(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &share, h->stream, cvr::Scratch{h->plan_ws.dev, h->plan_ws.dev_bytes});      // (the share alone: no ranking of the columns)
         in.hub_select_s += now_s() - th0;
         if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
         if (share >= 0.25) {       // (of the whole matrix: the panels' own tables, ranked inside their ranges, hold more)
@@ -549,7 +549,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     if (P > 1 && panels_auto && dev_split && rule_miss >= 0 && !cvr::debug_env("no_pairs_rule")) {
         double ppn = 0;
         const double tq = now_s();
-        CREATE_TRY(pairs_per_nnz_dev(rp_d, ci_d, nrows, (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1, h->stream, &ppn));
+        CREATE_TRY(pairs_per_nnz_dev(rp_d, ci_d, nrows, (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1, h->stream, &ppn, cvr::Scratch{h->plan_ws.dev, h->plan_ws.dev_bytes}));
         if (!panels_pay(rule_miss, ppn)) {
             if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] %d column panels dropped: L2 miss share %.3f against %.3f (row, panel) pairs per non-zero\n", P, rule_miss, ppn);
             P = 1;
@@ -587,7 +587,23 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         std::vector<int64_t> nsubs((size_t)P, 0);
         if (dev_split) {        // nothing but a few counts comes to the host: the sub-rows are planned where they are (cvr_plan_dev.hip)
             const int64_t  width = (ncols + P - 1) / P > 0 ? (ncols + P - 1) / P : 1;
+            // the distinct values are looked for in the unsplit array on a second stream, beside the split (round 5: 0.3 ms of the soc-LiveJournal1
+            // shape's preprocessing stood behind the combine tables as a pass of its own over the sixteen panels)
+            hipStream_t dict_stream = nullptr;
+            if (opt.value_dict != 0 && sj1 > sj0 && !h->preconverted && !h->dict_scanned && h->small_clean && !cvr::debug_env("no_early_dict")) {
+                dict_stream = side_stream(h->device, 0);
+                if (dict_stream == h->stream) dict_stream = nullptr;
+                if (dict_stream) {
+                    h->dict_tab.assign(1024, ~0ull);
+                    if (enqueue_dict_scan(h, va_d, sj0, sj1, f32, true, h->dict_tab.data(), h->dict_flags, true, dict_stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(dict_stream); dict_stream = nullptr; }
+                }
+            }
             const hipError_t e = cvr::split_panels_device(rp_d, ci_d, va_d, f32, nrows, sj0, sj1, width, P, &dsg.d, h->stream);
+            if (dict_stream) {       // (before the staging copy goes)
+                const hipError_t ed = hipStreamSynchronize(dict_stream);
+                h->small_clean = false;
+                if (ed == hipSuccess) h->dict_scanned = true; else (void)hipGetLastError();      // (the pass over the panels below runs instead)
+            }
             if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "column-panel split on the device: %s", hipGetErrorString(e)); }
             staged.release();       // the split arrays replace the staging copy
             for (int p = 0; p < P; p++) nsubs[(size_t)p] = dsg.d.sub0[p + 1] - dsg.d.sub0[p];

@@ -148,13 +148,15 @@ __global__ __launch_bounds__(256) void hub_share_kernel(const uint32_t *__restri
 // the columns' counts, then a histogram of the count VALUES, walked from the top until hmax columns are in.  cvr_create asks this of a
 // matrix that is about to get column panels (are its popular columns worth hub tables?): the sort of all column counts it replaces was
 // ~0.6 of the 1.0 ms of that question on the soc-LiveJournal1 shape.
-hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, double *share, hipStream_t st)
+hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, double *share, hipStream_t st, Scratch lent)
 {
     *share = 0;
     if (n1 <= n0 || ncols <= 0 || hmax == 0) return hipSuccess;
     void *arena = nullptr;
     const size_t nc = (size_t)ncols, o_hist = (4 * nc + 255) & ~(size_t)255, hist_bytes = sizeof(unsigned long long) * (kShareBins + 2);
-    hipError_t e = hipMalloc(&arena, o_hist + hist_bytes);
+    const bool   own = !(lent.p && lent.bytes >= o_hist + hist_bytes);          // (lent by cvr_create: the planner's scratch, idle until the split is done)
+    hipError_t e = hipSuccess;
+    if (own) e = hipMalloc(&arena, o_hist + hist_bytes); else arena = lent.p;
     if (e != hipSuccess) return e;
     uint32_t           *cnt = static_cast<uint32_t *>(arena);
     unsigned long long *hist = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(arena) + o_hist);
@@ -168,7 +170,7 @@ hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t n
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), hist, hist_bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(arena);
+    if (own) (void)hipFree(arena);
     if (e != hipSuccess) return e;
     unsigned long long left = hmax, sum = 0;
     { const unsigned long long take = std::min(left, h[kShareBins]); sum += h[kShareBins] ? h[kShareBins + 1] * take / h[kShareBins] : 0; left -= take; }      // (more such columns than hmax cannot happen with a sample of 2^23)

@@ -20,6 +20,8 @@
 #include <rocprim/block/block_radix_sort.hpp>
 
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 #include <type_traits>
 
 namespace cvr {
@@ -62,9 +64,10 @@ template <int NT, int IPT, int RB> struct ChunkSort { typedef rocprim::block_rad
 
 template <int NT, int IPT, int RB>
 __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restrict__ t, const void *__restrict__ dict_v, uint32_t ndict, int G, uint32_t col_bits, uint32_t cbits,
-                                                                  uint32_t flags, uint32_t *__restrict__ err)
+                                                                  uint32_t flags, uint32_t *__restrict__ err, unsigned long long *__restrict__ clk)
 {
     typedef typename ChunkSort<NT, IPT, RB>::type Sort;
+    if (clk && threadIdx.x == 0) clk[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();          // (CVR_DEBUG=ilv_clocks: the stages of a chunk on the 100-MHz counter)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *const   rstart = reinterpret_cast<uint32_t *>(smem);       // [nri]; the sort's storage takes its place afterwards
     const bool        f32 = flags & kIlvF32, use_dict = flags & kIlvDict, tag = flags & kIlvTag;
@@ -98,7 +101,9 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
         } else { key[i] = q.pad_col; val[i] = 0xffffffffu; }
     }
     __syncthreads();
+    if (clk && threadIdx.x == 0) clk[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     Sort().sort_to_striped(key, val, *reinterpret_cast<typename Sort::storage_type *>(smem), 0u, cbits);
+    if (clk && threadIdx.x == 0) clk[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 
     // the dictionary (sorted by bit pattern, at most 256 entries) goes to LDS in the sort's place: a search per element is eight LDS reads
     uint64_t *const dl = reinterpret_cast<uint64_t *>(smem);
@@ -151,6 +156,7 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
             }
         }
     }
+    if (clk && threadIdx.x == 0) clk[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -168,8 +174,25 @@ hipError_t launch_chunks(const IlvTable *d_tab, uint32_t nchunks_tot, const Devi
         attr = true;
     }
     if (lds > kLdsBytes) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((ilv_chunk_kernel<NT, IPT, RB>), dim3(nchunks_tot), dim3(NT), lds, st, d_tab, c.dict, c.ndict, c.G, c.col_bits, cbits, flags, err_flag);
-    return hipGetLastError();
+    unsigned long long *clk = nullptr;
+    if (cvr::debug_env("ilv_clocks") && hipMalloc(&clk, sizeof(unsigned long long) * 4 * (size_t)nchunks_tot) != hipSuccess) { (void)hipGetLastError(); clk = nullptr; }
+    hipLaunchKernelGGL((ilv_chunk_kernel<NT, IPT, RB>), dim3(nchunks_tot), dim3(NT), lds, st, d_tab, c.dict, c.ndict, c.G, c.col_bits, cbits, flags, err_flag, clk);
+    hipError_t le = hipGetLastError();
+    if (clk) {          // diagnostics: mean time per stage over the chunks, and the launch from its first stamp to its last
+        std::vector<unsigned long long> hc(4 * (size_t)nchunks_tot);
+        if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hc.data(), clk, sizeof(unsigned long long) * hc.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            double d[3] = {0, 0, 0};
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (uint32_t k = 0; k < nchunks_tot; k++) {
+                for (int i = 0; i < 3; i++) d[i] += (double)(hc[4 * k + i + 1] - hc[4 * k + i]);
+                t0 = std::min(t0, hc[4 * k]); t1 = std::max(t1, hc[4 * k + 3]);
+            }
+            fprintf(stderr, "[ilv_clocks] %u chunks x %d threads x %d pairs, LDS %zu: load + rows %.1f us, sort %.1f us, dictionary + write %.1f us per chunk; launch %.1f us\n", nchunks_tot, NT, IPT, lds,
+                    d[0] / nchunks_tot / 100.0, d[1] / nchunks_tot / 100.0, d[2] / nchunks_tot / 100.0, (double)(t1 - t0) / 100.0);
+        }
+        (void)hipFree(clk);
+    }
+    return le;
 }
 }  // namespace
 

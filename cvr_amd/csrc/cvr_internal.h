@@ -277,10 +277,10 @@ struct PanelSplit {
 
 void       split_panels(const cvr_csr_view &v, int P, PanelSplit &out);
 double     l2_miss_estimate(const cvr_csr_view &v);
-hipError_t l2_miss_estimate_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t ncols, bool f32, hipStream_t st, double *miss);
+hipError_t l2_miss_estimate_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t ncols, bool f32, hipStream_t st, double *miss, cvr::Scratch lent = cvr::Scratch());
 int        panels_from_miss(double xb, double miss);
 double     pairs_per_nnz(const cvr_csr_view &v, int64_t width);
-hipError_t pairs_per_nnz_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t width, hipStream_t st, double *out);
+hipError_t pairs_per_nnz_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t width, hipStream_t st, double *out, cvr::Scratch lent = cvr::Scratch());
 bool       panels_pay(double miss, double pairs_per_nonzero);
 int        auto_panels(const cvr_csr_view &v, double *miss_out);
 int        xcd_panel_count(int P, double xbytes);

@@ -70,7 +70,10 @@ inline int64_t hub_sample_stride(int64_t nnz) { return nnz > (int64_t)(1 << 23) 
 hipError_t select_hubs(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, HubSelection *out, hipStream_t st, bool full_order = false);
 void       free_hubs(HubSelection &s);
 // select_hubs' share alone (no ranking, no tables): synchronises st
-hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, double *share, hipStream_t st);
+// Scratch: device memory the caller lends for the duration of the call (round 5: the analysis passes of cvr_create allocated and freed their own -- a
+// hipMalloc + hipFree pair costs more than the kernels between them); too small or null: the pass allocates.
+struct Scratch { void *p = nullptr; size_t bytes = 0; };
+hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, double *share, hipStream_t st, Scratch lent = Scratch());
 hipError_t launch_hub_gather(const DeviceImage &img, const void *x_ext, hipStream_t st);     // hub_x = x[hub_cols]
 
 struct DeviceCsr {
@@ -130,10 +133,12 @@ hipError_t split_panels_device(const int64_t *rp_dev, const int32_t *ci_dev, con
                                int64_t nz1, int64_t width, int P, DeviceSplit *out, hipStream_t st);
 void       free_device_split(DeviceSplit &s);
 // the panel rule's second question (cvr_split.hip): (row, panel) pairs of the same windows for panels of `width` columns
-hipError_t panel_pairs_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t width, double *pairs, hipStream_t st);
+// (refs[w] = the window's non-zeros)
+hipError_t panel_pairs_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t width, double *pairs, double *refs, hipStream_t st,
+                              Scratch lent = Scratch());
 // the panel rule's L2 model for a device-resident CSR (cvr_split.hip): per window of W rows, gathers and hits among the `resident` most used lines
 hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t ncols, bool f32, size_t resident,
-                          double *refs, double *hits, hipStream_t st);
+                          double *refs, double *hits, hipStream_t st, Scratch lent = Scratch());
 
 // ---- the chunk planner on the device (cvr_plan_dev.hip): the plan of plan_chunks from a device-resident row_ptr ----
 struct Plan;

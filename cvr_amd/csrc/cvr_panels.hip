@@ -138,7 +138,7 @@ double l2_miss_estimate(const cvr_csr_view &v)
 }
 
 // the same estimate from a CSR in device memory (cvr_split.hip: l2_hits_device): same windows, same integers
-hipError_t l2_miss_estimate_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t ncols, bool f32, hipStream_t st, double *miss)
+hipError_t l2_miss_estimate_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t ncols, bool f32, hipStream_t st, double *miss, cvr::Scratch lent)
 {
     *miss = 0.0;
     const int64_t W = std::min<int64_t>(65536, nrows);
@@ -147,7 +147,7 @@ hipError_t l2_miss_estimate_dev(const int64_t *rp_dev, const int32_t *ci_dev, in
     int64_t   r0[8];
     double    refs[8], hits[8];
     for (int w = 0; w < nwin; w++) r0[w] = nwin == 1 ? 0 : (nrows - W) * w / (nwin - 1);
-    const hipError_t e = cvr::l2_hits_device(rp_dev, ci_dev, r0, nwin, W, ncols, f32, (size_t)(4u << 20) / 128, refs, hits, st);
+    const hipError_t e = cvr::l2_hits_device(rp_dev, ci_dev, r0, nwin, W, ncols, f32, (size_t)(4u << 20) / 128, refs, hits, st, lent);
     if (e != hipSuccess) return e;
     double refs_all = 0, miss_all = 0;
     for (int w = 0; w < nwin; w++) { refs_all += refs[w]; miss_all += refs[w] - hits[w]; }
@@ -181,25 +181,19 @@ double pairs_per_nnz(const cvr_csr_view &v, int64_t width)
     return refs > 0 ? pairs / refs : 0.0;
 }
 
-hipError_t pairs_per_nnz_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t width, hipStream_t st, double *out)
+hipError_t pairs_per_nnz_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t width, hipStream_t st, double *out, cvr::Scratch lent)
 {
     *out = 0.0;
     const int64_t W = std::min<int64_t>(65536, nrows);
     if (W <= 0 || width < 1) return hipSuccess;
     const int nwin = nrows == W ? 1 : 8;
-    int64_t   r0[8], edge[16];
-    double    pairs[8];
+    int64_t   r0[8];
+    double    pairs[8], refs_w[8];
     for (int w = 0; w < nwin; w++) r0[w] = nwin == 1 ? 0 : (nrows - W) * w / (nwin - 1);
-    hipError_t e = cvr::panel_pairs_device(rp_dev, ci_dev, r0, nwin, W, width, pairs, st);
+    hipError_t e = cvr::panel_pairs_device(rp_dev, ci_dev, r0, nwin, W, width, pairs, refs_w, st, lent);      // (the windows' non-zeros come back with the counts)
     if (e != hipSuccess) return e;
     double refs = 0, all = 0;
-    for (int w = 0; w < nwin; w++) {          // (the windows' non-zeros: two row pointers each)
-        e = hipMemcpy(&edge[2 * w], rp_dev + r0[w], sizeof(int64_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(&edge[2 * w + 1], rp_dev + r0[w] + W, sizeof(int64_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return e;
-        refs += (double)(edge[2 * w + 1] - edge[2 * w]);
-        all += pairs[w];
-    }
+    for (int w = 0; w < nwin; w++) { refs += refs_w[w]; all += pairs[w]; }
     *out = refs > 0 ? all / refs : 0.0;
     return hipSuccess;
 }

@@ -283,9 +283,18 @@ __global__ __launch_bounds__(256) void est_hist_kernel(const uint32_t *__restric
 
 uint32_t grid_for(long long n) { return (uint32_t)std::min<long long>(4096, std::max<long long>(1, (n + 255) / 256)); }
 
-struct Tmp {            // frees whatever was allocated, on every path
+struct Tmp {            // frees whatever was allocated, on every path; memory the caller lent is carved first (cvr_kernels.h: Scratch)
     std::vector<void *> p;
-    template <typename U> hipError_t alloc(U **q, size_t bytes) { hipError_t e = hipMalloc(q, std::max<size_t>(bytes, 16)); if (e == hipSuccess) p.push_back(*q); return e; }
+    Scratch             lent;
+    size_t              used = 0;
+    template <typename U> hipError_t alloc(U **q, size_t bytes)
+    {
+        const size_t b = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+        if (lent.p && used + b <= lent.bytes) { *q = reinterpret_cast<U *>(static_cast<uint8_t *>(lent.p) + used); used += b; return hipSuccess; }
+        hipError_t e = hipMalloc(q, b);
+        if (e == hipSuccess) p.push_back(*q);
+        return e;
+    }
     ~Tmp() { for (void *q : p) (void)hipFree(q); }
 };
 
@@ -295,12 +304,13 @@ struct Tmp {            // frees whatever was allocated, on every path
 // 128-byte line of x among the `resident` most used lines of the window, first touches excluded -- the same integers the host
 // estimator computes (sum of the top counts minus one each), through a histogram of the line counts instead of a selection.
 hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t ncols, bool f32, size_t resident,
-                          double *refs, double *hits, hipStream_t st)
+                          double *refs, double *hits, hipStream_t st, Scratch lent)
 {
     if (nwin < 1 || nwin > 64) return hipErrorInvalidValue;
     const uint32_t  per_line = f32 ? 32 : 16;
     const long long nlines = ncols / per_line + 1;
     Tmp             tmp;
+    tmp.lent = lent;
     uint32_t           *cnt = nullptr, *hist = nullptr;
     unsigned long long *small = nullptr;     // [nwin] refs, [2 nwin] big, then the windows' first rows
     hipError_t e = tmp.alloc(&cnt, sizeof(uint32_t) * (size_t)nwin * (size_t)nlines);
@@ -343,10 +353,11 @@ hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const in
 // for rows whose columns ascend (an unsorted row counts more pairs than it has: the estimate then errs against panels).  A pair begins
 // where the panel changes between neighbouring non-zeros, or where a row begins inside a run of one panel.
 __global__ __launch_bounds__(256) void est_pairs_kernel(const long long *__restrict__ rp, const int32_t *__restrict__ ci, const long long *__restrict__ r0, long long W,
-                                                        uint32_t width, unsigned long long *__restrict__ pairs)
+                                                        uint32_t width, unsigned long long *__restrict__ pairs, unsigned long long *__restrict__ refs)
 {
     const uint32_t  w = blockIdx.y;
     const long long ra = r0[w], j0 = rp[ra], j1 = rp[ra + W];
+    if (blockIdx.x == 0 && threadIdx.x == 0) refs[w] = (unsigned long long)(j1 - j0);
     unsigned long long n = 0;
     for (long long j = j0 + 1 + (long long)blockIdx.x * 256 + threadIdx.x; j < j1; j += (long long)gridDim.x * 256) n += (uint32_t)ci[j] / width != (uint32_t)ci[j - 1] / width;
     for (long long r = ra + (long long)blockIdx.x * 256 + threadIdx.x; r < ra + W; r += (long long)gridDim.x * 256) {
@@ -358,24 +369,26 @@ __global__ __launch_bounds__(256) void est_pairs_kernel(const long long *__restr
     if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&pairs[w], n);
 }
 
-hipError_t panel_pairs_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t width, double *pairs, hipStream_t st)
+hipError_t panel_pairs_device(const int64_t *rp_dev, const int32_t *ci_dev, const int64_t *r0_host, int nwin, int64_t W, int64_t width, double *pairs, double *refs, hipStream_t st,
+                              Scratch lent)
 {
     if (nwin < 1 || nwin > 64 || width < 1) return hipErrorInvalidValue;
     Tmp                 tmp;
-    unsigned long long *small = nullptr;     // [nwin] pairs, then the windows' first rows
-    hipError_t e = tmp.alloc(&small, sizeof(unsigned long long) * 2 * (size_t)nwin);
+    tmp.lent = lent;
+    unsigned long long *small = nullptr;     // [nwin] pairs, [nwin] non-zeros, then the windows' first rows
+    hipError_t e = tmp.alloc(&small, sizeof(unsigned long long) * 3 * (size_t)nwin);
     if (e != hipSuccess) return e;
-    long long *d_r0 = reinterpret_cast<long long *>(small + nwin);
-    e = hipMemsetAsync(small, 0, sizeof(unsigned long long) * (size_t)nwin, st);
+    long long *d_r0 = reinterpret_cast<long long *>(small + 2 * nwin);
+    e = hipMemsetAsync(small, 0, sizeof(unsigned long long) * 2 * (size_t)nwin, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_r0, r0_host, sizeof(long long) * (size_t)nwin, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(est_pairs_kernel, dim3(256, (uint32_t)nwin), dim3(256), 0, st, reinterpret_cast<const long long *>(rp_dev), ci_dev, d_r0, (long long)W,
-                       (uint32_t)std::min<int64_t>(width, 0x7fffffff), small);
-    std::vector<unsigned long long> sm((size_t)nwin);
+                       (uint32_t)std::min<int64_t>(width, 0x7fffffff), small, small + nwin);
+    std::vector<unsigned long long> sm(2 * (size_t)nwin);
     e = hipMemcpyAsync(sm.data(), small, sizeof(unsigned long long) * sm.size(), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return e;
-    for (int w = 0; w < nwin; w++) pairs[w] = (double)sm[(size_t)w];
+    for (int w = 0; w < nwin; w++) { pairs[w] = (double)sm[(size_t)w]; refs[w] = (double)sm[(size_t)(nwin + w)]; }
     return hipSuccess;
 }
 
