@@ -531,8 +531,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     if (P > 1 && dev_split && panels_auto && opt.hub_table < 0 && opt.waves_per_block == 0 && opt.x_window <= 0 && !cvr::debug_env("no_auto_layout")) {      // (the predicate of choose_hubs: only panels that will get tables are widened)
         const int64_t room = ((int64_t)cvr::kLdsBytes / (int64_t)vsz - 8 * (cvr::kLanes + 512) - cvr::kDictMax - 8) & ~(int64_t)1023;
         double            share = 0;
+        std::vector<double> col_share(cvr::kColBins, 0.0);          // the non-zeros' shares of 1 024 equal column ranges (same pass)
         const double      th0 = now_s();
-        const hipError_t  e = cvr::hub_share_device(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &share, h->stream, cvr::Scratch{h->plan_ws.dev, h->plan_ws.dev_bytes});      // (the share alone: no ranking of the columns)
+        const hipError_t  e = cvr::hub_share_device(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &share, h->stream, cvr::Scratch{h->plan_ws.dev, h->plan_ws.dev_bytes}, col_share.data());      // (the share alone: no ranking of the columns)
         in.hub_select_s += now_s() - th0;
         if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
         if (share >= 0.25) {       // (of the whole matrix: the panels' own tables, ranked inside their ranges, hold more)
@@ -544,6 +545,33 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         // matrix's share at most: LiveJournal shape 0.06): the panels skip their own counting passes and take interleaved chunks instead
         // (web-Google shape x 2.2, whose share lies between 0.08 and 0.25: 72 us as plain panels that end up without tables, 55 us interleaved)
         if (share < (cvr::debug_env("flat_share") ? atof(cvr::debug_env("flat_share")) : 0.25)) opt.hub_table = 0;
+        // Panels that run one per XCD are equally WIDE, not equally full: when the non-zeros crowd into some column ranges, the XCD with the
+        // fullest panels sets the time (round 5 hold-out: a bipartite matrix whose columns thin out towards the end -- the first of 16 panels
+        // holds 15.7 % of the non-zeros, 1.26 x an XCD's fair share -- ran 187 us as 16 panels, 112 us as 32).  The shares of the panels come
+        // from the pass above; the count is doubled (up to 64) until the heaviest XCD -- panels dealt as run_spmv's table deals them, the
+        // fullest first to the least loaded XCD -- is within 15 % of the mean.
+        if (opt.hub_table == 0 && xcd_panels && P > 1 && P <= 64 && !cvr::debug_env("no_balance_rule")) {
+            auto imbalance = [&](int Pt) {
+                std::vector<double> load((size_t)Pt, 0.0);
+                const int64_t       w = (ncols + Pt - 1) / Pt > 0 ? (ncols + Pt - 1) / Pt : 1;
+                for (uint32_t b = 0; b < cvr::kColBins; b++) load[(size_t)std::min<int64_t>(Pt - 1, (int64_t)(((double)b + 0.5) * (double)ncols / cvr::kColBins) / w)] += col_share[b];
+                std::sort(load.begin(), load.end(), std::greater<double>());
+                const size_t rounds = ((size_t)Pt + 7) / 8;
+                double       x[8] = {0, 0, 0, 0, 0, 0, 0, 0}, all = 0;
+                size_t       used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (double l : load) {
+                    int best = -1;
+                    for (int q = 0; q < 8; q++) if (used[q] < rounds && (best < 0 || x[q] < x[best])) best = q;
+                    x[best] += l; used[best]++; all += l;
+                }
+                return all > 0 ? *std::max_element(x, x + 8) * 8.0 / all : 1.0;
+            };
+            int    Pb = P;
+            double ib = imbalance(P);
+            for (int Pt = 2 * P; ib > 1.15 && Pt <= 64; Pt *= 2) { const double it = imbalance(Pt); if (it < ib - 0.02) { ib = it; Pb = Pt; } }
+            if (cvr::debug_env("fused_trace") && Pb != P) fprintf(stderr, "[cvr] %d column panels instead of %d: the heaviest XCD at %.2f of the mean instead of %.2f\n", Pb, P, ib, imbalance(P));
+            P = Pb;
+        }
     }
     // the rule's second question, for the count it arrived at: do the panels' partial sums cost less than the misses they save?  (cvr_panels.hip: panels_pay)
     if (P > 1 && panels_auto && dev_split && rule_miss >= 0 && !cvr::debug_env("no_pairs_rule")) {
@@ -626,9 +654,14 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         int ilv_generations = 0;          // > 0: the chunk length was chosen for this many generations of workgroups (checked against the plan below)
         if (panel_opt.interleave > 0) {
             panel_opt.hub_table = 0; panel_opt.col_phases = 1;
+            int64_t nsub_all = 0;
+            for (int64_t v : nsubs) nsub_all += v;
+            // Mostly-empty matrices -- fewer (row, panel) pairs than rows: the wiki-Talk shape, 0.27 per row -- get two wavefronts per workgroup
+            // instead of four: their chunks are short (the row cap of the LDS accumulators ends them, not the steps), and with two wavefronts a
+            // chunk may span twice the rows (wiki-Talk shape 39.7 -> 36.6 us, x 2 at another seed 70.3 -> 66.0; every other shape of
+            // profiles/r05_wpb_probe.log loses 1-20 % with two, which is why this is not the general rule)
+            if (panel_opt.waves_per_block == 0 && panels_auto && nsub_all < nrows && !cvr::debug_env("no_sparse_waves")) panel_opt.waves_per_block = 2;
             if (panel_opt.steps_per_chunk == 0) {       // one chunk length for all panels (they share a launch): from the mean sub-row and the mean panel
-                int64_t nsub_all = 0;
-                for (int64_t v : nsubs) nsub_all += v;
                 IOpt one = panel_opt;
                 panel_opt.steps_per_chunk = interleave_steps((sj1 - sj0) / P, std::max<int64_t>(nsub_all / P, 1), f32, one);
                 if (xcd_panels && dev_split && !cvr::debug_env("ilv_plain_steps")) {      // panels one per XCD: the length that fills whole generations of workgroups

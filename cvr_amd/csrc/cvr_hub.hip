@@ -128,19 +128,34 @@ hipError_t select_hubs(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols,
 
 // per count value c < kShareBins: how many columns were counted c times; [kShareBins]: number and sum of the larger counts
 constexpr uint32_t kShareBins = 4096;
+// hist[kShareBins + 2 + b], b < kColBins: the sampled non-zeros whose column lies in the b-th of kColBins equal column ranges (what the panel rule
+// weighs the panels' loads with: cvr_capi.hip, balanced_panel_count)
 __global__ __launch_bounds__(256) void hub_share_kernel(const uint32_t *__restrict__ cnt, uint32_t ncols, unsigned long long *__restrict__ hist)
 {
     __shared__ uint32_t h[kShareBins];
+    __shared__ uint32_t cb[kColBins];
     for (uint32_t i = threadIdx.x; i < kShareBins; i += 256) h[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kColBins; i += 256) cb[i] = 0;
     __syncthreads();
     unsigned long long nbig = 0, sbig = 0;
-    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < ncols; c += gridDim.x * 256) {
-        const uint32_t v = cnt[c];
+    const uint32_t     lane = threadIdx.x & 63u;
+    for (uint32_t c0 = blockIdx.x * 256 + (threadIdx.x & ~63u); c0 < ncols; c0 += gridDim.x * 256) {          // (a wavefront's 64 columns at a time)
+        const uint32_t c = c0 + lane;
+        const uint32_t v = c < ncols ? cnt[c] : 0u;
+        const uint32_t last = c0 + 63u < ncols ? c0 + 63u : ncols - 1u;
+        const uint32_t b0 = (uint32_t)((unsigned long long)c0 * kColBins / ncols), b1 = (uint32_t)((unsigned long long)last * kColBins / ncols);
+        if (b0 == b1) {          // all in one column range: one LDS atomic for the wavefront
+            uint32_t sum = v;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (lane == 0 && sum) atomicAdd(&cb[b0], sum);
+        } else if (v) atomicAdd(&cb[(uint32_t)((unsigned long long)c * kColBins / ncols)], v);
         if (v < 2) continue;
         if (v < kShareBins) atomicAdd(&h[v], 1u); else { nbig++; sbig += v; }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kShareBins; i += 256) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+    for (uint32_t i = threadIdx.x; i < kColBins; i += 256) if (cb[i]) atomicAdd(&hist[kShareBins + 2 + i], (unsigned long long)cb[i]);
     if (nbig) { atomicAdd(&hist[kShareBins], nbig); atomicAdd(&hist[kShareBins + 1], sbig); }
 }
 
@@ -148,19 +163,20 @@ __global__ __launch_bounds__(256) void hub_share_kernel(const uint32_t *__restri
 // the columns' counts, then a histogram of the count VALUES, walked from the top until hmax columns are in.  cvr_create asks this of a
 // matrix that is about to get column panels (are its popular columns worth hub tables?): the sort of all column counts it replaces was
 // ~0.6 of the 1.0 ms of that question on the soc-LiveJournal1 shape.
-hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, double *share, hipStream_t st, Scratch lent)
+hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, double *share, hipStream_t st, Scratch lent, double *col_share)
 {
     *share = 0;
+    if (col_share) for (uint32_t b = 0; b < kColBins; b++) col_share[b] = 0;
     if (n1 <= n0 || ncols <= 0 || hmax == 0) return hipSuccess;
     void *arena = nullptr;
-    const size_t nc = (size_t)ncols, o_hist = (4 * nc + 255) & ~(size_t)255, hist_bytes = sizeof(unsigned long long) * (kShareBins + 2);
+    const size_t nc = (size_t)ncols, o_hist = (4 * nc + 255) & ~(size_t)255, hist_bytes = sizeof(unsigned long long) * (kShareBins + 2 + kColBins);
     const bool   own = !(lent.p && lent.bytes >= o_hist + hist_bytes);          // (lent by cvr_create: the planner's scratch, idle until the split is done)
     hipError_t e = hipSuccess;
     if (own) e = hipMalloc(&arena, o_hist + hist_bytes); else arena = lent.p;
     if (e != hipSuccess) return e;
     uint32_t           *cnt = static_cast<uint32_t *>(arena);
     unsigned long long *hist = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(arena) + o_hist);
-    std::vector<unsigned long long> h(kShareBins + 2);
+    std::vector<unsigned long long> h(kShareBins + 2 + kColBins);
     e = hipMemsetAsync(arena, 0, o_hist + hist_bytes, st);
     const int64_t stride = hub_sample_stride(n1 - n0), nsamp = (n1 - n0 + stride - 1) / stride;
     if (e == hipSuccess) {
@@ -176,6 +192,7 @@ hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t n
     { const unsigned long long take = std::min(left, h[kShareBins]); sum += h[kShareBins] ? h[kShareBins + 1] * take / h[kShareBins] : 0; left -= take; }      // (more such columns than hmax cannot happen with a sample of 2^23)
     for (uint32_t v = kShareBins - 1; v >= 2 && left > 0; v--) { const unsigned long long take = std::min(left, h[v]); sum += take * v; left -= take; }
     *share = (double)sum / (double)nsamp;
+    if (col_share) for (uint32_t b = 0; b < kColBins; b++) col_share[b] = (double)h[kShareBins + 2 + b] / (double)nsamp;
     return hipSuccess;
 }
 

@@ -243,8 +243,13 @@ hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const Devi
     if (ipt <= 12) return launch_chunks<1024, 12>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 16) return launch_chunks<1024, 16>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 24) return launch_chunks<1024, 24>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
-    if (ipt <= 32) return launch_chunks<1024, 32>(d_tab, c, c0, ystage_max, cbits, err_flag, st);          // (768 threads x 44 pairs -- 170 registers each -- spill 364 bytes and take as long)
-    return launch_chunks<1024, 36>(d_tab, c, c0, ystage_max, cbits, err_flag, st);          // (chunks of up to 576 steps: what lets a launch of 8 200 chunks at S = 508 fit eight generations of workgroups instead of nine)
+    // 32 / 36 pairs per thread: digits of ten bits -- the 19-20 bits of a panel's columns in two passes instead of three of eight: the sort of a
+    // 444-step chunk 124 -> 98 us, the launch 2.66 -> 2.52 ms on the soc-LiveJournal1 shape (six bits: 145 us; profiles/r05_convert_probe.log).
+    // What these lengths cost beside 16 pairs (no spills, 64 KiB of LDS, two workgroups per CU: 1.48 ms for the same matrix at S = 256) is the
+    // price of the long chunks the SpMV wants (305 us at S = 256 against 275).
+    if (ipt <= 32 && cvr::debug_env("ilv_rb8")) return launch_chunks<1024, 32>(d_tab, c, c0, ystage_max, cbits, err_flag, st);      // (diagnostics: the former three passes)
+    if (ipt <= 32) return launch_chunks<1024, 32, 10>(d_tab, c, c0, ystage_max, cbits, err_flag, st);          // (768 threads x 44 pairs -- 170 registers each -- spill 364 bytes and take as long)
+    return launch_chunks<1024, 36, 10>(d_tab, c, c0, ystage_max, cbits, err_flag, st);          // (chunks of up to 576 steps: what lets a launch of 8 200 chunks at S = 508 fit eight generations of workgroups instead of nine)
 }
 
 }  // namespace cvr

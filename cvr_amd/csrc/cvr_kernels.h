@@ -73,7 +73,9 @@ void       free_hubs(HubSelection &s);
 // Scratch: device memory the caller lends for the duration of the call (round 5: the analysis passes of cvr_create allocated and freed their own -- a
 // hipMalloc + hipFree pair costs more than the kernels between them); too small or null: the pass allocates.
 struct Scratch { void *p = nullptr; size_t bytes = 0; };
-hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, double *share, hipStream_t st, Scratch lent = Scratch());
+// col_share (optional, kColBins entries): the share of the sampled non-zeros in each of kColBins equal column ranges
+constexpr uint32_t kColBins = 1024;
+hipError_t hub_share_device(const int32_t *ci, int64_t n0, int64_t n1, int64_t ncols, uint32_t hmax, double *share, hipStream_t st, Scratch lent = Scratch(), double *col_share = nullptr);
 hipError_t launch_hub_gather(const DeviceImage &img, const void *x_ext, hipStream_t st);     // hub_x = x[hub_cols]
 
 struct DeviceCsr {

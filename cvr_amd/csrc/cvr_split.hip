@@ -253,13 +253,15 @@ constexpr uint32_t kEstBins = 4096;        // line counts 1 .. 4094 have a bin e
 // window w = rows [r0[w], r0[w] + W): one count per 128-byte line of x
 __global__ __launch_bounds__(256) void est_count_kernel(const long long *__restrict__ rp, const int32_t *__restrict__ ci, const long long *__restrict__ r0,
                                                         long long W, uint32_t per_line, long long nlines, uint32_t *__restrict__ cnt,
-                                                        unsigned long long *__restrict__ refs)
+                                                        unsigned long long *__restrict__ refs, uint32_t nwin)
 {
-    const uint32_t  w = blockIdx.y;
+    // (a 1-D grid with the window in the low bits of the workgroup number: workgroups go round the XCDs, so with eight windows every
+    // window's counters are touched from one XCD only)
+    const uint32_t  w = blockIdx.x % nwin, bx = blockIdx.x / nwin, gx = gridDim.x / nwin;
     const long long j0 = rp[r0[w]], j1 = rp[r0[w] + W];
     uint32_t       *c = cnt + (size_t)w * (size_t)nlines;
-    for (long long j = j0 + (long long)blockIdx.x * 256 + threadIdx.x; j < j1; j += (long long)gridDim.x * 256) atomicAdd(&c[(uint32_t)ci[j] / per_line], 1u);
-    if (blockIdx.x == 0 && threadIdx.x == 0) refs[w] = (unsigned long long)(j1 - j0);
+    for (long long j = j0 + (long long)bx * 256 + threadIdx.x; j < j1; j += (long long)gx * 256) atomicAdd(&c[(uint32_t)ci[j] / per_line], 1u);
+    if (bx == 0 && threadIdx.x == 0) refs[w] = (unsigned long long)(j1 - j0);
 }
 
 // per window: how many lines were touched c times (c < kEstBins - 1), and number and sum of the larger counts
@@ -324,8 +326,8 @@ hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const in
     if (e == hipSuccess) e = hipMemsetAsync(small, 0, sizeof(unsigned long long) * 3 * (size_t)nwin, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_r0, r0_host, sizeof(long long) * (size_t)nwin, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(est_count_kernel, dim3(512, (uint32_t)nwin), dim3(256), 0, st, reinterpret_cast<const long long *>(rp_dev), ci_dev, d_r0, (long long)W, per_line,
-                       nlines, cnt, d_refs);
+    hipLaunchKernelGGL(est_count_kernel, dim3(512 * (uint32_t)nwin), dim3(256), 0, st, reinterpret_cast<const long long *>(rp_dev), ci_dev, d_r0, (long long)W, per_line,
+                       nlines, cnt, d_refs, (uint32_t)nwin);
     hipLaunchKernelGGL(est_hist_kernel, dim3(64, (uint32_t)nwin), dim3(256), 0, st, cnt, nlines, hist, d_big);
     std::vector<uint32_t>           h((size_t)nwin * kEstBins);
     std::vector<unsigned long long> sm(3 * (size_t)nwin);

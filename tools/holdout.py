@@ -141,7 +141,30 @@ def wikitalk_x2():
     return n, n, rp.cpu().numpy(), ci.cpu().numpy(), va.cpu().numpy()
 
 
-SHAPES = dict(webgoogle_seed7=webgoogle_seed7, webgoogle_real=webgoogle_real, lj_half=lj_half, lj_x2=lj_x2, road=road, citation=citation, rmat21b=rmat21b,
+def forum_sparse(seed=104):
+    """mostly-empty rows of another family than wiki-Talk: 3 M rows, 88 % empty, the others 8-40 uniformly random columns (no popular head)"""
+    n = int(3_000_000 * SCALE)
+    g = _gen(seed)
+    act = torch.nonzero(torch.rand(n, generator=g, device=DEV) < 0.12).flatten()
+    deg = (8 + 32 * torch.rand(len(act), generator=g, device=DEV)).to(torch.int64)
+    rows = act.repeat_interleave(deg)
+    cols = (n * torch.rand(len(rows), generator=g, device=DEV, dtype=torch.float64)).to(torch.int64).clamp_(0, n - 1)
+    return _csr(rows, cols, n)
+
+
+def bipartite_sparse(seed=105):
+    """a bipartite rating-like matrix stored square: 4 M rows of which the first 8 % (the "users") hold everything, 25 entries each, columns among the
+    other 92 % with a mild popularity skew (u ** 1.5), real values"""
+    n = int(4_000_000 * SCALE)
+    nu = max(1, int(0.08 * n))
+    g = _gen(seed)
+    rows = torch.arange(nu, device=DEV, dtype=torch.int64).repeat_interleave(25)
+    cols = nu + ((n - nu) * torch.rand(len(rows), generator=g, device=DEV, dtype=torch.float64) ** 1.5).to(torch.int64).clamp_(0, n - nu - 1)
+    rng = np.random.default_rng(seed)
+    return _csr(rows, cols, n, vals=lambda m: rng.random(m) * 2 - 1)
+
+
+SHAPES = dict(forum_sparse=forum_sparse, bipartite_sparse=bipartite_sparse, webgoogle_seed7=webgoogle_seed7, webgoogle_real=webgoogle_real, lj_half=lj_half, lj_x2=lj_x2, road=road, citation=citation, rmat21b=rmat21b,
               orkut_half=orkut_half, wikitalk_x2=wikitalk_x2, uniform16=uniform16)
 
 PLAIN = dict(col_panels=1, col_phases=1, x_window=0, waves_per_block=1, hub_table=0, interleave=0)
@@ -159,6 +182,9 @@ def candidates(n, ncols, nnz, vbytes):
             if xb / P >= 0.5e6:
                 c.append((f"{P} panels plain", dict(col_panels=P, interleave=0)))
                 c.append((f"{P} panels interleaved", dict(col_panels=P, interleave=1)))
+                if P <= 16:
+                    c.append((f"{P} panels interleaved, 2 wavefronts", dict(col_panels=P, interleave=1, waves_per_block=2)))
+                    c.append((f"{P} panels interleaved, 4 wavefronts", dict(col_panels=P, interleave=1, waves_per_block=4)))
         c.append(("1 image interleaved", dict(col_panels=1, interleave=1)))
     return c
 

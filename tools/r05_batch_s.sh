@@ -1,0 +1,4 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
+export TMPDIR=/tmp
+timeout 900 python3 tools/r05_convert_probe.py 2>&1 | grep -E "^---|ilv_clocks|convert" > $OUT/r05_convert_probe.log; cat $OUT/r05_convert_probe.log
