@@ -253,6 +253,23 @@ def _cpu_topology():
     return pk
 
 
+def _cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us); None: no limit.  Round 5: the
+    GPU boxes of this pool show 256 logical CPUs and a quota of 16 -- 64 reference threads were throttled in 80 % of the scheduler periods
+    (cpu.stat nr_throttled), which is where a spread of a factor of three between identical runs came from."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, q // per)
+    except Exception:
+        return None
+
+
 def _run_reference(exe, path, T, iters, nnz, nrows, ncols, prefix=(), cpus=None):
     """one run of the reference binary; cpus: the CPUs the child is pinned to before it starts (its loader thread first-touches every
     page there, its OpenMP threads are placed inside the set: what `numactl --membind` does for the reference, run_sample.sh:10)"""
@@ -304,13 +321,18 @@ def _cpu_reference(nrows, ncols, rp, ci, logical, physical):
     runs = []
     topo = _cpu_topology()
     configs = []          # (label, threads, cpus or None)
+    quota = _cpu_quota()
     if topo:
         pkg0 = sorted(topo)[0]
-        one = topo[pkg0][:68]
+        room = max(1, quota - 1) if quota else 68          # (never more threads than the container's CPU quota -- they would be throttled, not run --, and one CPU left to the parent and the children's loaders: with all 16 of 16 taken, 15 scheduler periods of a run were still throttled)
+        one = topo[pkg0][:min(68, room)]
         every = sorted(c for cs in topo.values() for c in cs)
-        configs.append((f"one socket: {len(one)} threads on {len(one)} cores of package {pkg0}", len(one), set(one)))
-        if len(every) > len(one):
+        configs.append((f"one socket: {len(one)} threads on {len(one)} cores of package {pkg0}" + (f" (the container's CPU quota: {quota})" if quota and quota < 68 else ""), len(one), set(one)))
+        if len(every) > len(one) and (quota is None or quota >= len(every)):
             configs.append((f"all {len(every)} physical cores of {len(topo)} packages", len(every), set(every)))
+        elif quota and len(topo) > 1 and quota < len(every):          # the same number of threads over all sockets (more memory channels, remote pages)
+            spread_set = sorted(c for cs in topo.values() for c in cs[:max(1, room // len(topo))])
+            configs.append((f"{len(spread_set)} threads over {len(topo)} packages", len(spread_set), set(spread_set)))
         placement = "child pinned with sched_setaffinity before it starts (threads and first-touched pages inside the set)"
         prefix = ()
     else:
@@ -349,7 +371,7 @@ def _cpu_reference(nrows, ncols, rp, ci, logical, physical):
                       "`value` is the median run of the configuration whose median is better",
             "ms_per_step": best["ms_per_step"], "preprocess_s": best["preprocess_s"], "gbs_alg": best["gbs_alg"], "spread": pick["spread_max_minus_min_over_median"],
             "reference_convention_gflops": best["reference_convention_gflops"], "per_thread_count": stats, "memory_placement": placement, "runs": runs,
-            "host_state": {"before": host_before, "after": _host_state(), "logical_cpus_visible": len(os.sched_getaffinity(0))}}
+            "host_state": {"before": host_before, "after": _host_state(), "logical_cpus_visible": len(os.sched_getaffinity(0)), "cpu_quota": quota}}
 
 
 def _cpu_port(nrows, ncols, rp, ci, va, cores, budget_s=8.0, probe=(8, 16, 32, 64, 128)):
@@ -361,6 +383,9 @@ def _cpu_port(nrows, ncols, rp, ci, va, cores, budget_s=8.0, probe=(8, 16, 32, 6
     m = synth.to_refcompat(nrows, ncols, rp, ci, va)
     x = np.ones(ncols + 2)
     best = None
+    quota = _cpu_quota()
+    if quota:          # (threads beyond the container's CPU quota are throttled, not run)
+        cores = min(cores, quota)
     for T in sorted({max(1, min(cores, t)) for t in probe}):     # thread count: quick probe, keep the best
         c = O.Cvr8(m, T)
         if c.rc != 0:

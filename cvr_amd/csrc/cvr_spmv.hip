@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void fixup_kernel(const in
 // wiki-Talk shape: 6 % of the rows hold all the non-zeros -- a block of 1 024 rows has a few dozen partial sums per panel and the pass is
 // all launch and round-trip latency (2 339 workgroups, 13.7 us); with MUL = 8 a workgroup has eight times the entries per round trip and
 // there are an eighth of the workgroups.
-template <typename T, int kBatch, int MUL>
+template <typename T, int kBatch, int kEach, int MUL>
 __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off,
                                                       uint32_t nblocks, T *__restrict__ y, uint32_t nrows)
 {
@@ -1023,10 +1023,22 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
     // soc-LiveJournal1 shape); what a panel holds beyond 256 * kEach entries for this block is added behind them.
     // (kBatch = 8 for up to eight panels: ONE round trip per block -- a matrix with few non-zeros per row block, the wiki-Talk shape, spends
     // its combine pass waiting for those round trips, not moving bytes)
-    constexpr int kEach = 4;
+    // Round 5: the panels' table entries (pointers, the block's range in every panel) come to LDS in one round trip in front of everything --
+    // they used to be loaded inside every batch, a dependent trip in front of the data's: soc-LiveJournal1 shape 45.6 -> 36.5 us (rocprofv3
+    // averages; 178 MB of partial sums, row numbers and y: 4.9 TB/s), com-Orkut shape 684 -> 672-678 us whole.  Wider batches do not add to it
+    // (16 panels x 2 or x 1 entries per thread: 275 / 267 us whole against 265 with 4 x 4 -- the registers cost more occupancy than the
+    // round trips they save), nor do eight blocks per workgroup outside the mostly-empty shapes (283 us): profiles/r05_combine_tables.log.
     constexpr uint32_t kRows = (uint32_t)kCombineRows * MUL;
-    __shared__ T acc[kRows];
+    __shared__ T               acc[kRows];
+    __shared__ uint32_t        s_lo[kMaxSplitPanels], s_hi[kMaxSplitPanels];
+    __shared__ const T        *s_z[kMaxSplitPanels];
+    __shared__ const uint32_t *s_rows[kMaxSplitPanels];
     const uint32_t b = blockIdx.x * MUL, b1 = min(b + (uint32_t)MUL, nblocks), r0 = b * kCombineRows;      // the blocks [b, b1) of the tables
+    if (threadIdx.x < npanels) {
+        const CombinePanel cp = panels[threadIdx.x];
+        s_z[threadIdx.x] = static_cast<const T *>(cp.z); s_rows[threadIdx.x] = cp.rows;
+        s_lo[threadIdx.x] = block_off[(size_t)threadIdx.x * (nblocks + 1) + b]; s_hi[threadIdx.x] = block_off[(size_t)threadIdx.x * (nblocks + 1) + b1];
+    }
     for (uint32_t i = threadIdx.x; i < kRows; i += blockDim.x) acc[i] = 0;
     __syncthreads();
     for (uint32_t p0 = 0; p0 < npanels; p0 += kBatch) {
@@ -1038,11 +1050,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
             uint32_t       lo = 0, hi = 0;
             const T       *z = nullptr;
             const uint32_t *rows = nullptr;
-            if (p < npanels) {
-                const CombinePanel cp = panels[p];
-                lo = block_off[(size_t)p * (nblocks + 1) + b]; hi = block_off[(size_t)p * (nblocks + 1) + b1];
-                z = static_cast<const T *>(cp.z); rows = cp.rows;
-            }
+            if (p < npanels) { lo = s_lo[p]; hi = s_hi[p]; z = s_z[p]; rows = s_rows[p]; }
 #pragma unroll
             for (int e = 0; e < kEach; e++) {
                 const uint32_t u = lo + threadIdx.x + (uint32_t)e * 256u;
@@ -1056,10 +1064,10 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
             if (p < npanels) {                                 // (uniform)
 #pragma unroll
                 for (int e = 0; e < kEach; e++) if (rw[q][e] != 0xffffffffu) acc[rw[q][e] - r0] += v[q][e];
-                const CombinePanel cp = panels[p];
-                const uint32_t     lo = block_off[(size_t)p * (nblocks + 1) + b], hi = block_off[(size_t)p * (nblocks + 1) + b1];
-                const T           *z = static_cast<const T *>(cp.z);
-                for (uint32_t u = lo + threadIdx.x + (uint32_t)kEach * 256u; u < hi; u += 256u) acc[cp.rows[u] - r0] += z[u];
+                const uint32_t  lo = s_lo[p], hi = s_hi[p];
+                const T        *z = s_z[p];
+                const uint32_t *rows = s_rows[p];
+                for (uint32_t u = lo + threadIdx.x + (uint32_t)kEach * 256u; u < hi; u += 256u) acc[rows[u] - r0] += z[u];
             }
             __syncthreads();
         }
@@ -1118,13 +1126,17 @@ hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const ui
     auto go = [&](auto real) {
         using T = decltype(real);
         T *yt = static_cast<T *>(y);
+        // batch: 4 / 8 = that many panels per round trip with four entries per thread each; 16 / 17 = sixteen panels with two / one
         if (mul == 8) {
             const uint32_t grid = (nblocks + 7) / 8;
-            if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else hipLaunchKernelGGL((combine_kernel<T, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            if (batch >= 16) hipLaunchKernelGGL((combine_kernel<T, 16, 2, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else hipLaunchKernelGGL((combine_kernel<T, 4, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
         } else {
-            if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else hipLaunchKernelGGL((combine_kernel<T, 4, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            if (batch == 17) hipLaunchKernelGGL((combine_kernel<T, 16, 1, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else if (batch == 16) hipLaunchKernelGGL((combine_kernel<T, 16, 2, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 4, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else hipLaunchKernelGGL((combine_kernel<T, 4, 4, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
         }
     };
     if (f32) go(float{}); else go(double{});
