@@ -99,9 +99,11 @@ struct Part {
     int32_t   multi_slot = -1; // panels that run one per XCD: round * 8 + XCD slot of this panel in cvr_handle::d_multi
 
     bool      csr_borrowed = false;      // d_ci / d_va point into the handle's split arena (column panels split on the device): not this part's to free
+    bool      rp_borrowed = false;       // d_rp is a slice of cvr_handle::panel_rp (the panels' row pointers in one allocation: a hipFree of a few megabytes takes ~0.2 ms, sixteen of them were 3 ms of cvr_preprocess)
     void release_csr()
     {
-        if (d_rp) (void)hipFree(d_rp);
+        if (d_rp && !rp_borrowed) (void)hipFree(d_rp);
+        rp_borrowed = false;
         if (d_ci && !csr_borrowed) (void)hipFree(d_ci);
         if (d_va && !csr_borrowed) (void)hipFree(d_va);
         if (d_nzb) (void)hipFree(d_nzb);
@@ -139,7 +141,8 @@ struct cvr_handle {
     uint32_t *d_rows = nullptr, *d_block_off = nullptr;
     int32_t  *split_ci = nullptr;          // the device split's column indices and values, panel after panel: the parts' CSR arrays are slices of these
     void     *split_va = nullptr;          // (freed with the parts' CSR: after the conversion, or with the handle when it keeps its CSR)
-    void      release_split() { if (split_ci) (void)hipFree(split_ci); if (split_va) (void)hipFree(split_va); split_ci = nullptr; split_va = nullptr; }
+    int64_t  *panel_rp = nullptr;          // the panels' rebased row pointers, one allocation (Part::rp_borrowed)
+    void      release_split() { if (split_ci) (void)hipFree(split_ci); if (split_va) (void)hipFree(split_va); if (panel_rp) (void)hipFree(panel_rp); split_ci = nullptr; split_va = nullptr; panel_rp = nullptr; }
     cvr::CombinePanel *d_cpanels = nullptr;
     void     *d_dict = nullptr;           // value dictionary (sorted by bit pattern) shared by all parts, or null
     uint32_t  ndict = 0;

@@ -559,17 +559,23 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
     }
     auto abandon = [&]() {          // (nothing of the attempt stays: the caller allocates again)
         for (int i = 0; i < nst; i++) (void)hipStreamSynchronize(sts[i]);
-        for (Part &part : h->parts) {
-            for (void *q : {(void *)part.d_rp, (void *)part.d_nzb, (void *)part.d_pad, (void *)part.img.desc, (void *)part.img.desc2, (void *)part.img.shared}) if (q) (void)hipFree(q);
-            part.d_rp = nullptr; part.d_nzb = nullptr; part.d_pad = nullptr; part.img.desc = nullptr; part.img.desc2 = nullptr; part.img.shared = nullptr;
-        }
+        release_panel_plans(h);
         return CVR_OK;
     };
+    {   // the panels' row pointers: one allocation, a slice each
+        size_t total = 0;
+        for (int p = 0; p < P; p++) total += (sizeof(int64_t) * ((size_t)nsubs[(size_t)p] + 1) + 255) & ~(size_t)255;
+        if (h->panel_rp) { (void)hipFree(h->panel_rp); h->panel_rp = nullptr; }
+        HIP_TRY(hipMalloc(&h->panel_rp, std::max<size_t>(total, 256)));
+    }
+    size_t rp_off = 0;
     for (int p = 0; p < P; p++) {
         Part           &part = h->parts[(size_t)p];
         const int64_t   ns = nsubs[(size_t)p], nzp = d.off[p + 1] - d.off[p], nb = bound[(size_t)p];
         const hipStream_t st = sts[p % nst];
-        HIP_TRY(hipMalloc(&part.d_rp, sizeof(int64_t) * ((size_t)ns + 1)));
+        part.d_rp = reinterpret_cast<int64_t *>(reinterpret_cast<uint8_t *>(h->panel_rp) + rp_off);
+        part.rp_borrowed = true;
+        rp_off += (sizeof(int64_t) * ((size_t)ns + 1) + 255) & ~(size_t)255;
         HIP_TRY(cvr::launch_shift_rows(d.rp + d.sub0[p], ns + 1, d.off[p], part.d_rp, st));
         HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nb + 1)));
         HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nb, 1)));
@@ -615,9 +621,11 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
 void release_panel_plans(cvr_handle *h)
 {
     for (Part &part : h->parts) {
-        for (void *q : {(void *)part.d_rp, (void *)part.d_nzb, (void *)part.d_pad, (void *)part.img.desc, (void *)part.img.desc2, (void *)part.img.shared}) if (q) (void)hipFree(q);
-        part.d_rp = nullptr; part.d_nzb = nullptr; part.d_pad = nullptr; part.img.desc = nullptr; part.img.desc2 = nullptr; part.img.shared = nullptr;
+        if (part.d_rp && !part.rp_borrowed) (void)hipFree(part.d_rp);
+        for (void *q : {(void *)part.d_nzb, (void *)part.d_pad, (void *)part.img.desc, (void *)part.img.desc2, (void *)part.img.shared}) if (q) (void)hipFree(q);
+        part.d_rp = nullptr; part.rp_borrowed = false; part.d_nzb = nullptr; part.d_pad = nullptr; part.img.desc = nullptr; part.img.desc2 = nullptr; part.img.shared = nullptr;
     }
+    if (h->panel_rp) { (void)hipFree(h->panel_rp); h->panel_rp = nullptr; }
 }
 
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
