@@ -1082,6 +1082,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Part &p : h->parts) p.release_all();
     h->release_split();
+    if (h->panel_tables) (void)hipFree(h->panel_tables);
     cvr::free_plan_scratch(h->plan_ws);
     if (h->seg_arena) (void)hipFree(h->seg_arena);
     if (h->d_small) (void)hipFree(h->d_small);

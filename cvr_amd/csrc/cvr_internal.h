@@ -99,26 +99,28 @@ struct Part {
     int32_t   multi_slot = -1; // panels that run one per XCD: round * 8 + XCD slot of this panel in cvr_handle::d_multi
 
     bool      csr_borrowed = false;      // d_ci / d_va point into the handle's split arena (column panels split on the device): not this part's to free
-    bool      rp_borrowed = false;       // d_rp is a slice of cvr_handle::panel_rp (the panels' row pointers in one allocation: a hipFree of a few megabytes takes ~0.2 ms, sixteen of them were 3 ms of cvr_preprocess)
+    bool      tables_borrowed = false;   // img.desc / desc2 / shared are slices of cvr_handle::panel_tables (they live as long as the handle)
+    bool      rp_borrowed = false;       // d_rp, d_nzb, d_pad are slices of cvr_handle::panel_rp (the panels' row pointers in one allocation: a hipFree of a few megabytes takes ~0.2 ms, sixteen of them were 3 ms of cvr_preprocess)
     void release_csr()
     {
         if (d_rp && !rp_borrowed) (void)hipFree(d_rp);
-        rp_borrowed = false;
         if (d_ci && !csr_borrowed) (void)hipFree(d_ci);
         if (d_va && !csr_borrowed) (void)hipFree(d_va);
-        if (d_nzb) (void)hipFree(d_nzb);
-        if (d_pad) (void)hipFree(d_pad);
+        if (d_nzb && !rp_borrowed) (void)hipFree(d_nzb);          // (with the row pointers: slices of the same allocation)
+        if (d_pad && !rp_borrowed) (void)hipFree(d_pad);
+        rp_borrowed = false;
         d_rp = nullptr; d_ci = nullptr; d_va = nullptr; d_nzb = nullptr; d_pad = nullptr;
     }
     void release_all()
     {
         release_csr();
         if (img.stream) (void)hipFree(img.stream);
-        if (img.desc) (void)hipFree(img.desc);
+        if (img.desc && !tables_borrowed) (void)hipFree(img.desc);
         if (img.target) (void)hipFree(img.target);
-        if (img.shared) (void)hipFree(img.shared);
+        if (img.shared && !tables_borrowed) (void)hipFree(img.shared);
         if (img.win_base) (void)hipFree(img.win_base);
-        if (img.desc2) (void)hipFree(img.desc2);
+        if (img.desc2 && !tables_borrowed) (void)hipFree(img.desc2);
+        tables_borrowed = false;
         if (img.cbase) (void)hipFree(img.cbase);
         if (img.hub_cols) (void)hipFree(img.hub_cols);
         if (img.hub_index) (void)hipFree(img.hub_index);
@@ -141,7 +143,8 @@ struct cvr_handle {
     uint32_t *d_rows = nullptr, *d_block_off = nullptr;
     int32_t  *split_ci = nullptr;          // the device split's column indices and values, panel after panel: the parts' CSR arrays are slices of these
     void     *split_va = nullptr;          // (freed with the parts' CSR: after the conversion, or with the handle when it keeps its CSR)
-    int64_t  *panel_rp = nullptr;          // the panels' rebased row pointers, one allocation (Part::rp_borrowed)
+    void     *panel_tables = nullptr;      // the panels' chunk tables (desc, desc2, cut rows), one allocation (Part::tables_borrowed); freed with the handle
+    int64_t  *panel_rp = nullptr;          // the panels' rebased row pointers, chunk starts and pad counts, one allocation (Part::rp_borrowed)
     void      release_split() { if (split_ci) (void)hipFree(split_ci); if (split_va) (void)hipFree(split_va); if (panel_rp) (void)hipFree(panel_rp); split_ci = nullptr; split_va = nullptr; panel_rp = nullptr; }
     cvr::CombinePanel *d_cpanels = nullptr;
     void     *d_dict = nullptr;           // value dictionary (sorted by bit pattern) shared by all parts, or null

@@ -562,27 +562,37 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
         release_panel_plans(h);
         return CVR_OK;
     };
-    {   // the panels' row pointers: one allocation, a slice each
-        size_t total = 0;
-        for (int p = 0; p < P; p++) total += (sizeof(int64_t) * ((size_t)nsubs[(size_t)p] + 1) + 255) & ~(size_t)255;
+    auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    {   // two allocations for all panels, a slice each: what goes with the CSR (row pointers, chunk starts, pad counts) and what stays with the images
+        // (desc, desc2, cut rows) -- ~100 hipMalloc calls and as many hipFree calls less for sixteen panels
+        size_t total = 0, tables = 0;
+        for (int p = 0; p < P; p++) {
+            const size_t nb = std::max<size_t>((size_t)bound[(size_t)p], 1);
+            total += up256(sizeof(int64_t) * ((size_t)nsubs[(size_t)p] + 1)) + up256(sizeof(int64_t) * (nb + 1)) + up256(sizeof(uint32_t) * nb);
+            tables += up256(16 * nb) + up256(24 * nb) + up256(8 * nb);
+        }
         if (h->panel_rp) { (void)hipFree(h->panel_rp); h->panel_rp = nullptr; }
+        if (h->panel_tables) { (void)hipFree(h->panel_tables); h->panel_tables = nullptr; }
         HIP_TRY(hipMalloc(&h->panel_rp, std::max<size_t>(total, 256)));
+        HIP_TRY(hipMalloc(&h->panel_tables, std::max<size_t>(tables, 256)));
     }
-    size_t rp_off = 0;
+    size_t rp_off = 0, tab_off = 0;
+    auto carve = [&](void *base, size_t &off, size_t bytes) { void *q = static_cast<uint8_t *>(base) + off; off += up256(bytes); return q; };
     for (int p = 0; p < P; p++) {
         Part           &part = h->parts[(size_t)p];
         const int64_t   ns = nsubs[(size_t)p], nzp = d.off[p + 1] - d.off[p], nb = bound[(size_t)p];
         const hipStream_t st = sts[p % nst];
-        part.d_rp = reinterpret_cast<int64_t *>(reinterpret_cast<uint8_t *>(h->panel_rp) + rp_off);
+        const size_t nb1 = std::max<size_t>((size_t)nb, 1);
+        part.d_rp = static_cast<int64_t *>(carve(h->panel_rp, rp_off, sizeof(int64_t) * ((size_t)ns + 1)));
+        part.d_nzb = static_cast<int64_t *>(carve(h->panel_rp, rp_off, sizeof(int64_t) * (nb1 + 1)));
+        part.d_pad = static_cast<uint32_t *>(carve(h->panel_rp, rp_off, sizeof(uint32_t) * nb1));
         part.rp_borrowed = true;
-        rp_off += (sizeof(int64_t) * ((size_t)ns + 1) + 255) & ~(size_t)255;
         HIP_TRY(cvr::launch_shift_rows(d.rp + d.sub0[p], ns + 1, d.off[p], part.d_rp, st));
-        HIP_TRY(hipMalloc(&part.d_nzb, sizeof(int64_t) * ((size_t)nb + 1)));
-        HIP_TRY(hipMalloc(&part.d_pad, sizeof(uint32_t) * std::max<size_t>((size_t)nb, 1)));
-        HIP_TRY(hipMalloc(&part.img.desc, 16 * std::max<size_t>((size_t)nb, 1)));
-        HIP_TRY(hipMalloc(&part.img.shared, 24 * std::max<size_t>((size_t)nb, 1)));
         const bool phased = pps[(size_t)p].phases > 1;
-        if (phased) HIP_TRY(hipMalloc(&part.img.desc2, 8 * std::max<size_t>((size_t)nb, 1)));
+        part.img.desc = static_cast<decltype(part.img.desc)>(carve(h->panel_tables, tab_off, 16 * nb1));
+        part.img.shared = static_cast<decltype(part.img.shared)>(carve(h->panel_tables, tab_off, 24 * nb1));
+        part.img.desc2 = phased ? static_cast<decltype(part.img.desc2)>(carve(h->panel_tables, tab_off, 8 * nb1)) : nullptr;
+        part.tables_borrowed = true;
         cvr::PlanTables tables;
         tables.desc = part.img.desc; tables.desc2 = part.img.desc2; tables.pad = part.d_pad; tables.nzb = part.d_nzb; tables.room = (uint32_t)nb; tables.phased = phased;
         tables.totals = own.d_tot + 4 * (size_t)p;
@@ -621,11 +631,12 @@ int plan_panels_batched(cvr_handle *h, const cvr::DeviceSplit &d, const std::vec
 void release_panel_plans(cvr_handle *h)
 {
     for (Part &part : h->parts) {
-        if (part.d_rp && !part.rp_borrowed) (void)hipFree(part.d_rp);
-        for (void *q : {(void *)part.d_nzb, (void *)part.d_pad, (void *)part.img.desc, (void *)part.img.desc2, (void *)part.img.shared}) if (q) (void)hipFree(q);
-        part.d_rp = nullptr; part.rp_borrowed = false; part.d_nzb = nullptr; part.d_pad = nullptr; part.img.desc = nullptr; part.img.desc2 = nullptr; part.img.shared = nullptr;
+        if (!part.rp_borrowed) for (void *q : {(void *)part.d_rp, (void *)part.d_nzb, (void *)part.d_pad}) if (q) (void)hipFree(q);
+        if (!part.tables_borrowed) for (void *q : {(void *)part.img.desc, (void *)part.img.desc2, (void *)part.img.shared}) if (q) (void)hipFree(q);
+        part.d_rp = nullptr; part.rp_borrowed = false; part.tables_borrowed = false; part.d_nzb = nullptr; part.d_pad = nullptr; part.img.desc = nullptr; part.img.desc2 = nullptr; part.img.shared = nullptr;
     }
     if (h->panel_rp) { (void)hipFree(h->panel_rp); h->panel_rp = nullptr; }
+    if (h->panel_tables) { (void)hipFree(h->panel_tables); h->panel_tables = nullptr; }
 }
 
 // device side of one image: allocations and uploads for a planned part (pp = nullptr: plan here, timed into *plan_s)
