@@ -435,3 +435,37 @@ def test_power_law_stand_ins_have_their_shapes():
     key = torch.repeat_interleave(torch.arange(n), d) * n + ci
     assert bool((key[1:] > key[:-1]).all())
     assert set(va.unique().tolist()) <= set(float(v) for v in range(13))
+
+
+def test_bench_cpu_baseline_respects_the_cgroup_quota(monkeypatch, tmp_path):
+    """bench.py's CPU baseline never starts more reference threads than the container's CPU quota allows (round 5: the GPU boxes show 256 logical
+    CPUs and `cpu.max` = 1600000 100000; 64 threads were throttled in 80 % of the scheduler periods and identical pinned runs differed by a
+    factor of three).  _cpu_quota reads cgroup v2 / v1 files; no file or "max": no limit."""
+    import builtins
+    import importlib
+    import io
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    real_open = builtins.open
+    files = {}
+
+    def fake_open(path, *a, **k):
+        if isinstance(path, str) and path.startswith("/sys/fs/cgroup/"):
+            if path in files:
+                return io.StringIO(files[path])
+            raise FileNotFoundError(path)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert bench._cpu_quota() is None
+    files["/sys/fs/cgroup/cpu.max"] = "1600000 100000\n"
+    assert bench._cpu_quota() == 16
+    files["/sys/fs/cgroup/cpu.max"] = "max 100000\n"
+    assert bench._cpu_quota() is None
+    del files["/sys/fs/cgroup/cpu.max"]
+    files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "250000\n"
+    files["/sys/fs/cgroup/cpu/cpu.cfs_period_us"] = "100000\n"
+    assert bench._cpu_quota() == 2
+    files["/sys/fs/cgroup/cpu/cpu.cfs_quota_us"] = "-1\n"
+    assert bench._cpu_quota() is None
