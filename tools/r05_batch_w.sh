@@ -1,11 +1,15 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
-timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pair_list or panel or image_cache or power" > $OUT/r05_tests_w.txt 2>&1; tail -5 $OUT/r05_tests_w.txt
-: > $OUT/r05_sparse_combine.log
-timeout 900 python3 tools/helper_probe.py wikitalk 0,16,1 0,16,1,dbg_no_sparse_combine=1 2>&1 | grep -v amdgpu.ids >> $OUT/r05_sparse_combine.log
-HOLDOUT_LOG=$OUT/r05_sparse_combine.log timeout 900 python3 tools/holdout.py forum_sparse wikitalk_x2 > /dev/null 2>&1
-grep -E "^#|helpers|automatic|2 wavefronts" $OUT/r05_sparse_combine.log | cut -c1-200
+timeout 900 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -k "scatter_kernel" > $OUT/r05_tests_w.txt 2>&1; grep -E "^E  |passed|failed|FAILED" $OUT/r05_tests_w.txt | head -20 | cut -c1-300
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_wikitalk2 -- python3 $R/bench.py --workload wikitalk --steps 200 --warmup 20 --no-cpu-baseline --other-workloads none > $OUT/trace_wikitalk2.json 2>/dev/null
-grep -E "spmv_ilv|combine|fixup" $OUT/trace_wikitalk2/*/*kernel_stats.csv | awk -F'",' '{print substr($1,1,90), $2}' | cut -c1-200
+for knob in x split_unfused; do
+CVR_DEBUG=$knob rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pre_trace_lj_$knob -- python3 $R/tools/compare_csr.py livejournal > $OUT/pre_trace_lj_$knob.log 2>&1
+python3 -c "
+import csv,glob
+f=glob.glob(\"$OUT/pre_trace_lj_$knob/*/*kernel_stats.csv\")[0]
+print(\"$knob\")
+for r in csv.DictReader(open(f)):
+    if any(k in r[\"Name\"] for k in (\"part_\",\"split_\",\"DeviceScan\",\"scan\")): print(round(float(r[\"AverageNs\"])/1e3,1), r[\"Calls\"], r[\"Name\"][:80])
+"
+done
