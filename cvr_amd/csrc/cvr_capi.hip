@@ -517,6 +517,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             CREATE_TRY(l2_miss_estimate_dev(rp_d, ci_d, nrows, ncols, f32, h->stream, &miss, cvr::Scratch{h->plan_ws.dev, h->plan_ws.dev_bytes}));      // (the planner's scratch is idle until the split is done)
             P = panels_from_miss(xbytes, miss);
             rule_miss = miss;
+            if (cvr::debug_env("panel_rule_trace")) fprintf(stderr, "[cvr] panel rule: L2 miss share %.17g of the gathers in eight windows of rows -> %d panels\n", miss, P);
         } else P = auto_panels(*csr, nullptr);          // (the host rule asks both questions itself)
     }
     const double panel_rule_s = now_s() - t_rule0;          // part of the analysis: added to plan_s below

@@ -264,6 +264,39 @@ __global__ __launch_bounds__(256) void est_count_kernel(const long long *__restr
     if (bx == 0 && threadIdx.x == 0) refs[w] = (unsigned long long)(j1 - j0);
 }
 
+// The same counts without global atomics (round 5: scattered atomics run at 16-24 G/s on this chip -- 7.5 M of them were 0.38-0.47 ms of the
+// soc-LiveJournal1 shape's panel rule): workgroup (q, w) reads ALL of window w's column indices and counts the lines of its range q in LDS, then
+// stores its range of the counters.  For up to 32 ranges (what the windows' indices are re-read); wider matrices keep the atomic kernel.
+constexpr uint32_t kEstRangeLines = 16384;          // 64 KiB of LDS counters: two workgroups per CU
+__global__ __launch_bounds__(1024) void est_count_lds_kernel(const long long *__restrict__ rp, const int32_t *__restrict__ ci, const long long *__restrict__ r0,
+                                                             long long W, uint32_t per_line, long long nlines, uint32_t *__restrict__ cnt,
+                                                             unsigned long long *__restrict__ refs)
+{
+    __shared__ uint32_t c[kEstRangeLines];
+    const uint32_t  q = blockIdx.x, w = blockIdx.y, lo = q * kEstRangeLines;
+    const long long j0 = rp[r0[w]], j1 = rp[r0[w] + W];
+    for (uint32_t i = threadIdx.x; i < kEstRangeLines; i += 1024u) c[i] = 0;
+    __syncthreads();
+    // 16-byte loads, four in flight per thread (one 4-byte load at a time this pass waits for memory: 0.3 ms; eight of them: 0.19): the indices in front of
+    // the first 16-byte boundary and behind the last one go one by one
+    auto count = [&](int32_t v) { const uint32_t l = (uint32_t)v / per_line - lo; if (l < kEstRangeLines) atomicAdd(&c[l], 1u); };      // (below the range: wraps to a large number)
+    const long long ja = std::min<long long>(j1, j0 + (long long)((4u - (uint32_t)((reinterpret_cast<uintptr_t>(ci + j0) >> 2) & 3u)) & 3u)), nq = (j1 - ja) / 4, jb = ja + 4 * nq;
+    for (long long j = j0 + threadIdx.x; j < ja; j += 1024) count(ci[j]);
+    for (long long j = jb + threadIdx.x; j < j1; j += 1024) count(ci[j]);
+    const int4 *q4 = reinterpret_cast<const int4 *>(ci + ja);
+    for (long long i = threadIdx.x; i < nq; i += 1024 * 4) {
+        int4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const long long ii = i + (long long)u * 1024; v[u] = ii < nq ? q4[ii] : int4{-1, -1, -1, -1}; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (v[u].x >= 0) { count(v[u].x); count(v[u].y); count(v[u].z); count(v[u].w); }
+    }
+    __syncthreads();
+    uint32_t *out = cnt + (size_t)w * (size_t)nlines + lo;
+    for (uint32_t i = threadIdx.x; i < kEstRangeLines && (long long)lo + i < nlines; i += 1024u) out[i] = c[i];
+    if (q == 0 && threadIdx.x == 0) refs[w] = (unsigned long long)(j1 - j0);
+}
+
 // per window: how many lines were touched c times (c < kEstBins - 1), and number and sum of the larger counts
 __global__ __launch_bounds__(256) void est_hist_kernel(const uint32_t *__restrict__ cnt, long long nlines, uint32_t *__restrict__ hist,
                                                        unsigned long long *__restrict__ big)
@@ -321,13 +354,17 @@ hipError_t l2_hits_device(const int64_t *rp_dev, const int32_t *ci_dev, const in
     if (e != hipSuccess) return e;
     unsigned long long *d_refs = small, *d_big = small + nwin;
     long long          *d_r0 = reinterpret_cast<long long *>(small + 3 * nwin);
-    e = hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)nwin * (size_t)nlines, st);
+    const uint32_t nranges = (uint32_t)((nlines + kEstRangeLines - 1) / kEstRangeLines);
+    const bool     in_lds = nranges <= 32 && !cvr::debug_env("est_atomics");          // (every counter is stored by its range's workgroup: no zero fill)
+    e = in_lds ? hipSuccess : hipMemsetAsync(cnt, 0, sizeof(uint32_t) * (size_t)nwin * (size_t)nlines, st);
     if (e == hipSuccess) e = hipMemsetAsync(hist, 0, sizeof(uint32_t) * (size_t)nwin * kEstBins, st);
     if (e == hipSuccess) e = hipMemsetAsync(small, 0, sizeof(unsigned long long) * 3 * (size_t)nwin, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_r0, r0_host, sizeof(long long) * (size_t)nwin, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(est_count_kernel, dim3(512 * (uint32_t)nwin), dim3(256), 0, st, reinterpret_cast<const long long *>(rp_dev), ci_dev, d_r0, (long long)W, per_line,
-                       nlines, cnt, d_refs, (uint32_t)nwin);
+    if (in_lds) hipLaunchKernelGGL(est_count_lds_kernel, dim3(nranges, (uint32_t)nwin), dim3(1024), 0, st, reinterpret_cast<const long long *>(rp_dev), ci_dev, d_r0, (long long)W, per_line,
+                                   nlines, cnt, d_refs);
+    else hipLaunchKernelGGL(est_count_kernel, dim3(512 * (uint32_t)nwin), dim3(256), 0, st, reinterpret_cast<const long long *>(rp_dev), ci_dev, d_r0, (long long)W, per_line,
+                            nlines, cnt, d_refs, (uint32_t)nwin);
     hipLaunchKernelGGL(est_hist_kernel, dim3(64, (uint32_t)nwin), dim3(256), 0, st, cnt, nlines, hist, d_big);
     std::vector<uint32_t>           h((size_t)nwin * kEstBins);
     std::vector<unsigned long long> sm(3 * (size_t)nwin);

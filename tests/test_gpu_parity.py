@@ -169,6 +169,38 @@ def test_interleaved_column_panels_one_per_xcd(f32):
     A.close()
 
 
+def test_panel_rule_counts_lines_in_lds_or_with_atomics(monkeypatch, capfd):
+    """the panel rule's L2-miss estimate on the device counts the touched lines of x per window of rows in LDS, one workgroup per range of lines
+    (cvr_split.hip: est_count_lds_kernel), or with global atomics (CVR_DEBUG=est_atomics, and matrices of more than 32 ranges): the same counters,
+    hence the same miss share to the last digit and the same panels -- on a scattered matrix (panels) and on a banded one (none)"""
+    import torch
+    n = 3_200_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17)
+    rows = torch.arange(n, device="cuda", dtype=torch.int64).repeat_interleave(5)
+    for kind in ("scattered", "banded"):
+        if kind == "scattered":
+            cols = (n * torch.rand(len(rows), generator=g, device="cuda", dtype=torch.float64)).to(torch.int64).clamp_(0, n - 1)
+        else:
+            cols = (rows + torch.randint(-40, 41, (len(rows),), generator=g, device="cuda")).clamp_(0, n - 1)
+        key = torch.unique(rows * n + cols)
+        r = torch.div(key, n, rounding_mode="floor")
+        ci = (key - r * n).to(torch.int32).cpu().numpy()
+        rp = np.concatenate([[0], np.cumsum(torch.bincount(r, minlength=n).cpu().numpy())]).astype(np.int64)
+        va = (np.arange(len(ci)) % 13).astype(np.float64)
+        got = []
+        for knob in ("fused_trace", "fused_trace,est_atomics"):
+            monkeypatch.setenv("CVR_DEBUG", knob + ",panel_rule_trace")
+            A = cvr_amd.CvrMatrix(n, n, rp, ci, va)
+            err = capfd.readouterr().err
+            miss = [ln for ln in err.splitlines() if "L2 miss share" in ln]
+            got.append((A.info.col_panels, A.info.interleave, miss[-1] if miss else None))
+            A.close()
+        assert got[0] == got[1] and got[0][2] is not None, got
+        assert (got[0][0] > 1) == (kind == "scattered"), got
+    monkeypatch.delenv("CVR_DEBUG")
+
+
 def test_interleaved_panels_planned_again_when_the_estimate_is_low(monkeypatch, capfd):
     """the chunk length of one-per-XCD panels is chosen for whole generations of workgroups from an ESTIMATE of the chunk counts; when the
     plan has a generation more, cvr_create plans once more with longer chunks (here the estimate is scaled down to 70 % to force that)"""
