@@ -622,6 +622,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             if (opt.value_dict != 0 && sj1 > sj0 && !h->preconverted && !h->dict_scanned && h->small_clean && !cvr::debug_env("no_early_dict")) {
                 dict_stream = side_stream(h->device, 0);
                 if (dict_stream == h->stream) dict_stream = nullptr;
+                if (dict_stream && hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipGetLastError(); dict_stream = nullptr; }      // (the table's initial fill was enqueued on the handle's stream: with panels asked for, nothing has waited for it yet)
                 if (dict_stream) {
                     h->dict_tab.assign(1024, ~0ull);
                     if (enqueue_dict_scan(h, va_d, sj0, sj1, f32, true, h->dict_tab.data(), h->dict_flags, true, dict_stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(dict_stream); dict_stream = nullptr; }
