@@ -1527,14 +1527,18 @@ def test_automatic_layout_on_held_out_shapes(shape):
     f32 = va.dtype == np.float32
     x = synth.x_rand(nc, va.dtype)
     yref, absy = O.csr_spmv64(rp, ci, va.astype(np.float64), x.astype(np.float64))
-    t = {}
+    t, layout = {}, {}
     for label, kw in (("automatic", {}), ("plain", dict(H.PLAIN))):
         A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, **kw)
         y, _ = A.spmv(x)
         _assert_close(y, yref, absy, TOL32 if f32 else TOL64, (shape, label))
-        t[label] = min(A.bench(5, 50) for _ in range(2))
+        t[label] = min(A.bench(5, 50) for _ in range(3))
+        i = A.info
+        layout[label] = (i.steps_per_chunk, i.waves_per_block, i.col_panels, i.col_phases, i.x_window, i.hub_entries, i.interleave, i.value_dict, i.nchunks)
         A.close()
-    assert t["automatic"] <= 1.10 * t["plain"], (shape, t)
+    if layout["automatic"] == layout["plain"]:          # (the rules chose the plain layout itself: one code path, nothing to compare but two runs of it)
+        return
+    assert t["automatic"] <= 1.10 * t["plain"], (shape, t, layout)
 
 
 def test_bench_device_built_workload():
