@@ -60,14 +60,108 @@ __device__ __forceinline__ uint32_t part_of_chunk(const IlvTable *__restrict__ t
 // HBM, 2.0 of the 8.0 ms of the soc-LiveJournal1 shape's preprocessing, and 24 bytes of scratch per non-zero.)
 // Also desc2[k].x = the groups of chunk k that hold non-zeros (the SpMV kernel stops there).
 constexpr uint32_t kIlvF32 = 1u, kIlvDict = 2u, kIlvTag = 4u;
-template <int NT, int IPT, int RB> struct ChunkSort { typedef rocprim::block_radix_sort<uint32_t, NT, IPT, uint32_t, 1, 1, RB> type; };
+template <int NT, int IPT, int RB> struct ChunkSort { typedef rocprim::block_radix_sort<uint32_t, NT, IPT, uint32_t, 1, 1, (RB < 0 ? 0 : RB)> type; };      // (RB < 0: chunk_sort_to_striped instead)
+
+// The chunk's sort, hand-written (round 5).  rocprim's block sort keeps 32 keys, 32 values and 32 ranks per thread plus its temporaries: at 1 024
+// threads (128 registers) that spills 476 bytes per lane, and every stage of the conversion pays 1.5 x per element for the scratch traffic
+// (profiles/r05_convert_probe.log).  Here the ranks live packed two to a register (a position inside the chunk has 16 bits), there are two
+// passes of at most ten bits, and nothing else is live: a stable LSD radix sort by wavefront-wide matching --
+//   items stand wave-striped (wavefront w, item i, lane l <-> sorted index w * 64 IPT + 64 i + l); per pass every item finds the lanes of its
+//   wavefront with the same digit (one ballot per bit), the lowest of them adds their number to the wavefront's counter of that digit (LDS) and
+//   passes the old value on: rank among the wavefront's items = old value + peers in lower lanes; a scan over (digit, wavefront) turns the
+//   counters into first positions; keys and values go to their positions through LDS (one array at a time: 33 words per 32, no bank conflicts
+//   on the way back) and are read back wave-striped again, after the last pass striped over the workgroup (element e = item e / 1 024 of thread
+//   e % 1 024: what the write-out expects).
+// In: key / val blocked (thread t holds positions t IPT .. t IPT + IPT - 1).  cbits <= 20.
+// Measured (soc-LiveJournal1 shape, 444-step chunks, us per chunk; CVR_DEBUG=ilv_clocks): to wave-striped 4.3 | pass 1: ranks 23, scan 3, positions 3, moves 22 |
+// pass 2: 21, 4, 1, 19 = 100 for the sort, as rocprim's (97) -- the compiler still spills 380 bytes per lane around it (476 with rocprim) -- but the stage in
+// front of it falls from 55 to 24 us: the launch 2.52 -> 2.12 ms (CVR_DEBUG=ilv_rocprim_sort: the library sort).
+template <int IPT>
+__device__ __forceinline__ void chunk_sort_to_striped(uint32_t (&key)[IPT], uint32_t (&val)[IPT], uint8_t *smem, uint32_t cbits, unsigned long long *tclk = nullptr)
+{
+    int stamp_i = 0;
+    auto stamp = [&]() { if (tclk && threadIdx.x == 0) tclk[stamp_i] = __builtin_amdgcn_s_memrealtime(); stamp_i++; };
+    constexpr uint32_t NT = 1024, NW = 16, WI = (uint32_t)IPT * 64u;
+    uint32_t *const xch = reinterpret_cast<uint32_t *>(smem);            // [NT IPT 33 / 32]; the counters [NW][2^bits] alias it
+    uint32_t *const cnt = xch;
+    uint32_t *const wsum = xch + std::max<uint32_t>(NT * (uint32_t)IPT / 32u * 33u, NW * 1024u);          // [NW], behind both (dynamic LDS: the kernel asks for all of the CU's)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    auto pad = [](uint32_t i) { return i + (i >> 5); };
+    auto blocked_to_wave_striped = [&](uint32_t (&a)[IPT]) {
+#pragma unroll
+        for (int i = 0; i < IPT; i++) xch[pad(tid * (uint32_t)IPT + (uint32_t)i)] = a[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IPT; i++) a[i] = xch[pad(w * WI + (uint32_t)i * 64u + lane)];
+        __syncthreads();
+    };
+    stamp();
+    blocked_to_wave_striped(key);
+    blocked_to_wave_striped(val);
+    stamp();
+    auto pass = [&](uint32_t shift, uint32_t bits, bool last) {
+        const uint32_t ND = 1u << bits, dm = ND - 1u;
+        for (uint32_t j = tid; j < NW * ND; j += NT) cnt[j] = 0;
+        __syncthreads();
+        uint32_t rk[IPT / 2];
+#pragma unroll
+        for (int i = 0; i < IPT / 2; i++) rk[i] = 0;
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const uint32_t d = (key[i] >> shift) & dm;
+            unsigned long long m = ~0ull;
+            for (uint32_t bb = 0; bb < bits; bb++) { const bool one = (d >> bb) & 1u; const unsigned long long bal = __ballot(one); m &= one ? bal : ~bal; }
+            const uint32_t lower = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)), total = (uint32_t)__popcll(m);
+            uint32_t base = 0;
+            if (lower == 0) base = atomicAdd(&cnt[w * ND + d], total);
+            base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+            rk[i >> 1] |= (base + lower) << (16 * (i & 1));
+        }
+        __syncthreads();
+        stamp();
+        uint32_t run = 0;
+        if (tid < ND) for (uint32_t v = 0; v < NW; v++) { const uint32_t c = cnt[v * ND + tid]; cnt[v * ND + tid] = run; run += c; }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o); if ((int)lane >= o) incl += u; }
+        if (lane == 63u) wsum[w] = incl;
+        __syncthreads();
+        uint32_t first = incl - run;
+        for (uint32_t v = 0; v < w; v++) first += wsum[v];
+        if (tid < ND) for (uint32_t v = 0; v < NW; v++) cnt[v * ND + tid] += first;
+        __syncthreads();
+        stamp();
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const uint32_t d = (key[i] >> shift) & dm, sh = 16u * ((uint32_t)i & 1u), lr = (rk[i >> 1] >> sh) & 0xffffu;
+            const uint32_t pos = cnt[w * ND + d] + lr;
+            rk[i >> 1] = (rk[i >> 1] & ~(0xffffu << sh)) | (pos << sh);
+        }
+        __syncthreads();
+        stamp();
+        auto move = [&](uint32_t (&a)[IPT]) {
+#pragma unroll
+            for (int i = 0; i < IPT; i++) xch[pad((rk[i >> 1] >> (16 * (i & 1))) & 0xffffu)] = a[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < IPT; i++) a[i] = xch[pad(last ? (uint32_t)i * NT + tid : w * WI + (uint32_t)i * 64u + lane)];
+            __syncthreads();
+        };
+        move(val);
+        move(key);
+        stamp();
+    };
+    const uint32_t b0 = (cbits + 1u) / 2u;
+    pass(0u, b0, false);
+    pass(b0, cbits - b0, true);
+}
 
 template <int NT, int IPT, int RB>
 __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restrict__ t, const void *__restrict__ dict_v, uint32_t ndict, int G, uint32_t col_bits, uint32_t cbits,
                                                                   uint32_t flags, uint32_t *__restrict__ err, unsigned long long *__restrict__ clk)
 {
     typedef typename ChunkSort<NT, IPT, RB>::type Sort;
-    if (clk && threadIdx.x == 0) clk[blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();          // (CVR_DEBUG=ilv_clocks: the stages of a chunk on the 100-MHz counter)
+    if (clk && threadIdx.x == 0) clk[blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();          // (CVR_DEBUG=ilv_clocks: the stages of a chunk on the 100-MHz counter)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *const   rstart = reinterpret_cast<uint32_t *>(smem);       // [nri]; the sort's storage takes its place afterwards
     const bool        f32 = flags & kIlvF32, use_dict = flags & kIlvDict, tag = flags & kIlvTag;
@@ -101,9 +195,10 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
         } else { key[i] = q.pad_col; val[i] = 0xffffffffu; }
     }
     __syncthreads();
-    if (clk && threadIdx.x == 0) clk[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-    Sort().sort_to_striped(key, val, *reinterpret_cast<typename Sort::storage_type *>(smem), 0u, cbits);
-    if (clk && threadIdx.x == 0) clk[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (clk && threadIdx.x == 0) clk[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (RB < 0) chunk_sort_to_striped<IPT>(key, val, smem, cbits, clk ? clk + (size_t)blockIdx.x * 16 + 4 : nullptr);
+    else Sort().sort_to_striped(key, val, *reinterpret_cast<typename Sort::storage_type *>(smem), 0u, cbits);
+    if (clk && threadIdx.x == 0) clk[blockIdx.x * 16 + 2] = __builtin_amdgcn_s_memrealtime();
 
     // the dictionary (sorted by bit pattern, at most 256 entries) goes to LDS in the sort's place: a search per element is eight LDS reads
     uint64_t *const dl = reinterpret_cast<uint64_t *>(smem);
@@ -156,7 +251,7 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
             }
         }
     }
-    if (clk && threadIdx.x == 0) clk[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    if (clk && threadIdx.x == 0) clk[blockIdx.x * 16 + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -165,7 +260,8 @@ inline uint32_t bits_of(uint64_t v) { uint32_t b = 1; while (b < 63 && ((uint64_
 template <int NT, int IPT, int RB = 0>
 hipError_t launch_chunks(const IlvTable *d_tab, uint32_t nchunks_tot, const DeviceImage &c, uint32_t ystage_max, uint32_t cbits, uint32_t *err_flag, hipStream_t st)
 {
-    const size_t   lds = std::max(sizeof(typename ChunkSort<NT, IPT, RB>::type::storage_type), std::max<size_t>(2048, sizeof(uint32_t) * (size_t)std::max<uint32_t>(ystage_max, 1u)));
+    const size_t   sort_lds = RB < 0 ? std::max<size_t>((size_t)NT * IPT / 32 * 33 * sizeof(uint32_t), (size_t)16 * 1024 * sizeof(uint32_t)) + 256 : sizeof(typename ChunkSort<NT, IPT, RB>::type::storage_type);
+    const size_t   lds = std::max(sort_lds, std::max<size_t>(2048, sizeof(uint32_t) * (size_t)std::max<uint32_t>(ystage_max, 1u)));
     const uint32_t flags = (c.f32 ? kIlvF32 : 0u) | (c.dict ? kIlvDict : 0u) | (c.tag16 ? kIlvTag : 0u);
     static bool    attr = false;
     if (!attr) {
@@ -175,20 +271,23 @@ hipError_t launch_chunks(const IlvTable *d_tab, uint32_t nchunks_tot, const Devi
     }
     if (lds > kLdsBytes) return hipErrorInvalidValue;
     unsigned long long *clk = nullptr;
-    if (cvr::debug_env("ilv_clocks") && hipMalloc(&clk, sizeof(unsigned long long) * 4 * (size_t)nchunks_tot) != hipSuccess) { (void)hipGetLastError(); clk = nullptr; }
+    if (cvr::debug_env("ilv_clocks") && hipMalloc(&clk, sizeof(unsigned long long) * 16 * (size_t)nchunks_tot) != hipSuccess) { (void)hipGetLastError(); clk = nullptr; }
     hipLaunchKernelGGL((ilv_chunk_kernel<NT, IPT, RB>), dim3(nchunks_tot), dim3(NT), lds, st, d_tab, c.dict, c.ndict, c.G, c.col_bits, cbits, flags, err_flag, clk);
     hipError_t le = hipGetLastError();
     if (clk) {          // diagnostics: mean time per stage over the chunks, and the launch from its first stamp to its last
-        std::vector<unsigned long long> hc(4 * (size_t)nchunks_tot);
+        std::vector<unsigned long long> hc(16 * (size_t)nchunks_tot);
         if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hc.data(), clk, sizeof(unsigned long long) * hc.size(), hipMemcpyDeviceToHost) == hipSuccess) {
-            double d[3] = {0, 0, 0};
+            double d[3] = {0, 0, 0}, ds[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             unsigned long long t0 = ~0ull, t1 = 0;
             for (uint32_t k = 0; k < nchunks_tot; k++) {
-                for (int i = 0; i < 3; i++) d[i] += (double)(hc[4 * k + i + 1] - hc[4 * k + i]);
-                t0 = std::min(t0, hc[4 * k]); t1 = std::max(t1, hc[4 * k + 3]);
+                for (int i = 0; i < 3; i++) d[i] += (double)(hc[16 * k + i + 1] - hc[16 * k + i]);
+                t0 = std::min(t0, hc[16 * k]); t1 = std::max(t1, hc[16 * k + 3]);
+                if (RB < 0) for (int i = 0; i < 9; i++) ds[i] += (double)(hc[16 * k + 5 + i] - hc[16 * k + 4 + i]);
             }
-            fprintf(stderr, "[ilv_clocks] %u chunks x %d threads x %d pairs, LDS %zu: load + rows %.1f us, sort %.1f us, dictionary + write %.1f us per chunk; launch %.1f us\n", nchunks_tot, NT, IPT, lds,
+            fprintf(stderr, "[ilv_clocks] %u chunks x %d threads x %d pairs (%s), LDS %zu: load + rows %.1f us, sort %.1f us, dictionary + write %.1f us per chunk; launch %.1f us\n", nchunks_tot, NT, IPT, RB < 0 ? "own sort" : "rocprim", lds,
                     d[0] / nchunks_tot / 100.0, d[1] / nchunks_tot / 100.0, d[2] / nchunks_tot / 100.0, (double)(t1 - t0) / 100.0);
+            if (RB < 0) fprintf(stderr, "[ilv_clocks] own sort: to wave-striped %.1f | pass 1: ranks %.1f scan %.1f positions %.1f moves %.1f | pass 2: %.1f %.1f %.1f %.1f us\n", ds[0] / nchunks_tot / 100, ds[1] / nchunks_tot / 100,
+                            ds[2] / nchunks_tot / 100, ds[3] / nchunks_tot / 100, ds[4] / nchunks_tot / 100, ds[5] / nchunks_tot / 100, ds[6] / nchunks_tot / 100, ds[7] / nchunks_tot / 100, ds[8] / nchunks_tot / 100);
         }
         (void)hipFree(clk);
     }
@@ -238,6 +337,15 @@ hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const Devi
     if (rc != hipSuccess) return rc;
     // (1 024 threads leave 128 registers each: 16 (column, position) pairs per thread sort without spills, 24 spill 92 bytes, 32 spill 470;
     // 512 threads x 48 / 64 pairs spill more and ran slower: 2.8 against 2.2 ms on the soc-LiveJournal1 shape)
+    if (cbits <= 20 && !cvr::debug_env("ilv_rocprim_sort")) {          // the hand-written sort (chunk_sort_to_striped): no spills at any length
+        if (ipt <= 4) return launch_chunks<1024, 4, -1>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+        if (ipt <= 8) return launch_chunks<1024, 8, -1>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+        if (ipt <= 12) return launch_chunks<1024, 12, -1>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+        if (ipt <= 16) return launch_chunks<1024, 16, -1>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+        if (ipt <= 24) return launch_chunks<1024, 24, -1>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+        if (ipt <= 32) return launch_chunks<1024, 32, -1>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+        return launch_chunks<1024, 36, -1>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
+    }
     if (ipt <= 4) return launch_chunks<1024, 4>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 8) return launch_chunks<1024, 8>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
     if (ipt <= 12) return launch_chunks<1024, 12>(d_tab, c, c0, ystage_max, cbits, err_flag, st);
