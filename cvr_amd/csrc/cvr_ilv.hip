@@ -73,9 +73,11 @@ template <int NT, int IPT, int RB> struct ChunkSort { typedef rocprim::block_rad
 //   on the way back) and are read back wave-striped again, after the last pass striped over the workgroup (element e = item e / 1 024 of thread
 //   e % 1 024: what the write-out expects).
 // In: key / val blocked (thread t holds positions t IPT .. t IPT + IPT - 1).  cbits <= 20.
-// Measured (soc-LiveJournal1 shape, 444-step chunks, us per chunk; CVR_DEBUG=ilv_clocks): to wave-striped 4.3 | pass 1: ranks 23, scan 3, positions 3, moves 22 |
-// pass 2: 21, 4, 1, 19 = 100 for the sort, as rocprim's (97) -- the compiler still spills 380 bytes per lane around it (476 with rocprim) -- but the stage in
-// front of it falls from 55 to 24 us: the launch 2.52 -> 2.12 ms (CVR_DEBUG=ilv_rocprim_sort: the library sort).
+// Measured (soc-LiveJournal1 shape, 444-step chunks, us per chunk; CVR_DEBUG=ilv_clocks): to wave-striped 3.7 | pass 1: ranks 24, scan 3, positions 2, moves 16 |
+// pass 2: 24, 4, 3, 18 = 97 for the sort, as rocprim's (97) -- the compiler still spills 240 bytes per lane around it (476 with rocprim; 380 before the
+// digits and the padded addresses were made opaque between their uses, which kept 32 + 32 registers alive across the barriers) -- but the stage in front of
+// it falls from 55 to 24 us and the write-out from 51 to 40: the launch 2.52 -> 2.00 ms (CVR_DEBUG=ilv_rocprim_sort: the library sort).  The ranking is not
+// bound by its LDS atomics (a plain read and write per peer group instead: the same 24 us) nor by the ballots' branches (unrolled: the same).
 template <int IPT>
 __device__ __forceinline__ void chunk_sort_to_striped(uint32_t (&key)[IPT], uint32_t (&val)[IPT], uint8_t *smem, uint32_t cbits, unsigned long long *tclk = nullptr)
 {
@@ -113,7 +115,9 @@ __device__ __forceinline__ void chunk_sort_to_striped(uint32_t (&key)[IPT], uint
             for (uint32_t bb = 0; bb < bits; bb++) { const bool one = (d >> bb) & 1u; const unsigned long long bal = __ballot(one); m &= one ? bal : ~bal; }
             const uint32_t lower = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)), total = (uint32_t)__popcll(m);
             uint32_t base = 0;
-            if (lower == 0) base = atomicAdd(&cnt[w * ND + d], total);
+            // (the counters of a wavefront are its own, and the lowest lanes of the peer groups have different digits: a plain read and write --
+            // LDS operations of a wavefront execute in order -- where an atomic with return cost ~90 cycles per item and wavefront: 23 -> x us per pass)
+            if (lower == 0) { volatile uint32_t *cw = cnt + w * ND + d; base = *cw; *cw = base + total; }
             base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
             rk[i >> 1] |= (base + lower) << (16 * (i & 1));
         }
@@ -131,20 +135,24 @@ __device__ __forceinline__ void chunk_sort_to_striped(uint32_t (&key)[IPT], uint
         if (tid < ND) for (uint32_t v = 0; v < NW; v++) cnt[v * ND + tid] += first;
         __syncthreads();
         stamp();
+        uint32_t shift2 = shift;
+        asm volatile("" : "+s"(shift2));          // (opaque: the digits are computed again here, not kept in 32 registers since the ranking above)
 #pragma unroll
         for (int i = 0; i < IPT; i++) {
-            const uint32_t d = (key[i] >> shift) & dm, sh = 16u * ((uint32_t)i & 1u), lr = (rk[i >> 1] >> sh) & 0xffffu;
+            const uint32_t d = (key[i] >> shift2) & dm, sh = 16u * ((uint32_t)i & 1u), lr = (rk[i >> 1] >> sh) & 0xffffu;
             const uint32_t pos = cnt[w * ND + d] + lr;
             rk[i >> 1] = (rk[i >> 1] & ~(0xffffu << sh)) | (pos << sh);
         }
         __syncthreads();
         stamp();
         auto move = [&](uint32_t (&a)[IPT]) {
+            uint32_t zero = 0;
+            asm volatile("" : "+v"(zero));          // (opaque: the 32 padded addresses are computed per array, not kept from one array's move to the other's)
 #pragma unroll
-            for (int i = 0; i < IPT; i++) xch[pad((rk[i >> 1] >> (16 * (i & 1))) & 0xffffu)] = a[i];
+            for (int i = 0; i < IPT; i++) xch[pad(((rk[i >> 1] >> (16 * (i & 1))) & 0xffffu) + zero)] = a[i];
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < IPT; i++) a[i] = xch[pad(last ? (uint32_t)i * NT + tid : w * WI + (uint32_t)i * 64u + lane)];
+            for (int i = 0; i < IPT; i++) a[i] = xch[pad((last ? (uint32_t)i * NT + tid : w * WI + (uint32_t)i * 64u + lane) + zero)];
             __syncthreads();
         };
         move(val);
