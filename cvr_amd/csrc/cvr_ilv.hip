@@ -77,7 +77,9 @@ template <int NT, int IPT, int RB> struct ChunkSort { typedef rocprim::block_rad
 // pass 2: 24, 4, 3, 18 = 97 for the sort, as rocprim's (97) -- the compiler still spills 240 bytes per lane around it (476 with rocprim; 380 before the
 // digits and the padded addresses were made opaque between their uses, which kept 32 + 32 registers alive across the barriers) -- but the stage in front of
 // it falls from 55 to 24 us and the write-out from 51 to 40: the launch 2.52 -> 2.00 ms (CVR_DEBUG=ilv_rocprim_sort: the library sort).  The ranking is not
-// bound by its LDS atomics (a plain read and write per peer group instead: the same 24 us) nor by the ballots' branches (unrolled: the same).
+// bound by its LDS atomics (a plain read and write per peer group instead: the same 24 us) nor by the ballots' branches (unrolled: the same) nor by
+// spills (half the values parked in LDS meanwhile: the same 24 us, not kept): ~110 vector instructions per item at 4 cycles each for a 64-wide wavefront, 32 items, four
+// wavefronts per SIMD = 27 us.
 template <int IPT>
 __device__ __forceinline__ void chunk_sort_to_striped(uint32_t (&key)[IPT], uint32_t (&val)[IPT], uint8_t *smem, uint32_t cbits, unsigned long long *tclk = nullptr)
 {
