@@ -1,5 +1,9 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
-timeout 1200 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "interleav or ilv" > $OUT/r05_tests_w.txt 2>&1; grep -E "^E  |passed|failed|FAILED" $OUT/r05_tests_w.txt | head -10 | cut -c1-300
-( CVR_DEBUG=ilv_clocks timeout 900 python3 tools/compare_csr.py livejournal ) 2>&1 | grep -E "ilv_clocks|convert_device|\"total\"|result_ok" | head -5
+SECONDS=0
+bash tools/rank_emulation.sh rmat26 8 > /dev/null 2>&1; python3 -c "
+import json; d=json.load(open('gpurun_out/rank_emulation_rmat26.json')); print('rmat26', [round(x['kernel_us']) for x in d['per_rank']], d['all_rows_checked_wrong'], [x['col_panels'] for x in d['per_rank']])"
+bash tools/rank_emulation.sh banded28e6 8 > /dev/null 2>&1; python3 -c "
+import json; d=json.load(open('gpurun_out/rank_emulation_banded28e6.json')); print('banded28e6', [round(x['kernel_us']) for x in d['per_rank']], d['all_rows_checked_wrong'])"
+echo "${SECONDS}s"
