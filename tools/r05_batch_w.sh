@@ -1,9 +1,7 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
-SECONDS=0
-bash tools/rank_emulation.sh rmat26 8 > /dev/null 2>&1; python3 -c "
-import json; d=json.load(open('gpurun_out/rank_emulation_rmat26.json')); print('rmat26', [round(x['kernel_us']) for x in d['per_rank']], d['all_rows_checked_wrong'], [x['col_panels'] for x in d['per_rank']])"
-bash tools/rank_emulation.sh banded28e6 8 > /dev/null 2>&1; python3 -c "
-import json; d=json.load(open('gpurun_out/rank_emulation_banded28e6.json')); print('banded28e6', [round(x['kernel_us']) for x in d['per_rank']], d['all_rows_checked_wrong'])"
-echo "${SECONDS}s"
+: > $OUT/r05_wpb_helpers2.log
+timeout 900 python3 tools/helper_probe.py livejournal 2,24,2 3,24,2,waves_per_block=3,col_panels=16,interleave=1 4,24,2,waves_per_block=3,col_panels=16,interleave=1 4,32,2,waves_per_block=3,col_panels=16,interleave=1 6,24,2,waves_per_block=2,col_panels=16,interleave=1 2,24,2 3,24,2,waves_per_block=3,col_panels=16,interleave=1 2>&1 | grep -v amdgpu.ids >> $OUT/r05_wpb_helpers2.log
+timeout 900 python3 tools/helper_probe.py orkut 2,24,2 3,24,2,waves_per_block=3,col_panels=8,interleave=1 4,24,2,waves_per_block=3,col_panels=8,interleave=1 2,24,2 2>&1 | grep -v amdgpu.ids >> $OUT/r05_wpb_helpers2.log
+cut -c1-220 $OUT/r05_wpb_helpers2.log
