@@ -776,15 +776,17 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         CREATE_TRY(hipMemsetAsync(h->d_z, 0, vsz * (size_t)std::max<int64_t>(zoff, 1), h->stream));
         std::vector<cvr::CombinePanel> cps((size_t)P);
         std::vector<uint32_t>          block_off;
+        CREATE_TRY(hipMalloc(&h->d_rows16, sizeof(uint16_t) * (size_t)std::max<int64_t>(nsub, 1)));
         if (dev_split) {
             h->d_rows = dsg.d.rows;        // the split's row numbers are the combine pass's, as they stand
             dsg.d.rows = nullptr;
             int64_t roff = 0;
             for (int p = 0; p < P; p++) {
                 CREATE_TRY(cvr::launch_block_off(h->d_rows + roff, (uint32_t)nsubs[(size_t)p], nblocks, h->d_block_off + (size_t)p * (nblocks + 1), h->stream));
-                cps[(size_t)p] = cvr::CombinePanel{static_cast<uint8_t *>(h->d_z) + (size_t)h->parts[(size_t)p].zoff * vsz, h->d_rows + roff};
+                cps[(size_t)p] = cvr::CombinePanel{static_cast<uint8_t *>(h->d_z) + (size_t)h->parts[(size_t)p].zoff * vsz, h->d_rows16 + roff};
                 roff += nsubs[(size_t)p];
             }
+            CREATE_TRY(cvr::launch_narrow_rows(h->d_rows, (size_t)nsub, h->d_rows16, h->stream));
         } else {
             block_off.resize(nboff);
             for (int p = 0; p < P; p++) {
@@ -802,9 +804,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             for (int p = 0; p < P; p++) {
                 const Raw<uint32_t> &rows = sp.rows[(size_t)p];
                 if (rows.size()) CREATE_TRY(hipMemcpyAsync(h->d_rows + roff, rows.data(), sizeof(uint32_t) * rows.size(), hipMemcpyHostToDevice, h->stream));
-                cps[(size_t)p] = cvr::CombinePanel{static_cast<uint8_t *>(h->d_z) + (size_t)h->parts[(size_t)p].zoff * vsz, h->d_rows + roff};
+                cps[(size_t)p] = cvr::CombinePanel{static_cast<uint8_t *>(h->d_z) + (size_t)h->parts[(size_t)p].zoff * vsz, h->d_rows16 + roff};
                 roff += (int64_t)rows.size();
             }
+            CREATE_TRY(cvr::launch_narrow_rows(h->d_rows, (size_t)nsub, h->d_rows16, h->stream));
             CREATE_TRY(hipMemcpyAsync(h->d_block_off, block_off.data(), sizeof(uint32_t) * block_off.size(), hipMemcpyHostToDevice, h->stream));
         }
         in.plan_s += now_s() - t1;
@@ -1090,7 +1093,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->d_small) (void)hipFree(h->d_small);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->z_free) (void)hipEventDestroy(h->z_free);
-    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, (void *)h->d_multi, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_rows16, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, (void *)h->d_multi, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
     release_stream(h->device, h->stream);
     delete h;
     return CVR_OK;

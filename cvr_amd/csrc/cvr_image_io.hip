@@ -268,13 +268,15 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         LOAD_TRY(r.dev(h->d_block_off, pinned, pinned_bytes, h->stream, sizeof(uint32_t) * (uint64_t)nparts * (nblocks + 1)));
         LOAD_TRY(hipMalloc(&h->d_z, vsz * (size_t)std::max<int64_t>(ztotal, 1)));
         LOAD_TRY(hipMemsetAsync(h->d_z, 0, vsz * (size_t)std::max<int64_t>(ztotal, 1), h->stream));
+        LOAD_TRY(hipMalloc(&h->d_rows16, sizeof(uint16_t) * (size_t)std::max<int64_t>(nsub_all, 1)));
+        LOAD_TRY(cvr::launch_narrow_rows(h->d_rows, (size_t)nsub_all, h->d_rows16, h->stream));          // (what the combine pass reads: cvr_kernels.h, CombinePanel)
         std::vector<cvr::CombinePanel> cps(nparts);
         std::vector<cvr::FixPart>      fp(nparts);
         int64_t                        roff = 0;
         for (uint32_t i = 0; i < nparts; i++) {
             const Part &p = h->parts[i];
             uint8_t    *z = static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz;
-            cps[i] = cvr::CombinePanel{z, h->d_rows + roff};
+            cps[i] = cvr::CombinePanel{z, h->d_rows16 + roff};
             fp[i] = cvr::FixPart{p.img.shared, z, (uint32_t)p.nshared, (uint32_t)p.nrows};
             roff += p.nrows;
         }

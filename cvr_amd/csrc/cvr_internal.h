@@ -141,6 +141,7 @@ struct cvr_handle {
     // where each block of kCombineRows rows starts in every panel (combine_kernel)
     void     *d_z = nullptr;
     uint32_t *d_rows = nullptr, *d_block_off = nullptr;
+    uint16_t *d_rows16 = nullptr;          // the low halves of d_rows: what the combine pass reads (2 instead of 4 bytes per (row, panel) pair)
     int32_t  *split_ci = nullptr;          // the device split's column indices and values, panel after panel: the parts' CSR arrays are slices of these
     void     *split_va = nullptr;          // (freed with the parts' CSR: after the conversion, or with the handle when it keeps its CSR)
     void     *panel_tables = nullptr;      // the panels' chunk tables (desc, desc2, cut rows), one allocation (Part::tables_borrowed); freed with the handle

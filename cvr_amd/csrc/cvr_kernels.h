@@ -228,7 +228,8 @@ hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t ma
 // column panels: y = sum over the panels, in panel order, of their partial sums.  Panel p's partial sum u stands at z[u]
 // and belongs to row rows[u] (ascending); block_off[p * (nblocks + 1) + b] = first u of panel p with rows[u] >= b * kCombineRows.
 constexpr int kCombineRows = 1024;
-struct CombinePanel { const void *z; const uint32_t *rows; };
+struct CombinePanel { const void *z; const uint16_t *rows; };          // rows: the LOW 16 BITS of the sub-rows' row numbers (a workgroup of the pass owns at most 8 192 consecutive rows: the difference to its first row, modulo 65 536, is the row's place there)
+hipError_t launch_narrow_rows(const uint32_t *rows, size_t n, uint16_t *rows16, hipStream_t st);
 hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch = 4, int mul = 1);      // batch: panels whose loads share a round trip (4 or 8); mul: blocks of kCombineRows rows per workgroup (1 or 8)
 
 // 16-B-per-lane streaming copy (roofline calibration)

@@ -1028,11 +1028,13 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
     // averages; 178 MB of partial sums, row numbers and y: 4.9 TB/s), com-Orkut shape 684 -> 672-678 us whole.  Wider batches do not add to it
     // (16 panels x 2 or x 1 entries per thread: 275 / 267 us whole against 265 with 4 x 4 -- the registers cost more occupancy than the
     // round trips they save), nor do eight blocks per workgroup outside the mostly-empty shapes (283 us): profiles/r05_combine_tables.log.
+    // The row numbers are read as their low 16 bits (CombinePanel): 2 instead of 4 bytes per pair -- round 3 had found no gain in that when the pass waited
+    // for round trips (r03_combine_variants.log); at 4.9 TB/s it is 23 MB less of 178 on the soc-LiveJournal1 shape (36.3 -> 35.6 us).
     constexpr uint32_t kRows = (uint32_t)kCombineRows * MUL;
     __shared__ T               acc[kRows];
     __shared__ uint32_t        s_lo[kMaxSplitPanels], s_hi[kMaxSplitPanels];
     __shared__ const T        *s_z[kMaxSplitPanels];
-    __shared__ const uint32_t *s_rows[kMaxSplitPanels];
+    __shared__ const uint16_t *s_rows[kMaxSplitPanels];
     const uint32_t b = blockIdx.x * MUL, b1 = min(b + (uint32_t)MUL, nblocks), r0 = b * kCombineRows;      // the blocks [b, b1) of the tables
     if (threadIdx.x < npanels) {
         const CombinePanel cp = panels[threadIdx.x];
@@ -1049,12 +1051,12 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
             const uint32_t p = p0 + q;
             uint32_t       lo = 0, hi = 0;
             const T       *z = nullptr;
-            const uint32_t *rows = nullptr;
+            const uint16_t *rows = nullptr;
             if (p < npanels) { lo = s_lo[p]; hi = s_hi[p]; z = s_z[p]; rows = s_rows[p]; }
 #pragma unroll
             for (int e = 0; e < kEach; e++) {
                 const uint32_t u = lo + threadIdx.x + (uint32_t)e * 256u;
-                rw[q][e] = u < hi ? rows[u] : 0xffffffffu;
+                rw[q][e] = u < hi ? (uint32_t)rows[u] : 0xffffffffu;
                 v[q][e] = u < hi ? z[u] : T(0);
             }
         }
@@ -1063,11 +1065,11 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
             const uint32_t p = p0 + q;
             if (p < npanels) {                                 // (uniform)
 #pragma unroll
-                for (int e = 0; e < kEach; e++) if (rw[q][e] != 0xffffffffu) acc[rw[q][e] - r0] += v[q][e];
+                for (int e = 0; e < kEach; e++) if (rw[q][e] != 0xffffffffu) acc[(rw[q][e] - r0) & 0xffffu] += v[q][e];
                 const uint32_t  lo = s_lo[p], hi = s_hi[p];
                 const T        *z = s_z[p];
-                const uint32_t *rows = s_rows[p];
-                for (uint32_t u = lo + threadIdx.x + (uint32_t)kEach * 256u; u < hi; u += 256u) acc[rows[u] - r0] += z[u];
+                const uint16_t *rows = s_rows[p];
+                for (uint32_t u = lo + threadIdx.x + (uint32_t)kEach * 256u; u < hi; u += 256u) acc[((uint32_t)rows[u] - r0) & 0xffffu] += z[u];
             }
             __syncthreads();
         }
@@ -1140,6 +1142,20 @@ hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const ui
         }
     };
     if (f32) go(float{}); else go(double{});
+    return hipGetLastError();
+}
+
+namespace {
+__global__ __launch_bounds__(256) void narrow_rows_kernel(const uint32_t *__restrict__ rows, size_t n, uint16_t *__restrict__ rows16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) rows16[i] = (uint16_t)rows[i];
+}
+}  // namespace
+
+hipError_t launch_narrow_rows(const uint32_t *rows, size_t n, uint16_t *rows16, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(narrow_rows_kernel, dim3((uint32_t)std::min<size_t>(4096, (n + 255) / 256)), dim3(256), 0, st, rows, n, rows16);
     return hipGetLastError();
 }
 
