@@ -99,7 +99,7 @@ void ilv_runtime_settings(cvr_handle *h)
     size_t stream_all = 0, sums = 0;
     for (const Part &p : h->parts) if (p.img.ilv) { stream_all += p.stream_bytes; if (h->paneled()) sums += (size_t)p.yext * h->vsz; }
     // "does not stay": what an SpMV walks -- the image, the panels' partial sums, x and y -- against the 256 MiB of the cache.  (The rule was the image
-    // alone above 192 MiB until the soc-LiveJournal1 shape x 0.5 -- image 190 MB, partial sums 46, x and y 39: 275 MB -- turned out to run 158 us without
+    // alone above 192 MiB until the soc-LiveJournal1 shape x 0.5 -- image 181 MB, partial sums 38, x and y 39: 259 MB -- turned out to run 158 us without
     // helpers and 129 with; x 0.45 -- 232 MB -- 139.5 and 125.5; x 0.4 -- 228 MB, one generation of workgroups -- 89.3 and 90.3: profiles/r05_helper_threshold*.log.
     // The line is drawn at 230 MB: what the cache keeps of a walk is less than its 268 MB.)
     const size_t walked = stream_all + sums + (size_t)(h->info.ncols + h->info.nrows) * h->vsz;
