@@ -114,7 +114,7 @@ void ilv_runtime_settings(cvr_handle *h)
         p.img.ilv_ahead = (e = cvr::debug_env("ilv_ahead")) ? (uint32_t)std::max(1, atoi(e)) : 24u;
         p.img.ilv_flip = (e = cvr::debug_env("ilv_flip")) ? (uint32_t)std::max(0, atoi(e)) : big ? 1u : 0u;
     }
-    if (const char *e = cvr::debug_env("combine_batch")) { const int v = atoi(e); h->combine_batch = v == 8 || v == 16 || v == 17 ? v : 4; }
+    if (const char *e = cvr::debug_env("combine_batch")) { const int v = atoi(e); h->combine_batch = v == 8 || (v >= 9 && v <= 12) || v == 16 || v == 17 ? v : 4; }
     // the combine pass of a matrix whose rows are mostly empty (fewer partial sums over all panels than rows): eight blocks of rows per workgroup,
     // the loads of eight panels per round trip (combine_kernel)
     if (h->paneled()) {
@@ -123,7 +123,10 @@ void ilv_runtime_settings(cvr_handle *h)
         const bool sparse = pairs < h->info.nrows;
         const char *e = cvr::debug_env("combine_mul");
         h->combine_mul = e ? (atoi(e) == 8 ? 8 : 1) : sparse ? 8 : 1;
-        if (!cvr::debug_env("combine_batch") && sparse && h->parts.size() <= 8) h->combine_batch = 8;
+        // (and workgroups of 1 024 threads with one entry per thread and panel: a workgroup's eight blocks hold a few hundred sums per panel and 64 KB of y to
+        // write, with about one workgroup per CU -- 256 threads left most of the CU's memory pipeline idle: wiki-Talk shape 35.5 -> 33.8 us, x 2 61.3 -> 53.7,
+        // the forum-like hold-out shape 54.3 -> 52.2: profiles/r05_sparse_combine_threads.log; launch_combine: 9 = eight panels per round trip, 12 = sixteen)
+        if (!cvr::debug_env("combine_batch") && sparse) h->combine_batch = h->parts.size() <= 8 ? 9 : 12;
     }
 }
 

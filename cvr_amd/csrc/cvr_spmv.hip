@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void fixup_kernel(const in
 // wiki-Talk shape: 6 % of the rows hold all the non-zeros -- a block of 1 024 rows has a few dozen partial sums per panel and the pass is
 // all launch and round-trip latency (2 339 workgroups, 13.7 us); with MUL = 8 a workgroup has eight times the entries per round trip and
 // there are an eighth of the workgroups.
-template <typename T, int kBatch, int kEach, int MUL>
-__global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off,
+template <typename T, int kBatch, int kEach, int MUL, int NT = 256>
+__global__ __launch_bounds__(NT) void combine_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off,
                                                       uint32_t nblocks, T *__restrict__ y, uint32_t nrows)
 {
     // The loads of kBatch panels are issued together (kEach entries per thread and panel in registers), then added panel by panel:
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
             if (p < npanels) { lo = s_lo[p]; hi = s_hi[p]; z = s_z[p]; rows = s_rows[p]; }
 #pragma unroll
             for (int e = 0; e < kEach; e++) {
-                const uint32_t u = lo + threadIdx.x + (uint32_t)e * 256u;
+                const uint32_t u = lo + threadIdx.x + (uint32_t)e * (uint32_t)NT;
                 rw[q][e] = u < hi ? (uint32_t)rows[u] : 0xffffffffu;
                 v[q][e] = u < hi ? z[u] : T(0);
             }
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const CombinePanel *__rest
                 const uint32_t  lo = s_lo[p], hi = s_hi[p];
                 const T        *z = s_z[p];
                 const uint16_t *rows = s_rows[p];
-                for (uint32_t u = lo + threadIdx.x + (uint32_t)kEach * 256u; u < hi; u += 256u) acc[((uint32_t)rows[u] - r0) & 0xffffu] += z[u];
+                for (uint32_t u = lo + threadIdx.x + (uint32_t)kEach * (uint32_t)NT; u < hi; u += (uint32_t)NT) acc[((uint32_t)rows[u] - r0) & 0xffffu] += z[u];
             }
             __syncthreads();
         }
@@ -1128,10 +1128,15 @@ hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const ui
     auto go = [&](auto real) {
         using T = decltype(real);
         T *yt = static_cast<T *>(y);
-        // batch: 4 / 8 = that many panels per round trip with four entries per thread each; 16 / 17 = sixteen panels with two / one
+        // batch: 4 / 8 = that many panels per round trip with four entries per thread each; 16 / 17 = sixteen panels with two / one; 9 - 12 (eight blocks per
+        // workgroup only): 1 024 or 512 threads -- 9 = 8 panels x 1 entry x 1 024 threads, 10 = 8 x 2 x 1 024, 11 = 8 x 2 x 512, 12 = 16 x 1 x 1 024
         if (mul == 8) {
             const uint32_t grid = (nblocks + 7) / 8;
             if (batch >= 16) hipLaunchKernelGGL((combine_kernel<T, 16, 2, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else if (batch == 9) hipLaunchKernelGGL((combine_kernel<T, 8, 1, 8, 1024>), dim3(grid), dim3(1024), 0, st, panels, npanels, block_off, nblocks, yt, nrows);      // (1 024 threads for the eight blocks)
+            else if (batch == 10) hipLaunchKernelGGL((combine_kernel<T, 8, 2, 8, 1024>), dim3(grid), dim3(1024), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else if (batch == 11) hipLaunchKernelGGL((combine_kernel<T, 8, 2, 8, 512>), dim3(grid), dim3(512), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            else if (batch == 12) hipLaunchKernelGGL((combine_kernel<T, 16, 1, 8, 1024>), dim3(grid), dim3(1024), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
             else if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
             else hipLaunchKernelGGL((combine_kernel<T, 4, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
         } else {
