@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(kLanes * kWavesPerBlock) void fixup_kernel(const in
 // there are an eighth of the workgroups.
 template <typename T, int kBatch, int kEach, int MUL, int NT = 256>
 __global__ __launch_bounds__(NT) void combine_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off,
-                                                      uint32_t nblocks, T *__restrict__ y, uint32_t nrows)
+                                                      uint32_t nblocks, T *__restrict__ y, uint32_t nrows, uint32_t plain_store)
 {
     // The loads of kBatch panels are issued together (kEach entries per thread and panel in registers), then added panel by panel:
     // one memory round trip per batch instead of one per panel in front of every barrier (16 panels: 54 -> 3x us on the
@@ -1074,7 +1074,9 @@ __global__ __launch_bounds__(NT) void combine_kernel(const CombinePanel *__restr
             __syncthreads();
         }
     }
-    for (uint32_t i = threadIdx.x; i < kRows && r0 + i < nrows; i += blockDim.x) y[r0 + i] = acc[i];
+    // y is written past the caches (nontemporal): nobody on this chip reads it before the caller does, and it need not displace x or the image there
+    if (plain_store) for (uint32_t i = threadIdx.x; i < kRows && r0 + i < nrows; i += blockDim.x) y[r0 + i] = acc[i];
+    else for (uint32_t i = threadIdx.x; i < kRows && r0 + i < nrows; i += blockDim.x) __builtin_nontemporal_store(acc[i], &y[r0 + i]);
 }
 
 // plain streaming copy: the achievable-HBM-rate yardstick beside the 8 TB/s nominal peak.  Four independent
@@ -1125,6 +1127,7 @@ hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const ui
 {
     if (nrows == 0) return hipSuccess;
     const uint32_t nblocks = (nrows + kCombineRows - 1) / kCombineRows;
+    const uint32_t plain = cvr::debug_env("combine_plain_store") ? 1u : 0u;
     auto go = [&](auto real) {
         using T = decltype(real);
         T *yt = static_cast<T *>(y);
@@ -1132,18 +1135,18 @@ hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const ui
         // workgroup only): 1 024 or 512 threads -- 9 = 8 panels x 1 entry x 1 024 threads, 10 = 8 x 2 x 1 024, 11 = 8 x 2 x 512, 12 = 16 x 1 x 1 024
         if (mul == 8) {
             const uint32_t grid = (nblocks + 7) / 8;
-            if (batch >= 16) hipLaunchKernelGGL((combine_kernel<T, 16, 2, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else if (batch == 9) hipLaunchKernelGGL((combine_kernel<T, 8, 1, 8, 1024>), dim3(grid), dim3(1024), 0, st, panels, npanels, block_off, nblocks, yt, nrows);      // (1 024 threads for the eight blocks)
-            else if (batch == 10) hipLaunchKernelGGL((combine_kernel<T, 8, 2, 8, 1024>), dim3(grid), dim3(1024), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else if (batch == 11) hipLaunchKernelGGL((combine_kernel<T, 8, 2, 8, 512>), dim3(grid), dim3(512), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else if (batch == 12) hipLaunchKernelGGL((combine_kernel<T, 16, 1, 8, 1024>), dim3(grid), dim3(1024), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else hipLaunchKernelGGL((combine_kernel<T, 4, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            if (batch >= 16) hipLaunchKernelGGL((combine_kernel<T, 16, 2, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
+            else if (batch == 9) hipLaunchKernelGGL((combine_kernel<T, 8, 1, 8, 1024>), dim3(grid), dim3(1024), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);      // (1 024 threads for the eight blocks)
+            else if (batch == 10) hipLaunchKernelGGL((combine_kernel<T, 8, 2, 8, 1024>), dim3(grid), dim3(1024), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
+            else if (batch == 11) hipLaunchKernelGGL((combine_kernel<T, 8, 2, 8, 512>), dim3(grid), dim3(512), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
+            else if (batch == 12) hipLaunchKernelGGL((combine_kernel<T, 16, 1, 8, 1024>), dim3(grid), dim3(1024), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
+            else if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
+            else hipLaunchKernelGGL((combine_kernel<T, 4, 4, 8>), dim3(grid), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
         } else {
-            if (batch == 17) hipLaunchKernelGGL((combine_kernel<T, 16, 1, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else if (batch == 16) hipLaunchKernelGGL((combine_kernel<T, 16, 2, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 4, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
-            else hipLaunchKernelGGL((combine_kernel<T, 4, 4, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows);
+            if (batch == 17) hipLaunchKernelGGL((combine_kernel<T, 16, 1, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
+            else if (batch == 16) hipLaunchKernelGGL((combine_kernel<T, 16, 2, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
+            else if (batch == 8) hipLaunchKernelGGL((combine_kernel<T, 8, 4, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
+            else hipLaunchKernelGGL((combine_kernel<T, 4, 4, 1>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, yt, nrows, plain);
         }
     };
     if (f32) go(float{}); else go(double{});
