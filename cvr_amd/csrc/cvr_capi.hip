@@ -113,6 +113,7 @@ void ilv_runtime_settings(cvr_handle *h)
         p.img.ilv_per_line = (e = cvr::debug_env("ilv_per_line")) ? (uint32_t)std::max(1, atoi(e)) : 2u;
         p.img.ilv_ahead = (e = cvr::debug_env("ilv_ahead")) ? (uint32_t)std::max(1, atoi(e)) : 24u;
         p.img.ilv_flip = (e = cvr::debug_env("ilv_flip")) ? (uint32_t)std::max(0, atoi(e)) : big ? 1u : 0u;
+        p.img.ilv_stream_nt = (e = cvr::debug_env("ilv_stream_nt")) ? (uint32_t)std::max(0, atoi(e)) : big ? 1u : 0u;          // (and the stream past the caches: cvr_spmv.hip, ring_ld128s)
     }
     if (const char *e = cvr::debug_env("combine_batch")) { const int v = atoi(e); h->combine_batch = v == 8 || (v >= 9 && v <= 12) || v == 16 || v == 17 ? v : 4; }
     // the combine pass of a matrix whose rows are mostly empty (fewer partial sums over all panels than rows): eight blocks of rows per workgroup,

@@ -765,6 +765,24 @@ template <int R> __device__ __forceinline__ void ring_ld32(uint32_t voff, __amdg
 {
     asm volatile("buffer_load_dword v[%0], %1, %2, %3 offen" ::"n"(R), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
+// the same for the matrix stream; NT: non-temporal -- for images too large to stay in the caches from one SpMV to the next, so that the stream's lines leave an
+// L2 before its panel's slice of x does (soc-LiveJournal1 shape 256.1 -> 252.4 us, com-Orkut shape 678 -> 658; an image that does stay -- wiki-Talk -- is evicted
+// by it: 33.6 -> 39.3 us; profiles/r05_stream_nt.log).  The modifier is part of the instruction: two instantiations of the kernel.
+template <int R, bool NT> __device__ __forceinline__ void ring_ld128s(uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff)
+{
+    if constexpr (NT) asm volatile("buffer_load_dwordx4 v[%0:%1], %2, %3, %4 offen nt" ::"n"(R), "n"(R + 3), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    else asm volatile("buffer_load_dwordx4 v[%0:%1], %2, %3, %4 offen" ::"n"(R), "n"(R + 3), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int R, bool NT> __device__ __forceinline__ void ring_ld64s(uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff)
+{
+    if constexpr (NT) asm volatile("buffer_load_dwordx2 v[%0:%1], %2, %3, %4 offen nt" ::"n"(R), "n"(R + 1), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    else asm volatile("buffer_load_dwordx2 v[%0:%1], %2, %3, %4 offen" ::"n"(R), "n"(R + 1), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int R, bool NT> __device__ __forceinline__ void ring_ld32s(uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff)
+{
+    if constexpr (NT) asm volatile("buffer_load_dword v[%0], %1, %2, %3 offen nt" ::"n"(R), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    else asm volatile("buffer_load_dword v[%0], %1, %2, %3 offen" ::"n"(R), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
 template <int R> __device__ __forceinline__ uint32_t ring_get()
 {
     uint32_t v;
@@ -803,7 +821,7 @@ template <int REGS> __device__ __forceinline__ void ring_claim()          // (th
 // The scalar data cache is a second path from the CU to the L2: `nw_compute` < blockDim / 64 makes the workgroup's other wavefronts HELPERS
 // that touch the lines of their chunk's stream with s_load a few groups ahead of the computing wavefront's buffer loads (paced by a
 // progress word the computing wavefront keeps in LDS), so that those find their lines in the L2.  Helpers read no data and write nothing.
-template <typename T, bool DICT, bool TAG>
+template <typename T, bool DICT, bool TAG, bool SNT>
 __global__ __launch_bounds__((RingLayout<T, DICT, TAG>::THREADS)) __attribute__((amdgpu_num_vgpr(kRingCap))) void spmv_ilv_kernel(
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint2 *__restrict__ desc2_a, const T *__restrict__ x, T *__restrict__ yext_a, int G_alloc,
     uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes_a, const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, uint32_t col_bits,
@@ -864,11 +882,11 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG>::THREADS)) __attribute__(
         // (the group's offset goes into the VECTOR offset: the buffer's range check covers that one only, not the scalar offset -- a
         // load past the chunk's last group must not reach memory, the ring runs up to 4 D - 1 groups ahead)
         const uint32_t so = grp * GB;
-        ring_ld128<R>(vo_c + so, rs, 0u);
-        if constexpr (TAG) ring_ld64<R + L::TOFF>(vo_t + so, rs, 0u);
-        if constexpr (DICT) ring_ld32<R + L::VOFF>(vo_code + so, rs, 0u);
-        else if constexpr (sizeof(T) == 8) { ring_ld128<R + L::VOFF>(vo_v0 + so, rs, 0u); ring_ld128<R + L::VOFF + 4>(vo_v1 + so, rs, 0u); }
-        else ring_ld128<R + L::VOFF>(vo_v0 + so, rs, 0u);
+        ring_ld128s<R, SNT>(vo_c + so, rs, 0u);
+        if constexpr (TAG) ring_ld64s<R + L::TOFF, SNT>(vo_t + so, rs, 0u);
+        if constexpr (DICT) ring_ld32s<R + L::VOFF, SNT>(vo_code + so, rs, 0u);
+        else if constexpr (sizeof(T) == 8) { ring_ld128s<R + L::VOFF, SNT>(vo_v0 + so, rs, 0u); ring_ld128s<R + L::VOFF + 4, SNT>(vo_v1 + so, rs, 0u); }
+        else ring_ld128s<R + L::VOFF, SNT>(vo_v0 + so, rs, 0u);
     };
     // run-in, first half: the stream of the first D groups (through the allocation's descriptor: the count of groups that hold non-zeros
     // is one of the loads in flight; groups behind it are padding of the chunk's own allocation)
@@ -1230,8 +1248,10 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                     using L = RingLayout<T, kDict, decltype(TG)::value>;
                     const uint32_t room = (uint32_t)L::THREADS / kLanes, hmax = room / wpb > 0 ? room / wpb - 1u : 0u;
                     const uint32_t H = std::min<uint32_t>(hmax, img.ilv_helpers);
-                    hipLaunchKernelGGL((spmv_ilv_kernel<T, kDict, decltype(TG)::value>), dim3(grid), dim3(kLanes * wpb * (1u + H)), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
-                                       img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi, wpb, img.ilv_ahead, img.ilv_per_line, img.flip_now);
+                    with_flag(img.ilv_stream_nt != 0, [&](auto SN) {
+                        hipLaunchKernelGGL((spmv_ilv_kernel<T, kDict, decltype(TG)::value, decltype(SN)::value>), dim3(grid), dim3(kLanes * wpb * (1u + H)), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
+                                           img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi, wpb, img.ilv_ahead, img.ilv_per_line, img.flip_now);
+                    });
                 });
             } else if (img.phases > 1) {    // column phases: every piece carries its row
                 with_flag(img.tag16, [&](auto TG) { with_flag(use_win, [&](auto WI) { with_flag(loaders > 0, [&](auto LD) {

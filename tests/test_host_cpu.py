@@ -229,7 +229,7 @@ def test_ring_kernel_isa_guard():
         pytest.skip("no hipcc")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "cvr_amd", "csrc"), "isa-check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "isa_check: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("vgpr spills 0") == 8          # every instantiation was looked at
+    assert r.stdout.count("vgpr spills 0") == 16         # every instantiation was looked at (value type x dictionary x 16-bit tags x non-temporal stream loads)
     env = dict(os.environ, HIPCC_EXTRA="-DCVR_RING_CAP=24")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "cvr_amd", "csrc"), "isa-check"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and "isa_check: FAIL" in r.stdout, r.stdout[-3000:]

@@ -147,7 +147,7 @@ def check(path, expected):
 
 
 def main():
-    expected = int(os.environ.get("ISA_CHECK_EXPECTED", "8"))          # float / double x dictionary x 16-bit tags
+    expected = int(os.environ.get("ISA_CHECK_EXPECTED", "16"))          # float / double x dictionary x 16-bit tags x non-temporal stream loads
     path = sys.argv[1] if len(sys.argv) > 1 else compile_to_asm()
     errors = check(path, expected)
     for e in errors[:40]:

@@ -1,9 +1,12 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
-for w in wikitalk livejournal orkut; do for k in x z_plain_store x z_plain_store; do CVR_DEBUG=$k python3 bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline --other-workloads none 2>/dev/null | python3 -c "
+timeout 2400 python3 -m pytest tests -m gpu -x -q > $OUT/r05_gpu_suite_y.txt 2>&1; grep -E "passed|failed" $OUT/r05_gpu_suite_y.txt | tail -2
+for w in livejournal orkut wikitalk; do python3 bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline --other-workloads none 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('$w', '$k', round(d['roofline']['kernel_us'], 2), round(d['roofline']['frac'], 4), d['verdict_wrong_rows'])
-"; done; done | tee $OUT/r05_z_nontemporal.log
+        d = json.loads(l); print('$w', round(d['roofline']['kernel_us'], 2), round(d['roofline']['frac'], 4), d['verdict_wrong_rows'])
+"; done
+rm -f $OUT/r05_holdout_end3.log
+HOLDOUT_LOG=$OUT/r05_holdout_end3.log timeout 2400 python3 tools/holdout.py > /dev/null 2>&1; grep -E "^# " $OUT/r05_holdout_end3.log | tail -15 | cut -c1-200
