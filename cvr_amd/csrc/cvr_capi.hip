@@ -104,6 +104,13 @@ void ilv_runtime_settings(cvr_handle *h)
     // The line is drawn at 230 MB: what the cache keeps of a walk is less than its 268 MB.)
     const size_t walked = stream_all + sums + (size_t)(h->info.ncols + h->info.nrows) * h->vsz;
     const bool   big = walked > (size_t)230000000;
+    {   // the same question for images with a hub table (spmv_kernel, WIN == 3: cvr_spmv.hip)
+        size_t hub_stream = 0, hub_sums = 0;
+        for (const Part &p : h->parts) if (p.img.hub_n) { hub_stream += p.stream_bytes; if (h->paneled()) hub_sums += (size_t)p.yext * h->vsz; }
+        const char *e = cvr::debug_env("ilv_stream_nt");
+        for (Part &p : h->parts)
+            if (p.img.hub_n && !p.img.ilv) p.img.ilv_stream_nt = e ? (uint32_t)std::max(0, atoi(e)) : hub_stream + hub_sums + (size_t)(h->info.ncols + h->info.nrows) * h->vsz > (size_t)230000000 ? 1u : 0u;
+    }
     if (cvr::debug_env("fused_trace") && stream_all) fprintf(stderr, "[cvr] interleaved image: stream %.0f MB + partial sums %.0f MB + x, y %.0f MB = %.0f MB walked per SpMV: helper wavefronts %s\n", stream_all / 1e6, sums / 1e6,
                                                                   (double)(h->info.ncols + h->info.nrows) * h->vsz / 1e6, walked / 1e6, big ? "on" : "off");
     for (Part &p : h->parts) {

@@ -47,7 +47,7 @@ struct DeviceImage {
     uint32_t  ilv_helpers = 0, ilv_ahead = 16, ilv_per_line = 1;
     uint32_t  stream_mod = 0;       // profiling only (CVR_DEBUG=stream_mod=M): every chunk streams the image of chunk k % M (L2-resident stream, wrong sums)
     uint32_t  ilv_flip = 0;         // interleaved: 1 = every other SpMV walks the workgroups in reverse order (what the last one streamed last is still in the Infinity Cache); set per launch
-    uint32_t  ilv_stream_nt = 0; // interleaved: the stream is loaded non-temporally (images that do not stay in the caches between SpMVs: ilv_runtime_settings)
+    uint32_t  ilv_stream_nt = 0; // interleaved images and images with a hub table: the stream is loaded non-temporally (images that do not stay in the caches between SpMVs: ilv_runtime_settings)
     uint32_t  flip_now = 0;      // interleaved: helper wavefronts per chunk (scalar prefetch of the stream), how many groups ahead, loads per line
     uint32_t  piece_max = 0;        // column phases: (row, phase) segments are cut into pieces at the multiples of this many elements from the chunk's first (0 = whole segments)
     uint32_t  col_bits = 31;        // column phases: the LAST column word of a segment carries the chunk's row of the segment

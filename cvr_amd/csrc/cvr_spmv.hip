@@ -305,7 +305,9 @@ __global__ __launch_bounds__(MW ? kLanes * kMaxWavesPerBlock : kLanes) void spmv
 
     // software pipeline: the x gather runs DEPTH groups ahead of the FMAs, the matrix stream QA groups ahead of the gather
     constexpr int  QN = DEPTH + QA;
-    constexpr int  SPOL = kPolDefault;
+    // (WIN == 3: the hub-table kernel of an image that does not stay in the caches between SpMVs loads its stream non-temporally, so that it leaves the
+    // L2s before x does: R-MAT-22 fp32 293 -> 271 us, R-MAT-24 1 197 -> 1 133; the plain kernel of a banded matrix LOSES by it, 178 -> 197: profiles/r05_stream_nt_hub.log)
+    constexpr int  SPOL = WIN == 3 ? 2 : kPolDefault;
     Group<T, DICT> Q[QN];
     X4<T>          xs[DEPTH];
     __amdgpu_buffer_rsrc_t rs;
@@ -1279,7 +1281,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                                            x, y, img.G, img.nchunks, per, swz, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems, dict, img.ndict, img.ystage, static_cast<const T *>(img.hub_x),
                                            img.hub_n, kstride, img.cbase, img.pad_col, multi, img.stream_mod);
                     };
-                    if (use_win && img.hub_n) go(std::integral_constant<int, 2>{}); else if (use_win) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 0>{});
+                    if (use_win && img.hub_n && img.ilv_stream_nt) go(std::integral_constant<int, 3>{}); else if (use_win && img.hub_n) go(std::integral_constant<int, 2>{}); else if (use_win) go(std::integral_constant<int, 1>{}); else go(std::integral_constant<int, 0>{});
                 });
             }
         });
