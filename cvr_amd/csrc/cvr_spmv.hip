@@ -1076,8 +1076,13 @@ __global__ __launch_bounds__(NT) void combine_kernel(const CombinePanel *__restr
 #pragma unroll
             for (int e = 0; e < kEach; e++) {
                 const uint32_t u = lo + threadIdx.x + (uint32_t)e * (uint32_t)NT;
-                rw[q][e] = u < hi ? (uint32_t)rows[u] : 0xffffffffu;
-                v[q][e] = u < hi ? z[u] : T(0);
+                if (plain_store & 2u) {
+                    rw[q][e] = u < hi ? (uint32_t)rows[u] : 0xffffffffu;
+                    v[q][e] = u < hi ? z[u] : T(0);
+                } else {          // (read once: past the caches -- level on the soc-LiveJournal1 and com-Orkut shapes, wiki-Talk 34.8 -> 33.8 us: profiles/r05_combine_nontemporal.log)
+                    rw[q][e] = u < hi ? (uint32_t)__builtin_nontemporal_load(rows + u) : 0xffffffffu;
+                    v[q][e] = u < hi ? __builtin_nontemporal_load(z + u) : T(0);
+                }
             }
         }
 #pragma unroll
@@ -1095,7 +1100,7 @@ __global__ __launch_bounds__(NT) void combine_kernel(const CombinePanel *__restr
         }
     }
     // y is written past the caches (nontemporal): nobody on this chip reads it before the caller does, and it need not displace x or the image there
-    if (plain_store) for (uint32_t i = threadIdx.x; i < kRows && r0 + i < nrows; i += blockDim.x) y[r0 + i] = acc[i];
+    if (plain_store & 1u) for (uint32_t i = threadIdx.x; i < kRows && r0 + i < nrows; i += blockDim.x) y[r0 + i] = acc[i];
     else for (uint32_t i = threadIdx.x; i < kRows && r0 + i < nrows; i += blockDim.x) __builtin_nontemporal_store(acc[i], &y[r0 + i]);
 }
 
@@ -1147,7 +1152,7 @@ hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const ui
 {
     if (nrows == 0) return hipSuccess;
     const uint32_t nblocks = (nrows + kCombineRows - 1) / kCombineRows;
-    const uint32_t plain = cvr::debug_env("combine_plain_store") ? 1u : 0u;
+    const uint32_t plain = (cvr::debug_env("combine_plain_store") ? 1u : 0u) | (cvr::debug_env("combine_plain_loads") ? 2u : 0u);
     auto go = [&](auto real) {
         using T = decltype(real);
         T *yt = static_cast<T *>(y);

@@ -2,16 +2,10 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
 timeout 2400 python3 -m pytest tests -m gpu -x -q > $OUT/r05_gpu_suite_y.txt 2>&1; grep -E "passed|failed" $OUT/r05_gpu_suite_y.txt | tail -2
-for w in rmat22 rmat24 rmat26 rmat20; do python3 bench.py --workload $w --steps 100 --warmup 20 --no-cpu-baseline --other-workloads none 2>/dev/null | python3 -c "
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+for w in wikitalk livejournal; do python3 bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline --other-workloads none 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); print('$w', round(d['roofline']['kernel_us'], 2), round(d['roofline']['frac'], 4), d['verdict_wrong_rows'])
 "; done
-for k in x ilv_stream_nt=0; do CVR_DEBUG=$k python3 bench.py --workload rmat20 --steps 200 --warmup 20 --no-cpu-baseline --other-workloads none 2>/dev/null | python3 -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); print('rmat20', '$k', round(d['roofline']['kernel_us'], 2), round(d['roofline']['frac'], 4), d['verdict_wrong_rows'])
-"; done
-HOLDOUT_LOG=/dev/null timeout 900 python3 tools/holdout.py rmat21b 2>&1 | grep -E "automatic|plain  |hub table|->" | cut -c1-200
