@@ -1,12 +1,9 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
-cp cvr_amd/libcvr_amd.so /tmp/plain.so; cp cvr_amd/libcvr_amd_A.so /tmp/A.so; cp cvr_amd/libcvr_amd_B.so /tmp/B.so
-run() { python3 bench.py --workload $1 --steps 200 --warmup 20 --no-cpu-baseline --other-workloads none 2>/dev/null | python3 -c "
+for w in livejournal orkut; do for k in x ilv_flip=0 ilv_helpers=3 ilv_helpers=1 ilv_ahead=16 ilv_ahead=32 x; do CVR_DEBUG=$k python3 bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline --other-workloads none 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('$1', '$2', round(d['roofline']['kernel_us'], 2), round(d['roofline']['frac'], 4), d['verdict_wrong_rows'])
-"; }
-for rep in 1 2; do for v in plain A; do cp /tmp/$v.so cvr_amd/libcvr_amd.so; run webgoogle $v; done; for v in plain B; do cp /tmp/$v.so cvr_amd/libcvr_amd.so; run rmat22 $v; done; done | tee $OUT/r05_policy_probe.log
-cp /tmp/plain.so cvr_amd/libcvr_amd.so
+        d = json.loads(l); print('$w', '$k', round(d['roofline']['kernel_us'], 2), round(d['roofline']['frac'], 4), d['verdict_wrong_rows'])
+"; done; done | tee $OUT/r05_helpers_with_nt.log
