@@ -665,9 +665,11 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if constexpr (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pc[3] = prof_now(); }
     if (!epi.out) {
+        // (y leaves past the caches -- nontemporal: nobody on the chip reads it before the caller does, and its 7 MB need not displace x or the window's
+        // lines in the L2s for the next SpMV: 21.05 -> 20.69 us on the web-Google shape, same box, three pairs of runs: profiles/r05_headline_nt_store.log)
         for (uint32_t i = lane; i < nri; i += kLanes) {
             const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
-            store_y(yext + dst, ystage[i]);
+            __builtin_nontemporal_store(ystage[i], yext + dst);
         }
         if constexpr (PROF) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the stores have left the wavefront; the kernel's end also waits for the L2's write-back)
