@@ -41,6 +41,16 @@ def main():
         rp, ci, va = rp_t.cpu().numpy(), ci_t.cpu().numpy(), va_t.cpu().numpy()
         del rp_t, ci_t, va_t
         f32 = True
+    elif which in ("orkut", "wikitalk"):
+        import torch
+        from cvr_amd import synth_dev as D
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        sc = float(os.environ.get("PROBE_SCALE", "1.0"))
+        n, rp_t, ci_t, va_t = (D.orkut_like if which == "orkut" else D.wikitalk_like)(scale=sc, device=dev)
+        nc = n
+        rp, ci, va = rp_t.cpu().numpy(), ci_t.cpu().numpy(), va_t.cpu().numpy()
+        del rp_t, ci_t, va_t
+        torch.cuda.empty_cache() if dev == "cuda" else None
     else:
         fn = getattr(synth, which)
         n, nc, rp, ci, va = fn()
@@ -48,13 +58,17 @@ def main():
     path = f"/tmp/{which}.csr"
     write_csr(path, n, nc, rp, ci, va, f32)
     print(f"# {which}: {n} x {nc}, nnz {len(ci)}, built + written in {time.time() - t0:.1f} s", flush=True)
-    exe = os.path.join(ROOT, "tools", "ubench", "sorted_spmv")
     for c in cfgs:
         a = c.split()
+        env = dict(os.environ)
+        while a and "=" in a[0]:                       # leading NAME=value tokens: the run's environment (TOK_U=2, EXE=sorted_spmv_nt, SAME_STREAM=8 ...)
+            k, v = a.pop(0).split("=", 1)
+            env[k] = v
+        exe = os.path.join(ROOT, "tools", "ubench", env.get("EXE", "sorted_spmv"))
         R, W, S, P, mode, depth = a[:6]
         rest = a[6:]
         cmd = [exe, path, "f32" if f32 else "f64", R, W, S, P, mode, depth, "50"] + rest
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
         print(f"## {c}\n{r.stdout}{r.stderr[-2000:] if r.returncode else ''}", flush=True)
 
 

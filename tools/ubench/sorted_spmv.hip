@@ -196,6 +196,11 @@ __global__ __launch_bounds__(1024) void sorted_spmv_kernel(const uint8_t *__rest
 // here (a compiler-issued one would be counted by the compiler without these).
 //   x ring : 4 slots of 8 registers  v[96 + 8 s ...]   (four gathered values of a group)
 //   Q ring : 8 slots of 16 registers v[128 + 16 s ...] ([0:3] column words, [4:5] tags, [6:13] values / [6] codes)
+#ifdef STREAM_NT
+#define NTS " nt"
+#else
+#define NTS ""
+#endif
 #define S_(x) #x
 #define S(x) S_(x)
 #define RING_CLOBBER "memory", "v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127", \
@@ -208,10 +213,17 @@ __global__ __launch_bounds__(1024) void sorted_spmv_kernel(const uint8_t *__rest
 #define XR(s, j, n) "v[96+8*" S(s) "+" S(n) "*" S(j) ":96+8*" S(s) "+" S(n) "*" S(j) "+" S(n) "-1]"
 #define XR1(s, o) "v[96+8*" S(s) "+" S(o) "]"
 
-template <typename T, bool DICT, bool TAG, bool SHARED, bool BAR = false, bool REP = false>
+// TOK = U > 0 (mode 4, round 6): the W wavefronts of a workgroup share one chunk and take its groups in UNITS of U groups in turn (unit n = groups
+// [n U, (n + 1) U) belongs to wavefront n % W); a unit's LDS additions are issued only once the token word in LDS says it is unit n's turn, and the
+// token moves on behind them -- LDS operations execute in the order the LDS receives them, so every row's products are added in the order of the
+// chunk's sorted list whatever the wavefronts' timing: bitwise reproducible, the sums of the CSR loop.  Loads, gathers and products run ahead freely.
+// GBASE (mode 5): no 16-bit tag block -- the column word holds the column's offset from its group's first (smallest) column in its low 17 bits and the
+// row above them; the groups' first columns stand in a table per wavefront (scalar loads, a revolution of the ring ahead).
+template <typename T, bool DICT, bool TAG, bool SHARED, bool BAR = false, bool REP = false, int TOK = 0, bool GBASE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sorted_spmv_ring_kernel(const uint8_t *__restrict__ stream, const ChunkDesc *__restrict__ desc, const uint32_t *__restrict__ wg_first,
                                                            const uint32_t *__restrict__ wg_count, const T *__restrict__ x, T *__restrict__ z, uint32_t col_bits,
-                                                           uint32_t R, const T *__restrict__ dict_g, uint32_t ndict, const uint32_t *__restrict__ rowslot = nullptr)
+                                                           uint32_t R, const T *__restrict__ dict_g, uint32_t ndict, const uint32_t *__restrict__ rowslot = nullptr,
+                                                           const uint32_t *__restrict__ gbase = nullptr, uint32_t gb_stride = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr uint32_t GB = group_bytes<T, DICT, TAG>();
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
     ChunkDesc d = live ? desc[k] : ChunkDesc{0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (SHARED) { for (uint32_t i = threadIdx.x; i <= (REP ? d.nacc : d.nrows); i += blockDim.x) acc[i] = T(0); }
     else if (live) for (uint32_t i = lane; i <= d.nrows; i += 64u) acc[i] = T(0);
+    if constexpr (TOK > 0) if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(acc_all + R + 1) = 0u;
     if constexpr (SHARED || DICT) __syncthreads();
     if (!live) return;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(stream + d.stream_off, d.G * GB);
@@ -244,21 +257,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
 #define LOADQ(u, grp)                                                                                                                   \
     do {                                                                                                                                \
         const uint32_t so_ = __builtin_amdgcn_readfirstlane((grp) * GB);                                                               \
-        asm volatile("buffer_load_dwordx4 " QR(u, 0, 4) ", %0, %1, %2 offen" ::"v"(vo_c), "s"(rs), "s"(so_) : RING_CLOBBER);           \
-        if constexpr (TAG) asm volatile("buffer_load_dwordx2 " QR(u, 4, 2) ", %0, %1, %2 offen" ::"v"(vo_t), "s"(rs), "s"(so_) : RING_CLOBBER); \
-        if constexpr (DICT) asm volatile("buffer_load_dword " QR1(u, 6) ", %0, %1, %2 offen" ::"v"(vo_code), "s"(rs), "s"(so_) : RING_CLOBBER); \
+        asm volatile("buffer_load_dwordx4 " QR(u, 0, 4) ", %0, %1, %2 offen" NTS ::"v"(vo_c), "s"(rs), "s"(so_) : RING_CLOBBER);           \
+        if constexpr (TAG) asm volatile("buffer_load_dwordx2 " QR(u, 4, 2) ", %0, %1, %2 offen" NTS ::"v"(vo_t), "s"(rs), "s"(so_) : RING_CLOBBER); \
+        if constexpr (DICT) asm volatile("buffer_load_dword " QR1(u, 6) ", %0, %1, %2 offen" NTS ::"v"(vo_code), "s"(rs), "s"(so_) : RING_CLOBBER); \
         else if constexpr (sizeof(T) == 8) {                                                                                            \
-            asm volatile("buffer_load_dwordx4 " QR(u, 6, 4) ", %0, %1, %2 offen" ::"v"(vo_v0), "s"(rs), "s"(so_) : RING_CLOBBER);      \
-            asm volatile("buffer_load_dwordx4 " QR(u, 10, 4) ", %0, %1, %2 offen" ::"v"(vo_v1), "s"(rs), "s"(so_) : RING_CLOBBER);     \
-        } else asm volatile("buffer_load_dwordx4 " QR(u, 6, 4) ", %0, %1, %2 offen" ::"v"(vo_v0), "s"(rs), "s"(so_) : RING_CLOBBER);   \
+            asm volatile("buffer_load_dwordx4 " QR(u, 6, 4) ", %0, %1, %2 offen" NTS ::"v"(vo_v0), "s"(rs), "s"(so_) : RING_CLOBBER);      \
+            asm volatile("buffer_load_dwordx4 " QR(u, 10, 4) ", %0, %1, %2 offen" NTS ::"v"(vo_v1), "s"(rs), "s"(so_) : RING_CLOBBER);     \
+        } else asm volatile("buffer_load_dwordx4 " QR(u, 6, 4) ", %0, %1, %2 offen" NTS ::"v"(vo_v0), "s"(rs), "s"(so_) : RING_CLOBBER);   \
     } while (0)
     // gather the x of the group in Q slot `un` into x slot `xsl`
-#define GATHER(un, xsl)                                                                                                                 \
+#define GATHER(un, xsl, gbv)                                                                                                            \
     do {                                                                                                                                \
         uint32_t c0_, c1_, c2_, c3_;                                                                                                    \
         asm volatile("v_mov_b32 %0, " QR1(un, 0) "\n\tv_mov_b32 %1, " QR1(un, 1) "\n\tv_mov_b32 %2, " QR1(un, 2) "\n\tv_mov_b32 %3, " QR1(un, 3)   \
                      : "=v"(c0_), "=v"(c1_), "=v"(c2_), "=v"(c3_)::"memory");                                                       \
-        c0_ = (c0_ & cmask) * (uint32_t)sizeof(T); c1_ = (c1_ & cmask) * (uint32_t)sizeof(T); c2_ = (c2_ & cmask) * (uint32_t)sizeof(T); c3_ = (c3_ & cmask) * (uint32_t)sizeof(T); \
+        const uint32_t gb__ = GBASE ? (gbv) : 0u;                                                                                       \
+        c0_ = ((c0_ & cmask) + gb__) * (uint32_t)sizeof(T); c1_ = ((c1_ & cmask) + gb__) * (uint32_t)sizeof(T); c2_ = ((c2_ & cmask) + gb__) * (uint32_t)sizeof(T); c3_ = ((c3_ & cmask) + gb__) * (uint32_t)sizeof(T); \
         if constexpr (sizeof(T) == 8) {                                                                                                 \
             asm volatile("buffer_load_dwordx2 " XR(xsl, 0, 2) ", %0, %4, 0 offen\n\tbuffer_load_dwordx2 " XR(xsl, 1, 2) ", %1, %4, 0 offen\n\t"         \
                          "buffer_load_dwordx2 " XR(xsl, 2, 2) ", %2, %4, 0 offen\n\tbuffer_load_dwordx2 " XR(xsl, 3, 2) ", %3, %4, 0 offen"             \
@@ -292,8 +306,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
     do {                                                                                                                                \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");                                                                       \
         TAKE(u, xsl);                                                                                                                   \
-        GATHER(un, xsl);                                                                                                                \
-        LOADQ(u, gb + (uint32_t)(u + QN) * gs);                                                                                         \
+        GATHER(un, xsl, (u < 4 ? bcur[(u + 4) & 7] : bnext[(u + 4) & 7]));                                                              \
+        LOADQ(u, GG(tb + (uint32_t)(u + QN)));                                                                                          \
+        if constexpr (TOK > 0) if ((u) % TOK == 0 && tb + (u) < Tw) {          /* this unit's turn? (unit n of the chunk = wavefront n % W) */ \
+            const uint32_t n_ = ((tb + (u)) / (uint32_t)TOK) * nwv + wv_u;                                                              \
+            asm volatile("" ::: "memory");                                                                                              \
+            while (__hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n_) __builtin_amdgcn_s_sleep(1);            \
+            asm volatile("" ::: "memory");                                                                                              \
+        }                                                                                                                               \
         _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                                                \
             T av, xv;                                                                                                                   \
             if constexpr (DICT) av = dict[(vv_[0] >> (8 * j)) & 0xffu];                                                                 \
@@ -307,24 +327,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
             lds_add<T, SHARED>(acc + row, av * xv);                                                                                     \
         }                                                                                                                               \
         if constexpr (BAR) __builtin_amdgcn_s_barrier();      /* mode 2: every wavefront has added its group of the round */         \
+        if constexpr (TOK > 0) if ((u) % TOK == TOK - 1 && tb + (u) < Tw) {          /* the token moves on behind this unit's additions */ \
+            const uint32_t n_ = ((tb + (u)) / (uint32_t)TOK) * nwv + wv_u;                                                              \
+            asm volatile("" ::: "memory");                                                                                              \
+            if (lane == 0) __hip_atomic_store(tok, n_ + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                            \
+            asm volatile("" ::: "memory");                                                                                              \
+        }                                                                                                                               \
     } while (0)
 
+    // the wavefront's t-th group is group GG(t) of the chunk (private: t; shared: the groups, or units of TOK groups, in turn)
+#define GG(t) (TOK > 0 ? ((t) / (uint32_t)TOK) * (nwv * (uint32_t)TOK) + wv_u * (uint32_t)TOK + (t) % (uint32_t)TOK : g0 + (t) * gs)
+    // groups every wavefront walks (the same count in all of them with a barrier or a token: every unit's turn must be taken)
+    const uint32_t Tw = TOK > 0 ? (d.G + nwv * (uint32_t)TOK - 1u) / (nwv * (uint32_t)TOK) * (uint32_t)TOK : BAR ? (d.G + gs - 1u) / gs : d.G > g0 ? (d.G - g0 + gs - 1u) / gs : 0u;
+    uint32_t *const tok = reinterpret_cast<uint32_t *>(acc_all + R + 1);
+    (void)tok;
+    const uint32_t *gbw = GBASE ? gbase + d.nacc + wv_u * gb_stride : nullptr;
+    uint32_t bcur[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bnext[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (GBASE) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) bcur[i] = gbw[i];
+    }
     // run-in: the stream of the first QN groups, then virtual steps -D .. -1 issue what steps of the loop would have issued
     {
-        const uint32_t gb = g0;
-        LOADQ(0, gb + 0u * gs); LOADQ(1, gb + 1u * gs); LOADQ(2, gb + 2u * gs); LOADQ(3, gb + 3u * gs);
+        LOADQ(0, GG(0u)); LOADQ(1, GG(1u)); LOADQ(2, GG(2u)); LOADQ(3, GG(3u));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        GATHER(0, 0); LOADQ(4, gb + 4u * gs);
-        GATHER(1, 1); LOADQ(5, gb + 5u * gs);
-        GATHER(2, 2); LOADQ(6, gb + 6u * gs);
-        GATHER(3, 3); LOADQ(7, gb + 7u * gs);
+        GATHER(0, 0, bcur[0]); LOADQ(4, GG(4u));
+        GATHER(1, 1, bcur[1]); LOADQ(5, GG(5u));
+        GATHER(2, 2, bcur[2]); LOADQ(6, GG(6u));
+        GATHER(3, 3, bcur[3]); LOADQ(7, GG(7u));
     }
-    for (uint32_t gb = g0, rb = 0; BAR ? rb < d.G : gb < d.G; gb += gs * QN, rb += gs * QN) {      // (BAR: the same trip count in every wavefront)
+    for (uint32_t tb = 0; tb < Tw; tb += QN) {
+        if constexpr (GBASE) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) bnext[i] = gbw[tb + 8u + (uint32_t)i];
+        }
         STEP(0, 4, 0); STEP(1, 5, 1); STEP(2, 6, 2); STEP(3, 7, 3);
         STEP(4, 0, 0); STEP(5, 1, 1); STEP(6, 2, 2); STEP(7, 3, 3);
+        if constexpr (GBASE) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) bcur[i] = bnext[i];
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef STEP
+#undef GG
 #undef TAKE
 #undef GATHER
 #undef LOADQ
@@ -437,7 +483,10 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     // ---- formats
     uint32_t col_bits = 1; while ((1ull << col_bits) < pw) col_bits++;
     uint32_t row_bits = 1; while ((1ull << row_bits) < (uint64_t)Reff + 1) row_bits++;      // tags 0 .. Reff
-    const bool tag = col_bits + row_bits > 32 || mode == 3;
+    const bool gbm = mode == 5;                                   // group-base packing: 17 bits of column offset + the row in one word
+    const uint32_t TOKU = getenv("TOK_U") ? (uint32_t)atoi(getenv("TOK_U")) : 1u;      // modes 4 / 5: groups per unit (1, 2, 4, 8)
+    if (gbm && row_bits > 15) { fprintf(stderr, "rows per chunk beyond 15 bits\n"); return 1; }
+    const bool tag = !gbm && (col_bits + row_bits > 32 || mode == 3);
     if (tag && Reff + 1 > 65536) { fprintf(stderr, "rows per chunk beyond 16-bit tags\n"); return 1; }
     const uint32_t GB = 1024u + (tag ? 512u : 0u) + (use_dict ? 256u : sizeof(T) == 8 ? 2048u : 1024u);
     std::vector<ChunkDesc> desc(nch);
@@ -451,6 +500,11 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     std::vector<uint8_t> stream(soff + 8 * GB, 0);
     std::vector<int32_t> zrow(zoff);
     std::vector<uint32_t> rowslot(zoff + 1, 0);
+    uint32_t Gmax = 0; for (auto &dd : desc) Gmax = std::max(Gmax, dd.G);
+    const uint32_t gb_stride = ((Gmax + W * TOKU - 1) / (W * TOKU) * TOKU + 7) / 8 * 8 + 16;      // a wavefront's table: its groups' first columns, then zeros for the run-ahead
+    std::vector<uint32_t> gbase(gbm ? (size_t)nch * W * gb_stride + 64 : 64, 0);
+    int64_t gb_bad = 0;
+    if (mode >= 4) for (size_t k = 0; k < nch; k++) desc[k].nacc = (uint32_t)(k * W * gb_stride);
     const long hotT = getenv("HOT_T") ? atol(getenv("HOT_T")) : 16;
     int64_t nrep_tot = 0, nconf_tot = 0; uint32_t nacc_max = 0;
     double t0 = omp_get_wtime();
@@ -504,6 +558,16 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
             row += 1u;            // tags are biased by one: tag 0 (what a load past the end returns) is the dump accumulator
             if (mode == 3) row = e < n ? slot[row - 1] + (rep[row - 1] ? (uint32_t)(e / 256) % W : 0u) : 0u;
             uint32_t cw = tag ? col : (col_bits >= 32 ? col : col | (row << col_bits));
+            if (gbm) {
+                const uint32_t e256 = g * 256u, bcol = e256 < (uint32_t)n ? (uint32_t)(key[idx[e256]] >> 24) : 0u;      // the group's first = smallest column
+                if (e % 256 == 0 && e < n) { const uint32_t wq = (g / TOKU) % W, tq = (g / (TOKU * W)) * TOKU + g % TOKU; gbase[desc[k].nacc + wq * gb_stride + tq] = bcol; }
+                const uint32_t off = e < n ? col - bcol : 0u;
+                if (off >= (1u << 17)) {
+#pragma omp atomic
+                    gb_bad++;
+                }
+                cw = e < n ? (off & 0x1ffffu) | (row << 17) : 0u;
+            }
             reinterpret_cast<uint32_t *>(gp)[ln * 4 + j] = cw;
             if (tag) reinterpret_cast<uint16_t *>(gp + 1024)[ln * 4 + j] = (uint16_t)row;
             uint8_t *vp = gp + 1024 + (tag ? 512 : 0);
@@ -535,7 +599,8 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
         }
     } else for (auto &q : xq[0]) { wg_first.push_back(q.first); wg_count.push_back(q.second); }
     const uint32_t nwg = (uint32_t)wg_first.size();
-    const size_t lds = (size_t)(use_dict ? 256 : 0) * sizeof(T) + (mode == 3 ? (size_t)(nacc_max + 1) : (size_t)(mode >= 1 ? 1 : W) * (Reff + 1)) * sizeof(T);
+    const size_t lds = (size_t)(use_dict ? 256 : 0) * sizeof(T) + (mode == 3 ? (size_t)(nacc_max + 1) : (size_t)(mode >= 1 ? 1 : W) * (Reff + 1)) * sizeof(T) + 16;
+    if (mode >= 4) printf("# mode %d: token units of %u groups%s; column offsets beyond 17 bits: %ld\n", mode, TOKU, gbm ? ", group-base packing" : "", (long)gb_bad);
     if (mode == 3) printf("# mode 3: hot rows from %ld non-zeros; replicated rows %ld of %ld (%.1f %%), of them for a conflict %ld; most accumulators in a chunk %u\n", hotT, (long)nrep_tot, (long)npairs, 100.0 * nrep_tot / npairs, (long)nconf_tot, nacc_max);
     int64_t slots = 0; for (auto &d : desc) slots += (int64_t)d.G * 256;
     printf("# %s nrows %ld nnz %ld | P %u (%u cols, %.2f MB) pairs %.2fM chunks %zu wgs %u slots/nnz %.3f | R %u W %u Smax %u mode %d depth %d tag %d dict %d(%zu) bits %u+%u GB %u stream %.1f MB lds %zu | build %.1fs\n",
@@ -549,7 +614,8 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
         zz = (zz ^ (zz >> 30)) * 0xBF58476D1CE4E5B9ull; zz = (zz ^ (zz >> 27)) * 0x94D049BB133111EBull; zz ^= zz >> 31;
         x[j] = (T)((double)(zz >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0);
     }
-    uint8_t *d_stream; ChunkDesc *d_desc; uint32_t *d_first, *d_count, *d_rowslot; T *d_x, *d_z, *d_dict;
+    uint8_t *d_stream; ChunkDesc *d_desc; uint32_t *d_first, *d_count, *d_rowslot, *d_gbase; T *d_x, *d_z, *d_dict;
+    CK(hipMalloc(&d_gbase, gbase.size() * 4)); CK(hipMemcpy(d_gbase, gbase.data(), gbase.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_rowslot, rowslot.size() * 4)); CK(hipMemcpy(d_rowslot, rowslot.data(), rowslot.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_stream, stream.size())); CK(hipMemcpy(d_stream, stream.data(), stream.size(), hipMemcpyHostToDevice));
     // SAME_STREAM=M (timing only, wrong sums): every chunk streams the image of one of the first M chunks of its panel (its own x slice and
@@ -577,7 +643,9 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
 #define L(DI, TG, DP, SH, NA) hipLaunchKernelGGL((sorted_spmv_kernel<T, DI, TG, DP, SH, NA>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size())
 #define L_NA(DI, TG, DP, SH) do { if (noadd) L(DI, TG, DP, SH, 1); else L(DI, TG, DP, SH, 0); } while (0)
 #define L_SH(DI, TG, DP) do { if (mode >= 1) L_NA(DI, TG, DP, true); else L_NA(DI, TG, DP, false); } while (0)
-#define L_RING(DI, TG) do { if (mode == 3) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size(), d_rowslot); \
+#define L_TOK(DI, TG, U, GBM) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, false, false, U, GBM>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, GBM ? 17u : tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size(), d_rowslot, d_gbase, gb_stride)
+#define L_TOKU(DI, TG, GBM) do { if (TOKU == 1) L_TOK(DI, TG, 1, GBM); else if (TOKU == 2) L_TOK(DI, TG, 2, GBM); else if (TOKU == 4) L_TOK(DI, TG, 4, GBM); else L_TOK(DI, TG, 8, GBM); } while (0)
+#define L_RING(DI, TG) do { if (mode == 5) { if constexpr (!TG) L_TOKU(DI, false, true); } else if (mode == 4) L_TOKU(DI, TG, false); else if (mode == 3) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size(), d_rowslot); \
         else if (mode == 2) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
         else if (mode == 1) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
         else hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, false>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); } while (0)
@@ -595,6 +663,28 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     // ---- check: y[row] = sum of the chunks' partial sums, against the CSR loop in double
     std::vector<T> z(zoff);
     CK(hipMemcpy(z.data(), d_z, zoff * sizeof(T), hipMemcpyDeviceToHost));
+    // bitwise: a second launch gives the same bits, and every chunk's row sum is the sequential sum of its rounded products in column order
+    // (the order of the CSR loop) -- what a reproducible layout must deliver whatever the wavefronts' timing
+    if (!noadd && !getenv("SAME_STREAM")) {
+        launch(); CK(hipDeviceSynchronize());
+        std::vector<T> z2(zoff);
+        CK(hipMemcpy(z2.data(), d_z, zoff * sizeof(T), hipMemcpyDeviceToHost));
+        const bool same = memcmp(z.data(), z2.data(), zoff * sizeof(T)) == 0;
+        int64_t nord = 0;
+        if (mode != 3)
+#pragma omp parallel for reduction(+ : nord) schedule(dynamic, 8)
+        for (size_t k = 0; k < nch; k++) {
+            const auto &c = chunks[k];
+            const Panel &pp = pan[c.panel];
+            for (int64_t sidx = c.sub0; sidx < c.sub1; sidx++) {
+                const int64_t b0 = std::max(pp.sp[sidx], c.e0), b1 = std::min(pp.sp[sidx + 1], c.e1);
+                T acc = 0;
+                for (int64_t e = b0; e < b1; e++) { const T pr = (T)pp.val[e] * x[(size_t)c.panel * pw + pp.col[e]]; acc += pr; }
+                if (memcmp(&acc, &z[desc[k].zoff + (sidx - c.sub0)], sizeof(T)) != 0) nord++;
+            }
+        }
+        printf("# rerun bitwise %s; partial sums that differ from the column-ordered sum: %ld of %lu\n", same ? "EQUAL" : "DIFFERENT", (long)nord, (unsigned long)zoff);
+    }
     std::vector<double> y(A.nrows, 0.0);
     for (uint64_t i = 0; i < zoff; i++) y[zrow[i]] += (double)z[i];
     int64_t bad = 0; double worst = 0;
