@@ -138,6 +138,24 @@ def measure_other_workload(kind, dev, steps=60, warmup=6):
     b.record()
     torch.cuda.synchronize()
     per = a.elapsed_time(b) * 1e-3 / steps
+    # the same matrix with full values in the stream (value_dict = 0): what the format does without the compression of the 13 distinct values the
+    # reference's loader gives a pattern file (spmv.cpp:417); the fraction is reported beside the main one, never instead of it
+    per_nodict = None
+    if int(info.value_dict) > 0 and not os.environ.get("CVR_BENCH_NO_DICT_OFF_RUN"):
+        try:
+            B = cvr_amd.CvrMatrix.from_device(n, nc, rp_t.data_ptr(), ci_t.data_ptr(), va_t.data_ptr(), is_f32=f32, device=dev.index or 0, value_dict=0)
+            yb = torch.zeros(max(B.info.yext_elems, 1), dtype=tdt, device=dev)
+            B.spmv_device(x.data_ptr(), yb.data_ptr(), sptr, repeat=warmup)
+            a2, b2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a2.record()
+            B.spmv_device(x.data_ptr(), yb.data_ptr(), sptr, repeat=max(steps // 2, 10))
+            b2.record()
+            torch.cuda.synchronize()
+            per_nodict = a2.elapsed_time(b2) * 1e-3 / max(steps // 2, 10)
+            B.close()
+            del yb
+        except Exception as e:
+            print(f"[bench] {kind}: value_dict = 0 run failed: {e!r}", file=sys.stderr)
     yref_t, absy_t = D.csr_spmv_reference(rp_t, ci_t, va_t, x[:nc])
     wrong = int(torch.count_nonzero((y[:n].to(torch.float64) - yref_t).abs() > (1e-5 if f32 else 1e-12) * absy_t + 1e-300).item())
     vb = 4 if f32 else 8
@@ -145,6 +163,7 @@ def measure_other_workload(kind, dev, steps=60, warmup=6):
     out = {"workload": f"{source}: {n}x{nc}, nnz {nnz}, {'fp32' if f32 else 'fp64'}", "dtype": "f32" if f32 else "f64", "nnz": nnz, "steps": steps,
            "ms_per_step": per * 1e3, "kernel_us": per * 1e6, "gflops": 2.0 * nnz / per / 1e9, "algorithmic_bytes_per_launch": int(balg),
            "achieved_gbs": balg / per / 1e9, "frac": balg / per / 1e9 / HBM_PEAK_GBS, "wrong_rows": wrong,
+           "kernel_us_value_dict_off": per_nodict * 1e6 if per_nodict else None, "frac_value_dict_off": balg / per_nodict / 1e9 / HBM_PEAK_GBS if per_nodict else None,
            "layout": {"col_panels": int(info.col_panels), "interleave": int(info.interleave), "steps_per_chunk": int(info.steps_per_chunk), "chunks": int(info.nchunks),
                       "waves_per_workgroup": int(info.waves_per_block), "hub_entries": int(info.hub_entries), "hub_reorder": int(info.hub_reorder),
                       "value_dictionary_entries": int(info.value_dict), "image_bytes": int(info.image_bytes), "spmv_launches": int(info.spmv_launches)},
@@ -736,6 +755,8 @@ def main():
     e0.record(stream)
     step(args.steps)
     e1.record(stream)
+    while not e1.query():        # (poll: a blocking wait wakes this thread 10-20 us after the last kernel has ended, which is 5 % of a 20-step run of the headline)
+        pass
     sync()
     wall = time.perf_counter() - t0
     ev_s = e0.elapsed_time(e1) * 1e-3
@@ -938,6 +959,9 @@ def main():
                          "kernel": kname, "kernel_us": kern_s * 1e6,
                          "kernel_us_median_single_launches": singles[len(singles) // 2] if singles else None, "kernel_us_min_single_launches": singles[0] if singles else None,
                          "copy_kernel_gbs": copy_gbs, "frac_of_copy_kernel": achieved / copy_gbs if copy_gbs else None,
+                         # the boxes of the pool run stream-bound kernels in one of two modes ~17 % apart (profiles/r05_bimodal_probe.log); the copy kernel
+                         # lands in the same mode as the process's other streaming kernels: which one this line was taken in
+                         "box_mode": None if not copy_gbs else ("fast (copy kernel >= 5.6 TB/s)" if copy_gbs >= 5600 else "slow (copy kernel < 5.6 TB/s)"),
                          "algorithmic_bytes_per_launch": int(balg_local),
                          "streamed_bytes_per_launch": streamed_local, "streamed_gbs": streamed_local / kern_s / 1e9,
                          "kernel_us_value_dict_off": None if kern_nodict_s is None else kern_nodict_s * 1e6,

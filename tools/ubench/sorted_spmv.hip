@@ -201,6 +201,9 @@ __global__ __launch_bounds__(1024) void sorted_spmv_kernel(const uint8_t *__rest
 #else
 #define NTS ""
 #endif
+#ifndef TOK_SLEEP
+#define TOK_SLEEP 1
+#endif
 #define S_(x) #x
 #define S(x) S_(x)
 #define RING_CLOBBER "memory", "v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127", \
@@ -308,12 +311,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
         TAKE(u, xsl);                                                                                                                   \
         GATHER(un, xsl, (u < 4 ? bcur[(u + 4) & 7] : bnext[(u + 4) & 7]));                                                              \
         LOADQ(u, GG(tb + (uint32_t)(u + QN)));                                                                                          \
-        if constexpr (TOK > 0) if ((u) % TOK == 0 && tb + (u) < Tw) {          /* this unit's turn? (unit n of the chunk = wavefront n % W) */ \
-            const uint32_t n_ = ((tb + (u)) / (uint32_t)TOK) * nwv + wv_u;                                                              \
-            asm volatile("" ::: "memory");                                                                                              \
-            while (__hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n_) __builtin_amdgcn_s_sleep(1);            \
-            asm volatile("" ::: "memory");                                                                                              \
-        }                                                                                                                               \
+        T pr_[4]; uint32_t rw_[4];            /* products and rows first: with a token nothing but the additions themselves happens while it is held */ \
         _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                                                \
             T av, xv;                                                                                                                   \
             if constexpr (DICT) av = dict[(vv_[0] >> (8 * j)) & 0xffu];                                                                 \
@@ -321,18 +319,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
             else av = __builtin_bit_cast(float, vv_[j]);                                                                                \
             if constexpr (sizeof(T) == 8) xv = __builtin_bit_cast(double, (uint64_t)xx_[2 * j] | ((uint64_t)xx_[2 * j + 1] << 32));    \
             else xv = __builtin_bit_cast(float, xx_[j]);                                                                                \
-            uint32_t row;                                                                                                               \
-            if constexpr (TAG) row = (tg_[j >> 1] >> (16 * (j & 1))) & 0xffffu;                                                          \
-            else row = col_bits >= 32 ? 0u : cw_[j] >> col_bits;                                                                        \
-            lds_add<T, SHARED>(acc + row, av * xv);                                                                                     \
+            if constexpr (TAG) rw_[j] = (tg_[j >> 1] >> (16 * (j & 1))) & 0xffffu;                                                       \
+            else rw_[j] = col_bits >= 32 ? 0u : cw_[j] >> col_bits;                                                                     \
+            pr_[j] = av * xv;                                                                                                           \
+        }                                                                                                                               \
+        if constexpr (TOK > 0) {          /* the unit's products wait in registers; its last group takes the token, adds them all in order, passes it on */ \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) { prb[(u) % TOK][j] = pr_[j]; rwb[(u) % TOK][j] = rw_[j]; }                    \
+            if ((u) % TOK == TOK - 1) {                                                                                                 \
+                _Pragma("unroll") for (int q = 0; q < TOK; q++) _Pragma("unroll") for (int j = 0; j < 4; j++) { asm volatile("" : "+v"(prb[q][j])); asm volatile("" : "+v"(rwb[q][j])); } \
+                if (tb + (u) < Tw) {                                                                                                    \
+                    const uint32_t n_ = ((tb + (u)) / (uint32_t)TOK) * nwv + wv_u;                                                      \
+                    asm volatile("" ::: "memory");                                                                                      \
+                    while (__hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n_) { if (TOK_SLEEP > 0) __builtin_amdgcn_s_sleep(TOK_SLEEP); } \
+                    asm volatile("" ::: "memory");                                                                                      \
+                    _Pragma("unroll") for (int q = 0; q < TOK; q++) _Pragma("unroll") for (int j = 0; j < 4; j++) lds_add<T, SHARED>(acc + rwb[q][j], prb[q][j]); \
+                    asm volatile("" ::: "memory");                                                                                      \
+                    if (lane == 0) __hip_atomic_store(tok, n_ + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                    \
+                    asm volatile("" ::: "memory");                                                                                      \
+                }                                                                                                                       \
+            }                                                                                                                           \
+        } else {                                                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) lds_add<T, SHARED>(acc + rw_[j], pr_[j]);                                     \
         }                                                                                                                               \
         if constexpr (BAR) __builtin_amdgcn_s_barrier();      /* mode 2: every wavefront has added its group of the round */         \
-        if constexpr (TOK > 0) if ((u) % TOK == TOK - 1 && tb + (u) < Tw) {          /* the token moves on behind this unit's additions */ \
-            const uint32_t n_ = ((tb + (u)) / (uint32_t)TOK) * nwv + wv_u;                                                              \
-            asm volatile("" ::: "memory");                                                                                              \
-            if (lane == 0) __hip_atomic_store(tok, n_ + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                            \
-            asm volatile("" ::: "memory");                                                                                              \
-        }                                                                                                                               \
     } while (0)
 
     // the wavefront's t-th group is group GG(t) of the chunk (private: t; shared: the groups, or units of TOK groups, in turn)
@@ -341,6 +350,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
     const uint32_t Tw = TOK > 0 ? (d.G + nwv * (uint32_t)TOK - 1u) / (nwv * (uint32_t)TOK) * (uint32_t)TOK : BAR ? (d.G + gs - 1u) / gs : d.G > g0 ? (d.G - g0 + gs - 1u) / gs : 0u;
     uint32_t *const tok = reinterpret_cast<uint32_t *>(acc_all + R + 1);
     (void)tok;
+    T        prb[TOK > 0 ? TOK : 1][4];
+    uint32_t rwb[TOK > 0 ? TOK : 1][4];
+    (void)prb; (void)rwb;
     const uint32_t *gbw = GBASE ? gbase + d.nacc + wv_u * gb_stride : nullptr;
     uint32_t bcur[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bnext[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if constexpr (GBASE) {
