@@ -35,7 +35,7 @@ class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("steps_per_chunk", C.c_int32), ("split_threshold", C.c_int64),
                 ("xcd_swizzle", C.c_int32), ("x_window", C.c_int32), ("waves_per_block", C.c_int32),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("hub_table", C.c_int32), ("narrow_cols", C.c_int32),
-                ("hub_reorder", C.c_int32), ("row_tags16", C.c_int32), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("interleave", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("hub_reorder", C.c_int32), ("row_tags16", C.c_int32), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("interleave", C.c_int32), ("gang", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Timing(C.Structure):
@@ -52,7 +52,7 @@ class Info(C.Structure):
                 ("plan_s", C.c_double), ("upload_s", C.c_double), ("convert_s", C.c_double),
                 ("col_panels", C.c_int32), ("value_dict", C.c_int32), ("col_phases", C.c_int32), ("waves_per_block", C.c_int32),
                 ("x_window", C.c_int32), ("lds_bytes", C.c_int32), ("nsegments", C.c_int64), ("chunk_row_cap", C.c_int64), ("near_diagonal_share", C.c_double), ("hub_entries", C.c_int32), ("narrow_cols", C.c_int32), ("hub_reorder", C.c_int32), ("row_tags16", C.c_int32), ("hub_share", C.c_double),
-                ("hub_select_s", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("spmv_launches", C.c_int32), ("preprocess_fused", C.c_int32), ("interleave", C.c_int32), ("reserved_info", C.c_int32)]
+                ("hub_select_s", C.c_double), ("probe_s", C.c_double), ("dict_s", C.c_double), ("preprocess_wall_s", C.c_double), ("row_bands", C.c_int32), ("piece_max", C.c_int32), ("spmv_launches", C.c_int32), ("preprocess_fused", C.c_int32), ("interleave", C.c_int32), ("gang", C.c_int32)]
 
 
 class MmMatrix(C.Structure):
@@ -64,7 +64,7 @@ class MmMatrix(C.Structure):
 # every symbol include/cvr_amd.h declares (tests check the library exports all of them)
 SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_count", "cvr_create", "cvr_preprocess",
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
-           "cvr_spmv_bench", "cvr_debug_phase_clocks", "cvr_device_copy_bench", "cvr_export_image", "cvr_plan_bound", "cvr_plan_chunks", "cvr_plan_selfcheck", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
+           "cvr_spmv_bench", "cvr_debug_phase_clocks", "cvr_device_copy_bench", "cvr_export_image", "cvr_export_gang", "cvr_plan_bound", "cvr_plan_chunks", "cvr_plan_selfcheck", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
            "cvr_tune_steps", "cvr_tune", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat",
            "cvr_source_key_of", "cvr_mm_write_bin_keyed", "cvr_mm_read_bin_keyed", "cvr_mm_read_cached", "cvr_save_image", "cvr_load_image",
@@ -110,6 +110,7 @@ def lib():
         L.cvr_spmv_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.cvr_debug_phase_clocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.cvr_export_image.argtypes = [C.c_void_p] * 5
+        L.cvr_export_gang.argtypes = [C.c_void_p] * 3
         L.cvr_device_copy_bench.argtypes = [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_double)]
         L.cvr_plan_selfcheck.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cvr_plan_selfcheck.restype = C.c_int
@@ -347,7 +348,7 @@ class CvrMatrix:
     def __init__(self, nrows, ncols, row_ptr, col_idx, vals, device=0, steps_per_chunk=0, split_threshold=0,
                  xcd_swizzle=-1, x_window=-1, keep_csr=False, debug_col_mask=0,
                  col_panels=-1, value_dict=-1, tune_steps=False, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1,
-                 row_tags16=-1, row_bands=-1, piece_max=-1, interleave=-1):
+                 row_tags16=-1, row_bands=-1, piece_max=-1, interleave=-1, gang=-1):
         """tune_steps: choose steps_per_chunk by measurement first (cvr_tune_steps; its cost is self.tuning_s).
         debug_col_mask is a profiling knob (tools/sweep.py): it travels through the environment (CVR_DEBUG_COL_MASK), not through cvr_options."""
         self._h = C.c_void_p()
@@ -366,7 +367,7 @@ class CvrMatrix:
         view = CsrView(nrows, ncols, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, int(self.f32))
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, keep_csr,
                     debug_col_mask, col_panels, value_dict, tune_steps, waves_per_block, col_phases, hub_table, narrow_cols, hub_reorder,
-                    row_tags16, row_bands, piece_max, interleave)
+                    row_tags16, row_bands, piece_max, interleave, gang)
 
     def save_image(self, path, key=None):
         """cvr_save_image: the converted image on disk, keyed by `key` (capi.source_key of the .mtx file; None = no source key),
@@ -402,7 +403,7 @@ class CvrMatrix:
 
     @classmethod
     def from_device(cls, nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, is_f32=False, device=0, steps_per_chunk=0,
-                    split_threshold=0, keep_csr=False, col_panels=-1, value_dict=-1, tune_steps=False, hub_table=-1, hub_reorder=-1, interleave=-1):
+                    split_threshold=0, keep_csr=False, col_panels=-1, value_dict=-1, tune_steps=False, hub_table=-1, hub_reorder=-1, interleave=-1, gang=-1):
         """CSR arrays already in the memory of `device` (raw pointers: int64 row_ptr[nrows+1], int32 col_idx, fp64/fp32 vals),
         e.g. the .data_ptr() of torch tensors: cvr_csr_view.arrays_on_device = 1"""
         self = cls.__new__(cls)
@@ -412,12 +413,12 @@ class CvrMatrix:
         self.dtype = np.float32 if self.f32 else np.float64
         view = CsrView(nrows, ncols, row_ptr_dev, col_idx_dev, vals_dev, int(self.f32), 1)
         self._build(view, nrows, ncols, device, steps_per_chunk, split_threshold, -1, -1, keep_csr, 0, col_panels, value_dict, tune_steps,
-                    hub_table=hub_table, hub_reorder=hub_reorder, interleave=interleave)
+                    hub_table=hub_table, hub_reorder=hub_reorder, interleave=interleave, gang=gang)
         return self
 
     def _build(self, view, nrows, ncols, device, steps_per_chunk, split_threshold, xcd_swizzle, x_window, keep_csr,
                debug_col_mask, col_panels, value_dict, tune_steps, waves_per_block=0, col_phases=-1, hub_table=-1, narrow_cols=-1, hub_reorder=-1,
-               row_tags16=-1, row_bands=-1, piece_max=-1, interleave=-1):
+               row_tags16=-1, row_bands=-1, piece_max=-1, interleave=-1, gang=-1):
         opt = Options()
         lib().cvr_default_options(C.byref(opt))
         opt.device, opt.steps_per_chunk, opt.split_threshold = device, steps_per_chunk, split_threshold
@@ -425,6 +426,7 @@ class CvrMatrix:
         opt.waves_per_block, opt.col_phases, opt.hub_table, opt.narrow_cols = waves_per_block, col_phases, hub_table, narrow_cols
         opt.hub_reorder, opt.row_tags16, opt.row_bands, opt.piece_max = hub_reorder, row_tags16, row_bands, piece_max
         opt.interleave = interleave
+        opt.gang = gang
         # profiling knobs (tools/sweep.py): cvr_create / cvr_tune read them from the environment.  Only a knob the caller passed is
         # touched, and what the environment held before comes back once the handle exists (a value the user exported stays theirs).
         saved = {}
@@ -547,7 +549,15 @@ class CvrMatrix:
         rc = lib().cvr_export_image(self._h, image.ctypes.data, desc.ctypes.data, target.ctypes.data, shared.ctypes.data)
         if rc:
             raise CvrError(rc, "cvr_export_image")
-        return dict(image=image, desc=desc, target=target, shared=shared)
+        out = dict(image=image, desc=desc, target=target, shared=shared)
+        if i.gang:                      # gang chunks: the groups' first columns and the gangs' group counts
+            gbase = np.zeros(i.nchunks * (i.steps_per_chunk // 4), dtype=np.uint32)
+            desc2 = np.zeros((i.nchunks, 2), dtype=np.uint32)
+            rc = lib().cvr_export_gang(self._h, gbase.ctypes.data, desc2.ctypes.data)
+            if rc:
+                raise CvrError(rc, "cvr_export_gang")
+            out.update(gbase=gbase, desc2=desc2)
+        return out
 
     def close(self):
         if self._h:

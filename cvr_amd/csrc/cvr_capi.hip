@@ -178,6 +178,7 @@ void cvr_default_options(cvr_options *o)
     o->row_bands = -1;
     o->piece_max = -1;
     o->interleave = -1;
+    o->gang = -1;
 }
 
 }  // extern "C"
@@ -610,6 +611,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     in.col_panels = P;
     h->parts.resize((size_t)P);
     if (P == 1 && opt.interleave < 0) opt.interleave = 0;      // (a single image is interleaved only when asked to)
+    if (P == 1 && opt.gang < 0) opt.gang = 0;                  // (and its chunks ganged only when asked to)
     if (P == 1) {
         if (staged.rp) {          // the staging copy becomes the part's device CSR
             Part &part = h->parts[0];
@@ -681,6 +683,10 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             // chunk may span twice the rows (wiki-Talk shape 39.7 -> 36.6 us, x 2 at another seed 70.3 -> 66.0; every other shape of
             // profiles/r05_wpb_probe.log loses 1-20 % with two, which is why this is not the general rule)
             if (panel_opt.waves_per_block == 0 && panels_auto && nsub_all < nrows && !cvr::debug_env("no_sparse_waves")) panel_opt.waves_per_block = 2;
+            // gang chunks (automatic): the four chunks of an interleaved workgroup sorted together and walked by its wavefronts in turn -- four times the
+            // non-zeros share the lines of x a gather touches (prototype: soc-LiveJournal1 shape 246 -> 178 us, com-Orkut shape 736 -> 510: profiles/r06_token_probe_*.log);
+            // not the two-wavefront workgroups of mostly-empty matrices (their chunks end at the row cap: short lists, few workgroups)
+            if (panel_opt.gang < 0) panel_opt.gang = panel_opt.waves_per_block == 0 && !cvr::debug_env("no_gang") ? 1 : 0;
             if (panel_opt.steps_per_chunk == 0) {       // one chunk length for all panels (they share a launch): from the mean sub-row and the mean panel
                 IOpt one = panel_opt;
                 panel_opt.steps_per_chunk = interleave_steps((sj1 - sj0) / P, std::max<int64_t>(nsub_all / P, 1), f32, one);
@@ -892,7 +898,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (plain) {
             const size_t per_round = cvr::debug_env("xcd_panels_debug") ? (size_t)atoi(cvr::debug_env("xcd_panels_debug")) : 8;      // (diagnostics: fewer panels side by side)
             const size_t rounds = (h->parts.size() + per_round - 1) / per_round;
-            std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u});
+            std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u, nullptr});
             h->multi_chunks.assign(rounds, 0u);
             // which panel runs where: the heaviest first, each to the XCD with the least work so far that still has a round free (the XCDs
             // go through their panels independently: what counts is every XCD's sum, not the rounds'); equal-width panels of a real graph
@@ -918,7 +924,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 const Part &p = h->parts[j];
                 const size_t i = slot_of[j];
                 h->parts[j].multi_slot = (int32_t)i;
-                pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col};
+                pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col, p.img.gbase};
                 h->multi_chunks[i / 8] = std::max(h->multi_chunks[i / 8], p.img.nchunks);
                 h->multi_ystage = std::max(h->multi_ystage, p.img.ystage);
                 if (cvr::debug_env("xcd_panels_trace")) fprintf(stderr, "[xcd panels] part %zu slot %zu nchunks %u ystage %u S %d G %d zoff %lld yext %lld nshared %u stream %p\n", j, i, p.img.nchunks, p.img.ystage, p.img.S, p.img.G, (long long)p.zoff, (long long)p.yext, p.img.nshared, (void *)p.img.stream);
@@ -938,6 +944,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     in.row_bands = 1;
     in.piece_max = (int32_t)h->parts[0].img.piece_max;
     in.interleave = h->parts[0].img.ilv ? 1 : 0;
+    in.gang = (int32_t)h->parts[0].img.gang;
     in.chunk_row_cap = h->parts[0].img.phases > 1 ? (int64_t)h->parts[0].img.ystage - 1 : 0;
     for (const Part &p : h->parts) {
         in.nchunks += p.nchunks; in.nshared += p.nshared; in.nslots += p.nchunks * 64 * p.img.S;
@@ -1003,15 +1010,16 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
     // handle (column panels) are converted one after the other and share the table, sized for the largest
     size_t seg_n1 = 0, seg_chunks = 0;
     int64_t ilv_nnz = 0;             // interleaved images: converted together behind the loop (one sort over all their non-zeros)
-    bool    any_ilv = false;
+    bool     any_ilv = false, any_gang = false;
+    uint32_t ilv_chunks = 0;
     for (const Part &p : h->parts)
-        if (p.img.ilv) { ilv_nnz += p.nnz; any_ilv = true; }
+        if (p.img.ilv) { ilv_nnz += p.nnz; ilv_chunks += (uint32_t)p.nchunks; any_ilv = true; any_gang = any_gang || p.img.gang != 0; }
         else if (p.img.phases > 1 && p.nchunks > 0) {
             seg_n1 = std::max(seg_n1, (size_t)p.nchunks * (size_t)cvr::kLanes * (size_t)p.img.S);
             seg_chunks = std::max(seg_chunks, (size_t)p.nchunks);
         }
     struct IlvGuard { void *p = nullptr; ~IlvGuard() { (void)hipFree(p); } } ilv;
-    const size_t ilv_scratch = any_ilv ? cvr::convert_interleaved_scratch(ilv_nnz, 0) : 0;
+    const size_t ilv_scratch = any_ilv ? cvr::convert_interleaved_scratch(ilv_nnz, ilv_chunks, any_gang) : 0;
     if (ilv_scratch) HIP_TRY(hipMalloc(&ilv.p, ilv_scratch));
     std::vector<const cvr::DeviceImage *> ilv_imgs;
     std::vector<cvr::DeviceCsr>           ilv_csrs;
@@ -1061,19 +1069,51 @@ int cvr_preprocess(cvr_handle *h, int keep_csr, double *seconds)
         }
         if (wstream == h->stream) HIP_TRY(cvr::launch_window(p.img, csr, h->stream));
     }
-    if (!ilv_imgs.empty()) {
+    auto convert_ilv = [&]() -> int {
         // groups of up to 64 images with equal layout parameters (the panels of one matrix: one group)
         for (size_t i0 = 0; i0 < ilv_imgs.size();) {
             size_t i1 = i0 + 1;
-            while (i1 < ilv_imgs.size() && i1 - i0 < 64 && ilv_imgs[i1]->G == ilv_imgs[i0]->G && ilv_imgs[i1]->tag16 == ilv_imgs[i0]->tag16 && ilv_imgs[i1]->col_bits == ilv_imgs[i0]->col_bits) i1++;
+            while (i1 < ilv_imgs.size() && i1 - i0 < 64 && ilv_imgs[i1]->G == ilv_imgs[i0]->G && ilv_imgs[i1]->tag16 == ilv_imgs[i0]->tag16 && ilv_imgs[i1]->col_bits == ilv_imgs[i0]->col_bits && ilv_imgs[i1]->gang == ilv_imgs[i0]->gang) i1++;
             HIP_TRY(cvr::launch_convert_interleaved(ilv_imgs.data() + i0, ilv_csrs.data() + i0, ilv_n0.data() + i0, ilv_n1.data() + i0, (int)(i1 - i0), h->d_err, ilv.p, ilv_scratch, h->stream));
             i0 = i1;
         }
-    }
+        return CVR_OK;
+    };
+    if (!ilv_imgs.empty()) { const int rci = convert_ilv(); if (rci) return rci; }
     HIP_TRY(hipEventRecord(e1, h->stream));
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(&err, h->d_err, sizeof(err), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((err & 8u) && any_gang) {
+        // gang chunks: a column lies further than 2^17 from its group's first (a panel with few non-zeros, or one with wide empty column ranges): the
+        // images take 16-bit tags instead -- their streams are allocated again (a group is 512 bytes longer) and converted once more
+        if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] gang chunks: a column offset beyond %d bits: converting again with 16-bit tags\n", cvr::kGangOffBits);
+        for (Part &p : h->parts) {
+            if (!p.img.gang || p.img.tag16) continue;
+            (void)hipFree(p.img.stream); p.img.stream = nullptr;
+            if (p.img.gbase) { (void)hipFree(p.img.gbase); p.img.gbase = nullptr; }
+            p.img.tag16 = true; p.img.col_bits = 31;
+            p.img.col_mask = h->opt_used.debug_col_mask ? (cvr::kColMask & (uint32_t)h->opt_used.debug_col_mask) : cvr::kColMask;
+            const size_t before = p.stream_bytes;
+            const int    rcf = finish_part(h, p);
+            if (rcf) return rcf;
+            h->info.image_bytes += (int64_t)p.stream_bytes - (int64_t)before;
+        }
+        if (h->d_multi && !h->multi_chunks.empty()) {          // the panels' launch table names the streams
+            std::vector<cvr::PanelArgs> pa(h->multi_chunks.size() * 8);
+            HIP_TRY(hipMemcpy(pa.data(), h->d_multi, sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyDeviceToHost));
+            for (const Part &p : h->parts) if (p.multi_slot >= 0 && (size_t)p.multi_slot < pa.size()) { pa[(size_t)p.multi_slot].stream = p.img.stream; pa[(size_t)p.multi_slot].gbase = p.img.gbase; }
+            HIP_TRY(hipMemcpy(h->d_multi, pa.data(), sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyHostToDevice));
+        }
+        h->info.row_tags16 = 1;
+        HIP_TRY(hipMemsetAsync(h->d_err, 0, sizeof(uint32_t), h->stream));
+        HIP_TRY(hipEventRecord(e0, h->stream));
+        { const int rci = convert_ilv(); if (rci) return rci; }
+        HIP_TRY(hipEventRecord(e1, h->stream));
+        HIP_TRY(hipMemcpyAsync(&err, h->d_err, sizeof(err), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        ilv_runtime_settings(h);
+    }
     if (wstream != h->stream) HIP_TRY(hipStreamSynchronize(wstream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -1249,6 +1289,24 @@ int cvr_export_image(cvr_handle *h, void *stream_image, uint32_t *desc, uint8_t 
     if (desc && nc) HIP_TRY(hipMemcpy(desc, p.img.desc, 16 * nc, hipMemcpyDeviceToHost));
     if (target && nc) HIP_TRY(hipMemcpy(target, p.img.target, 64 * nc, hipMemcpyDeviceToHost));
     if (shared && p.nshared) HIP_TRY(hipMemcpy(shared, p.img.shared, 24 * (size_t)p.nshared, hipMemcpyDeviceToHost));
+    return CVR_OK;
+}
+
+int cvr_export_gang(cvr_handle *h, uint32_t *group_first_cols, uint32_t *desc2)
+{
+    if (!h) return fail(CVR_ERR_INVALID, "handle is null");
+    if (!h->converted) return fail(CVR_ERR_STATE, "cvr_export_gang before cvr_preprocess");
+    if (h->paneled()) return fail(CVR_ERR_STATE, "cvr_export_gang exports one image: create the handle with col_panels = 1");
+    const Part  &p = h->parts[0];
+    if (!p.img.gang) return fail(CVR_ERR_STATE, "cvr_export_gang: the image has no gang chunks");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t nc = (size_t)p.nchunks, ng = nc * (size_t)p.img.G;
+    if (group_first_cols && ng) {
+        if (p.img.gbase) HIP_TRY(hipMemcpy(group_first_cols, p.img.gbase, sizeof(uint32_t) * ng, hipMemcpyDeviceToHost));
+        else memset(group_first_cols, 0, sizeof(uint32_t) * ng);
+    }
+    if (desc2 && nc) HIP_TRY(hipMemcpy(desc2, p.img.desc2, 8 * nc, hipMemcpyDeviceToHost));
     return CVR_OK;
 }
 

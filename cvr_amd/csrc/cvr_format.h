@@ -58,6 +58,13 @@ constexpr int      kWavesPerBlock = 1;   // converter / fix-up launches; the SpM
 constexpr int64_t  kPlanRowBlock = 65536;   // the planner restarts a chunk at every multiple of this many rows (blocks are planned in parallel)
 constexpr int      kMaxWavesPerBlock = 16;   // SpMV workgroups of several consecutive chunks share an LDS window of x (cvr_options.waves_per_block)
 constexpr size_t   kLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
+// gang chunks (cvr_options.gang; cvr_spmv.hip: spmv_gang_kernel): the chunks of an interleaved workgroup sorted TOGETHER -- element e of the gang's list
+// sorted by (column, position) stands in group e / 256 of the gang's stream (the chunks' allocations, one behind the other) -- and walked by the workgroup's
+// wavefronts in turn, units of kGangUnit groups each; a slot's row tag = chunk inside the gang * accumulators per chunk + row inside the chunk (kGangTagBits
+// bits), and its column word holds the column's offset from the group's first (smallest) column in the kGangOffBits bits below the tag (gbase[] keeps the
+// groups' first columns); with 16-bit tags of their own the column word keeps the panel's column
+constexpr int      kGangOffBits = 17, kGangTagBits = 15;
+constexpr int      kGangUnit = 2;        // groups a wavefront takes in a row (their products wait in registers until the unit's turn: the token)
 constexpr int      kIlvMaxSteps = 576;      // longest interleaved chunk: the converter sorts a chunk's 64 S (column, position) pairs in one workgroup's LDS, up to 36 per thread (cvr_ilv.hip)
 
 inline int group_bytes(bool f32, bool dict = false, bool c16 = false, bool tag16 = false) { return (dict ? kGroupBytesDict : c16 ? (f32 ? kGroupBytes32C16 : kGroupBytes64C16) : f32 ? kGroupBytes32 : kGroupBytes64) + (tag16 ? kTagBytes : 0); }

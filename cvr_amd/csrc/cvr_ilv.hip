@@ -18,6 +18,7 @@
 
 #include <cstring>
 #include <rocprim/block/block_radix_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -40,6 +41,9 @@ struct IlvPartDev {
     int64_t        e0;          // where its elements start in the concatenated key array
     uint32_t       nchunks, chunk0;      // its chunks are numbered chunk0 .. chunk0 + nchunks - 1 over all parts
     uint32_t       pad_col, col_base;
+    uint32_t       gang0, ngangs;        // gang chunks: its gangs are numbered gang0 .. gang0 + ngangs - 1 over all parts
+    uint32_t      *gbase;                // gang chunks without tags: the first column of every group
+    uint32_t       ystage, pad_;         // gang chunks: accumulators per chunk of this image (a tag = chunk inside the gang * ystage + row)
 };
 struct IlvTable { IlvPartDev part[kIlvMaxParts]; int64_t e_end[kIlvMaxParts]; uint32_t chunk_end[kIlvMaxParts]; uint32_t nparts; };
 
@@ -267,6 +271,170 @@ __global__ __launch_bounds__(NT) void ilv_chunk_kernel(const IlvTable *__restric
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline uint32_t bits_of(uint64_t v) { uint32_t b = 1; while (b < 63 && ((uint64_t)1 << b) <= v) b++; return b; }      // bits that hold 0 .. v
 
+// ---- gang chunks (cvr_format.h; spmv_gang_kernel) -----------------------------------------------------------------------------------------
+// The gw chunks of a workgroup are sorted TOGETHER: the list of a gang holds up to gw * 64 S non-zeros (147 000 at four chunks of 576 steps),
+// more than a workgroup sorts in LDS -- so all gangs of all images go through ONE device-wide stable radix sort of (gang << cbits | column,
+// position), four or five passes of eight bits over 8 bytes per non-zero (rocPRIM), and one workgroup per gang writes the gang's groups:
+//   1. gang_key_kernel   : per chunk, key = gang number << cbits | column inside the image, value = the element's place in the images' concatenated order
+//   2. radix_sort_pairs  : stable -- equal (gang, column) keep their positions' order, i.e. ascend by row
+//   3. gang_write_kernel : per gang: the chunks' row starts to LDS; item (group, lane) = the four slots of a lane in a group: chunk and row of each
+//                          element's position (compare with the chunks' first positions, search among the chunk's rows) -> tag = chunk * ystage + row;
+//                          column word = column - the group's first column | tag << 17 (gbase[group] = that column), or column | end flag + 16-bit tag;
+//                          value or dictionary code; desc2[first chunk].x = the gang's groups that hold non-zeros
+// A column further than 2^17 from its group's first sets *err_flag bit 3: cvr_preprocess converts again with 16-bit tags (sparse panels).
+template <typename K>
+__global__ __launch_bounds__(256) void gang_key_kernel(const IlvTable *__restrict__ t, uint32_t gw, uint32_t cbits, K *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                        int64_t *__restrict__ gang_e0, uint32_t ngangs_tot, int64_t n_tot)
+{
+    const uint32_t    kk = blockIdx.x;
+    const IlvPartDev &q = t->part[part_of_chunk(t, kk)];
+    const uint32_t    k = kk - q.chunk0;
+    const int64_t     b = q.nzb[k], e = q.nzb[k + 1];
+    const uint32_t    gang = q.gang0 + k / gw;
+    const K           hi = (K)gang << cbits;
+    if (threadIdx.x == 0 && k % gw == 0) gang_e0[gang] = q.e0 + (b - q.n0);
+    if (kk == 0 && threadIdx.x == 0) gang_e0[ngangs_tot] = n_tot;
+    for (int64_t p = b + threadIdx.x; p < e; p += 256) {
+        const int64_t i = q.e0 + (p - q.n0);
+        keys[i] = hi | (K)((uint32_t)q.ci[p] - q.col_base);
+        vals[i] = (uint32_t)i;
+    }
+}
+
+template <typename K>
+__global__ __launch_bounds__(1024) void gang_write_kernel(const IlvTable *__restrict__ t, const K *__restrict__ keys, const uint32_t *__restrict__ vals, const int64_t *__restrict__ gang_e0,
+                                                           const void *__restrict__ dict_v, uint32_t ndict, int G, uint32_t gw, uint32_t cbits, uint32_t flags,
+                                                           uint32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint64_t *const dl = reinterpret_cast<uint64_t *>(smem);                   // [256] the dictionary
+    uint32_t *const rstart = reinterpret_cast<uint32_t *>(smem + 2048);        // [gw][ystage] the chunks' row starts, relative to the gang's first position
+    __shared__ int64_t  s_cb[kMaxWavesPerBlock + 1];                           // the chunks' first positions (relative likewise), [nc] = the gang's end
+    __shared__ uint32_t s_nri[kMaxWavesPerBlock];
+    const bool     f32 = flags & kIlvF32, use_dict = flags & kIlvDict, tag = flags & kIlvTag;
+    const uint32_t gi = blockIdx.x;
+    uint32_t       pi = 0;
+    while (pi + 1 < t->nparts && t->part[pi].gang0 + t->part[pi].ngangs <= gi) pi++;
+    const IlvPartDev &q = t->part[pi];
+    const uint32_t    ystage = q.ystage;
+    const uint32_t    kg = (gi - q.gang0) * gw, nc = min(gw, q.nchunks - kg);
+    const int64_t     p0 = q.nzb[kg];                                          // the gang's first position in the part's CSR arrays
+    const int64_t     E0 = gang_e0[gi];
+    const uint32_t    n = (uint32_t)(gang_e0[gi + 1] - E0);
+    const uint32_t    GGn = (n + 255u) / 256u;
+    if (threadIdx.x <= nc) s_cb[threadIdx.x] = q.nzb[kg + threadIdx.x] - p0;
+    if (threadIdx.x < nc) { s_nri[threadIdx.x] = q.desc2[kg + threadIdx.x].y; q.desc2[kg + threadIdx.x].x = threadIdx.x == 0 ? GGn : 0u; }
+    uint32_t code0 = 0;
+    if (use_dict) for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) dl[i] = i < ndict ? (f32 ? (uint64_t)static_cast<const uint32_t *>(dict_v)[i] : static_cast<const uint64_t *>(dict_v)[i]) : ~(uint64_t)0;
+    __syncthreads();
+    for (uint32_t c = 0; c < nc; c++) {
+        const uint32_t row_first = q.desc[kg + c].x, nri = s_nri[c];
+        const int64_t  cb = s_cb[c], ce = s_cb[c + 1];
+        for (uint32_t i = threadIdx.x; i < nri; i += blockDim.x) {
+            const int64_t r = q.rp[row_first + i] - p0;                        // (a row cut over chunks begins before its chunk)
+            rstart[c * ystage + i] = (uint32_t)(r < cb ? cb : r > ce ? ce : r);
+        }
+    }
+    __syncthreads();
+    if (use_dict) {
+        while (code0 < ndict && dl[code0] != 0) code0++;
+        if (code0 >= ndict) { if (threadIdx.x == 0) atomicOr(err, 4u); code0 = 0; }
+    }
+    const uint32_t GB = (use_dict ? kGroupBytesDict : f32 ? kGroupBytes32 : kGroupBytes64) + (tag ? kTagBytes : 0);
+    const uint32_t VB = kColsBytes + (tag ? kTagBytes : 0);
+    uint8_t *const base = q.stream + (size_t)kg * G * GB;
+    const K        cm = ((K)1 << cbits) - 1;
+    const uint32_t dump = s_nri[0];                                            // the first chunk's dump entry: where the padding behind the gang's last element adds its zeros
+    const void *const va = q.vals;
+    for (uint32_t it = threadIdx.x; it < GGn * 64u; it += blockDim.x) {
+        const uint32_t g = it >> 6, lane = it & 63u;
+        const uint32_t bcol = (uint32_t)(keys[E0 + (int64_t)g * 256] & cm);    // the group's first = smallest column
+        uint32_t cw[4], tg[4], code[4];
+        uint64_t bits[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t el = g * 256u + (uint32_t)j * 64u + lane;
+            cw[j] = tag ? q.pad_col | kEndBit : 0u | (dump << kGangOffBits);
+            tg[j] = dump; code[j] = code0; bits[j] = 0;
+            if (el < n) {
+                const uint32_t col = (uint32_t)(keys[E0 + el] & cm);
+                const int64_t  rel = (int64_t)vals[E0 + el] - q.e0 + q.n0 - p0;    // the element's position, relative to the gang's first
+                uint32_t       c = 0;
+                while (c + 1 < nc && s_cb[c + 1] <= rel) c++;
+                const uint32_t *rs = rstart + c * ystage;
+                uint32_t        lo = 0, hi = s_nri[c];                         // the last row of the chunk that starts at or before the position
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if ((int64_t)rs[mid] <= rel) lo = mid; else hi = mid; }
+                tg[j] = c * ystage + lo;
+                if (tag) cw[j] = col | kEndBit;
+                else {
+                    const uint32_t off = col - bcol;
+                    if (off >> kGangOffBits) atomicOr(err, 8u);
+                    cw[j] = (off & ((1u << kGangOffBits) - 1u)) | (tg[j] << kGangOffBits);
+                }
+                const int64_t p = p0 + rel;
+                bits[j] = f32 ? (uint64_t)static_cast<const uint32_t *>(va)[p] : static_cast<const uint64_t *>(va)[p];
+            }
+        }
+        if (use_dict) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t el = g * 256u + (uint32_t)j * 64u + lane;
+                if (el < n) {
+                    uint32_t a = 0;
+#pragma unroll
+                    for (uint32_t st = 128; st > 0; st >>= 1) a += dl[a + st - 1] < bits[j] ? st : 0u;
+                    if (a >= ndict || dl[a] != bits[j]) { atomicOr(err, 4u); a = 0; }
+                    code[j] = a;
+                }
+            }
+        }
+        uint8_t *grp = base + (size_t)g * GB;
+        reinterpret_cast<uint4 *>(grp)[lane] = uint4{cw[0], cw[1], cw[2], cw[3]};
+        if (tag) reinterpret_cast<uint2 *>(grp + kColsBytes)[lane] = uint2{tg[0] | (tg[1] << 16), tg[2] | (tg[3] << 16)};
+        if (use_dict) reinterpret_cast<uint32_t *>(grp + VB)[lane] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+        else if (!f32) {
+            reinterpret_cast<uint64_t *>(grp + VB)[lane * 2] = bits[0]; reinterpret_cast<uint64_t *>(grp + VB)[lane * 2 + 1] = bits[1];
+            reinterpret_cast<uint64_t *>(grp + VB + kLanes * 16)[lane * 2] = bits[2]; reinterpret_cast<uint64_t *>(grp + VB + kLanes * 16)[lane * 2 + 1] = bits[3];
+        } else reinterpret_cast<uint4 *>(grp + VB)[lane] = uint4{(uint32_t)bits[0], (uint32_t)bits[1], (uint32_t)bits[2], (uint32_t)bits[3]};
+        if (!tag && lane == 0 && q.gbase) q.gbase[(size_t)kg * G + g] = bcol;
+    }
+}
+
+template <typename K>
+hipError_t convert_gang_typed(const IlvTable &tab, IlvTable *d_tab, uint32_t nchunks_tot, uint32_t ngangs_tot, int64_t N, const DeviceImage &c0, uint32_t ystage_max, uint32_t cbits, uint32_t gbits,
+                              uint32_t *err_flag, uint8_t *scratch, size_t scratch_bytes, size_t off, hipStream_t st)
+{
+    (void)tab;
+    const size_t n = (size_t)N;
+    K        *k_in = reinterpret_cast<K *>(scratch + off);            off += up256(sizeof(K) * n);
+    K        *k_out = reinterpret_cast<K *>(scratch + off);           off += up256(sizeof(K) * n);
+    uint32_t *v_in = reinterpret_cast<uint32_t *>(scratch + off);     off += up256(sizeof(uint32_t) * n);
+    uint32_t *v_out = reinterpret_cast<uint32_t *>(scratch + off);    off += up256(sizeof(uint32_t) * n);
+    int64_t  *ge0 = reinterpret_cast<int64_t *>(scratch + off);       off += up256(sizeof(int64_t) * ((size_t)ngangs_tot + 1));
+    if (off > scratch_bytes) return hipErrorInvalidValue;
+    size_t temp_bytes = scratch_bytes - off;
+    size_t need = 0;
+    hipError_t e = n ? rocprim::radix_sort_pairs(nullptr, need, k_in, k_out, v_in, v_out, n, 0u, cbits + gbits, st) : hipSuccess;
+    if (e != hipSuccess) return e;
+    if (need > temp_bytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gang_key_kernel<K>, dim3(nchunks_tot), dim3(256), 0, st, d_tab, c0.gang, cbits, k_in, v_in, ge0, ngangs_tot, N);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (n) e = rocprim::radix_sort_pairs(scratch + off, need, k_in, k_out, v_in, v_out, n, 0u, cbits + gbits, st);
+    if (e != hipSuccess) return e;
+    const uint32_t flags = (c0.f32 ? kIlvF32 : 0u) | (c0.dict ? kIlvDict : 0u) | (c0.tag16 ? kIlvTag : 0u);
+    const size_t   lds = 2048 + sizeof(uint32_t) * (size_t)c0.gang * ystage_max;
+    static bool    attr[2] = {false, false};
+    if (!attr[sizeof(K) == 8]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gang_write_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsBytes - 1024));
+        if (e != hipSuccess) return e;
+        attr[sizeof(K) == 8] = true;
+    }
+    if (lds > kLdsBytes - 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gang_write_kernel<K>, dim3(ngangs_tot), dim3(1024), lds, st, d_tab, k_out, v_out, ge0, c0.dict, c0.ndict, c0.G, c0.gang, cbits, flags, err_flag);
+    return hipGetLastError();
+}
+
 template <int NT, int IPT, int RB = 0>
 hipError_t launch_chunks(const IlvTable *d_tab, uint32_t nchunks_tot, const DeviceImage &c, uint32_t ystage_max, uint32_t cbits, uint32_t *err_flag, hipStream_t st)
 {
@@ -306,10 +474,18 @@ hipError_t launch_chunks(const IlvTable *d_tab, uint32_t nchunks_tot, const Devi
 }  // namespace
 
 // device scratch of a conversion (the table of the images; the sort itself happens in LDS)
-size_t convert_interleaved_scratch(int64_t nnz, uint32_t nchunks)
+size_t convert_interleaved_scratch(int64_t nnz, uint32_t nchunks, bool gang)
 {
-    (void)nnz; (void)nchunks;
-    return up256(sizeof(IlvTable)) + 256;
+    size_t bytes = up256(sizeof(IlvTable)) + 256;
+    if (gang) {          // keys (64 bits at most) and positions, in and out; the gangs' first elements (a gang has two chunks or more); the sort's own storage
+        const size_t n = (size_t)std::max<int64_t>(nnz, 0);
+        size_t       temp = 0;
+        uint64_t    *k = nullptr;
+        uint32_t    *v = nullptr;
+        if (n && rocprim::radix_sort_pairs(nullptr, temp, k, k, v, v, n, 0u, 64u, (hipStream_t) nullptr) != hipSuccess) temp = n * 16 + (1 << 20);
+        bytes += 2 * up256(8 * n) + 2 * up256(4 * n) + up256(8 * ((size_t)nchunks + 2 * kIlvMaxParts + 2)) + up256(temp) + 4096;
+    }
+    return bytes;
 }
 
 // The interleaved images imgs[0 .. n) (all of one handle: same chunk length, value type, dictionary, tag width and row field) converted
@@ -343,6 +519,21 @@ hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const Devi
     static_assert((kIlvMaxSteps + 15) / 16 <= 36, "the longest interleaved chunk needs more than 36 pairs per thread");
     if (up256(sizeof(IlvTable)) > scratch_bytes || ipt > 36 || ystage_max > 65536u) return hipErrorInvalidValue;      // (position 16 bits, row 16 bits in the sort's payload; 36 pairs per thread: 144 KiB of LDS)
     IlvTable *d_tab = static_cast<IlvTable *>(scratch);
+    if (c0.gang) {          // gang chunks: one device-wide sort, one workgroup per gang writes
+        uint32_t ng = 0;
+        for (int i = 0; i < n; i++) {
+            if (imgs[i]->gang != c0.gang || (!c0.tag16 && !imgs[i]->gbase)) return hipErrorInvalidValue;
+            tab.part[i].gang0 = ng; tab.part[i].ngangs = (imgs[i]->nchunks + c0.gang - 1) / c0.gang; tab.part[i].gbase = imgs[i]->gbase; tab.part[i].ystage = imgs[i]->ystage;
+            ng += tab.part[i].ngangs;
+        }
+        if (e >= (int64_t)0xffffffffll || c0.gang > (uint32_t)kMaxWavesPerBlock || (uint64_t)c0.gang * ystage_max > (c0.tag16 ? 65536ull : (1ull << kGangTagBits))) return hipErrorInvalidValue;
+        hipError_t rg = hipMemcpyAsync(d_tab, &tab, sizeof(IlvTable), hipMemcpyHostToDevice, st);
+        if (rg != hipSuccess) return rg;
+        const uint32_t gbits = bits_of(ng ? ng - 1 : 0);
+        uint8_t *const sc = static_cast<uint8_t *>(scratch);
+        if (cbits + gbits <= 32) return convert_gang_typed<uint32_t>(tab, d_tab, c, ng, e, c0, ystage_max, cbits, gbits, err_flag, sc, scratch_bytes, up256(sizeof(IlvTable)), st);
+        return convert_gang_typed<uint64_t>(tab, d_tab, c, ng, e, c0, ystage_max, cbits, gbits, err_flag, sc, scratch_bytes, up256(sizeof(IlvTable)), st);
+    }
     hipError_t rc = hipMemcpyAsync(d_tab, &tab, sizeof(IlvTable), hipMemcpyHostToDevice, st);
     if (rc != hipSuccess) return rc;
     // (1 024 threads leave 128 registers each: 16 (column, position) pairs per thread sort without spills, 24 spill 92 bytes, 32 spill 470;

@@ -11,7 +11,7 @@ using namespace cvrh;
 namespace {
 
 constexpr uint64_t kImgMagic = 0x3130474d49525643ull;      // "CVRIMG01"
-constexpr uint32_t kImgVersion = 9;                        // bump when DeviceImage / the handle's tables change
+constexpr uint32_t kImgVersion = 10;                       // bump when DeviceImage / the handle's tables change
 
 struct ImgKey {
     uint64_t       magic;
@@ -88,7 +88,7 @@ struct ImgScalars {
     int64_t  part_nrows, part_nnz, part_nnz_span, part_nchunks, part_nshared, part_yext, part_zoff;
     uint64_t stream_bytes;
     int32_t  multi_slot, ilv;      // where the panel stands in the rounds of eight (-1: none)
-    uint32_t col_base, reserved;
+    uint32_t col_base, gang;          // gang: wavefronts that walk one common list (0 = none)
 };
 
 }  // namespace
@@ -127,7 +127,7 @@ int cvr_save_image(cvr_handle *h, const char *path, const cvr_source_key *key)
         s.piece_max = g.piece_max; s.hub_n = g.hub_n; s.order_n = g.order_n; s.ncus = g.ncus;
         s.part_nrows = p.nrows; s.part_nnz = p.nnz; s.part_nnz_span = p.nnz_span; s.part_nchunks = p.nchunks; s.part_nshared = p.nshared; s.part_yext = p.yext; s.part_zoff = p.zoff;
         s.stream_bytes = p.stream_bytes;
-        s.multi_slot = p.multi_slot; s.ilv = g.ilv ? 1 : 0; s.col_base = g.col_base;
+        s.multi_slot = p.multi_slot; s.ilv = g.ilv ? 1 : 0; s.col_base = g.col_base; s.gang = g.gang;
         w.pod(s);
         const size_t nc = (size_t)g.nchunks;
         const size_t slack = 8 * (size_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16);
@@ -139,6 +139,7 @@ int cvr_save_image(cvr_handle *h, const char *path, const cvr_source_key *key)
         w.dev(g.win_base, sizeof(uint32_t) * (nc / std::max<uint32_t>(g.wpb, 1u) + 1), host);
         w.dev(g.desc2, g.desc2 ? 8 * nc : 0, host);
         w.dev(g.cbase, g.cbase ? sizeof(uint32_t) * nc : 0, host);
+        w.dev(g.gbase, g.gbase ? sizeof(uint32_t) * (nc * (size_t)g.G + 4096) : 0, host);
         w.dev(g.hub_cols, g.hub_cols ? sizeof(int32_t) * (size_t)(g.order_n ? g.order_n : g.hub_n) : 0, host);
         nsub += p.nrows;
     }
@@ -222,7 +223,7 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         g.piece_max = s.piece_max; g.hub_n = s.hub_n; g.order_n = s.order_n; g.ncus = s.ncus;
         p.nrows = s.part_nrows; p.nnz = s.part_nnz; p.nnz_span = s.part_nnz_span; p.nchunks = s.part_nchunks; p.nshared = s.part_nshared; p.yext = s.part_yext; p.zoff = s.part_zoff;
         p.stream_bytes = (size_t)s.stream_bytes;
-        p.multi_slot = s.multi_slot; g.ilv = s.ilv != 0; g.col_base = s.col_base;
+        p.multi_slot = s.multi_slot; g.ilv = s.ilv != 0; g.col_base = s.col_base; g.gang = s.gang;
         g.dict = h->d_dict;
         // the scalars must describe one consistent image: every array below is then required to have exactly the size they imply, and the
         // kernels' LDS and index arithmetic stays inside what cvr_create could have produced
@@ -233,7 +234,8 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
                               g.phases >= 1 && g.phases <= 64 && g.ystage >= 1 && g.ystage <= 65532 && g.col_bits <= 31 && g.ndict == h->ndict && (g.f32 ? 4u : 8u) == have.vsz &&
                               (uint64_t)g.col_base + g.pad_col <= (uint64_t)h->info.ncols && (g.ilv ? h->info.col_panels > 1 || (g.col_base == 0 && g.pad_col == (uint64_t)h->info.ncols) : g.col_base == 0 && g.pad_col == (uint64_t)h->info.ncols) && (!g.c16 || (!g.tag16 && g.phases == 1)) && (g.order_n == 0 || g.order_n == g.pad_col) &&
                               s.stream_bytes == nc * (uint64_t)s.G * (uint64_t)cvr::group_bytes(g.f32, g.dict != nullptr, g.c16, g.tag16) &&
-                              (s.multi_slot < 0 || (has_multi && (uint32_t)s.multi_slot < nrounds * 8)) && cvr::spmv_lds_bytes(g) <= cvr::kLdsBytes;
+                              (s.multi_slot < 0 || (has_multi && (uint32_t)s.multi_slot < nrounds * 8)) && cvr::spmv_lds_bytes(g) <= cvr::kLdsBytes &&
+                              (g.gang == 0 || (g.ilv && g.gang == g.wpb && g.gang >= 2 && (uint64_t)g.gang * g.ystage <= (g.tag16 ? 65536ull : 1ull << cvr::kGangTagBits) && (g.tag16 || g.col_bits == (uint32_t)cvr::kGangOffBits)));
             if (!sane) { r.ok = false; LOAD_TRY(hipSuccess); }
             // panels that run one per XCD: every part has a slot of its own in d_multi (two parts on one slot would leave one of them
             // unlaunched -- its slice of z stays zero, y silently wrong --; a part without a slot in a file that has the table likewise)
@@ -255,6 +257,8 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         if (g.phases > 1 && nc64 && !g.desc2) { r.ok = false; LOAD_TRY(hipSuccess); }
         LOAD_TRY(r.dev(g.cbase, pinned, pinned_bytes, h->stream, sizeof(uint32_t) * nc64, !g.c16));
         if (g.c16 && nc64 && !g.cbase) { r.ok = false; LOAD_TRY(hipSuccess); }
+        LOAD_TRY(r.dev(g.gbase, pinned, pinned_bytes, h->stream, sizeof(uint32_t) * (nc64 * (uint64_t)g.G + 4096), !(g.gang && !g.tag16)));
+        if (g.gang && !g.tag16 && !g.gbase) { r.ok = false; LOAD_TRY(hipSuccess); }
         LOAD_TRY(r.dev(g.hub_cols, pinned, pinned_bytes, h->stream, sizeof(int32_t) * (uint64_t)(g.order_n ? g.order_n : g.hub_n), g.hub_n == 0));
         if (g.hub_n && !g.hub_cols) { r.ok = false; LOAD_TRY(hipSuccess); }
         if (g.hub_n) LOAD_TRY(hipMalloc(&g.hub_x, vsz * (g.order_n ? ((size_t)g.order_n + 8) : ((g.hub_n + 3u) & ~3u))));
@@ -287,10 +291,10 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         LOAD_TRY(hipMemcpy(h->d_fixparts, fp.data(), sizeof(cvr::FixPart) * nparts, hipMemcpyHostToDevice));
         if (has_multi) {
             const size_t per_round = 8;
-            std::vector<cvr::PanelArgs> pa((size_t)nrounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u});
+            std::vector<cvr::PanelArgs> pa((size_t)nrounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u, nullptr});
             for (uint32_t j = 0; j < nparts; j++) {       // every panel where cvr_create placed it (the heaviest first, each on the XCD with the least work)
                 const Part &p = h->parts[j];
-                pa[p.multi_slot >= 0 ? (size_t)p.multi_slot : (j / per_round) * 8 + j % per_round] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col};
+                pa[p.multi_slot >= 0 ? (size_t)p.multi_slot : (j / per_round) * 8 + j % per_round] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col, p.img.gbase};
             }
             LOAD_TRY(hipMalloc(&h->d_multi, sizeof(cvr::PanelArgs) * pa.size()));
             LOAD_TRY(hipMemcpy(h->d_multi, pa.data(), sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyHostToDevice));

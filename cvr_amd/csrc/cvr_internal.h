@@ -127,6 +127,7 @@ struct Part {
         if (img.hub_bitmap) (void)hipFree(img.hub_bitmap);
         if (img.hub_x) (void)hipFree(img.hub_x);
         if (img.prof) (void)hipFree(img.prof);
+        if (img.gbase) (void)hipFree(img.gbase);
         img = cvr::DeviceImage{};
     }
 };
@@ -216,6 +217,7 @@ struct PartPlan {
     bool     tag16 = false;        // column phases: the rows of the pieces in 16-bit tags of their own
     bool     lds_short = false;    // column phases do not fit beside the window
     bool     ilv = false;          // interleaved chunks (cvr_options.interleave): planned like an image with column phases (row cap, accumulators in LDS)
+    bool     gang = false;         // gang chunks (cvr_options.gang): the workgroup's chunks are sorted together; the row field is the tag's share of a chunk
     int      plan_threads = 0;     // 0: the planner's own small team; 1: the caller plans several images side by side
     int64_t  hub_n = 0;            // hub table entries staged in LDS in front of the window (decided before planning)
     // the plan stayed on the device (plan_panels_batched): nzb / pad / desc / cut rows are in the part's buffers already, only the counts came back

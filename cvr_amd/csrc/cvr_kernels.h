@@ -42,6 +42,8 @@ struct DeviceImage {
     bool      tag16 = false;        // column phases: the rows of the pieces stand in 16-bit tags of their own (col_bits = 31)
     uint32_t  col_base = 0;         // interleaved column panels: the image's column indices are relative to this column (pad_col = the panel's width)
     bool      ilv = false;          // interleaved chunks (cvr_ilv.hip): the image is written in the column-phase format with every slot a piece of its own
+    uint32_t  gang = 0;             // > 0 (= wpb): gang chunks -- the wpb chunks of a workgroup sorted together, walked by its wavefronts in turn (cvr_format.h)
+    uint32_t *gbase = nullptr;      // gang chunks without 16-bit tags: [nchunks * G] the first column of every group (group g of gang b at (b * wpb) * G + g)
     unsigned long long *prof = nullptr;      // CVR_DEBUG=phase_clocks: [workgroups * 16 wavefronts][8] time stamps of spmv_seg_kernel's phases (diagnostics; null otherwise)
     uint32_t  prof_words = 0;
     uint32_t  ilv_helpers = 0, ilv_ahead = 16, ilv_per_line = 1;
@@ -112,7 +114,7 @@ hipError_t launch_convert(const DeviceImage &img, const DeviceCsr &csr, uint32_t
 // interleaved chunks (cvr_ilv.hip): the images' non-zeros sorted by column inside every chunk and dealt to the lanes in that order; the
 // images of one handle (same chunk length, value type, dictionary, tag width) go together: one sort, one writing pass.
 // `scratch`: convert_interleaved_scratch(sum of the non-zeros, ..) bytes of device memory; *err_flag bit 2: a value that is not in the dictionary
-size_t     convert_interleaved_scratch(int64_t nnz, uint32_t nchunks);
+size_t     convert_interleaved_scratch(int64_t nnz, uint32_t nchunks, bool gang = false);      // gang: + the device-wide sort's keys, positions and storage (cvr_ilv.hip)
 hipError_t launch_convert_interleaved(const DeviceImage *const *imgs, const DeviceCsr *csrs, const int64_t *n0, const int64_t *n1, int n, uint32_t *err_flag, void *scratch,
                                       size_t scratch_bytes, hipStream_t st);
 // codes[j] = dictionary code of vals[j], j in [n0, n1) (one coalesced pass; *err_flag bit 2: a value that is not in the dictionary)
@@ -207,7 +209,7 @@ hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, 
 hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st, const uint32_t *nchunks_dev = nullptr);
 
 // column panels, one panel per XCD at a time: what differs between the eight panels of one launch (device array of 8; nchunks = 0: none)
-struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *target; void *yext; uint32_t nchunks, ystage; const uint2 *desc2; uint32_t col_base, pad_col; };      // (col_base, pad_col: interleaved panels keep panel-local columns)
+struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *target; void *yext; uint32_t nchunks, ystage; const uint2 *desc2; uint32_t col_base, pad_col; const uint32_t *gbase; };      // (col_base, pad_col: interleaved panels keep panel-local columns)
 // y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0 and with_fixup)
 // multi != null: eight panels in one launch (plain layout, one chunk per workgroup, no LDS tables): workgroup b takes chunk b >> 3 of
 // panel b & 7 of its round; multi[rounds][8]; multi_chunks = the most chunks any panel has (the rounds follow each other in ONE grid:

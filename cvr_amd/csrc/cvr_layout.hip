@@ -42,6 +42,8 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
     // inside it are served by ds_read instead of a 128-byte L1 fill each.
     pp.win = std::min<int64_t>(opt.x_window < 0 ? 0 : opt.x_window, ncols + 1) & ~(int64_t)3;      // whole 16-byte loads, inside x_ext
     if (pp.ilv) pp.win = 0;
+    // gang chunks: the workgroup's chunks sorted together and walked by its wavefronts in turn (spmv_gang_kernel); at least two of them
+    pp.gang = pp.ilv && opt.gang > 0 && pp.wpb >= 2;
     const int64_t vs = f32 ? 4 : 8;
     int64_t       max_rows = 0;
     if (pp.phases > 1) {
@@ -52,7 +54,10 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
         while (((int64_t)1 << pp.col_bits) <= std::max<int64_t>(ncols, opt.col_span)) pp.col_bits++;      // (column panels of one launch: one width for all)
         // (an interleaved column word has no end flag -- every slot ends a piece --, so its row field has one bit more; and its chunks may
         // take every accumulator the LDS holds: 5 052 fp64 rows for each of four wavefronts)
-        const int64_t row_field = pp.ilv ? (pp.col_bits < 32 ? ((int64_t)1 << (32 - pp.col_bits)) - 1 : 0) : pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
+        // (gang chunks: the column word holds an offset of kGangOffBits bits from the group's first column, whatever the image's width, and a tag of
+        // kGangTagBits bits = chunk inside the gang * accumulators + row: a chunk's share of the tags is its row field)
+        if (pp.gang) pp.col_bits = cvr::kGangOffBits;
+        const int64_t row_field = pp.gang ? (((int64_t)1 << cvr::kGangTagBits) / pp.wpb) - 1 : pp.ilv ? (pp.col_bits < 32 ? ((int64_t)1 << (32 - pp.col_bits)) - 1 : 0) : pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
         auto rows_for = [&](int64_t win) {
             const int64_t left = (int64_t)cvr::kLdsBytes - (cvr::kDictMax + win + 8) * vs;      // (no steal slots: spmv_seg_kernel; window + zero slot + the epilogue's arrival counter)
             return std::min<int64_t>((left / pp.wpb / vs) & ~(int64_t)3, pp.ilv ? 2 * (int64_t)cvr::kYStageMax : cvr::kYStageMax);
@@ -63,7 +68,7 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
         // wide row tags (16 bits of their own per slot) when the column word has no room for the rows such a chunk may hold
         pp.tag16 = opt.row_tags16 > 0 || (opt.row_tags16 < 0 && row_field + 1 < want) || (pp.ilv && row_field + 1 < 64);      // (an interleaved image always has its accumulators: tags when the column word has no room at all)
         if (pp.tag16) pp.col_bits = 31;
-        pp.stage = std::min<int64_t>(want, pp.tag16 ? (int64_t)65532 : (row_field + 1) & ~(int64_t)3);
+        pp.stage = std::min<int64_t>(want, pp.tag16 ? (pp.gang ? ((int64_t)65536 / pp.wpb) & ~(int64_t)3 : (int64_t)65532) : (row_field + 1) & ~(int64_t)3);
         if (pp.stage < 64) { pp.lds_short = true; pp.phases = 1; pp.stage = 64; }
         else max_rows = pp.stage - 1;                 // + the dump entry of the pad segment
     }
@@ -484,6 +489,7 @@ int setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, in
         // pieces: a lane that sits on a long row's segment falls behind the column ranges the other lanes have moved on to; with
         // chunks longer than a few steps per phase the segments are cut (auto: 8 elements once a phase takes 8 steps or more)
         img.ilv = pp.ilv;
+        img.gang = pp.gang ? (uint32_t)pp.wpb : 0u;
         if (cvr::debug_env("phase_clocks") && !pp.ilv && !f32) {          // room for the time stamps of every wavefront of the launch (spmv_seg_kernel<.., PROF>)
             const size_t words = ((size_t)nchunks / (size_t)std::max(pp.wpb, 1) + 16) * 16 * 8;
             if (hipMalloc(&img.prof, words * sizeof(unsigned long long)) == hipSuccess) { img.prof_words = (uint32_t)words; (void)hipMemset(img.prof, 0, words * sizeof(unsigned long long)); }
@@ -796,6 +802,14 @@ int finish_part(cvr_handle *h, Part &part)
         HIP_TRY(hipExtMallocWithFlags((void **)&img.stream, part.stream_bytes + slack, hipDeviceMallocUncached));
     else
         HIP_TRY(hipMalloc(&img.stream, part.stream_bytes + slack));
+    // gang chunks: only the groups that hold a gang's non-zeros are written by the converter; the rest of its chunks' allocations is never read, but an
+    // image is a deterministic function of its matrix (the image cache, the mirror's bits): zeros
+    if (img.gang) HIP_TRY(hipMemsetAsync(img.stream, 0, part.stream_bytes + slack, h->stream));
+    if (img.gang && !img.tag16) {          // gang chunks: the first column of every group (zeros behind a gang's last group and behind the last gang: the kernel's ring runs ahead)
+        const size_t nb = sizeof(uint32_t) * ((size_t)part.nchunks * img.G + 4096);
+        HIP_TRY(hipMalloc(&img.gbase, nb));
+        HIP_TRY(hipMemsetAsync(img.gbase, 0, nb, h->stream));
+    }
     return CVR_OK;
 }
 

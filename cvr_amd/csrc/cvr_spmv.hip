@@ -211,6 +211,10 @@ template <typename T> __device__ __forceinline__ void lds_add(T *p, T v)
 {
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);      // ds_add_f64 / ds_add_f32
 }
+template <typename T> __device__ __forceinline__ void lds_add_wg(T *p, T v)      // the same instruction; accumulators that other wavefronts of the workgroup add into as well (gang chunks)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // four steps of all 64 lanes: FMA, then the write-back of the lanes whose segment ends at the step.  (Images with column phases
 // run through spmv_seg_kernel below, which needs none of this hand-out state.)
@@ -799,13 +803,13 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-template <typename T, bool DICT, bool TAG> struct RingLayout {
+template <typename T, bool DICT, bool TAG, int CAP = kRingCap> struct RingLayout {
     static constexpr int D = 4;                                                                     // groups of gathers in flight
     static constexpr int XSZ = sizeof(T) == 8 ? 8 : 4;                                              // registers of an x slot
     static constexpr int TOFF = 4, VOFF = 4 + (TAG ? 2 : 0);                                        // tags / values inside a Q slot
     static constexpr int QSZ = (VOFF + (DICT ? 1 : sizeof(T) == 8 ? 8 : 4) + 1) & ~1;               // registers of a Q slot (even: 64-bit pairs stay aligned)
     static constexpr int NS = 1 + (TAG ? 1 : 0) + (DICT ? 1 : sizeof(T) == 8 ? 2 : 1);              // stream loads per group
-    static constexpr int XB = kRingCap, QB = XB + D * XSZ, TOP = QB + 2 * D * QSZ;
+    static constexpr int XB = CAP, QB = XB + D * XSZ, TOP = QB + 2 * D * QSZ;
     static_assert(TOP <= 256, "the ring does not fit 256 registers");
     // registers of the kernel (ring included) -> wavefronts a SIMD holds -> the largest workgroup: 4 chunks' computing wavefronts + their
     // helper wavefronts (below)
@@ -1005,6 +1009,239 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG>::THREADS)) __attribute__(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (uint32_t i = lane; i < nri; i += kLanes) {          // the rows leave coalesced (head / last row of a chunk that shares it: its carry slot)
+        const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
+        store_y(yext + dst, ystage[i]);
+    }
+}
+
+
+// ---- gang chunks: spmv_gang_kernel (round 6) ---------------------------------------------------------------------------------------------
+// The interleaved kernel above keeps one sorted list per wavefront: a gather instruction's 64 columns come from ~36 000 non-zeros spread over
+// a panel's 2-3 MB of x, about two of them per 128-byte line, and the L2s' request count -- lines, not lanes -- stays at ~0.46
+// per non-zero.  A GANG is the workgroup's nw chunks sorted TOGETHER (cvr_ilv.hip): element e of the common list stands in group e / 256 of
+// the gang's stream, so an instruction's 64 columns are neighbours among ~140 000 non-zeros and share their lines four times as often.  The
+// wavefronts take the groups in turn, kGangUnit at a time (unit n -> wavefront n % nw); rows' sums still live in the chunks' LDS accumulators
+// (a slot's tag = chunk inside the gang * ystage + row), every chunk is written out by its own wavefront as before.
+// ORDER: several wavefronts now add into the same accumulators, and y must not depend on their timing.  A unit's products are computed as its
+// loads land and wait in registers; the additions themselves are issued only while the unit holds the TOKEN -- a word in LDS that counts the
+// units done: unit n spins until it reads n, issues its 4 kGangUnit ds_add, writes n + 1.  The LDS executes what it receives in order, so
+// every row's products are added in the order of the gang's sorted list -- column order, the order of the CSR loop (spmv.cpp:1843-1850) --
+// bit for bit, whatever the wavefronts do in between.  Nothing but those additions happens inside the hold (the first form held it across
+// the dictionary look-ups and ran 380 us where private chunks ran 246; with only the adds inside: 205, with two groups per unit 200, and
+// 178 us at 4 x 4 800 rows on the soc-LiveJournal1 shape, 510 against 736 on the com-Orkut shape: profiles/r06_token_probe_*.log).
+// Column words without 16-bit tags: offset from the group's first column (17 bits) | tag (15 bits); the groups' first columns come through
+// the scalar cache a revolution of the ring ahead (gbase).
+constexpr int kGangCap = 72;          // the compiler's registers v0 .. v71 (the ilv kernel's 40 + a unit's products and tags); the ring above
+template <typename T, bool DICT, bool TAG, bool SNT>
+__global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __attribute__((amdgpu_num_vgpr(kGangCap))) void spmv_gang_kernel(
+    const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint2 *__restrict__ desc2_a, const T *__restrict__ x, T *__restrict__ yext_a, int G_alloc,
+    uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes_a, const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, uint32_t col_bits,
+    uint32_t col_base_a, const PanelArgs *__restrict__ multi, uint32_t nw_compute, uint32_t help_ahead, uint32_t help_per_line, uint32_t flip, const uint32_t *__restrict__ gbase_a)
+{
+    using L = RingLayout<T, DICT, TAG, kGangCap>;
+    constexpr int D = L::D, QN = 2 * D, XB = L::XB, QB = L::QB, K = (D - 1) * (4 + L::NS), U = kGangUnit;
+    static_assert(QN % U == 0, "a unit is whole ring slots");
+    ring_claim<L::REGS>();
+    const uint8_t *__restrict__  stream = stream_a;
+    const uint4 *__restrict__    desc = desc_a;
+    const uint2 *__restrict__    desc2 = desc2_a;
+    const uint32_t *__restrict__ gbase = gbase_a;
+    T *__restrict__              yext = yext_a;
+    const uint32_t               bx = flip ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+    uint32_t                     nchunks = nchunks_a, ystage_n = ystage_a, bidx = bx, col_base = col_base_a, xbytes = xbytes_a;
+    if (multi) {
+        const uint32_t  round = bx / nblocks_per_xcd, b = bx - round * nblocks_per_xcd;
+        const PanelArgs pa = multi[round * 8u + (b & 7u)];
+        stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
+        col_base = pa.col_base; xbytes = (pa.pad_col + 1u) * (uint32_t)sizeof(T); gbase = pa.gbase;
+        bidx = b >> 3;
+    }
+    constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
+    constexpr uint32_t VB = kColsBytes + (TAG ? kTagBytes : 0);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t nw = nw_compute, nwt = blockDim.x >> 6;
+    T *const ystage_all = reinterpret_cast<T *>(smem);
+    T *const dict = ystage_all + nw * ystage_n;
+    uint32_t *const prog = reinterpret_cast<uint32_t *>(dict + (DICT ? kDictMax : 0));      // [0]: the gang's group the first wavefront has reached (the helpers' pace); [8]: the token
+    uint32_t *const tok = prog + 8;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t blk = remap_block(bidx, nblocks_per_xcd, swz);
+    const bool     helper = wv >= nw;
+    const uint32_t kg = __builtin_amdgcn_readfirstlane(blk * nw);          // the gang's first chunk
+    const uint32_t k = __builtin_amdgcn_readfirstlane(kg + (helper ? 0u : wv));      // this wavefront's own chunk: the rows it writes out
+    const bool     live = kg < nchunks, own = !helper && k < nchunks;
+    T dv[4] = {T(0), T(0), T(0), T(0)};
+    if constexpr (DICT) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = threadIdx.x + (uint32_t)u * blockDim.x; if (i < ndict) dv[u] = dict_g[i]; }
+    }
+    const uint4    d = own ? desc[k] : uint4{0, 0, 0, 0};
+    const uint2    d2 = own ? desc2[k] : uint2{0, 0};
+    const uint32_t GGl = live ? desc2[kg].x : 0u;                        // the groups of the gang that hold its non-zeros (written by the converter)
+    const uint64_t sbase = reinterpret_cast<uint64_t>(stream + (size_t)(live ? kg : 0) * ((size_t)G_alloc * GB));
+    const uint64_t sbase_u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sbase) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32)) << 32);
+    const uint32_t galloc = __builtin_amdgcn_readfirstlane(min(nw, nchunks - min(kg, nchunks)) * (uint32_t)G_alloc);      // groups of the gang's chunks' allocations
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(reinterpret_cast<const void *>(sbase_u), __builtin_amdgcn_readfirstlane(galloc * GB));
+    const uint32_t vo_c = lane * 16u, vo_t = lane * 8u + (uint32_t)kColsBytes, vo_code = lane * 4u + VB, vo_v0 = lane * 16u + VB, vo_v1 = vo_v0 + (uint32_t)kLanes * 16u;
+    (void)vo_t; (void)vo_code; (void)vo_v1;
+    // the wavefront's t-th group is group gg(t) of the gang: units of U groups in turn
+    const uint32_t wvU = wv * (uint32_t)U, nwU = nw * (uint32_t)U;
+    auto gg = [&](uint32_t t) { return (t / (uint32_t)U) * nwU + wvU + t % (uint32_t)U; };
+    auto load_q_from = [&](const __amdgpu_buffer_rsrc_t rs, auto qsc, uint32_t grp) {
+        constexpr int  R = QB + decltype(qsc)::value * L::QSZ;
+        const uint32_t so = grp * GB;
+        ring_ld128s<R, SNT>(vo_c + so, rs, 0u);
+        if constexpr (TAG) ring_ld64s<R + L::TOFF, SNT>(vo_t + so, rs, 0u);
+        if constexpr (DICT) ring_ld32s<R + L::VOFF, SNT>(vo_code + so, rs, 0u);
+        else if constexpr (sizeof(T) == 8) { ring_ld128s<R + L::VOFF, SNT>(vo_v0 + so, rs, 0u); ring_ld128s<R + L::VOFF + 4, SNT>(vo_v1 + so, rs, 0u); }
+        else ring_ld128s<R + L::VOFF, SNT>(vo_v0 + so, rs, 0u);
+    };
+    if (live && !helper) static_for<0, D>([&](auto ic) { load_q_from(rs0, ic, gg((uint32_t)decltype(ic)::value)); });
+    if (!helper) for (uint32_t i = lane; i < ystage_n; i += kLanes) ystage_all[wv * ystage_n + i] = T(0);
+    if (threadIdx.x < 16u) prog[threadIdx.x] = 0u;
+    if constexpr (DICT) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = threadIdx.x + (uint32_t)u * blockDim.x; if (i < (uint32_t)kDictMax) dict[i] = dv[u]; }
+    }
+    __syncthreads();                                                     // accumulators zeroed, token 0: from here on any wavefront may add into any chunk's rows
+    if (!live) return;
+    const uint32_t nri = d2.y;
+    const uint32_t G = __builtin_amdgcn_readfirstlane(min(galloc, GGl));
+    if (helper) {
+        // as in spmv_ilv_kernel, over the gang's stream: helper h of all H takes batches h, h + H, ..., paced by the first wavefront's place in the gang
+        constexpr uint32_t kHB = 15, LPG = GB / 128u;
+        static_assert(GB % 128u == 0, "a group is whole 128-byte lines");
+        const uint32_t H = nwt - nw, h = wv - nw;
+        const uint32_t nlines = G * LPG, last = nlines ? (nlines - 1u) * 128u : 0u;
+        const uint32_t step = help_per_line > 1 ? 64u : 128u, per = help_per_line > 1 ? kHB / 2u : kHB;
+        const uint32_t ahead = help_ahead * nw, late = (uint32_t)QN * nw + 2u;
+        for (uint32_t line = (uint32_t)(2 * QN) * nw * LPG + h * per; line < nlines; line += H * per) {
+            const uint32_t tg = line / LPG;
+            uint32_t       gc;
+            for (;;) {
+                gc = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tg <= gc + ahead) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (tg < gc + late) continue;
+            const uint32_t o0 = line * 128u;
+            uint32_t       j[kHB];
+#pragma unroll
+            for (uint32_t i = 0; i < kHB; i++) {
+                const uint32_t off = min(o0 + i * step, last);
+                asm volatile("s_load_dword %0, %1, %2" : "=&s"(j[i]) : "s"(sbase_u), "s"(off) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+s"(j[0]), "+s"(j[1]), "+s"(j[2]), "+s"(j[3]), "+s"(j[4]), "+s"(j[5]), "+s"(j[6]), "+s"(j[7]), "+s"(j[8]), "+s"(j[9]), "+s"(j[10]), "+s"(j[11]), "+s"(j[12]),
+                           "+s"(j[13]), "+s"(j[14])
+                         :: "memory");
+        }
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x + col_base, xbytes);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const void *>(sbase_u), __builtin_amdgcn_readfirstlane(G * GB));
+    auto load_q = [&](auto qsc, uint32_t grp) { load_q_from(rs, qsc, grp); };
+    // the groups' first columns (no tags): gang group g at gb[g]; a wavefront's groups of one revolution are QN / U pairs nw U apart
+    // (through the scalar cache: the pointer is made wave-uniform and constant-address-space by hand -- as a generic pointer out of PanelArgs the
+    // compiler loads through the vector path, which the counted waits of the ring do not allow)
+    typedef const uint32_t __attribute__((address_space(4))) *cptr_t;
+    const uint64_t gbp = reinterpret_cast<uint64_t>(gbase ? gbase + (size_t)kg * (size_t)G_alloc : nullptr);
+    const cptr_t   gb = (cptr_t)((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)gbp) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(gbp >> 32)) << 32));
+    uint32_t bcur[QN], bnext[QN];
+#pragma unroll
+    for (int i = 0; i < QN; i++) { bcur[i] = 0u; bnext[i] = 0u; }
+    auto bases_of = [&](uint32_t tb, uint32_t (&b)[QN]) {
+        if constexpr (!TAG) {
+#pragma unroll
+            for (int i = 0; i < QN; i++) b[i] = gb[gg(tb + (uint32_t)i)];          // (the table has slack behind the last gang and zeros behind a gang's last group)
+        }
+    };
+    auto gather_x = [&](auto qsc, auto xsc, uint32_t base) {
+        constexpr int R = QB + decltype(qsc)::value * L::QSZ, X = XB + decltype(xsc)::value * L::XSZ;
+        const uint32_t o0 = ((ring_get<R>() & cmask) + base) * (uint32_t)sizeof(T), o1 = ((ring_get<R + 1>() & cmask) + base) * (uint32_t)sizeof(T),
+                       o2 = ((ring_get<R + 2>() & cmask) + base) * (uint32_t)sizeof(T), o3 = ((ring_get<R + 3>() & cmask) + base) * (uint32_t)sizeof(T);
+        if constexpr (sizeof(T) == 8) { ring_ld64<X>(o0, rx, 0u); ring_ld64<X + 2>(o1, rx, 0u); ring_ld64<X + 4>(o2, rx, 0u); ring_ld64<X + 6>(o3, rx, 0u); }
+        else { ring_ld32<X>(o0, rx, 0u); ring_ld32<X + 1>(o1, rx, 0u); ring_ld32<X + 2>(o2, rx, 0u); ring_ld32<X + 3>(o3, rx, 0u); }
+    };
+    bases_of(0u, bcur);
+    // groups every wavefront walks: the same count in all of them -- every unit's turn must be taken, also one that holds nothing
+    const uint32_t Tw = (G + nwU - 1u) / nwU * (uint32_t)U;
+    T        prb[U][kGroupSteps];
+    uint32_t rwb[U][kGroupSteps];
+    asm volatile("; CVR_RING_BEGIN cap=%0" ::"n"(kGangCap) : "memory");
+    ring_wait<0>();
+    static_for<0, D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        gather_x(ic, ic, bcur[i]);
+        load_q(std::integral_constant<int, i + D>{}, gg((uint32_t)(i + D)));
+    });
+    for (uint32_t tb = 0; tb < Tw; tb += QN) {
+        bases_of(tb + (uint32_t)QN, bnext);
+        static_for<0, QN>([&](auto ic) {
+            constexpr int  i = decltype(ic)::value, R = QB + i * L::QSZ, X = XB + (i % D) * L::XSZ, q = i % U;
+            const uint32_t t = tb + (uint32_t)i, g = gg(t);
+            if (nwt > nw && wv == 0u && lane == 0) prog[0] = g;
+            ring_wait<K>();
+            const uint32_t cw[4] = {ring_get<R>(), ring_get<R + 1>(), ring_get<R + 2>(), ring_get<R + 3>()};
+            uint32_t       tg[2] = {0, 0}, vv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (TAG) { tg[0] = ring_get<R + L::TOFF>(); tg[1] = ring_get<R + L::TOFF + 1>(); }
+            if constexpr (DICT) vv[0] = ring_get<R + L::VOFF>();
+            else static_for<0, (sizeof(T) == 8 ? 8 : 4)>([&](auto jc) { vv[decltype(jc)::value] = ring_get<R + L::VOFF + decltype(jc)::value>(); });
+            static_for<0, L::XSZ>([&](auto jc) { xx[decltype(jc)::value] = ring_get<X + decltype(jc)::value>(); });
+            gather_x(std::integral_constant<int, (i + D) % QN>{}, std::integral_constant<int, i % D>{}, i < D ? bcur[(i + D) % QN] : bnext[(i + D) % QN]);
+            load_q(ic, gg(t + (uint32_t)QN));
+            // products and tags of this group into the unit's registers (a group behind the gang's last: zeros that are never added)
+#pragma unroll
+            for (int j = 0; j < kGroupSteps; j++) {
+                T av, xv;
+                if constexpr (DICT) av = dict[(vv[0] >> (8 * j)) & 0xffu];
+                else if constexpr (sizeof(T) == 8) av = __builtin_bit_cast(double, (uint64_t)vv[2 * j] | ((uint64_t)vv[2 * j + 1] << 32));
+                else av = __builtin_bit_cast(float, vv[j]);
+                if constexpr (sizeof(T) == 8) xv = __builtin_bit_cast(double, (uint64_t)xx[2 * j] | ((uint64_t)xx[2 * j + 1] << 32));
+                else xv = __builtin_bit_cast(float, xx[j]);
+                if constexpr (TAG) rwb[q][j] = (tg[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                else rwb[q][j] = cw[j] >> col_bits;
+                prb[q][j] = g < G ? fma_t(av, xv, T(0)) : T(0);          // (= the rounded product)
+                if (g >= G) rwb[q][j] = ystage_n - 1u;                  // (behind the gang's last group: +0 into the first chunk's dump entry)
+            }
+            if constexpr (q == U - 1) {
+                if (t < Tw) {
+#pragma unroll
+                    for (int qq = 0; qq < U; qq++) {
+#pragma unroll
+                        for (int j = 0; j < kGroupSteps; j++) { asm volatile("" : "+v"(prb[qq][j])); asm volatile("" : "+v"(rwb[qq][j])); }
+                    }
+                    const uint32_t n = (t / (uint32_t)U) * nw + wv;     // this unit's number in the gang
+                    asm volatile("" ::: "memory");
+                    while (__hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n) {}
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int qq = 0; qq < U; qq++) {
+#pragma unroll
+                        for (int j = 0; j < kGroupSteps; j++) lds_add_wg(ystage_all + rwb[qq][j], prb[qq][j]);
+                    }
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(tok, n + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("" ::: "memory");
+                }
+            }
+        });
+#pragma unroll
+        for (int i = 0; i < QN; i++) bcur[i] = bnext[i];
+    }
+    ring_wait<0>();
+    asm volatile("; CVR_RING_END" ::: "memory");
+    if (nwt > nw && wv == 0u && lane == 0) prog[0] = 0x7ffffff0u;
+    if (!own) return;
+    // every unit's additions are in the accumulators once the token has counted them all
+    {
+        const uint32_t all = Tw / (uint32_t)U * nw;
+        while (__hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != all) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    }
+    const T *const ystage = ystage_all + wv * ystage_n;
+    for (uint32_t i = lane; i < nri; i += kLanes) {
         const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
         store_y(yext + dst, ystage[i]);
     }
@@ -1257,6 +1494,15 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                     using L = RingLayout<T, kDict, decltype(TG)::value>;
                     const uint32_t room = (uint32_t)L::THREADS / kLanes, hmax = room / wpb > 0 ? room / wpb - 1u : 0u;
                     const uint32_t H = std::min<uint32_t>(hmax, img.ilv_helpers);
+                    if (img.gang) {          // gang chunks: the workgroup's wavefronts walk one common list (spmv_gang_kernel)
+                        using LG = RingLayout<T, kDict, decltype(TG)::value, kGangCap>;
+                        const uint32_t roomg = (uint32_t)LG::THREADS / kLanes, Hg = roomg > wpb ? std::min<uint32_t>(roomg - wpb, img.ilv_helpers * wpb) : 0u;      // helpers: all on the gang's stream
+                        with_flag(img.ilv_stream_nt != 0, [&](auto SN) {
+                            hipLaunchKernelGGL((spmv_gang_kernel<T, kDict, decltype(TG)::value, decltype(SN)::value>), dim3(grid), dim3(kLanes * (wpb + Hg)), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
+                                               img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi, wpb, img.ilv_ahead, img.ilv_per_line, img.flip_now, img.gbase);
+                        });
+                        return;
+                    }
                     with_flag(img.ilv_stream_nt != 0, [&](auto SN) {
                         hipLaunchKernelGGL((spmv_ilv_kernel<T, kDict, decltype(TG)::value, decltype(SN)::value>), dim3(grid), dim3(kLanes * wpb * (1u + H)), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
                                            img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi, wpb, img.ilv_ahead, img.ilv_per_line, img.flip_now);

@@ -112,7 +112,12 @@ typedef struct {
                                   rows' sums are accumulated in LDS (four chunks of up to 5 051 rows per workgroup).  For matrices whose x
                                   is far larger than an L2 and whose columns are scattered.  0 = off, 1 = on,
                                   <0 = auto (default): for column panels that run one per XCD and get no hub tables                       */
-    int32_t reserved[4];       /* 0 */
+    int32_t gang;              /* gang chunks (interleaved images only): the chunks of a workgroup are sorted by column TOGETHER and the workgroup's
+                                  wavefronts walk the common list in turn (units of two groups), adding into the chunks' accumulators in the list's
+                                  order -- a token in LDS passes from unit to unit, so the sums are those of the CSR loop whatever the wavefronts'
+                                  timing (bitwise reproducible) -- : four times the non-zeros share the lines of x a gather instruction touches.
+                                  0 = off, 1 = on, <0 = auto (default): for interleaved column panels of four wavefronts per workgroup          */
+    int32_t reserved[3];       /* 0 */
 } cvr_options;
 /* Automatic layout: with steps_per_chunk = 0, waves_per_block = 0, x_window < 0 and col_phases < 0 (the defaults) cvr_create
  * looks at the uploaded CSR on the device (are the rows sorted by column? which share of the non-zeros lies near the
@@ -171,7 +176,7 @@ typedef struct {
     int32_t preprocess_fused;      /* 1: cvr_create ran analysis, chunk plan, segment table and conversion as one submission (resident
                                     * layouts, cvr_fused.hip: plan_s covers all of it, the first cvr_preprocess has nothing left to do) */
     int32_t interleave;            /* 1: the image's chunks are interleaved (cvr_options.interleave)                                      */
-    int32_t reserved_info;         /* 0 */
+    int32_t gang;                  /* > 0: gang chunks (cvr_options.gang) -- the wavefronts of a workgroup that walk one common list            */
 } cvr_info;
 
 void        cvr_default_options(cvr_options *opt);
@@ -327,6 +332,11 @@ int cvr_device_copy_bench(int device, int64_t bytes, int iters, double *gbs);
  * shared = 3 i64 per shared row {row, first chunk, last chunk}.  With column phases desc[k][1] counts the (row, phase)
  * segments of the chunk and the last column word of a segment carries the chunk's row of the segment above the column index. */
 int cvr_export_image(cvr_handle *h, void *stream_image, uint32_t *desc, uint8_t *target, int64_t *shared);
+/* The rest of an image with gang chunks (cvr_options.gang), for the same comparison: group_first_cols = nchunks * S/4 u32 -- the first column of
+ * every group of every gang, gang b's groups from (b * waves_per_block) * S/4 on, zeros behind its last (all zeros when the image carries 16-bit
+ * tags) --, desc2 = 2 u32 per chunk {groups of the gang that hold non-zeros (at its first chunk; 0 at the others), rows of the chunk}.
+ * Either pointer may be NULL.  CVR_ERR_STATE for images without gang chunks. */
+int cvr_export_gang(cvr_handle *h, uint32_t *group_first_cols, uint32_t *desc2);
 /* host planner only (no device needed): chunk boundaries for a row_ptr; returns nchunks or <0.
  * out arrays (each may be NULL) need room for cvr_plan_bound(nrows, nnz, S) chunks. */
 int64_t cvr_plan_bound(int64_t nrows, int64_t nnz, int32_t S);

@@ -448,10 +448,126 @@ int orc_cvr64_build_ilv(int64_t nrows, int64_t ncols, const int64_t *rp, const i
     return rc;
 }
 
+
+/* Gang chunks (cvr_options.gang; cvr_amd/csrc/cvr_ilv.hip: gang_write_kernel, cvr_spmv.hip: spmv_gang_kernel).  Written from the definition in
+ * cvr_format.h: the plan is that of interleaved chunks; the `gang` consecutive chunks k0 .. k0 + gang - 1 of a workgroup put their non-zeros into ONE list
+ * sorted by (column, position); element e stands in group e / 256 of the gang's stream = the chunks' allocations one behind the other, at step (e / 64) % 4,
+ * lane e % 64; its tag = (chunk - k0) * ystage + row inside its chunk (the chunk of a position: the last whose first position is at or before it).  The slots
+ * behind the last element of the gang's last group: offset 0 (or the pad column with tags), the dump entry of the gang's first chunk, value 0; groups
+ * behind that one are not written (zeros).  gbase[k0 * S/4 + g] = column of element 256 g; ggroups[k0] = groups that hold non-zeros. */
+int orc_cvr64_build_gang(int64_t nrows, int64_t ncols, const int64_t *rp, const int32_t *cols, const void *vals, int is_f32,
+                         int S, int64_t thr, int use_dict, int64_t max_rows, int tag16, int gang, int ystage, orc_cvr64 *c)
+{
+    memset(c, 0, sizeof(*c));
+    if (gang < 2 || gang > 16 || ystage < 1 || max_rows <= 0 || max_rows >= ystage) return -7;
+    if ((int64_t)gang * ystage > (tag16 ? 65536 : 32768)) return -7;
+    c->tag16 = tag16 != 0;
+    c->phases = 2;
+    c->col_bits = c->tag16 ? 31 : 17;
+    c->ilv = 1;
+    c->gang = gang; c->ystage = ystage;
+    if (S < 4 || S % 4) return -1;
+    const int64_t cap = (int64_t)W * S;
+    if (thr <= 0) thr = cap / 4;
+    if (thr > cap / 2) thr = cap / 2;
+    c->nrows = nrows; c->ncols = ncols; c->nnz = nrows ? rp[nrows] - rp[0] : 0; c->S = S; c->is_f32 = is_f32;
+    chunk_t *ch;
+    c->nchunks = plan(nrows, rp, cap, thr, max_rows, &ch, &c->shared, &c->nshared);
+    const int64_t NC = c->nchunks;
+    const int G = S / 4;
+    if (use_dict) {
+        c->ndict = build_dict(vals, is_f32, nrows ? rp[0] : 0, nrows ? rp[nrows] : 0, c->dict);
+        if (c->ndict < 0) { free(ch); return -5; }
+    }
+    const size_t gb = (c->ndict ? 1280 : is_f32 ? 2048 : 3072) + (c->tag16 ? 512 : 0);
+    const size_t cbytes = 1024 + (c->tag16 ? 512 : 0);
+    c->image_bytes = (int64_t)((size_t)NC * G * gb);
+    c->image = (uint8_t *)calloc((size_t)c->image_bytes + 16, 1);
+    c->desc = (uint32_t *)calloc((size_t)NC * 4 + 4, sizeof(uint32_t));
+    c->target = (uint8_t *)calloc((size_t)NC * W + 1, 1);
+    c->nz_begin = (int64_t *)calloc((size_t)NC + 1, sizeof(int64_t));
+    c->pad_cnt = (int64_t *)calloc((size_t)NC + 1, sizeof(int64_t));
+    c->seg_off = (uint32_t *)calloc((size_t)NC + 1, sizeof(uint32_t));
+    c->nrows_in = (uint32_t *)calloc((size_t)NC + 1, sizeof(uint32_t));
+    c->seg_row = (uint16_t *)calloc(1, sizeof(uint16_t));
+    c->gbase = (uint32_t *)calloc((size_t)NC * G + 1, sizeof(uint32_t));
+    c->ggroups = (uint32_t *)calloc((size_t)NC + 1, sizeof(uint32_t));
+    ilvkey_t *key = (ilvkey_t *)malloc(sizeof(ilvkey_t) * (size_t)(cap * gang + 1));
+    int code0 = 0;
+    while (code0 < c->ndict && c->dict[code0] != 0) code0++;
+    int rc = 0;
+    for (int64_t k = 0; k < NC; k++) {          /* the chunks' tables: those of interleaved chunks */
+        const chunk_t *q = &ch[k];
+        c->nz_begin[k] = q->nzb; c->pad_cnt[k] = q->pad;
+        c->nrows_in[k] = (uint32_t)q->nrows_in;
+        c->desc[4 * k + 0] = (uint32_t)q->row_first;
+        c->desc[4 * k + 1] = (uint32_t)q->nseg;
+        for (int w = 0; w < 2; w++) {
+            const int64_t s = w ? q->nrows_in - 1 : 0;
+            uint32_t d;
+            if (s == 0 && q->head) d = (uint32_t)(nrows + 1 + 2 * k);
+            else if (s == q->nrows_in - 1 && q->tail) d = (uint32_t)(nrows + 1 + 2 * k + 1);
+            else d = (uint32_t)(q->row_first + s);
+            c->desc[4 * k + 2 + w] = d;
+        }
+        if (q->nrows_in >= ystage) rc = -7;
+    }
+    if (NC) c->nz_begin[NC] = nrows ? rp[nrows] : 0;
+    for (int64_t k0 = 0; k0 < NC && !rc; k0 += gang) {
+        const int64_t nc = NC - k0 < gang ? NC - k0 : gang;
+        const int64_t b = c->nz_begin[k0], e = c->nz_begin[k0 + nc], n = e - b;
+        if (n > cap * nc) { rc = -2; break; }
+        for (int64_t i = 0; i < n; i++) { key[i].col = cols[b + i]; key[i].pos = b + i; }
+        qsort(key, (size_t)n, sizeof(ilvkey_t), cmp_ilv);
+        const int64_t GGn = (n + 255) / 256;
+        c->ggroups[k0] = (uint32_t)GGn;
+        const uint32_t dump = (uint32_t)ch[k0].nrows_in;          /* the first chunk's dump entry */
+        for (int64_t s = 0; s < GGn * 256; s++) {
+            const int64_t g = s / 256;
+            const int j = (int)((s / W) % 4), l = (int)(s % W);
+            uint8_t *grp = c->image + ((size_t)k0 * G + (size_t)g) * gb;
+            const uint32_t bcol = (uint32_t)key[g * 256].col;
+            if (s % 256 == 0 && !c->tag16) c->gbase[(size_t)k0 * G + (size_t)g] = bcol;
+            uint32_t col = c->tag16 ? (uint32_t)ncols : bcol, tag = dump;
+            double v = 0;
+            if (s < n) {
+                const int64_t p = key[s].pos;
+                int64_t kc = k0;
+                while (kc + 1 < k0 + nc && c->nz_begin[kc + 1] <= p) kc++;
+                const chunk_t *q = &ch[kc];
+                int64_t r = q->row_first;
+                while (r + 1 < q->row_first + q->nrows_in && rp[r + 1] <= p) r++;
+                col = (uint32_t)key[s].col; tag = (uint32_t)((kc - k0) * ystage + (r - q->row_first));
+                v = is_f32 ? (double)((const float *)vals)[p] : ((const double *)vals)[p];
+            }
+            if (c->tag16) { ((uint32_t *)grp)[l * 4 + j] = col | 0x80000000u; ((uint16_t *)(grp + 1024))[l * 4 + j] = (uint16_t)tag; }
+            else {
+                const uint32_t off = col - bcol;
+                if (off >> 17) rc = -9;
+                ((uint32_t *)grp)[l * 4 + j] = (off & 0x1ffffu) | tag << 17;
+            }
+            if (c->ndict) {
+                int code = code0;
+                if (s < n) {
+                    uint64_t bits;
+                    if (is_f32) { float f = (float)v; uint32_t u; memcpy(&u, &f, 4); bits = u; } else memcpy(&bits, &v, 8);
+                    code = 0;
+                    while (code < c->ndict && c->dict[code] != bits) code++;
+                }
+                (grp + cbytes)[l * 4 + j] = (uint8_t)code;
+            }
+            else if (is_f32) ((float *)(grp + cbytes))[l * 4 + j] = (float)v;
+            else ((double *)(grp + cbytes + (j / 2) * 1024))[l * 2 + j % 2] = v;
+        }
+    }
+    free(key); free(ch);
+    return rc;
+}
+
 void orc_cvr64_free(orc_cvr64 *c)
 {
     free(c->image); free(c->desc); free(c->target); free(c->shared); free(c->nz_begin); free(c->pad_cnt);
-    free(c->seg_off); free(c->seg_row); free(c->nrows_in); free(c->hub_cols); free(c->cbase);
+    free(c->seg_off); free(c->seg_row); free(c->nrows_in); free(c->hub_cols); free(c->cbase); free(c->gbase); free(c->ggroups);
     memset(c, 0, sizeof(*c));
 }
 
@@ -474,7 +590,42 @@ void orc_cvr64_spmv(const orc_cvr64 *c, const void *xv, void *yv)
     const int ph = c->phases > 1;          /* column phases: a segment's sum is ADDED to its row's accumulator (LDS on the device) */
     double *yext = (double *)calloc(next + 1, sizeof(double));
     double *yloc = (double *)calloc((size_t)W * S + 2, sizeof(double));
-    for (int64_t k = 0; k < NC; k++) {
+    /* gang chunks: the gang's list is walked group by group, step by step, lane by lane -- the order the token of spmv_gang_kernel enforces whatever its
+     * wavefronts' timing --: every slot's rounded product is added to the accumulator its tag names; then every chunk writes its rows */
+    if (c->gang) {
+        double *ya = (double *)calloc((size_t)c->gang * c->ystage + 1, sizeof(double));
+        for (int64_t k0 = 0; k0 < NC; k0 += c->gang) {
+            const int64_t nc = NC - k0 < c->gang ? NC - k0 : c->gang;
+            for (int64_t i = 0; i < (int64_t)c->gang * c->ystage; i++) ya[i] = 0;
+            for (uint32_t g = 0; g < c->ggroups[k0]; g++) {
+                const uint8_t *grp = c->image + ((size_t)k0 * G + g) * gb;
+                const uint32_t bcol = c->gbase[(size_t)k0 * G + g];
+                for (int j = 0; j < 4; j++)
+                    for (int l = 0; l < W; l++) {
+                        const uint32_t cw = ((const uint32_t *)grp)[l * 4 + j];
+                        const uint32_t col = c->tag16 ? cw & 0x7fffffffu : bcol + (cw & 0x1ffffu);
+                        const uint32_t tag = c->tag16 ? ((const uint16_t *)(grp + 1024))[l * 4 + j] : cw >> 17;
+                        if (c->is_f32) {
+                            float v;
+                            if (c->ndict) { const uint32_t u = (uint32_t)c->dict[(grp + cbytes)[l * 4 + j]]; memcpy(&v, &u, 4); }
+                            else v = ((const float *)(grp + cbytes))[l * 4 + j];
+                            ya[tag] = (double)((float)ya[tag] + fmaf(v, ((const float *)xv)[col], 0.0f));
+                        } else {
+                            double v;
+                            if (c->ndict) memcpy(&v, &c->dict[(grp + cbytes)[l * 4 + j]], 8);
+                            else v = ((const double *)(grp + cbytes + (j / 2) * 1024))[l * 2 + j % 2];
+                            ya[tag] += fma(v, ((const double *)xv)[col], 0.0);
+                        }
+                    }
+            }
+            for (int64_t kc = k0; kc < k0 + nc; kc++) {
+                const uint32_t row_first = c->desc[4 * kc], hd = c->desc[4 * kc + 2], ld = c->desc[4 * kc + 3], nri = c->nrows_in[kc];
+                for (uint32_t i = 0; i < nri; i++) yext[i == 0 ? hd : i == nri - 1 ? ld : row_first + i] = ya[(size_t)(kc - k0) * c->ystage + i];
+            }
+        }
+        free(ya);
+    }
+    for (int64_t k = 0; k < NC && !c->gang; k++) {
         const uint32_t row_first = c->desc[4 * k], n = c->desc[4 * k + 1], hd = c->desc[4 * k + 2], ld = c->desc[4 * k + 3];
         const uint32_t nri = ph ? c->nrows_in[k] : 0;
         const uint32_t cmask = ph && !c->tag16 ? (1u << c->col_bits) - 1u : 0x7fffffffu;

@@ -102,6 +102,10 @@ typedef struct {
     uint32_t *cbase;         /* narrow: [nchunks] smallest column of the chunk                                              */
     int       tag16;         /* phases > 1: the rows of the pieces stand in [64][4] u16 tags (512 B) behind the column words (col_bits = 31) */
     int       ilv;           /* interleaved chunks (orc_cvr64_build_ilv): every slot ends a piece; without tags its column word holds the row in bits [col_bits, 32) */
+    int       gang;          /* gang chunks (orc_cvr64_build_gang): `gang` consecutive chunks share one sorted list; 0 = none                                      */
+    int       ystage;        /* gang chunks: accumulators per chunk -- a slot's tag = chunk inside the gang * ystage + row inside the chunk                        */
+    uint32_t *gbase;         /* gang chunks: [nchunks * S/4] the first column of every group of every gang (gang b's groups from (b * gang) * S/4 on; zeros behind its last, and with 16-bit tags) */
+    uint32_t *ggroups;       /* gang chunks: [nchunks] groups of the gang that hold non-zeros, at the gang's first chunk (0 at the others)                         */
 } orc_cvr64;
 
 int  orc_cvr64_build(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols,
@@ -128,6 +132,12 @@ int  orc_cvr64_build_tag(int64_t nrows, int64_t ncols, const int64_t *rowptr, co
 /* interleaved chunks (cvr_options.interleave): the chunk's non-zeros dealt to the lanes in column order, every slot a piece of its own */
 int  orc_cvr64_build_ilv(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
                          int S, int64_t split_threshold, int use_dict, int64_t max_rows, int tag16, orc_cvr64 *out);
+/* gang chunks (cvr_options.gang; cvr_amd/csrc/cvr_format.h): the plan of interleaved chunks, but the `gang` consecutive chunks of a workgroup are sorted
+ * TOGETHER -- element e of the gang's list sorted by (column, position) stands in group e / 256, step (e / 64) % 4, lane e % 64 of the gang's stream (its chunks'
+ * allocations, one behind the other) --, a slot's tag = chunk inside the gang * ystage + row inside the chunk; without 16-bit tags the column word holds the
+ * column's offset from its group's first column in bits [0, 17) and the tag above (-9: an offset does not fit 17 bits; the product then takes 16-bit tags) */
+int  orc_cvr64_build_gang(int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *cols, const void *vals, int is_f32,
+                          int S, int64_t split_threshold, int use_dict, int64_t max_rows, int tag16, int gang, int ystage, orc_cvr64 *out);
 void orc_cvr64_free(orc_cvr64 *c);
 /* interpret the image exactly as the HIP kernel does (same per-lane order of operations) */
 void orc_cvr64_spmv(const orc_cvr64 *c, const void *x, void *y);

@@ -30,7 +30,8 @@ class OrcCvr64(C.Structure):
                 ("ndict", C.c_int), ("dict", C.c_uint64 * 256), ("phases", C.c_int),
                 ("seg_off", C.POINTER(C.c_uint32)), ("seg_row", C.POINTER(C.c_uint16)), ("nrows_in", C.POINTER(C.c_uint32)),
                 ("col_bits", C.c_int), ("hub_n", C.c_int), ("hub_cols", C.POINTER(C.c_int32)),
-                ("order_n", C.c_int), ("narrow", C.c_int), ("cbase", C.POINTER(C.c_uint32)), ("tag16", C.c_int), ("ilv", C.c_int)]
+                ("order_n", C.c_int), ("narrow", C.c_int), ("cbase", C.POINTER(C.c_uint32)), ("tag16", C.c_int), ("ilv", C.c_int),
+                ("gang", C.c_int), ("ystage", C.c_int), ("gbase", C.POINTER(C.c_uint32)), ("ggroups", C.POINTER(C.c_uint32))]
 
 
 def lib():
@@ -62,6 +63,8 @@ def lib():
                                              C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(OrcCvr64)]
         _lib.orc_cvr64_build_ilv.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.POINTER(OrcCvr64)]
+        _lib.orc_cvr64_build_gang.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(OrcCvr64)]
         _lib.orc_write_mtx_pattern.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     return _lib
 
@@ -180,13 +183,17 @@ class Cvr8:
 class Cvr64:
     """CPU mirror of the device format (arrays copied to numpy)"""
 
-    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0, use_dict=False, phases=1, max_rows=0, hub_max=0, narrow=False, reorder=False, tag16=False, piece_max=0, interleave=False):
+    def __init__(self, nrows, ncols, rowptr, cols, vals, S, thr=0, use_dict=False, phases=1, max_rows=0, hub_max=0, narrow=False, reorder=False, tag16=False, piece_max=0, interleave=False,
+                 gang=0, ystage=0):
         self.rp = np.ascontiguousarray(rowptr, dtype=np.int64)
         self.cl = np.ascontiguousarray(cols, dtype=np.int32)
         self.f32 = vals.dtype == np.float32
         self.vl = np.ascontiguousarray(vals, dtype=np.float32 if self.f32 else np.float64)
         self.c = OrcCvr64()
-        if interleave:
+        if gang:
+            self.rc = lib().orc_cvr64_build_gang(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data, int(self.f32), S, thr, int(use_dict),
+                                                 max_rows, int(bool(tag16)), int(gang), int(ystage), C.byref(self.c))
+        elif interleave:
             self.rc = lib().orc_cvr64_build_ilv(nrows, ncols, self.rp.ctypes.data, self.cl.ctypes.data, self.vl.ctypes.data, int(self.f32), S, thr, int(use_dict),
                                                 max_rows, int(bool(tag16)), C.byref(self.c))
         else:
@@ -206,6 +213,9 @@ class Cvr64:
         self.phases = c.phases
         self.hub_n = c.hub_n
         self.hub_cols = _np(c.hub_cols, c.hub_n, np.int32) if c.hub_n else np.zeros(0, np.int32)
+        if c.gang:
+            self.gbase = _np(c.gbase, c.nchunks * (c.S // 4), np.uint32)
+            self.ggroups = _np(c.ggroups, c.nchunks, np.uint32)
         if c.phases > 1:
             self.seg_off = _np(c.seg_off, c.nchunks + 1, np.uint32)
             self.seg_row = _np(c.seg_row, int(self.seg_off[-1]) if c.nchunks else 0, np.uint16)

@@ -247,3 +247,65 @@ def test_interleaved_mirror_fp32_and_limits():
     assert len(bad) == 0, worst
     with pytest.raises(RuntimeError):          # the row field of the column word cannot hold that many rows
         O.Cvr64(nrows, ncols, rp, ci, va, 16, max_rows=1 << 20, tag16=0, interleave=True)
+
+
+# ---- gang chunks (cvr_options.gang; oracle: orc_cvr64_build_gang) ----
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("S,gang,tags,use_dict", [(4, 4, 0, 0), (16, 4, 1, 1), (32, 2, 0, 1), (16, 8, 0, 0)])
+def test_gang_mirror_matches_csr_oracle(name, S, gang, tags, use_dict):
+    """gang chunks: the chunks of a workgroup sorted together -- the mirror's image gives the CSR loop's y, every gang's list is in column order and a
+    permutation of its chunks' non-zeros, the groups' first columns are what the offsets are relative to, the tags name (chunk, row) of the plan"""
+    nrows, ncols, rp, ci, va = CASES[name]
+    if use_dict and len(np.unique(va)) > 255:
+        pytest.skip("more than 255 distinct values")
+    ystage = 512
+    max_rows = min(64 * S, ystage - 1)
+    try:
+        m = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=bool(use_dict), max_rows=max_rows, tag16=tags, gang=gang, ystage=ystage)
+    except RuntimeError as e:
+        assert "-9" in str(e) and not tags          # a column further than 2^17 from its group's first: the product falls back to tags
+        m = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=bool(use_dict), max_rows=max_rows, tag16=1, gang=gang, ystage=ystage)
+        tags = 1
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(ncols, mode)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        bad, worst = O.tol_check(m.spmv(x), yref, absy, tol=1e-12)
+        assert len(bad) == 0, (mode, worst, bad[:5])
+    G = S // 4
+    gb = (1280 if use_dict else 3072) + (512 if tags else 0)
+    img = m.image.reshape(-1, gb)
+    cw = img[:, :1024].copy().view(np.uint32).reshape(-1, 64, 4)                       # [group of the image][lane][step]
+    seen = 0
+    for k0 in range(0, m.nchunks, gang):
+        k1 = min(k0 + gang, m.nchunks)
+        n = int(m.nz_begin[k1] - m.nz_begin[k0])
+        gg = int(m.ggroups[k0])
+        assert gg == (n + 255) // 256 and gg <= (k1 - k0) * G
+        w = cw[k0 * G:k0 * G + gg].transpose(0, 2, 1).reshape(-1)                      # the gang's slots in list order
+        if tags:
+            col = (w & 0x7FFFFFFF).astype(np.int64)
+            tg = img[k0 * G:k0 * G + gg, 1024:1536].copy().view(np.uint16).reshape(-1, 64, 4).transpose(0, 2, 1).reshape(-1).astype(np.int64)
+        else:
+            col = (w & 0x1FFFF).astype(np.int64) + np.repeat(m.gbase[k0 * G:k0 * G + gg].astype(np.int64), 256)
+            tg = (w >> 17).astype(np.int64)
+        assert np.all(np.diff(col[:n]) >= 0)                                           # column order
+        assert np.array_equal(np.sort(col[:n]), np.sort(ci[m.nz_begin[k0]:m.nz_begin[k1]]).astype(np.int64))
+        assert np.all(tg[:n] // ystage < k1 - k0)
+        rows_of = m.desc[k0:k1, 0].astype(np.int64)[tg[:n] // ystage] + tg[:n] % ystage   # the rows the tags name
+        want = np.repeat(np.arange(nrows), np.diff(rp))[m.nz_begin[k0]:m.nz_begin[k1]]
+        assert np.array_equal(np.sort(rows_of), np.sort(want))
+        seen += n
+    assert seen == len(ci)
+
+
+def test_gang_mirror_fp32_and_limits():
+    nrows, ncols, rp, ci, va = CASES32["power_law_3000"]
+    m = O.Cvr64(nrows, ncols, rp, ci, va, 16, max_rows=500, tag16=0, gang=4, ystage=512)
+    x = O.x_vec_fast(ncols, "rand").astype(np.float32)
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    bad, worst = O.tol_check(m.spmv(x), yref, absy, tol=1e-5)
+    assert len(bad) == 0, worst
+    with pytest.raises(RuntimeError):          # the tags of a gang have 15 bits: 8 chunks x 8 192 accumulators do not fit
+        O.Cvr64(nrows, ncols, rp, ci, va, 16, max_rows=500, tag16=0, gang=8, ystage=8192)
+    with pytest.raises(RuntimeError):          # a chunk's rows must leave room for its dump entry
+        O.Cvr64(nrows, ncols, rp, ci, va, 16, max_rows=512, tag16=0, gang=4, ystage=512)

@@ -125,12 +125,13 @@ def test_fuzz_interleaved_chunks():
         wpb = int(rng.choice([0, 1, 2, 4, 8]))
         tags = int(rng.choice([-1, -1, 0, 1]))
         dev_plan = bool(rng.integers(0, 3) == 0)
-        ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, P=P, wpb=wpb, tags=tags, f32=f32, srt=srt, dev_plan=dev_plan)
+        gang = int(rng.integers(0, 2))          # gang chunks: the workgroup's chunks sorted together (takes effect with two wavefronts or more)
+        ctx = dict(case=case, nrows=nrows, ncols=ncols, nnz=len(ci), S=S, P=P, wpb=wpb, tags=tags, f32=f32, srt=srt, dev_plan=dev_plan, gang=gang)
         if dev_plan:
             os.environ["CVR_DEBUG"] = "device_plan_rows=0"
         try:
             try:
-                A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, col_panels=P, waves_per_block=wpb, row_tags16=tags, interleave=1)
+                A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, col_panels=P, waves_per_block=wpb, row_tags16=tags, interleave=1, gang=gang)
             except cvr_amd.CvrError as e:          # (tags forced off where column and row do not fit one word: a refusal with a code, not a wrong image)
                 assert tags == 0, (ctx, str(e))
                 continue
@@ -143,10 +144,18 @@ def test_fuzz_interleaved_chunks():
         y, _ = A.spmv(x)
         bad, worst = O.tol_check(y, yref, absy + 1e-30, tol=1e-5 if f32 else 1e-12)
         assert len(bad) == 0, (ctx, bad[:5], worst)
+        assert (i.gang > 0) == (gang > 0 and i.waves_per_block >= 2), ctx
         if i.col_panels == 1:
-            mir = O.Cvr64(nrows, ncols, rp, ci, va, i.steps_per_chunk, use_dict=i.value_dict > 0, max_rows=i.chunk_row_cap, tag16=i.row_tags16, interleave=True)
+            if i.gang:
+                vs = 4 if f32 else 8
+                ystage = (i.lds_bytes - 80 - (256 * vs if i.value_dict else 0)) // (i.waves_per_block * vs)
+                mir = O.Cvr64(nrows, ncols, rp, ci, va, i.steps_per_chunk, use_dict=i.value_dict > 0, max_rows=i.chunk_row_cap, tag16=i.row_tags16, gang=i.gang, ystage=ystage)
+            else:
+                mir = O.Cvr64(nrows, ncols, rp, ci, va, i.steps_per_chunk, use_dict=i.value_dict > 0, max_rows=i.chunk_row_cap, tag16=i.row_tags16, interleave=True)
             img = A.export_image()
             assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc) and np.array_equal(img["shared"], mir.shared), ctx
+            if i.gang:
+                assert np.array_equal(img["gbase"], mir.gbase) and np.array_equal(img["desc2"][:, 0], mir.ggroups), ctx
             if i.nshared == 0:
                 assert np.array_equal(y.view(np.uint8), mir.spmv(x).view(np.uint8)), ctx
         y2, _ = A.spmv(x)

@@ -120,6 +120,91 @@ def test_interleaved_chunks_image_bit_exact_and_y_parity(name, S, wpb, tags):
     A.close()
 
 
+def _gang_ystage(i, f32):
+    """accumulators per chunk of a gang image, from the workgroup's LDS (cvr_spmv.hip: spmv_lds_bytes)"""
+    vs = 4 if f32 else 8
+    return (i.lds_bytes - 80 - (256 * vs if i.value_dict else 0)) // (i.waves_per_block * vs)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("S,wpb,tags", [(4, 4, -1), (16, 4, 1), (32, 2, -1), (64, 4, -1), (16, 8, -1)])
+def test_gang_chunks_image_bit_exact_and_y_parity(name, S, wpb, tags):
+    """cvr_options.gang: the chunks of a workgroup sorted together and walked by its wavefronts in turn, the additions in the list's order by a token in
+    LDS (spmv_gang_kernel).  The image, the groups' first columns and the gangs' group counts against the CPU mirror (orc_cvr64_build_gang) bit for bit, y
+    against the CSR oracle, y bitwise equal to the mirror's walk of the list when no row is cut over chunks, and bitwise equal from run to run."""
+    nrows, ncols, rp, ci, va = CASES[name]
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=S, waves_per_block=wpb, row_tags16=tags, interleave=1, gang=1, col_panels=1)
+    i = A.info
+    assert (i.interleave, i.gang, i.waves_per_block, i.col_panels) == (1, wpb, wpb, 1)
+    ystage = _gang_ystage(i, False)
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, S, use_dict=i.value_dict > 0, max_rows=i.chunk_row_cap, tag16=i.row_tags16, gang=wpb, ystage=ystage)
+    img = A.export_image()
+    assert (i.nchunks, i.nshared, i.value_dict) == (mir.nchunks, mir.nshared, mir.ndict)
+    for key in ("desc", "shared", "image", "gbase"):
+        assert np.array_equal(img[key], getattr(mir, key)), key
+    assert np.array_equal(img["desc2"][:, 0], mir.ggroups) and np.array_equal(img["desc2"][:, 1], mir.nrows_in)
+    for mode in ("ones", "rand"):
+        x = O.x_vec_fast(ncols, mode)
+        yref, absy = O.csr_spmv64(rp, ci, va, x)
+        y, _ = A.spmv(x)
+        _assert_close(y, yref, absy, TOL64, (name, S, wpb, tags, mode))
+        if i.nshared == 0:
+            assert np.array_equal(y, mir.spmv(x)), (name, S, wpb, tags, mode)
+        for _ in range(3):
+            y2, _ = A.spmv(x)
+            assert np.array_equal(y, y2)
+    A.close()
+
+
+def test_gang_chunks_fall_back_to_tags_and_fp32_panels():
+    """(1) a matrix whose gangs hold few non-zeros over 600 000 columns: a group's 256 sorted columns span more than the 17 bits of an offset, the converter
+    says so and cvr_preprocess converts again with 16-bit tags -- same y, the mirror's bits; (2) the automatic layout's configuration scaled down: sixteen
+    fp32 / fp64 panels one per XCD, four wavefronts per workgroup, gang chunks by the rule; unsorted rows are fine (the converter sorts)"""
+    rng = np.random.default_rng(5)
+    nrows, ncols = 4000, 600_000
+    deg = rng.integers(0, 6, nrows)
+    rp = np.zeros(nrows + 1, dtype=np.int64)
+    rp[1:] = np.cumsum(deg)
+    ci = np.concatenate([np.sort(rng.choice(ncols, d, replace=False)) for d in deg]).astype(np.int32)
+    va = rng.random(len(ci))
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=8, waves_per_block=4, interleave=1, gang=1, col_panels=1)
+    i = A.info
+    assert (i.gang, i.row_tags16) == (4, 1), (i.gang, i.row_tags16)
+    mir = O.Cvr64(nrows, ncols, rp, ci, va, 8, use_dict=i.value_dict > 0, max_rows=i.chunk_row_cap, tag16=1, gang=4, ystage=_gang_ystage(i, False))
+    img = A.export_image()
+    assert np.array_equal(img["image"], mir.image) and np.array_equal(img["desc"], mir.desc) and not img["gbase"].any()
+    x = O.x_vec_fast(ncols, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    y, _ = A.spmv(x)
+    _assert_close(y, yref, absy, TOL64, "gang, tags after the fall-back")
+    if i.nshared == 0:
+        assert np.array_equal(y, mir.spmv(x))
+    A.close()
+    for f32 in (False, True):
+        n, nc, rp, ci, va = synth.livejournal_like(scale=0.03)
+        if f32:
+            va = (rng.random(len(ci)) - 0.5).astype(np.float32)
+        for r in rng.integers(0, n, 200):
+            a, b = int(rp[r]), int(rp[r + 1])
+            p = rng.permutation(b - a)
+            ci[a:b], va[a:b] = ci[a:b][p], va[a:b][p]
+        A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, col_panels=16, interleave=1)
+        i = A.info
+        assert (i.interleave, i.gang, i.col_panels, i.waves_per_block, i.spmv_launches) == (1, 4, 16, 4, 1), (i.interleave, i.gang, i.col_panels, i.waves_per_block)
+        for mode in ("ones", "rand"):
+            x = O.x_vec_fast(nc, mode).astype(va.dtype)
+            yref, absy = O.csr_spmv64(rp, ci, va, x)
+            y, _ = A.spmv(x)
+            _assert_close(y, yref, absy, TOL32 if f32 else TOL64, ("gang panels", f32, mode))
+            y2, _ = A.spmv(x)
+            assert np.array_equal(y, y2)
+        B = cvr_amd.CvrMatrix(n, nc, rp, ci, va, col_panels=16, interleave=1, gang=0)          # the private chunks of round 4: the same sums, bit for bit (both add in column order)
+        assert B.info.gang == 0
+        yb, _ = B.spmv(x)
+        assert np.array_equal(y, yb)
+        A.close(); B.close()
+
+
 def test_interleaved_chunk_length_limits():
     """interleave = 1 with the longest chunks the converter sorts in one workgroup (S = 508: 32 pairs per thread; S = 576: 36) converts and
     runs, image and y the mirror's bits; one group more is refused by cvr_create with CVR_ERR_INVALID and a message, before any planning

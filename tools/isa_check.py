@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/isa_check.py [cvr_spmv.s] -- build-time guard of spmv_ilv_kernel's hand-scheduled register ring (cvr_amd/csrc/cvr_spmv.hip).
+"""tools/isa_check.py [cvr_spmv.s] -- build-time guard of the hand-scheduled register ring of spmv_ilv_kernel and spmv_gang_kernel (cvr_amd/csrc/cvr_spmv.hip).
 
 The kernel keeps its in-flight loads in v[cap..255], registers the compiler does not allocate (amdgpu_num_vgpr(cap)), issues them from
 asm statements and waits with COUNTED s_waitcnt vmcnt(K).  That is correct only while, between the run-in and the end of the loop,
@@ -46,7 +46,7 @@ def kernels(lines):
     """{symbol: (first line, last line)} of the function bodies of spmv_ilv_kernel instantiations"""
     out, cur, start = {}, None, 0
     for i, l in enumerate(lines):
-        m = re.match(r"^(_ZN3cvr\S*spmv_ilv_kernel\S*):", l)
+        m = re.match(r"^(_ZN3cvr\S*spmv_(?:ilv|gang)_kernel\S*):", l)
         if m:
             cur, start = m.group(1), i
         elif cur and l.startswith(".Lfunc_end"):
@@ -96,11 +96,17 @@ def check(path, expected):
     lines = open(path).read().splitlines()
     ks, md = kernels(lines), metadata(lines)
     errors = []
-    if len(ks) != expected:
-        errors.append(f"{len(ks)} instantiations of spmv_ilv_kernel in the assembly, {expected} expected")
+    # both ring kernels must be there; their number follows the launch code's template dispatch (float / double x dictionary x 16-bit tags x
+    # non-temporal stream loads: 16 each today) and is only pinned when the caller asks for it (ISA_CHECK_EXPECTED) -- a 17th instantiation, or a
+    # compiler that merges two, is not an error of the ring
+    for kname in ("spmv_ilv_kernel", "spmv_gang_kernel"):
+        if not any(kname in sym for sym in ks):
+            errors.append(f"no instantiation of {kname} in the assembly")
+    if expected and len(ks) != expected:
+        errors.append(f"{len(ks)} instantiations of the ring kernels in the assembly, {expected} expected")
     for sym, (a, b) in sorted(ks.items()):
-        short = re.search(r"spmv_ilv_kernelI(\w+?)EEv", sym)
-        name = f"spmv_ilv_kernel<{short.group(1) if short else '?'}>"
+        short = re.search(r"(spmv_(?:ilv|gang)_kernel)I(\w+?)EEv", sym)
+        name = f"{short.group(1) if short else 'spmv_ilv_kernel'}<{short.group(2) if short else '?'}>"
         m = md.get(sym, {})
         for key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count"):
             if m.get(key, -1) != 0:
@@ -147,7 +153,7 @@ def check(path, expected):
 
 
 def main():
-    expected = int(os.environ.get("ISA_CHECK_EXPECTED", "16"))          # float / double x dictionary x 16-bit tags x non-temporal stream loads
+    expected = int(os.environ.get("ISA_CHECK_EXPECTED", "0"))           # 0: any number (at least one of each kernel)
     path = sys.argv[1] if len(sys.argv) > 1 else compile_to_asm()
     errors = check(path, expected)
     for e in errors[:40]:
