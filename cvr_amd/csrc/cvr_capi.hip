@@ -116,7 +116,10 @@ void ilv_runtime_settings(cvr_handle *h)
     for (Part &p : h->parts) {
         if (!p.img.ilv) continue;
         const char *e;
-        p.img.ilv_helpers = (e = cvr::debug_env("ilv_helpers")) ? (uint32_t)std::max(0, atoi(e)) : big ? 2u : 0u;
+        // (gang chunks: none -- the common list takes a CU's stream 25 % faster than four private chunks did, more of the helpers' batches come too late, and
+        // what they still bring costs issue slots: soc-LiveJournal1 shape 212.0 us without, 214.2 / 220.8 with one / two per chunk; com-Orkut 594 / 589 / 600:
+        // profiles/r06_gang_launch_parameters.log)
+        p.img.ilv_helpers = (e = cvr::debug_env("ilv_helpers")) ? (uint32_t)std::max(0, atoi(e)) : big && !p.img.gang ? 2u : 0u;
         p.img.ilv_per_line = (e = cvr::debug_env("ilv_per_line")) ? (uint32_t)std::max(1, atoi(e)) : 2u;
         p.img.ilv_ahead = (e = cvr::debug_env("ilv_ahead")) ? (uint32_t)std::max(1, atoi(e)) : 24u;
         p.img.ilv_flip = (e = cvr::debug_env("ilv_flip")) ? (uint32_t)std::max(0, atoi(e)) : big ? 1u : 0u;

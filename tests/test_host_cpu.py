@@ -218,7 +218,7 @@ def test_host_sources_under_sanitizers():
 
 
 def test_ring_kernel_isa_guard():
-    """spmv_ilv_kernel keeps its in-flight loads in registers the compiler does not allocate and waits with counted vmcnt: the build
+    """spmv_ilv_kernel and spmv_gang_kernel keep their in-flight loads in registers the compiler does not allocate and wait with counted vmcnt: the build
     checks the compiler's assembly for spills, for compiler-issued vector-memory instructions inside the ring region and for compiler
     use of the ring's registers (make isa-check, tools/isa_check.py; also run by __graft_entry__.build()).  The guard must pass on the
     kernel as it is and must FAIL the build -- not a parity test -- on one compiled with a register cap the compiler cannot keep."""
@@ -229,7 +229,8 @@ def test_ring_kernel_isa_guard():
         pytest.skip("no hipcc")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "cvr_amd", "csrc"), "isa-check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "isa_check: ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("vgpr spills 0") == 16         # every instantiation was looked at (value type x dictionary x 16-bit tags x non-temporal stream loads)
+    # every instantiation of both ring kernels was looked at (value type x dictionary x 16-bit tags x non-temporal stream loads, each)
+    assert r.stdout.count("spmv_ilv_kernel<") == r.stdout.count("spmv_gang_kernel<") == 16 and r.stdout.count("vgpr spills 0") == 32
     env = dict(os.environ, HIPCC_EXTRA="-DCVR_RING_CAP=24")
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "cvr_amd", "csrc"), "isa-check"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and "isa_check: FAIL" in r.stdout, r.stdout[-3000:]
