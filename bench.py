@@ -928,7 +928,7 @@ def main():
         per = wall / args.steps
         emu = bool(args.emulate_rank)
         job_nnz = lnnz if emu else nnz            # (an emulated rank: the flops of its shard)
-        kname = ("cvr::spmv_ilv_kernel" if info.interleave else "cvr::spmv_seg_kernel" if info.col_phases > 1 else "cvr::spmv_kernel") + ("<float>" if f32 else "<double>")      # (column phases: the kernel without hand-out state; interleaved chunks: the hand-pipelined one)
+        kname = ("cvr::spmv_gang_kernel" if info.gang else "cvr::spmv_ilv_kernel" if info.interleave else "cvr::spmv_seg_kernel" if info.col_phases > 1 else "cvr::spmv_kernel") + ("<float>" if f32 else "<double>")      # (column phases: the kernel without hand-out state; interleaved chunks: the hand-pipelined one)
         workload_text = f"{source}: {nrows}x{ncols}, nnz {nnz}, {'fp32' if f32 else 'fp64'}, y = A x with A (CVR64 image), x, y resident in HBM"
         out = {
             "metric": "SpMV GFLOP/s (2*nnz/t), web-Google fp64" if args.workload == "webgoogle" else f"SpMV GFLOP/s (2*nnz/t), {args.workload} {'fp32' if f32 else 'fp64'}"

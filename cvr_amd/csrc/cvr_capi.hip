@@ -42,6 +42,17 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
         shared.flip_now = shared.ilv_flip ? (h->spmv_calls++ & 1u) : 0u;
         uint32_t most = 0;
         for (uint32_t c : h->multi_chunks) most = std::max(most, c);
+        if (most && h->d_fuse) {      // gang chunks: the workgroup that completes a block of rows adds its partial sums and writes y -- no combine launch
+            hipError_t e = cvr::launch_spmv(shared, x, nullptr, st, false, h->d_multi, most, (uint32_t)h->multi_chunks.size(), nullptr, h->d_fuse, y);
+            if (e != hipSuccess) return e;
+            if (h->max_nshared) {          // rows cut over chunks: their carries summed as before, then those rows' y once more
+                e = cvr::launch_fixup_multi(h->d_fixparts, (uint32_t)h->parts.size(), h->max_nshared, h->vsz == 4, st);
+                if (e == hipSuccess) e = cvr::launch_fuse_patch(h->d_fuse_cut, h->fuse_ncut, h->d_fuse_panels, h->d_cpanels, h->d_fuse_nsub, (uint32_t)h->parts.size(), y, h->vsz == 4, st);
+                if (e != hipSuccess) return e;
+            }
+            h->z_used = true;
+            return hipEventRecord(h->z_free, st);
+        }
         if (most) {      // all rounds in one grid
             const hipError_t e = cvr::launch_spmv(shared, x, nullptr, st, false, h->d_multi, most, (uint32_t)h->multi_chunks.size());
             if (e != hipSuccess) return e;
@@ -57,6 +68,62 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
     if (e != hipSuccess) return e;
     h->z_used = true;
     return hipEventRecord(h->z_free, st);
+}
+
+// The fused combine (cvr_kernels.h: FuseArgs) for a handle whose panels all carry gang chunks and run one per XCD: the gangs' block ranges, the blocks'
+// expected counts, the counters, the panels' table for the set-up kernels and the list of rows cut over chunks -- one allocation, made on the handle's
+// stream behind whatever wrote the panels' chunk tables.  CVR_DEBUG=no_fuse keeps the combine pass a launch of its own.
+int setup_fuse(cvr_handle *h)
+{
+    // MEASURED AND NOT ADOPTED (round 6; CVR_DEBUG=fuse switches it on, the parity tests run it): a block of rows is complete only when the LAST of its
+    // panels has delivered, i.e. during the second round of panels, and all ~130 blocks of a gang's row range complete at the same workgroup -- a few dozen
+    // workgroups chip-wide then add 178 MB of partial sums at one CU's rate each while the others wait for nothing: soc-LiveJournal1 shape 1 796 us against
+    // 210 with the pass as a launch of its own, com-Orkut shape 1 208 against 588 (profiles/r06_fused_combine_not_adopted.log).
+    if (!cvr::debug_env("fuse")) return CVR_OK;
+    if (!h->paneled() || !h->d_multi || !h->d_cpanels || !h->d_block_off || !h->d_rows || h->info.nrows <= 0) return CVR_OK;
+    const uint32_t P = (uint32_t)h->parts.size(), gw = h->parts[0].img.gang;
+    if (!gw || P > (uint32_t)cvr::kMaxSplitPanels) return CVR_OK;
+    uint32_t ngangs = 0, ncut = 0;
+    std::vector<cvr::FusePanel> fp(P);
+    std::vector<uint32_t>       nsub(P), cut0(P);
+    int64_t roff = 0;
+    for (uint32_t p = 0; p < P; p++) {
+        const Part &q = h->parts[p];
+        if (q.img.gang != gw || !q.img.desc2) return CVR_OK;
+        fp[p] = cvr::FusePanel{q.img.desc, q.img.desc2, h->d_rows + roff, q.img.nchunks, ngangs};
+        nsub[p] = (uint32_t)q.nrows; cut0[p] = ncut;
+        roff += q.nrows;
+        ngangs += (q.img.nchunks + gw - 1) / gw;
+        ncut += (uint32_t)q.nshared;
+    }
+    if (!ngangs) return CVR_OK;
+    const uint32_t nblocks = (uint32_t)((h->info.nrows + cvr::kCombineRows - 1) / cvr::kCombineRows);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_args = 0, o_cnt = o_args + up(sizeof(cvr::FuseArgs)), o_exp = o_cnt + up(4 * (size_t)nblocks), o_rng = o_exp + up(4 * (size_t)nblocks), o_fl = o_rng + up(8 * (size_t)ngangs),
+                 o_pan = o_fl + up(8 * ((size_t)ngangs + 1)), o_nsub = o_pan + up(sizeof(cvr::FusePanel) * P), o_cut = o_nsub + up(4 * (size_t)P), total = o_cut + up(4 * (size_t)std::max(ncut, 1u));
+    HIP_TRY(hipMalloc(&h->fuse_mem, total));
+    uint8_t *m = static_cast<uint8_t *>(h->fuse_mem);
+    cvr::FuseArgs fa;
+    fa.cnt = reinterpret_cast<uint32_t *>(m + o_cnt); fa.expect = reinterpret_cast<uint32_t *>(m + o_exp); fa.range = reinterpret_cast<uint2 *>(m + o_rng);
+    fa.panels = h->d_cpanels; fa.block_off = h->d_block_off; fa.npanels = P; fa.nblocks = nblocks; fa.nrows = (uint32_t)h->info.nrows; fa.ngangs = ngangs;
+    h->d_fuse_panels = reinterpret_cast<cvr::FusePanel *>(m + o_pan);
+    h->d_fuse_nsub = reinterpret_cast<uint32_t *>(m + o_nsub);
+    h->d_fuse_cut = reinterpret_cast<uint32_t *>(m + o_cut);
+    h->fuse_ncut = ncut;
+    HIP_TRY(hipMemcpyAsync(m + o_args, &fa, sizeof(fa), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_fuse_panels, fp.data(), sizeof(cvr::FusePanel) * P, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_fuse_nsub, nsub.data(), 4 * (size_t)P, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(m + o_fl, 0, 8 * ((size_t)ngangs + 1), h->stream));
+    HIP_TRY(cvr::launch_fuse_setup(h->d_fuse_panels, P, gw, ngangs, nblocks, reinterpret_cast<uint2 *>(m + o_rng), reinterpret_cast<uint32_t *>(m + o_fl), reinterpret_cast<uint32_t *>(m + o_exp), fa.cnt, h->stream));
+    for (uint32_t p = 0; p < P; p++) HIP_TRY(cvr::launch_fuse_cut_rows(h->parts[p].img.shared, (uint32_t)h->parts[p].nshared, fp[p].rows, h->d_fuse_cut + cut0[p], h->stream));
+    // the panels' launch table: every panel's first gang in this numbering
+    std::vector<cvr::PanelArgs> pa(h->multi_chunks.size() * 8);
+    HIP_TRY(hipStreamSynchronize(h->stream));          // (the staging vectors above go out of scope)
+    HIP_TRY(hipMemcpy(pa.data(), h->d_multi, sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyDeviceToHost));
+    for (uint32_t p = 0; p < P; p++) { const int32_t s = h->parts[p].multi_slot; if (s < 0 || (size_t)s >= pa.size()) { (void)hipFree(h->fuse_mem); h->fuse_mem = nullptr; return CVR_OK; } pa[(size_t)s].gang0 = fp[p].gang0; }
+    HIP_TRY(hipMemcpy(h->d_multi, pa.data(), sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyHostToDevice));
+    h->d_fuse = reinterpret_cast<cvr::FuseArgs *>(m + o_args);
+    return CVR_OK;
 }
 
 IOpt make_iopt(const cvr_options *in)
@@ -901,7 +968,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (plain) {
             const size_t per_round = cvr::debug_env("xcd_panels_debug") ? (size_t)atoi(cvr::debug_env("xcd_panels_debug")) : 8;      // (diagnostics: fewer panels side by side)
             const size_t rounds = (h->parts.size() + per_round - 1) / per_round;
-            std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u, nullptr});
+            std::vector<cvr::PanelArgs> pa(rounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u, nullptr, 0u, 0u});
             h->multi_chunks.assign(rounds, 0u);
             // which panel runs where: the heaviest first, each to the XCD with the least work so far that still has a round free (the XCDs
             // go through their panels independently: what counts is every XCD's sum, not the rounds'); equal-width panels of a real graph
@@ -927,7 +994,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
                 const Part &p = h->parts[j];
                 const size_t i = slot_of[j];
                 h->parts[j].multi_slot = (int32_t)i;
-                pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col, p.img.gbase};
+                pa[i] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col, p.img.gbase, 0u, 0u};
                 h->multi_chunks[i / 8] = std::max(h->multi_chunks[i / 8], p.img.nchunks);
                 h->multi_ystage = std::max(h->multi_ystage, p.img.ystage);
                 if (cvr::debug_env("xcd_panels_trace")) fprintf(stderr, "[xcd panels] part %zu slot %zu nchunks %u ystage %u S %d G %d zoff %lld yext %lld nshared %u stream %p\n", j, i, p.img.nchunks, p.img.ystage, p.img.S, p.img.G, (long long)p.zoff, (long long)p.yext, p.img.nshared, (void *)p.img.stream);
@@ -937,6 +1004,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }
     }
     if (!h->z_free && in.hub_entries) CREATE_TRY(hipEventCreateWithFlags(&h->z_free, hipEventDisableTiming));
+    { rc = setup_fuse(h); if (rc) { cvr_destroy(h); return rc; } }
     in.steps_per_chunk = h->parts[0].img.S;
     in.col_phases = h->parts[0].img.ilv ? 1 : (int32_t)h->parts[0].img.phases;      // (an interleaved image is planned like one with phases, but has none)
     in.waves_per_block = (int32_t)h->parts[0].img.wpb; in.x_window = (int32_t)h->parts[0].img.win_elems;
@@ -1149,6 +1217,7 @@ int cvr_destroy(cvr_handle *h)
     for (Part &p : h->parts) p.release_all();
     h->release_split();
     if (h->panel_tables) (void)hipFree(h->panel_tables);
+    if (h->fuse_mem) (void)hipFree(h->fuse_mem);
     cvr::free_plan_scratch(h->plan_ws);
     if (h->seg_arena) (void)hipFree(h->seg_arena);
     if (h->d_small) (void)hipFree(h->d_small);

@@ -291,10 +291,10 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         LOAD_TRY(hipMemcpy(h->d_fixparts, fp.data(), sizeof(cvr::FixPart) * nparts, hipMemcpyHostToDevice));
         if (has_multi) {
             const size_t per_round = 8;
-            std::vector<cvr::PanelArgs> pa((size_t)nrounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u, nullptr});
+            std::vector<cvr::PanelArgs> pa((size_t)nrounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u, nullptr, 0u, 0u});
             for (uint32_t j = 0; j < nparts; j++) {       // every panel where cvr_create placed it (the heaviest first, each on the XCD with the least work)
                 const Part &p = h->parts[j];
-                pa[p.multi_slot >= 0 ? (size_t)p.multi_slot : (j / per_round) * 8 + j % per_round] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col, p.img.gbase};
+                pa[p.multi_slot >= 0 ? (size_t)p.multi_slot : (j / per_round) * 8 + j % per_round] = cvr::PanelArgs{p.img.stream, p.img.desc, p.img.target, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * vsz, p.img.nchunks, p.img.ystage, p.img.desc2, p.img.col_base, p.img.pad_col, p.img.gbase, 0u, 0u};
             }
             LOAD_TRY(hipMalloc(&h->d_multi, sizeof(cvr::PanelArgs) * pa.size()));
             LOAD_TRY(hipMemcpy(h->d_multi, pa.data(), sizeof(cvr::PanelArgs) * pa.size(), hipMemcpyHostToDevice));
@@ -315,6 +315,7 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
     (void)hipHostFree(pinned);
     pinned = nullptr;
 #undef LOAD_TRY
+    { const int rcf = setup_fuse(h); if (rcf) { cvr_destroy(h); return rcf; } }          // (the fused combine's tables follow from the chunk tables: made again, not stored)
     ilv_runtime_settings(h);
     h->converted = true;
     // what the first run spent on analysis and conversion does not apply to this handle

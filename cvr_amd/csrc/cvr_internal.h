@@ -154,6 +154,12 @@ struct cvr_handle {
     cvr::FixPart *d_fixparts = nullptr;   // panels: the fix-up of every panel in one launch
     // panels, one per XCD at a time (cvr_kernels.h: PanelArgs): rounds of eight panels per launch; d_multi[round][8]
     cvr::PanelArgs       *d_multi = nullptr;
+    // the combine pass inside the panel kernel (gang chunks; cvr_kernels.h: FuseArgs): tables in one allocation; null = the combine pass is a launch of its own
+    void                 *fuse_mem = nullptr;
+    cvr::FuseArgs        *d_fuse = nullptr;
+    cvr::FusePanel       *d_fuse_panels = nullptr;
+    uint32_t             *d_fuse_cut = nullptr, *d_fuse_nsub = nullptr;
+    uint32_t              fuse_ncut = 0;
     std::vector<uint32_t> multi_chunks;   // per round: the most chunks any of its panels has
     uint32_t              multi_ystage = 0;
     uint32_t  max_nshared = 0;
@@ -193,6 +199,7 @@ namespace cvrh {
 struct Chip { int cus = 256, xcds = 8; };
 Chip       chip_of(int device);
 hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st);
+int        setup_fuse(cvr_handle *h);                    // the fused combine's tables, for handles whose panels all carry gang chunks and run one per XCD (after d_multi)
 void       ilv_runtime_settings(cvr_handle *h);          // helper wavefronts / sweep direction of interleaved images (launch parameters)      // y_ext = A x for the whole handle on `st`
 IOpt       make_iopt(const cvr_options *in);
 int        check_csr(const cvr_csr_view *c, bool columns_on_host = true);

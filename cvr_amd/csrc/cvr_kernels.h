@@ -209,7 +209,7 @@ hipError_t launch_dict_scan(const void *vals, int64_t n0, int64_t n1, bool f32, 
 hipError_t launch_window(const DeviceImage &img, const DeviceCsr &csr, hipStream_t st, const uint32_t *nchunks_dev = nullptr);
 
 // column panels, one panel per XCD at a time: what differs between the eight panels of one launch (device array of 8; nchunks = 0: none)
-struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *target; void *yext; uint32_t nchunks, ystage; const uint2 *desc2; uint32_t col_base, pad_col; const uint32_t *gbase; };      // (col_base, pad_col: interleaved panels keep panel-local columns)
+struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *target; void *yext; uint32_t nchunks, ystage; const uint2 *desc2; uint32_t col_base, pad_col; const uint32_t *gbase; uint32_t gang0, pad_; };      // (gang0: the panel's first gang in the numbering of FuseArgs::range)      // (col_base, pad_col: interleaved panels keep panel-local columns)
 // y_ext = A x  (+ the ordered fix-up of rows cut over chunks when img.nshared > 0 and with_fixup)
 // multi != null: eight panels in one launch (plain layout, one chunk per workgroup, no LDS tables): workgroup b takes chunk b >> 3 of
 // panel b & 7 of its round; multi[rounds][8]; multi_chunks = the most chunks any panel has (the rounds follow each other in ONE grid:
@@ -219,9 +219,22 @@ struct PanelArgs { const uint8_t *stream; const uint4 *desc; const uint8_t *targ
 // before|| (prev: that step's partials, null = 1).  cvr_iter.hip's power_step_kernel is the same step as a pass of its own.
 struct IterEpilogue { void *xnext = nullptr; const double *prev = nullptr; double *out = nullptr; uint32_t nsets = 0; };
 bool iter_epilogue_ok(const DeviceImage &img);      // launch_spmv honours `epi` for this image
+// The combine pass of column panels INSIDE the panel kernel (gang chunks; round 6): a gang that has stored its rows' partial sums counts itself in at
+// every block of kCombineRows rows its sub-rows may lie in (range[gang] = {first, last block}; the ranges of a panel's gangs tile all blocks), and the
+// workgroup whose count completes a block -- expect[block] = gangs of all panels that cover it -- adds that block's partial sums, panel by panel in panel
+// order (the order of combine_kernel: the same bits), writes y and resets the counter.  Partial sums are stored and loaded past the non-coherent caches
+// (sc1), as the hand-off between workgroups on different XCDs requires.  Tables made by launch_fuse_setup; y comes with the launch.
+struct FuseArgs { uint32_t *cnt; const uint32_t *expect; const uint2 *range; const struct CombinePanel *panels; const uint32_t *block_off; uint32_t npanels, nblocks, nrows, ngangs; };
+struct FusePanel { const uint4 *desc; const uint2 *desc2; const uint32_t *rows; uint32_t nchunks, gang0; };      // per panel: its chunk tables, the rows of its sub-rows
+// range[] and expect[] of a handle's panels (gw chunks per gang); cnt zeroed.  Asynchronous on st.
+hipError_t launch_fuse_setup(const FusePanel *panels_dev, uint32_t npanels, uint32_t gw, uint32_t ngangs, uint32_t nblocks, uint2 *range, uint32_t *first_last, uint32_t *expect, uint32_t *cnt, hipStream_t st);
+// y[row] of the rows cut over chunks, once more after the fix-up launch has summed their carries (the fused combine read their partial sums too early):
+// rows_list[i] = a global row; per panel the sub-row with that row (binary search), its partial sum added in panel order
+hipError_t launch_fuse_cut_rows(const int64_t *shared, uint32_t nshared, const uint32_t *rows, uint32_t *out, hipStream_t st);      // out[i] = rows[shared[i].row]: the global rows of a panel's cut rows
+hipError_t launch_fuse_patch(const uint32_t *rows_list, uint32_t nlist, const FusePanel *panels_dev, const struct CombinePanel *cpanels, const uint32_t *nsub, uint32_t npanels, void *y, bool f32, hipStream_t st);
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup = true, const PanelArgs *multi = nullptr, uint32_t multi_chunks = 0,
                        uint32_t multi_rounds = 1,
-                       const IterEpilogue *epi = nullptr);
+                       const IterEpilogue *epi = nullptr, const FuseArgs *fuse = nullptr, void *y_fused = nullptr);
 size_t     spmv_lds_bytes(const DeviceImage &img);      // dynamic LDS of that launch
 
 // column panels: one fix-up launch for all panels (each with its own y_ext inside the partial-sum buffer)

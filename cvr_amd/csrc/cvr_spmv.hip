@@ -1031,12 +1031,116 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG>::THREADS)) __attribute__(
 // 178 us at 4 x 4 800 rows on the soc-LiveJournal1 shape, 510 against 736 on the com-Orkut shape: profiles/r06_token_probe_*.log).
 // Column words without 16-bit tags: offset from the group's first column (17 bits) | tag (15 bits); the groups' first columns come through
 // the scalar cache a revolution of the ring ahead (gbase).
+
+// ---- the combine pass inside the panel kernel (FuseArgs, cvr_kernels.h) -----------------------------------------------------------------
+// Stores and loads of the panels' partial sums go past the caches that other workgroups' stores do not reach (a CU's vector L1, another XCD's
+// L2): every store of them carries sc1 (write-through), every load of them is a buffer load with sc1, and the count that hands a block over is
+// an agent-scope atomic add issued behind the storing wavefronts' s_waitcnt vmcnt(0) and a workgroup barrier; the workgroup whose add returns
+// the block's last count loads (MI355X_MICROARCH.md, inter-workgroup visibility: the first row of its table of measured hand-offs).
+template <typename T> __device__ __forceinline__ void store_sc1(T *p, T v)
+{
+    typedef T __attribute__((address_space(1))) *gptr_t;
+    __hip_atomic_store((gptr_t)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // global_store_dword(x2) ... sc1
+}
+template <typename T> __device__ __forceinline__ T load_sc1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    if constexpr (sizeof(T) == 8) return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 16));
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));
+}
+
+// One block of kCombineRows rows, by all NT threads of the workgroup: y[r0 + i] = sum over the panels, in panel order, of the partial sums of row
+// r0 + i (combine_kernel's arithmetic: the same bits).  lds: 12 KiB of the workgroup's LDS that nothing else uses any more.
+template <typename T>
+__device__ __forceinline__ void fused_combine_block(const FuseArgs &fz, uint32_t b, T *__restrict__ y, uint8_t *lds)
+{
+    constexpr int kBatch = 4, kEach = 4;
+    T *const        acc = reinterpret_cast<T *>(lds);                                        // [kCombineRows]
+    uint32_t *const s_lo = reinterpret_cast<uint32_t *>(lds + 8192), *const s_hi = s_lo + kMaxSplitPanels;
+    uint64_t *const s_z = reinterpret_cast<uint64_t *>(lds + 8192 + 8 * kMaxSplitPanels), *const s_rows = s_z + kMaxSplitPanels;
+    const uint32_t  NT = blockDim.x, tid = threadIdx.x, r0 = b * (uint32_t)kCombineRows, npanels = fz.npanels, nblocks = fz.nblocks;
+    if (tid < npanels) {
+        const CombinePanel cp = fz.panels[tid];
+        s_z[tid] = reinterpret_cast<uint64_t>(cp.z); s_rows[tid] = reinterpret_cast<uint64_t>(cp.rows);
+        s_lo[tid] = fz.block_off[(size_t)tid * (nblocks + 1) + b]; s_hi[tid] = fz.block_off[(size_t)tid * (nblocks + 1) + b + 1];
+    }
+    for (uint32_t i = tid; i < (uint32_t)kCombineRows; i += NT) acc[i] = T(0);
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < npanels; p0 += kBatch) {
+        T        v[kBatch][kEach];
+        uint32_t rw[kBatch][kEach];
+#pragma unroll
+        for (int q = 0; q < kBatch; q++) {
+            const uint32_t p = p0 + q;
+            uint32_t       lo = 0, hi = 0;
+            uint64_t       zp = 0, rp = 0;
+            if (p < npanels) { lo = s_lo[p]; hi = s_hi[p]; zp = s_z[p]; rp = s_rows[p]; }
+            const uint64_t zu = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)zp) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(zp >> 32)) << 32);
+            const __amdgpu_buffer_rsrc_t rz = make_rsrc(reinterpret_cast<const void *>(zu), __builtin_amdgcn_readfirstlane(hi * (uint32_t)sizeof(T)));      // (entries behind hi: out of range, zeros, no traffic)
+            const uint16_t *rows = reinterpret_cast<const uint16_t *>(rp);
+#pragma unroll
+            for (int e = 0; e < kEach; e++) {
+                const uint32_t u = lo + tid + (uint32_t)e * NT;
+                rw[q][e] = u < hi ? (uint32_t)rows[u] : 0xffffffffu;
+                v[q][e] = load_sc1<T>(rz, u < hi ? u * (uint32_t)sizeof(T) : 0xfffffff0u);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kBatch; q++) {
+            const uint32_t p = p0 + q;
+            if (p < npanels) {                                 // (uniform)
+#pragma unroll
+                for (int e = 0; e < kEach; e++) if (rw[q][e] != 0xffffffffu) acc[(rw[q][e] - r0) & 0xffffu] += v[q][e];
+                const uint32_t lo = s_lo[p], hi = s_hi[p];
+                const uint64_t zp = s_z[p];
+                const uint64_t zu = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)zp) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(zp >> 32)) << 32);
+                const __amdgpu_buffer_rsrc_t rz = make_rsrc(reinterpret_cast<const void *>(zu), __builtin_amdgcn_readfirstlane(hi * (uint32_t)sizeof(T)));
+                const uint16_t *rows = reinterpret_cast<const uint16_t *>(s_rows[p]);
+                for (uint32_t u = lo + tid + (uint32_t)kEach * NT; u < hi; u += NT) acc[((uint32_t)rows[u] - r0) & 0xffffu] += load_sc1<T>(rz, u * (uint32_t)sizeof(T));
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < (uint32_t)kCombineRows && r0 + i < fz.nrows; i += NT) __builtin_nontemporal_store(acc[i], &y[r0 + i]);
+    __syncthreads();                                           // (the next block's zeroing must not overtake these reads of acc)
+}
+
+// The gang's workgroup, once every wavefront of it has stored its rows: count in at the gang's blocks, combine those this count completed.
+template <typename T>
+__device__ __forceinline__ void fused_combine(const FuseArgs *__restrict__ fzp, uint32_t gang, T *__restrict__ y, uint8_t *lds)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's partial sums have left (sc1 stores)
+    __syncthreads();                                           // ... and every other wavefront's
+    const FuseArgs fz = *fzp;
+    const uint2    rg = fz.range[gang];
+    uint32_t *const list = reinterpret_cast<uint32_t *>(lds + 8192 + 24 * kMaxSplitPanels);          // [1 + 64] blocks this workgroup completed, per pass of 64
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t bb = rg.x; bb <= rg.y; bb += 64u) {
+        if (wv == 0) {
+            const uint32_t b = bb + lane;
+            bool           last = false;
+            if (b <= rg.y) last = __hip_atomic_fetch_add(fz.cnt + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == fz.expect[b];
+            const uint64_t m = __ballot(last);
+            if (last) list[1 + lane_rank(m)] = b;
+            if (lane == 0) list[0] = (uint32_t)__popcll(m);
+        }
+        __syncthreads();                                       // (the adds have returned before anybody loads)
+        const uint32_t n = list[0];
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t b = list[1 + i];
+            fused_combine_block<T>(fz, b, y, lds);
+            if (threadIdx.x == 0) __hip_atomic_store(fz.cnt + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next SpMV
+        }
+        __syncthreads();
+    }
+}
+
 constexpr int kGangCap = 72;          // the compiler's registers v0 .. v71 (the ilv kernel's 40 + a unit's products and tags); the ring above
 template <typename T, bool DICT, bool TAG, bool SNT>
 __global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __attribute__((amdgpu_num_vgpr(kGangCap))) void spmv_gang_kernel(
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint2 *__restrict__ desc2_a, const T *__restrict__ x, T *__restrict__ yext_a, int G_alloc,
     uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes_a, const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, uint32_t col_bits,
-    uint32_t col_base_a, const PanelArgs *__restrict__ multi, uint32_t nw_compute, uint32_t help_ahead, uint32_t help_per_line, uint32_t flip, const uint32_t *__restrict__ gbase_a)
+    uint32_t col_base_a, const PanelArgs *__restrict__ multi, uint32_t nw_compute, uint32_t help_ahead, uint32_t help_per_line, uint32_t flip, const uint32_t *__restrict__ gbase_a,
+    const FuseArgs *__restrict__ fuse, T *__restrict__ y_fused)
 {
     using L = RingLayout<T, DICT, TAG, kGangCap>;
     constexpr int D = L::D, QN = 2 * D, XB = L::XB, QB = L::QB, K = (D - 1) * (4 + L::NS), U = kGangUnit;
@@ -1048,12 +1152,12 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __at
     const uint32_t *__restrict__ gbase = gbase_a;
     T *__restrict__              yext = yext_a;
     const uint32_t               bx = flip ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
-    uint32_t                     nchunks = nchunks_a, ystage_n = ystage_a, bidx = bx, col_base = col_base_a, xbytes = xbytes_a;
+    uint32_t                     nchunks = nchunks_a, ystage_n = ystage_a, bidx = bx, col_base = col_base_a, xbytes = xbytes_a, gang0 = 0;
     if (multi) {
         const uint32_t  round = bx / nblocks_per_xcd, b = bx - round * nblocks_per_xcd;
         const PanelArgs pa = multi[round * 8u + (b & 7u)];
         stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
-        col_base = pa.col_base; xbytes = (pa.pad_col + 1u) * (uint32_t)sizeof(T); gbase = pa.gbase;
+        col_base = pa.col_base; xbytes = (pa.pad_col + 1u) * (uint32_t)sizeof(T); gbase = pa.gbase; gang0 = pa.gang0;
         bidx = b >> 3;
     }
     constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
@@ -1233,18 +1337,26 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __at
     ring_wait<0>();
     asm volatile("; CVR_RING_END" ::: "memory");
     if (nwt > nw && wv == 0u && lane == 0) prog[0] = 0x7ffffff0u;
-    if (!own) return;
-    // every unit's additions are in the accumulators once the token has counted them all
-    {
+    if (!own && !fuse) return;
+    if (own) {
+        // every unit's additions are in the accumulators once the token has counted them all
         const uint32_t all = Tw / (uint32_t)U * nw;
         while (__hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != all) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
+        const T *const ystage = ystage_all + wv * ystage_n;
+        if (fuse) {          // the partial sums of a panel are handed to whichever workgroup completes their block: past the caches
+            for (uint32_t i = lane; i < nri; i += kLanes) {
+                const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
+                store_sc1(yext + dst, ystage[i]);
+            }
+        } else {
+            for (uint32_t i = lane; i < nri; i += kLanes) {
+                const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
+                store_y(yext + dst, ystage[i]);
+            }
+        }
     }
-    const T *const ystage = ystage_all + wv * ystage_n;
-    for (uint32_t i = lane; i < nri; i += kLanes) {
-        const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
-        store_y(yext + dst, ystage[i]);
-    }
+    if (fuse) fused_combine<T>(fuse, gang0 + blk, y_fused, smem);          // (no helper wavefronts with it: every wavefront of the workgroup is here)
 }
 
 // rows cut over chunks c0..c1: y[row] = carry_tail(c0) + sum_{c0 < c <= c1} carry_head(c), one wavefront per
@@ -1438,6 +1550,87 @@ hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st)
     return hipGetLastError();
 }
 
+
+namespace {
+// the fused combine's tables (FuseArgs): per gang the blocks of kCombineRows rows its first and its last sub-row lie in ...
+__global__ __launch_bounds__(256) void fuse_first_last_kernel(const FusePanel *__restrict__ panels, uint32_t npanels, uint32_t gw, uint32_t ngangs, uint32_t *__restrict__ first_last)
+{
+    const uint32_t gang = blockIdx.x * 256u + threadIdx.x;
+    if (gang >= ngangs) return;
+    uint32_t p = 0;
+    while (p + 1 < npanels && panels[p + 1].gang0 <= gang) p++;
+    const FusePanel q = panels[p];
+    const uint32_t  g = gang - q.gang0, k0 = g * gw, k1 = min(k0 + gw, q.nchunks) - 1u;
+    const uint32_t  s0 = q.desc[k0].x, s1 = q.desc[k1].x + max(q.desc2[k1].y, 1u) - 1u;
+    first_last[2 * gang] = q.rows[s0] / (uint32_t)kCombineRows;
+    first_last[2 * gang + 1] = q.rows[s1] / (uint32_t)kCombineRows;
+}
+// ... and from them the gang's range -- the ranges of a panel's gangs tile [0, nblocks): a gang takes the blocks up to the next gang's first, the
+// first gang starts at block 0, the last ends at the last block, so that every block is completed (and its rows written, empty ones as 0) -- and
+// expect[block] = the gangs of all panels whose range holds it
+__global__ __launch_bounds__(256) void fuse_range_kernel(const FusePanel *__restrict__ panels, uint32_t npanels, uint32_t gw, uint32_t ngangs, uint32_t nblocks,
+                                                         const uint32_t *__restrict__ first_last, uint2 *__restrict__ range, uint32_t *__restrict__ expect)
+{
+    const uint32_t gang = blockIdx.x * 256u + threadIdx.x;
+    if (gang >= ngangs) return;
+    uint32_t p = 0;
+    while (p + 1 < npanels && panels[p + 1].gang0 <= gang) p++;
+    const uint32_t g = gang - panels[p].gang0, ng = (panels[p].nchunks + gw - 1u) / gw;
+    const uint32_t b0 = g == 0 ? 0u : first_last[2 * gang];
+    const uint32_t b1 = g + 1 == ng ? nblocks - 1u : max(first_last[2 * gang + 1], first_last[2 * (gang + 1)] - min(first_last[2 * (gang + 1)], 1u));
+    range[gang] = uint2{b0, b1};
+    for (uint32_t b = b0; b <= b1; b++) atomicAdd(expect + b, 1u);
+}
+// y of the rows cut over chunks, after the fix-up launch: the partial sums of the row's sub-rows, panel by panel (the order of the combine)
+template <typename T>
+__global__ __launch_bounds__(64) void fuse_patch_kernel(const uint32_t *__restrict__ rows_list, uint32_t nlist, const FusePanel *__restrict__ panels, const CombinePanel *__restrict__ cpanels,
+                                                         const uint32_t *__restrict__ nsub, uint32_t npanels, T *__restrict__ y)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= nlist) return;
+    const uint32_t R = rows_list[i];
+    T acc = T(0);
+    for (uint32_t p = 0; p < npanels; p++) {
+        const uint32_t *rows = panels[p].rows;
+        uint32_t lo = 0, hi = nsub[p];
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rows[mid] < R) lo = mid + 1; else hi = mid; }
+        if (lo < nsub[p] && rows[lo] == R) acc += static_cast<const T *>(cpanels[p].z)[lo];
+    }
+    y[R] = acc;
+}
+__global__ __launch_bounds__(64) void fuse_cut_rows_kernel(const int64_t *__restrict__ shared, uint32_t nshared, const uint32_t *__restrict__ rows, uint32_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i < nshared) out[i] = rows[shared[3 * (size_t)i]];
+}
+}  // namespace
+
+hipError_t launch_fuse_setup(const FusePanel *panels_dev, uint32_t npanels, uint32_t gw, uint32_t ngangs, uint32_t nblocks, uint2 *range, uint32_t *first_last, uint32_t *expect, uint32_t *cnt, hipStream_t st)
+{
+    if (!ngangs || !nblocks) return hipSuccess;
+    hipError_t e = hipMemsetAsync(expect, 0, sizeof(uint32_t) * nblocks, st);
+    if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, sizeof(uint32_t) * nblocks, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fuse_first_last_kernel, dim3((ngangs + 255) / 256), dim3(256), 0, st, panels_dev, npanels, gw, ngangs, first_last);
+    hipLaunchKernelGGL(fuse_range_kernel, dim3((ngangs + 255) / 256), dim3(256), 0, st, panels_dev, npanels, gw, ngangs, nblocks, first_last, range, expect);
+    return hipGetLastError();
+}
+
+hipError_t launch_fuse_cut_rows(const int64_t *shared, uint32_t nshared, const uint32_t *rows, uint32_t *out, hipStream_t st)
+{
+    if (!nshared) return hipSuccess;
+    hipLaunchKernelGGL(fuse_cut_rows_kernel, dim3((nshared + 63) / 64), dim3(64), 0, st, shared, nshared, rows, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fuse_patch(const uint32_t *rows_list, uint32_t nlist, const FusePanel *panels_dev, const CombinePanel *cpanels, const uint32_t *nsub, uint32_t npanels, void *y, bool f32, hipStream_t st)
+{
+    if (!nlist) return hipSuccess;
+    if (f32) hipLaunchKernelGGL(fuse_patch_kernel<float>, dim3((nlist + 63) / 64), dim3(64), 0, st, rows_list, nlist, panels_dev, cpanels, nsub, npanels, static_cast<float *>(y));
+    else hipLaunchKernelGGL(fuse_patch_kernel<double>, dim3((nlist + 63) / 64), dim3(64), 0, st, rows_list, nlist, panels_dev, cpanels, nsub, npanels, static_cast<double *>(y));
+    return hipGetLastError();
+}
+
 bool iter_epilogue_ok(const DeviceImage &img) { return img.phases > 1 && !img.ilv && img.nshared == 0 && img.nchunks > 0 && (img.nchunks + (img.wpb > 1 ? img.wpb : 1) - 1) / (img.wpb > 1 ? img.wpb : 1) <= 1024u; }
 
 size_t spmv_lds_bytes(const DeviceImage &img)
@@ -1453,13 +1646,14 @@ template <typename F> inline void with_flag(bool v, F &&f) { if (v) f(std::true_
 template <typename F> inline void with_real(bool f32, F &&f) { if (f32) f(float{}); else f(double{}); }
 
 hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, hipStream_t st, bool with_fixup, const PanelArgs *multi, uint32_t multi_chunks, uint32_t multi_rounds,
-                       const IterEpilogue *epi)
+                       const IterEpilogue *epi, const FuseArgs *fuse, void *y_fused)
 {
     if (img.nchunks == 0 && !multi) return hipSuccess;
+    if (fuse && !(img.gang && multi && y_fused)) return hipErrorInvalidValue;
     if (epi && (multi || !iter_epilogue_ok(img))) return hipErrorInvalidValue;
     const uint32_t wpb = img.wpb > 1 ? img.wpb : 1;                     // consecutive chunks (wavefronts) per workgroup
     uint32_t       nblocks = (img.nchunks + wpb - 1) / wpb, kstride = 0;
-    const size_t   lds = spmv_lds_bytes(img);
+    const size_t   lds = std::max<size_t>(spmv_lds_bytes(img), fuse ? 12288 : 0);      // (the fused combine's accumulators and tables: 12 KiB of the workgroup's LDS, whatever the chunks' own take)
     if (lds > kLdsBytes) return hipErrorInvalidValue;                   // build_part sizes the stage and the window to fit; never reached
     // a hub table without a per-workgroup window: persistent workgroups (as many as are resident at once: 16 wavefronts per CU, or what
     // the LDS allows), each staging the table once and taking chunk groups blk, blk + grid, ...  (Without a table persistent
@@ -1496,10 +1690,10 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                     const uint32_t H = std::min<uint32_t>(hmax, img.ilv_helpers);
                     if (img.gang) {          // gang chunks: the workgroup's wavefronts walk one common list (spmv_gang_kernel)
                         using LG = RingLayout<T, kDict, decltype(TG)::value, kGangCap>;
-                        const uint32_t roomg = (uint32_t)LG::THREADS / kLanes, Hg = roomg > wpb ? std::min<uint32_t>(roomg - wpb, img.ilv_helpers * wpb) : 0u;      // helpers: all on the gang's stream
+                        const uint32_t roomg = (uint32_t)LG::THREADS / kLanes, Hg = fuse ? 0u : roomg > wpb ? std::min<uint32_t>(roomg - wpb, img.ilv_helpers * wpb) : 0u;      // helpers: all on the gang's stream (none with the fused combine: its barriers are the whole workgroup's)
                         with_flag(img.ilv_stream_nt != 0, [&](auto SN) {
                             hipLaunchKernelGGL((spmv_gang_kernel<T, kDict, decltype(TG)::value, decltype(SN)::value>), dim3(grid), dim3(kLanes * (wpb + Hg)), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
-                                               img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi, wpb, img.ilv_ahead, img.ilv_per_line, img.flip_now, img.gbase);
+                                               img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi, wpb, img.ilv_ahead, img.ilv_per_line, img.flip_now, img.gbase, fuse, static_cast<T *>(y_fused));
                         });
                         return;
                     }

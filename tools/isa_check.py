@@ -10,7 +10,7 @@ This script compiles cvr_spmv.hip to gfx950 assembly (or reads the file given) a
   1. private segment (scratch) size 0, no VGPR / SGPR spills (kernel metadata);
   2. between `; CVR_RING_BEGIN cap=N` and `; CVR_RING_END` every buffer_/global_/flat_/scratch_ instruction is a buffer_load_dword*
      whose destination lies in v[N..255], and stands inside an asm statement;
-  3. outside asm statements no instruction of the kernel names a register v[N..255].
+  3. outside asm statements no instruction of the kernel up to `; CVR_RING_END` names a register v[N..255] (behind it the ring is dead).
 Exit status 0 = all instantiations pass (they are listed); 1 = a violation (printed with its line).  `make -C cvr_amd/csrc isa-check`
 and __graft_entry__.build() run it; tests/test_host_cpu.py::test_ring_kernel_isa_guard runs it and checks that a broken kernel fails.
   HIPCC_EXTRA="-DX=1 ..." adds compiler flags (the test's way of breaking the kernel on purpose)."""
@@ -143,7 +143,9 @@ def check(path, expected):
                 ok = in_asm and re.match(r"^\s*buffer_load_dword(x[234])?\b", code) and (first_reg(code) or 0) >= cap
                 if not ok:
                     errors.append(f"{name}: vector-memory instruction inside the ring region that is not a ring load ({path}:{i + 1}): {code.strip()}")
-            if not in_asm and highest_vreg(code) >= cap:
+            # (behind CVR_RING_END the ring is dead and its registers are the compiler's again -- the gang kernel's fused combine uses a few; a value
+            # that lived THROUGH the region in one of them would have been named in front of it, which this rule still catches)
+            if not in_asm and not closed and highest_vreg(code) >= cap:
                 errors.append(f"{name}: the compiler uses a ring register ({path}:{i + 1}): {code.strip()}")
         if not closed or region:
             errors.append(f"{name}: CVR_RING_BEGIN without CVR_RING_END")

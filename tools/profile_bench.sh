@@ -25,7 +25,7 @@ import csv, glob, collections, json
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$OUT/pmc*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "spmv_kernel" not in r["Kernel_Name"] and "spmv_seg_kernel" not in r["Kernel_Name"] and "spmv_ilv_kernel" not in r["Kernel_Name"]: continue
+        if "spmv_kernel" not in r["Kernel_Name"] and "spmv_seg_kernel" not in r["Kernel_Name"] and "spmv_ilv_kernel" not in r["Kernel_Name"] and "spmv_gang_kernel" not in r["Kernel_Name"]: continue
         a = agg[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 s = {k: agg[k][0] / agg[k][1] for k in agg}
 # FETCH_SIZE / WRITE_SIZE come in KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B: double it
