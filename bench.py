@@ -712,6 +712,13 @@ def main():
                 comm = None
 
     xcheck("buffers, stream")
+    rccl_info = None
+    if comm is not None:
+        try:
+            rn, rr, rv = comm.info()
+            rccl_info = {"ranks": rn, "rank0_user_rank": rr, "version": rv}
+        except Exception as e:          # noqa: BLE001
+            rccl_info = {"error": repr(e)}
     overlap = [False]
 
     def step(n=1):
@@ -979,6 +986,8 @@ def main():
             "gathered_slices_differing_between_ranks": gathered_mismatch, "shard_checksums": shard_sums,
             "verdict_wrong_rows": wrong, "verdict_tolerance": "rows with |y - y_csr| > %g * sum |a x|" % (1e-5 if f32 else 1e-12),
             "verdict_wrong_rows_reference_criterion_abs_1e-3": wrong_ref if wrong_ref >= 0 else None, "gather_impl": gather_impl, "gather_calibration_ms_per_step": calib,
+            # what RCCL itself reports for the library's communicator (ncclCommCount / ncclCommUserRank / ncclGetVersion): a multi-GPU record shows that the collective saw N ranks
+            "rccl": rccl_info,
         }
         # the other power-law shapes, in this process, time-boxed (the default run must finish within minutes): each entry lets the
         # fractions be recomputed from nnz and kernel time

@@ -64,7 +64,7 @@ class MmMatrix(C.Structure):
 # every symbol include/cvr_amd.h declares (tests check the library exports all of them)
 SYMBOLS = ["cvr_default_options", "cvr_last_error", "cvr_version", "cvr_device_count", "cvr_create", "cvr_preprocess",
            "cvr_get_info", "cvr_destroy", "cvr_spmv", "cvr_spmv_device", "cvr_spmv_device_repeat", "cvr_x_device", "cvr_y_device", "cvr_stream",
-           "cvr_spmv_bench", "cvr_debug_phase_clocks", "cvr_device_copy_bench", "cvr_export_image", "cvr_export_gang", "cvr_plan_bound", "cvr_plan_chunks", "cvr_plan_selfcheck", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
+           "cvr_spmv_bench", "cvr_debug_phase_clocks", "cvr_device_copy_bench", "cvr_export_image", "cvr_export_gang", "cvr_comm_info", "cvr_plan_bound", "cvr_plan_chunks", "cvr_plan_selfcheck", "cvr_mm_read", "cvr_mm_free", "cvr_mm_write_bin", "cvr_mm_read_bin",
            "cvr_fill_x", "cvr_csr_spmv_host", "cvr_verdict",
            "cvr_tune_steps", "cvr_tune", "cvr_auto_panels", "cvr_power_iteration", "cvr_comm_unique_id", "cvr_comm_create", "cvr_comm_destroy", "cvr_comm_all_gather", "cvr_spmv_gather_repeat",
            "cvr_source_key_of", "cvr_mm_write_bin_keyed", "cvr_mm_read_bin_keyed", "cvr_mm_read_cached", "cvr_save_image", "cvr_load_image",
@@ -133,6 +133,7 @@ def lib():
         L.cvr_comm_unique_id.argtypes = [C.c_void_p]
         L.cvr_comm_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.cvr_comm_destroy.argtypes = [C.c_void_p]
+        L.cvr_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.cvr_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.cvr_spmv_gather_repeat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                              C.c_int64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
@@ -324,6 +325,14 @@ class Comm:
         rc = lib().cvr_comm_create(C.byref(self._c), unique_id, nranks, rank, device)
         if rc:
             raise CvrError(rc, "cvr_comm_create")
+
+    def info(self):
+        """(ranks, this rank, RCCL version) as the library reports them for this communicator (cvr_comm_info); -1 where it cannot say"""
+        n, r, v = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        rc = lib().cvr_comm_info(self._c, C.byref(n), C.byref(r), C.byref(v))
+        if rc:
+            raise CvrError(rc, "cvr_comm_info")
+        return n.value, r.value, v.value
 
     def all_gather(self, send_ptr, recv_ptr, count, is_f32=False, stream=None):
         rc = lib().cvr_comm_all_gather(self._c, send_ptr, recv_ptr, count, int(is_f32), stream)

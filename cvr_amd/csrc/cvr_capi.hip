@@ -672,6 +672,14 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] %d column panels dropped: L2 miss share %.3f against %.3f (row, panel) pairs per non-zero\n", P, rule_miss, ppn);
             P = 1;
             opt.hub_table = opt_in ? opt_in->hub_table : -1;          // (the flat-popularity shortcut above was taken for panels)
+            // The gathers of such a matrix do miss the L2s (the rule asked for panels), only panels would write more partial sums than they save misses: short rows
+            // whose columns are spread, but not evenly -- the citation-like hold-out shape.  What is left to save is the NUMBER of requests: one interleaved image
+            // with gang chunks (one sorted list of ~100 000 non-zeros per workgroup) -- 134 us plain, 123 interleaved, 111 as gangs (profiles/r06_holdout_single_image.log);
+            // every other hold-out shape that keeps one image has no misses to speak of (road-like) or a popular head (R-MAT: hub table) and never comes here
+            // (not rows of one or two non-zeros: nothing to accumulate per row, and the accumulators' row cap would end their chunks early)
+            if (sj1 - sj0 >= 3 * nrows && opt.interleave < 0 && opt.gang < 0 && opt.hub_table < 0 && opt.steps_per_chunk == 0 && opt.waves_per_block == 0 && opt.x_window < 0 && opt.col_phases < 0 && !cvr::debug_env("no_auto_layout") && !cvr::debug_env("no_single_gang")) {
+                opt.interleave = 1; opt.gang = 1; opt.hub_table = 0;
+            }
         }
         in.plan_s += now_s() - tq;
     }
@@ -752,11 +760,12 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             // instead of four: their chunks are short (the row cap of the LDS accumulators ends them, not the steps), and with two wavefronts a
             // chunk may span twice the rows (wiki-Talk shape 39.7 -> 36.6 us, x 2 at another seed 70.3 -> 66.0; every other shape of
             // profiles/r05_wpb_probe.log loses 1-20 % with two, which is why this is not the general rule)
-            if (panel_opt.waves_per_block == 0 && panels_auto && nsub_all < nrows && !cvr::debug_env("no_sparse_waves")) panel_opt.waves_per_block = 2;
             // gang chunks (automatic): the four chunks of an interleaved workgroup sorted together and walked by its wavefronts in turn -- four times the
-            // non-zeros share the lines of x a gather touches (prototype: soc-LiveJournal1 shape 246 -> 178 us, com-Orkut shape 736 -> 510: profiles/r06_token_probe_*.log);
-            // not the two-wavefront workgroups of mostly-empty matrices (their chunks end at the row cap: short lists, few workgroups)
+            // non-zeros share the lines of x a gather touches (prototype: soc-LiveJournal1 shape 246 -> 178 us, com-Orkut shape 736 -> 510: profiles/r06_token_probe_*.log)
             if (panel_opt.gang < 0) panel_opt.gang = panel_opt.waves_per_block == 0 && !cvr::debug_env("no_gang") ? 1 : 0;
+            // (round 5's rule of two wavefronts for mostly-empty matrices holds only for private chunks: with a gang the four chunks' rows share one list anyway --
+            // forum-like hold-out shape 53.4 us with two wavefronts, 48.6 as a gang of four; wiki-Talk x 2: 54.2 / 50.2; wiki-Talk itself 35.8 / 36.1: profiles/r06_holdout.log)
+            if (panel_opt.waves_per_block == 0 && panel_opt.gang <= 0 && panels_auto && nsub_all < nrows && !cvr::debug_env("no_sparse_waves")) panel_opt.waves_per_block = 2;
             if (panel_opt.steps_per_chunk == 0) {       // one chunk length for all panels (they share a launch): from the mean sub-row and the mean panel
                 IOpt one = panel_opt;
                 panel_opt.steps_per_chunk = interleave_steps((sj1 - sj0) / P, std::max<int64_t>(nsub_all / P, 1), f32, one);

@@ -28,6 +28,9 @@ const RcclApi *rccl_api()
             a.comm_init_all = (decltype(a.comm_init_all))dlsym(a.lib, "ncclCommInitAll");
             a.group_start = (decltype(a.group_start))dlsym(a.lib, "ncclGroupStart");
             a.group_end = (decltype(a.group_end))dlsym(a.lib, "ncclGroupEnd");
+            a.comm_count = (decltype(a.comm_count))dlsym(a.lib, "ncclCommCount");
+            a.comm_user_rank = (decltype(a.comm_user_rank))dlsym(a.lib, "ncclCommUserRank");
+            a.get_version = (decltype(a.get_version))dlsym(a.lib, "ncclGetVersion");
             if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather || !a.error_string || !a.comm_init_all || !a.group_start || !a.group_end) a.lib = nullptr;
         }
         return a;
@@ -98,6 +101,21 @@ int cvr_comm_destroy(cvr_comm *c)
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return CVR_OK;
+}
+
+int cvr_comm_info(cvr_comm *c, int *nranks, int *rank, int *rccl_version)
+{
+    if (!c) return fail(CVR_ERR_INVALID, "communicator is null");
+    const RcclApi *api = rccl_api();
+    if (!api || !c->comm) return fail(CVR_ERR_STATE, "no RCCL communicator behind this handle");
+    int n = -1, r = -1, v = -1;
+    if (api->comm_count) RCCL_TRY(api, api->comm_count(c->comm, &n));
+    if (api->comm_user_rank) RCCL_TRY(api, api->comm_user_rank(c->comm, &r));
+    if (api->get_version) RCCL_TRY(api, api->get_version(&v));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (rccl_version) *rccl_version = v;
     return CVR_OK;
 }
 

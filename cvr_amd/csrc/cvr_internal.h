@@ -241,7 +241,7 @@ inline int64_t device_plan_rows() { const char *e = cvr::debug_env("device_plan_
 
 constexpr size_t kSmallProbe = 0, kSmallDictTab = 16 << 10, kSmallDictFlags = 24 << 10, kSmallBytes = 32 << 10;
 constexpr size_t kPinnedProbe = 0, kPinnedDictTab = 16 << 10, kPinnedDictFlags = 24 << 10, kPinnedSmall = 32 << 10;      // in front of the planner's part of the pinned buffer
-int        pick_steps(int64_t nslots_est, int64_t max_row = 0, double cus = 256.0);
+int        pick_steps(int64_t nslots_est, int64_t max_row = 0, double cus = 256.0, int64_t nrows = 0);
 int        interleave_steps(int64_t nnz, int64_t nrows, bool f32, const IOpt &opt);
 int        interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<int64_t> &nsub, int64_t col_span, int rounds, bool f32, const IOpt &opt, int *generations = nullptr);
 int        panel_generations(const std::vector<int64_t> &chunks, int rounds, int wpb, int cus_per_xcd, double *fullest = nullptr);
@@ -312,6 +312,10 @@ struct RcclApi {
     decltype(&ncclCommInitAll)    comm_init_all = nullptr;      // one process driving several GPUs (cvr_multi.hip)
     decltype(&ncclGroupStart)     group_start = nullptr;
     decltype(&ncclGroupEnd)       group_end = nullptr;
+    // optional (cvr_comm_info: what the library itself reports about a communicator)
+    decltype(&ncclCommCount)      comm_count = nullptr;
+    decltype(&ncclCommUserRank)   comm_user_rank = nullptr;
+    decltype(&ncclGetVersion)     get_version = nullptr;
 };
 const RcclApi *rccl_api();      // null when librccl cannot be loaded
 

@@ -7,7 +7,7 @@ using namespace cvrh;
 
 namespace cvrh {
 
-int pick_steps(int64_t nslots_est, int64_t max_row, double cus)
+int pick_steps(int64_t nslots_est, int64_t max_row, double cus, int64_t nrows)
 {
     // The plain layout (one chunk per workgroup).  Images of more than 12 chunks per CU at S = 32 run in rounds and take
     // S = 32 (LiveJournal panels, R-MAT, banded: within 1 % of the best S, profiles/r02_steps_rule_check.log,
@@ -18,7 +18,9 @@ int pick_steps(int64_t nslots_est, int64_t max_row, double cus)
     // 9.8 and 11.8 us).  cvr_tune measures instead.
     const double kCus = cus;             // (a column panel that runs on one XCD counts its chunks against that XCD's 32 CUs)
     auto chunks = [&](int S) { return (double)nslots_est * 1.004 / (64.0 * S) + 1.0; };
-    if (chunks(32) > kCus * 12.0) return 32;
+    // (rows of fewer than four slots on average -- the road-network-like hold-out shape, 2.6 per row -- : a chunk of 32 steps holds ~800 rows, whose sums leave through
+    // one wavefront's staged write-out; half the length runs 6-7 % faster: 43.0 against 46.0 us, profiles/r06_holdout.log)
+    if (chunks(32) > kCus * 12.0) return nrows > 0 && nslots_est < 4 * nrows ? 16 : 32;
     int S = (int)std::min<int64_t>(64, std::max<int64_t>(12, ((max_row + 15) / 16 + 3) / 4 * 4));
     while (S < 64 && chunks(S) > kCus * 12.0) S += 4;
     return S;
@@ -178,7 +180,7 @@ hipError_t plan_part(PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, const
             if (rp) for (int64_t r = 0; r < nrows; r++) max_row = std::max(max_row, rp[r + 1] - rp[r]);
             else { const hipError_t e = cvr::max_row_device(dr->rp, nrows, &max_row, dr->st); if (e != hipSuccess) return e; }
         }
-        pp.S = pick_steps(nz1 - nz0 + nrows / 4, max_row, cus);
+        pp.S = pick_steps(nz1 - nz0 + nrows / 4, max_row, cus, nrows);
     }
     const int64_t max_rows = plan_layout(pp, ncols, f32, opt);
     if (rp) {

@@ -278,6 +278,9 @@ int cvr_comm_unique_id(void *id128);
 /* collective over all ranks; `device` is this rank's GPU */
 int cvr_comm_create(cvr_comm **comm, const void *id128, int nranks, int rank, int device);
 int cvr_comm_destroy(cvr_comm *comm);
+/* What RCCL itself says about the communicator -- ncclCommCount, ncclCommUserRank, ncclGetVersion (-1 where the loaded library lacks the call):
+ * a record of a multi-GPU run can show that the collective saw N ranks.  Any pointer may be NULL. */
+int cvr_comm_info(cvr_comm *comm, int *nranks, int *rank, int *rccl_version);
 /* one all-gather of `count` values per rank (type by is_f32) on `stream`: recv_dev holds nranks * count values */
 int cvr_comm_all_gather(cvr_comm *comm, const void *send_dev, void *recv_dev, int64_t count, int is_f32, void *stream);
 /* `n` sharded SpMVs of the fixed-x loop (spmv.cpp:1024), each followed by the all-gather of this rank's y slice

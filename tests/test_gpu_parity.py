@@ -978,6 +978,8 @@ def test_power_iteration_device_resident():
     assert lam2 == lam and torch.equal(x2.view(torch.int64), x.view(torch.int64))
     # the sharded form of the loop with a 1-rank RCCL communicator (all-gather, un-padding, rebuilt x)
     comm = cvr_amd.Comm(cvr_amd.comm_unique_id(), 1, 0, 0)
+    ranks, rank, version = comm.info()                                    # what RCCL itself reports (bench.py's "rccl" field at N > 1)
+    assert (ranks, rank) == (1, 0) and version > 20000, (ranks, rank, version)
     lam3, x3, _ = power.power_iteration(A, nrows, bounds=[0, nrows], comm=comm, iters=30)
     assert lam3 == lam and torch.equal(x3.view(torch.int64), x.view(torch.int64))
     with pytest.raises(cvr_amd.CvrError):
@@ -1596,14 +1598,20 @@ def test_bench_eight_ranks_on_one_device(workload, tmp_path):
     assert len(bad) == 0, (len(bad), worst, "wrong rows per rank's slice", per_slice)
 
 
-@pytest.mark.parametrize("shape", ["webgoogle_seed7", "webgoogle_real", "lj_half", "road", "citation", "rmat21b", "wikitalk_x2", "uniform16", "forum_sparse", "bipartite_sparse"])
+# the layout that came out best for each hold-out shape in the full sweep of tools/holdout.py (profiles/r06_holdout.log): what the automatic choice is held against
+HOLDOUT_CONTENDER = {"webgoogle_seed7": "resident 7x48 window phases", "webgoogle_real": "measured (cvr_tune)", "lj_half": "16 panels interleaved", "lj_x2": "32 panels interleaved",
+                     "road": "plain S=16", "citation": "1 image interleaved, gang", "rmat21b": "measured (cvr_tune)", "orkut_half": "8 panels interleaved",
+                     "wikitalk_x2": "16 panels interleaved", "uniform16": "8 panels interleaved", "forum_sparse": "8 panels interleaved", "bipartite_sparse": "8 panels interleaved"}
+
+
+@pytest.mark.parametrize("shape", sorted(HOLDOUT_CONTENDER))
 def test_automatic_layout_on_held_out_shapes(shape):
-    """The automatic layout against the PLAIN layout (one chunk per workgroup, no window, phases, panels, tables or interleaving) on shapes its
-    rules were not fitted on -- other seeds and other families: road-network-like, citation-like, uniform random, a flatter R-MAT, real
-    values (tools/holdout.py; the full sweep with the regret table: profiles/r05_holdout.log).  Never more than 10 % slower than plain,
-    and the same y (round-4 verdict, item 4: before the panel rule weighed the partial sums, the citation-like shape ran 33 % slower; before it
-    weighed the panels' loads, the bipartite shape -- non-zeros crowding into the first column ranges -- ran 3 % slower than plain and twice
-    the time of 32 panels)."""
+    """The automatic layout on the twelve shapes its rules were not fitted on (tools/holdout.py: other seeds and other families -- road-network-like,
+    citation-like, uniform random, a flatter R-MAT, real values, mostly-empty and bipartite matrices, the big stand-ins halved and doubled) against (1) the PLAIN
+    layout -- never slower, up to timing noise -- and (2) the layout that won the full sweep of 15-25 explicit layouts for that shape (profiles/r06_holdout.log):
+    within 8 % of it; the same y everywhere.  (Round 4: the citation-like shape ran 33 % slower than plain before the panel rule weighed the partial sums; round 5:
+    the bipartite shape 3 % slower than plain and twice the time of 32 panels; round 6: the citation-like shape 21 % behind one interleaved image of gang chunks
+    until the dropped-panels case took that layout.)"""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
@@ -1612,18 +1620,21 @@ def test_automatic_layout_on_held_out_shapes(shape):
     f32 = va.dtype == np.float32
     x = synth.x_rand(nc, va.dtype)
     yref, absy = O.csr_spmv64(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    cand = dict(H.candidates(n, nc, len(ci), 4 if f32 else 8))
+    best_label = HOLDOUT_CONTENDER[shape]
     t, layout = {}, {}
-    for label, kw in (("automatic", {}), ("plain", dict(H.PLAIN))):
+    for label, kw in (("automatic", {}), ("plain", dict(H.PLAIN)), (best_label, cand[best_label])):
         A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, **kw)
         y, _ = A.spmv(x)
         _assert_close(y, yref, absy, TOL32 if f32 else TOL64, (shape, label))
         t[label] = min(A.bench(5, 50) for _ in range(3))
         i = A.info
-        layout[label] = (i.steps_per_chunk, i.waves_per_block, i.col_panels, i.col_phases, i.x_window, i.hub_entries, i.interleave, i.value_dict, i.nchunks)
+        layout[label] = (i.steps_per_chunk, i.waves_per_block, i.col_panels, i.col_phases, i.x_window, i.hub_entries, i.interleave, i.gang, i.value_dict, i.nchunks)
         A.close()
-    if layout["automatic"] == layout["plain"]:          # (the rules chose the plain layout itself: one code path, nothing to compare but two runs of it)
-        return
-    assert t["automatic"] <= 1.10 * t["plain"], (shape, t, layout)
+    if layout["automatic"] != layout["plain"]:          # (else the rules chose the plain layout itself: two runs of one code path)
+        assert t["automatic"] <= 1.03 * t["plain"], (shape, t, layout)
+    if layout["automatic"] != layout[best_label]:
+        assert t["automatic"] <= 1.08 * t[best_label], (shape, t, layout)
 
 
 def test_bench_device_built_workload():

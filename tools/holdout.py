@@ -9,7 +9,7 @@ explicit layouts (the plain layout, other chunk lengths, panels plain / interlea
     regret = t(automatic) / min over the sweep (automatic included) - 1
 
 Every candidate's y is checked against the library's host CSR loop (a layout that computes something else does not count).  Output: one
-line per candidate and a table per shape -> profiles/r05_holdout.log (the bar: regret <= 8 % everywhere, and the automatic layout never
+line per candidate and a table per shape -> profiles/r06_holdout.log (the bar: regret <= 8 % everywhere, and the automatic layout never
 more than 10 % slower than the plain layout: tests/test_gpu_parity.py::test_automatic_layout_on_held_out_shapes asserts the latter).
 
   python tools/holdout.py                 all shapes
@@ -181,11 +181,14 @@ def candidates(n, ncols, nnz, vbytes):
         for P in (8, 16, 32):
             if xb / P >= 0.5e6:
                 c.append((f"{P} panels plain", dict(col_panels=P, interleave=0)))
-                c.append((f"{P} panels interleaved", dict(col_panels=P, interleave=1)))
+                c.append((f"{P} panels interleaved", dict(col_panels=P, interleave=1)))          # (gang chunks by the rule: four wavefronts on one sorted list)
+                if P <= 16:
+                    c.append((f"{P} panels interleaved, private", dict(col_panels=P, interleave=1, gang=0)))      # (round 4's chunks: a sorted list per wavefront)
                 if P <= 16:
                     c.append((f"{P} panels interleaved, 2 wavefronts", dict(col_panels=P, interleave=1, waves_per_block=2)))
                     c.append((f"{P} panels interleaved, 4 wavefronts", dict(col_panels=P, interleave=1, waves_per_block=4)))
         c.append(("1 image interleaved", dict(col_panels=1, interleave=1)))
+        c.append(("1 image interleaved, gang", dict(col_panels=1, interleave=1, gang=1)))
     return c
 
 
@@ -214,7 +217,7 @@ def run_shape(name, out):
         s = A.bench(10, 100 if nnz > 50e6 else 200)
         i = A.info
         out(f"  {label:34s} {s * 1e6:9.2f} us  {balg / s / 8e12 * 100:5.1f} %  wrong {wrong}  S {i.steps_per_chunk} wpb {i.waves_per_block} panels {i.col_panels} ilv {i.interleave} "
-            f"phases {i.col_phases} win {i.x_window} hub {i.hub_entries} ({i.hub_share:.2f}) dict {i.value_dict} chunks {i.nchunks}")
+            f"phases {i.col_phases} win {i.x_window} hub {i.hub_entries} ({i.hub_share:.2f}) dict {i.value_dict} chunks {i.nchunks} gang {i.gang}")
         A.close()
         if wrong == 0:
             res.append((label, s))

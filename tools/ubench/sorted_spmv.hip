@@ -222,16 +222,18 @@ __global__ __launch_bounds__(1024) void sorted_spmv_kernel(const uint8_t *__rest
 // chunk's sorted list whatever the wavefronts' timing: bitwise reproducible, the sums of the CSR loop.  Loads, gathers and products run ahead freely.
 // GBASE (mode 5): no 16-bit tag block -- the column word holds the column's offset from its group's first (smallest) column in its low 17 bits and the
 // row above them; the groups' first columns stand in a table per wavefront (scalar loads, a revolution of the ring ahead).
-template <typename T, bool DICT, bool TAG, bool SHARED, bool BAR = false, bool REP = false, int TOK = 0, bool GBASE = false>
+// PACK4 (mode 6): GBASE with the dictionary code in the column word too -- offset (13 bits) | tag (15 bits) << 13 | code (4 bits) << 28: 4 bytes per slot, one
+// stream load per group (dictionaries of at most 16 entries)
+template <typename T, bool DICT, bool TAG, bool SHARED, bool BAR = false, bool REP = false, int TOK = 0, bool GBASE = false, bool PACK4 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sorted_spmv_ring_kernel(const uint8_t *__restrict__ stream, const ChunkDesc *__restrict__ desc, const uint32_t *__restrict__ wg_first,
                                                            const uint32_t *__restrict__ wg_count, const T *__restrict__ x, T *__restrict__ z, uint32_t col_bits,
                                                            uint32_t R, const T *__restrict__ dict_g, uint32_t ndict, const uint32_t *__restrict__ rowslot = nullptr,
                                                            const uint32_t *__restrict__ gbase = nullptr, uint32_t gb_stride = 0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr uint32_t GB = group_bytes<T, DICT, TAG>();
+    constexpr uint32_t GB = PACK4 ? 1024u : group_bytes<T, DICT, TAG>();
     constexpr uint32_t VB = 1024u + (TAG ? 512u : 0u);
-    constexpr int      NS = 1 + (TAG ? 1 : 0) + (DICT ? 1 : sizeof(T) == 8 ? 2 : 1);       // stream loads per group
+    constexpr int      NS = PACK4 ? 1 : 1 + (TAG ? 1 : 0) + (DICT ? 1 : sizeof(T) == 8 ? 2 : 1);       // stream loads per group
     constexpr int      D = 4, QN = 8, K = (D - 1) * (4 + NS);
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     T *const dict = reinterpret_cast<T *>(smem);
@@ -262,7 +264,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
         const uint32_t so_ = __builtin_amdgcn_readfirstlane((grp) * GB);                                                               \
         asm volatile("buffer_load_dwordx4 " QR(u, 0, 4) ", %0, %1, %2 offen" NTS ::"v"(vo_c), "s"(rs), "s"(so_) : RING_CLOBBER);           \
         if constexpr (TAG) asm volatile("buffer_load_dwordx2 " QR(u, 4, 2) ", %0, %1, %2 offen" NTS ::"v"(vo_t), "s"(rs), "s"(so_) : RING_CLOBBER); \
-        if constexpr (DICT) asm volatile("buffer_load_dword " QR1(u, 6) ", %0, %1, %2 offen" NTS ::"v"(vo_code), "s"(rs), "s"(so_) : RING_CLOBBER); \
+        if constexpr (PACK4) {}                                                                                                         \
+        else if constexpr (DICT) asm volatile("buffer_load_dword " QR1(u, 6) ", %0, %1, %2 offen" NTS ::"v"(vo_code), "s"(rs), "s"(so_) : RING_CLOBBER); \
         else if constexpr (sizeof(T) == 8) {                                                                                            \
             asm volatile("buffer_load_dwordx4 " QR(u, 6, 4) ", %0, %1, %2 offen" NTS ::"v"(vo_v0), "s"(rs), "s"(so_) : RING_CLOBBER);      \
             asm volatile("buffer_load_dwordx4 " QR(u, 10, 4) ", %0, %1, %2 offen" NTS ::"v"(vo_v1), "s"(rs), "s"(so_) : RING_CLOBBER);     \
@@ -292,7 +295,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
     asm volatile("v_mov_b32 %0, " QR1(u, 0) "\n\tv_mov_b32 %1, " QR1(u, 1) "\n\tv_mov_b32 %2, " QR1(u, 2) "\n\tv_mov_b32 %3, " QR1(u, 3)           \
                  : "=v"(cw_[0]), "=v"(cw_[1]), "=v"(cw_[2]), "=v"(cw_[3])::"memory");                                                  \
     if constexpr (TAG) asm volatile("v_mov_b32 %0, " QR1(u, 4) "\n\tv_mov_b32 %1, " QR1(u, 5) : "=v"(tg_[0]), "=v"(tg_[1])::"memory");       \
-    if constexpr (DICT) asm volatile("v_mov_b32 %0, " QR1(u, 6) : "=v"(vv_[0])::"memory");                                             \
+    if constexpr (PACK4) {}                                                                                                             \
+    else if constexpr (DICT) asm volatile("v_mov_b32 %0, " QR1(u, 6) : "=v"(vv_[0])::"memory");                                             \
     else if constexpr (sizeof(T) == 8)                                                                                                  \
         asm volatile("v_mov_b32 %0, " QR1(u, 6) "\n\tv_mov_b32 %1, " QR1(u, 7) "\n\tv_mov_b32 %2, " QR1(u, 8) "\n\tv_mov_b32 %3, " QR1(u, 9) "\n\t"   \
                      "v_mov_b32 %4, " QR1(u, 10) "\n\tv_mov_b32 %5, " QR1(u, 11) "\n\tv_mov_b32 %6, " QR1(u, 12) "\n\tv_mov_b32 %7, " QR1(u, 13)     \
@@ -314,12 +318,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
         T pr_[4]; uint32_t rw_[4];            /* products and rows first: with a token nothing but the additions themselves happens while it is held */ \
         _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                                                \
             T av, xv;                                                                                                                   \
-            if constexpr (DICT) av = dict[(vv_[0] >> (8 * j)) & 0xffu];                                                                 \
+            if constexpr (PACK4) av = dict[cw_[j] >> 28];                                                                               \
+            else if constexpr (DICT) av = dict[(vv_[0] >> (8 * j)) & 0xffu];                                                            \
             else if constexpr (sizeof(T) == 8) av = __builtin_bit_cast(double, (uint64_t)vv_[2 * j] | ((uint64_t)vv_[2 * j + 1] << 32)); \
             else av = __builtin_bit_cast(float, vv_[j]);                                                                                \
             if constexpr (sizeof(T) == 8) xv = __builtin_bit_cast(double, (uint64_t)xx_[2 * j] | ((uint64_t)xx_[2 * j + 1] << 32));    \
             else xv = __builtin_bit_cast(float, xx_[j]);                                                                                \
-            if constexpr (TAG) rw_[j] = (tg_[j >> 1] >> (16 * (j & 1))) & 0xffffu;                                                       \
+            if constexpr (PACK4) rw_[j] = (cw_[j] >> 13) & 0x7fffu;                                                                      \
+            else if constexpr (TAG) rw_[j] = (tg_[j >> 1] >> (16 * (j & 1))) & 0xffffu;                                                  \
             else rw_[j] = col_bits >= 32 ? 0u : cw_[j] >> col_bits;                                                                     \
             pr_[j] = av * xv;                                                                                                           \
         }                                                                                                                               \
@@ -495,12 +501,14 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     // ---- formats
     uint32_t col_bits = 1; while ((1ull << col_bits) < pw) col_bits++;
     uint32_t row_bits = 1; while ((1ull << row_bits) < (uint64_t)Reff + 1) row_bits++;      // tags 0 .. Reff
-    const bool gbm = mode == 5;                                   // group-base packing: 17 bits of column offset + the row in one word
+    const bool pack4 = mode == 6;                                 // group-base packing with the code in the word: 13 + 15 + 4 bits
+    const bool gbm = mode == 5 || pack4;                          // group-base packing: 17 bits of column offset + the row in one word
     const uint32_t TOKU = getenv("TOK_U") ? (uint32_t)atoi(getenv("TOK_U")) : 1u;      // modes 4 / 5: groups per unit (1, 2, 4, 8)
     if (gbm && row_bits > 15) { fprintf(stderr, "rows per chunk beyond 15 bits\n"); return 1; }
     const bool tag = !gbm && (col_bits + row_bits > 32 || mode == 3);
     if (tag && Reff + 1 > 65536) { fprintf(stderr, "rows per chunk beyond 16-bit tags\n"); return 1; }
-    const uint32_t GB = 1024u + (tag ? 512u : 0u) + (use_dict ? 256u : sizeof(T) == 8 ? 2048u : 1024u);
+    if (pack4 && (!use_dict || dict.size() > 16)) { fprintf(stderr, "mode 6 needs a dictionary of at most 16 entries\n"); return 1; }
+    const uint32_t GB = pack4 ? 1024u : 1024u + (tag ? 512u : 0u) + (use_dict ? 256u : sizeof(T) == 8 ? 2048u : 1024u);
     std::vector<ChunkDesc> desc(nch);
     uint64_t soff = 0, zoff = 0;
     for (size_t k = 0; k < nch; k++) {
@@ -574,16 +582,22 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
                 const uint32_t e256 = g * 256u, bcol = e256 < (uint32_t)n ? (uint32_t)(key[idx[e256]] >> 24) : 0u;      // the group's first = smallest column
                 if (e % 256 == 0 && e < n) { const uint32_t wq = (g / TOKU) % W, tq = (g / (TOKU * W)) * TOKU + g % TOKU; gbase[desc[k].nacc + wq * gb_stride + tq] = bcol; }
                 const uint32_t off = e < n ? col - bcol : 0u;
-                if (off >= (1u << 17)) {
+                if (off >= (pack4 ? 1u << 13 : 1u << 17)) {
 #pragma omp atomic
                     gb_bad++;
                 }
                 cw = e < n ? (off & 0x1ffffu) | (row << 17) : 0u;
+                if (pack4) {
+                    const T tv = (T)v;
+                    const uint32_t code = (uint32_t)(std::lower_bound(dict.begin(), dict.end(), tv) - dict.begin());
+                    cw = e < n ? (off & 0x1fffu) | (row << 13) | (code << 28) : (uint32_t)(std::lower_bound(dict.begin(), dict.end(), (T)0) - dict.begin()) << 28;
+                }
             }
             reinterpret_cast<uint32_t *>(gp)[ln * 4 + j] = cw;
             if (tag) reinterpret_cast<uint16_t *>(gp + 1024)[ln * 4 + j] = (uint16_t)row;
             uint8_t *vp = gp + 1024 + (tag ? 512 : 0);
-            if (use_dict) { const T tv = (T)v; const uint32_t code = (uint32_t)(std::lower_bound(dict.begin(), dict.end(), tv) - dict.begin()); vp[ln * 4 + j] = (uint8_t)code; }
+            if (pack4) {}
+            else if (use_dict) { const T tv = (T)v; const uint32_t code = (uint32_t)(std::lower_bound(dict.begin(), dict.end(), tv) - dict.begin()); vp[ln * 4 + j] = (uint8_t)code; }
             else if (sizeof(T) == 8) reinterpret_cast<double *>(vp + (j >= 2 ? 1024 : 0))[ln * 2 + (j & 1)] = v;
             else reinterpret_cast<float *>(vp)[ln * 4 + j] = (float)v;
         }
@@ -655,9 +669,10 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
 #define L(DI, TG, DP, SH, NA) hipLaunchKernelGGL((sorted_spmv_kernel<T, DI, TG, DP, SH, NA>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size())
 #define L_NA(DI, TG, DP, SH) do { if (noadd) L(DI, TG, DP, SH, 1); else L(DI, TG, DP, SH, 0); } while (0)
 #define L_SH(DI, TG, DP) do { if (mode >= 1) L_NA(DI, TG, DP, true); else L_NA(DI, TG, DP, false); } while (0)
-#define L_TOK(DI, TG, U, GBM) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, false, false, U, GBM>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, GBM ? 17u : tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size(), d_rowslot, d_gbase, gb_stride)
+#define L_TOK(DI, TG, U, GBM) do { if (pack4) { if constexpr (DI && GBM) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, true, false, true, false, false, U, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, 13u, Reff, d_dict, (uint32_t)dict.size(), d_rowslot, d_gbase, gb_stride); } \
+    else hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, false, false, U, GBM>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, GBM ? 17u : tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size(), d_rowslot, d_gbase, gb_stride); } while (0)
 #define L_TOKU(DI, TG, GBM) do { if (TOKU == 1) L_TOK(DI, TG, 1, GBM); else if (TOKU == 2) L_TOK(DI, TG, 2, GBM); else if (TOKU == 4) L_TOK(DI, TG, 4, GBM); else L_TOK(DI, TG, 8, GBM); } while (0)
-#define L_RING(DI, TG) do { if (mode == 5) { if constexpr (!TG) L_TOKU(DI, false, true); } else if (mode == 4) L_TOKU(DI, TG, false); else if (mode == 3) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size(), d_rowslot); \
+#define L_RING(DI, TG) do { if (mode == 5 || mode == 6) { if constexpr (!TG) L_TOKU(DI, false, true); } else if (mode == 4) L_TOKU(DI, TG, false); else if (mode == 3) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size(), d_rowslot); \
         else if (mode == 2) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
         else if (mode == 1) hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, true>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); \
         else hipLaunchKernelGGL((sorted_spmv_ring_kernel<T, DI, TG, false>), dim3(nwg), dim3(64 * W), lds, 0, d_stream, d_desc, d_first, d_count, d_x, d_z, tag ? 32u : col_bits, Reff, d_dict, (uint32_t)dict.size()); } while (0)
