@@ -384,6 +384,8 @@ def _cpu_reference(nrows, ncols, rp, ci, logical, physical):
     chosen = sorted(by_c[pick["config"]], key=lambda x: x["ms_per_step"])
     best = chosen[len(chosen) // 2]
     return {"value": best["gflops"], "unit": "GFLOP/s", "cores": best["threads"], "kind": "reference",
+            # the reference's own configuration is 68 threads on one node (run_sample.sh:10); a container with a CPU quota runs as many threads as the quota leaves room for
+            "baseline_threads": best["threads"], "reference_threads": 68, "quota_limited": bool(quota and quota < 68),
             "sample": f"unmodified reference source built by oracle/Makefile (g++ -O3 -mavx512f -fopenmp, 4 intrinsic-spelling aliases in oracle/ref_shim.h), "
                       f"{iters} timed SpMV iterations of the full matrix per run, y zeroing outside the timer as the reference does (spmv.cpp:1026-1033); "
                       f"{repeats} runs per configuration ({'; '.join(c[0] for c in configs)}), memory: {placement}; "

@@ -669,8 +669,10 @@ __global__ __launch_bounds__(kLanes * kMaxWavesPerBlock) void spmv_seg_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if constexpr (PROF) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pc[3] = prof_now(); }
     if (!epi.out) {
-        // (y leaves past the caches -- nontemporal: nobody on the chip reads it before the caller does, and its 7 MB need not displace x or the window's
-        // lines in the L2s for the next SpMV: 21.05 -> 20.69 us on the web-Google shape, same box, three pairs of runs: profiles/r05_headline_nt_store.log)
+        // (y leaves past the caches -- nontemporal: on the headline's single image nobody on the chip reads it before the caller does, and its 7 MB need not
+        // displace x or the window's lines in the L2s for the next SpMV: 21.05 -> 20.69 us on the web-Google shape, same box, three pairs of runs:
+        // profiles/r05_headline_nt_store.log.  The same stores also write the carry slots that fixup_kernel reads next and, for column panels through this
+        // kernel, the partial sums that combine_kernel reads: correct across the kernel boundary, measured on the headline only)
         for (uint32_t i = lane; i < nri; i += kLanes) {
             const uint32_t dst = i == 0 ? d.z : i == nri - 1 ? d.w : d.x + i;
             __builtin_nontemporal_store(ystage[i], yext + dst);
@@ -845,11 +847,16 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG>::THREADS)) __attribute__(
     const uint32_t              bx = flip ? gridDim.x - 1u - blockIdx.x : blockIdx.x;          // (flip: the launch walks its workgroups backwards)
     uint32_t                    nchunks = nchunks_a, ystage_n = ystage_a, bidx = bx, col_base = col_base_a, xbytes = xbytes_a;
     if (multi) {          // column panels, one per XCD at a time (spmv_kernel); the panel's columns are relative to its first
-        const uint32_t  round = bx / nblocks_per_xcd, b = bx - round * nblocks_per_xcd;
+        // (a flipped launch walks the rounds and a panel's workgroups backwards but keeps every panel on the XCD of its slot -- the workgroup's own index
+        // modulo 8 --, whose L2 may still hold lines of its slice: reversing the whole index put panel s on XCD 7 - s every other SpMV)
+        uint32_t       round = blockIdx.x / nblocks_per_xcd;
+        const uint32_t b = blockIdx.x - round * nblocks_per_xcd;
+        uint32_t       idx = b >> 3;
+        if (flip) { round = gridDim.x / nblocks_per_xcd - 1u - round; idx = (nblocks_per_xcd >> 3) - 1u - idx; }
         const PanelArgs pa = multi[round * 8u + (b & 7u)];
         stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
         col_base = pa.col_base; xbytes = (pa.pad_col + 1u) * (uint32_t)sizeof(T);
-        bidx = b >> 3;
+        bidx = idx;
     }
     constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
     constexpr uint32_t VB = kColsBytes + (TAG ? kTagBytes : 0);
@@ -1153,12 +1160,15 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __at
     T *__restrict__              yext = yext_a;
     const uint32_t               bx = flip ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
     uint32_t                     nchunks = nchunks_a, ystage_n = ystage_a, bidx = bx, col_base = col_base_a, xbytes = xbytes_a, gang0 = 0;
-    if (multi) {
-        const uint32_t  round = bx / nblocks_per_xcd, b = bx - round * nblocks_per_xcd;
+    if (multi) {          // (a flipped launch keeps every panel on its slot's XCD: spmv_ilv_kernel)
+        uint32_t       round = blockIdx.x / nblocks_per_xcd;
+        const uint32_t b = blockIdx.x - round * nblocks_per_xcd;
+        uint32_t       idx = b >> 3;
+        if (flip) { round = gridDim.x / nblocks_per_xcd - 1u - round; idx = (nblocks_per_xcd >> 3) - 1u - idx; }
         const PanelArgs pa = multi[round * 8u + (b & 7u)];
         stream = pa.stream; desc = pa.desc; desc2 = pa.desc2; yext = static_cast<T *>(pa.yext); nchunks = pa.nchunks; ystage_n = pa.ystage;
         col_base = pa.col_base; xbytes = (pa.pad_col + 1u) * (uint32_t)sizeof(T); gbase = pa.gbase; gang0 = pa.gang0;
-        bidx = b >> 3;
+        bidx = idx;
     }
     constexpr uint32_t GB = (DICT ? kGroupBytesDict : sizeof(T) == 8 ? kGroupBytes64 : kGroupBytes32) + (TAG ? kTagBytes : 0);
     constexpr uint32_t VB = kColsBytes + (TAG ? kTagBytes : 0);
@@ -1706,7 +1716,9 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                 with_flag(img.tag16, [&](auto TG) { with_flag(use_win, [&](auto WI) { with_flag(loaders > 0, [&](auto LD) {
                     constexpr int kWin = decltype(WI)::value ? 1 : 0;
                     if constexpr (decltype(LD)::value && !decltype(WI)::value) return;          // (loaders only come with a window)
-                    else if (img.prof && !multi && !epi) {          // the same kernel with its phases' time stamps (CVR_DEBUG=phase_clocks)
+                    else if (img.prof && !multi && !epi && std::is_same<T, double>::value && kDict && decltype(LD)::value && !decltype(TG)::value) {
+                        // the same kernel with its phases' time stamps (CVR_DEBUG=phase_clocks): that one instantiation exists -- fp64, dictionary, loader
+                        // wavefronts, no 16-bit tags, the headline's --; every other layout runs its ordinary kernel (it used to launch nothing and leave y as it was)
                         if constexpr (std::is_same<T, double>::value && kDict && decltype(LD)::value && !decltype(TG)::value)
                             hipLaunchKernelGGL((spmv_seg_kernel<T, 1, 1, kWin, kDict, true, false, true>), dim3(grid), dim3(kLanes * (wpb + loaders)), lds, st, img.stream, img.desc, x, y,
                                                img.G, img.nchunks, per, swz, img.col_mask, (uint32_t)xb, img.win_base, img.win_elems, dict, img.ndict, img.ystage, img.desc2, img.col_bits, wpb, 0, multi,
