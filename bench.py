@@ -738,7 +738,7 @@ def main():
         torch.cuda.synchronize()
         if sharded:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()          # (one rank alone: nothing new to drain -- a synchronize of an idle device takes ~10 us, 2 % of a 20-step run of the headline)
 
     calib = None
     if comm is not None:         # in-order or overlapped gather: whichever this node runs faster (untimed, every rank agrees)
@@ -760,14 +760,20 @@ def main():
     sync()
     xcheck("warmup")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream); e1.record(stream)          # (a torch event is created at its first record: not inside the timed region)
+    sync()
     t0 = time.perf_counter()
     e0.record(stream)
+    t_a = time.perf_counter()
     step(args.steps)
+    t_b = time.perf_counter()
     e1.record(stream)
     while not e1.query():        # (poll: a blocking wait wakes this thread 10-20 us after the last kernel has ended, which is 5 % of a 20-step run of the headline)
         pass
+    t_c = time.perf_counter()
     sync()
     wall = time.perf_counter() - t0
+    timed_region_us = {"event_record": (t_a - t0) * 1e6, "launch_calls_returned": (t_b - t0) * 1e6, "last_kernel_done_seen": (t_c - t0) * 1e6, "after_synchronize": wall * 1e6}
     ev_s = e0.elapsed_time(e1) * 1e-3
     if sharded:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -978,6 +984,7 @@ def main():
             "image_bytes": int(info.image_bytes),
             "gbs_alg_whole_job": synth.b_alg(lrows if emu else nrows, ncols, job_nnz, vbytes) / per / 1e9,
             "event_ms_per_step_rank0": ev_s / args.steps * 1e3,
+            "timed_region_host_clock_us": timed_region_us,          # where the K steps' wall time goes beside K kernels: host time stamps from the start of the timed region
             "spmv_only_ms_max_over_ranks": kern_max_s * 1e3, "gflops_spmv_only_no_exchange": 2.0 * job_nnz / kern_max_s / 1e9,
             "rank0_spmv_only_ms": kern_s * 1e3, "rank0_allgather_only_ms": None if gather_s is None else gather_s * 1e3,
             "preprocess": {**_pre_times(info), "tune_s": A.tuning_s, "workload_build_s": build_s, "create_and_preprocess_wall_s": create_s,
