@@ -205,6 +205,29 @@ def test_gang_chunks_fall_back_to_tags_and_fp32_panels():
         A.close(); B.close()
 
 
+@pytest.mark.parametrize("debug", ["ilv_helpers=2,ilv_flip=1,ilv_stream_nt=1,ilv_ahead=8", "ilv_helpers=1,ilv_per_line=1", "combine_mul=8,combine_batch=9", "combine_mul=8,combine_batch=12",
+                                   "combine_batch=8", "combine_batch=16", "fuse"])
+@pytest.mark.parametrize("gang", [0, 1])
+def test_launch_parameter_paths_on_small_matrices(debug, gang, monkeypatch):
+    """The launch parameters that the rules switch on for large handles only -- helper wavefronts, the alternating sweep direction, non-temporal stream loads,
+    the combine pass's wide workgroups and batches, and the combine pass inside the gang kernel (CVR_DEBUG=fuse: measured, not adopted) -- forced onto a small
+    matrix of interleaved panels, with private chunks and with gang chunks: the same y, bit for bit, as without them, several SpMVs in a row (the sweep alternates)."""
+    n, nc, rp, ci, va = synth.livejournal_like(scale=0.02)
+    x = O.x_vec_fast(nc, "rand")
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, col_panels=16, interleave=1, gang=gang)
+    y0, _ = A.spmv(x)
+    _assert_close(y0, yref, absy, TOL64, ("plain launch", gang))
+    A.close()
+    monkeypatch.setenv("CVR_DEBUG", debug)
+    B = cvr_amd.CvrMatrix(n, nc, rp, ci, va, col_panels=16, interleave=1, gang=gang)
+    assert (B.info.gang > 0) == bool(gang)
+    for _ in range(4):
+        y, _ = B.spmv(x)
+        assert np.array_equal(y, y0), (debug, gang)
+    B.close()
+
+
 def test_interleaved_chunk_length_limits():
     """interleave = 1 with the longest chunks the converter sorts in one workgroup (S = 508: 32 pairs per thread; S = 576: 36) converts and
     runs, image and y the mirror's bits; one group more is refused by cvr_create with CVR_ERR_INVALID and a message, before any planning
@@ -806,7 +829,7 @@ def test_multi_device_shards_take_interleaved_panels():
     M.close()
 
 
-@pytest.mark.parametrize("kind", ["resident_phases", "plain", "panels", "hub", "interleaved", "interleaved_panels"])
+@pytest.mark.parametrize("kind", ["resident_phases", "plain", "panels", "hub", "interleaved", "interleaved_panels", "gang", "gang_tags"])
 def test_image_cache_roundtrip_and_staleness(tmp_path, kind):
     """cvr_save_image / cvr_load_image: the converted image from disk gives the same y bit for bit without analysis, planner or
     converter; a file written for another source file, other options or a damaged file is refused with a code"""
@@ -817,7 +840,8 @@ def test_image_cache_roundtrip_and_staleness(tmp_path, kind):
         nrows, ncols, rp, ci, va = synth.web_google_like(scale=0.05)
         opts = dict(resident_phases=dict(steps_per_chunk=12, waves_per_block=8, x_window=2048, col_phases=6), plain=dict(steps_per_chunk=16),
                     panels=dict(col_panels=3, steps_per_chunk=16), interleaved=dict(col_panels=1, interleave=1, steps_per_chunk=32, waves_per_block=4),
-                    interleaved_panels=dict(col_panels=8, interleave=1))[kind]
+                    interleaved_panels=dict(col_panels=8, interleave=1), gang=dict(col_panels=1, interleave=1, steps_per_chunk=32, waves_per_block=4, gang=1),
+                    gang_tags=dict(col_panels=1, interleave=1, steps_per_chunk=16, waves_per_block=2, gang=1, row_tags16=1))[kind]
     x = O.x_vec_fast(ncols, "rand").astype(va.dtype)
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, **opts)
     y, _ = A.spmv(x)
@@ -827,13 +851,14 @@ def test_image_cache_roundtrip_and_staleness(tmp_path, kind):
     B = cvr_amd.CvrMatrix.from_image(path, key, **opts)
     assert (B.info.nchunks, B.info.nshared, B.info.col_panels, B.info.col_phases, B.info.value_dict, B.info.hub_entries, B.info.interleave, B.info.spmv_launches) == \
            (A.info.nchunks, A.info.nshared, A.info.col_panels, A.info.col_phases, A.info.value_dict, A.info.hub_entries, A.info.interleave, A.info.spmv_launches)
-    assert A.info.interleave == (1 if kind.startswith("interleaved") else 0)
+    assert A.info.interleave == (1 if kind.startswith("interleaved") or kind.startswith("gang") else 0)
+    assert (A.info.gang, B.info.gang) == ((A.info.waves_per_block,) * 2 if kind != "interleaved" and A.info.interleave else (0, 0))
     assert B.info.plan_s == 0 and B.info.convert_s == 0
     y2, _ = B.spmv(x)
     assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))
-    if kind in ("resident_phases", "plain", "interleaved"):
+    if kind in ("resident_phases", "plain", "interleaved", "gang", "gang_tags"):
         ia, ib = A.export_image(), B.export_image()
-        for k in ("image", "desc", "target", "shared"):
+        for k in ("image", "desc", "target", "shared") + (("gbase", "desc2") if kind.startswith("gang") else ()):
             assert np.array_equal(ia[k], ib[k]), k
     B.close()
     A.close()

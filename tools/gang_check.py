@@ -1,4 +1,4 @@
-"""round 6: first parity check of gang chunks (cvr_options.gang) on the GPU -- y against the CSR oracle, bitwise reruns -- on the small cases of the
+"""tools/gang_check.py -- parity check of gang chunks (cvr_options.gang) on the GPU -- y against the CSR oracle, bitwise reruns -- on the small cases of the
 parity tests (forced: one image, four or two wavefronts per workgroup, with and without 16-bit tags, fp32, no dictionary) and on scaled stand-ins
 with the automatic layout"""
 import os
