@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __at
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint2 *__restrict__ desc2_a, const T *__restrict__ x, T *__restrict__ yext_a, int G_alloc,
     uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes_a, const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, uint32_t col_bits,
     uint32_t col_base_a, const PanelArgs *__restrict__ multi, uint32_t nw_compute, uint32_t help_ahead, uint32_t help_per_line, uint32_t flip, const uint32_t *__restrict__ gbase_a,
-    const FuseArgs *__restrict__ fuse, T *__restrict__ y_fused)
+    const FuseArgs *__restrict__ fuse, T *__restrict__ y_fused, uint32_t no_token)
 {
     using L = RingLayout<T, DICT, TAG, kGangCap>;
     constexpr int D = L::D, QN = 2 * D, XB = L::XB, QB = L::QB, K = (D - 1) * (4 + L::NS), U = kGangUnit;
@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __at
                     }
                     const uint32_t n = (t / (uint32_t)U) * nw + wv;     // this unit's number in the gang
                     asm volatile("" ::: "memory");
-                    while (__hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n) {}
+                    while (!no_token && __hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n) {}          // (no_token: CVR_DEBUG=gang_no_token -- the additions in whatever order, a timing experiment: y is no longer reproducible)
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int qq = 0; qq < U; qq++) {
@@ -1347,11 +1347,12 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __at
     ring_wait<0>();
     asm volatile("; CVR_RING_END" ::: "memory");
     if (nwt > nw && wv == 0u && lane == 0) prog[0] = 0x7ffffff0u;
+    if (no_token) __syncthreads();
     if (!own && !fuse) return;
     if (own) {
         // every unit's additions are in the accumulators once the token has counted them all
         const uint32_t all = Tw / (uint32_t)U * nw;
-        while (__hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != all) __builtin_amdgcn_s_sleep(1);
+        while (!no_token && __hip_atomic_load(tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != all) __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
         const T *const ystage = ystage_all + wv * ystage_n;
         if (fuse) {          // the partial sums of a panel are handed to whichever workgroup completes their block: past the caches
@@ -1703,7 +1704,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                         const uint32_t roomg = (uint32_t)LG::THREADS / kLanes, Hg = fuse ? 0u : roomg > wpb ? std::min<uint32_t>(roomg - wpb, img.ilv_helpers * wpb) : 0u;      // helpers: all on the gang's stream (none with the fused combine: its barriers are the whole workgroup's)
                         with_flag(img.ilv_stream_nt != 0, [&](auto SN) {
                             hipLaunchKernelGGL((spmv_gang_kernel<T, kDict, decltype(TG)::value, decltype(SN)::value>), dim3(grid), dim3(kLanes * (wpb + Hg)), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
-                                               img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi, wpb, img.ilv_ahead, img.ilv_per_line, img.flip_now, img.gbase, fuse, static_cast<T *>(y_fused));
+                                               img.col_mask, (uint32_t)xb, dict, img.ndict, img.ystage, img.col_bits, img.col_base, multi, wpb, img.ilv_ahead, img.ilv_per_line, img.flip_now, img.gbase, fuse, static_cast<T *>(y_fused), cvr::debug_env("gang_no_token") ? 1u : 0u);
                         });
                         return;
                     }
