@@ -62,7 +62,9 @@ int64_t plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt)
         const int64_t row_field = pp.gang ? (((int64_t)1 << cvr::kGangTagBits) / pp.wpb) - 1 : pp.ilv ? (pp.col_bits < 32 ? ((int64_t)1 << (32 - pp.col_bits)) - 1 : 0) : pp.col_bits < 31 ? ((int64_t)1 << (31 - pp.col_bits)) - 1 : 0;
         auto rows_for = [&](int64_t win) {
             const int64_t left = (int64_t)cvr::kLdsBytes - (cvr::kDictMax + win + 8) * vs;      // (no steal slots: spmv_seg_kernel; window + zero slot + the epilogue's arrival counter)
-            return std::min<int64_t>((left / pp.wpb / vs) & ~(int64_t)3, pp.ilv ? 2 * (int64_t)cvr::kYStageMax : cvr::kYStageMax);
+            int64_t rows = std::min<int64_t>((left / pp.wpb / vs) & ~(int64_t)3, pp.ilv ? 2 * (int64_t)cvr::kYStageMax : cvr::kYStageMax);
+            if (const char *e = cvr::debug_env("ilv_rows_cap")) if (pp.ilv) rows = std::min<int64_t>(rows, std::max<int64_t>(64, atoll(e) & ~(int64_t)3));      // (experiments: fewer accumulators per chunk -> several workgroups per CU)
+            return rows;
         };
         while (pp.win > 0 && rows_for(pp.win) < 512) pp.win = (pp.win - 1024 > 0 ? pp.win - 1024 : 0) & ~(int64_t)3;      // the window gives way
         // a chunk of S steps holds at most 64 S rows: no need for more accumulators than that (keeps the LDS small)
@@ -142,8 +144,9 @@ int interleave_steps_panels(const std::vector<int64_t> &nnz, const std::vector<i
     int           cb = 1;
     while (((int64_t)1 << cb) <= col_span) cb++;
     const int64_t field = cb < 32 ? ((int64_t)1 << (32 - cb)) : 0;
-    const int64_t rows = std::max<int64_t>(63, std::min<int64_t>(std::min<int64_t>((((int64_t)cvr::kLdsBytes / vs - cvr::kDictMax - 8) / wpb) & ~(int64_t)3, 2 * (int64_t)cvr::kYStageMax), field & ~(int64_t)3) - 1);
-    const double  cus = (double)opt.cus / opt.xcds;
+    int64_t       rows = std::max<int64_t>(63, std::min<int64_t>(std::min<int64_t>((((int64_t)cvr::kLdsBytes / vs - cvr::kDictMax - 8) / wpb) & ~(int64_t)3, 2 * (int64_t)cvr::kYStageMax), field & ~(int64_t)3) - 1);
+    if (const char *e = cvr::debug_env("ilv_rows_cap")) rows = std::min<int64_t>(rows, std::max<int64_t>(63, (atoll(e) & ~(int64_t)3) - 1));
+    const double  cus = (double)opt.cus / opt.xcds * (cvr::debug_env("ilv_wgs_per_cu") ? atof(cvr::debug_env("ilv_wgs_per_cu")) : 1.0);      // (experiments: several workgroups per CU fill a generation)
     const size_t  P = nnz.size();
     const double margin = cvr::debug_env("ilv_est_percent") ? atof(cvr::debug_env("ilv_est_percent")) / 100.0 : 1.02;      // (a test hook: an estimate that is too low makes cvr_create plan twice)
     auto workgroups = [&](int64_t S) {                 // of the XCD with the most
