@@ -799,19 +799,62 @@ template <int R> __device__ __forceinline__ uint32_t ring_get()
     asm volatile("v_mov_b32 %0, v[%1]" : "=v"(v) : "n"(R) : "memory");
     return v;
 }
+// ring registers as OPERANDS (spmv_gang_kernel): a copy per register and group was 17 of the ~110 vector instructions of a group
+template <int R> __device__ __forceinline__ uint32_t ring_and(uint32_t m)          // v[R] & m (m uniform)
+{
+    uint32_t v;
+    asm volatile("v_and_b32 %0, %1, v[%2]" : "=v"(v) : "s"(m), "n"(R) : "memory");
+    return v;
+}
+template <int R> __device__ __forceinline__ uint32_t ring_shr(uint32_t sh)         // v[R] >> sh (sh uniform)
+{
+    uint32_t v;
+    asm volatile("v_lshrrev_b32 %0, %1, v[%2]" : "=v"(v) : "s"(sh), "n"(R) : "memory");
+    return v;
+}
+template <int R, int OFF, int W> __device__ __forceinline__ uint32_t ring_bfe()    // (v[R] >> OFF) & (2^W - 1)
+{
+    uint32_t v;
+    asm volatile("v_bfe_u32 %0, v[%1], %2, %3" : "=v"(v) : "n"(R), "n"(OFF), "n"(W) : "memory");
+    return v;
+}
+template <int X> __device__ __forceinline__ double ring_prod(double a)             // the rounded product a * v[X : X + 1]
+{
+    double p;
+    asm volatile("v_fma_f64 %0, %1, v[%2:%3], 0" : "=v"(p) : "v"(a), "n"(X), "n"(X + 1) : "memory");
+    return p;
+}
+template <int X> __device__ __forceinline__ float ring_prod(float a)
+{
+    float p;
+    asm volatile("v_fma_f32 %0, %1, v[%2], 0" : "=v"(p) : "v"(a), "n"(X) : "memory");
+    return p;
+}
+template <int A, int X> __device__ __forceinline__ double ring_prod2(double)       // v[A : A + 1] * v[X : X + 1]
+{
+    double p;
+    asm volatile("v_fma_f64 %0, v[%1:%2], v[%3:%4], 0" : "=v"(p) : "n"(A), "n"(A + 1), "n"(X), "n"(X + 1) : "memory");
+    return p;
+}
+template <int A, int X> __device__ __forceinline__ float ring_prod2(float)
+{
+    float p;
+    asm volatile("v_fma_f32 %0, v[%1], v[%2], 0" : "=v"(p) : "n"(A), "n"(X) : "memory");
+    return p;
+}
 template <int N> __device__ __forceinline__ void ring_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f)
 {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
-template <typename T, bool DICT, bool TAG, int CAP = kRingCap> struct RingLayout {
+template <typename T, bool DICT, bool TAG, int CAP = kRingCap, int XSLOTS = 4> struct RingLayout {
     static constexpr int D = 4;                                                                     // groups of gathers in flight
     static constexpr int XSZ = sizeof(T) == 8 ? 8 : 4;                                              // registers of an x slot
     static constexpr int TOFF = 4, VOFF = 4 + (TAG ? 2 : 0);                                        // tags / values inside a Q slot
     static constexpr int QSZ = (VOFF + (DICT ? 1 : sizeof(T) == 8 ? 8 : 4) + 1) & ~1;               // registers of a Q slot (even: 64-bit pairs stay aligned)
     static constexpr int NS = 1 + (TAG ? 1 : 0) + (DICT ? 1 : sizeof(T) == 8 ? 2 : 1);              // stream loads per group
-    static constexpr int XB = CAP, QB = XB + D * XSZ, TOP = QB + 2 * D * QSZ;
+    static constexpr int XB = CAP, QB = XB + XSLOTS * XSZ, TOP = QB + 2 * D * QSZ;      // (XSLOTS = D: a group's gathers land in the slot the step has just copied out; 2 D: in a slot of their own)
     static_assert(TOP <= 256, "the ring does not fit 256 registers");
     // registers of the kernel (ring included) -> wavefronts a SIMD holds -> the largest workgroup: 4 chunks' computing wavefronts + their
     // helper wavefronts (below)
@@ -1143,13 +1186,13 @@ __device__ __forceinline__ void fused_combine(const FuseArgs *__restrict__ fzp, 
 
 constexpr int kGangCap = 72;          // the compiler's registers v0 .. v71 (the ilv kernel's 40 + a unit's products and tags); the ring above
 template <typename T, bool DICT, bool TAG, bool SNT>
-__global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __attribute__((amdgpu_num_vgpr(kGangCap))) void spmv_gang_kernel(
+__global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap, 8>::THREADS)) __attribute__((amdgpu_num_vgpr(kGangCap))) void spmv_gang_kernel(
     const uint8_t *__restrict__ stream_a, const uint4 *__restrict__ desc_a, const uint2 *__restrict__ desc2_a, const T *__restrict__ x, T *__restrict__ yext_a, int G_alloc,
     uint32_t nchunks_a, uint32_t nblocks_per_xcd, int swz, uint32_t cmask, uint32_t xbytes_a, const T *__restrict__ dict_g, uint32_t ndict, uint32_t ystage_a, uint32_t col_bits,
     uint32_t col_base_a, const PanelArgs *__restrict__ multi, uint32_t nw_compute, uint32_t help_ahead, uint32_t help_per_line, uint32_t flip, const uint32_t *__restrict__ gbase_a,
     const FuseArgs *__restrict__ fuse, T *__restrict__ y_fused, uint32_t no_token)
 {
-    using L = RingLayout<T, DICT, TAG, kGangCap>;
+    using L = RingLayout<T, DICT, TAG, kGangCap, 8>;          // (an x slot per ring position: a group's gathers never land in registers a step still reads)
     constexpr int D = L::D, QN = 2 * D, XB = L::XB, QB = L::QB, K = (D - 1) * (4 + L::NS), U = kGangUnit;
     static_assert(QN % U == 0, "a unit is whole ring slots");
     ring_claim<L::REGS>();
@@ -1273,8 +1316,8 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __at
     };
     auto gather_x = [&](auto qsc, auto xsc, uint32_t base) {
         constexpr int R = QB + decltype(qsc)::value * L::QSZ, X = XB + decltype(xsc)::value * L::XSZ;
-        const uint32_t o0 = ((ring_get<R>() & cmask) + base) * (uint32_t)sizeof(T), o1 = ((ring_get<R + 1>() & cmask) + base) * (uint32_t)sizeof(T),
-                       o2 = ((ring_get<R + 2>() & cmask) + base) * (uint32_t)sizeof(T), o3 = ((ring_get<R + 3>() & cmask) + base) * (uint32_t)sizeof(T);
+        const uint32_t o0 = (ring_and<R>(cmask) + base) * (uint32_t)sizeof(T), o1 = (ring_and<R + 1>(cmask) + base) * (uint32_t)sizeof(T),
+                       o2 = (ring_and<R + 2>(cmask) + base) * (uint32_t)sizeof(T), o3 = (ring_and<R + 3>(cmask) + base) * (uint32_t)sizeof(T);
         if constexpr (sizeof(T) == 8) { ring_ld64<X>(o0, rx, 0u); ring_ld64<X + 2>(o1, rx, 0u); ring_ld64<X + 4>(o2, rx, 0u); ring_ld64<X + 6>(o3, rx, 0u); }
         else { ring_ld32<X>(o0, rx, 0u); ring_ld32<X + 1>(o1, rx, 0u); ring_ld32<X + 2>(o2, rx, 0u); ring_ld32<X + 3>(o3, rx, 0u); }
     };
@@ -1293,31 +1336,30 @@ __global__ __launch_bounds__((RingLayout<T, DICT, TAG, kGangCap>::THREADS)) __at
     for (uint32_t tb = 0; tb < Tw; tb += QN) {
         bases_of(tb + (uint32_t)QN, bnext);
         static_for<0, QN>([&](auto ic) {
-            constexpr int  i = decltype(ic)::value, R = QB + i * L::QSZ, X = XB + (i % D) * L::XSZ, q = i % U;
+            constexpr int  i = decltype(ic)::value, R = QB + i * L::QSZ, X = XB + i * L::XSZ, q = i % U;
             const uint32_t t = tb + (uint32_t)i, g = gg(t);
             if (nwt > nw && wv == 0u && lane == 0) prog[0] = g;
             ring_wait<K>();
-            const uint32_t cw[4] = {ring_get<R>(), ring_get<R + 1>(), ring_get<R + 2>(), ring_get<R + 3>()};
-            uint32_t       tg[2] = {0, 0}, vv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if constexpr (TAG) { tg[0] = ring_get<R + L::TOFF>(); tg[1] = ring_get<R + L::TOFF + 1>(); }
-            if constexpr (DICT) vv[0] = ring_get<R + L::VOFF>();
-            else static_for<0, (sizeof(T) == 8 ? 8 : 4)>([&](auto jc) { vv[decltype(jc)::value] = ring_get<R + L::VOFF + decltype(jc)::value>(); });
-            static_for<0, L::XSZ>([&](auto jc) { xx[decltype(jc)::value] = ring_get<X + decltype(jc)::value>(); });
-            gather_x(std::integral_constant<int, (i + D) % QN>{}, std::integral_constant<int, i % D>{}, i < D ? bcur[(i + D) % QN] : bnext[(i + D) % QN]);
-            load_q(ic, gg(t + (uint32_t)QN));
-            // products and tags of this group into the unit's registers (a group behind the gang's last: zeros that are never added)
+            // the gathers of the group D ahead first (into their own x slot), then what this group's stream registers hold -- tags, codes or values --, then
+            // the stream of the group 2 D ahead into those registers, then the products; ring registers are operands of these instructions, not copied
+            gather_x(std::integral_constant<int, (i + D) % QN>{}, std::integral_constant<int, (i + D) % QN>{}, i < D ? bcur[(i + D) % QN] : bnext[(i + D) % QN]);
+            if (g < G) {          // (uniform)
+                if constexpr (TAG) { rwb[q][0] = ring_bfe<R + L::TOFF, 0, 16>(); rwb[q][1] = ring_bfe<R + L::TOFF, 16, 16>(); rwb[q][2] = ring_bfe<R + L::TOFF + 1, 0, 16>(); rwb[q][3] = ring_bfe<R + L::TOFF + 1, 16, 16>(); }
+                else { rwb[q][0] = ring_shr<R>(col_bits); rwb[q][1] = ring_shr<R + 1>(col_bits); rwb[q][2] = ring_shr<R + 2>(col_bits); rwb[q][3] = ring_shr<R + 3>(col_bits); }
+                if constexpr (DICT) {
+                    const uint32_t c0 = ring_bfe<R + L::VOFF, 0, 8>(), c1 = ring_bfe<R + L::VOFF, 8, 8>(), c2 = ring_bfe<R + L::VOFF, 16, 8>(), c3 = ring_bfe<R + L::VOFF, 24, 8>();
+                    load_q(ic, gg(t + (uint32_t)QN));
+                    const T a0 = dict[c0], a1 = dict[c1], a2 = dict[c2], a3 = dict[c3];
+                    prb[q][0] = ring_prod<X>(a0); prb[q][1] = ring_prod<X + (int)sizeof(T) / 4>(a1); prb[q][2] = ring_prod<X + 2 * (int)sizeof(T) / 4>(a2); prb[q][3] = ring_prod<X + 3 * (int)sizeof(T) / 4>(a3);
+                } else {
+                    constexpr int V = R + L::VOFF, W = (int)sizeof(T) / 4;
+                    prb[q][0] = ring_prod2<V, X>(T(0)); prb[q][1] = ring_prod2<V + W, X + W>(T(0)); prb[q][2] = ring_prod2<V + 2 * W, X + 2 * W>(T(0)); prb[q][3] = ring_prod2<V + 3 * W, X + 3 * W>(T(0));
+                    load_q(ic, gg(t + (uint32_t)QN));
+                }
+            } else {          // a group behind the gang's last: +0 into the first chunk's dump entry (its loads return zeros: nothing of them is used)
+                load_q(ic, gg(t + (uint32_t)QN));
 #pragma unroll
-            for (int j = 0; j < kGroupSteps; j++) {
-                T av, xv;
-                if constexpr (DICT) av = dict[(vv[0] >> (8 * j)) & 0xffu];
-                else if constexpr (sizeof(T) == 8) av = __builtin_bit_cast(double, (uint64_t)vv[2 * j] | ((uint64_t)vv[2 * j + 1] << 32));
-                else av = __builtin_bit_cast(float, vv[j]);
-                if constexpr (sizeof(T) == 8) xv = __builtin_bit_cast(double, (uint64_t)xx[2 * j] | ((uint64_t)xx[2 * j + 1] << 32));
-                else xv = __builtin_bit_cast(float, xx[j]);
-                if constexpr (TAG) rwb[q][j] = (tg[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-                else rwb[q][j] = cw[j] >> col_bits;
-                prb[q][j] = g < G ? fma_t(av, xv, T(0)) : T(0);          // (= the rounded product)
-                if (g >= G) rwb[q][j] = ystage_n - 1u;                  // (behind the gang's last group: +0 into the first chunk's dump entry)
+                for (int j = 0; j < kGroupSteps; j++) { prb[q][j] = T(0); rwb[q][j] = ystage_n - 1u; }
             }
             if constexpr (q == U - 1) {
                 if (t < Tw) {
@@ -1700,7 +1742,7 @@ hipError_t launch_spmv(const DeviceImage &img, const void *x_ext, void *y_ext, h
                     const uint32_t room = (uint32_t)L::THREADS / kLanes, hmax = room / wpb > 0 ? room / wpb - 1u : 0u;
                     const uint32_t H = std::min<uint32_t>(hmax, img.ilv_helpers);
                     if (img.gang) {          // gang chunks: the workgroup's wavefronts walk one common list (spmv_gang_kernel)
-                        using LG = RingLayout<T, kDict, decltype(TG)::value, kGangCap>;
+                        using LG = RingLayout<T, kDict, decltype(TG)::value, kGangCap, 8>;
                         const uint32_t roomg = (uint32_t)LG::THREADS / kLanes, Hg = fuse ? 0u : roomg > wpb ? std::min<uint32_t>(roomg - wpb, img.ilv_helpers * wpb) : 0u;      // helpers: all on the gang's stream (none with the fused combine: its barriers are the whole workgroup's)
                         with_flag(img.ilv_stream_nt != 0, [&](auto SN) {
                             hipLaunchKernelGGL((spmv_gang_kernel<T, kDict, decltype(TG)::value, decltype(SN)::value>), dim3(grid), dim3(kLanes * (wpb + Hg)), lds, st, img.stream, img.desc, img.desc2, x, y, img.G, img.nchunks, per, swz,
