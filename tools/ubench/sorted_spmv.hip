@@ -443,6 +443,28 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     uint32_t pw = (uint32_t)((A.ncols + P - 1) / P);
     pw = (pw + per_line - 1) / per_line * per_line;
     P = (uint32_t)((A.ncols + pw - 1) / pw);
+    // panel p = columns [pb[p], pb[p + 1]): equal widths, or (BALANCE=1) cut where the running count of non-zeros passes p / P of them, on
+    // 128-byte lines of x -- R-MAT's hot low columns then make a narrow first panel and every XCD gets the same number of non-zeros
+    std::vector<uint32_t> pb(P + 1);
+    for (uint32_t p = 0; p <= P; p++) pb[p] = (uint32_t)std::min<int64_t>((int64_t)p * pw, A.ncols);
+    if (getenv("BALANCE") && atoi(getenv("BALANCE"))) {
+        std::vector<int64_t> cc((size_t)A.ncols + 1, 0);
+        for (int64_t i = 0; i < A.nnz; i++) cc[(size_t)A.ci[i] + 1]++;
+        for (int64_t c = 0; c < A.ncols; c++) cc[(size_t)c + 1] += cc[(size_t)c];
+        for (uint32_t p = 1; p < P; p++) {
+            const int64_t want = A.nnz * (int64_t)p / P;
+            int64_t       c = std::lower_bound(cc.begin(), cc.end(), want) - cc.begin();
+            c = (c + per_line - 1) / per_line * per_line;
+            pb[p] = (uint32_t)std::min<int64_t>(std::max<int64_t>(c, (int64_t)pb[p - 1] + per_line), A.ncols);
+        }
+        pb[P] = (uint32_t)A.ncols;
+        pw = 0;
+        for (uint32_t p = 0; p < P; p++) pw = std::max(pw, pb[p + 1] - pb[p]);
+        printf("# nnz-balanced panels, first columns:");
+        for (uint32_t p = 0; p <= P; p++) printf(" %u", pb[p]);
+        printf("\n");
+    }
+    auto panel_of = [&](int32_t c) { return (int)(std::upper_bound(pb.begin() + 1, pb.end() - 1, (uint32_t)c) - (pb.begin() + 1)); };
     const uint32_t Reff = mode >= 1 ? R * W : R;          // (mode 3: rows per chunk; its accumulators -- rows + 3 per replicated row -- must fit the LDS)
     // ---- split into panels: per panel the sub-rows (row, begin) and the elements, in row order
     struct Panel { std::vector<int64_t> sp; std::vector<int32_t> srow; std::vector<int32_t> col; std::vector<double> val; };
@@ -452,16 +474,16 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
         std::vector<int64_t> pn(P, 0), ps(P, 0);
         for (int64_t r = 0; r < A.nrows; r++) {
             int lastp = -1;
-            for (int64_t j = A.rp[r]; j < A.rp[r + 1]; j++) { const int p = A.ci[j] / pw; pn[p]++; if (p != lastp) { ps[p]++; lastp = p; } }
+            for (int64_t j = A.rp[r]; j < A.rp[r + 1]; j++) { const int p = panel_of(A.ci[j]); pn[p]++; if (p != lastp) { ps[p]++; lastp = p; } }
             if (P == 1 && A.rp[r] == A.rp[r + 1]) ps[0]++;      // one panel: empty rows stay (they are written as 0 by their chunk)
         }
         for (uint32_t p = 0; p < P; p++) { pan[p].sp.reserve(ps[p] + 1); pan[p].srow.reserve(ps[p]); pan[p].col.reserve(pn[p]); pan[p].val.reserve(pn[p]); pan[p].sp.push_back(0); }
         for (int64_t r = 0; r < A.nrows; r++) {
             int lastp = -1;
             for (int64_t j = A.rp[r]; j < A.rp[r + 1]; j++) {
-                const int p = A.ci[j] / pw;
+                const int p = panel_of(A.ci[j]);
                 if (p != lastp) { if (lastp >= 0) pan[lastp].sp.push_back((int64_t)pan[lastp].col.size()); pan[p].srow.push_back((int32_t)r); lastp = p; }
-                pan[p].col.push_back(A.ci[j] - p * pw); pan[p].val.push_back(A.va[j]);
+                pan[p].col.push_back(A.ci[j] - (int32_t)pb[p]); pan[p].val.push_back(A.va[j]);
             }
             if (lastp >= 0) pan[lastp].sp.push_back((int64_t)pan[lastp].col.size());
             else if (P == 1) { pan[0].srow.push_back((int32_t)r); pan[0].sp.push_back((int64_t)pan[0].col.size()); }
@@ -514,7 +536,7 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
     for (size_t k = 0; k < nch; k++) {
         const auto &c = chunks[k];
         const uint32_t G = (uint32_t)((c.e1 - c.e0 + 255) / 256);
-        desc[k] = {soff, G, (uint32_t)(c.sub1 - c.sub0), zoff, (uint32_t)c.panel * pw, (uint32_t)std::min<int64_t>(pw, A.ncols - (int64_t)c.panel * pw), 0u, 0u};
+        desc[k] = {soff, G, (uint32_t)(c.sub1 - c.sub0), zoff, pb[c.panel], pb[c.panel + 1] - pb[c.panel], 0u, 0u};
         soff += (uint64_t)G * GB; zoff += (uint64_t)(c.sub1 - c.sub0);
     }
     std::vector<uint8_t> stream(soff + 8 * GB, 0);
@@ -706,7 +728,7 @@ static int run(const Csr &A, uint32_t R, uint32_t W, uint32_t Smax, uint32_t P, 
             for (int64_t sidx = c.sub0; sidx < c.sub1; sidx++) {
                 const int64_t b0 = std::max(pp.sp[sidx], c.e0), b1 = std::min(pp.sp[sidx + 1], c.e1);
                 T acc = 0;
-                for (int64_t e = b0; e < b1; e++) { const T pr = (T)pp.val[e] * x[(size_t)c.panel * pw + pp.col[e]]; acc += pr; }
+                for (int64_t e = b0; e < b1; e++) { const T pr = (T)pp.val[e] * x[(size_t)pb[c.panel] + pp.col[e]]; acc += pr; }
                 if (memcmp(&acc, &z[desc[k].zoff + (sidx - c.sub0)], sizeof(T)) != 0) nord++;
             }
         }
