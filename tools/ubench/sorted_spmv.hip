@@ -196,10 +196,15 @@ __global__ __launch_bounds__(1024) void sorted_spmv_kernel(const uint8_t *__rest
 // here (a compiler-issued one would be counted by the compiler without these).
 //   x ring : 4 slots of 8 registers  v[96 + 8 s ...]   (four gathered values of a group)
 //   Q ring : 8 slots of 16 registers v[128 + 16 s ...] ([0:3] column words, [4:5] tags, [6:13] values / [6] codes)
-#ifdef STREAM_NT
+#if defined(STREAM_POL)
+#define NTS STREAM_POL
+#elif defined(STREAM_NT)
 #define NTS " nt"
 #else
 #define NTS ""
+#endif
+#ifndef XPOL
+#define XPOL ""          // cache policy bits of the x gathers (-DXPOL='" sc1"': probe, profiles/r06_gather_policy_probe.log)
 #endif
 #ifndef TOK_SLEEP
 #define TOK_SLEEP 1
@@ -280,12 +285,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(96))) void sort
         const uint32_t gb__ = GBASE ? (gbv) : 0u;                                                                                       \
         c0_ = ((c0_ & cmask) + gb__) * (uint32_t)sizeof(T); c1_ = ((c1_ & cmask) + gb__) * (uint32_t)sizeof(T); c2_ = ((c2_ & cmask) + gb__) * (uint32_t)sizeof(T); c3_ = ((c3_ & cmask) + gb__) * (uint32_t)sizeof(T); \
         if constexpr (sizeof(T) == 8) {                                                                                                 \
-            asm volatile("buffer_load_dwordx2 " XR(xsl, 0, 2) ", %0, %4, 0 offen\n\tbuffer_load_dwordx2 " XR(xsl, 1, 2) ", %1, %4, 0 offen\n\t"         \
-                         "buffer_load_dwordx2 " XR(xsl, 2, 2) ", %2, %4, 0 offen\n\tbuffer_load_dwordx2 " XR(xsl, 3, 2) ", %3, %4, 0 offen"             \
+            asm volatile("buffer_load_dwordx2 " XR(xsl, 0, 2) ", %0, %4, 0 offen" XPOL "\n\tbuffer_load_dwordx2 " XR(xsl, 1, 2) ", %1, %4, 0 offen" XPOL "\n\t"         \
+                         "buffer_load_dwordx2 " XR(xsl, 2, 2) ", %2, %4, 0 offen" XPOL "\n\tbuffer_load_dwordx2 " XR(xsl, 3, 2) ", %3, %4, 0 offen" XPOL             \
                          ::"v"(c0_), "v"(c1_), "v"(c2_), "v"(c3_), "s"(rx) : RING_CLOBBER);                                              \
         } else {                                                                                                                        \
-            asm volatile("buffer_load_dword " XR1(xsl, 0) ", %0, %4, 0 offen\n\tbuffer_load_dword " XR1(xsl, 1) ", %1, %4, 0 offen\n\t"               \
-                         "buffer_load_dword " XR1(xsl, 2) ", %2, %4, 0 offen\n\tbuffer_load_dword " XR1(xsl, 3) ", %3, %4, 0 offen"                   \
+            asm volatile("buffer_load_dword " XR1(xsl, 0) ", %0, %4, 0 offen" XPOL "\n\tbuffer_load_dword " XR1(xsl, 1) ", %1, %4, 0 offen" XPOL "\n\t"               \
+                         "buffer_load_dword " XR1(xsl, 2) ", %2, %4, 0 offen" XPOL "\n\tbuffer_load_dword " XR1(xsl, 3) ", %3, %4, 0 offen" XPOL                   \
                          ::"v"(c0_), "v"(c1_), "v"(c2_), "v"(c3_), "s"(rx) : RING_CLOBBER);                                              \
         }                                                                                                                               \
     } while (0)
