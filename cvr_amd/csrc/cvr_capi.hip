@@ -23,19 +23,42 @@ int fail(int code, const char *fmt, ...)
 // y_ext = A x for the whole handle on `st`: one SpMV launch, or one per column panel followed by the combine
 hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
 {
+    // A buffer of the handle that every SpMV writes and reads (the panels' partial sums h->d_z; the hub table's compacted copy of x): a launch on ANOTHER stream
+    // must not start before the previous one is through with it.  The event is recorded when the stream CHANGES, on the stream of the launches before (behind
+    // their last pass), not after every SpMV: back-to-back launches on one stream are ordered by the stream, and an event per SpMV is a packet between the
+    // combine pass and the next panel kernel (profiles/r06_z_event.log).
+    static const bool event_per_spmv = cvr::debug_env("z_event_per_spmv");
+    auto enter = [&]() -> hipError_t {
+        if (!h->z_used) return hipSuccess;
+        if (event_per_spmv) return hipStreamWaitEvent(st, h->z_free, 0);
+        if (h->z_stream == st) return hipSuccess;
+        // (stream capture: a dependency between a capturing stream and one outside the capture cannot be expressed -- and recording on the legacy stream would
+        //  end the capture; the graph's replays are ordered by the stream they are launched into.  Two streams of ONE capture do get their edge.)
+        hipStreamCaptureStatus cap_now = hipStreamCaptureStatusNone, cap_before = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap_now);
+        if (hipStreamIsCapturing(h->z_stream, &cap_before) != hipSuccess) { (void)hipGetLastError(); cap_before = hipStreamCaptureStatusNone; }
+        if ((cap_now == hipStreamCaptureStatusActive) != (cap_before == hipStreamCaptureStatusActive)) return hipSuccess;
+        if (hipEventRecord(h->z_free, h->z_stream) != hipSuccess) {      // (that stream was destroyed meanwhile: whatever it still runs is waited for the blunt way)
+            (void)hipGetLastError();
+            return hipDeviceSynchronize();
+        }
+        return hipStreamWaitEvent(st, h->z_free, 0);
+    };
+    auto leave = [&]() -> hipError_t {
+        h->z_used = true;
+        h->z_stream = st;
+        return event_per_spmv ? hipEventRecord(h->z_free, st) : hipSuccess;
+    };
     if (!h->paneled()) {
         if (h->parts.empty()) return hipSuccess;
         if (h->parts[0].img.hub_n == 0) return cvr::launch_spmv(h->parts[0].img, x, y, st);
-        // the hub table's compacted copy of x is a buffer of the handle: launches on different streams are kept apart
-        if (h->z_used) { const hipError_t e = hipStreamWaitEvent(st, h->z_free, 0); if (e != hipSuccess) return e; }
-        const hipError_t e = cvr::launch_spmv(h->parts[0].img, x, y, st);
+        hipError_t e = enter();
         if (e != hipSuccess) return e;
-        h->z_used = true;
-        return hipEventRecord(h->z_free, st);
+        e = cvr::launch_spmv(h->parts[0].img, x, y, st);
+        if (e != hipSuccess) return e;
+        return leave();
     }
-    // the panels' partial sums share one buffer (h->d_z): a launch on another stream must not start before the combine pass of
-    // the previous one has read them
-    if (h->z_used) { const hipError_t e = hipStreamWaitEvent(st, h->z_free, 0); if (e != hipSuccess) return e; }
+    { const hipError_t e = enter(); if (e != hipSuccess) return e; }
     if (h->d_multi) {          // eight panels per launch, panel b & 7 on the XCD of the workgroups b
         cvr::DeviceImage shared = h->parts[0].img;
         shared.ystage = h->multi_ystage;
@@ -50,8 +73,7 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
                 if (e == hipSuccess) e = cvr::launch_fuse_patch(h->d_fuse_cut, h->fuse_ncut, h->d_fuse_panels, h->d_cpanels, h->d_fuse_nsub, (uint32_t)h->parts.size(), y, h->vsz == 4, st);
                 if (e != hipSuccess) return e;
             }
-            h->z_used = true;
-            return hipEventRecord(h->z_free, st);
+            return leave();
         }
         if (most) {      // all rounds in one grid
             const hipError_t e = cvr::launch_spmv(shared, x, nullptr, st, false, h->d_multi, most, (uint32_t)h->multi_chunks.size());
@@ -66,8 +88,7 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
     if (e != hipSuccess) return e;
     e = cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st, h->combine_batch, h->combine_mul);
     if (e != hipSuccess) return e;
-    h->z_used = true;
-    return hipEventRecord(h->z_free, st);
+    return leave();
 }
 
 // The fused combine (cvr_kernels.h: FuseArgs) for a handle whose panels all carry gang chunks and run one per XCD: the gangs' block ranges, the blocks'

@@ -170,6 +170,7 @@ struct cvr_handle {
     std::vector<hipEvent_t> events;
     hipEvent_t z_free = nullptr;         // column panels: recorded after the combine pass; the next SpMV (on any stream) waits for it
     bool       z_used = false;
+    hipStream_t z_stream = nullptr;      // ... the stream of the launches so far: the event is recorded there when a launch comes on another one (run_spmv)
     int        combine_mul = 1;          // blocks of kCombineRows rows per workgroup of the combine pass: 8 when the panels' partial sums are fewer than the rows (mostly empty rows)
     int        combine_batch = 4;        // panels whose loads share a round trip in the combine pass (CVR_DEBUG=combine_batch=8: experiment)
     uint32_t   spmv_calls = 0;           // SpMVs launched so far (interleaved panels with ilv_flip: every other one walks the workgroups backwards)

@@ -1415,16 +1415,20 @@ def test_panels_keep_their_slices_of_the_split_until_the_csr_is_released():
     assert abs(torch.cuda.mem_get_info()[0] - free0) < (8 << 20)
 
 
-def test_spmv_launches_can_be_captured_in_a_hip_graph():
-    """cvr_spmv_device makes no synchronising call: a caller can capture it (here with torch.cuda.graph) and replay"""
+@pytest.mark.parametrize("kw", [{}, {"steps_per_chunk": 16, "col_panels": 4}, {"steps_per_chunk": 16, "col_panels": 4, "interleave": 1, "waves_per_block": 4, "gang": 1}])
+def test_spmv_launches_can_be_captured_in_a_hip_graph(kw):
+    """cvr_spmv_device makes no synchronising call: a caller can capture it (here with torch.cuda.graph) and replay.  With column panels the handle has been used
+    on the default stream before: the capture on a side stream must neither fail nor touch that stream (run_spmv: the partial sums' event and stream capture)"""
     import torch
     nrows, ncols, rp, ci, va = CASES["power_law_3000"]
-    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va)
+    A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, **kw)
+    assert A.info.col_panels == kw.get("col_panels", 1)
     dev = torch.device("cuda", 0)
     xh = O.x_vec_fast(ncols)
     x = torch.zeros(A.info.x_elems, dtype=torch.float64, device=dev)
     x[:ncols] = torch.from_numpy(xh).to(dev)
     y = torch.full((A.info.yext_elems,), float("nan"), dtype=torch.float64, device=dev)
+    A.spmv_device(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)          # (an ordinary launch first)
     g = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
@@ -1440,6 +1444,16 @@ def test_spmv_launches_can_be_captured_in_a_hip_graph():
     g.replay()
     torch.cuda.synchronize()
     _assert_close(y[:nrows].cpu().numpy(), 2.0 * yref, 2.0 * absy, TOL64, "graph replay, new x")
+    y.fill_(float("nan"))                               # and ordinary launches again, on the default stream and on a third one
+    A.spmv_device(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    _assert_close(y[:nrows].cpu().numpy(), 2.0 * yref, 2.0 * absy, TOL64, "after the graph")
+    third = torch.cuda.Stream(device=dev)
+    y.fill_(float("nan"))
+    torch.cuda.synchronize()
+    A.spmv_device(x.data_ptr(), y.data_ptr(), third.cuda_stream)
+    torch.cuda.synchronize()
+    _assert_close(y[:nrows].cpu().numpy(), 2.0 * yref, 2.0 * absy, TOL64, "after the graph, third stream")
     A.close()
 
 
@@ -1744,7 +1758,7 @@ def test_amortisation_report_small():
 
 def test_panelled_handle_on_two_streams_keeps_its_launches_apart():
     """a handle with column panels keeps the panels' partial sums in one buffer: launches on two streams with different x must
-    not mix them (the library orders them with an event after the combine pass)"""
+    not mix them (the library orders them with an event recorded on the stream it leaves, when the stream changes: run_spmv)"""
     torch = pytest.importorskip("torch")
     nrows, ncols, rp, ci, va = synth.livejournal_like(scale=0.05)
     A = cvr_amd.CvrMatrix(nrows, ncols, rp, ci, va, steps_per_chunk=16, col_panels=4)
