@@ -130,12 +130,16 @@ def measure_other_workload(kind, dev, steps=60, warmup=6):
     x = torch.zeros(info.x_elems, dtype=tdt, device=dev)
     x[:nc] = D.x_rand(nc, device=dev, dtype=tdt)
     y = torch.zeros(max(info.yext_elems, 1), dtype=tdt, device=dev)
-    sptr = torch.cuda.current_stream(dev).cuda_stream
+    # a stream of its own, as the headline has: launches on the legacy default stream are ordered against every other blocking stream of the process, which
+    # costs the two-launch shapes ~2 us per launch (soc-LiveJournal1 shape 209.4 on the default stream, 205.8 on its own: profiles/r06_final_numbers.log)
+    side = torch.cuda.Stream(device=dev)
+    sptr = side.cuda_stream
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     A.spmv_device(x.data_ptr(), y.data_ptr(), sptr, repeat=warmup)
-    a.record()
+    a.record(side)
     A.spmv_device(x.data_ptr(), y.data_ptr(), sptr, repeat=steps)
-    b.record()
+    b.record(side)
     torch.cuda.synchronize()
     per = a.elapsed_time(b) * 1e-3 / steps
     # the same matrix with full values in the stream (value_dict = 0): what the format does without the compression of the 13 distinct values the
@@ -145,11 +149,12 @@ def measure_other_workload(kind, dev, steps=60, warmup=6):
         try:
             B = cvr_amd.CvrMatrix.from_device(n, nc, rp_t.data_ptr(), ci_t.data_ptr(), va_t.data_ptr(), is_f32=f32, device=dev.index or 0, value_dict=0)
             yb = torch.zeros(max(B.info.yext_elems, 1), dtype=tdt, device=dev)
+            torch.cuda.synchronize()
             B.spmv_device(x.data_ptr(), yb.data_ptr(), sptr, repeat=warmup)
             a2, b2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a2.record()
+            a2.record(side)
             B.spmv_device(x.data_ptr(), yb.data_ptr(), sptr, repeat=max(steps // 2, 10))
-            b2.record()
+            b2.record(side)
             torch.cuda.synchronize()
             per_nodict = a2.elapsed_time(b2) * 1e-3 / max(steps // 2, 10)
             B.close()
