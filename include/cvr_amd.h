@@ -207,7 +207,9 @@ int cvr_spmv(cvr_handle *h, const void *x_host, void *y_host, int iters, cvr_tim
  * scratch: carry slots of rows cut over chunks).  Rows without
  * non-zeros are written as 0 on every call; y needs no zeroing.  The call makes the handle's device current.  A handle with
  * column panels (info.col_panels > 1) keeps the panels' partial sums in one buffer of its own: launches of such a handle on
- * different streams are ordered one after the other by the library (an event after the combine pass), so they do not overlap. */
+ * different streams are ordered one after the other by the library (an event recorded on the stream it leaves when a launch
+ * comes on another one; the stream of the earlier launches must still exist then, or the library waits for the device), so they
+ * do not overlap.  Launches on one stream are ordered by that stream alone. */
 int cvr_spmv_device(cvr_handle *h, const void *x_dev, void *y_dev, void *stream);
 /* the same, `n` launches back to back (the Ntimes loop of spmv.cpp:1024 without a host round trip per launch) */
 int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *stream, int n);
