@@ -86,9 +86,26 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
         }
     hipError_t e = cvr::launch_fixup_multi(h->d_fixparts, (uint32_t)h->parts.size(), h->max_nshared, h->vsz == 4, st);
     if (e != hipSuccess) return e;
-    e = cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st, h->combine_batch, h->combine_mul);
+    e = cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st, h->combine_batch, h->combine_mul, h->d_cbits);
     if (e != hipSuccess) return e;
     return leave();
+}
+
+int setup_combine_bits(cvr_handle *h, int64_t nsub)
+{
+    if (!h->paneled() || !h->d_cpanels || !h->d_block_off || h->info.nrows <= 0 || h->d_cbits) return CVR_OK;
+    const size_t   P = h->parts.size();
+    const uint32_t nrows = (uint32_t)h->info.nrows, nblocks = (nrows + cvr::kCombineRows - 1) / cvr::kCombineRows;
+    // The bitmap form issues a load instruction per (row, panel) whether the sum exists or not: it pays where most of them do -- half or more of the (row, panel)
+    // pairs filled.  com-Orkut shape (6.5 sums per row in 8 panels: 81 %) 574 -> 566 us; soc-LiveJournal1 shape (2.4 in 16: 15 %) 206 -> 231, wiki-Talk (0.11 in 8)
+    // 32.7 -> 39.4: those keep their row numbers (profiles/r06_combine_bitmap.log)
+    bool on = P <= 16 && nsub * 2 >= (int64_t)P * (int64_t)nrows;
+    if (const char *e = cvr::debug_env("combine_bits")) on = atoi(e) != 0 && P <= 16;
+    if (!on) return CVR_OK;
+    if (hipMalloc(&h->d_cbits, sizeof(uint32_t) * 32 * (size_t)nblocks * P) != hipSuccess) { (void)hipGetLastError(); h->d_cbits = nullptr; return CVR_OK; }      // (no memory for it: the row numbers do)
+    if (cvr::launch_combine_bits_build(h->d_cpanels, (uint32_t)P, h->d_block_off, nrows, h->d_cbits, h->stream) != hipSuccess) return CVR_ERR_HIP;
+    h->info.image_bytes += (int64_t)(sizeof(uint32_t) * 32 * (size_t)nblocks * P);
+    return CVR_OK;
 }
 
 // The fused combine (cvr_kernels.h: FuseArgs) for a handle whose panels all carry gang chunks and run one per XCD: the gangs' block ranges, the blocks'
@@ -945,6 +962,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }
         CREATE_TRY(hipMalloc(&h->d_fixparts, sizeof(cvr::FixPart) * (size_t)P));
         CREATE_TRY(hipMemcpyAsync(h->d_fixparts, fp.data(), sizeof(cvr::FixPart) * (size_t)P, hipMemcpyHostToDevice, h->stream));
+        if (setup_combine_bits(h, nsub) != CVR_OK) { cvr_destroy(h); return CVR_ERR_HIP; }
         CREATE_TRY(hipStreamSynchronize(h->stream));
         clk.lap("  tables synchronised");
         in.yext_elems = nrows + 1;
@@ -1253,7 +1271,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->d_small) (void)hipFree(h->d_small);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->z_free) (void)hipEventDestroy(h->z_free);
-    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_rows16, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, (void *)h->d_multi, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_rows16, (void *)h->d_cbits, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, (void *)h->d_multi, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
     release_stream(h->device, h->stream);
     delete h;
     return CVR_OK;

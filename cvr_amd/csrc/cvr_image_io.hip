@@ -289,6 +289,11 @@ int cvr_load_image(cvr_handle **out, const char *path, const cvr_source_key *exp
         LOAD_TRY(hipMalloc(&h->d_fixparts, sizeof(cvr::FixPart) * nparts));
         LOAD_TRY(hipMemcpy(h->d_cpanels, cps.data(), sizeof(cvr::CombinePanel) * nparts, hipMemcpyHostToDevice));
         LOAD_TRY(hipMemcpy(h->d_fixparts, fp.data(), sizeof(cvr::FixPart) * nparts, hipMemcpyHostToDevice));
+        {          // the combine pass's bitmap is rebuilt from the row numbers (its bytes are in the saved image_bytes already)
+            const int64_t bytes = h->info.image_bytes;
+            if (setup_combine_bits(h, nsub_all) != CVR_OK) r.ok = false;
+            h->info.image_bytes = bytes;
+        }
         if (has_multi) {
             const size_t per_round = 8;
             std::vector<cvr::PanelArgs> pa((size_t)nrounds * 8, cvr::PanelArgs{nullptr, nullptr, nullptr, nullptr, 0u, 0u, nullptr, 0u, 0u, nullptr, 0u, 0u});

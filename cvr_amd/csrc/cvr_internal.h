@@ -142,6 +142,7 @@ struct cvr_handle {
     // where each block of kCombineRows rows starts in every panel (combine_kernel)
     void     *d_z = nullptr;
     uint32_t *d_rows = nullptr, *d_block_off = nullptr;
+    uint32_t *d_cbits = nullptr;           // the rows that have a partial sum, a bit per (row, panel): the combine pass's bitmap form (setup_combine_bits; null: row numbers)
     uint16_t *d_rows16 = nullptr;          // the low halves of d_rows: what the combine pass reads (2 instead of 4 bytes per (row, panel) pair)
     int32_t  *split_ci = nullptr;          // the device split's column indices and values, panel after panel: the parts' CSR arrays are slices of these
     void     *split_va = nullptr;          // (freed with the parts' CSR: after the conversion, or with the handle when it keeps its CSR)
@@ -200,7 +201,10 @@ namespace cvrh {
 struct Chip { int cus = 256, xcds = 8; };
 Chip       chip_of(int device);
 hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st);
-int        setup_fuse(cvr_handle *h);                    // the fused combine's tables, for handles whose panels all carry gang chunks and run one per XCD (after d_multi)
+int        setup_fuse(cvr_handle *h);
+// The combine pass's bitmap (cvr_kernels.h: launch_combine_bits_build) for a panelled handle with at most 16 panels and half or more of its (row, panel) pairs filled:
+// allocated and filled on the handle's stream behind the combine tables.  nsub = the handle's partial sums (all panels).  CVR_DEBUG=combine_bits=0|1 overrides the rule.
+int        setup_combine_bits(cvr_handle *h, int64_t nsub);                    // the fused combine's tables, for handles whose panels all carry gang chunks and run one per XCD (after d_multi)
 void       ilv_runtime_settings(cvr_handle *h);          // helper wavefronts / sweep direction of interleaved images (launch parameters)      // y_ext = A x for the whole handle on `st`
 IOpt       make_iopt(const cvr_options *in);
 int        check_csr(const cvr_csr_view *c, bool columns_on_host = true);

@@ -246,7 +246,10 @@ hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t ma
 constexpr int kCombineRows = 1024;
 struct CombinePanel { const void *z; const uint16_t *rows; };          // rows: the LOW 16 BITS of the sub-rows' row numbers (a workgroup of the pass owns at most 8 192 consecutive rows: the difference to its first row, modulo 65 536, is the row's place there)
 hipError_t launch_narrow_rows(const uint32_t *rows, size_t n, uint16_t *rows16, hipStream_t st);
-hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch = 4, int mul = 1);      // batch: panels whose loads share a round trip (4 or 8); mul: blocks of kCombineRows rows per workgroup (1 or 8)
+hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch = 4, int mul = 1,
+                          const uint32_t *bits = nullptr);      // bits (mul = 1, <= 16 panels): the bitmap form -- a thread owns four rows, no row numbers read (combine_bits_kernel)
+// bits[(p * nblocks + b) * 32 + w]: the rows b * kCombineRows + 32 w .. that have a partial sum in panel p (nblocks = ceil(nrows / kCombineRows)); asynchronous on st
+hipError_t launch_combine_bits_build(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, uint32_t nrows, uint32_t *bits, hipStream_t st);      // batch: panels whose loads share a round trip (4 or 8); mul: blocks of kCombineRows rows per workgroup (1 or 8)
 
 // 16-B-per-lane streaming copy (roofline calibration)
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t st);

@@ -1508,6 +1508,82 @@ __global__ __launch_bounds__(NT) void combine_kernel(const CombinePanel *__restr
     else for (uint32_t i = threadIdx.x; i < kRows && r0 + i < nrows; i += blockDim.x) __builtin_nontemporal_store(acc[i], &y[r0 + i]);
 }
 
+// The same pass over a BITMAP of the rows that have a partial sum in a panel (bits[(p * nblocks + b) * 32 + w]: rows b * 1 024 + 32 w ..), for matrices where
+// most (row, panel) pairs hold a sum (setup_combine_bits: half or more) -- the bitmap (P bits per row) then replaces 2 bytes of row number per sum.
+// A thread OWNS four rows of the block and adds their sums in registers, panel after panel: a row's sum in panel p stands at
+// block_off[p][b] + (set bits of the panel below the row's), so there is nothing to scatter -- no LDS accumulators, no barrier between panels, and the loads of
+// all panels of two rows are in flight together.  The additions are combine_kernel's (panel order, absent sums skipped): the same bits.
+// com-Orkut shape: 40 MB of row numbers -> 3 MB of bitmap beside 160 MB of sums and 25 MB of y, 41.6 -> 33 us (profiles/r06_combine_bitmap.log); a
+// load instruction is issued per (row, panel) whether the sum exists or not, which is why sparsely filled shapes keep the row numbers.
+template <typename T, int PMAX>
+__global__ __launch_bounds__(256) void combine_bits_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off, uint32_t nblocks,
+                                                           const uint32_t *__restrict__ bits, T *__restrict__ y, uint32_t nrows)
+{
+    __shared__ uint2    s_bp[PMAX][32];          // .x = the word's bits, .y = set bits of the panel in the block's words before it
+    __shared__ uint32_t s_lo[PMAX];
+    __shared__ const T *s_z[PMAX];
+    const uint32_t b = blockIdx.x, r0 = b * (uint32_t)kCombineRows, tid = threadIdx.x;
+    if (tid < npanels) { s_z[tid] = static_cast<const T *>(panels[tid].z); s_lo[tid] = block_off[(size_t)tid * (nblocks + 1) + b]; }
+    for (uint32_t idx = tid; idx < npanels * 32u; idx += 256u) {          // (a half wavefront per panel)
+        const uint32_t p = idx >> 5, w = idx & 31u;
+        const uint32_t v = bits[((size_t)p * nblocks + b) * 32u + w];
+        uint32_t       c = (uint32_t)__popc(v);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { const uint32_t t = __shfl_up(c, o, 32); if (w >= (uint32_t)o) c += t; }
+        s_bp[p][w] = uint2{v, c - (uint32_t)__popc(v)};
+    }
+    __syncthreads();
+    const T *zp[PMAX];
+    uint32_t lo[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; p++) {
+        const bool     in = (uint32_t)p < npanels;
+        const uint64_t a = reinterpret_cast<uint64_t>(in ? s_z[p] : nullptr);
+        zp[p] = reinterpret_cast<const T *>((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32));
+        lo[p] = __builtin_amdgcn_readfirstlane(in ? s_lo[p] : 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < kCombineRows / 256; k += 2) {
+        const uint32_t iA = tid + (uint32_t)k * 256u, iB = iA + 256u, wA = iA >> 5, wB = iB >> 5, mA = 1u << (iA & 31u), mB = 1u << (iB & 31u);
+        T        vA[PMAX], vB[PMAX];
+        uint32_t hasA = 0, hasB = 0;
+#pragma unroll
+        for (int p = 0; p < PMAX; p++) {
+            vA[p] = T(0); vB[p] = T(0);
+            if ((uint32_t)p < npanels) {          // (uniform)
+                const uint2 a = s_bp[p][wA], c = s_bp[p][wB];
+                if (a.x & mA) { hasA |= 1u << p; vA[p] = __builtin_nontemporal_load(zp[p] + (lo[p] + a.y + (uint32_t)__popc(a.x & (mA - 1u)))); }
+                if (c.x & mB) { hasB |= 1u << p; vB[p] = __builtin_nontemporal_load(zp[p] + (lo[p] + c.y + (uint32_t)__popc(c.x & (mB - 1u)))); }
+            }
+        }
+        T accA = T(0), accB = T(0);
+#pragma unroll
+        for (int p = 0; p < PMAX; p++) {
+            if (hasA & (1u << p)) accA += vA[p];
+            if (hasB & (1u << p)) accB += vB[p];
+        }
+        if (r0 + iA < nrows) __builtin_nontemporal_store(accA, &y[r0 + iA]);
+        if (r0 + iB < nrows) __builtin_nontemporal_store(accB, &y[r0 + iB]);
+    }
+}
+
+// the bitmap of one (block, panel): the low 16 bits of its sums' row numbers -> bits, through LDS
+__global__ __launch_bounds__(128) void combine_bits_build_kernel(const CombinePanel *__restrict__ panels, const uint32_t *__restrict__ block_off, uint32_t nblocks, uint32_t *__restrict__ bits)
+{
+    __shared__ uint32_t s[32];
+    const uint32_t b = blockIdx.x, p = blockIdx.y, r0 = b * (uint32_t)kCombineRows;
+    if (threadIdx.x < 32u) s[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t  lo = block_off[(size_t)p * (nblocks + 1) + b], hi = block_off[(size_t)p * (nblocks + 1) + b + 1];
+    const uint16_t *rows = panels[p].rows;
+    for (uint32_t u = lo + threadIdx.x; u < hi; u += blockDim.x) {
+        const uint32_t i = ((uint32_t)rows[u] - r0) & 0xffffu;
+        atomicOr(&s[(i >> 5) & 31u], 1u << (i & 31u));
+    }
+    __syncthreads();
+    if (threadIdx.x < 32u) bits[((size_t)p * nblocks + b) * 32u + threadIdx.x] = s[threadIdx.x];
+}
+
 // plain streaming copy: the achievable-HBM-rate yardstick beside the 8 TB/s nominal peak.  Four independent
 // 16-byte loads per lane in flight, block-contiguous tiles.
 __global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n)
@@ -1552,10 +1628,28 @@ hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t ma
     return hipGetLastError();
 }
 
-hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch, int mul)
+hipError_t launch_combine_bits_build(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, uint32_t nrows, uint32_t *bits, hipStream_t st)
+{
+    if (nrows == 0 || npanels == 0) return hipSuccess;
+    const uint32_t nblocks = (nrows + kCombineRows - 1) / kCombineRows;
+    hipLaunchKernelGGL(combine_bits_build_kernel, dim3(nblocks, npanels), dim3(128), 0, st, panels, block_off, nblocks, bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch, int mul, const uint32_t *bits)
 {
     if (nrows == 0) return hipSuccess;
     const uint32_t nblocks = (nrows + kCombineRows - 1) / kCombineRows;
+    if (bits && mul == 1 && npanels <= 16u) {          // the bitmap form (combine_bits_kernel)
+        if (npanels <= 8u) {
+            if (f32) hipLaunchKernelGGL((combine_bits_kernel<float, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<float *>(y), nrows);
+            else hipLaunchKernelGGL((combine_bits_kernel<double, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<double *>(y), nrows);
+        } else {
+            if (f32) hipLaunchKernelGGL((combine_bits_kernel<float, 16>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<float *>(y), nrows);
+            else hipLaunchKernelGGL((combine_bits_kernel<double, 16>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<double *>(y), nrows);
+        }
+        return hipGetLastError();
+    }
     const uint32_t plain = (cvr::debug_env("combine_plain_store") ? 1u : 0u) | (cvr::debug_env("combine_plain_loads") ? 2u : 0u);
     auto go = [&](auto real) {
         using T = decltype(real);

@@ -206,7 +206,7 @@ def test_gang_chunks_fall_back_to_tags_and_fp32_panels():
 
 
 @pytest.mark.parametrize("debug", ["ilv_helpers=2,ilv_flip=1,ilv_stream_nt=1,ilv_ahead=8", "ilv_helpers=1,ilv_per_line=1", "combine_mul=8,combine_batch=9", "combine_mul=8,combine_batch=12",
-                                   "combine_batch=8", "combine_batch=16", "fuse"])
+                                   "combine_batch=8", "combine_batch=16", "fuse", "combine_bits=0", "combine_bits=1"])
 @pytest.mark.parametrize("gang", [0, 1])
 def test_launch_parameter_paths_on_small_matrices(debug, gang, monkeypatch):
     """The launch parameters that the rules switch on for large handles only -- helper wavefronts, the alternating sweep direction, non-temporal stream loads,
@@ -226,6 +226,33 @@ def test_launch_parameter_paths_on_small_matrices(debug, gang, monkeypatch):
         y, _ = B.spmv(x)
         assert np.array_equal(y, y0), (debug, gang)
     B.close()
+
+
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("kw", [{"col_panels": 8, "steps_per_chunk": 16}, {"col_panels": 16, "interleave": 1, "gang": 1}, {"col_panels": 3, "steps_per_chunk": 8},
+                                {"col_panels": 16, "steps_per_chunk": 4}])
+def test_combine_bitmap_form_is_the_row_number_form(kw, f32, monkeypatch):
+    """The combine pass over a bitmap of the rows that have a partial sum in a panel (combine_bits_kernel: a thread owns four rows and adds their sums in panel
+    order in registers) writes the bits of the pass over row numbers (combine_kernel: LDS accumulators, a barrier per panel) -- plain and interleaved panels,
+    8 / 16 / an odd number of panels, fp32, rows cut over chunks (short chunks), a row count that is no multiple of the pass's 1 024-row blocks, empty rows."""
+    n, nc, rp, ci, va = synth.livejournal_like(scale=0.021)
+    va = (va.astype(np.float32) if f32 else va)
+    x = O.x_vec_fast(nc, "rand").astype(np.float32 if f32 else np.float64)
+    ys = []
+    for form in ("0", "1"):
+        monkeypatch.setenv("CVR_DEBUG", "combine_bits=" + form)
+        A = cvr_amd.CvrMatrix(n, nc, rp, ci, va, **kw)
+        assert A.info.col_panels == kw["col_panels"]
+        if kw.get("steps_per_chunk") == 4:
+            assert A.info.nshared > 0          # (rows cut over chunks: the fix-up launch runs in front of either form)
+        y, _ = A.spmv(x)
+        y2, _ = A.spmv(x)
+        assert np.array_equal(y, y2)
+        ys.append(y)
+        A.close()
+    assert np.array_equal(ys[0].view(np.uint8), ys[1].view(np.uint8)), kw
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    _assert_close(ys[1], yref, absy, TOL32 if f32 else TOL64, ("bitmap combine", kw, f32))
 
 
 def test_interleaved_chunk_length_limits():
