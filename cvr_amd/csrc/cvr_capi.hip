@@ -84,9 +84,12 @@ hipError_t run_spmv(cvr_handle *h, const void *x, void *y, hipStream_t st)
             hipError_t e = cvr::launch_spmv(p.img, x, static_cast<uint8_t *>(h->d_z) + (size_t)p.zoff * h->vsz, st, false);
             if (e != hipSuccess) return e;
         }
-    hipError_t e = cvr::launch_fixup_multi(h->d_fixparts, (uint32_t)h->parts.size(), h->max_nshared, h->vsz == 4, st);
+    // rows cut over chunks: their carries are summed by a launch in front of the combine pass -- or, a handful of them and the pass in its bitmap form, inside it
+    const bool fold = h->d_cbits && h->d_cut && h->ncut_fold && h->combine_mul == 1 && h->parts.size() <= 16;
+    hipError_t e = fold ? hipSuccess : cvr::launch_fixup_multi(h->d_fixparts, (uint32_t)h->parts.size(), h->max_nshared, h->vsz == 4, st);
     if (e != hipSuccess) return e;
-    e = cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st, h->combine_batch, h->combine_mul, h->d_cbits);
+    e = cvr::launch_combine(h->d_cpanels, (uint32_t)h->parts.size(), h->d_block_off, y, (uint32_t)h->info.nrows, h->vsz == 4, st, h->combine_batch, h->combine_mul, h->d_cbits, fold ? h->d_cut : nullptr,
+                            fold ? h->ncut_fold : 0u);
     if (e != hipSuccess) return e;
     return leave();
 }
@@ -105,6 +108,19 @@ int setup_combine_bits(cvr_handle *h, int64_t nsub)
     if (hipMalloc(&h->d_cbits, sizeof(uint32_t) * 32 * (size_t)nblocks * P) != hipSuccess) { (void)hipGetLastError(); h->d_cbits = nullptr; return CVR_OK; }      // (no memory for it: the row numbers do)
     if (cvr::launch_combine_bits_build(h->d_cpanels, (uint32_t)P, h->d_block_off, nrows, h->d_cbits, h->stream) != hipSuccess) return CVR_ERR_HIP;
     h->info.image_bytes += (int64_t)(sizeof(uint32_t) * 32 * (size_t)nblocks * P);
+    // the rows cut over chunks, when they are few: folded into the pass (CutEntry, cvr_kernels.h) -- the com-Orkut shape's two rows cost a launch of 4.7 us per SpMV
+    int64_t cut = 0;
+    for (const Part &p : h->parts) cut += p.nshared;
+    if (cut > 0 && cut <= (int64_t)cvr::kMaxCutFold && h->d_fixparts && h->d_rows && h->d_rows16 && !cvr::debug_env("no_cut_fold")) {
+        void *m = nullptr;
+        if (hipMalloc(&m, sizeof(cvr::CutEntry) * cvr::kMaxCutFold + 16) != hipSuccess) { (void)hipGetLastError(); return CVR_OK; }
+        h->d_cut = static_cast<cvr::CutEntry *>(m);
+        uint32_t *count = reinterpret_cast<uint32_t *>(h->d_cut + cvr::kMaxCutFold);
+        if (hipMemsetAsync(m, 0, sizeof(cvr::CutEntry) * cvr::kMaxCutFold + 16, h->stream) != hipSuccess) return CVR_ERR_HIP;
+        if (cvr::launch_cut_table(h->d_fixparts, (uint32_t)P, h->max_nshared, h->d_cpanels, h->d_rows16, h->d_rows, h->d_cut, count, h->stream) != hipSuccess) return CVR_ERR_HIP;
+        h->ncut_fold = (uint32_t)cut;
+    }
+    if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] combine pass: bitmap form (%zu panels, %lld partial sums for %u rows), %u cut rows folded into it\n", P, (long long)nsub, nrows, h->ncut_fold);
     return CVR_OK;
 }
 
@@ -1271,7 +1287,7 @@ int cvr_destroy(cvr_handle *h)
     if (h->d_small) (void)hipFree(h->d_small);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     if (h->z_free) (void)hipEventDestroy(h->z_free);
-    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_rows16, (void *)h->d_cbits, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, (void *)h->d_multi, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)h->d_err, h->d_z, (void *)h->d_rows, (void *)h->d_rows16, (void *)h->d_cbits, (void *)h->d_cut, (void *)h->d_block_off, (void *)h->d_cpanels, (void *)h->d_fixparts, (void *)h->d_multi, h->d_dict, h->d_x, h->d_y}) if (p) (void)hipFree(p);
     release_stream(h->device, h->stream);
     delete h;
     return CVR_OK;

@@ -143,6 +143,8 @@ struct cvr_handle {
     void     *d_z = nullptr;
     uint32_t *d_rows = nullptr, *d_block_off = nullptr;
     uint32_t *d_cbits = nullptr;           // the rows that have a partial sum, a bit per (row, panel): the combine pass's bitmap form (setup_combine_bits; null: row numbers)
+    cvr::CutEntry *d_cut = nullptr;        // ... and the few rows cut over chunks that pass folds in (ncut_fold of them; 0: the fix-up launch runs in front of the pass)
+    uint32_t  ncut_fold = 0;
     uint16_t *d_rows16 = nullptr;          // the low halves of d_rows: what the combine pass reads (2 instead of 4 bytes per (row, panel) pair)
     int32_t  *split_ci = nullptr;          // the device split's column indices and values, panel after panel: the parts' CSR arrays are slices of these
     void     *split_va = nullptr;          // (freed with the parts' CSR: after the conversion, or with the handle when it keeps its CSR)

@@ -246,8 +246,16 @@ hipError_t launch_fixup_multi(const FixPart *parts, uint32_t nparts, uint32_t ma
 constexpr int kCombineRows = 1024;
 struct CombinePanel { const void *z; const uint16_t *rows; };          // rows: the LOW 16 BITS of the sub-rows' row numbers (a workgroup of the pass owns at most 8 192 consecutive rows: the difference to its first row, modulo 65 536, is the row's place there)
 hipError_t launch_narrow_rows(const uint32_t *rows, size_t n, uint16_t *rows16, hipStream_t st);
+// Rows cut over chunks, folded into the bitmap form of the pass (a handful per handle: the com-Orkut shape has two): entry = the panel, the row's place u among the
+// panel's partial sums, its block of rows, the carries c0 .. c1 that make its sum (FixPart.shared) and where the panel's carries begin.  The workgroup of that
+// block sums the carries with fixup_multi_kernel's own instructions and uses the result in place of the panel's sum u -- no fix-up launch in front of the pass.
+struct CutEntry { uint32_t panel, u, block, carry_off; int64_t c0, c1; };
+constexpr uint32_t kMaxCutFold = 8;
+// out[0 .. total): the entries of all panels' cut rows (total <= kMaxCutFold, counted on the host); count: a zeroed device word.  rows32 / rows16_base: the
+// 32-bit row numbers of all panels' partial sums and the array CombinePanel.rows points into (the same order).  Asynchronous on st.
+hipError_t launch_cut_table(const struct FixPart *parts, uint32_t nparts, uint32_t max_nshared, const struct CombinePanel *panels, const uint16_t *rows16_base, const uint32_t *rows32, CutEntry *out, uint32_t *count, hipStream_t st);
 hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch = 4, int mul = 1,
-                          const uint32_t *bits = nullptr);      // bits (mul = 1, <= 16 panels): the bitmap form -- a thread owns four rows, no row numbers read (combine_bits_kernel)
+                          const uint32_t *bits = nullptr, const CutEntry *cut = nullptr, uint32_t ncut = 0);      // bits (mul = 1, <= 16 panels): the bitmap form -- a thread owns four rows, no row numbers read (combine_bits_kernel)
 // bits[(p * nblocks + b) * 32 + w]: the rows b * kCombineRows + 32 w .. that have a partial sum in panel p (nblocks = ceil(nrows / kCombineRows)); asynchronous on st
 hipError_t launch_combine_bits_build(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, uint32_t nrows, uint32_t *bits, hipStream_t st);      // batch: panels whose loads share a round trip (4 or 8); mul: blocks of kCombineRows rows per workgroup (1 or 8)
 

@@ -1517,13 +1517,16 @@ __global__ __launch_bounds__(NT) void combine_kernel(const CombinePanel *__restr
 // load instruction is issued per (row, panel) whether the sum exists or not, which is why sparsely filled shapes keep the row numbers.
 template <typename T, int PMAX>
 __global__ __launch_bounds__(256) void combine_bits_kernel(const CombinePanel *__restrict__ panels, uint32_t npanels, const uint32_t *__restrict__ block_off, uint32_t nblocks,
-                                                           const uint32_t *__restrict__ bits, T *__restrict__ y, uint32_t nrows)
+                                                           const uint32_t *__restrict__ bits, T *__restrict__ y, uint32_t nrows, const CutEntry *__restrict__ cut, uint32_t ncut)
 {
     __shared__ uint2    s_bp[PMAX][32];          // .x = the word's bits, .y = set bits of the panel in the block's words before it
     __shared__ uint32_t s_lo[PMAX];
     __shared__ const T *s_z[PMAX];
+    __shared__ CutEntry s_cut[kMaxCutFold];
+    __shared__ T        s_fix[kMaxCutFold];
     const uint32_t b = blockIdx.x, r0 = b * (uint32_t)kCombineRows, tid = threadIdx.x;
     if (tid < npanels) { s_z[tid] = static_cast<const T *>(panels[tid].z); s_lo[tid] = block_off[(size_t)tid * (nblocks + 1) + b]; }
+    if (tid < ncut) s_cut[tid] = cut[tid];          // (ncut = 0 for nearly every handle: no load)
     for (uint32_t idx = tid; idx < npanels * 32u; idx += 256u) {          // (a half wavefront per panel)
         const uint32_t p = idx >> 5, w = idx & 31u;
         const uint32_t v = bits[((size_t)p * nblocks + b) * 32u + w];
@@ -1533,6 +1536,23 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const CombinePanel *_
         s_bp[p][w] = uint2{v, c - (uint32_t)__popc(v)};
     }
     __syncthreads();
+    // rows cut over chunks whose block this is (rare): the sum of a row's carries, by fixup_multi_kernel's instructions -- one wavefront per row, the same tree
+    bool mine = false;
+    for (uint32_t e = 0; e < ncut; e++) mine = mine || s_cut[e].block == b;
+    if (mine) {          // (uniform)
+        for (uint32_t e = tid >> 6; e < ncut; e += 4u) {
+            const CutEntry c = s_cut[e];
+            if (c.block != b) continue;
+            const uint32_t lane = tid & 63u;
+            const T       *carry = s_z[c.panel] + c.carry_off;
+            T              v = 0;
+            for (int64_t cc = c.c0 + 1 + lane; cc <= c.c1; cc += kLanes) v += carry[2 * cc];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) s_fix[e] = carry[2 * c.c0 + 1] + v;
+        }
+        __syncthreads();
+    }
     const T *zp[PMAX];
     uint32_t lo[PMAX];
 #pragma unroll
@@ -1556,6 +1576,19 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const CombinePanel *_
                 if (c.x & mB) { hasB |= 1u << p; vB[p] = __builtin_nontemporal_load(zp[p] + (lo[p] + c.y + (uint32_t)__popc(c.x & (mB - 1u)))); }
             }
         }
+        if (mine) {          // (uniform, rare) the cut rows' sums in place of what the panel's chunks left at their places
+            for (uint32_t e = 0; e < ncut; e++) {
+                const CutEntry c = s_cut[e];
+                if (c.block != b) continue;
+#pragma unroll
+                for (int p = 0; p < PMAX; p++) {
+                    if ((uint32_t)p != c.panel || (uint32_t)p >= npanels) continue;
+                    const uint2 a = s_bp[p][wA], d = s_bp[p][wB];
+                    if ((a.x & mA) && lo[p] + a.y + (uint32_t)__popc(a.x & (mA - 1u)) == c.u) vA[p] = s_fix[e];
+                    if ((d.x & mB) && lo[p] + d.y + (uint32_t)__popc(d.x & (mB - 1u)) == c.u) vB[p] = s_fix[e];
+                }
+            }
+        }
         T accA = T(0), accB = T(0);
 #pragma unroll
         for (int p = 0; p < PMAX; p++) {
@@ -1565,6 +1598,19 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const CombinePanel *_
         if (r0 + iA < nrows) __builtin_nontemporal_store(accA, &y[r0 + iA]);
         if (r0 + iB < nrows) __builtin_nontemporal_store(accB, &y[r0 + iB]);
     }
+}
+
+// the table of the cut rows a handle's bitmap pass folds in (CutEntry, cvr_kernels.h): blockIdx.y = panel, a thread per cut row
+__global__ __launch_bounds__(64) void cut_table_kernel(const FixPart *__restrict__ parts, const CombinePanel *__restrict__ panels, const uint16_t *__restrict__ rows16_base,
+                                                        const uint32_t *__restrict__ rows32, CutEntry *__restrict__ out, uint32_t *__restrict__ count)
+{
+    const FixPart  p = parts[blockIdx.y];
+    const uint32_t s = blockIdx.x * 64u + threadIdx.x;
+    if (s >= p.nshared) return;
+    const int64_t  row = p.shared[3 * (size_t)s], c0 = p.shared[3 * (size_t)s + 1], c1 = p.shared[3 * (size_t)s + 2];
+    const uint32_t global_row = rows32[(size_t)(panels[blockIdx.y].rows - rows16_base) + (size_t)row];
+    const uint32_t slot = atomicAdd(count, 1u);
+    if (slot < kMaxCutFold) out[slot] = CutEntry{blockIdx.y, (uint32_t)row, global_row / (uint32_t)kCombineRows, p.nrows + 1u, c0, c1};
 }
 
 // the bitmap of one (block, panel): the low 16 bits of its sums' row numbers -> bits, through LDS
@@ -1636,17 +1682,25 @@ hipError_t launch_combine_bits_build(const CombinePanel *panels, uint32_t npanel
     return hipGetLastError();
 }
 
-hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch, int mul, const uint32_t *bits)
+hipError_t launch_cut_table(const FixPart *parts, uint32_t nparts, uint32_t max_nshared, const CombinePanel *panels, const uint16_t *rows16_base, const uint32_t *rows32, CutEntry *out, uint32_t *count, hipStream_t st)
+{
+    if (nparts == 0 || max_nshared == 0) return hipSuccess;
+    hipLaunchKernelGGL(cut_table_kernel, dim3((max_nshared + 63) / 64, nparts), dim3(64), 0, st, parts, panels, rows16_base, rows32, out, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_combine(const CombinePanel *panels, uint32_t npanels, const uint32_t *block_off, void *y, uint32_t nrows, bool f32, hipStream_t st, int batch, int mul, const uint32_t *bits, const CutEntry *cut,
+                          uint32_t ncut)
 {
     if (nrows == 0) return hipSuccess;
     const uint32_t nblocks = (nrows + kCombineRows - 1) / kCombineRows;
     if (bits && mul == 1 && npanels <= 16u) {          // the bitmap form (combine_bits_kernel)
         if (npanels <= 8u) {
-            if (f32) hipLaunchKernelGGL((combine_bits_kernel<float, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<float *>(y), nrows);
-            else hipLaunchKernelGGL((combine_bits_kernel<double, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<double *>(y), nrows);
+            if (f32) hipLaunchKernelGGL((combine_bits_kernel<float, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<float *>(y), nrows, cut, ncut);
+            else hipLaunchKernelGGL((combine_bits_kernel<double, 8>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<double *>(y), nrows, cut, ncut);
         } else {
-            if (f32) hipLaunchKernelGGL((combine_bits_kernel<float, 16>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<float *>(y), nrows);
-            else hipLaunchKernelGGL((combine_bits_kernel<double, 16>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<double *>(y), nrows);
+            if (f32) hipLaunchKernelGGL((combine_bits_kernel<float, 16>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<float *>(y), nrows, cut, ncut);
+            else hipLaunchKernelGGL((combine_bits_kernel<double, 16>), dim3(nblocks), dim3(256), 0, st, panels, npanels, block_off, nblocks, bits, static_cast<double *>(y), nrows, cut, ncut);
         }
         return hipGetLastError();
     }

@@ -255,6 +255,45 @@ def test_combine_bitmap_form_is_the_row_number_form(kw, f32, monkeypatch):
     _assert_close(ys[1], yref, absy, TOL32 if f32 else TOL64, ("bitmap combine", kw, f32))
 
 
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("kw", [{"col_panels": 8, "steps_per_chunk": 32}, {"col_panels": 8, "interleave": 1, "gang": 1, "steps_per_chunk": 32, "waves_per_block": 4}])
+def test_cut_rows_folded_into_the_bitmap_combine(kw, f32, monkeypatch, capfd):
+    """A handful of rows cut over chunks (here three rows with 3 000-4 500 non-zeros inside ONE panel each, in a matrix of 12 per row; chunks of 2 048 slots) on a panelled handle whose
+    combine pass runs in its bitmap form: the pass sums those rows' carries itself (CutEntry; no fix-up launch) -- the bits of the fix-up launch in front of the
+    pass (CVR_DEBUG=no_cut_fold) and of the row-number form (combine_bits=0)."""
+    rng = np.random.default_rng(99)
+    n = 40_000
+    deg = np.full(n, 12, dtype=np.int64)
+    long_rows = {123: (4500, 0), 20_001: (4000, 20_000), 39_990: (3000, 35_000)}          # row: (non-zeros, first column of the panel they lie in; a panel is 5 000 columns wide)
+    for r, (d, _) in long_rows.items():
+        deg[r] = d
+    rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    ci = np.empty(rp[-1], dtype=np.int32)
+    for r in range(n):
+        if r in long_rows:
+            ci[rp[r]:rp[r + 1]] = long_rows[r][1] + np.sort(rng.choice(5000, size=deg[r], replace=False))
+        else:
+            ci[rp[r]:rp[r + 1]] = np.sort(rng.choice(n, size=deg[r], replace=False))
+    va = (rng.random(rp[-1]) * 2 - 1).astype(np.float32 if f32 else np.float64)
+    x = (rng.random(n) * 2 - 1).astype(va.dtype)
+    ys, infos = [], []
+    for dbg in ("fused_trace", "fused_trace,no_cut_fold", "fused_trace,combine_bits=0"):
+        monkeypatch.setenv("CVR_DEBUG", dbg)
+        capfd.readouterr()
+        A = cvr_amd.CvrMatrix(n, n, rp, ci, va, **kw)
+        err = capfd.readouterr().err
+        assert A.info.col_panels == 8 and 0 < A.info.nshared <= 8, A.info.nshared
+        assert ("3 cut rows folded" in err) == (dbg == "fused_trace") and ("bitmap form" in err) == ("combine_bits=0" not in dbg), err
+        y, _ = A.spmv(x)
+        y2, _ = A.spmv(x)
+        assert np.array_equal(y, y2)
+        ys.append(y)
+        A.close()
+    assert np.array_equal(ys[0].view(np.uint8), ys[1].view(np.uint8)) and np.array_equal(ys[0].view(np.uint8), ys[2].view(np.uint8)), kw
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    _assert_close(ys[0], yref, absy, TOL32 if f32 else TOL64, ("cut rows folded", kw, f32))
+
+
 def test_interleaved_chunk_length_limits():
     """interleave = 1 with the longest chunks the converter sorts in one workgroup (S = 508: 32 pairs per thread; S = 576: 36) converts and
     runs, image and y the mirror's bits; one group more is refused by cvr_create with CVR_ERR_INVALID and a message, before any planning
