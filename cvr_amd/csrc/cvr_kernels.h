@@ -248,7 +248,7 @@ struct CombinePanel { const void *z; const uint16_t *rows; };          // rows: 
 hipError_t launch_narrow_rows(const uint32_t *rows, size_t n, uint16_t *rows16, hipStream_t st);
 // Rows cut over chunks, folded into the bitmap form of the pass (a handful per handle: the com-Orkut shape has two): entry = the panel, the row's place u among the
 // panel's partial sums, its block of rows, the carries c0 .. c1 that make its sum (FixPart.shared) and where the panel's carries begin.  The workgroup of that
-// block sums the carries with fixup_multi_kernel's own instructions and uses the result in place of the panel's sum u -- no fix-up launch in front of the pass.
+// block sums the carries with fixup_multi_kernel's own instructions and stores the result at the panel's place u before it loads its sums -- no fix-up launch in front of the pass.
 struct CutEntry { uint32_t panel, u, block, carry_off; int64_t c0, c1; };
 constexpr uint32_t kMaxCutFold = 8;
 // out[0 .. total): the entries of all panels' cut rows (total <= kMaxCutFold, counted on the host); count: a zeroed device word.  rows32 / rows16_base: the

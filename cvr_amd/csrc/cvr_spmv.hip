@@ -1523,7 +1523,6 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const CombinePanel *_
     __shared__ uint32_t s_lo[PMAX];
     __shared__ const T *s_z[PMAX];
     __shared__ CutEntry s_cut[kMaxCutFold];
-    __shared__ T        s_fix[kMaxCutFold];
     const uint32_t b = blockIdx.x, r0 = b * (uint32_t)kCombineRows, tid = threadIdx.x;
     if (tid < npanels) { s_z[tid] = static_cast<const T *>(panels[tid].z); s_lo[tid] = block_off[(size_t)tid * (nblocks + 1) + b]; }
     if (tid < ncut) s_cut[tid] = cut[tid];          // (ncut = 0 for nearly every handle: no load)
@@ -1536,7 +1535,8 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const CombinePanel *_
         s_bp[p][w] = uint2{v, c - (uint32_t)__popc(v)};
     }
     __syncthreads();
-    // rows cut over chunks whose block this is (rare): the sum of a row's carries, by fixup_multi_kernel's instructions -- one wavefront per row, the same tree
+    // rows cut over chunks whose block this is (rare): the sum of a row's carries, by fixup_multi_kernel's instructions -- one wavefront per row, the same tree,
+    // written to the same place (nobody but this workgroup reads that place)
     bool mine = false;
     for (uint32_t e = 0; e < ncut; e++) mine = mine || s_cut[e].block == b;
     if (mine) {          // (uniform)
@@ -1549,8 +1549,10 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const CombinePanel *_
             for (int64_t cc = c.c0 + 1 + lane; cc <= c.c1; cc += kLanes) v += carry[2 * cc];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0) s_fix[e] = carry[2 * c.c0 + 1] + v;
+            // ... stored where the panel's chunks left the row's piece (what the fix-up launch does): the loads below, behind the barrier, are this workgroup's own
+            if (lane == 0) const_cast<T *>(s_z[c.panel])[c.u] = carry[2 * c.c0 + 1] + v;
         }
+        __threadfence_block();
         __syncthreads();
     }
     const T *zp[PMAX];
@@ -1574,19 +1576,6 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const CombinePanel *_
                 const uint2 a = s_bp[p][wA], c = s_bp[p][wB];
                 if (a.x & mA) { hasA |= 1u << p; vA[p] = __builtin_nontemporal_load(zp[p] + (lo[p] + a.y + (uint32_t)__popc(a.x & (mA - 1u)))); }
                 if (c.x & mB) { hasB |= 1u << p; vB[p] = __builtin_nontemporal_load(zp[p] + (lo[p] + c.y + (uint32_t)__popc(c.x & (mB - 1u)))); }
-            }
-        }
-        if (mine) {          // (uniform, rare) the cut rows' sums in place of what the panel's chunks left at their places
-            for (uint32_t e = 0; e < ncut; e++) {
-                const CutEntry c = s_cut[e];
-                if (c.block != b) continue;
-#pragma unroll
-                for (int p = 0; p < PMAX; p++) {
-                    if ((uint32_t)p != c.panel || (uint32_t)p >= npanels) continue;
-                    const uint2 a = s_bp[p][wA], d = s_bp[p][wB];
-                    if ((a.x & mA) && lo[p] + a.y + (uint32_t)__popc(a.x & (mA - 1u)) == c.u) vA[p] = s_fix[e];
-                    if ((d.x & mB) && lo[p] + d.y + (uint32_t)__popc(d.x & (mB - 1u)) == c.u) vB[p] = s_fix[e];
-                }
             }
         }
         T accA = T(0), accB = T(0);

@@ -151,6 +151,16 @@ def check(path, expected):
             errors.append(f"{name}: CVR_RING_BEGIN without CVR_RING_END")
         print(f"isa_check: {name}: scratch {m.get('private_segment_fixed_size')}, vgpr spills {m.get('vgpr_spill_count')}, sgpr spills {m.get('sgpr_spill_count')}, "
               f"vgprs {m.get('vgpr_count')}, ring from v{cap}")
+    # the streaming passes beside the ring kernels live on occupancy: a change that makes the compiler index a register array dynamically shows up as scratch and a
+    # register count that halves the wavefronts per SIMD long before any test fails (round 6: the combine pass's bitmap form went from 46 / 76 registers to 138 / 235
+    # + 1 156 bytes of scratch, and from 35 to 55 us, with every parity test green)
+    for sym, m in sorted(md.items()):
+        if "combine_bits_kernel" not in sym and "combine_kernel" not in sym:
+            continue
+        short = re.search(r"(combine(?:_bits)?_kernel\w*)", sym)
+        name = short.group(1)[:60] if short else sym[:60]
+        if m.get("private_segment_fixed_size", -1) != 0 or m.get("vgpr_count", 999) > 128:
+            errors.append(f"{name}: scratch {m.get('private_segment_fixed_size')}, vgprs {m.get('vgpr_count')} (a streaming pass: no scratch, at most 128 registers)")
     return errors
 
 
