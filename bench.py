@@ -90,9 +90,11 @@ def capi_row_cost():
 OTHER_WORKLOADS = ("livejournal", "rmat22", "orkut", "wikitalk")      # the power-law shapes beside the headline (north_star: "three SuiteSparse power-law matrices")
 
 
-def measure_other_workload(kind, dev, steps=60, warmup=6):
+def measure_other_workload(kind, dev, steps=200, warmup=40):
     """One more shape in the same process (N = 1): built (on the device where a generator exists), converted with the library's own rules,
-    timed with HIP events over `steps` back-to-back SpMVs on the current stream, every row checked against a torch fp64 segment sum.
+    timed with HIP events over `steps` back-to-back SpMVs on a stream of its own behind `warmup` untimed ones (the headline's kernel time is taken over >= 200
+    launches behind its whole timed loop; with 6 + 60 launches straight after the conversion these shapes read 1.5 % slower than in a process of their own:
+    soc-LiveJournal1 shape 208.6-209.4 against 205.4-206.4 us), every row checked against a torch fp64 segment sum.
     Returns what the judge needs to recompute the fraction: nnz, algorithmic bytes, kernel time."""
     import torch
     import cvr_amd
@@ -788,7 +790,10 @@ def main():
     # the SpMV kernel alone, HIP events on the launch stream (N > 1: this rank's shard, no gather)
     def kernel_time(M, ybuf):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        M.spmv_device(x.data_ptr(), ybuf.data_ptr(), sptr, repeat=args.warmup)
+        # behind ~30 ms of untimed launches: after an idle spell the chip needs some ten milliseconds of work before a kernel takes its steady time (the headline
+        # behind a 20-step run: 20.93 us over the next 200 launches, 20.6 behind 1 000 steps -- what rocprofv3 averages over a whole run; profiles/r06_timed_region_20_steps.log)
+        n_w = max(args.warmup, min(2000, int(0.03 / max(wall / max(args.steps, 1), 1e-6))))
+        M.spmv_device(x.data_ptr(), ybuf.data_ptr(), sptr, repeat=n_w)
         n_t = max(args.steps, 200)               # >= 100 timed back-to-back launches, whatever --steps says
         a.record(stream)
         M.spmv_device(x.data_ptr(), ybuf.data_ptr(), sptr, repeat=n_t)
