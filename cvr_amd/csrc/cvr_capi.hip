@@ -680,6 +680,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         const hipError_t  e = cvr::hub_share_device(ci_d, sj0, sj1, ncols, (uint32_t)std::max<int64_t>(room, 1024), &share, h->stream, cvr::Scratch{h->plan_ws.dev, h->plan_ws.dev_bytes}, col_share.data());      // (the share alone: no ranking of the columns)
         in.hub_select_s += now_s() - th0;
         if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "hub selection: %s", hipGetErrorString(e)); }
+        if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] popularity: the %lld most popular columns hold %.3f of the non-zeros (%d panels so far, x %.1f MB)\n", (long long)std::max<int64_t>(room, 1024), share, P, xbytes / 1e6);
         if (share >= 0.25) {       // (of the whole matrix: the panels' own tables, ranked inside their ranges, hold more)
             const int Pw = std::max(2, (int)std::ceil((double)ncols * (double)vsz / 16e6));
             if (mid_range) P = 1;      // (an x of one such panel: the single image with its hub table, as before -- R-MAT-22 fp32)
@@ -693,7 +694,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         // fullest panels sets the time (round 5 hold-out: a bipartite matrix whose columns thin out towards the end -- the first of 16 panels
         // holds 15.7 % of the non-zeros, 1.26 x an XCD's fair share -- ran 187 us as 16 panels, 112 us as 32).  The shares of the panels come
         // from the pass above; the count is doubled (up to 64) until the heaviest XCD -- panels dealt as run_spmv's table deals them, the
-        // fullest first to the least loaded XCD -- is within 15 % of the mean.
+        // fullest first to the least loaded XCD -- is within 30 % of the mean (15 % until round 6: with gang chunks the same bipartite shape runs 78.4 / 79.3 / 83.0 us as
+        // 8 / 16 / 32 panels -- its 16 panels at 1.21 of the mean no longer want doubling; profiles/r06_holdout.log).
         if (opt.hub_table == 0 && xcd_panels && P > 1 && P <= 64 && !cvr::debug_env("no_balance_rule")) {
             auto imbalance = [&](int Pt) {
                 std::vector<double> load((size_t)Pt, 0.0);
@@ -712,7 +714,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             };
             int    Pb = P;
             double ib = imbalance(P);
-            for (int Pt = 2 * P; ib > 1.15 && Pt <= 64; Pt *= 2) { const double it = imbalance(Pt); if (it < ib - 0.02) { ib = it; Pb = Pt; } }
+            for (int Pt = 2 * P; ib > 1.30 && Pt <= 64; Pt *= 2) { const double it = imbalance(Pt); if (it < ib - 0.02) { ib = it; Pb = Pt; } }
             if (cvr::debug_env("fused_trace") && Pb != P) fprintf(stderr, "[cvr] %d column panels instead of %d: the heaviest XCD at %.2f of the mean instead of %.2f\n", Pb, P, ib, imbalance(P));
             P = Pb;
         }
@@ -733,6 +735,17 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
             // (not rows of one or two non-zeros: nothing to accumulate per row, and the accumulators' row cap would end their chunks early)
             if (sj1 - sj0 >= 3 * nrows && opt.interleave < 0 && opt.gang < 0 && opt.hub_table < 0 && opt.steps_per_chunk == 0 && opt.waves_per_block == 0 && opt.x_window < 0 && opt.col_phases < 0 && !cvr::debug_env("no_auto_layout") && !cvr::debug_env("no_single_gang")) {
                 opt.interleave = 1; opt.gang = 1; opt.hub_table = 0;
+            }
+        }
+        // Thin lists (round 6, late): a gang's sorted list shares lines of x once it holds a few non-zeros per line of its panel's slice -- the requests per non-zero
+        // follow (1 - exp(-d)) / d for d = non-zeros of a gang / lines of the slice (measured 0.64 / 0.227 / 0.215 at d = 1.1 / 4.9 / 4.8: wiki-Talk, soc-LiveJournal1,
+        // com-Orkut shapes).  A matrix too small to give its gangs two non-zeros per line gets panels half as wide, when the partial sums that costs are few:
+        // wiki-Talk shape (d = 1.1, 0.05 pairs per non-zero) 33.2 us as 8 panels, 28.7 as 16; not the forum-like shape (d = 1.5, but 0.32 pairs per non-zero: 45.5 / 49.0)
+        // nor anything with d >= 2 (wiki-Talk x 2: 46.9 as 16, 49.5 as 32) -- profiles/r06_thin_lists_rule.log
+        if (P > 1 && P <= 32 && xcd_panels && opt.hub_table == 0 && opt.interleave != 0 && opt.gang != 0 && opt.waves_per_block == 0 && !cvr::debug_env("no_auto_layout") && !cvr::debug_env("no_thin_lists_rule")) {
+            if (thin_lists(P, xbytes, sj1 - sj0, opt.cus, ppn)) {          // (cvr_panels.hip)
+                if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] %d column panels instead of %d: fewer than two non-zeros of a gang per line of a panel's slice of x, %.3f (row, panel) pairs per non-zero\n", 2 * P, P, ppn);
+                P *= 2;
             }
         }
         in.plan_s += now_s() - tq;

@@ -305,6 +305,7 @@ int        panels_from_miss(double xb, double miss);
 double     pairs_per_nnz(const cvr_csr_view &v, int64_t width);
 hipError_t pairs_per_nnz_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64_t nrows, int64_t width, hipStream_t st, double *out, cvr::Scratch lent = cvr::Scratch());
 bool       panels_pay(double miss, double pairs_per_nonzero);
+bool       thin_lists(int P, double xbytes, int64_t nnz, int cus, double pairs_per_nonzero);      // gang chunks with fewer than two non-zeros per line of a panel's slice, few partial sums: panels half as wide (cvr_panels.hip)
 int        auto_panels(const cvr_csr_view &v, double *miss_out);
 int        xcd_panel_count(int P, double xbytes);
 

@@ -200,6 +200,15 @@ hipError_t pairs_per_nnz_dev(const int64_t *rp_dev, const int32_t *ci_dev, int64
 
 bool panels_pay(double miss, double pairs_per_nonzero) { return miss >= 0.68 * pairs_per_nonzero; }
 
+// Thin lists: a gang's sorted list shares lines of x once it holds a few non-zeros per line of its panel's slice (requests per non-zero ~ (1 - exp(-d)) / d for
+// d = non-zeros of a gang / lines of the slice); a matrix whose gangs get fewer than two takes panels half as wide when the partial sums that costs are few.
+bool thin_lists(int P, double xbytes, int64_t nnz, int cus, double pairs_per_nonzero)
+{
+    if (P <= 1 || P > 32) return false;
+    const double per_gang = std::min((double)nnz / (double)std::max(cus, 1), 100000.0);          // one gang per CU at least; ~100 000 non-zeros at most
+    return per_gang < 2.0 * (xbytes / (double)P / 128.0) && pairs_per_nonzero < 0.15;
+}
+
 int panels_from_miss(double xb, double miss) { return miss > 0.17 ? std::min(64, std::max(2, (int)(xb * miss / 1.8e6 + 0.5))) : 1; }
 
 // Panels that run one per XCD at a time, eight per launch (run_spmv, d_multi): the count the miss rule gave is for slices that share
@@ -227,7 +236,11 @@ int auto_panels(const cvr_csr_view &v, double *miss_out)
     }
     if (miss_out) *miss_out = miss;
     P = xcd_panel_count(P, xb);         // (as cvr_create counts them on a whole MI355X: eight XCDs)
-    if (P > 1 && !cvr::debug_env("no_pairs_rule") && !panels_pay(miss, pairs_per_nnz(v, (v.ncols + P - 1) / P > 0 ? (v.ncols + P - 1) / P : 1))) P = 1;
+    if (P > 1 && !cvr::debug_env("no_pairs_rule")) {
+        const double ppn = pairs_per_nnz(v, (v.ncols + P - 1) / P > 0 ? (v.ncols + P - 1) / P : 1);
+        if (!panels_pay(miss, ppn)) P = 1;
+        else if (thin_lists(P, xb, nnz, 256, ppn) && !cvr::debug_env("no_thin_lists_rule")) P *= 2;          // (cvr_create's rule for gang chunks, on a whole MI355X)
+    }
     return P;
 }
 

@@ -1801,6 +1801,8 @@ def test_full_size_shapes_every_row(name):
     assert np.array_equal(y.view(np.uint8), y2.view(np.uint8))
     if name == "livejournal":
         assert A.info.col_panels > 1
+    if name == "wikitalk" and A.info.gang > 0:
+        assert A.info.col_panels == 16          # (thin lists: fewer than two non-zeros of a gang per line of an eighth of x -- panels half as wide: cvr_panels.hip, thin_lists)
     A.close()
     assert time.time() - t0 < 180, "time box"
 
