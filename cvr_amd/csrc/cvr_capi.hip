@@ -541,8 +541,8 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         if (rc) return rc;
         const double xb = (double)hostv.ncols * (hostv.is_f32 ? 4.0 : 8.0);
         civa_kind = hipMemcpyDeviceToDevice;
-        if (opt.col_panels < 0 && !(j1 > 0 && (xb >= 24e6 || (xb >= kMidPanelBytes && resident_out_of_reach(hostv.nrows, j1 - j0, hostv.ncols, hostv.is_f32 != 0, opt)))))
-            opt.col_panels = 1;      // (else: the panel rule runs on the device arrays below)
+        if (opt.col_panels < 0 && !(j1 > 0 && (xb >= kNoWindowPanelBytes || (xb >= kMidPanelBytes && resident_out_of_reach(hostv.nrows, j1 - j0, hostv.ncols, hostv.is_f32 != 0, opt)))))
+            opt.col_panels = 1;      // (else: the panel rule runs on the device arrays below -- from 8 MB of x on it may be asked after the layout probe: ask_window)
         // (column panels of device arrays are split on the device: cvr_split.hip)
     }
 
@@ -630,8 +630,13 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
     const double   xbytes = (double)ncols * (double)vsz;
     // (x of 12 .. 24 MB: the rule also runs for matrices too large for the resident layout -- web-Google shapes of 12-16 M non-zeros run
     // 21-28 % faster as eight panels, one per XCD, than as one plain image: profiles/r03_mid_size_panels.log)
-    const bool     mid_range = P < 0 && xbytes >= kMidPanelBytes && xbytes < 24e6 && sj1 > sj0 && resident_out_of_reach(nrows, sj1 - sj0, ncols, f32, opt);
-    if (!on_device && (P > 1 || (P < 0 && (xbytes >= 24e6 || mid_range))) && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !cvr::debug_env("host_split")) {
+    bool           mid_range = P < 0 && xbytes >= kMidPanelBytes && xbytes < 24e6 && sj1 > sj0 && resident_out_of_reach(nrows, sj1 - sj0, ncols, f32, opt);
+    // (x of 8 .. 24 MB with every layout option left to the rules: the rule also runs for matrices that have no use for the resident layout's window -- decided below, on
+    // the device copy, by the layout probe's near-diagonal share: wiki-Talk-like matrices of 9.6 / 14.4 MB of x ran 37.4 / 60.8 us as one image, 21.4 / 23.9 as sixteen
+    // gang panels: profiles/r06_thin_lists_rule.log)
+    const bool     ask_window = P < 0 && !mid_range && xbytes >= kNoWindowPanelBytes && xbytes < 24e6 && sj1 > sj0 && nrows >= 4096 && ncols >= 4096 && opt.steps_per_chunk == 0 && opt.waves_per_block == 0 &&
+                                opt.x_window < 0 && opt.col_phases < 0 && opt.interleave < 0 && opt.gang < 0 && opt.hub_table < 0 && !opt.debug_col_mask && !cvr::debug_env("no_auto_layout") && !cvr::debug_env("no_window_question");
+    if (!on_device && (P > 1 || (P < 0 && (xbytes >= 24e6 || mid_range || ask_window))) && sj1 > 0 && sj1 < (int64_t)0xffffffffll && !cvr::debug_env("host_split")) {
         auto         up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t b_rp = up(sizeof(int64_t) * ((size_t)nrows + 1)), b_ci = up(sizeof(int32_t) * (size_t)sj1), b_va = up(vsz * (size_t)sj1);
         if (hipMalloc(&staged.rp, b_rp + b_ci + b_va) == hipSuccess) {
@@ -650,6 +655,22 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         }
     }
     clk.lap("staging upload");
+    bool no_window = false;
+    if (ask_window && dev_split) {          // the layout probe in front of the panel rule: the share of the non-zeros the resident layout's window would hold
+        unsigned long long *d_out = reinterpret_cast<unsigned long long *>(h->d_small + kSmallProbe);
+        std::vector<unsigned long long> outv(2 * cvr::kProbeBlocks, 0);
+        const int64_t win = (96 * 1024) / (int64_t)vsz;
+        hipError_t e = cvr::launch_probe(rp_d, ci_d, nrows, ncols, (uint32_t)(win / 4), d_out, h->stream, h->small_clean);
+        if (e == hipSuccess) e = hipMemcpyAsync(outv.data(), d_out, sizeof(unsigned long long) * outv.size(), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof(unsigned long long) * outv.size(), h->stream);          // (the probe's part of the small scratch is clean again: auto_layout, the early dictionary scan)
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { cvr_destroy(h); return fail(CVR_ERR_HIP, "layout probe: %s", hipGetErrorString(e)); }
+        unsigned long long cnt = 0;
+        for (uint32_t b = 0; b < cvr::kProbeBlocks; b++) cnt += outv[2 * b + 1];
+        const double near = (double)cnt / std::max<double>((double)(sj1 - sj0), 1.0);
+        if (near < 0.15) { mid_range = true; no_window = true; }          // (no window for it: the panel question is asked as for a matrix beyond the resident layout)
+        if (cvr::debug_env("fused_trace")) fprintf(stderr, "[cvr] x %.1f MB, %.3f of the non-zeros near the diagonal: the panel question is %s\n", xbytes / 1e6, near, mid_range ? "asked" : "not asked (resident layout)");
+    }
     // the panel rule (col_panels < 0): on the device copy when there is one (same windows, same integers as the host form)
     const double t_rule0 = now_s();
     double       rule_miss = -1;          // >= 0: the device rule ran and its count is still to be weighed against the partial sums it costs (below)
@@ -817,7 +838,7 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         // non-zeros on (with the chunk length that fills whole generations of workgroups: wiki-Talk shape, 5 M, 48.6 -> 43.6 us; a 2.4-M-row
         // matrix of single-entry rows 36.9 -> 38.6: stays plain; web-Google shape x 2.2 / 2.6 / 3: 72 -> 55, 84 -> 65, 95 -> 86; com-Orkut
         // shape 1 307 -> 765: profiles/r04_ilv_auto_probe.log)
-        if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && sj1 - sj0 >= (cvr::debug_env("ilv_min_nnz") ? atoll(cvr::debug_env("ilv_min_nnz")) : (int64_t)4 << 20) && !cvr::debug_env("no_auto_layout") ? 1 : 0;
+        if (panel_opt.interleave < 0) panel_opt.interleave = xcd_panels && dev_split && panel_opt.hub_table == 0 && panel_opt.waves_per_block == 0 && panel_opt.x_window <= 0 && sj1 - sj0 >= (cvr::debug_env("ilv_min_nnz") ? atoll(cvr::debug_env("ilv_min_nnz")) : no_window ? (int64_t)1 << 20 : (int64_t)4 << 20) && !cvr::debug_env("no_auto_layout") ? 1 : 0;
         int ilv_generations = 0;          // > 0: the chunk length was chosen for this many generations of workgroups (checked against the plan below)
         if (panel_opt.interleave > 0) {
             panel_opt.hub_table = 0; panel_opt.col_phases = 1;

@@ -258,6 +258,7 @@ int64_t    plan_layout(PartPlan &pp, int64_t ncols, bool f32, const IOpt &opt);
 void       plan_stage(PartPlan &pp, bool f32);
 bool       resident_candidate(double slots, int cus, int *best_w, int *best_S);
 bool       resident_out_of_reach(int64_t nrows, int64_t nnz, int64_t ncols, bool f32, const IOpt &opt);
+constexpr double kNoWindowPanelBytes = 8e6;  // ... and from here on for matrices whose non-zeros are not near the diagonal (no use for the resident layout's window: cvr_create)
 constexpr double kMidPanelBytes = 12e6;      // x from here to 24 MB: the panel rule runs only for matrices beyond the resident layout
 int        setup_image(cvr_handle *h, Part &part, const PartPlan &pp, int64_t nrows, int64_t ncols, bool f32, int64_t nchunks, int64_t nshared, const IOpt &opt, const IOpt &popt);
 // cvr_fused.hip: analysis, plan and conversion of a single resident-layout image as one submission (no host round trip between planner

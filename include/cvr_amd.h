@@ -217,7 +217,11 @@ int cvr_spmv_device_repeat(cvr_handle *h, const void *x_dev, void *y_dev, void *
  * -- or >= 12 MB and the matrix is too large for the resident layout (more slots or rows than its workgroups hold in one pass) --
  * and the estimated share of x gathers missing a 4-MiB L2 (*l2_miss_estimate, sampled over eight windows of 65 536
  * rows) exceeds 0.17; then one panel per 1.8 MB of missing x, counted in rounds of eight (one panel per XCD at a time: eight up
- * to 27 MB of x, then 8 * ceil(x / 20.8 MB)).  Returns the count (>= 1) or a negative error. */
+ * to 27 MB of x, then 8 * ceil(x / 20.8 MB)); doubled once for thin lists (fewer than two non-zeros of a workgroup's list per
+ * 128-byte line of a panel's slice of x, and fewer than 0.15 (row, panel) pairs per non-zero).  cvr_create differs from this host
+ * rule in what it measures on the device: hub tables (popular columns) widen or drop the panels, unevenly filled panels are
+ * doubled, and from 8 MB of x on a matrix whose non-zeros are not near the diagonal is asked the panel question as well.
+ * Returns the count (>= 1) or a negative error. */
 int cvr_auto_panels(const cvr_csr_view *csr, double *l2_miss_estimate);
 
 /* Optional tuning of steps_per_chunk by measurement: builds the matrix with S = 8, 12, ... 64 on the device, times the

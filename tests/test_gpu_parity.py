@@ -294,6 +294,45 @@ def test_cut_rows_folded_into_the_bitmap_combine(kw, f32, monkeypatch, capfd):
     _assert_close(ys[0], yref, absy, TOL32 if f32 else TOL64, ("cut rows folded", kw, f32))
 
 
+def test_panel_question_for_mid_size_matrices_without_a_diagonal(monkeypatch, capfd):
+    """x of 8 .. 24 MB with every layout option left to the rules: the layout probe runs in front of the panel rule, and a matrix whose non-zeros are not near the
+    diagonal (no use for the resident layout's window) is asked the panel question like one beyond the resident layout -- a wiki-Talk-like matrix of 14 MB of x becomes
+    gang panels (60.8 -> 23.9 us: profiles/r06_thin_lists_rule.log); a web-Google-like one of 11 MB keeps the resident layout with its window.  y checked for both."""
+    torch = pytest.importorskip("torch")
+    from cvr_amd import synth_dev as D
+    monkeypatch.setenv("CVR_DEBUG", "fused_trace")
+    n, rp_t, ci_t, va_t = D.wikitalk_like(scale=0.75, device="cuda")
+    rp, ci, va = rp_t.cpu().numpy(), ci_t.cpu().numpy(), va_t.cpu().numpy()
+    del rp_t, ci_t, va_t
+    for arrays_on_device in (False, True):
+        capfd.readouterr()
+        if arrays_on_device:
+            t = [torch.from_numpy(a).cuda() for a in (rp, ci, va)]
+            A = cvr_amd.CvrMatrix.from_device(n, n, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), is_f32=False, device=0)
+        else:
+            A = cvr_amd.CvrMatrix(n, n, rp, ci, va)
+        err = capfd.readouterr().err
+        assert "the panel question is asked" in err, err[-600:]
+        assert A.info.col_panels >= 8 and A.info.interleave == 1 and A.info.gang > 0, (A.info.col_panels, A.info.interleave, A.info.gang)
+        if not arrays_on_device:
+            x = O.x_vec_fast(n, "rand")
+            y, _ = A.spmv(x)
+            yref, absy = O.csr_spmv64(rp, ci, va, x)
+            _assert_close(y, yref, absy, TOL64, "wiki-Talk x 0.75")
+        A.close()
+    n, nc, rp, ci, va = synth.web_google_like(scale=1.5)
+    capfd.readouterr()
+    A = cvr_amd.CvrMatrix(n, nc, rp, ci, va)
+    err = capfd.readouterr().err
+    assert "not asked (resident layout)" in err, err[-600:]
+    assert A.info.col_panels == 1 and A.info.x_window > 0, (A.info.col_panels, A.info.x_window)
+    x = O.x_vec_fast(nc, "rand")
+    y, _ = A.spmv(x)
+    yref, absy = O.csr_spmv64(rp, ci, va, x)
+    _assert_close(y, yref, absy, TOL64, "web-Google x 1.5")
+    A.close()
+
+
 def test_interleaved_chunk_length_limits():
     """interleave = 1 with the longest chunks the converter sorts in one workgroup (S = 508: 32 pairs per thread; S = 576: 36) converts and
     runs, image and y the mirror's bits; one group more is refused by cvr_create with CVR_ERR_INVALID and a message, before any planning
