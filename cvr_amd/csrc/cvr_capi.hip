@@ -717,7 +717,9 @@ int cvr_create(cvr_handle **out, const cvr_csr_view *csr_in, const cvr_options *
         // from the pass above; the count is doubled (up to 64) until the heaviest XCD -- panels dealt as run_spmv's table deals them, the
         // fullest first to the least loaded XCD -- is within 30 % of the mean (15 % until round 6: with gang chunks the same bipartite shape runs 78.4 / 79.3 / 83.0 us as
         // 8 / 16 / 32 panels -- its 16 panels at 1.21 of the mean no longer want doubling; profiles/r06_holdout.log).
-        if (opt.hub_table == 0 && xcd_panels && P > 1 && P <= 64 && !cvr::debug_env("no_balance_rule")) {
+        // (Round 6: for PRIVATE interleaved chunks only.  With gang chunks the same shape runs 78.4 / 79.3 / 83.0 us as 8 / 16 / 32 panels and, at 0.45 of its size,
+        // 54.2 as 8 panels at 1.53 of the mean against 65.0 as 16 at 1.21 -- a sparse gang's time goes with its rows, not with its non-zeros: profiles/r06_thin_lists_rule.log)
+        if (opt.hub_table == 0 && xcd_panels && P > 1 && P <= 64 && (opt.gang == 0 || cvr::debug_env("balance_rule")) && !cvr::debug_env("no_balance_rule")) {
             auto imbalance = [&](int Pt) {
                 std::vector<double> load((size_t)Pt, 0.0);
                 const int64_t       w = (ncols + Pt - 1) / Pt > 0 ? (ncols + Pt - 1) / Pt : 1;
